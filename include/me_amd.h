@@ -1,0 +1,182 @@
+/*
+ * me_amd.h — C ABI of the MI355X (gfx950) sparse-convolution hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no torch / pybind types.  Every pointer
+ * named *_dev is DEVICE memory owned by the caller (in the PyTorch-ROCm host layer these are
+ * tensor.data_ptr() values, so the torch caching allocator plays the role of the reference's
+ * c10 allocator, src/allocators.cuh:74-103).  `stream` is a hipStream_t passed as void*; all
+ * work is enqueued on it and nothing synchronises the device except the functions documented
+ * as "SYNC" (they must return a count to the host, exactly where the reference synchronises).
+ *
+ * Each entry point cites the reference interface (path:line under the MinkowskiEngine tree) that
+ * it replaces.  The reference reaches those through pybind11 (pybind/extern.hpp); INTEGRATION.md
+ * shows the binding a maintainer would add.
+ *
+ * Return value: 0 on success, non-zero on error; me_last_error() describes the last failure of
+ * the calling thread (mirrors the reference's ASSERT -> std::runtime_error, src/utils.hpp:141-150).
+ */
+#ifndef ME_AMD_H
+#define ME_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ME_MAX_DIM 7 /* spatial dimensions D; coordinates carry D+1 int32 (batch index first) */
+
+/* region types: src/types.hpp:148-152 (RegionType::HYPER_CUBE / HYPER_CROSS / CUSTOM) */
+#define ME_REGION_HYPER_CUBE 0
+#define ME_REGION_HYPER_CROSS 1
+
+/* Kernel geometry of one layer; replaces gpu_kernel_region (src/kernel_region.hpp:283-398).
+ * Neighbour offsets follow kernel_region.hpp:198-247 (axis 0 fastest; odd sizes centred, even
+ * sizes start at 0; multiplied by dilation * tensor_stride). */
+typedef struct me_region {
+  int32_t ncol;                    /* D + 1 */
+  int32_t region_type;             /* ME_REGION_* */
+  int32_t kernel_size[ME_MAX_DIM]; /* per spatial axis */
+  int32_t dilation[ME_MAX_DIM];
+  int32_t tensor_stride[ME_MAX_DIM]; /* tensor stride of the map that is LOOKED UP (the "in" map) */
+} me_region;
+
+/* ---- library ------------------------------------------------------------------------------- */
+int me_version(void);
+const char *me_last_error(void);
+/* kernel volume of a region: src/kernel_region.hpp:250-270 (set_volume) */
+int64_t me_region_volume(const me_region *region);
+
+/* ---- coordinate hash map (replaces CoordinateMapGPU, src/coordinate_map_gpu.cuh:47-223) ------ */
+
+/* Number of 8-byte slots for n keys: power of two >= 2n (<= 50 % load; the reference uses 25-50 %,
+ * src/coordinate_map_manager.hpp:139-155). */
+int64_t me_hash_capacity(int64_t n);
+/* Scratch bytes needed by me_coords_insert_and_map for n rows. */
+int64_t me_insert_workspace_bytes(int64_t n);
+
+/* insert + dedup + row maps.  Replaces CoordinateMapGPU::insert<true>
+ * (src/coordinate_map_gpu.cu:196-278) but with the CPU path's deterministic semantics
+ * (CoordinateMapCPU::insert_and_map, src/coordinate_map_cpu.hpp:353-380): the FIRST occurrence of
+ * a coordinate wins and unique rows keep first-occurrence order.
+ *   coords_dev      int32 [n, ncol] contiguous (16-byte aligned when ncol == 4)
+ *   table_dev       uint64 [capacity]          (out) open-addressing table {hash tag, row}
+ *   coords_unique   int32 [n, ncol]            (out) first n_unique rows valid
+ *   unique_map_dev  int64 [n]                  (out) first n_unique valid: input row of each unique row
+ *   inverse_map_dev int64 [n]                  (out) unique row of each input row
+ *   n_unique        host int64                 (out)  — SYNC (one 8-byte D2H copy)
+ */
+int me_coords_insert_and_map(const int32_t *coords_dev, int64_t n, int32_t ncol, uint64_t *table_dev,
+                             int64_t capacity, int32_t *coords_unique_dev, int64_t *unique_map_dev,
+                             int64_t *inverse_map_dev, int64_t *n_unique, void *workspace_dev,
+                             int64_t workspace_bytes, void *stream);
+
+/* out[i] = floor(c / ts_out) * ts_out on the spatial columns, batch column copied.
+ * Replaces stride_copy (src/coordinate_map_gpu.cu:363-397; CPU detail::stride_coordinate,
+ * src/coordinate_map.hpp:58-66).  Integer floor division (== the reference's float floor for
+ * |c| < 2^24). */
+int me_coords_stride(const int32_t *coords_dev, int64_t n, int32_t ncol,
+                     const int32_t *out_tensor_stride /* host [ncol-1] */, int32_t *out_coords_dev,
+                     void *stream);
+
+/* rows[q] = row of query q in the map, or -1.  Replaces CoordinateMapGPU::find
+ * (src/coordinate_map_gpu.cu:284-361). */
+int me_coords_find(const uint64_t *table_dev, int64_t capacity, const int32_t *map_coords_dev,
+                   int32_t ncol, const int32_t *queries_dev, int64_t nq, int32_t *rows_dev,
+                   void *stream);
+
+/* ---- kernel map (replaces CoordinateMapGPU::kernel_map, src/coordinate_map_gpu.cu:1546-1745, and
+ *      gpu_kernel_map::decompose, src/kernel_map.cuh:313-405) ----------------------------------- */
+
+/* Scratch bytes for the two kernel-map passes. */
+int64_t me_kernel_map_workspace_bytes(int64_t n_out, int64_t volume);
+
+/* Pass 1: neighbour table + per-offset pair counts.
+ *   nbr_dev   int32 [volume, n_out] (out): in-map row of (out row u, offset k) or -1
+ *   k_offsets host int64 [volume + 1] (out): exclusive prefix of pair counts — SYNC
+ * The iteration direction is the reference's: iterate OUTPUT coordinates, look up the INPUT map
+ * (src/coordinate_map_cpu.hpp:626-649). */
+int me_kernel_map_probe(const uint64_t *in_table_dev, int64_t in_capacity,
+                        const int32_t *in_coords_dev, const int32_t *out_coords_dev, int64_t n_out,
+                        const me_region *region, int32_t *nbr_dev, int64_t *k_offsets,
+                        void *workspace_dev, int64_t workspace_bytes, void *stream);
+
+/* Pass 2: wavefront ballot/prefix-sum compaction of the table into the reference's per-offset
+ * pair lists (kernel_map.hpp:40-53): pairs of offset k live at [k_offsets[k], k_offsets[k+1]),
+ * sorted by output row (deterministic).  Must follow me_kernel_map_probe with the same workspace. */
+int me_kernel_map_compact(const int32_t *nbr_dev, int64_t n_out, int64_t volume,
+                          int32_t *in_pairs_dev, int32_t *out_pairs_dev, void *workspace_dev,
+                          int64_t workspace_bytes, void *stream);
+
+/* Transposed neighbour table: nbrT[k, i] = out row paired with in row i under offset k, or -1.
+ * (each (k, in row) occurs in at most one pair).   k_offsets_dev: int64 [volume+1] on device. */
+int me_kernel_map_transpose(const int32_t *in_pairs_dev, const int32_t *out_pairs_dev,
+                            const int64_t *k_offsets_dev, int64_t volume, int64_t n_pairs,
+                            int64_t n_in, int32_t *nbrT_dev, void *stream);
+
+/* ---- tile plan for the target-stationary convolution ----------------------------------------- */
+/* A plan cuts the target rows into tiles of ME_TILE_ROWS; per tile the valid (offset k, source row)
+ * entries are grouped by k and padded to groups of 16 (one MFMA 16x16x4 M-tile per group). */
+#define ME_TILE_ROWS 128
+#define ME_GROUP_ROWS 16
+int64_t me_plan_num_tiles(int64_t n_tgt);
+/* upper bound on the number of groups for a table with n_pairs valid entries */
+int64_t me_plan_max_groups(int64_t n_tgt, int64_t volume, int64_t n_pairs);
+int64_t me_plan_workspace_bytes(int64_t n_tgt, int64_t volume);
+/*   tbl_dev        int32 [volume, n_tgt]  neighbour table (nbr for forward, nbrT for dgrad)
+ *   plan_src_dev   int32 [16 * max_groups] (out) source row per slot, -1 = padding
+ *   plan_dst_dev   int32 [16 * max_groups] (out) target row local to its tile, -1 = padding
+ *   group_k_dev    int32 [max_groups]      (out) kernel offset of each group
+ *   tile_gptr_dev  int32 [num_tiles + 1]   (out) group range of each tile
+ */
+int me_plan_build(const int32_t *tbl_dev, int64_t n_tgt, int64_t volume, int32_t *plan_src_dev,
+                  int32_t *plan_dst_dev, int32_t *group_k_dev, int32_t *tile_gptr_dev,
+                  void *workspace_dev, int64_t workspace_bytes, void *stream);
+
+/* ---- convolution feature kernels (replace ConvolutionForwardKernelGPU / BackwardKernelGPU,
+ *      src/convolution_kernel.cu:320-496, 553-757; CPU twins src/convolution_kernel.hpp:33-144) -- */
+
+/* Target-stationary gather -> LDS -> MFMA(fp32 16x16x4) -> LDS accumulate -> one coalesced store.
+ *   dst[t, :] = sum over plan entries (k, s) of tile(t):  src[s, :] @ w[k]      (w[k]: [c_src, c_dst])
+ * Forward: src = in_feat, w = kernel, plan from nbr.  dgrad: src = grad_out, w = kernel^T (per k),
+ * plan from nbrT.  Every target row is written (rows without entries get zeros). */
+int me_conv_target_f32(const float *src_feat_dev, int64_t n_src, int32_t c_src, const float *w_dev,
+                       int64_t volume, int32_t c_dst, const int32_t *plan_src_dev,
+                       const int32_t *plan_dst_dev, const int32_t *group_k_dev,
+                       const int32_t *tile_gptr_dev, float *dst_feat_dev, int64_t n_tgt,
+                       void *stream);
+
+/* wt[k, j, i] = w[k, i, j] */
+int me_transpose_kernel_f32(const float *w_dev, int64_t volume, int32_t c_in, int32_t c_out,
+                            float *wt_dev, void *stream);
+
+/* Weight gradient: grad_w[k] = sum over pairs e of offset k of  x[in[e], :]^T (outer) dy[out[e], :]
+ * (src/convolution_kernel.hpp:128-142).  MFMA fp32 32x32x2 over chunks of ME_WGRAD_CHUNK pairs,
+ * partial tiles to workspace, deterministic second-pass reduction.
+ *   k_offsets: host int64 [volume+1] (sizes the grid), k_offsets_dev: the same values on the device;
+ *   workspace bytes from me_conv_wgrad_workspace_bytes. */
+#define ME_WGRAD_CHUNK 2048
+int64_t me_conv_wgrad_workspace_bytes(const int64_t *k_offsets, int64_t volume, int32_t c_in,
+                                      int32_t c_out);
+int me_conv_wgrad_f32(const float *x_dev, int32_t c_in, const float *dy_dev, int32_t c_out,
+                      const int32_t *in_pairs_dev, const int32_t *out_pairs_dev,
+                      const int64_t *k_offsets /* host */, const int64_t *k_offsets_dev,
+                      int64_t volume, float *grad_w_dev, void *workspace_dev,
+                      int64_t workspace_bytes, void *stream);
+
+/* Plain VALU + atomics versions on the pair lists (debug cross-check only; never the default).
+ * out / grad_in / grad_w must be zero-filled by the caller. */
+int me_conv_forward_naive_f32(const float *in_feat_dev, int32_t c_in, const float *w_dev, int32_t c_out,
+                              const int32_t *in_pairs_dev, const int32_t *out_pairs_dev,
+                              const int64_t *k_offsets_dev, int64_t volume, int64_t n_pairs,
+                              float *out_feat_dev, void *stream);
+int me_conv_backward_naive_f32(const float *in_feat_dev, int32_t c_in, const float *grad_out_dev,
+                               int32_t c_out, const float *w_dev, const int32_t *in_pairs_dev,
+                               const int32_t *out_pairs_dev, const int64_t *k_offsets_dev,
+                               int64_t volume, int64_t n_pairs, float *grad_in_dev,
+                               float *grad_w_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ME_AMD_H */

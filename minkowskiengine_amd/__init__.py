@@ -1,0 +1,30 @@
+"""minkowskiengine_amd — MI355X (gfx950) sparse-tensor convolution engine that keeps the
+MinkowskiEngine Python API for the hot path: SparseTensor / CoordinateManager /
+MinkowskiConvolution[Transpose] over hand-written HIP kernels (csrc/, C ABI in include/me_amd.h).
+
+    import minkowskiengine_amd as ME
+    x = ME.SparseTensor(features.cuda(), coordinates.cuda())
+    y = ME.MinkowskiConvolution(64, 128, kernel_size=3, dimension=3).cuda()(x)
+"""
+__version__ = "0.1.0"
+
+from . import backend as MinkowskiEngineBackend  # noqa: F401  (the `_C`-compatible operator module)
+from .backend import (  # noqa: F401
+    BroadcastMode, ConvolutionMode, CoordinateMapKey, CoordinateMapType, GPUMemoryAllocatorType,
+    MinkowskiAlgorithm, PoolingMode, RegionType, cuda_version, cudart_version, get_gpu_memory_info,
+    is_cuda_available)
+from .common import convert_to_int_list, get_minkowski_function  # noqa: F401
+from .convolution import (  # noqa: F401
+    MinkowskiConvolution, MinkowskiConvolutionFunction, MinkowskiConvolutionTranspose,
+    MinkowskiConvolutionTransposeFunction)
+from .coordinate_manager import (  # noqa: F401
+    CoordinateManager, set_gpu_allocator, set_memory_manager_backend)
+from .kernel_generator import KernelGenerator, get_kernel_volume  # noqa: F401
+from .layers import (  # noqa: F401
+    MinkowskiBatchNorm, MinkowskiDropout, MinkowskiELU, MinkowskiLeakyReLU, MinkowskiLinear, MinkowskiReLU,
+    MinkowskiSigmoid, MinkowskiSyncBatchNorm, MinkowskiTanh, cat)
+from .sparse_tensor import (  # noqa: F401
+    SparseTensor, SparseTensorOperationMode, SparseTensorQuantizationMode, clear_global_coordinate_manager,
+    global_coordinate_manager, set_global_coordinate_manager, set_sparse_tensor_operation_mode,
+    sparse_tensor_operation_mode)
+from . import utils  # noqa: F401

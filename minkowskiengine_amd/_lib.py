@@ -1,0 +1,105 @@
+"""ctypes binding of the C ABI declared in include/me_amd.h (libme_amd.so, built by
+__graft_entry__.build()).
+
+The product path has no CPU fallback: if the HIP library is missing or a call fails, a
+RuntimeError is raised (mirroring the reference's ASSERT -> std::runtime_error -> RuntimeError,
+/root/reference/src/utils.hpp:141-150).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libme_amd.so")
+
+ME_MAX_DIM = 7
+ME_TILE_ROWS = 128
+ME_GROUP_ROWS = 16
+ME_WGRAD_CHUNK = 2048
+
+c_i32, c_i64, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
+
+
+class MeRegion(ctypes.Structure):
+    """struct me_region (include/me_amd.h)."""
+    _fields_ = [
+        ("ncol", c_i32),
+        ("region_type", c_i32),
+        ("kernel_size", c_i32 * ME_MAX_DIM),
+        ("dilation", c_i32 * ME_MAX_DIM),
+        ("tensor_stride", c_i32 * ME_MAX_DIM),
+    ]
+
+
+_P_REGION = ctypes.POINTER(MeRegion)
+_P_I64 = ctypes.POINTER(c_i64)
+_P_I32 = ctypes.POINTER(c_i32)
+
+# name -> (restype, argtypes); must list every symbol include/me_amd.h declares
+SIGNATURES = {
+    "me_version": (ctypes.c_int, []),
+    "me_last_error": (ctypes.c_char_p, []),
+    "me_region_volume": (c_i64, [_P_REGION]),
+    "me_hash_capacity": (c_i64, [c_i64]),
+    "me_insert_workspace_bytes": (c_i64, [c_i64]),
+    "me_coords_insert_and_map": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp, c_vp, _P_I64,
+                                                c_vp, c_i64, c_vp]),
+    "me_coords_stride": (ctypes.c_int, [c_vp, c_i64, c_i32, _P_I32, c_vp, c_vp]),
+    "me_coords_find": (ctypes.c_int, [c_vp, c_i64, c_vp, c_i32, c_vp, c_i64, c_vp, c_vp]),
+    "me_kernel_map_workspace_bytes": (c_i64, [c_i64, c_i64]),
+    "me_kernel_map_probe": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, _P_REGION, c_vp, _P_I64, c_vp,
+                                           c_i64, c_vp]),
+    "me_kernel_map_compact": (ctypes.c_int, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "me_kernel_map_transpose": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp]),
+    "me_plan_num_tiles": (c_i64, [c_i64]),
+    "me_plan_max_groups": (c_i64, [c_i64, c_i64, c_i64]),
+    "me_plan_workspace_bytes": (c_i64, [c_i64, c_i64]),
+    "me_plan_build": (ctypes.c_int, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "me_conv_target_f32": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp,
+                                          c_vp, c_i64, c_vp]),
+    "me_transpose_kernel_f32": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
+    "me_conv_wgrad_workspace_bytes": (c_i64, [_P_I64, c_i64, c_i32, c_i32]),
+    "me_conv_wgrad_f32": (ctypes.c_int, [c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, _P_I64, c_vp, c_i64, c_vp,
+                                         c_vp, c_i64, c_vp]),
+    "me_conv_forward_naive_f32": (ctypes.c_int, [c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_i64,
+                                                 c_vp, c_vp]),
+    "me_conv_backward_naive_f32": (ctypes.c_int, [c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i64,
+                                                  c_i64, c_vp, c_vp, c_vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libme_amd.so (once) and attach the prototypes.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"minkowskiengine_amd: HIP library {LIB_PATH} not found. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+            "There is no CPU fallback for the MI355X path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().me_last_error()
+        raise RuntimeError(msg.decode() if msg else f"libme_amd call failed with code {rc}")
+
+
+def make_region(ncol, region_type, kernel_size, dilation, tensor_stride):
+    rg = MeRegion()
+    rg.ncol = int(ncol)
+    rg.region_type = int(region_type)
+    for d in range(ME_MAX_DIM):
+        rg.kernel_size[d] = int(kernel_size[d]) if d < ncol - 1 else 1
+        rg.dilation[d] = int(dilation[d]) if d < ncol - 1 else 1
+        rg.tensor_stride[d] = int(tensor_stride[d]) if d < ncol - 1 else 1
+    return rg

@@ -1,0 +1,620 @@
+"""Host-side mirror of the reference's operator module ``MinkowskiEngineBackend._C``
+(/root/reference/pybind/extern.hpp:515-838) for the hot path, written over the C ABI of
+include/me_amd.h.
+
+Exported with the reference's names and argument meaning:
+  enums      RegionType, ConvolutionMode, MinkowskiAlgorithm, CoordinateMapType,
+             GPUMemoryAllocatorType, PoolingMode, BroadcastMode          (extern.hpp:669-741)
+  classes    CoordinateMapKey (extern.hpp:744-764),
+             CoordinateMapManagerGPU_c10 / CoordinateMapManagerGPU_default (extern.hpp:767-806)
+  functions  ConvolutionForwardGPU / ConvolutionBackwardGPU,
+             ConvolutionTransposeForwardGPU / ConvolutionTransposeBackwardGPU (extern.hpp:53-181)
+             is_cuda_available, cuda_version, cudart_version, get_gpu_memory_info
+
+Errors are RuntimeError, like the reference's ASSERT (src/utils.hpp:141-150).  There is no CPU
+implementation here: CPU tensors are rejected (the reference's CPU path is the test oracle).
+"""
+import ctypes
+import enum
+import os
+import random
+import string
+
+import torch
+
+from . import _lib
+
+
+# ------------------------------------------------------------------------------------------------
+# enums (pybind/extern.hpp:669-741)
+# ------------------------------------------------------------------------------------------------
+class GPUMemoryAllocatorType(enum.IntEnum):
+    PYTORCH = 0
+    CUDA = 1
+
+
+class CUDAKernelMapMode(enum.IntEnum):
+    MEMORY_EFFICIENT = 0
+    SPEED_OPTIMIZED = 1
+
+
+class MinkowskiAlgorithm(enum.IntEnum):
+    DEFAULT = 0
+    MEMORY_EFFICIENT = 1
+    SPEED_OPTIMIZED = 2
+
+
+class CoordinateMapType(enum.IntEnum):
+    CPU = 0
+    CUDA = 1
+
+
+class RegionType(enum.IntEnum):
+    HYPER_CUBE = 0
+    HYPER_CROSS = 1
+    CUSTOM = 2
+
+
+class PoolingMode(enum.IntEnum):
+    LOCAL_SUM_POOLING = 0
+    LOCAL_AVG_POOLING = 1
+    LOCAL_MAX_POOLING = 2
+    GLOBAL_SUM_POOLING_DEFAULT = 3
+    GLOBAL_AVG_POOLING_DEFAULT = 4
+    GLOBAL_MAX_POOLING_DEFAULT = 5
+    GLOBAL_SUM_POOLING_KERNEL = 6
+    GLOBAL_AVG_POOLING_KERNEL = 7
+    GLOBAL_MAX_POOLING_KERNEL = 8
+    GLOBAL_SUM_POOLING_PYTORCH_INDEX = 9
+    GLOBAL_AVG_POOLING_PYTORCH_INDEX = 10
+    GLOBAL_MAX_POOLING_PYTORCH_INDEX = 11
+
+
+class BroadcastMode(enum.IntEnum):
+    ELEMENTWISE_ADDITON = 0
+    ELEMENTWISE_MULTIPLICATION = 1
+
+
+class ConvolutionMode(enum.IntEnum):
+    DEFAULT = 0
+    DIRECT_GEMM = 1
+    COPY_GEMM = 2
+
+
+def is_cuda_available():
+    return True
+
+
+def cuda_version():
+    return -1
+
+
+def cudart_version():
+    return -1
+
+
+def get_gpu_memory_info():
+    free, total = torch.cuda.mem_get_info()
+    return free, total
+
+
+def _check(cond, *msg):
+    if not cond:
+        raise RuntimeError("assertion failed. " + " ".join(str(m) for m in msg))
+
+
+# ------------------------------------------------------------------------------------------------
+# CoordinateMapKey (src/coordinate_map_key.hpp:44-157)
+# ------------------------------------------------------------------------------------------------
+class CoordinateMapKey:
+    """Identity of a coordinate map: (tensor_stride, string_id); may be created unset and filled in
+    by an operator (lazy key, coordinate_map_key.hpp:52-53, 91-98)."""
+
+    __slots__ = ("_coordinate_size", "_key")
+
+    def __init__(self, arg, string_id=""):
+        if isinstance(arg, int):
+            self._coordinate_size = int(arg)
+            self._key = None
+        else:
+            ts = [int(s) for s in arg]
+            self._coordinate_size = len(ts) + 1
+            self._key = (tuple(ts), str(string_id))
+
+    def get_coordinate_size(self):
+        return self._coordinate_size
+
+    def is_key_set(self):
+        return self._key is not None
+
+    def set_key(self, *args):
+        if len(args) == 1:
+            tensor_stride, string_id = args[0]
+        else:
+            tensor_stride, string_id = args
+        ts = tuple(int(s) for s in tensor_stride)
+        _check(self._coordinate_size - 1 == len(ts), "Invalid tensor_stride size:", ts,
+               "coordinate_size:", self._coordinate_size)
+        self._key = (ts, str(string_id))
+
+    def get_key(self):
+        _check(self._key is not None, "Key not set")
+        return (list(self._key[0]), self._key[1])
+
+    def _hashable(self):
+        _check(self._key is not None, "Key not set")
+        return self._key
+
+    def get_tensor_stride(self):
+        _check(self._key is not None, "Key not set")
+        return list(self._key[0])
+
+    def __eq__(self, other):
+        if not isinstance(other, CoordinateMapKey):
+            return NotImplemented
+        if self._key is None or other._key is None:
+            return False
+        return self._key == other._key
+
+    def __hash__(self):
+        return hash(self._hashable())
+
+    def __repr__(self):
+        if self._key is None:
+            return "coordinate map key: (unset)"
+        s = "coordinate map key:" + str(list(self._key[0]))
+        if self._key[1]:
+            s += ":" + self._key[1]
+        return s
+
+
+# ------------------------------------------------------------------------------------------------
+# device objects
+# ------------------------------------------------------------------------------------------------
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _workspace(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+class _CoordinateMapGPU:
+    """One coordinate map resident in HBM: unique int32 coordinates [n, D+1] in row order and the
+    open-addressing table {hash tag | row} (replaces CoordinateMapGPU,
+    src/coordinate_map_gpu.cuh:47-223)."""
+
+    __slots__ = ("coords", "table", "capacity", "tensor_stride", "n")
+
+    def __init__(self, coords, table, capacity, tensor_stride, n):
+        self.coords, self.table, self.capacity = coords, table, capacity
+        self.tensor_stride, self.n = tuple(tensor_stride), int(n)
+
+
+def _insert(coords, tensor_stride):
+    """coords: int32 [N, D+1] contiguous on the GPU -> (_CoordinateMapGPU, unique_map, inverse_map)."""
+    lib = _lib.load()
+    dev = coords.device
+    n, ncol = int(coords.shape[0]), int(coords.shape[1])
+    cap = int(lib.me_hash_capacity(n))
+    table = torch.empty(cap, dtype=torch.int64, device=dev)
+    coords_unique = torch.empty((max(n, 1), ncol), dtype=torch.int32, device=dev)
+    unique_map = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+    inverse_map = torch.empty(max(n, 1), dtype=torch.int64, device=dev)
+    wsb = int(lib.me_insert_workspace_bytes(n))
+    ws = _workspace(wsb, dev)
+    n_unique = ctypes.c_int64(0)
+    with torch.cuda.device(dev):
+        _lib.check(lib.me_coords_insert_and_map(_ptr(coords), n, ncol, _ptr(table), cap, _ptr(coords_unique),
+                                                _ptr(unique_map), _ptr(inverse_map), ctypes.byref(n_unique),
+                                                _ptr(ws), ws.numel(), _stream(dev)))
+    nu = int(n_unique.value)
+    cmap = _CoordinateMapGPU(coords_unique[:nu], table, cap, tensor_stride, nu)
+    return cmap, unique_map[:nu], inverse_map[:n]
+
+
+class KernelMapGPU:
+    """Kernel map resident in HBM (replaces gpu_kernel_map, src/kernel_map.cuh:48-429).
+
+    * ``in_pairs`` / ``out_pairs`` + ``k_offsets``: the reference's per-offset (in row, out row)
+      lists, concatenated; offset k owns [k_offsets[k], k_offsets[k+1]).
+    * ``table('out')`` = nbr[k, out row] -> in row or -1, ``table('in')`` its transpose; the tile
+      plans of the target-stationary convolution are built from them on first use and cached.
+    A transposed view (``swapped()``) shares all device buffers with in/out roles exchanged
+    (src/coordinate_map_manager.cpp:763-774).
+    """
+
+    def __init__(self, volume, n_in, n_out, k_offsets, k_offsets_dev, in_pairs, out_pairs, store=None,
+                 flip=False):
+        self.volume, self.n_in, self.n_out = int(volume), int(n_in), int(n_out)
+        self.k_offsets = k_offsets            # host list of volume+1 ints
+        self.k_offsets_dev = k_offsets_dev    # int64 [volume+1] on the device
+        self.in_pairs, self.out_pairs = in_pairs, out_pairs
+        self._store = store if store is not None else {}
+        self._flip = flip
+
+    @property
+    def n_pairs(self):
+        return int(self.k_offsets[-1])
+
+    @property
+    def device(self):
+        return self.k_offsets_dev.device
+
+    def _name(self, kind, target):
+        if self._flip:
+            target = "in" if target == "out" else "out"
+        return kind + "_" + target
+
+    def swapped(self):
+        return KernelMapGPU(self.volume, self.n_out, self.n_in, self.k_offsets, self.k_offsets_dev,
+                            self.out_pairs, self.in_pairs, store=self._store, flip=not self._flip)
+
+    def table(self, target):
+        """target 'out': [volume, n_out] -> in row; target 'in': [volume, n_in] -> out row."""
+        name = self._name("nbr", target)
+        if name not in self._store:
+            lib = _lib.load()
+            dev = self.device
+            # the missing table is the transpose of the existing one: scatter the pair lists
+            n_tgt = self.n_out if target == "out" else self.n_in
+            src_pairs = self.in_pairs if target == "out" else self.out_pairs   # values stored
+            tgt_pairs = self.out_pairs if target == "out" else self.in_pairs   # rows indexed
+            tbl = torch.empty((self.volume, max(n_tgt, 1)), dtype=torch.int32, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(lib.me_kernel_map_transpose(_ptr(tgt_pairs), _ptr(src_pairs), _ptr(self.k_offsets_dev),
+                                                       self.volume, self.n_pairs, n_tgt, _ptr(tbl), _stream(dev)))
+            self._store[name] = tbl
+        return self._store[name]
+
+    def plan(self, target):
+        """Tile plan with `target` rows stationary: (plan_src, plan_dst, group_k, tile_gptr)."""
+        name = self._name("plan", target)
+        if name not in self._store:
+            lib = _lib.load()
+            dev = self.device
+            n_tgt = self.n_out if target == "out" else self.n_in
+            tbl = self.table(target)
+            max_groups = int(lib.me_plan_max_groups(n_tgt, self.volume, self.n_pairs))
+            n_tiles = int(lib.me_plan_num_tiles(n_tgt))
+            plan_src = torch.empty(max_groups * _lib.ME_GROUP_ROWS, dtype=torch.int32, device=dev)
+            plan_dst = torch.empty(max_groups * _lib.ME_GROUP_ROWS, dtype=torch.int32, device=dev)
+            group_k = torch.empty(max_groups, dtype=torch.int32, device=dev)
+            tile_gptr = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
+            ws = _workspace(lib.me_plan_workspace_bytes(n_tgt, self.volume), dev)
+            with torch.cuda.device(dev):
+                _lib.check(lib.me_plan_build(_ptr(tbl), n_tgt, self.volume, _ptr(plan_src), _ptr(plan_dst),
+                                             _ptr(group_k), _ptr(tile_gptr), _ptr(ws), ws.numel(), _stream(dev)))
+            self._store[name] = (plan_src, plan_dst, group_k, tile_gptr)
+        return self._store[name]
+
+    def to_dict(self):
+        """{k: int32 [2, n_k]} with row 0 = in rows, row 1 = out rows; only non-empty k
+        (src/coordinate_map_manager.cpp:1358-1387)."""
+        out = {}
+        for k in range(self.volume):
+            b, e = self.k_offsets[k], self.k_offsets[k + 1]
+            if e > b:
+                out[k] = torch.stack((self.in_pairs[b:e], self.out_pairs[b:e]))
+        return out
+
+
+def _build_kernel_map(in_map, out_map, region):
+    """Iterate OUT coordinates, look up the IN map (src/coordinate_map_cpu.hpp:569-670)."""
+    lib = _lib.load()
+    dev = in_map.coords.device
+    volume = int(lib.me_region_volume(ctypes.byref(region)))
+    _check(volume > 0, "invalid kernel region")
+    n_out, n_in = out_map.n, in_map.n
+    nbr = torch.empty((volume, max(n_out, 1)), dtype=torch.int32, device=dev)
+    ws = _workspace(lib.me_kernel_map_workspace_bytes(n_out, volume), dev)
+    koffs = (ctypes.c_int64 * (volume + 1))()
+    with torch.cuda.device(dev):
+        _lib.check(lib.me_kernel_map_probe(_ptr(in_map.table), in_map.capacity, _ptr(in_map.coords),
+                                           _ptr(out_map.coords), n_out, ctypes.byref(region), _ptr(nbr), koffs,
+                                           _ptr(ws), ws.numel(), _stream(dev)))
+        k_offsets = [int(v) for v in koffs]
+        n_pairs = k_offsets[-1]
+        in_pairs = torch.empty(max(n_pairs, 1), dtype=torch.int32, device=dev)
+        out_pairs = torch.empty(max(n_pairs, 1), dtype=torch.int32, device=dev)
+        _lib.check(lib.me_kernel_map_compact(_ptr(nbr), n_out, volume, _ptr(in_pairs), _ptr(out_pairs), _ptr(ws),
+                                             ws.numel(), _stream(dev)))
+    k_offsets_dev = torch.tensor(k_offsets, dtype=torch.int64, device=dev)
+    return KernelMapGPU(volume, n_in, n_out, k_offsets, k_offsets_dev, in_pairs[:max(n_pairs, 0)],
+                        out_pairs[:max(n_pairs, 0)], store={"nbr_out": nbr})
+
+
+# ------------------------------------------------------------------------------------------------
+# CoordinateMapManager (src/coordinate_map_manager.{hpp,cpp,cu})
+# ------------------------------------------------------------------------------------------------
+_CHARSET = string.digits + string.ascii_uppercase + string.ascii_lowercase
+
+
+class CoordinateMapManagerGPU_c10:
+    """Owner of the coordinate maps and the kernel-map cache of one process / one GPU
+    (src/coordinate_map_manager.hpp:130-156, 530-554).  Device memory comes from the torch caching
+    allocator, as with the reference's c10 allocator."""
+
+    def __init__(self, algorithm=MinkowskiAlgorithm.DEFAULT, num_threads=0):
+        self.algorithm = MinkowskiAlgorithm(algorithm)
+        self.num_threads = num_threads
+        self._maps = {}          # (tensor_stride tuple, string_id) -> _CoordinateMapGPU
+        self._kernel_maps = {}   # kernel_map_key (src/types.hpp:183-192) -> KernelMapGPU
+        self._origin_maps = {}
+
+    # ---- keys -----------------------------------------------------------------------------------
+    @staticmethod
+    def _k(key):
+        if isinstance(key, CoordinateMapKey):
+            return key._hashable()
+        ts, sid = key
+        return (tuple(int(s) for s in ts), str(sid))
+
+    def exists(self, key):
+        return self._k(key) in self._maps
+
+    def _get(self, key):
+        k = self._k(key)
+        _check(k in self._maps, "coordinate map not found", k)
+        return self._maps[k]
+
+    def get_random_string_id(self, tensor_stride, string_id):
+        """src/coordinate_map_manager.hpp:473-485"""
+        ts = tuple(int(s) for s in tensor_stride)
+        while True:
+            rnd = "".join(random.choice(_CHARSET) for _ in range(5))
+            key = (ts, (string_id + "-" + rnd) if string_id else rnd)
+            if key not in self._maps:
+                return (list(key[0]), key[1])
+
+    def get_coordinate_map_keys(self, tensor_stride):
+        ts = tuple(int(s) for s in tensor_stride)
+        return [CoordinateMapKey(list(k[0]), k[1]) for k in self._maps if k[0] == ts]
+
+    # ---- maps -----------------------------------------------------------------------------------
+    def insert_and_map(self, coordinates, tensor_stride, string_id=""):
+        """src/coordinate_map_manager.cpp:349-399 -> (CoordinateMapKey, (unique_map, inverse_map))."""
+        _check(isinstance(coordinates, torch.Tensor) and coordinates.dim() == 2, "coordinates must be 2-D")
+        _check(coordinates.is_contiguous(), "coordinates must be contiguous")
+        _check(coordinates.dtype == torch.int32, "coordinates must be int32")
+        _check(coordinates.is_cuda, "coordinates must be on the GPU (the MI355X path has no CPU map)")
+        ts = tuple(int(s) for s in tensor_stride)
+        _check(coordinates.shape[1] - 1 == len(ts), "The coordinate dimension (coordinate_size - 1):",
+               coordinates.shape[1] - 1, " must match the size of tensor stride:", list(ts))
+        key = (ts, str(string_id))
+        if key in self._maps:
+            k = self.get_random_string_id(ts, string_id)
+            key = (tuple(k[0]), k[1])
+        cmap, unique_map, inverse_map = _insert(coordinates, ts)
+        self._maps[key] = cmap
+        return CoordinateMapKey(list(key[0]), key[1]), (unique_map, inverse_map)
+
+    def stride(self, in_key, kernel_stride, string_id=""):
+        """py_stride: src/coordinate_map_manager.cpp:402-429 -> CoordinateMapKey of the strided map."""
+        ik = self._k(in_key)
+        _check(ik in self._maps, "coordinate map not found", ik)
+        stride = [int(s) for s in kernel_stride]
+        _check(len(stride) == len(ik[0]), "stride size mismatch.")
+        _check(all(s > 0 for s in stride), "Invalid stride", stride)
+        out_ts = tuple(t * s for t, s in zip(ik[0], stride))
+        ok = (out_ts, ik[1] if string_id == "" else str(string_id))
+        if ok not in self._maps:
+            in_map = self._maps[ik]
+            lib = _lib.load()
+            dev = in_map.coords.device
+            ncol = len(out_ts) + 1
+            strided = torch.empty((max(in_map.n, 1), ncol), dtype=torch.int32, device=dev)
+            ts_arr = (ctypes.c_int32 * len(out_ts))(*out_ts)
+            with torch.cuda.device(dev):
+                _lib.check(lib.me_coords_stride(_ptr(in_map.coords), in_map.n, ncol, ts_arr, _ptr(strided),
+                                                _stream(dev)))
+            cmap, _, inverse = _insert(strided[:in_map.n], out_ts)
+            self._maps[ok] = cmap
+        return CoordinateMapKey(list(ok[0]), ok[1])
+
+    def get_coordinates(self, key):
+        return self._get(key).coords
+
+    def size(self, key):
+        return self._get(key).n
+
+    # ---- kernel maps ----------------------------------------------------------------------------
+    def _kernel_map(self, in_key, out_key, kernel_size, kernel_stride, kernel_dilation, region_type,
+                    offset, is_transpose, is_pool):
+        """src/coordinate_map_manager.cpp:655-823 -> KernelMapGPU (cached)."""
+        _check(int(region_type) != int(RegionType.CUSTOM), "Not implemented yet.")
+        ks = tuple(int(v) for v in kernel_size)
+        st = tuple(int(v) for v in kernel_stride)
+        dl = tuple(int(v) for v in kernel_dilation)
+        _check(len(ks) == len(st) == len(dl), "kernel size mismatch")
+        ik, ok = self._k(in_key), self._k(out_key)
+        key = (ik, ok, ks, st, dl, int(region_type), bool(is_transpose), bool(is_pool))
+        km = self._kernel_maps.get(key)
+        if km is not None:
+            return km
+        in_map, out_map = self._get(ik), self._get(ok)
+        _check(len(ks) + 1 == in_map.coords.shape[1], "kernel size mismatch")
+        if not is_transpose:
+            # (pooling with stride == kernel uses the same generic path: the result is identical)
+            region = _lib.make_region(len(ks) + 1, int(region_type), ks, dl, in_map.tensor_stride)
+            km = _build_kernel_map(in_map, out_map, region)
+        else:
+            swapped_key = (ok, ik, ks, st, dl, int(region_type), False, bool(is_pool))
+            fwd = self._kernel_maps.get(swapped_key)
+            if fwd is None:
+                # out -> in map with the (finer) out tensor stride, then swap
+                region = _lib.make_region(len(ks) + 1, int(region_type), ks, dl, out_map.tensor_stride)
+                fwd = _build_kernel_map(out_map, in_map, region)
+            km = fwd.swapped()
+        self._kernel_maps[key] = km
+        return km
+
+    def kernel_map(self, in_key, out_key, kernel_size, kernel_stride, kernel_dilation, region_type, offset,
+                   is_transpose, is_pool):
+        """kernel_map_th: dict {k: int32 [2, n_k]} (src/coordinate_map_manager.cpp:1358-1387)."""
+        return self._kernel_map(in_key, out_key, kernel_size, kernel_stride, kernel_dilation, region_type,
+                                offset, is_transpose, is_pool).to_dict()
+
+    def __repr__(self):
+        s = f"{self.__class__.__name__}(\n"
+        for k, m in self._maps.items():
+            s += f"\t{list(k[0])}{':' + k[1] if k[1] else ''}:\tCoordinateMapGPU:{m.n}x{m.coords.shape[1]}\n"
+        for k, km in self._kernel_maps.items():
+            s += f"\t{list(k[0][0])}->{list(k[1][0])}:\tgpu_kernel_map: number of unique maps:{km.volume}, pairs:{km.n_pairs}\n"
+        return s + f"\talgorithm={self.algorithm.name}\n)"
+
+
+CoordinateMapManagerGPU_default = CoordinateMapManagerGPU_c10
+
+
+# ------------------------------------------------------------------------------------------------
+# convolution operators (src/convolution_gpu.cu:45-244, src/convolution_transpose_gpu.cu)
+# ------------------------------------------------------------------------------------------------
+_ALGO = os.environ.get("ME_AMD_CONV_ALGO", "mfma")  # "naive" = VALU/atomics cross-check kernels
+
+
+def _check_feat(name, t):
+    _check(t.is_contiguous(), name, "must be contiguous")
+    _check(t.is_cuda, name, "must be CUDA (ROCm) — the MI355X path has no CPU implementation")
+    _check(t.dtype == torch.float32, name, "must be float32 (this round implements the fp32 path)")
+
+
+def _conv_target(src_feat, weights, km, target, n_tgt):
+    """dst[t] = sum over plan entries of src[s] @ weights[k]   (weights: [K, c_src, c_dst])."""
+    lib = _lib.load()
+    dev = src_feat.device
+    c_src, c_dst = int(weights.shape[1]), int(weights.shape[2])
+    out = torch.empty((n_tgt, c_dst), dtype=torch.float32, device=dev)
+    if n_tgt == 0:
+        return out
+    plan_src, plan_dst, group_k, tile_gptr = km.plan(target)
+    with torch.cuda.device(dev):
+        _lib.check(lib.me_conv_target_f32(_ptr(src_feat), src_feat.shape[0], c_src, _ptr(weights), km.volume, c_dst,
+                                          _ptr(plan_src), _ptr(plan_dst), _ptr(group_k), _ptr(tile_gptr),
+                                          _ptr(out), n_tgt, _stream(dev)))
+    return out
+
+
+def _conv_forward(in_feat, kernel, km, algo=None):
+    algo = algo or _ALGO
+    if algo == "naive":
+        lib = _lib.load()
+        dev = in_feat.device
+        out = torch.zeros((km.n_out, kernel.shape[2]), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.me_conv_forward_naive_f32(_ptr(in_feat), kernel.shape[1], _ptr(kernel), kernel.shape[2],
+                                                     _ptr(km.in_pairs), _ptr(km.out_pairs), _ptr(km.k_offsets_dev),
+                                                     km.volume, km.n_pairs, _ptr(out), _stream(dev)))
+        return out
+    return _conv_target(in_feat, kernel, km, "out", km.n_out)
+
+
+def _conv_backward(in_feat, grad_out, kernel, km, algo=None):
+    algo = algo or _ALGO
+    lib = _lib.load()
+    dev = in_feat.device
+    volume, c_in, c_out = int(kernel.shape[0]), int(kernel.shape[1]), int(kernel.shape[2])
+    if algo == "naive":
+        grad_in = torch.zeros((km.n_in, c_in), dtype=torch.float32, device=dev)
+        grad_w = torch.zeros_like(kernel)
+        with torch.cuda.device(dev):
+            _lib.check(lib.me_conv_backward_naive_f32(_ptr(in_feat), c_in, _ptr(grad_out), c_out, _ptr(kernel),
+                                                      _ptr(km.in_pairs), _ptr(km.out_pairs), _ptr(km.k_offsets_dev),
+                                                      km.volume, km.n_pairs, _ptr(grad_in), _ptr(grad_w),
+                                                      _stream(dev)))
+        return grad_in, grad_w
+    # dgrad: the same target-stationary kernel with the per-offset transposed weights
+    wt = torch.empty((volume, c_out, c_in), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.me_transpose_kernel_f32(_ptr(kernel), volume, c_in, c_out, _ptr(wt), _stream(dev)))
+    grad_in = _conv_target(grad_out, wt, km, "in", km.n_in)
+    # wgrad
+    grad_w = torch.empty_like(kernel)
+    koffs = (ctypes.c_int64 * (volume + 1))(*km.k_offsets)
+    wsb = int(lib.me_conv_wgrad_workspace_bytes(koffs, volume, c_in, c_out))
+    ws = _workspace(wsb, dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.me_conv_wgrad_f32(_ptr(in_feat), c_in, _ptr(grad_out), c_out, _ptr(km.in_pairs),
+                                         _ptr(km.out_pairs), koffs, _ptr(km.k_offsets_dev), volume, _ptr(grad_w),
+                                         _ptr(ws), ws.numel(), _stream(dev)))
+    return grad_in, grad_w
+
+
+def _prepare_conv(in_feat, kernel, kernel_stride, expand_coordinates, in_key, out_key, manager, transpose):
+    _check_feat("in_feat", in_feat)
+    _check_feat("kernel", kernel)
+    _check(in_feat.dim() == 2, "in_feat.dim():", in_feat.dim())
+    _check(kernel.dim() == 3, "kernel.dim():", kernel.dim())
+    _check(in_feat.shape[1] == kernel.shape[1], "Input feature size and kernel size mismatch")
+    _check(manager.exists(in_key), "coordinate map not found")
+    _check(in_feat.shape[0] == manager.size(in_key), "Invalid in_feat size", in_feat.shape[0], "!=",
+           manager.size(in_key))
+    if not out_key.is_key_set():
+        _check(not expand_coordinates, "expand_coordinates (stride_region) is not part of the hot path yet")
+        if not transpose:
+            out_key.set_key(manager.stride(in_key, kernel_stride).get_key())
+        else:
+            # src/convolution_transpose_cpu.cpp:76-97: out tensor stride = in / stride; the map must exist
+            ts = in_key.get_tensor_stride()
+            st = [int(s) for s in kernel_stride]
+            _check(all(t % s == 0 for t, s in zip(ts, st)), "Invalid up stride on tensor stride:", ts,
+                   "kernel stride:", st)
+            out_ts = [t // s for t, s in zip(ts, st)]
+            cand = (out_ts, "")
+            _check(manager.exists(cand),
+                   "transposed convolution without an existing output map needs stride_region "
+                   "(generative; not part of the hot path yet)")
+            out_key.set_key(cand)
+
+
+def ConvolutionForwardGPU(in_feat, kernel, kernel_size, kernel_stride, kernel_dilation, region_type, offset,
+                          expand_coordinates, convolution_mode, in_key, out_key, manager):
+    """src/convolution_gpu.cu:45-159 (CPU twin src/convolution_cpu.cpp:42-135)."""
+    _prepare_conv(in_feat, kernel, kernel_stride, expand_coordinates, in_key, out_key, manager, False)
+    km = manager._kernel_map(in_key, out_key, kernel_size, kernel_stride, kernel_dilation, region_type, offset,
+                             False, False)
+    return _conv_forward(in_feat, kernel, km)
+
+
+def ConvolutionBackwardGPU(in_feat, grad_out_feat, kernel, kernel_size, kernel_stride, kernel_dilation,
+                           region_type, offset, convolution_mode, in_key, out_key, manager):
+    """src/convolution_gpu.cu:161-244 -> (grad_in_feat, grad_kernel)."""
+    _check_feat("in_feat", in_feat)
+    _check_feat("kernel", kernel)
+    if not grad_out_feat.is_contiguous():
+        grad_out_feat = grad_out_feat.contiguous()
+    _check_feat("grad_out_feat", grad_out_feat)
+    _check(in_feat.shape[1] == kernel.shape[1], "Input feature size and kernel size mismatch")
+    _check(grad_out_feat.shape[1] == kernel.shape[2], "Output feature size and kernel size mismatch")
+    km = manager._kernel_map(in_key, out_key, kernel_size, kernel_stride, kernel_dilation, region_type, offset,
+                             False, False)
+    _check(grad_out_feat.shape[0] == km.n_out, "Invalid grad_out size")
+    return _conv_backward(in_feat, grad_out_feat, kernel, km)
+
+
+def ConvolutionTransposeForwardGPU(in_feat, kernel, kernel_size, kernel_stride, kernel_dilation, region_type,
+                                   offset, expand_coordinates, convolution_mode, in_key, out_key, manager):
+    """src/convolution_transpose_gpu.cu (CPU twin src/convolution_transpose_cpu.cpp:41-125)."""
+    _prepare_conv(in_feat, kernel, kernel_stride, expand_coordinates, in_key, out_key, manager, True)
+    km = manager._kernel_map(in_key, out_key, kernel_size, kernel_stride, kernel_dilation, region_type, offset,
+                             True, False)
+    return _conv_forward(in_feat, kernel, km)
+
+
+def ConvolutionTransposeBackwardGPU(in_feat, grad_out_feat, kernel, kernel_size, kernel_stride,
+                                    kernel_dilation, region_type, offset, convolution_mode, in_key, out_key,
+                                    manager):
+    """src/convolution_transpose_cpu.cpp:127-191 -> (grad_in_feat, grad_kernel)."""
+    _check_feat("in_feat", in_feat)
+    _check_feat("kernel", kernel)
+    if not grad_out_feat.is_contiguous():
+        grad_out_feat = grad_out_feat.contiguous()
+    _check_feat("grad_out_feat", grad_out_feat)
+    km = manager._kernel_map(in_key, out_key, kernel_size, kernel_stride, kernel_dilation, region_type, offset,
+                             True, False)
+    _check(grad_out_feat.shape[0] == km.n_out, "Invalid grad_out size")
+    return _conv_backward(in_feat, grad_out_feat, kernel, km)

@@ -1,0 +1,168 @@
+"""MinkowskiConvolution / MinkowskiConvolutionTranspose modules and their autograd Functions
+(reference: MinkowskiEngine/MinkowskiConvolution.py:42-634).  The Functions resolve
+`Convolution{Forward,Backward}GPU` in the backend by name, exactly as the reference does through
+get_minkowski_function (MinkowskiCommon.py:110-120)."""
+import math
+
+import torch
+from torch.autograd import Function
+from torch.nn import Module, Parameter
+
+from .backend import ConvolutionMode, CoordinateMapKey, RegionType
+from .common import get_minkowski_function
+from .kernel_generator import KernelGenerator
+from .sparse_tensor import SparseTensor, _get_coordinate_map_key
+
+
+class MinkowskiConvolutionFunction(Function):
+    @staticmethod
+    def forward(ctx, input_features, kernel_weights, kernel_generator, convolution_mode, in_coordinate_map_key,
+                out_coordinate_map_key=None, coordinate_manager=None):
+        if out_coordinate_map_key is None:
+            out_coordinate_map_key = CoordinateMapKey(in_coordinate_map_key.get_coordinate_size())
+        input_features = input_features.contiguous()
+        ctx.input_features = input_features
+        ctx.kernel_weights = kernel_weights
+        ctx.misc = (kernel_generator, convolution_mode, in_coordinate_map_key, out_coordinate_map_key,
+                    coordinate_manager)
+        fw_fn = get_minkowski_function("ConvolutionForward", input_features)
+        return fw_fn(input_features, kernel_weights, kernel_generator.kernel_size, kernel_generator.kernel_stride,
+                     kernel_generator.kernel_dilation, kernel_generator.region_type,
+                     kernel_generator.region_offsets, kernel_generator.expand_coordinates, convolution_mode,
+                     in_coordinate_map_key, out_coordinate_map_key, coordinate_manager._manager)
+
+    @staticmethod
+    def backward(ctx, grad_out_feat):
+        grad_out_feat = grad_out_feat.contiguous()
+        kernel_generator, convolution_mode, in_key, out_key, coordinate_manager = ctx.misc
+        bw_fn = get_minkowski_function("ConvolutionBackward", grad_out_feat)
+        grad_in_feat, grad_kernel = bw_fn(ctx.input_features, grad_out_feat, ctx.kernel_weights,
+                                          kernel_generator.kernel_size, kernel_generator.kernel_stride,
+                                          kernel_generator.kernel_dilation, kernel_generator.region_type,
+                                          kernel_generator.region_offsets, convolution_mode, in_key, out_key,
+                                          coordinate_manager._manager)
+        return grad_in_feat, grad_kernel, None, None, None, None, None
+
+
+class MinkowskiConvolutionTransposeFunction(Function):
+    @staticmethod
+    def forward(ctx, input_features, kernel_weights, kernel_generator, convolution_mode, in_coordinate_map_key,
+                out_coordinate_map_key=None, coordinate_manager=None):
+        if out_coordinate_map_key is None:
+            out_coordinate_map_key = CoordinateMapKey(in_coordinate_map_key.get_coordinate_size())
+        input_features = input_features.contiguous()
+        ctx.input_features = input_features
+        ctx.kernel_weights = kernel_weights
+        ctx.misc = (kernel_generator, convolution_mode, in_coordinate_map_key, out_coordinate_map_key,
+                    coordinate_manager)
+        fw_fn = get_minkowski_function("ConvolutionTransposeForward", input_features)
+        return fw_fn(input_features, kernel_weights, kernel_generator.kernel_size, kernel_generator.kernel_stride,
+                     kernel_generator.kernel_dilation, kernel_generator.region_type,
+                     kernel_generator.region_offsets, kernel_generator.expand_coordinates, convolution_mode,
+                     in_coordinate_map_key, out_coordinate_map_key, coordinate_manager._manager)
+
+    @staticmethod
+    def backward(ctx, grad_out_feat):
+        grad_out_feat = grad_out_feat.contiguous()
+        kernel_generator, convolution_mode, in_key, out_key, coordinate_manager = ctx.misc
+        bw_fn = get_minkowski_function("ConvolutionTransposeBackward", grad_out_feat)
+        grad_in_feat, grad_kernel = bw_fn(ctx.input_features, grad_out_feat, ctx.kernel_weights,
+                                          kernel_generator.kernel_size, kernel_generator.kernel_stride,
+                                          kernel_generator.kernel_dilation, kernel_generator.region_type,
+                                          kernel_generator.region_offsets, convolution_mode, in_key, out_key,
+                                          coordinate_manager._manager)
+        return grad_in_feat, grad_kernel, None, None, None, None, None
+
+
+class MinkowskiModuleBase(Module):
+    pass
+
+
+class MinkowskiConvolutionBase(MinkowskiModuleBase):
+    def __init__(self, in_channels, out_channels, kernel_size=-1, stride=1, dilation=1, bias=False,
+                 kernel_generator=None, is_transpose=False, expand_coordinates=False,
+                 convolution_mode=ConvolutionMode.DEFAULT, dimension=-1):
+        super().__init__()
+        assert dimension > 0, f"Invalid dimension. Please provide a valid dimension argument. dimension={dimension}"
+        if kernel_generator is None:
+            kernel_generator = KernelGenerator(kernel_size=kernel_size, stride=stride, dilation=dilation,
+                                               expand_coordinates=expand_coordinates, dimension=dimension)
+        else:
+            kernel_generator.expand_coordinates = expand_coordinates
+        self.is_transpose = is_transpose
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.kernel_generator = kernel_generator
+        self.dimension = dimension
+        # kernel volume 1 and all strides 1 -> a plain matrix product (MinkowskiConvolution.py:264-270)
+        self.use_mm = (kernel_generator.kernel_volume == 1 and kernel_generator.requires_strided_coordinates)
+        if self.use_mm:
+            kernel_shape = (in_channels, out_channels)
+        else:
+            kernel_shape = (kernel_generator.kernel_volume, in_channels, out_channels)
+        self.kernel = Parameter(torch.empty(*kernel_shape, dtype=torch.float32))
+        self.bias = Parameter(torch.empty(1, out_channels, dtype=torch.float32)) if bias else None
+        self.convolution_mode = convolution_mode
+        self.conv = (MinkowskiConvolutionTransposeFunction() if is_transpose else MinkowskiConvolutionFunction())
+
+    def forward(self, input, coordinates=None):
+        assert isinstance(input, SparseTensor)
+        assert input.D == self.dimension
+        if self.use_mm:
+            out_coordinate_map_key = input.coordinate_map_key
+            outfeat = input.F.mm(self.kernel)
+        else:
+            # (the reference passes expand_coordinates positionally into the tensor_stride slot,
+            # MinkowskiConvolution.py:311-313; passed by keyword here)
+            out_coordinate_map_key = _get_coordinate_map_key(
+                input, coordinates, expand_coordinates=self.kernel_generator.expand_coordinates)
+            outfeat = self.conv.apply(input.F, self.kernel, self.kernel_generator, self.convolution_mode,
+                                      input.coordinate_map_key, out_coordinate_map_key, input._manager)
+        if self.bias is not None:
+            outfeat = outfeat + self.bias
+        return SparseTensor(outfeat, coordinate_map_key=out_coordinate_map_key, coordinate_manager=input._manager)
+
+    def reset_parameters(self, is_transpose=False):
+        with torch.no_grad():
+            n = (self.out_channels if is_transpose else self.in_channels) * self.kernel_generator.kernel_volume
+            stdv = 1.0 / math.sqrt(n)
+            self.kernel.data.uniform_(-stdv, stdv)
+            if self.bias is not None:
+                self.bias.data.uniform_(-stdv, stdv)
+
+    def __repr__(self):
+        s = f"(in={self.in_channels}, out={self.out_channels}, "
+        if self.kernel_generator.region_type in [RegionType.CUSTOM]:
+            s += f"region_type={self.kernel_generator.region_type}, kernel_volume={self.kernel_generator.kernel_volume}, "
+        else:
+            s += f"kernel_size={self.kernel_generator.kernel_size}, "
+        s += f"stride={self.kernel_generator.kernel_stride}, dilation={self.kernel_generator.kernel_dilation})"
+        return self.__class__.__name__ + s
+
+
+class MinkowskiConvolution(MinkowskiConvolutionBase):
+    """out_u = sum_k W_k^T x_{u + offset(k)} over the existing input voxels
+    (MinkowskiConvolution.py:360-451)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=-1, stride=1, dilation=1, bias=False,
+                 kernel_generator=None, expand_coordinates=False, convolution_mode=ConvolutionMode.DEFAULT,
+                 dimension=None):
+        super().__init__(in_channels, out_channels, kernel_size, stride, dilation, bias, kernel_generator,
+                         is_transpose=False, expand_coordinates=expand_coordinates,
+                         convolution_mode=convolution_mode, dimension=dimension)
+        self.reset_parameters()
+
+
+class MinkowskiConvolutionTranspose(MinkowskiConvolutionBase):
+    """Transposed (up-sampling) convolution (MinkowskiConvolution.py:454-560)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=-1, stride=1, dilation=1, bias=False,
+                 kernel_generator=None, expand_coordinates=False, convolution_mode=ConvolutionMode.DEFAULT,
+                 dimension=None):
+        if kernel_generator is None:
+            kernel_generator = KernelGenerator(kernel_size=kernel_size, stride=stride, dilation=dilation,
+                                               dimension=dimension)
+        super().__init__(in_channels, out_channels, kernel_size, stride, dilation, bias, kernel_generator,
+                         is_transpose=True, expand_coordinates=expand_coordinates,
+                         convolution_mode=convolution_mode, dimension=dimension)
+        self.reset_parameters(True)

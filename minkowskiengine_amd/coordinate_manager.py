@@ -1,0 +1,104 @@
+"""CoordinateManager: thin Python wrapper that owns a backend coordinate-map manager
+(reference: MinkowskiEngine/MinkowskiCoordinateManager.py:107-440)."""
+import os
+
+import torch
+
+from . import backend as MEB
+from .backend import (CoordinateMapKey, CoordinateMapType, GPUMemoryAllocatorType, MinkowskiAlgorithm,
+                      RegionType)
+from .common import convert_to_int_list
+
+_allocator_type = GPUMemoryAllocatorType.PYTORCH
+_coordinate_map_type = CoordinateMapType.CUDA
+_minkowski_algorithm = MinkowskiAlgorithm.DEFAULT
+
+
+def set_coordinate_map_type(coordinate_map_type):
+    global _coordinate_map_type
+    _coordinate_map_type = coordinate_map_type
+
+
+def set_gpu_allocator(backend):
+    """MinkowskiCoordinateManager.py:63-89.  Both values use the torch caching allocator here."""
+    assert isinstance(backend, GPUMemoryAllocatorType)
+    global _allocator_type
+    _allocator_type = backend
+
+
+def set_memory_manager_backend(backend):
+    set_gpu_allocator(backend)
+
+
+class CoordinateManager:
+    def __init__(self, D=0, num_threads=-1, coordinate_map_type=None, allocator_type=None,
+                 minkowski_algorithm=None):
+        if D < 1:
+            raise ValueError(f"Invalid rank D > 0, D = {D}.")
+        if num_threads < 0:
+            num_threads = min(os.cpu_count() or 1, 20)
+        if coordinate_map_type is None:
+            coordinate_map_type = _coordinate_map_type
+        if allocator_type is None:
+            allocator_type = _allocator_type
+        if minkowski_algorithm is None:
+            minkowski_algorithm = _minkowski_algorithm
+        if coordinate_map_type == CoordinateMapType.CPU:
+            raise RuntimeError("minkowskiengine_amd has no CPU coordinate map: the MI355X path keeps maps in HBM. "
+                               "Pass GPU coordinates.")
+        self._CoordinateManagerClass = (MEB.CoordinateMapManagerGPU_c10
+                                        if allocator_type == GPUMemoryAllocatorType.PYTORCH
+                                        else MEB.CoordinateMapManagerGPU_default)
+        self._manager = self._CoordinateManagerClass(minkowski_algorithm, num_threads)
+        self.D = D
+        self.minkowski_algorithm = minkowski_algorithm
+
+    # ---- maps -----------------------------------------------------------------------------------
+    def insert_and_map(self, coordinates, tensor_stride=1, string_id=""):
+        """-> (CoordinateMapKey, (unique_map, inverse_map)); MinkowskiCoordinateManager.py:153-179"""
+        tensor_stride = convert_to_int_list(tensor_stride, self.D)
+        return self._manager.insert_and_map(coordinates, tensor_stride, string_id)
+
+    def stride(self, coordinate_map_key, stride, string_id=""):
+        stride = convert_to_int_list(stride, self.D)
+        return self._manager.stride(coordinate_map_key, stride, string_id)
+
+    def size(self, coordinate_map_key):
+        return self._manager.size(coordinate_map_key)
+
+    def exists_coordinate_map_key(self, coordinate_map_key):
+        return self._manager.exists(coordinate_map_key)
+
+    def get_coordinates(self, coords_key_or_tensor_strides):
+        key = coords_key_or_tensor_strides
+        if not isinstance(key, CoordinateMapKey):
+            key = CoordinateMapKey(convert_to_int_list(key, self.D), "")
+        return self._manager.get_coordinates(key)
+
+    def get_unique_coordinate_map_key(self, tensor_stride):
+        ts = convert_to_int_list(tensor_stride, self.D)
+        sid = self._manager.get_random_string_id(ts, "")
+        return CoordinateMapKey(sid[0], sid[1])
+
+    def get_coordinate_map_keys(self, tensor_stride):
+        return self._manager.get_coordinate_map_keys(convert_to_int_list(tensor_stride, self.D))
+
+    # ---- kernel maps ----------------------------------------------------------------------------
+    def kernel_map(self, in_key, out_key, stride=1, kernel_size=3, dilation=1, region_type=RegionType.HYPER_CUBE,
+                   region_offset=None, is_transpose=False, is_pool=False):
+        """dict {k: int32 [2, n_k]}; MinkowskiCoordinateManager.py:377-421"""
+        D = in_key.get_coordinate_size() - 1
+        if region_offset is None:
+            region_offset = torch.IntTensor()
+        return self._manager.kernel_map(in_key, out_key, convert_to_int_list(kernel_size, D),
+                                        convert_to_int_list(stride, D), convert_to_int_list(dilation, D),
+                                        region_type, region_offset, is_transpose, is_pool)
+
+    def number_of_unique_batch_indices(self):
+        keys = list(self._manager._maps.values())
+        if not keys:
+            return 0
+        return int(torch.unique(keys[0].coords[:, 0]).numel())
+
+    def __repr__(self):
+        return f"{self.__class__.__name__}(\n{self._manager!r}\n)"

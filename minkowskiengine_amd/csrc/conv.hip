@@ -1,0 +1,565 @@
+// Sparse convolution feature kernels for gfx950 (MI355X): forward / dgrad / wgrad in exact fp32 on
+// the matrix cores (v_mfma_f32_16x16x4_f32 and v_mfma_f32_32x32x2_f32).
+//
+// Replaces ConvolutionForwardKernelGPU / ConvolutionBackwardKernelGPU
+// (src/convolution_kernel.cu:320-496, 553-757).  The reference launches one gather-GEMM-scatter per
+// kernel offset and scatters with one global atomicAdd per output element
+// (src/convolution_kernel.cu:114-180).  Here the TARGET rows are stationary instead:
+//
+//   * a workgroup owns ME_TILE_ROWS target rows x NC output columns; its fp32 accumulator tile
+//     lives in LDS (128 x 64 x 4 B = 32 KiB of the CU's 160 KiB);
+//   * the tile plan (coords.hip) lists, per tile, the valid (offset k, source row) entries grouped
+//     by k in groups of 16 rows = one MFMA M-tile, so no matrix-core work is spent on absent
+//     neighbours beyond the padding of the last group of each (tile, k);
+//   * source rows are gathered with 16-byte loads into a padded LDS tile (register-staged, issued
+//     one batch ahead of the MFMAs that consume it), each wave keeps its 16-column slice of W_k
+//     in registers for the whole run of groups of one offset, and adds its 16x16 result block into
+//     the LDS accumulator at the target rows (wave-private columns -> no atomics, fixed summation
+//     order -> bitwise reproducible);
+//   * every target row is written exactly once with coalesced 16-byte stores: no zero-fill pass,
+//     no global atomics.
+// dgrad is the same kernel with source = grad_out, W = per-offset transposed kernel and the plan
+// of the transposed neighbour table.  wgrad reduces over the per-offset pair lists in chunks.
+#include "common.hpp"
+
+namespace me {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kTile = ME_TILE_ROWS;  // target rows per workgroup
+constexpr int kGB = 4;               // groups (of 16 gathered rows) per LDS batch
+constexpr int kRows = kGB * 16;      // gathered rows per batch
+
+// =================================================================================================
+// target-stationary convolution (forward and dgrad)
+// =================================================================================================
+template <int NC, int KC>
+__global__ __launch_bounds__(NC * 4) void k_conv_target_f32(
+    const float *__restrict__ src, int c_src, const float *__restrict__ w, int c_dst,
+    const int32_t *__restrict__ plan_src, const int32_t *__restrict__ plan_dst,
+    const int32_t *__restrict__ group_k, const int32_t *__restrict__ tile_gptr,
+    float *__restrict__ dst, int64_t n_tgt) {
+  constexpr int WAVES = NC / 16;
+  constexpr int NT = WAVES * 64;
+  constexpr int A_LD = KC + 4;         // floats; +16 B per row spreads ds_read_b128 over the banks
+  constexpr int KQ = KC / 4;           // MFMA k-steps per chunk (= B registers per lane)
+  constexpr int F4_PER_ROW = KC / 4;   // 16-byte pieces per gathered row
+  constexpr int ITER = kRows * F4_PER_ROW / NT;
+  static_assert(kRows * F4_PER_ROW % NT == 0, "gather work must divide evenly");
+  static_assert(KC % 16 == 0, "KC must be a multiple of 16");
+
+  __shared__ __attribute__((aligned(16))) float s_acc[kTile * NC];
+  __shared__ __attribute__((aligned(16))) float s_a[kRows * A_LD];
+  __shared__ int32_t s_dst[kRows];
+  __shared__ int32_t s_k[kGB];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int i16 = lane & 15;  // MFMA row (A) / column (B, D) index of this lane
+  const int q = lane >> 4;    // MFMA k index (A, B) / row block (D) of this lane
+  const int tile = blockIdx.x;
+  const int col_base = blockIdx.y * NC;
+  const int col = col_base + wave * 16 + i16;
+  const int g_begin = tile_gptr[tile];
+  const int g_end = tile_gptr[tile + 1];
+  const bool vec_ok = (c_src % 4) == 0;
+
+  for (int x = tid; x < kTile * NC / 4; x += NT)
+    reinterpret_cast<f32x4 *>(s_acc)[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int c0 = 0; c0 < c_src; c0 += KC) {
+    float breg[KQ];
+    int cur_k = -1;
+    f32x4 stage[ITER];
+
+    // issue the gather loads of batch `gb` (global -> registers)
+    auto gather_issue = [&](int gb) {
+      const int ng = min(kGB, g_end - gb);
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) {
+        const int idx = it * NT + tid;
+        const int r = idx / F4_PER_ROW;
+        const int ch = c0 + (idx % F4_PER_ROW) * 4;
+        int s = -1;
+        if (r < ng * 16) s = plan_src[(int64_t)gb * 16 + r];
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+        if (s >= 0 && ch < c_src) {
+          const float *rowp = src + (int64_t)s * c_src + ch;
+          if (vec_ok) {
+            t = *reinterpret_cast<const f32x4 *>(rowp);
+          } else {
+            t.x = rowp[0];
+            if (ch + 1 < c_src) t.y = rowp[1];
+            if (ch + 2 < c_src) t.z = rowp[2];
+            if (ch + 3 < c_src) t.w = rowp[3];
+          }
+        }
+        stage[it] = t;
+      }
+    };
+
+    if (g_begin < g_end) gather_issue(g_begin);
+
+    for (int gb = g_begin; gb < g_end; gb += kGB) {
+      const int ng = min(kGB, g_end - gb);
+      __syncthreads();  // consumers of the previous batch are done with s_a / s_dst / s_k
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) {
+        const int idx = it * NT + tid;
+        const int r = idx / F4_PER_ROW;
+        const int p = idx % F4_PER_ROW;
+        *reinterpret_cast<f32x4 *>(&s_a[r * A_LD + p * 4]) = stage[it];
+      }
+      if (tid < kRows) s_dst[tid] = (tid < ng * 16) ? plan_dst[(int64_t)gb * 16 + tid] : -1;
+      if (tid < kGB) s_k[tid] = (tid < ng) ? group_k[gb + tid] : -1;
+      __syncthreads();
+      // next batch's loads fly while this batch is multiplied
+      if (gb + kGB < g_end) gather_issue(gb + kGB);
+
+      int g = 0;
+      while (g < ng) {
+        const int k0 = s_k[g];
+        const bool two = (g + 1 < ng) && (s_k[g + 1] == k0);
+        if (k0 != cur_k) {
+          cur_k = k0;
+#pragma unroll
+          for (int s = 0; s < KQ; ++s) {
+            const int kidx = c0 + q * KQ + s;
+            breg[s] = (kidx < c_src && col < c_dst)
+                          ? w[((int64_t)k0 * c_src + kidx) * c_dst + col]
+                          : 0.f;
+          }
+        }
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
+        const float *a0p = &s_a[(g * 16 + i16) * A_LD + q * KQ];
+        if (two) {
+          const float *a1p = a0p + 16 * A_LD;
+#pragma unroll
+          for (int s4 = 0; s4 < KQ / 4; ++s4) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(a0p + s4 * 4);
+            const f32x4 a1 = *reinterpret_cast<const f32x4 *>(a1p + s4 * 4);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, breg[s4 * 4 + 0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, breg[s4 * 4 + 0], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, breg[s4 * 4 + 1], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, breg[s4 * 4 + 1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, breg[s4 * 4 + 2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, breg[s4 * 4 + 2], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, breg[s4 * 4 + 3], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, breg[s4 * 4 + 3], acc1, 0, 0, 0);
+          }
+        } else {
+#pragma unroll
+          for (int s4 = 0; s4 < KQ / 4; ++s4) {
+            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(a0p + s4 * 4);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, breg[s4 * 4 + 0], acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, breg[s4 * 4 + 1], acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, breg[s4 * 4 + 2], acc0, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, breg[s4 * 4 + 3], acc0, 0, 0, 0);
+          }
+        }
+        // D[row = q*4 + r][col = i16] -> accumulator rows named by the plan (wave-private columns)
+        float *accp = &s_acc[wave * 16 + i16];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int d0 = s_dst[g * 16 + q * 4 + r];
+          if (d0 >= 0) accp[d0 * NC] += acc0[r];
+        }
+        if (two) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int d1 = s_dst[(g + 1) * 16 + q * 4 + r];
+            if (d1 >= 0) accp[d1 * NC] += acc1[r];
+          }
+        }
+        g += two ? 2 : 1;
+      }
+    }
+    __syncthreads();  // all reads of s_a done before the next chunk restages it
+  }
+
+  __syncthreads();
+  const int64_t row0 = (int64_t)tile * kTile;
+  const int rows_here = (int)min((int64_t)kTile, n_tgt - row0);
+  const bool vec_out = (c_dst % 4) == 0;
+  for (int x = tid; x < kTile * NC / 4; x += NT) {
+    const int row = x / (NC / 4);
+    const int cc = col_base + (x % (NC / 4)) * 4;
+    if (row < rows_here && cc < c_dst) {
+      const f32x4 v = reinterpret_cast<const f32x4 *>(s_acc)[x];
+      float *o = dst + (row0 + row) * c_dst + cc;
+      if (vec_out) {
+        *reinterpret_cast<f32x4 *>(o) = v;
+      } else {
+        o[0] = v.x;
+        if (cc + 1 < c_dst) o[1] = v.y;
+        if (cc + 2 < c_dst) o[2] = v.z;
+        if (cc + 3 < c_dst) o[3] = v.w;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_transpose_kernel(const float *__restrict__ w, int64_t volume,
+                                                         int c_in, int c_out,
+                                                         float *__restrict__ wt) {
+  // wt[k][j][i] = w[k][i][j]; 32x32 LDS tile transpose
+  __shared__ float s[32][33];
+  const int k = blockIdx.z;
+  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const float *wk = w + (int64_t)k * c_in * c_out;
+  float *wtk = wt + (int64_t)k * c_in * c_out;
+  for (int r = ty; r < 32; r += 8) {
+    const int i = i0 + r, j = j0 + tx;
+    s[r][tx] = (i < c_in && j < c_out) ? wk[(int64_t)i * c_out + j] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int j = j0 + r, i = i0 + tx;
+    if (i < c_in && j < c_out) wtk[(int64_t)j * c_in + i] = s[tx][r];
+  }
+}
+
+// =================================================================================================
+// wgrad: grad_w[k] = X_g^T (c_in x n_k) . dY_g (n_k x c_out), reduction over the pairs of offset k
+// =================================================================================================
+constexpr int kWgPB = 32;       // pairs per LDS batch
+constexpr int kWgLD = 64 + 16;  // floats per staged row (stride = 16 mod 32 banks)
+
+// chunk -> (k, first pair, last pair): chunks are ME_WGRAD_CHUNK pairs of one offset
+__device__ __forceinline__ void wgrad_locate_chunk(const int64_t *__restrict__ koffs, int volume,
+                                                   int chunk, int &k_out, int64_t &e0, int64_t &e1) {
+  int c = 0;
+  k_out = -1;
+  e0 = e1 = 0;
+  for (int k = 0; k < volume; ++k) {
+    const int64_t b = koffs[k], e = koffs[k + 1];
+    const int nck = (int)((e - b + ME_WGRAD_CHUNK - 1) / ME_WGRAD_CHUNK);
+    if (chunk < c + nck) {
+      k_out = k;
+      e0 = b + (int64_t)(chunk - c) * ME_WGRAD_CHUNK;
+      e1 = min(e, e0 + ME_WGRAD_CHUNK);
+      return;
+    }
+    c += nck;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_wgrad_f32(const float *__restrict__ x, int c_in,
+                                                  const float *__restrict__ dy, int c_out,
+                                                  const int32_t *__restrict__ in_pairs,
+                                                  const int32_t *__restrict__ out_pairs,
+                                                  const int64_t *__restrict__ koffs, int volume,
+                                                  float *__restrict__ partial) {
+  __shared__ __attribute__((aligned(16))) float s_x[kWgPB * kWgLD];
+  __shared__ __attribute__((aligned(16))) float s_y[kWgPB * kWgLD];
+  __shared__ int s_k;
+  __shared__ int64_t s_e[2];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int chunk = blockIdx.x;
+  const int ci0 = blockIdx.y * 64, co0 = blockIdx.z * 64;
+  if (tid == 0) {
+    int k;
+    int64_t e0, e1;
+    wgrad_locate_chunk(koffs, volume, chunk, k, e0, e1);
+    s_k = k;
+    s_e[0] = e0;
+    s_e[1] = e1;
+  }
+  __syncthreads();
+  const int64_t e0 = s_e[0], e1 = s_e[1];
+  const int wm = wave >> 1, wn = wave & 1;
+  const bool vx = (c_in % 4) == 0, vy = (c_out % 4) == 0;
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  // 32 rows x 16 float4 per operand = 512 float4; 256 threads -> 2 per thread per operand
+  f32x4 sx[2], sy[2];
+  auto issue = [&](int64_t eb) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int idx = it * 256 + tid;
+      const int r = idx >> 4;
+      const int p = idx & 15;
+      const int64_t e = eb + r;
+      f32x4 tx = {0.f, 0.f, 0.f, 0.f}, ty = {0.f, 0.f, 0.f, 0.f};
+      if (e < e1) {
+        const int ci = ci0 + p * 4, co = co0 + p * 4;
+        if (ci < c_in) {
+          const float *xp = x + (int64_t)in_pairs[e] * c_in + ci;
+          if (vx) {
+            tx = *reinterpret_cast<const f32x4 *>(xp);
+          } else {
+            tx.x = xp[0];
+            if (ci + 1 < c_in) tx.y = xp[1];
+            if (ci + 2 < c_in) tx.z = xp[2];
+            if (ci + 3 < c_in) tx.w = xp[3];
+          }
+        }
+        if (co < c_out) {
+          const float *yp = dy + (int64_t)out_pairs[e] * c_out + co;
+          if (vy) {
+            ty = *reinterpret_cast<const f32x4 *>(yp);
+          } else {
+            ty.x = yp[0];
+            if (co + 1 < c_out) ty.y = yp[1];
+            if (co + 2 < c_out) ty.z = yp[2];
+            if (co + 3 < c_out) ty.w = yp[3];
+          }
+        }
+      }
+      sx[it] = tx;
+      sy[it] = ty;
+    }
+  };
+
+  if (e0 < e1) issue(e0);
+  for (int64_t eb = e0; eb < e1; eb += kWgPB) {
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const int idx = it * 256 + tid;
+      const int r = idx >> 4, p = idx & 15;
+      *reinterpret_cast<f32x4 *>(&s_x[r * kWgLD + p * 4]) = sx[it];
+      *reinterpret_cast<f32x4 *>(&s_y[r * kWgLD + p * 4]) = sy[it];
+    }
+    __syncthreads();
+    if (eb + kWgPB < e1) issue(eb + kWgPB);
+    const float *ap = &s_x[(lane >> 5) * kWgLD + wm * 32 + (lane & 31)];
+    const float *bp = &s_y[(lane >> 5) * kWgLD + wn * 32 + (lane & 31)];
+#pragma unroll
+    for (int s = 0; s < kWgPB / 2; ++s)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[s * 2 * kWgLD], bp[s * 2 * kWgLD], acc, 0, 0, 0);
+  }
+
+  float *pp = partial + (int64_t)chunk * c_in * c_out;
+  const int colo = co0 + wn * 32 + (lane & 31);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = ci0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (row < c_in && colo < c_out) pp[(int64_t)row * c_out + colo] = acc[r];
+  }
+}
+
+// grad_w[k][idx] = sum of the partial tiles of offset k's chunks, in chunk order (deterministic)
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ partial,
+                                                     const int64_t *__restrict__ koffs, int volume,
+                                                     int64_t cc, float *__restrict__ grad_w) {
+  __shared__ int s_c[2];
+  const int k = blockIdx.y;
+  if (threadIdx.x == 0) {
+    int c = 0;
+    for (int kk = 0; kk < k; ++kk)
+      c += (int)((koffs[kk + 1] - koffs[kk] + ME_WGRAD_CHUNK - 1) / ME_WGRAD_CHUNK);
+    s_c[0] = c;
+    s_c[1] = c + (int)((koffs[k + 1] - koffs[k] + ME_WGRAD_CHUNK - 1) / ME_WGRAD_CHUNK);
+  }
+  __syncthreads();
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= cc) return;
+  float s = 0.f;
+  for (int c = s_c[0]; c < s_c[1]; ++c) s += partial[(int64_t)c * cc + idx];
+  grad_w[(int64_t)k * cc + idx] = s;
+}
+
+// =================================================================================================
+// naive cross-check kernels (VALU + global atomics on the pair lists)
+// =================================================================================================
+__device__ __forceinline__ int locate_offset(const int64_t *__restrict__ koffs, int volume, int64_t e) {
+  int lo = 0, hi = volume;  // largest k with koffs[k] <= e
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (koffs[mid] <= e) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void k_naive_forward(const float *__restrict__ in_feat, int c_in,
+                                                      const float *__restrict__ w, int c_out,
+                                                      const int32_t *__restrict__ in_pairs,
+                                                      const int32_t *__restrict__ out_pairs,
+                                                      const int64_t *__restrict__ koffs, int volume,
+                                                      int64_t n_pairs, float *out_feat) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_pairs * c_out) return;
+  const int64_t e = t / c_out;
+  const int j = (int)(t % c_out);
+  const int k = locate_offset(koffs, volume, e);
+  const float *xr = in_feat + (int64_t)in_pairs[e] * c_in;
+  const float *wk = w + (int64_t)k * c_in * c_out + j;
+  float s = 0.f;
+  for (int i = 0; i < c_in; ++i) s = fmaf(xr[i], wk[(int64_t)i * c_out], s);
+  atomicAdd(&out_feat[(int64_t)out_pairs[e] * c_out + j], s);
+}
+
+__global__ __launch_bounds__(256) void k_naive_dgrad(const float *__restrict__ grad_out, int c_out,
+                                                    const float *__restrict__ w, int c_in,
+                                                    const int32_t *__restrict__ in_pairs,
+                                                    const int32_t *__restrict__ out_pairs,
+                                                    const int64_t *__restrict__ koffs, int volume,
+                                                    int64_t n_pairs, float *grad_in) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_pairs * c_in) return;
+  const int64_t e = t / c_in;
+  const int i = (int)(t % c_in);
+  const int k = locate_offset(koffs, volume, e);
+  const float *gr = grad_out + (int64_t)out_pairs[e] * c_out;
+  const float *wk = w + ((int64_t)k * c_in + i) * c_out;
+  float s = 0.f;
+  for (int j = 0; j < c_out; ++j) s = fmaf(gr[j], wk[j], s);
+  atomicAdd(&grad_in[(int64_t)in_pairs[e] * c_in + i], s);
+}
+
+__global__ __launch_bounds__(256) void k_naive_wgrad(const float *__restrict__ in_feat, int c_in,
+                                                    const float *__restrict__ grad_out, int c_out,
+                                                    const int32_t *__restrict__ in_pairs,
+                                                    const int32_t *__restrict__ out_pairs,
+                                                    const int64_t *__restrict__ koffs, int volume,
+                                                    float *__restrict__ grad_w) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t cc = (int64_t)c_in * c_out;
+  if (t >= (int64_t)volume * cc) return;
+  const int k = (int)(t / cc);
+  const int i = (int)((t % cc) / c_out), j = (int)(t % c_out);
+  float s = 0.f;
+  for (int64_t e = koffs[k]; e < koffs[k + 1]; ++e)
+    s = fmaf(in_feat[(int64_t)in_pairs[e] * c_in + i], grad_out[(int64_t)out_pairs[e] * c_out + j], s);
+  grad_w[t] = s;
+}
+
+template <int NC, int KC>
+static int launch_conv_target(const float *src, int c_src, const float *w, int c_dst,
+                              const int32_t *plan_src, const int32_t *plan_dst, const int32_t *group_k,
+                              const int32_t *tile_gptr, float *dst, int64_t n_tgt, hipStream_t stream) {
+  const dim3 grid((unsigned)ceil_div(n_tgt, kTile), (unsigned)ceil_div(c_dst, NC));
+  hipLaunchKernelGGL((k_conv_target_f32<NC, KC>), grid, dim3(NC * 4), 0, stream, src, c_src, w, c_dst,
+                     plan_src, plan_dst, group_k, tile_gptr, dst, n_tgt);
+  ME_LAUNCH_CHECK();
+  return 0;
+}
+
+static int64_t wgrad_num_chunks(const int64_t *k_offsets, int64_t volume) {
+  int64_t c = 0;
+  for (int64_t k = 0; k < volume; ++k) c += ceil_div(k_offsets[k + 1] - k_offsets[k], ME_WGRAD_CHUNK);
+  return c;
+}
+
+}  // namespace me
+
+using namespace me;
+
+extern "C" {
+
+int me_conv_target_f32(const float *src, int64_t n_src, int32_t c_src, const float *w, int64_t volume,
+                       int32_t c_dst, const int32_t *plan_src, const int32_t *plan_dst,
+                       const int32_t *group_k, const int32_t *tile_gptr, float *dst, int64_t n_tgt,
+                       void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  (void)n_src;
+  (void)volume;
+  ME_CHECK(c_src > 0 && c_dst > 0, "channel counts must be positive");
+  ME_CHECK((uintptr_t)src % 16 == 0 && (uintptr_t)dst % 16 == 0, "feature pointers must be 16-byte aligned");
+  if (n_tgt == 0) return 0;
+  // columns per workgroup: 64 unless the last 64-column slab would be at most half full
+  const int rem = c_dst % 64;
+  const bool nc32 = (rem != 0 && rem <= 32);
+  // source-channel chunk: the largest of {64, 32, 16} that does not add padding beyond a multiple of 16
+  int kc;
+  if (c_src % 64 == 0) kc = 64;
+  else if (c_src % 32 == 0) kc = 32;
+  else if (c_src <= 16) kc = 16;
+  else if (c_src <= 32) kc = 32;
+  else kc = (align_up(c_src, 64) - c_src <= 16) ? 64 : ((align_up(c_src, 32) - c_src <= 16) ? 32 : 16);
+#define ME_CONV_CASE(NCV, KCV)                                                                    \
+  return launch_conv_target<NCV, KCV>(src, c_src, w, c_dst, plan_src, plan_dst, group_k, tile_gptr, \
+                                      dst, n_tgt, stream)
+  if (nc32) {
+    if (kc == 64) ME_CONV_CASE(32, 64);
+    if (kc == 32) ME_CONV_CASE(32, 32);
+    ME_CONV_CASE(32, 16);
+  } else {
+    if (kc == 64) ME_CONV_CASE(64, 64);
+    if (kc == 32) ME_CONV_CASE(64, 32);
+    ME_CONV_CASE(64, 16);
+  }
+#undef ME_CONV_CASE
+}
+
+int me_transpose_kernel_f32(const float *w, int64_t volume, int32_t c_in, int32_t c_out, float *wt,
+                            void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ME_CHECK(volume >= 1 && volume <= 65535, "kernel volume out of range");
+  const dim3 grid((unsigned)ceil_div(c_out, 32), (unsigned)ceil_div(c_in, 32), (unsigned)volume);
+  hipLaunchKernelGGL(k_transpose_kernel, grid, dim3(256), 0, stream, w, volume, c_in, c_out, wt);
+  ME_LAUNCH_CHECK();
+  return 0;
+}
+
+int64_t me_conv_wgrad_workspace_bytes(const int64_t *k_offsets, int64_t volume, int32_t c_in, int32_t c_out) {
+  int64_t chunks = wgrad_num_chunks(k_offsets, volume);
+  if (chunks < 1) chunks = 1;
+  return align_up(chunks * (int64_t)c_in * c_out * 4, 256);
+}
+
+int me_conv_wgrad_f32(const float *x, int32_t c_in, const float *dy, int32_t c_out, const int32_t *in_pairs,
+                      const int32_t *out_pairs, const int64_t *k_offsets, const int64_t *k_offsets_dev,
+                      int64_t volume, float *grad_w, void *workspace, int64_t workspace_bytes,
+                      void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ME_CHECK(volume >= 1 && volume <= 65535, "kernel volume out of range");
+  ME_CHECK(c_in > 0 && c_out > 0, "channel counts must be positive");
+  ME_CHECK((uintptr_t)x % 16 == 0 && (uintptr_t)dy % 16 == 0, "feature pointers must be 16-byte aligned");
+  ME_CHECK(workspace_bytes >= me_conv_wgrad_workspace_bytes(k_offsets, volume, c_in, c_out),
+           "workspace too small");
+  const int64_t chunks = wgrad_num_chunks(k_offsets, volume);
+  float *partial = reinterpret_cast<float *>(workspace);
+  if (chunks > 0) {
+    const dim3 grid((unsigned)chunks, (unsigned)ceil_div(c_in, 64), (unsigned)ceil_div(c_out, 64));
+    hipLaunchKernelGGL(k_wgrad_f32, grid, dim3(256), 0, stream, x, c_in, dy, c_out, in_pairs, out_pairs,
+                       k_offsets_dev, (int)volume, partial);
+    ME_LAUNCH_CHECK();
+  }
+  const int64_t cc = (int64_t)c_in * c_out;
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)ceil_div(cc, 256), (unsigned)volume), dim3(256), 0,
+                     stream, partial, k_offsets_dev, (int)volume, cc, grad_w);
+  ME_LAUNCH_CHECK();
+  return 0;
+}
+
+int me_conv_forward_naive_f32(const float *in_feat, int32_t c_in, const float *w, int32_t c_out,
+                              const int32_t *in_pairs, const int32_t *out_pairs, const int64_t *k_offsets_dev,
+                              int64_t volume, int64_t n_pairs, float *out_feat, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_pairs == 0) return 0;
+  const int64_t total = n_pairs * c_out;
+  hipLaunchKernelGGL(k_naive_forward, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream, in_feat,
+                     c_in, w, c_out, in_pairs, out_pairs, k_offsets_dev, (int)volume, n_pairs, out_feat);
+  ME_LAUNCH_CHECK();
+  return 0;
+}
+
+int me_conv_backward_naive_f32(const float *in_feat, int32_t c_in, const float *grad_out, int32_t c_out,
+                               const float *w, const int32_t *in_pairs, const int32_t *out_pairs,
+                               const int64_t *k_offsets_dev, int64_t volume, int64_t n_pairs, float *grad_in,
+                               float *grad_w, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_pairs > 0) {
+    const int64_t total = n_pairs * c_in;
+    hipLaunchKernelGGL(k_naive_dgrad, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream, grad_out,
+                       c_out, w, c_in, in_pairs, out_pairs, k_offsets_dev, (int)volume, n_pairs, grad_in);
+    ME_LAUNCH_CHECK();
+  }
+  const int64_t tw = volume * c_in * c_out;
+  hipLaunchKernelGGL(k_naive_wgrad, dim3((unsigned)ceil_div(tw, 256)), dim3(256), 0, stream, in_feat, c_in,
+                     grad_out, c_out, in_pairs, out_pairs, k_offsets_dev, (int)volume, grad_w);
+  ME_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

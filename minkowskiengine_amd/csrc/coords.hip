@@ -1,0 +1,632 @@
+// Coordinate hash map, kernel-map construction and tile plans for gfx950 (MI355X).
+//
+// Replaces the reference's CoordinateMapGPU (src/coordinate_map_gpu.cu) and gpu_kernel_map
+// (src/kernel_map.cuh).  Design differences (MI355X-first, not a translation):
+//   * 8-byte slots {hash tag : 32 | row : 32} in one flat open-addressing table, keys are NOT
+//     pointers: a miss costs one coalescable 8-byte read, a hit one more 16-byte read of the row's
+//     coordinates (the reference dereferences a pointer key on every compare,
+//     src/coordinate.hpp:223-241).
+//   * duplicates resolve with a 64-bit atomicMin on the slot, so the FIRST input row wins
+//     deterministically (the reference GPU path is racy; its CPU path is first-wins).
+//   * the kernel map is produced as a dense neighbour table nbr[k][out_row] (coalesced writes,
+//     one thread per (out row, offset)) and compacted with wavefront ballot + mbcnt prefix sums
+//     into per-offset pair lists sorted by output row; no sort_by_key, no remove_if.
+#include "common.hpp"
+
+namespace me {
+
+thread_local char g_last_error[512] = "";
+
+// =================================================================================================
+// scan
+// =================================================================================================
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s_wave /*[4+1]*/,
+                                                         uint32_t &block_total) {
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const uint32_t incl = wave_inclusive_scan(v);
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  uint32_t wave_off = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < kScanThreads / 64; ++w) {
+    const uint32_t t = s_wave[w];
+    if (w < wave) wave_off += t;
+    total += t;
+  }
+  __syncthreads();  // s_wave may be reused by the caller
+  block_total = total;
+  return wave_off + incl - v;
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_scan_block_sums(const uint32_t *__restrict__ in,
+                                                                 int64_t n,
+                                                                 uint32_t *__restrict__ bsums) {
+  __shared__ uint32_t s_wave[8];
+  const int64_t base = (int64_t)blockIdx.x * kScanBlock + (int64_t)threadIdx.x * kScanItems;
+  uint32_t s = 0;
+#pragma unroll
+  for (int j = 0; j < kScanItems; ++j)
+    if (base + j < n) s += in[base + j];
+  uint32_t total;
+  (void)block_exclusive_scan(s, s_wave, total);
+  if (threadIdx.x == 0) bsums[blockIdx.x] = total;
+}
+
+// single block: exclusive scan of the block sums in place, grand total to *total_dev
+__global__ __launch_bounds__(kScanThreads) void k_scan_of_sums(uint32_t *__restrict__ bsums,
+                                                              int64_t nb,
+                                                              uint32_t *__restrict__ total_dev) {
+  __shared__ uint32_t s_wave[8];
+  uint32_t carry = 0;
+  for (int64_t base = 0; base < nb; base += kScanThreads) {
+    const int64_t i = base + threadIdx.x;
+    const uint32_t v = (i < nb) ? bsums[i] : 0u;
+    uint32_t total;
+    const uint32_t ex = block_exclusive_scan(v, s_wave, total);
+    if (i < nb) bsums[i] = carry + ex;
+    carry += total;
+  }
+  if (threadIdx.x == 0 && total_dev) *total_dev = carry;
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_scan_apply(const uint32_t *__restrict__ in,
+                                                            uint32_t *__restrict__ out, int64_t n,
+                                                            const uint32_t *__restrict__ bsums) {
+  __shared__ uint32_t s_wave[8];
+  const int64_t base = (int64_t)blockIdx.x * kScanBlock + (int64_t)threadIdx.x * kScanItems;
+  uint32_t v[kScanItems];
+  uint32_t s = 0;
+#pragma unroll
+  for (int j = 0; j < kScanItems; ++j) {
+    v[j] = (base + j < n) ? in[base + j] : 0u;
+    s += v[j];
+  }
+  uint32_t total;
+  uint32_t ex = block_exclusive_scan(s, s_wave, total) + bsums[blockIdx.x];
+#pragma unroll
+  for (int j = 0; j < kScanItems; ++j) {
+    if (base + j < n) out[base + j] = ex;
+    ex += v[j];
+  }
+}
+
+int64_t scan_workspace_bytes(int64_t n) { return align_up((ceil_div(n, kScanBlock) + 1) * 4, 256); }
+
+int exclusive_scan_u32(const uint32_t *in, uint32_t *out, int64_t n, uint32_t *total_dev, void *ws,
+                       int64_t ws_bytes, hipStream_t stream) {
+  if (n <= 0) {
+    if (total_dev) ME_HIP(hipMemsetAsync(total_dev, 0, 4, stream));
+    return 0;
+  }
+  ME_CHECK(ws_bytes >= scan_workspace_bytes(n), "scan workspace too small");
+  uint32_t *bsums = reinterpret_cast<uint32_t *>(ws);
+  const int64_t nb = ceil_div(n, kScanBlock);
+  hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)nb), dim3(kScanThreads), 0, stream, in, n, bsums);
+  ME_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_scan_of_sums, dim3(1), dim3(kScanThreads), 0, stream, bsums, nb, total_dev);
+  ME_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(kScanThreads), 0, stream, in, out, n, bsums);
+  ME_LAUNCH_CHECK();
+  return 0;
+}
+
+// =================================================================================================
+// insert_and_map
+// =================================================================================================
+template <int NCOL>
+__global__ __launch_bounds__(256) void k_insert(const int32_t *__restrict__ coords, int64_t n,
+                                               uint64_t *table, uint32_t mask,
+                                               uint32_t *__restrict__ slot_of_row) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int32_t key[NCOL];
+  load_coords<NCOL>(coords, i, key);
+  const uint32_t h = hash_coords<NCOL>(key);
+  const uint64_t mine = ((uint64_t)h << 32) | (uint32_t)i;
+  uint32_t pos = h & mask;
+  for (uint32_t probe = 0; probe <= mask; ++probe) {
+    uint64_t cur = table[pos];
+    if (cur == kEmptySlot) {
+      const uint64_t old = atomicCAS(reinterpret_cast<unsigned long long *>(&table[pos]),
+                                     (unsigned long long)kEmptySlot, (unsigned long long)mine);
+      if (old == kEmptySlot) {
+        slot_of_row[i] = pos;
+        return;
+      }
+      cur = old;  // somebody else claimed the slot first: compare against it
+    }
+    if ((uint32_t)(cur >> 32) == h) {
+      const uint32_t r = (uint32_t)cur;
+      int32_t other[NCOL];
+      load_coords<NCOL>(coords, r, other);
+      if (coords_equal<NCOL>(other, key)) {
+        // same coordinate: the smallest input row owns the slot (tag bits are equal, so a
+        // 64-bit min is a min over the row field).
+        atomicMin(reinterpret_cast<unsigned long long *>(&table[pos]), (unsigned long long)mine);
+        slot_of_row[i] = pos;
+        return;
+      }
+    }
+    pos = (pos + 1) & mask;
+  }
+  slot_of_row[i] = 0xffffffffu;  // table full: cannot happen with capacity >= 2n
+}
+
+// flag[i] = 1 iff input row i is the first occurrence of its coordinate; wrow[i] = winning row
+__global__ __launch_bounds__(256) void k_insert_resolve(const uint64_t *__restrict__ table,
+                                                       const uint32_t *__restrict__ slot_of_row,
+                                                       int64_t n, uint32_t *__restrict__ wrow,
+                                                       uint32_t *__restrict__ flag) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t s = slot_of_row[i];
+  const uint32_t w = (s == 0xffffffffu) ? (uint32_t)i : (uint32_t)table[s];
+  wrow[i] = w;
+  flag[i] = (w == (uint32_t)i) ? 1u : 0u;
+}
+
+template <int NCOL>
+__global__ __launch_bounds__(256) void k_insert_finalize(
+    const int32_t *__restrict__ coords, int64_t n, uint64_t *table,
+    const uint32_t *__restrict__ slot_of_row, const uint32_t *__restrict__ wrow,
+    const uint32_t *__restrict__ newid, int32_t *__restrict__ coords_unique,
+    int64_t *__restrict__ unique_map, int64_t *__restrict__ inverse_map) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t w = wrow[i];
+  const uint32_t id = newid[w];
+  inverse_map[i] = (int64_t)id;
+  if (w == (uint32_t)i) {
+    unique_map[id] = i;
+    int32_t key[NCOL];
+    load_coords<NCOL>(coords, i, key);
+    store_coords<NCOL>(coords_unique, id, key);
+    const uint32_t s = slot_of_row[i];
+    if (s != 0xffffffffu) table[s] = (table[s] & 0xffffffff00000000ull) | (uint64_t)id;
+  }
+}
+
+// =================================================================================================
+// stride / find
+// =================================================================================================
+struct StrideArg {
+  int32_t ts[ME_MAX_DIM];
+};
+
+__device__ __forceinline__ int32_t floor_to_multiple(int32_t c, int32_t ts) {
+  int32_t q = c / ts;
+  if ((c % ts != 0) && ((c < 0) != (ts < 0))) --q;
+  return q * ts;
+}
+
+template <int NCOL>
+__global__ __launch_bounds__(256) void k_stride(const int32_t *__restrict__ coords, int64_t n,
+                                               StrideArg arg, int32_t *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int32_t c[NCOL];
+  load_coords<NCOL>(coords, i, c);
+#pragma unroll
+  for (int d = 1; d < NCOL; ++d) c[d] = floor_to_multiple(c[d], arg.ts[d - 1]);
+  store_coords<NCOL>(out, i, c);
+}
+
+template <int NCOL>
+__global__ __launch_bounds__(256) void k_find(const uint64_t *__restrict__ table, uint32_t mask,
+                                             const int32_t *__restrict__ map_coords,
+                                             const int32_t *__restrict__ queries, int64_t nq,
+                                             int32_t *__restrict__ rows) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  int32_t key[NCOL];
+  load_coords<NCOL>(queries, i, key);
+  rows[i] = table_find<NCOL>(table, mask, map_coords, key);
+}
+
+// =================================================================================================
+// kernel map
+// =================================================================================================
+// neighbour coordinate of offset k: src/kernel_region.hpp:198-247
+template <int NCOL>
+__device__ __forceinline__ void region_coordinate_at(const me_region &rg, int32_t k,
+                                                     const int32_t (&src)[NCOL],
+                                                     int32_t (&dst)[NCOL]) {
+  dst[0] = src[0];
+  if (rg.region_type == ME_REGION_HYPER_CUBE) {
+    int32_t rem = k;
+#pragma unroll
+    for (int d = 0; d < NCOL - 1; ++d) {
+      const int32_t ks = rg.kernel_size[d];
+      const int32_t idx = rem % ks;
+      rem /= ks;
+      const int32_t step = rg.dilation[d] * rg.tensor_stride[d];
+      dst[d + 1] = src[d + 1] + ((ks % 2 == 0) ? idx : (idx - ks / 2)) * step;
+    }
+  } else {  // HYPER_CROSS: centre first, then per axis the (ks-1) off-centre taps
+#pragma unroll
+    for (int d = 1; d < NCOL; ++d) dst[d] = src[d];
+    if (k == 0) return;
+    int32_t ind = k - 1;
+    int axis = 0;
+    while (axis < NCOL - 1) {
+      if (ind < rg.kernel_size[axis] - 1) break;
+      ind -= rg.kernel_size[axis] - 1;
+      ++axis;
+    }
+    if (axis >= NCOL - 1) return;
+    const int32_t r = (rg.kernel_size[axis] - 1) / 2;
+    const int32_t off = (ind < r) ? (ind + 1) : (ind - 2 * r);
+    // dst[axis + 1] with a runtime axis: unrolled select keeps the array in registers
+#pragma unroll
+    for (int d = 0; d < NCOL - 1; ++d)
+      if (d == axis) dst[d + 1] += off * rg.dilation[d] * rg.tensor_stride[d];
+  }
+}
+
+// one thread per (output row u, offset k = blockIdx.y); lanes = consecutive u
+template <int NCOL>
+__global__ __launch_bounds__(256) void k_kmap_probe(const uint64_t *__restrict__ in_table,
+                                                   uint32_t mask,
+                                                   const int32_t *__restrict__ in_coords,
+                                                   const int32_t *__restrict__ out_coords,
+                                                   int64_t n_out, me_region rg,
+                                                   int32_t *__restrict__ nbr,
+                                                   uint32_t *__restrict__ wcount, int64_t nw) {
+  const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int32_t k = blockIdx.y;
+  int32_t r = -1;
+  if (u < n_out) {
+    int32_t src[NCOL], key[NCOL];
+    load_coords<NCOL>(out_coords, u, src);
+    region_coordinate_at<NCOL>(rg, k, src, key);
+    r = table_find<NCOL>(in_table, mask, in_coords, key);
+    nbr[(int64_t)k * n_out + u] = r;
+  }
+  const unsigned long long m = __ballot(r >= 0);
+  const int64_t wave_global = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (lane_id() == 0 && wave_global < nw) wcount[(int64_t)k * nw + wave_global] = (uint32_t)__popcll(m);
+}
+
+__global__ void k_kmap_koffsets(const uint32_t *__restrict__ woffs, const uint32_t *__restrict__ total,
+                                int64_t nw, int64_t volume, int64_t *__restrict__ koffs) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < volume) koffs[k] = (int64_t)woffs[k * nw];
+  if (k == volume) koffs[k] = (int64_t)(*total);
+}
+
+__global__ __launch_bounds__(256) void k_kmap_compact(const int32_t *__restrict__ nbr, int64_t n_out,
+                                                     const uint32_t *__restrict__ woffs, int64_t nw,
+                                                     int32_t *__restrict__ in_pairs,
+                                                     int32_t *__restrict__ out_pairs) {
+  const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int32_t k = blockIdx.y;
+  const int32_t r = (u < n_out) ? nbr[(int64_t)k * n_out + u] : -1;
+  const unsigned long long m = __ballot(r >= 0);
+  const int64_t wave_global = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (r >= 0) {
+    const uint32_t dst = woffs[(int64_t)k * nw + wave_global] + mask_prefix(m);
+    in_pairs[dst] = r;
+    out_pairs[dst] = (int32_t)u;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_kmap_transpose(const int32_t *__restrict__ in_pairs,
+                                                       const int32_t *__restrict__ out_pairs,
+                                                       const int64_t *__restrict__ koffs,
+                                                       int64_t n_in, int32_t *__restrict__ nbrT) {
+  const int32_t k = blockIdx.y;
+  const int64_t e0 = koffs[k], e1 = koffs[k + 1];
+  for (int64_t e = e0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < e1;
+       e += (int64_t)gridDim.x * blockDim.x)
+    nbrT[(int64_t)k * n_in + in_pairs[e]] = out_pairs[e];
+}
+
+// =================================================================================================
+// tile plan
+// =================================================================================================
+// one wavefront per (tile, offset)
+__global__ __launch_bounds__(256) void k_plan_count(const int32_t *__restrict__ tbl, int64_t n_tgt,
+                                                   int64_t volume, int64_t n_items,
+                                                   uint32_t *__restrict__ gcount) {
+  const int64_t item = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (item >= n_items) return;  // wave-uniform
+  const int64_t t = item / volume, k = item % volume;
+  const int64_t row0 = t * ME_TILE_ROWS;
+  uint32_t count = 0;
+#pragma unroll
+  for (int c = 0; c < ME_TILE_ROWS / 64; ++c) {
+    const int64_t u = row0 + c * 64 + lane_id();
+    const int32_t r = (u < n_tgt) ? tbl[k * n_tgt + u] : -1;
+    count += (uint32_t)__popcll(__ballot(r >= 0));
+  }
+  if (lane_id() == 0) gcount[item] = (count + ME_GROUP_ROWS - 1) / ME_GROUP_ROWS;
+}
+
+__global__ __launch_bounds__(256) void k_plan_fill(const int32_t *__restrict__ tbl, int64_t n_tgt,
+                                                  int64_t volume, int64_t n_items,
+                                                  const uint32_t *__restrict__ goffs,
+                                                  const uint32_t *__restrict__ gtotal,
+                                                  int32_t *__restrict__ plan_src,
+                                                  int32_t *__restrict__ plan_dst,
+                                                  int32_t *__restrict__ group_k,
+                                                  int32_t *__restrict__ tile_gptr, int64_t n_tiles) {
+  const int64_t item = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (item >= n_items) return;  // wave-uniform
+  const int lane = lane_id();
+  const int64_t t = item / volume, k = item % volume;
+  const int64_t row0 = t * ME_TILE_ROWS;
+  const uint32_t g0 = goffs[item];
+  const int64_t slot0 = (int64_t)g0 * ME_GROUP_ROWS;
+  uint32_t running = 0;
+#pragma unroll
+  for (int c = 0; c < ME_TILE_ROWS / 64; ++c) {
+    const int local = c * 64 + lane;
+    const int64_t u = row0 + local;
+    const int32_t r = (u < n_tgt) ? tbl[k * n_tgt + u] : -1;
+    const unsigned long long m = __ballot(r >= 0);
+    if (r >= 0) {
+      const int64_t s = slot0 + running + mask_prefix(m);
+      plan_src[s] = r;
+      plan_dst[s] = local;
+    }
+    running += (uint32_t)__popcll(m);
+  }
+  const uint32_t groups = (running + ME_GROUP_ROWS - 1) / ME_GROUP_ROWS;
+  const uint32_t padded = groups * ME_GROUP_ROWS;
+  // padding slots of the last group (fewer than 16) and the group -> offset table (<= 8 groups)
+  if (running + lane < padded) {
+    plan_src[slot0 + running + lane] = -1;
+    plan_dst[slot0 + running + lane] = -1;
+  }
+  if ((uint32_t)lane < groups) group_k[g0 + lane] = (int32_t)k;
+  if (k == 0 && lane == 0) tile_gptr[t] = (int32_t)g0;
+  if (item == 0 && lane == 0) tile_gptr[n_tiles] = (int32_t)(*gtotal);
+}
+
+}  // namespace me
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+using namespace me;
+
+extern "C" {
+
+int me_version(void) { return 100; }
+const char *me_last_error(void) { return g_last_error; }
+
+int64_t me_region_volume(const me_region *rg) {
+  if (!rg || rg->ncol < 2 || rg->ncol > ME_MAX_DIM + 1) return -1;
+  int64_t v = 1;
+  if (rg->region_type == ME_REGION_HYPER_CUBE) {
+    for (int d = 0; d < rg->ncol - 1; ++d) v *= rg->kernel_size[d];
+  } else if (rg->region_type == ME_REGION_HYPER_CROSS) {
+    for (int d = 0; d < rg->ncol - 1; ++d) v += rg->kernel_size[d] - 1;
+  } else {
+    return -1;
+  }
+  return v;
+}
+
+int64_t me_hash_capacity(int64_t n) {
+  int64_t cap = 64;
+  while (cap < 2 * n) cap <<= 1;
+  return cap;
+}
+
+// workspace layout of insert: slot_of_row[n] | wrow[n] | flag/newid[n] | total | scan ws
+static int64_t insert_ws_arrays(int64_t n) { return align_up(n * 4, 256); }
+int64_t me_insert_workspace_bytes(int64_t n) {
+  if (n < 1) n = 1;
+  return 3 * insert_ws_arrays(n) + 256 + scan_workspace_bytes(n);
+}
+
+int me_coords_insert_and_map(const int32_t *coords, int64_t n, int32_t ncol, uint64_t *table,
+                             int64_t capacity, int32_t *coords_unique, int64_t *unique_map,
+                             int64_t *inverse_map, int64_t *n_unique, void *workspace,
+                             int64_t workspace_bytes, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ME_CHECK(n >= 0 && n < (1ll << 31), "number of coordinates must fit in int32");
+  ME_CHECK(capacity >= 2 * n && capacity >= 64 && (capacity & (capacity - 1)) == 0 &&
+               capacity <= (1ll << 32),
+           "capacity must be a power of two >= 2n");
+  ME_CHECK(n_unique != nullptr, "n_unique must not be null");
+  ME_CHECK(workspace_bytes >= me_insert_workspace_bytes(n), "workspace too small");
+  ME_CHECK(ncol != 4 || ((uintptr_t)coords % 16 == 0 && (uintptr_t)coords_unique % 16 == 0),
+           "coordinates with 4 columns must be 16-byte aligned");
+  ME_CHECK(ncol != 2 || ((uintptr_t)coords % 8 == 0 && (uintptr_t)coords_unique % 8 == 0),
+           "coordinates with 2 columns must be 8-byte aligned");
+  ME_HIP(hipMemsetAsync(table, 0xff, (size_t)capacity * 8, stream));
+  if (n == 0) {
+    *n_unique = 0;
+    return 0;
+  }
+  char *ws = reinterpret_cast<char *>(workspace);
+  const int64_t asz = insert_ws_arrays(n);
+  uint32_t *slot_of_row = reinterpret_cast<uint32_t *>(ws);
+  uint32_t *wrow = reinterpret_cast<uint32_t *>(ws + asz);
+  uint32_t *flag = reinterpret_cast<uint32_t *>(ws + 2 * asz);
+  uint32_t *total = reinterpret_cast<uint32_t *>(ws + 3 * asz);
+  void *scan_ws = ws + 3 * asz + 256;
+  const uint32_t mask = (uint32_t)(capacity - 1);
+  const dim3 grid((unsigned)ceil_div(n, 256)), block(256);
+  ME_DISPATCH_NCOL(ncol, hipLaunchKernelGGL(k_insert<NCOL>, grid, block, 0, stream, coords, n, table,
+                                            mask, slot_of_row));
+  ME_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_insert_resolve, grid, block, 0, stream, table, slot_of_row, n, wrow, flag);
+  ME_LAUNCH_CHECK();
+  if (int rc = exclusive_scan_u32(flag, flag, n, total, scan_ws, scan_workspace_bytes(n), stream)) return rc;
+  ME_DISPATCH_NCOL(ncol, hipLaunchKernelGGL(k_insert_finalize<NCOL>, grid, block, 0, stream, coords, n,
+                                            table, slot_of_row, wrow, flag, coords_unique,
+                                            unique_map, inverse_map));
+  ME_LAUNCH_CHECK();
+  uint32_t host_total = 0;
+  ME_HIP(hipMemcpyAsync(&host_total, total, 4, hipMemcpyDeviceToHost, stream));
+  ME_HIP(hipStreamSynchronize(stream));
+  *n_unique = (int64_t)host_total;
+  return 0;
+}
+
+int me_coords_stride(const int32_t *coords, int64_t n, int32_t ncol, const int32_t *out_ts,
+                     int32_t *out_coords, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ME_CHECK(ncol >= 2 && ncol <= ME_MAX_DIM + 1, "invalid coordinate size");
+  StrideArg arg;
+  for (int d = 0; d < ME_MAX_DIM; ++d) arg.ts[d] = 1;
+  for (int d = 0; d < ncol - 1; ++d) {
+    ME_CHECK(out_ts[d] > 0, "tensor stride must be positive");
+    arg.ts[d] = out_ts[d];
+  }
+  if (n == 0) return 0;
+  ME_CHECK(ncol != 4 || ((uintptr_t)coords % 16 == 0 && (uintptr_t)out_coords % 16 == 0),
+           "coordinates with 4 columns must be 16-byte aligned");
+  const dim3 grid((unsigned)ceil_div(n, 256)), block(256);
+  ME_DISPATCH_NCOL(ncol, hipLaunchKernelGGL(k_stride<NCOL>, grid, block, 0, stream, coords, n, arg, out_coords));
+  ME_LAUNCH_CHECK();
+  return 0;
+}
+
+int me_coords_find(const uint64_t *table, int64_t capacity, const int32_t *map_coords, int32_t ncol,
+                   const int32_t *queries, int64_t nq, int32_t *rows, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ME_CHECK(capacity >= 64 && (capacity & (capacity - 1)) == 0, "capacity must be a power of two");
+  if (nq == 0) return 0;
+  ME_CHECK(ncol != 4 || ((uintptr_t)map_coords % 16 == 0 && (uintptr_t)queries % 16 == 0),
+           "coordinates with 4 columns must be 16-byte aligned");
+  const dim3 grid((unsigned)ceil_div(nq, 256)), block(256);
+  const uint32_t mask = (uint32_t)(capacity - 1);
+  ME_DISPATCH_NCOL(ncol, hipLaunchKernelGGL(k_find<NCOL>, grid, block, 0, stream, table, mask, map_coords,
+                                            queries, nq, rows));
+  ME_LAUNCH_CHECK();
+  return 0;
+}
+
+// workspace layout of the kernel map: wcount/woffs [volume * nw] | total | koffs[volume+1] | scan ws
+static int64_t kmap_nw(int64_t n_out) { return ceil_div(n_out, 256) * 4; }
+static int64_t kmap_counts_bytes(int64_t n_out, int64_t volume) {
+  return align_up(volume * kmap_nw(n_out) * 4, 256);
+}
+int64_t me_kernel_map_workspace_bytes(int64_t n_out, int64_t volume) {
+  if (n_out < 1) n_out = 1;
+  return kmap_counts_bytes(n_out, volume) + 256 + align_up((volume + 1) * 8, 256) +
+         scan_workspace_bytes(volume * kmap_nw(n_out));
+}
+
+int me_kernel_map_probe(const uint64_t *in_table, int64_t in_capacity, const int32_t *in_coords,
+                        const int32_t *out_coords, int64_t n_out, const me_region *region,
+                        int32_t *nbr, int64_t *k_offsets, void *workspace, int64_t workspace_bytes,
+                        void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ME_CHECK(region != nullptr, "region must not be null");
+  const int64_t volume = me_region_volume(region);
+  ME_CHECK(volume >= 1 && volume <= 65535, "kernel volume out of range");
+  ME_CHECK(in_capacity >= 64 && (in_capacity & (in_capacity - 1)) == 0, "capacity must be a power of two");
+  ME_CHECK(n_out >= 0 && n_out * volume < (1ll << 32), "n_out * volume must fit in 32 bits");
+  for (int d = 0; d < region->ncol - 1; ++d)
+    ME_CHECK(region->kernel_size[d] > 0 && region->dilation[d] > 0 && region->tensor_stride[d] > 0,
+             "kernel size, dilation and tensor stride must be positive");
+  if (region->region_type == ME_REGION_HYPER_CROSS)
+    for (int d = 0; d < region->ncol - 1; ++d)
+      ME_CHECK(region->kernel_size[d] % 2 == 1, "HYPER_CROSS needs odd kernel sizes");
+  ME_CHECK(workspace_bytes >= me_kernel_map_workspace_bytes(n_out, volume), "workspace too small");
+  if (n_out == 0) {
+    for (int64_t k = 0; k <= volume; ++k) k_offsets[k] = 0;
+    return 0;
+  }
+  const int ncol = region->ncol;
+  ME_CHECK(ncol != 4 || ((uintptr_t)in_coords % 16 == 0 && (uintptr_t)out_coords % 16 == 0),
+           "coordinates with 4 columns must be 16-byte aligned");
+  char *ws = reinterpret_cast<char *>(workspace);
+  const int64_t nw = kmap_nw(n_out);
+  uint32_t *wcount = reinterpret_cast<uint32_t *>(ws);
+  uint32_t *total = reinterpret_cast<uint32_t *>(ws + kmap_counts_bytes(n_out, volume));
+  int64_t *koffs = reinterpret_cast<int64_t *>(ws + kmap_counts_bytes(n_out, volume) + 256);
+  void *scan_ws = ws + kmap_counts_bytes(n_out, volume) + 256 + align_up((volume + 1) * 8, 256);
+  const dim3 grid((unsigned)ceil_div(n_out, 256), (unsigned)volume), block(256);
+  const uint32_t mask = (uint32_t)(in_capacity - 1);
+  const me_region rg = *region;
+  ME_DISPATCH_NCOL(ncol, hipLaunchKernelGGL(k_kmap_probe<NCOL>, grid, block, 0, stream, in_table, mask,
+                                            in_coords, out_coords, n_out, rg, nbr, wcount, nw));
+  ME_LAUNCH_CHECK();
+  if (int rc = exclusive_scan_u32(wcount, wcount, volume * nw, total, scan_ws,
+                                  scan_workspace_bytes(volume * nw), stream))
+    return rc;
+  hipLaunchKernelGGL(k_kmap_koffsets, dim3((unsigned)ceil_div(volume + 1, 256)), dim3(256), 0, stream,
+                     wcount, total, nw, volume, koffs);
+  ME_LAUNCH_CHECK();
+  ME_HIP(hipMemcpyAsync(k_offsets, koffs, (size_t)(volume + 1) * 8, hipMemcpyDeviceToHost, stream));
+  ME_HIP(hipStreamSynchronize(stream));
+  return 0;
+}
+
+int me_kernel_map_compact(const int32_t *nbr, int64_t n_out, int64_t volume, int32_t *in_pairs,
+                          int32_t *out_pairs, void *workspace, int64_t workspace_bytes, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ME_CHECK(volume >= 1 && volume <= 65535, "kernel volume out of range");
+  ME_CHECK(workspace_bytes >= me_kernel_map_workspace_bytes(n_out, volume), "workspace too small");
+  if (n_out == 0) return 0;
+  const int64_t nw = kmap_nw(n_out);
+  const uint32_t *woffs = reinterpret_cast<const uint32_t *>(workspace);
+  const dim3 grid((unsigned)ceil_div(n_out, 256), (unsigned)volume), block(256);
+  hipLaunchKernelGGL(k_kmap_compact, grid, block, 0, stream, nbr, n_out, woffs, nw, in_pairs, out_pairs);
+  ME_LAUNCH_CHECK();
+  return 0;
+}
+
+int me_kernel_map_transpose(const int32_t *in_pairs, const int32_t *out_pairs, const int64_t *k_offsets_dev,
+                            int64_t volume, int64_t n_pairs, int64_t n_in, int32_t *nbrT, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ME_CHECK(volume >= 1 && volume <= 65535, "kernel volume out of range");
+  if (n_in == 0) return 0;
+  ME_HIP(hipMemsetAsync(nbrT, 0xff, (size_t)volume * n_in * 4, stream));
+  if (n_pairs == 0) return 0;
+  int64_t bx = ceil_div(ceil_div(n_pairs, volume), 256);
+  if (bx < 1) bx = 1;
+  if (bx > 4096) bx = 4096;
+  hipLaunchKernelGGL(k_kmap_transpose, dim3((unsigned)bx, (unsigned)volume), dim3(256), 0, stream, in_pairs,
+                     out_pairs, k_offsets_dev, n_in, nbrT);
+  ME_LAUNCH_CHECK();
+  return 0;
+}
+
+int64_t me_plan_num_tiles(int64_t n_tgt) { return ceil_div(n_tgt, ME_TILE_ROWS); }
+int64_t me_plan_max_groups(int64_t n_tgt, int64_t volume, int64_t n_pairs) {
+  const int64_t items = me_plan_num_tiles(n_tgt) * volume;
+  const int64_t nonempty = items < n_pairs ? items : n_pairs;
+  return n_pairs / ME_GROUP_ROWS + nonempty + 1;
+}
+int64_t me_plan_workspace_bytes(int64_t n_tgt, int64_t volume) {
+  const int64_t items = me_plan_num_tiles(n_tgt < 1 ? 1 : n_tgt) * volume;
+  return align_up(items * 4, 256) + 256 + scan_workspace_bytes(items);
+}
+
+int me_plan_build(const int32_t *tbl, int64_t n_tgt, int64_t volume, int32_t *plan_src, int32_t *plan_dst,
+                  int32_t *group_k, int32_t *tile_gptr, void *workspace, int64_t workspace_bytes,
+                  void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ME_CHECK(volume >= 1 && volume <= 65535, "kernel volume out of range");
+  ME_CHECK(workspace_bytes >= me_plan_workspace_bytes(n_tgt, volume), "workspace too small");
+  const int64_t n_tiles = me_plan_num_tiles(n_tgt);
+  if (n_tiles == 0) {
+    ME_HIP(hipMemsetAsync(tile_gptr, 0, 4, stream));
+    return 0;
+  }
+  const int64_t items = n_tiles * volume;
+  ME_CHECK(items < (1ll << 31), "too many (tile, offset) items");
+  char *ws = reinterpret_cast<char *>(workspace);
+  uint32_t *gcount = reinterpret_cast<uint32_t *>(ws);
+  uint32_t *gtotal = reinterpret_cast<uint32_t *>(ws + align_up(items * 4, 256));
+  void *scan_ws = ws + align_up(items * 4, 256) + 256;
+  const dim3 grid((unsigned)ceil_div(items, 4)), block(256);
+  hipLaunchKernelGGL(k_plan_count, grid, block, 0, stream, tbl, n_tgt, volume, items, gcount);
+  ME_LAUNCH_CHECK();
+  if (int rc = exclusive_scan_u32(gcount, gcount, items, gtotal, scan_ws, scan_workspace_bytes(items), stream))
+    return rc;
+  hipLaunchKernelGGL(k_plan_fill, grid, block, 0, stream, tbl, n_tgt, volume, items, gcount, gtotal,
+                     plan_src, plan_dst, group_k, tile_gptr, n_tiles);
+  ME_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,75 @@
+"""TEST INFRASTRUCTURE ONLY — loader for the reference's own CPU extension (oracle/_ref/_C.so,
+built unmodified from /root/reference by oracle/build_ref.py).  The shared object travels to the GPU
+box; /root/reference itself does not, so only the compiled operators are used here (never the
+reference's Python package)."""
+import importlib.machinery
+import importlib.util
+import os
+
+import torch  # noqa: F401  (libtorch must be loaded before the extension)
+
+from . import build_ref
+
+_mod = None
+
+
+def available():
+    return os.path.exists(build_ref.ref_so_path())
+
+
+def load():
+    """-> the pybind module (MinkowskiEngineBackend._C of the reference, CPU_ONLY build)."""
+    global _mod
+    if _mod is None:
+        so = build_ref.ref_so_path()
+        if not os.path.exists(so):
+            so = build_ref.build()
+        loader = importlib.machinery.ExtensionFileLoader("_C", so)
+        spec = importlib.util.spec_from_file_location("_C", so, loader=loader)
+        mod = importlib.util.module_from_spec(spec)
+        loader.exec_module(mod)
+        _mod = mod
+    return _mod
+
+
+class RefConv:
+    """One reference CPU convolution layer on fixed coordinates, through the reference's operators
+    ConvolutionForwardCPU / ConvolutionBackwardCPU (src/convolution_cpu.cpp:42-203) or their
+    transposed twins, with the reference's CoordinateMapManagerCPU."""
+
+    def __init__(self, coords, kernel_size, stride=1, dilation=1, D=None, transpose_from=None, num_threads=None):
+        C = load()
+        coords = coords.contiguous().int().cpu()
+        self.C = C
+        self.D = coords.shape[1] - 1 if D is None else D
+        D = self.D
+        aslist = lambda v: [int(v)] * D if isinstance(v, int) else [int(x) for x in v]
+        self.kernel_size, self.stride, self.dilation = aslist(kernel_size), aslist(stride), aslist(dilation)
+        nthreads = num_threads if num_threads is not None else min(os.cpu_count() or 1, 20)
+        self.manager = C.CoordinateMapManagerCPU(C.MinkowskiAlgorithm.DEFAULT, nthreads)
+        self.in_key, (self.unique_map, self.inverse_map) = self.manager.insert_and_map(coords, [1] * D, "")
+        self.out_key = C.CoordinateMapKey(D + 1)
+        self.empty_offset = torch.IntTensor()
+
+    def forward(self, feats, kernel):
+        C = self.C
+        return C.ConvolutionForwardCPU(feats, kernel, self.kernel_size, self.stride, self.dilation,
+                                       C.RegionType.HYPER_CUBE, self.empty_offset, False, C.ConvolutionMode.DEFAULT,
+                                       self.in_key, self.out_key, self.manager)
+
+    def backward(self, feats, grad_out, kernel):
+        C = self.C
+        return C.ConvolutionBackwardCPU(feats, grad_out, kernel, self.kernel_size, self.stride, self.dilation,
+                                        C.RegionType.HYPER_CUBE, self.empty_offset, C.ConvolutionMode.DEFAULT,
+                                        self.in_key, self.out_key, self.manager)
+
+    def kernel_map(self):
+        C = self.C
+        return self.manager.kernel_map(self.in_key, self.out_key, self.kernel_size, self.stride, self.dilation,
+                                       C.RegionType.HYPER_CUBE, self.empty_offset, False, False)
+
+    def in_coordinates(self):
+        return self.manager.get_coordinates(self.in_key)
+
+    def out_coordinates(self):
+        return self.manager.get_coordinates(self.out_key)
