@@ -389,6 +389,8 @@ class CoordinateMapManagerGPU_c10:
         if key in self._maps:
             k = self.get_random_string_id(ts, string_id)
             key = (tuple(k[0]), k[1])
+        if coordinates.data_ptr() % 16 != 0:   # a view into a larger buffer: the kernels use 16-byte loads
+            coordinates = coordinates.clone()
         cmap, unique_map, inverse_map = _insert(coordinates, ts)
         self._maps[key] = cmap
         return CoordinateMapKey(list(key[0]), key[1]), (unique_map, inverse_map)
@@ -483,7 +485,40 @@ def _check_feat(name, t):
     _check(t.dtype == torch.float32, name, "must be float32 (this round implements the fp32 path)")
 
 
-def _conv_target(src_feat, weights, km, target, n_tgt):
+class KernelTimer:
+    """Optional per-launch timing with HIP events on the launch stream (torch's current stream).
+    bench.py switches it on to measure the average duration of each hot kernel inside the timed
+    region; it is off (None) otherwise."""
+
+    def __init__(self):
+        self.events = {}
+
+    def record(self, name, device):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream(device))
+        return ev
+
+    def add(self, name, start, end):
+        self.events.setdefault(name, []).append((start, end))
+
+    def summary(self):
+        """{name: (launches, mean ms)} — call after torch.cuda.synchronize()."""
+        return {k: (len(v), sum(s.elapsed_time(e) for s, e in v) / len(v)) for k, v in self.events.items()}
+
+
+KERNEL_TIMER = None  # set to a KernelTimer() to time launches
+
+
+def _timed(name, device, launch):
+    if KERNEL_TIMER is None:
+        return launch()
+    s = KERNEL_TIMER.record(name, device)
+    r = launch()
+    KERNEL_TIMER.add(name, s, KERNEL_TIMER.record(name, device))
+    return r
+
+
+def _conv_target(src_feat, weights, km, target, n_tgt, name="conv_target"):
     """dst[t] = sum over plan entries of src[s] @ weights[k]   (weights: [K, c_src, c_dst])."""
     lib = _lib.load()
     dev = src_feat.device
@@ -493,9 +528,9 @@ def _conv_target(src_feat, weights, km, target, n_tgt):
         return out
     plan_src, plan_dst, group_k, tile_gptr = km.plan(target)
     with torch.cuda.device(dev):
-        _lib.check(lib.me_conv_target_f32(_ptr(src_feat), src_feat.shape[0], c_src, _ptr(weights), km.volume, c_dst,
-                                          _ptr(plan_src), _ptr(plan_dst), _ptr(group_k), _ptr(tile_gptr),
-                                          _ptr(out), n_tgt, _stream(dev)))
+        _timed(name, dev, lambda: _lib.check(lib.me_conv_target_f32(
+            _ptr(src_feat), src_feat.shape[0], c_src, _ptr(weights), km.volume, c_dst, _ptr(plan_src),
+            _ptr(plan_dst), _ptr(group_k), _ptr(tile_gptr), _ptr(out), n_tgt, _stream(dev))))
     return out
 
 
@@ -510,7 +545,7 @@ def _conv_forward(in_feat, kernel, km, algo=None):
                                                      _ptr(km.in_pairs), _ptr(km.out_pairs), _ptr(km.k_offsets_dev),
                                                      km.volume, km.n_pairs, _ptr(out), _stream(dev)))
         return out
-    return _conv_target(in_feat, kernel, km, "out", km.n_out)
+    return _conv_target(in_feat, kernel, km, "out", km.n_out, name="conv_forward")
 
 
 def _conv_backward(in_feat, grad_out, kernel, km, algo=None):
@@ -531,16 +566,16 @@ def _conv_backward(in_feat, grad_out, kernel, km, algo=None):
     wt = torch.empty((volume, c_out, c_in), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _lib.check(lib.me_transpose_kernel_f32(_ptr(kernel), volume, c_in, c_out, _ptr(wt), _stream(dev)))
-    grad_in = _conv_target(grad_out, wt, km, "in", km.n_in)
+    grad_in = _conv_target(grad_out, wt, km, "in", km.n_in, name="conv_dgrad")
     # wgrad
     grad_w = torch.empty_like(kernel)
     koffs = (ctypes.c_int64 * (volume + 1))(*km.k_offsets)
     wsb = int(lib.me_conv_wgrad_workspace_bytes(koffs, volume, c_in, c_out))
     ws = _workspace(wsb, dev)
     with torch.cuda.device(dev):
-        _lib.check(lib.me_conv_wgrad_f32(_ptr(in_feat), c_in, _ptr(grad_out), c_out, _ptr(km.in_pairs),
-                                         _ptr(km.out_pairs), koffs, _ptr(km.k_offsets_dev), volume, _ptr(grad_w),
-                                         _ptr(ws), ws.numel(), _stream(dev)))
+        _timed("conv_wgrad", dev, lambda: _lib.check(lib.me_conv_wgrad_f32(
+            _ptr(in_feat), c_in, _ptr(grad_out), c_out, _ptr(km.in_pairs), _ptr(km.out_pairs), koffs,
+            _ptr(km.k_offsets_dev), volume, _ptr(grad_w), _ptr(ws), ws.numel(), _stream(dev))))
     return grad_in, grad_w
 
 

@@ -103,7 +103,7 @@ class MinkowskiConvolutionBase(MinkowskiModuleBase):
         self.kernel = Parameter(torch.empty(*kernel_shape, dtype=torch.float32))
         self.bias = Parameter(torch.empty(1, out_channels, dtype=torch.float32)) if bias else None
         self.convolution_mode = convolution_mode
-        self.conv = (MinkowskiConvolutionTransposeFunction() if is_transpose else MinkowskiConvolutionFunction())
+        self.conv = MinkowskiConvolutionTransposeFunction if is_transpose else MinkowskiConvolutionFunction
 
     def forward(self, input, coordinates=None):
         assert isinstance(input, SparseTensor)

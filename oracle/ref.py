@@ -48,7 +48,8 @@ class RefConv:
         nthreads = num_threads if num_threads is not None else min(os.cpu_count() or 1, 20)
         self.manager = C.CoordinateMapManagerCPU(C.MinkowskiAlgorithm.DEFAULT, nthreads)
         self.in_key, (self.unique_map, self.inverse_map) = self.manager.insert_and_map(coords, [1] * D, "")
-        self.out_key = C.CoordinateMapKey(D + 1)
+        # same rule as ConvolutionForwardCPU (src/convolution_cpu.cpp:78-108): out map = stride(in map)
+        self.out_key = self.manager.stride(self.in_key, self.stride, "")
         self.empty_offset = torch.IntTensor()
 
     def forward(self, feats, kernel):

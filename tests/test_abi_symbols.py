@@ -1,0 +1,51 @@
+"""The C-ABI library loads (no GPU needed) and exports every symbol include/me_amd.h declares;
+the ctypes prototypes cover exactly that set."""
+import ctypes
+import os
+import re
+
+from minkowskiengine_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "me_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(me_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_entry_points():
+    syms = declared_symbols()
+    for s in ("me_coords_insert_and_map", "me_kernel_map_probe", "me_kernel_map_compact", "me_plan_build",
+              "me_conv_target_f32", "me_conv_wgrad_f32"):
+        assert s in syms
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for s in declared_symbols():
+        assert hasattr(lib, s), f"{s} declared in include/me_amd.h but not exported"
+
+
+def test_ctypes_prototypes_match_header():
+    assert sorted(_lib.SIGNATURES) == declared_symbols()
+    lib = _lib.load()
+    assert lib.me_version() >= 100
+
+
+def test_host_only_entry_points():
+    lib = _lib.load()
+    assert lib.me_hash_capacity(0) == 64
+    assert lib.me_hash_capacity(100000) == 262144
+    assert lib.me_plan_num_tiles(257) == 3
+    rg = _lib.make_region(4, 0, [3, 3, 3], [1, 1, 1], [1, 1, 1])
+    assert lib.me_region_volume(ctypes.byref(rg)) == 27
+    rg = _lib.make_region(4, 1, [3, 3, 5], [1, 1, 1], [1, 1, 1])
+    assert lib.me_region_volume(ctypes.byref(rg)) == 9
+    rg = _lib.make_region(5, 0, [3, 3, 3, 3], [1] * 4, [1] * 4)
+    assert lib.me_region_volume(ctypes.byref(rg)) == 81
+    koffs = (ctypes.c_int64 * 4)(0, 10, 10, 5000)
+    # chunks: ceil(10/2048) + 0 + ceil(4990/2048) = 1 + 3
+    assert lib.me_conv_wgrad_workspace_bytes(koffs, 3, 8, 16) == 4 * 8 * 16 * 4

@@ -1,0 +1,167 @@
+"""GPU parity of the convolution feature kernels (forward, dgrad, wgrad; strided and transposed maps)
+against the oracle and against the fixtures produced by the reference itself.  Tolerance: 1e-4
+(abs + rel, as BASELINE.json's north_star states for fp32); typical error is ~1e-6."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import me_oracle as O
+from helpers import golden_cases, golden_kmap, make_cloud, rel_err, row_mapping
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _run_layer(device, coords, cin, cout, ks, stride=1, dil=1, seed=0, bias=False):
+    import minkowskiengine_amd as ME
+    D = coords.shape[1] - 1
+    g = torch.Generator().manual_seed(seed)
+    feats = torch.rand(coords.shape[0], cin, generator=g)
+    conv = ME.MinkowskiConvolution(cin, cout, kernel_size=ks, stride=stride, dilation=dil, bias=bias, dimension=D)
+    with torch.no_grad():
+        conv.kernel.copy_(torch.rand(conv.kernel.shape, generator=g) - 0.5)
+    conv = conv.to(device)
+    x = ME.SparseTensor(feats.to(device), coords.to(device), requires_grad=True)
+    y = conv(x)
+    gy = torch.rand(y.F.shape, generator=g)
+    y.F.backward(gy.to(device))
+    return conv, x, y, feats, gy
+
+
+CONV_CASES = [
+    # n, extent, D, cin, cout, ks, stride, dil
+    (3000, 14, 3, 16, 32, 3, 1, 1),
+    (3000, 14, 3, 64, 128, 3, 1, 1),      # config-2 channel shape
+    (3000, 40, 3, 64, 128, 3, 1, 1),      # sparse: most (tile, offset) groups nearly empty
+    (2500, 14, 3, 3, 32, 5, 1, 1),        # MinkUNet stem: cin = 3, K = 125
+    (2500, 14, 3, 32, 96, 3, 1, 1),       # cout not a multiple of 64
+    (2500, 14, 3, 96, 32, 3, 1, 1),       # cin = 96 (chunks of 32)
+    (2500, 14, 3, 20, 24, 3, 1, 1),       # odd channel counts (scalar gather path off: 20 % 4 == 0)
+    (2500, 14, 3, 5, 7, 3, 1, 1),         # channels not multiples of 4 (scalar paths)
+    (2500, 14, 3, 32, 32, 2, 2, 1),       # down conv k=2 s=2
+    (2500, 14, 3, 16, 16, 3, 2, 1),
+    (2500, 14, 3, 8, 8, 3, 1, 2),
+    (2000, 8, 4, 32, 64, 3, 1, 1),        # 4-D, K = 81 (config-5 channel shape)
+    (300, 6, 3, 128, 256, 3, 1, 1),       # few rows, many channels
+    (1, 2, 3, 4, 4, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("n,extent,D,cin,cout,ks,stride,dil", CONV_CASES)
+def test_conv_forward_backward_vs_oracle(device, n, extent, D, cin, cout, ks, stride, dil):
+    coords = make_cloud(n, extent, D, seed=n + cin, batch=2 if n > 100 else 1, negative=True)
+    conv, x, y, feats, gy = _run_layer(device, coords, cin, cout, ks, stride, dil)
+    in_c = coords.numpy()
+    out_c = y.C.cpu().numpy()
+    if stride == 1:
+        assert np.array_equal(out_c, in_c)
+    else:
+        assert np.array_equal(out_c, O.stride_map(in_c, [stride] * D)[0])
+    _, km = O.kernel_map(in_c, out_c, O.make_region(D, ks, dil, 1))
+    w = conv.kernel.detach().cpu().numpy()
+    ref = O.conv_forward(feats.numpy(), w, km, len(out_c))
+    assert rel_err(y.F.detach().cpu().numpy(), ref) < TOL
+    gi, gw = O.conv_backward(feats.numpy(), gy.numpy(), w, km)
+    assert rel_err(x.F.grad.cpu().numpy(), gi) < TOL
+    assert rel_err(conv.kernel.grad.cpu().numpy(), gw) < TOL
+
+
+def test_mfma_and_naive_kernels_agree(device):
+    from minkowskiengine_amd import backend as MEB
+    coords = make_cloud(3000, 14, 3, seed=4, negative=True).to(device)
+    mgr = MEB.CoordinateMapManagerGPU_c10()
+    key, _ = mgr.insert_and_map(coords, [1, 1, 1], "")
+    km = mgr._kernel_map(key, key, [3] * 3, [1] * 3, [1] * 3, MEB.RegionType.HYPER_CUBE, None, False, False)
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(3000, 24, generator=g).to(device)
+    w = (torch.rand(27, 24, 40, generator=g) - 0.5).to(device)
+    gy = torch.rand(3000, 40, generator=g).to(device)
+    y1, y0 = MEB._conv_forward(x, w, km, "mfma"), MEB._conv_forward(x, w, km, "naive")
+    assert rel_err(y1.cpu().numpy(), y0.cpu().numpy()) < 1e-5
+    a1, b1 = MEB._conv_backward(x, gy, w, km, "mfma")
+    a0, b0 = MEB._conv_backward(x, gy, w, km, "naive")
+    assert rel_err(a1.cpu().numpy(), a0.cpu().numpy()) < 1e-5 and rel_err(b1.cpu().numpy(), b0.cpu().numpy()) < 1e-5
+
+
+def test_bitwise_reproducible(device):
+    coords = make_cloud(4000, 14, 3, seed=9)
+    r1 = _run_layer(device, coords, 32, 64, 3)
+    r2 = _run_layer(device, coords, 32, 64, 3)
+    assert torch.equal(r1[2].F, r2[2].F) and torch.equal(r1[1].F.grad, r2[1].F.grad)
+    assert torch.equal(r1[0].kernel.grad, r2[0].kernel.grad)
+
+
+def test_bias_and_use_mm(device):
+    import minkowskiengine_amd as ME
+    coords = make_cloud(500, 10, 3, seed=2).to(device)
+    x = ME.SparseTensor(torch.rand(500, 8).to(device), coords)
+    conv1 = ME.MinkowskiConvolution(8, 6, kernel_size=1, bias=True, dimension=3).to(device)
+    y = conv1(x)
+    assert torch.allclose(y.F, x.F @ conv1.kernel + conv1.bias, atol=1e-6)
+    assert y.coordinate_map_key == x.coordinate_map_key
+
+
+@pytest.mark.parametrize("path", golden_cases())
+def test_against_reference_fixtures(device, path):
+    """The fixtures hold the REFERENCE's outputs (tests/golden/make_golden.py).  Row order of strided
+    maps is implementation-defined in the reference, so output rows are relabelled by coordinate."""
+    import minkowskiengine_amd as ME
+    z = np.load(path)
+    D = z["coords"].shape[1] - 1
+    ks, st, dl = z["kernel_size"].tolist(), z["stride"].tolist(), z["dilation"].tolist()
+    cin, cout = z["kernel"].shape[1:]
+    coords = torch.from_numpy(z["coords"]).to(device)
+    mgr = ME.CoordinateManager(D=D)
+    key, (um, inv) = mgr.insert_and_map(coords, [1] * D, "")
+    assert np.array_equal(um.cpu().numpy(), z["unique_map"]) and np.array_equal(inv.cpu().numpy(), z["inverse_map"])
+    x = ME.SparseTensor(torch.from_numpy(z["feats"]).to(device), coordinate_map_key=key, coordinate_manager=mgr,
+                        requires_grad=True)
+    conv = ME.MinkowskiConvolution(cin, cout, kernel_size=ks, stride=st, dilation=dl, dimension=D)
+    with torch.no_grad():
+        conv.kernel.copy_(torch.from_numpy(z["kernel"]))
+    conv = conv.to(device)
+    y = conv(x)
+    assert y.tensor_stride == z["out_tensor_stride"].tolist()
+    m = row_mapping(y.C.cpu().numpy(), z["out_coords"])      # our out row -> reference out row
+    d = mgr.kernel_map(key, y.coordinate_map_key, stride=st, kernel_size=ks, dilation=dl)
+    O.assert_same_kernel_map({k: np.stack((v[0].cpu().numpy().astype(np.int64), m[v[1].cpu().numpy()]))
+                              for k, v in d.items()}, golden_kmap(z))
+    assert rel_err(y.F.detach().cpu().numpy(), z["out"][m]) < TOL
+    y.F.backward(torch.from_numpy(z["grad_out"][m]).to(device))
+    assert rel_err(x.F.grad.cpu().numpy(), z["grad_in"]) < TOL
+    assert rel_err(conv.kernel.grad.cpu().numpy(), z["grad_kernel"]) < TOL
+    if "up" in z.files:
+        convt = ME.MinkowskiConvolutionTranspose(cout, cin, kernel_size=ks, stride=st, dilation=dl, dimension=D)
+        with torch.no_grad():
+            convt.kernel.copy_(torch.from_numpy(z["kernel_t"]))
+        convt = convt.to(device)
+        xin = ME.SparseTensor(torch.from_numpy(z["out"][m]).to(device), coordinate_map_key=y.coordinate_map_key,
+                              coordinate_manager=mgr, requires_grad=True)
+        up = convt(xin)
+        assert up.coordinate_map_key == key
+        assert rel_err(up.F.detach().cpu().numpy(), z["up"]) < TOL
+        up.F.backward(torch.from_numpy(z["up_grad_out"]).to(device))
+        assert rel_err(xin.F.grad.cpu().numpy(), z["up_grad_in"][m]) < TOL
+        assert rel_err(convt.kernel.grad.cpu().numpy(), z["up_grad_kernel"]) < TOL
+
+
+def test_config2_full_size(device):
+    """BASELINE config 2 at full size (100k voxels, 64 -> 128, k = 3): oracle values (numpy, a few
+    seconds) + linearity as a size-independent property."""
+    coords = make_cloud(100000, 70, 3, seed=0)
+    conv, x, y, feats, gy = _run_layer(device, coords, 64, 128, 3)
+    _, km = O.kernel_map(coords.numpy(), coords.numpy(), O.make_region(3, 3))
+    w = conv.kernel.detach().cpu().numpy()
+    ref = O.conv_forward(feats.numpy(), w, km, 100000, dtype=np.float32)
+    assert rel_err(y.F.detach().cpu().numpy(), ref) < TOL
+    gi, gw = O.conv_backward(feats.numpy(), gy.numpy(), w, km, dtype=np.float32)
+    assert rel_err(x.F.grad.cpu().numpy(), gi) < TOL
+    assert rel_err(conv.kernel.grad.cpu().numpy(), gw) < TOL
+    # linearity: conv(2a - 3b) == 2 conv(a) - 3 conv(b)
+    import minkowskiengine_amd as ME
+    a, b = torch.rand_like(x.F.detach()), torch.rand_like(x.F.detach())
+    mk = lambda f: ME.SparseTensor(f, coordinate_map_key=x.coordinate_map_key, coordinate_manager=x.coordinate_manager)
+    with torch.no_grad():
+        lhs = conv(mk(2 * a - 3 * b)).F
+        rhs = 2 * conv(mk(a)).F - 3 * conv(mk(b)).F
+    assert float((lhs - rhs).abs().max()) < 1e-4

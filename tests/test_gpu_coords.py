@@ -1,0 +1,216 @@
+"""GPU parity of the coordinate path (hash insert / find / stride / kernel map / tile plan) against the
+oracle, called through the C ABI (via the backend module).  Index maps must be bit-exact."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import me_oracle as O
+from helpers import make_cloud, row_mapping
+
+pytestmark = pytest.mark.gpu
+
+
+def _mgr():
+    from minkowskiengine_amd import backend as MEB
+    return MEB, MEB.CoordinateMapManagerGPU_c10()
+
+
+@pytest.mark.parametrize("n,extent,D,dup", [(1, 4, 3, 0), (5000, 12, 3, 900), (20000, 40, 3, 0), (3000, 6, 4, 500),
+                                             (2000, 30, 2, 100), (1000, 200, 1, 300), (4000, 6, 5, 100)])
+def test_insert_and_map_bit_exact(device, n, extent, D, dup):
+    coords = make_cloud(n, extent, D, seed=n + D, batch=2, dup=dup, negative=True)
+    MEB, mgr = _mgr()
+    key, (um, inv) = mgr.insert_and_map(coords.to(device), [1] * D, "")
+    um_o, inv_o = O.insert_and_map(coords.numpy())
+    assert um.dtype == torch.int64 and inv.dtype == torch.int64
+    assert np.array_equal(um.cpu().numpy(), um_o), "unique_map differs from the oracle"
+    assert np.array_equal(inv.cpu().numpy(), inv_o), "inverse_map differs from the oracle"
+    got = mgr.get_coordinates(key).cpu().numpy()
+    assert np.array_equal(got, coords.numpy()[um_o]), "stored coordinates differ / wrong row order"
+    assert mgr.size(key) == len(um_o)
+    # round trip of the reference test (tests/python/coordinate_manager.py:33-58)
+    assert np.array_equal(coords.numpy(), got[inv.cpu().numpy()])
+
+
+def test_insert_all_duplicates_and_empty(device):
+    MEB, mgr = _mgr()
+    coords = torch.IntTensor([[0, 1, 2, 3]] * 257).to(device)
+    key, (um, inv) = mgr.insert_and_map(coords, [1, 1, 1], "")
+    assert um.tolist() == [0] and inv.tolist() == [0] * 257 and mgr.size(key) == 1
+    key2, (um2, inv2) = mgr.insert_and_map(torch.zeros((0, 4), dtype=torch.int32, device=device), [1, 1, 1], "e")
+    assert um2.numel() == 0 and inv2.numel() == 0 and mgr.size(key2) == 0
+
+
+def test_key_collision_gets_random_suffix(device):
+    MEB, mgr = _mgr()
+    c = make_cloud(100, 8, 3).to(device)
+    k1, _ = mgr.insert_and_map(c, [1, 1, 1], "")
+    k2, _ = mgr.insert_and_map(c, [1, 1, 1], "")
+    assert k1 != k2 and k1.get_key()[1] == "" and len(k2.get_key()[1]) == 5
+
+
+def test_find(device):
+    from minkowskiengine_amd import _lib
+    MEB, mgr = _mgr()
+    coords = make_cloud(3000, 14, 3, seed=5, negative=True)
+    key, _ = mgr.insert_and_map(coords.to(device), [1, 1, 1], "")
+    cmap = mgr._get(key)
+    q = make_cloud(4000, 18, 3, seed=6, negative=True).to(device)
+    rows = torch.empty(q.shape[0], dtype=torch.int32, device=device)
+    lib = _lib.load()
+    _lib.check(lib.me_coords_find(ctypes.c_void_p(cmap.table.data_ptr()), cmap.capacity,
+                                  ctypes.c_void_p(cmap.coords.data_ptr()), 4, ctypes.c_void_p(q.data_ptr()),
+                                  q.shape[0], ctypes.c_void_p(rows.data_ptr()),
+                                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    assert np.array_equal(rows.cpu().numpy(), O.find(coords.numpy(), q.cpu().numpy()))
+
+
+@pytest.mark.parametrize("D,stride", [(3, 2), (3, [2, 1, 4]), (2, 3), (4, 2), (1, 2)])
+def test_stride_map(device, D, stride):
+    coords = make_cloud(4000, 20, D, seed=11 + D, batch=2, negative=True)
+    MEB, mgr = _mgr()
+    key, _ = mgr.insert_and_map(coords.to(device), [1] * D, "")
+    st = [stride] * D if isinstance(stride, int) else stride
+    okey = mgr.stride(key, st)
+    assert okey.get_tensor_stride() == st
+    got = mgr.get_coordinates(okey).cpu().numpy()
+    exp, _ = O.stride_map(coords.numpy(), st)
+    # first-occurrence order in input-row order: identical to the oracle's (deterministic) order
+    assert np.array_equal(got, exp)
+    assert mgr.stride(key, st) == okey and len(mgr._maps) == 2   # cached, not rebuilt
+    assert mgr.stride(key, [1] * D) == key                        # all-ones stride reuses the map
+
+
+def test_negative_coordinate_stride(device):  # tests/python/coordinate_manager.py:183-200
+    MEB, mgr = _mgr()
+    coords = torch.IntTensor([[0, -3], [0, -2], [0, -1], [0, 0], [0, 1], [0, 2], [0, 3]]).to(device)
+    key, _ = mgr.insert_and_map(coords, [1], "")
+    out = mgr.get_coordinates(mgr.stride(key, [2])).cpu().numpy()
+    assert sorted(out[:, 1].tolist()) == [-4, -2, 0, 2]
+
+
+KMAP_CASES = [
+    # n, extent, D, kernel_size, stride, dilation, region
+    (6000, 20, 3, 3, 1, 1, 0),
+    (6000, 60, 3, 3, 1, 1, 0),          # sparse
+    (5000, 18, 3, 2, 2, 1, 0),          # MinkUNet down conv
+    (4000, 16, 3, 3, 2, 1, 0),
+    (3000, 14, 3, 5, 1, 1, 0),          # K = 125
+    (3000, 14, 3, 3, 1, 2, 0),          # dilation
+    (3000, 8, 4, 3, 1, 1, 0),           # 4-D, K = 81
+    (3000, 30, 2, [3, 2], 1, 1, 0),     # mixed odd/even
+    (3000, 14, 3, [3, 2, 2], 1, 1, 0),
+    (3000, 14, 3, 3, 1, 1, 1),          # HYPER_CROSS
+    (130, 6, 3, 3, 1, 1, 0),            # barely more than one tile
+    (1, 2, 3, 3, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("n,extent,D,ks,stride,dil,region", KMAP_CASES)
+def test_kernel_map_pair_sets_identical(device, n, extent, D, ks, stride, dil, region):
+    coords = make_cloud(n, extent, D, seed=n + D, batch=2 if n > 100 else 1, negative=True)
+    MEB, mgr = _mgr()
+    key, _ = mgr.insert_and_map(coords.to(device), [1] * D, "")
+    ksl = [ks] * D if isinstance(ks, int) else ks
+    okey = mgr.stride(key, [stride] * D)
+    km = mgr._kernel_map(key, okey, ksl, [stride] * D, [dil] * D, MEB.RegionType(region), None, False, False)
+    in_c = coords.numpy()
+    out_c = mgr.get_coordinates(okey).cpu().numpy()
+    nbr_o, km_o = O.kernel_map(in_c, out_c, O.make_region(D, ksl, dil, 1, region))
+    # dict API, reference format (int32 [2, n_k], only non-empty offsets)
+    d = mgr.kernel_map(key, okey, ksl, [stride] * D, [dil] * D, MEB.RegionType(region), None, False, False)
+    for k, v in d.items():
+        assert v.dtype == torch.int32 and v.shape[0] == 2
+    O.assert_same_kernel_map(d, km_o)
+    # our order is deterministic (sorted by output row), so here even the lists are identical
+    for k in km_o:
+        assert np.array_equal(d[k].cpu().numpy(), km_o[k])
+    assert km.n_pairs == sum(v.shape[1] for v in km_o.values())
+    # dense neighbour tables
+    assert np.array_equal(km.table("out").cpu().numpy()[:, :len(out_c)], nbr_o)
+    nbrT = km.table("in").cpu().numpy()
+    expT = np.full((km.volume, len(in_c)), -1, np.int32)
+    for k, io in km_o.items():
+        expT[k, io[0]] = io[1]
+    assert np.array_equal(nbrT[:, :len(in_c)], expT)
+    # cache hit returns the same object
+    assert mgr._kernel_map(key, okey, ksl, [stride] * D, [dil] * D, MEB.RegionType(region), None, False, False) is km
+
+
+@pytest.mark.parametrize("target", ["out", "in"])
+def test_tile_plan_covers_every_pair_once(device, target):
+    from minkowskiengine_amd import _lib
+    coords = make_cloud(5000, 16, 3, seed=21, batch=2, negative=True)
+    MEB, mgr = _mgr()
+    key, _ = mgr.insert_and_map(coords.to(device), [1, 1, 1], "")
+    okey = mgr.stride(key, [2, 2, 2])
+    km = mgr._kernel_map(key, okey, [3, 3, 3], [2, 2, 2], [1, 1, 1], MEB.RegionType.HYPER_CUBE, None, False, False)
+    plan_src, plan_dst, group_k, tile_gptr = [t.cpu().numpy() for t in km.plan(target)]
+    tbl = km.table(target).cpu().numpy()
+    n_tgt = km.n_out if target == "out" else km.n_in
+    T, G = _lib.ME_TILE_ROWS, _lib.ME_GROUP_ROWS
+    n_tiles = (n_tgt + T - 1) // T
+    assert tile_gptr[0] == 0 and np.all(np.diff(tile_gptr[:n_tiles + 1]) >= 0)
+    seen = set()
+    for t in range(n_tiles):
+        ks = group_k[tile_gptr[t]:tile_gptr[t + 1]]
+        assert np.all(np.diff(ks) >= 0), "groups of a tile must be sorted by offset"
+        for g in range(tile_gptr[t], tile_gptr[t + 1]):
+            k = int(group_k[g])
+            for j in range(G):
+                s, d = int(plan_src[g * G + j]), int(plan_dst[g * G + j])
+                if s < 0:
+                    assert d < 0
+                    continue
+                row = t * T + d
+                assert 0 <= d < T and row < n_tgt and tbl[k, row] == s
+                assert (k, row) not in seen
+                seen.add((k, row))
+    assert len(seen) == int((tbl[:, :n_tgt] >= 0).sum()) == km.n_pairs
+
+
+def test_transposed_map_reuses_forward_map(device):  # src/coordinate_map_manager.cpp:763-774
+    coords = make_cloud(3000, 14, 3, seed=31, negative=True)
+    MEB, mgr = _mgr()
+    key, _ = mgr.insert_and_map(coords.to(device), [1, 1, 1], "")
+    okey = mgr.stride(key, [2, 2, 2])
+    args = ([2, 2, 2], [2, 2, 2], [1, 1, 1], MEB.RegionType.HYPER_CUBE, None)
+    fwd = mgr._kernel_map(key, okey, *args, False, False)
+    tr = mgr._kernel_map(okey, key, *args, True, False)
+    assert tr.in_pairs.data_ptr() == fwd.out_pairs.data_ptr() and tr.n_in == fwd.n_out
+    # built directly (no cached forward map) it must be the same set
+    MEB2, mgr2 = _mgr()
+    key2, _ = mgr2.insert_and_map(coords.to(device), [1, 1, 1], "")
+    okey2 = mgr2.stride(key2, [2, 2, 2])
+    d2 = mgr2.kernel_map(okey2, key2, *args, True, False)
+    O.assert_same_kernel_map(d2, tr.to_dict())
+    fwd_o = O.kernel_map(coords.numpy(), mgr.get_coordinates(okey).cpu().numpy(), O.make_region(3, 2))[1]
+    O.assert_same_kernel_map(d2, {k: np.stack((v[1], v[0])) for k, v in fwd_o.items()})
+
+
+def test_kernel_map_100k_properties(device):
+    """Full config-2 size: size-independent properties + oracle pair sets (the C oracle takes < 1 s)."""
+    coords = make_cloud(100000, 70, 3, seed=0)
+    MEB, mgr = _mgr()
+    key, (um, inv) = mgr.insert_and_map(coords.to(device), [1, 1, 1], "")
+    assert um.numel() == 100000 and torch.equal(inv.cpu(), torch.arange(100000))
+    km = mgr._kernel_map(key, key, [3] * 3, [1] * 3, [1] * 3, MEB.RegionType.HYPER_CUBE, None, False, False)
+    d = km.to_dict()
+    _, km_o = O.kernel_map(coords.numpy(), coords.numpy(), O.make_region(3, 3))
+    O.assert_same_kernel_map(d, km_o)
+    # centre offset is the identity; offset k and 26-k are mirror images (stride-1 symmetry)
+    c = d[13].cpu().numpy()
+    assert np.array_equal(c[0], np.arange(100000)) and np.array_equal(c[1], c[0])
+    for k in range(13):
+        a, b = d[k].cpu().numpy(), d[26 - k].cpu().numpy()
+        pa = a.T[np.lexsort((a[1], a[0]))]
+        pb = b[::-1].T[np.lexsort((b[0], b[1]))]
+        assert np.array_equal(pa, pb)
+    # determinism: a second build gives identical lists
+    MEB2, mgr2 = _mgr()
+    key2, _ = mgr2.insert_and_map(coords.to(device), [1, 1, 1], "")
+    d2 = mgr2.kernel_map(key2, key2, [3] * 3, [1] * 3, [1] * 3, MEB.RegionType.HYPER_CUBE, None, False, False)
+    for k in d:
+        assert torch.equal(d[k], d2[k])

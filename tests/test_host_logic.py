@@ -1,0 +1,81 @@
+"""Host-side logic that needs no GPU: keys, kernel generator, argument checks, loud failure on
+CPU tensors (there is no CPU fallback in the product)."""
+import pytest
+import torch
+
+import minkowskiengine_amd as ME
+from minkowskiengine_amd import backend as MEB
+
+
+def test_coordinate_map_key_semantics():  # src/coordinate_map_key.hpp:44-157
+    unset = ME.CoordinateMapKey(4)
+    assert not unset.is_key_set() and unset.get_coordinate_size() == 4
+    with pytest.raises(RuntimeError):
+        unset.get_key()
+    k1 = ME.CoordinateMapKey([1, 1, 1], "")
+    k2 = ME.CoordinateMapKey([1, 1, 1], "")
+    k3 = ME.CoordinateMapKey([2, 2, 2], "a")
+    assert k1 == k2 and k1 != k3 and not (unset == unset)
+    assert k1.get_key() == ([1, 1, 1], "") and k3.get_tensor_stride() == [2, 2, 2]
+    unset.set_key([2, 2, 2], "a")
+    assert unset == k3 and hash(unset) == hash(k3)
+    with pytest.raises(RuntimeError):
+        ME.CoordinateMapKey(3).set_key([1, 1, 1], "")
+    assert "coordinate map key:[2, 2, 2]:a" == repr(k3)
+
+
+def test_kernel_generator():  # MinkowskiKernelGenerator.py:245-345
+    kg = ME.KernelGenerator(kernel_size=3, stride=2, dilation=1, dimension=3)
+    assert kg.kernel_volume == 27 and kg.kernel_stride == [2, 2, 2] and not kg.requires_strided_coordinates
+    assert ME.KernelGenerator(kernel_size=[3, 2, 2], dimension=3).kernel_volume == 12
+    assert ME.KernelGenerator(kernel_size=3, region_type=ME.RegionType.HYPER_CROSS, dimension=3).kernel_volume == 7
+    assert ME.KernelGenerator(kernel_size=1, dimension=3).requires_strided_coordinates
+
+
+def test_convolution_module_shapes():  # MinkowskiConvolution.py:264-279, 332-340
+    conv = ME.MinkowskiConvolution(8, 16, kernel_size=3, dimension=3, bias=True)
+    assert tuple(conv.kernel.shape) == (27, 8, 16) and tuple(conv.bias.shape) == (1, 16)
+    bound = 1.0 / (8 * 27) ** 0.5
+    assert float(conv.kernel.detach().abs().max()) <= bound
+    assert ME.MinkowskiConvolution(8, 16, kernel_size=1, dimension=3).use_mm
+    assert not ME.MinkowskiConvolution(8, 16, kernel_size=1, stride=2, dimension=3).use_mm
+    t = ME.MinkowskiConvolutionTranspose(8, 16, kernel_size=2, stride=2, dimension=3)
+    assert t.is_transpose and tuple(t.kernel.shape) == (8, 8, 16)
+    assert "MinkowskiConvolution(in=8, out=16, kernel_size=[3, 3, 3], stride=[1, 1, 1], dilation=[1, 1, 1])" == repr(
+        ME.MinkowskiConvolution(8, 16, kernel_size=3, dimension=3))
+
+
+def test_cpu_tensors_are_rejected_loudly():
+    coords = torch.IntTensor([[0, 0, 0, 0], [0, 1, 0, 0]])
+    feats = torch.rand(2, 4)
+    with pytest.raises(RuntimeError):
+        ME.SparseTensor(feats, coords)
+    mgr = MEB.CoordinateMapManagerGPU_c10()
+    with pytest.raises(RuntimeError):
+        mgr.insert_and_map(coords, [1, 1, 1], "")
+    with pytest.raises(RuntimeError):
+        mgr.insert_and_map(coords.float(), [1, 1, 1], "")
+    with pytest.raises(ValueError):
+        ME.get_minkowski_function("ConvolutionForward", feats)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from minkowskiengine_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_batched_coordinates():
+    a = torch.IntTensor([[1, 2], [3, 4]])
+    b = torch.IntTensor([[5, 6]])
+    bc = ME.utils.batched_coordinates([a, b])
+    assert bc.tolist() == [[0, 1, 2], [0, 3, 4], [1, 5, 6]] and bc.dtype == torch.int32
+
+
+def test_enums_match_reference_names():  # pybind/extern.hpp:669-741
+    assert int(ME.RegionType.HYPER_CUBE) == 0 and int(ME.RegionType.HYPER_CROSS) == 1
+    assert hasattr(ME.ConvolutionMode, "DIRECT_GEMM") and hasattr(ME.MinkowskiAlgorithm, "SPEED_OPTIMIZED")
+    assert hasattr(MEB, "ConvolutionForwardGPU") and hasattr(MEB, "ConvolutionTransposeBackwardGPU")
+    assert MEB.is_cuda_available()
