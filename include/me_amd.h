@@ -115,23 +115,28 @@ int me_kernel_map_transpose(const int32_t *in_pairs_dev, const int32_t *out_pair
                             int64_t n_in, int32_t *nbrT_dev, void *stream);
 
 /* ---- tile plan for the target-stationary convolution ----------------------------------------- */
-/* A plan cuts the target rows into tiles of ME_TILE_ROWS; per tile the valid (offset k, source row)
- * entries are grouped by k and padded to groups of 16 (one MFMA 16x16x4 M-tile per group). */
-#define ME_TILE_ROWS 128
+/* A plan cuts the target rows into tiles of `tile_rows` consecutive rows (any value in
+ * [ME_GROUP_ROWS, ME_MAX_TILE_ROWS]; me_conv_choose_tile_rows picks it so that tiles x column slabs
+ * fill the GPU's workgroup slots evenly).  Per tile the valid (offset k, source row) entries are
+ * grouped by k and padded to groups of 16 (one MFMA 16x16x4 M-tile per group). */
 #define ME_GROUP_ROWS 16
-int64_t me_plan_num_tiles(int64_t n_tgt);
+#define ME_MAX_TILE_ROWS 256
+int64_t me_plan_num_tiles(int64_t n_tgt, int32_t tile_rows);
 /* upper bound on the number of groups for a table with n_pairs valid entries */
-int64_t me_plan_max_groups(int64_t n_tgt, int64_t volume, int64_t n_pairs);
-int64_t me_plan_workspace_bytes(int64_t n_tgt, int64_t volume);
+int64_t me_plan_max_groups(int64_t n_tgt, int64_t volume, int64_t n_pairs, int32_t tile_rows);
+int64_t me_plan_workspace_bytes(int64_t n_tgt, int64_t volume, int32_t tile_rows);
 /*   tbl_dev        int32 [volume, n_tgt]  neighbour table (nbr for forward, nbrT for dgrad)
  *   plan_src_dev   int32 [16 * max_groups] (out) source row per slot, -1 = padding
- *   plan_dst_dev   int32 [16 * max_groups] (out) target row local to its tile, -1 = padding
+ *   plan_dst_dev   int32 [16 * max_groups] (out) target row local to its tile; padding slots point at
+ *                                                the dummy row `tile_rows`
  *   group_k_dev    int32 [max_groups]      (out) kernel offset of each group
+ *   group_nk_dev   int32 [max_groups]      (out) next offset of the same tile that has groups, or -1
  *   tile_gptr_dev  int32 [num_tiles + 1]   (out) group range of each tile
  */
-int me_plan_build(const int32_t *tbl_dev, int64_t n_tgt, int64_t volume, int32_t *plan_src_dev,
-                  int32_t *plan_dst_dev, int32_t *group_k_dev, int32_t *tile_gptr_dev,
-                  void *workspace_dev, int64_t workspace_bytes, void *stream);
+int me_plan_build(const int32_t *tbl_dev, int64_t n_tgt, int64_t volume, int32_t tile_rows,
+                  int32_t *plan_src_dev, int32_t *plan_dst_dev, int32_t *group_k_dev,
+                  int32_t *group_nk_dev, int32_t *tile_gptr_dev, void *workspace_dev,
+                  int64_t workspace_bytes, void *stream);
 
 /* ---- convolution feature kernels (replace ConvolutionForwardKernelGPU / BackwardKernelGPU,
  *      src/convolution_kernel.cu:320-496, 553-757; CPU twins src/convolution_kernel.hpp:33-144) -- */
@@ -143,8 +148,15 @@ int me_plan_build(const int32_t *tbl_dev, int64_t n_tgt, int64_t volume, int32_t
 int me_conv_target_f32(const float *src_feat_dev, int64_t n_src, int32_t c_src, const float *w_dev,
                        int64_t volume, int32_t c_dst, const int32_t *plan_src_dev,
                        const int32_t *plan_dst_dev, const int32_t *group_k_dev,
-                       const int32_t *tile_gptr_dev, float *dst_feat_dev, int64_t n_tgt,
-                       void *stream);
+                       const int32_t *group_nk_dev, const int32_t *tile_gptr_dev,
+                       float *dst_feat_dev, int64_t n_tgt, int32_t tile_rows, void *stream);
+
+/* Tile height for a (target rows, channels) problem: the largest tile that still fits the LDS budget
+ * of the chosen kernel variant while tiles x column slabs is just below a multiple of the GPU's
+ * resident-workgroup slots (a 100k-voxel layer is only ~2 workgroup rounds long, so an unlucky tile
+ * count can idle a third of the chip).  n_pairs steers the trade-off against 16-row group padding. */
+int32_t me_conv_choose_tile_rows(int64_t n_tgt, int64_t volume, int64_t n_pairs, int32_t c_src,
+                                 int32_t c_dst);
 
 /* wt[k, j, i] = w[k, i, j] */
 int me_transpose_kernel_f32(const float *w_dev, int64_t volume, int32_t c_in, int32_t c_out,

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libme_amd.so")
 
 ME_MAX_DIM = 7
-ME_TILE_ROWS = 128
+ME_MAX_TILE_ROWS = 256
 ME_GROUP_ROWS = 16
 ME_WGRAD_CHUNK = 2048
 
@@ -50,12 +50,14 @@ SIGNATURES = {
                                            c_i64, c_vp]),
     "me_kernel_map_compact": (ctypes.c_int, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "me_kernel_map_transpose": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp]),
-    "me_plan_num_tiles": (c_i64, [c_i64]),
-    "me_plan_max_groups": (c_i64, [c_i64, c_i64, c_i64]),
-    "me_plan_workspace_bytes": (c_i64, [c_i64, c_i64]),
-    "me_plan_build": (ctypes.c_int, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "me_plan_num_tiles": (c_i64, [c_i64, c_i32]),
+    "me_plan_max_groups": (c_i64, [c_i64, c_i64, c_i64, c_i32]),
+    "me_plan_workspace_bytes": (c_i64, [c_i64, c_i64, c_i32]),
+    "me_plan_build": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64,
+                                     c_vp]),
     "me_conv_target_f32": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp,
-                                          c_vp, c_i64, c_vp]),
+                                          c_vp, c_vp, c_i64, c_i32, c_vp]),
+    "me_conv_choose_tile_rows": (c_i32, [c_i64, c_i64, c_i64, c_i32, c_i32]),
     "me_transpose_kernel_f32": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
     "me_conv_wgrad_workspace_bytes": (c_i64, [_P_I64, c_i64, c_i32, c_i32]),
     "me_conv_wgrad_f32": (ctypes.c_int, [c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, _P_I64, c_vp, c_i64, c_vp,

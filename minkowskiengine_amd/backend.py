@@ -271,25 +271,28 @@ class KernelMapGPU:
             self._store[name] = tbl
         return self._store[name]
 
-    def plan(self, target):
-        """Tile plan with `target` rows stationary: (plan_src, plan_dst, group_k, tile_gptr)."""
-        name = self._name("plan", target)
+    def plan(self, target, tile_rows):
+        """Tile plan with `target` rows stationary and tiles of `tile_rows` rows:
+        (plan_src, plan_dst, group_k, group_nk, tile_gptr); built once per (target, tile_rows)."""
+        name = self._name("plan", target) + f"_{int(tile_rows)}"
         if name not in self._store:
             lib = _lib.load()
             dev = self.device
             n_tgt = self.n_out if target == "out" else self.n_in
             tbl = self.table(target)
-            max_groups = int(lib.me_plan_max_groups(n_tgt, self.volume, self.n_pairs))
-            n_tiles = int(lib.me_plan_num_tiles(n_tgt))
+            max_groups = int(lib.me_plan_max_groups(n_tgt, self.volume, self.n_pairs, tile_rows))
+            n_tiles = int(lib.me_plan_num_tiles(n_tgt, tile_rows))
             plan_src = torch.empty(max_groups * _lib.ME_GROUP_ROWS, dtype=torch.int32, device=dev)
             plan_dst = torch.empty(max_groups * _lib.ME_GROUP_ROWS, dtype=torch.int32, device=dev)
             group_k = torch.empty(max_groups, dtype=torch.int32, device=dev)
+            group_nk = torch.empty(max_groups, dtype=torch.int32, device=dev)
             tile_gptr = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
-            ws = _workspace(lib.me_plan_workspace_bytes(n_tgt, self.volume), dev)
+            ws = _workspace(lib.me_plan_workspace_bytes(n_tgt, self.volume, tile_rows), dev)
             with torch.cuda.device(dev):
-                _lib.check(lib.me_plan_build(_ptr(tbl), n_tgt, self.volume, _ptr(plan_src), _ptr(plan_dst),
-                                             _ptr(group_k), _ptr(tile_gptr), _ptr(ws), ws.numel(), _stream(dev)))
-            self._store[name] = (plan_src, plan_dst, group_k, tile_gptr)
+                _lib.check(lib.me_plan_build(_ptr(tbl), n_tgt, self.volume, tile_rows, _ptr(plan_src),
+                                             _ptr(plan_dst), _ptr(group_k), _ptr(group_nk), _ptr(tile_gptr),
+                                             _ptr(ws), ws.numel(), _stream(dev)))
+            self._store[name] = (plan_src, plan_dst, group_k, group_nk, tile_gptr)
         return self._store[name]
 
     def to_dict(self):
@@ -477,6 +480,7 @@ CoordinateMapManagerGPU_default = CoordinateMapManagerGPU_c10
 # convolution operators (src/convolution_gpu.cu:45-244, src/convolution_transpose_gpu.cu)
 # ------------------------------------------------------------------------------------------------
 _ALGO = os.environ.get("ME_AMD_CONV_ALGO", "mfma")  # "naive" = VALU/atomics cross-check kernels
+_TILE_ROWS = int(os.environ.get("ME_AMD_TILE_ROWS", "0"))  # 0 = me_conv_choose_tile_rows (tuning override)
 
 
 def _check_feat(name, t):
@@ -526,11 +530,13 @@ def _conv_target(src_feat, weights, km, target, n_tgt, name="conv_target"):
     out = torch.empty((n_tgt, c_dst), dtype=torch.float32, device=dev)
     if n_tgt == 0:
         return out
-    plan_src, plan_dst, group_k, tile_gptr = km.plan(target)
+    tile_rows = _TILE_ROWS or int(lib.me_conv_choose_tile_rows(n_tgt, km.volume, km.n_pairs, c_src, c_dst))
+    plan_src, plan_dst, group_k, group_nk, tile_gptr = km.plan(target, tile_rows)
     with torch.cuda.device(dev):
         _timed(name, dev, lambda: _lib.check(lib.me_conv_target_f32(
             _ptr(src_feat), src_feat.shape[0], c_src, _ptr(weights), km.volume, c_dst, _ptr(plan_src),
-            _ptr(plan_dst), _ptr(group_k), _ptr(tile_gptr), _ptr(out), n_tgt, _stream(dev))))
+            _ptr(plan_dst), _ptr(group_k), _ptr(group_nk), _ptr(tile_gptr), _ptr(out), n_tgt, tile_rows,
+            _stream(dev))))
     return out
 
 

@@ -6,8 +6,9 @@
 // kernel offset and scatters with one global atomicAdd per output element
 // (src/convolution_kernel.cu:114-180).  Here the TARGET rows are stationary instead:
 //
-//   * a workgroup owns ME_TILE_ROWS target rows x NC output columns; its fp32 accumulator tile
-//     lives in LDS (128 x 64 x 4 B = 32 KiB of the CU's 160 KiB);
+//   * a workgroup owns `tile_rows` target rows x NC output columns; its fp32 accumulator tile
+//     lives in LDS (e.g. 131 x 64 x 4 B = 33 KiB of the CU's 160 KiB; the tile height is chosen so
+//     that tiles x column slabs fill the chip's resident-workgroup slots evenly);
 //   * the tile plan (coords.hip) lists, per tile, the valid (offset k, source row) entries grouped
 //     by k in groups of 16 rows = one MFMA M-tile, so no matrix-core work is spent on absent
 //     neighbours beyond the padding of the last group of each (tile, k);
@@ -27,19 +28,44 @@ namespace me {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kTile = ME_TILE_ROWS;  // target rows per workgroup
-constexpr int kGB = 4;               // groups (of 16 gathered rows) per LDS batch
-constexpr int kRows = kGB * 16;      // gathered rows per batch
+constexpr int kGB = 4;            // groups (of 16 gathered rows) per LDS batch
+constexpr int kRows = kGB * 16;   // gathered rows per batch
+constexpr int kLdsBudget = 160 * 1024;
+
+// LDS bytes of one workgroup of k_conv_target_f32<NC, KC> with `tile_rows` target rows
+// (accumulator tile + one dummy row for padding slots, gathered-row tile, plan slice)
+__host__ __device__ constexpr int conv_lds_bytes(int NC, int KC, int tile_rows) {
+  return (tile_rows + 1) * NC * 4 + kRows * (KC + 4) * 4 + kRows * 4 + 2 * kGB * 4 + 32;
+}
 
 // =================================================================================================
 // target-stationary convolution (forward and dgrad)
 // =================================================================================================
+// R groups of one offset at once: R independent accumulators share every B register, which covers
+// the 40-cycle dependent-accumulator latency of v_mfma_f32_16x16x4_f32 (issue interval 32).
+template <int R, int KQ, int A_LD>
+__device__ __forceinline__ void mma_groups(const float *__restrict__ a0p, const float (&breg)[KQ],
+                                           f32x4 (&acc)[4]) {
+#pragma unroll
+  for (int s4 = 0; s4 < KQ / 4; ++s4) {
+    f32x4 a[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) a[r] = *reinterpret_cast<const f32x4 *>(a0p + r * 16 * A_LD + s4 * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][j], breg[s4 * 4 + j], acc[r], 0, 0, 0);
+    }
+  }
+}
+
 template <int NC, int KC>
-__global__ __launch_bounds__(NC * 4) void k_conv_target_f32(
+__global__ __launch_bounds__(NC * 4, (NC == 32 && KC == 64) ? 2 : 3) void k_conv_target_f32(
     const float *__restrict__ src, int c_src, const float *__restrict__ w, int c_dst,
     const int32_t *__restrict__ plan_src, const int32_t *__restrict__ plan_dst,
-    const int32_t *__restrict__ group_k, const int32_t *__restrict__ tile_gptr,
-    float *__restrict__ dst, int64_t n_tgt) {
+    const int32_t *__restrict__ group_k, const int32_t *__restrict__ group_nk,
+    const int32_t *__restrict__ tile_gptr, float *__restrict__ dst, int64_t n_tgt, int tile_rows) {
   constexpr int WAVES = NC / 16;
   constexpr int NT = WAVES * 64;
   constexpr int A_LD = KC + 4;         // floats; +16 B per row spreads ds_read_b128 over the banks
@@ -49,10 +75,12 @@ __global__ __launch_bounds__(NC * 4) void k_conv_target_f32(
   static_assert(kRows * F4_PER_ROW % NT == 0, "gather work must divide evenly");
   static_assert(KC % 16 == 0, "KC must be a multiple of 16");
 
-  __shared__ __attribute__((aligned(16))) float s_acc[kTile * NC];
-  __shared__ __attribute__((aligned(16))) float s_a[kRows * A_LD];
-  __shared__ int32_t s_dst[kRows];
-  __shared__ int32_t s_k[kGB];
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *s_acc = reinterpret_cast<float *>(smem);              // [(tile_rows + 1) x NC]
+  float *s_a = s_acc + (tile_rows + 1) * NC;                   // [kRows x A_LD]
+  int32_t *s_dst = reinterpret_cast<int32_t *>(s_a + kRows * A_LD);  // [kRows]
+  int32_t *s_k = s_dst + kRows;                                // [kGB]
+  int32_t *s_nk = s_k + kGB;                                   // [kGB]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -65,15 +93,24 @@ __global__ __launch_bounds__(NC * 4) void k_conv_target_f32(
   const int g_begin = tile_gptr[tile];
   const int g_end = tile_gptr[tile + 1];
   const bool vec_ok = (c_src % 4) == 0;
+  const int acc_f4 = (tile_rows + 1) * NC / 4;
 
-  for (int x = tid; x < kTile * NC / 4; x += NT)
-    reinterpret_cast<f32x4 *>(s_acc)[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int x = tid; x < acc_f4; x += NT) reinterpret_cast<f32x4 *>(s_acc)[x] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   for (int c0 = 0; c0 < c_src; c0 += KC) {
-    float breg[KQ];
+    float breg[KQ], bnext[KQ];
     int cur_k = -1;
     f32x4 stage[ITER];
 
+    // this wave's 16-column slice of W_k for the source channels of this chunk (K-permuted: MFMA
+    // k-step s of lane group q reads channel c0 + q*KQ + s, so a lane's A values are contiguous)
+    auto load_b = [&](int k, float (&b)[KQ]) {
+#pragma unroll
+      for (int s = 0; s < KQ; ++s) {
+        const int kidx = c0 + q * KQ + s;
+        b[s] = (kidx < c_src && col < c_dst) ? w[((int64_t)k * c_src + kidx) * c_dst + col] : 0.f;
+      }
+    };
     // issue the gather loads of batch `gb` (global -> registers)
     auto gather_issue = [&](int gb) {
       const int ng = min(kGB, g_end - gb);
@@ -100,7 +137,10 @@ __global__ __launch_bounds__(NC * 4) void k_conv_target_f32(
       }
     };
 
-    if (g_begin < g_end) gather_issue(g_begin);
+    if (g_begin < g_end) {
+      load_b(group_k[g_begin], bnext);  // weights of the first offset fly under the first gather
+      gather_issue(g_begin);
+    }
 
     for (int gb = g_begin; gb < g_end; gb += kGB) {
       const int ng = min(kGB, g_end - gb);
@@ -112,8 +152,11 @@ __global__ __launch_bounds__(NC * 4) void k_conv_target_f32(
         const int p = idx % F4_PER_ROW;
         *reinterpret_cast<f32x4 *>(&s_a[r * A_LD + p * 4]) = stage[it];
       }
-      if (tid < kRows) s_dst[tid] = (tid < ng * 16) ? plan_dst[(int64_t)gb * 16 + tid] : -1;
-      if (tid < kGB) s_k[tid] = (tid < ng) ? group_k[gb + tid] : -1;
+      if (tid < kRows) s_dst[tid] = (tid < ng * 16) ? plan_dst[(int64_t)gb * 16 + tid] : tile_rows;
+      if (tid < kGB) {
+        s_k[tid] = (tid < ng) ? group_k[gb + tid] : -1;
+        s_nk[tid] = (tid < ng) ? group_nk[gb + tid] : -1;
+      }
       __syncthreads();
       // next batch's loads fly while this batch is multiplied
       if (gb + kGB < g_end) gather_issue(gb + kGB);
@@ -121,70 +164,48 @@ __global__ __launch_bounds__(NC * 4) void k_conv_target_f32(
       int g = 0;
       while (g < ng) {
         const int k0 = s_k[g];
-        const bool two = (g + 1 < ng) && (s_k[g + 1] == k0);
+        int run = 1;
+        while (g + run < ng && s_k[g + run] == k0) ++run;
         if (k0 != cur_k) {
           cur_k = k0;
 #pragma unroll
-          for (int s = 0; s < KQ; ++s) {
-            const int kidx = c0 + q * KQ + s;
-            breg[s] = (kidx < c_src && col < c_dst)
-                          ? w[((int64_t)k0 * c_src + kidx) * c_dst + col]
-                          : 0.f;
-          }
+          for (int s = 0; s < KQ; ++s) breg[s] = bnext[s];
+          const int nk = s_nk[g];
+          if (nk >= 0) load_b(nk, bnext);  // prefetch the next offset's weights under this run
         }
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f};
-        f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
         const float *a0p = &s_a[(g * 16 + i16) * A_LD + q * KQ];
-        if (two) {
-          const float *a1p = a0p + 16 * A_LD;
-#pragma unroll
-          for (int s4 = 0; s4 < KQ / 4; ++s4) {
-            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(a0p + s4 * 4);
-            const f32x4 a1 = *reinterpret_cast<const f32x4 *>(a1p + s4 * 4);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, breg[s4 * 4 + 0], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, breg[s4 * 4 + 0], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, breg[s4 * 4 + 1], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, breg[s4 * 4 + 1], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, breg[s4 * 4 + 2], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, breg[s4 * 4 + 2], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, breg[s4 * 4 + 3], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, breg[s4 * 4 + 3], acc1, 0, 0, 0);
-          }
-        } else {
-#pragma unroll
-          for (int s4 = 0; s4 < KQ / 4; ++s4) {
-            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(a0p + s4 * 4);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, breg[s4 * 4 + 0], acc0, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, breg[s4 * 4 + 1], acc0, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, breg[s4 * 4 + 2], acc0, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, breg[s4 * 4 + 3], acc0, 0, 0, 0);
-          }
-        }
-        // D[row = q*4 + r][col = i16] -> accumulator rows named by the plan (wave-private columns)
+        if (run == 4) mma_groups<4, KQ, A_LD>(a0p, breg, acc);
+        else if (run == 3) mma_groups<3, KQ, A_LD>(a0p, breg, acc);
+        else if (run == 2) mma_groups<2, KQ, A_LD>(a0p, breg, acc);
+        else mma_groups<1, KQ, A_LD>(a0p, breg, acc);
+        // D[row = q*4 + i][col = i16] -> accumulator rows named by the plan.  The columns are private
+        // to this wave and a wave's LDS operations retire in order, so ds_add_f32 (no return) gives a
+        // fixed summation order; padding slots land in the dummy row `tile_rows`.
         float *accp = &s_acc[wave * 16 + i16];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int d0 = s_dst[g * 16 + q * 4 + r];
-          if (d0 >= 0) accp[d0 * NC] += acc0[r];
-        }
-        if (two) {
+          if (r < run) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int d1 = s_dst[(g + 1) * 16 + q * 4 + r];
-            if (d1 >= 0) accp[d1 * NC] += acc1[r];
+            for (int i = 0; i < 4; ++i) {
+              const int d = s_dst[(g + r) * 16 + q * 4 + i];
+              __hip_atomic_fetch_add(accp + d * NC, acc[r][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
           }
         }
-        g += two ? 2 : 1;
+        g += run;
       }
     }
     __syncthreads();  // all reads of s_a done before the next chunk restages it
   }
 
   __syncthreads();
-  const int64_t row0 = (int64_t)tile * kTile;
-  const int rows_here = (int)min((int64_t)kTile, n_tgt - row0);
+  const int64_t row0 = (int64_t)tile * tile_rows;
+  const int rows_here = (int)min((int64_t)tile_rows, n_tgt - row0);
   const bool vec_out = (c_dst % 4) == 0;
-  for (int x = tid; x < kTile * NC / 4; x += NT) {
+  for (int x = tid; x < tile_rows * NC / 4; x += NT) {
     const int row = x / (NC / 4);
     const int cc = col_base + (x % (NC / 4)) * 4;
     if (row < rows_here && cc < c_dst) {
@@ -433,13 +454,56 @@ __global__ __launch_bounds__(256) void k_naive_wgrad(const float *__restrict__ i
   grad_w[t] = s;
 }
 
+// kernel variant for a (c_src, c_dst) problem
+struct ConvVariant {
+  int nc;  // output columns per workgroup (64 or 32); waves per workgroup = nc / 16
+  int kc;  // source-channel chunk (64, 32 or 16)
+};
+
+static ConvVariant conv_variant(int c_src, int c_dst) {
+  ConvVariant v;
+  // columns per workgroup: 64 unless the last 64-column slab would be at most half full
+  const int rem = c_dst % 64;
+  v.nc = (rem != 0 && rem <= 32) ? 32 : 64;
+  // source-channel chunk: the largest of {64, 32, 16} that adds at most 16 channels of padding
+  if (c_src % 64 == 0) v.kc = 64;
+  else if (c_src % 32 == 0) v.kc = 32;
+  else if (c_src <= 16) v.kc = 16;
+  else if (c_src <= 32) v.kc = 32;
+  else v.kc = (align_up(c_src, 64) - c_src <= 16) ? 64 : ((align_up(c_src, 32) - c_src <= 16) ? 32 : 16);
+  return v;
+}
+
+static int device_cu_count() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+        prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
+    else
+      cus = 256;  // MI355X
+  }
+  return cus;
+}
+
 template <int NC, int KC>
 static int launch_conv_target(const float *src, int c_src, const float *w, int c_dst,
                               const int32_t *plan_src, const int32_t *plan_dst, const int32_t *group_k,
-                              const int32_t *tile_gptr, float *dst, int64_t n_tgt, hipStream_t stream) {
-  const dim3 grid((unsigned)ceil_div(n_tgt, kTile), (unsigned)ceil_div(c_dst, NC));
-  hipLaunchKernelGGL((k_conv_target_f32<NC, KC>), grid, dim3(NC * 4), 0, stream, src, c_src, w, c_dst,
-                     plan_src, plan_dst, group_k, tile_gptr, dst, n_tgt);
+                              const int32_t *group_nk, const int32_t *tile_gptr, float *dst, int64_t n_tgt,
+                              int tile_rows, hipStream_t stream) {
+  const int lds = conv_lds_bytes(NC, KC, tile_rows);
+  ME_CHECK(lds <= kLdsBudget, "tile_rows too large for the LDS of one workgroup");
+  static int max_lds_set = 0;  // per instantiation
+  if (lds > 64 * 1024 && lds > max_lds_set) {
+    ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_target_f32<NC, KC>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
+    max_lds_set = kLdsBudget;
+  }
+  const dim3 grid((unsigned)ceil_div(n_tgt, tile_rows), (unsigned)ceil_div(c_dst, NC));
+  hipLaunchKernelGGL((k_conv_target_f32<NC, KC>), grid, dim3(NC * 4), (size_t)lds, stream, src, c_src, w,
+                     c_dst, plan_src, plan_dst, group_k, group_nk, tile_gptr, dst, n_tgt, tile_rows);
   ME_LAUNCH_CHECK();
   return 0;
 }
@@ -456,36 +520,68 @@ using namespace me;
 
 extern "C" {
 
+int32_t me_conv_choose_tile_rows(int64_t n_tgt, int64_t volume, int64_t n_pairs, int32_t c_src,
+                                 int32_t c_dst) {
+  if (n_tgt <= 0 || volume <= 0 || c_src <= 0 || c_dst <= 0) return 128;
+  const ConvVariant v = conv_variant(c_src, c_dst);
+  const int waves = v.nc / 16;
+  const int64_t slabs = ceil_div(c_dst, v.nc);
+  const int chunks = (int)ceil_div(c_src, v.kc);
+  // resident workgroups per CU: 3 waves per SIMD by registers, then whatever the LDS allows
+  const int occ_regs = 12 / waves;
+  const int cus = device_cu_count();
+  // occupancy p of a neighbour offset (centre excluded) -> expected 16-row groups of a (tile, k)
+  const double p = volume > 1 ? (double)(n_pairs > n_tgt ? n_pairs - n_tgt : 0) / ((double)(volume - 1) * n_tgt)
+                              : 0.0;
+  double best_cost = 1e300;
+  int best_t = 0;
+  for (int occ = occ_regs; occ >= 1; --occ) {
+    const int64_t slots = (int64_t)cus * occ;
+    for (int rounds = 1; rounds <= 64; ++rounds) {
+      int64_t t = ceil_div(n_tgt * slabs, slots * rounds);
+      if (t < ME_GROUP_ROWS) t = ME_GROUP_ROWS;
+      if (t > ME_MAX_TILE_ROWS) continue;
+      if ((int64_t)conv_lds_bytes(v.nc, v.kc, (int)t) * occ > kLdsBudget) continue;
+      const double m = (double)t * p;
+      const double g_side = m < 6.0 ? (m <= 0 ? 0.0 : (1.0 - exp(-m)) * (1.0 + m / 16.0)) : m / 16.0 + 0.5;
+      const double groups = (double)ceil_div(t, 16) + (double)(volume - 1) * g_side;
+      const int64_t items = ceil_div(n_tgt, t) * slabs;
+      const double real_rounds = (double)ceil_div(items, slots);
+      // time ~ rounds x groups of one item x waves sharing a SIMD (+ a per-batch overhead term)
+      const double cost = real_rounds * (groups * chunks) * (double)(occ * waves) / 4.0 *
+                          (1.0 + 0.15 * 12.0 / (occ * waves));
+      if (cost < best_cost) {
+        best_cost = cost;
+        best_t = (int)t;
+      }
+      if (t == ME_GROUP_ROWS) break;
+    }
+  }
+  return best_t > 0 ? best_t : 128;
+}
+
 int me_conv_target_f32(const float *src, int64_t n_src, int32_t c_src, const float *w, int64_t volume,
                        int32_t c_dst, const int32_t *plan_src, const int32_t *plan_dst,
-                       const int32_t *group_k, const int32_t *tile_gptr, float *dst, int64_t n_tgt,
-                       void *stream_) {
+                       const int32_t *group_k, const int32_t *group_nk, const int32_t *tile_gptr, float *dst,
+                       int64_t n_tgt, int32_t tile_rows, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   (void)n_src;
   (void)volume;
   ME_CHECK(c_src > 0 && c_dst > 0, "channel counts must be positive");
+  ME_CHECK(tile_rows >= ME_GROUP_ROWS && tile_rows <= ME_MAX_TILE_ROWS, "tile_rows out of range");
   ME_CHECK((uintptr_t)src % 16 == 0 && (uintptr_t)dst % 16 == 0, "feature pointers must be 16-byte aligned");
   if (n_tgt == 0) return 0;
-  // columns per workgroup: 64 unless the last 64-column slab would be at most half full
-  const int rem = c_dst % 64;
-  const bool nc32 = (rem != 0 && rem <= 32);
-  // source-channel chunk: the largest of {64, 32, 16} that does not add padding beyond a multiple of 16
-  int kc;
-  if (c_src % 64 == 0) kc = 64;
-  else if (c_src % 32 == 0) kc = 32;
-  else if (c_src <= 16) kc = 16;
-  else if (c_src <= 32) kc = 32;
-  else kc = (align_up(c_src, 64) - c_src <= 16) ? 64 : ((align_up(c_src, 32) - c_src <= 16) ? 32 : 16);
+  const ConvVariant v = conv_variant(c_src, c_dst);
 #define ME_CONV_CASE(NCV, KCV)                                                                    \
-  return launch_conv_target<NCV, KCV>(src, c_src, w, c_dst, plan_src, plan_dst, group_k, tile_gptr, \
-                                      dst, n_tgt, stream)
-  if (nc32) {
-    if (kc == 64) ME_CONV_CASE(32, 64);
-    if (kc == 32) ME_CONV_CASE(32, 32);
+  return launch_conv_target<NCV, KCV>(src, c_src, w, c_dst, plan_src, plan_dst, group_k, group_nk, \
+                                      tile_gptr, dst, n_tgt, tile_rows, stream)
+  if (v.nc == 32) {
+    if (v.kc == 64) ME_CONV_CASE(32, 64);
+    if (v.kc == 32) ME_CONV_CASE(32, 32);
     ME_CONV_CASE(32, 16);
   } else {
-    if (kc == 64) ME_CONV_CASE(64, 64);
-    if (kc == 32) ME_CONV_CASE(64, 32);
+    if (v.kc == 64) ME_CONV_CASE(64, 64);
+    if (v.kc == 32) ME_CONV_CASE(64, 32);
     ME_CONV_CASE(64, 16);
   }
 #undef ME_CONV_CASE

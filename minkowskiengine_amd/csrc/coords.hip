@@ -325,45 +325,46 @@ __global__ __launch_bounds__(256) void k_kmap_transpose(const int32_t *__restric
 // =================================================================================================
 // tile plan
 // =================================================================================================
-// one wavefront per (tile, offset)
+// one wavefront per (tile, offset); tiles hold `tile_rows` consecutive target rows
 __global__ __launch_bounds__(256) void k_plan_count(const int32_t *__restrict__ tbl, int64_t n_tgt,
-                                                   int64_t volume, int64_t n_items,
+                                                   int64_t volume, int64_t n_items, int tile_rows,
                                                    uint32_t *__restrict__ gcount) {
   const int64_t item = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (item >= n_items) return;  // wave-uniform
   const int64_t t = item / volume, k = item % volume;
-  const int64_t row0 = t * ME_TILE_ROWS;
+  const int64_t row0 = t * tile_rows;
   uint32_t count = 0;
-#pragma unroll
-  for (int c = 0; c < ME_TILE_ROWS / 64; ++c) {
-    const int64_t u = row0 + c * 64 + lane_id();
-    const int32_t r = (u < n_tgt) ? tbl[k * n_tgt + u] : -1;
+  for (int c = 0; c < tile_rows; c += 64) {
+    const int local = c + lane_id();
+    const int64_t u = row0 + local;
+    const int32_t r = (local < tile_rows && u < n_tgt) ? tbl[k * n_tgt + u] : -1;
     count += (uint32_t)__popcll(__ballot(r >= 0));
   }
   if (lane_id() == 0) gcount[item] = (count + ME_GROUP_ROWS - 1) / ME_GROUP_ROWS;
 }
 
 __global__ __launch_bounds__(256) void k_plan_fill(const int32_t *__restrict__ tbl, int64_t n_tgt,
-                                                  int64_t volume, int64_t n_items,
+                                                  int64_t volume, int64_t n_items, int tile_rows,
+                                                  const uint32_t *__restrict__ gcount,
                                                   const uint32_t *__restrict__ goffs,
                                                   const uint32_t *__restrict__ gtotal,
                                                   int32_t *__restrict__ plan_src,
                                                   int32_t *__restrict__ plan_dst,
                                                   int32_t *__restrict__ group_k,
+                                                  int32_t *__restrict__ group_nk,
                                                   int32_t *__restrict__ tile_gptr, int64_t n_tiles) {
   const int64_t item = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (item >= n_items) return;  // wave-uniform
   const int lane = lane_id();
   const int64_t t = item / volume, k = item % volume;
-  const int64_t row0 = t * ME_TILE_ROWS;
+  const int64_t row0 = t * tile_rows;
   const uint32_t g0 = goffs[item];
   const int64_t slot0 = (int64_t)g0 * ME_GROUP_ROWS;
   uint32_t running = 0;
-#pragma unroll
-  for (int c = 0; c < ME_TILE_ROWS / 64; ++c) {
-    const int local = c * 64 + lane;
+  for (int c = 0; c < tile_rows; c += 64) {
+    const int local = c + lane;
     const int64_t u = row0 + local;
-    const int32_t r = (u < n_tgt) ? tbl[k * n_tgt + u] : -1;
+    const int32_t r = (local < tile_rows && u < n_tgt) ? tbl[k * n_tgt + u] : -1;
     const unsigned long long m = __ballot(r >= 0);
     if (r >= 0) {
       const int64_t s = slot0 + running + mask_prefix(m);
@@ -374,12 +375,28 @@ __global__ __launch_bounds__(256) void k_plan_fill(const int32_t *__restrict__ t
   }
   const uint32_t groups = (running + ME_GROUP_ROWS - 1) / ME_GROUP_ROWS;
   const uint32_t padded = groups * ME_GROUP_ROWS;
-  // padding slots of the last group (fewer than 16) and the group -> offset table (<= 8 groups)
+  // padding slots of the last group (fewer than 16): no source row, dummy accumulator row
   if (running + lane < padded) {
     plan_src[slot0 + running + lane] = -1;
-    plan_dst[slot0 + running + lane] = -1;
+    plan_dst[slot0 + running + lane] = tile_rows;
   }
-  if ((uint32_t)lane < groups) group_k[g0 + lane] = (int32_t)k;
+  if (groups > 0) {
+    // next offset of this tile that has any group (for the weight prefetch), or -1
+    int32_t nk = -1;
+    for (int64_t base = k + 1; base < volume; base += 64) {
+      const int64_t kk = base + lane;
+      const bool has = kk < volume && gcount[t * volume + kk] > 0;
+      const unsigned long long m = __ballot(has);
+      if (m) {
+        nk = (int32_t)(base + __builtin_ctzll(m));
+        break;
+      }
+    }
+    for (uint32_t j = lane; j < groups; j += 64) {
+      group_k[g0 + j] = (int32_t)k;
+      group_nk[g0 + j] = nk;
+    }
+  }
   if (k == 0 && lane == 0) tile_gptr[t] = (int32_t)g0;
   if (item == 0 && lane == 0) tile_gptr[n_tiles] = (int32_t)(*gtotal);
 }
@@ -590,24 +607,27 @@ int me_kernel_map_transpose(const int32_t *in_pairs, const int32_t *out_pairs, c
   return 0;
 }
 
-int64_t me_plan_num_tiles(int64_t n_tgt) { return ceil_div(n_tgt, ME_TILE_ROWS); }
-int64_t me_plan_max_groups(int64_t n_tgt, int64_t volume, int64_t n_pairs) {
-  const int64_t items = me_plan_num_tiles(n_tgt) * volume;
+int64_t me_plan_num_tiles(int64_t n_tgt, int32_t tile_rows) {
+  return tile_rows > 0 ? ceil_div(n_tgt, tile_rows) : -1;
+}
+int64_t me_plan_max_groups(int64_t n_tgt, int64_t volume, int64_t n_pairs, int32_t tile_rows) {
+  const int64_t items = me_plan_num_tiles(n_tgt, tile_rows) * volume;
   const int64_t nonempty = items < n_pairs ? items : n_pairs;
   return n_pairs / ME_GROUP_ROWS + nonempty + 1;
 }
-int64_t me_plan_workspace_bytes(int64_t n_tgt, int64_t volume) {
-  const int64_t items = me_plan_num_tiles(n_tgt < 1 ? 1 : n_tgt) * volume;
-  return align_up(items * 4, 256) + 256 + scan_workspace_bytes(items);
+int64_t me_plan_workspace_bytes(int64_t n_tgt, int64_t volume, int32_t tile_rows) {
+  const int64_t items = me_plan_num_tiles(n_tgt < 1 ? 1 : n_tgt, tile_rows) * volume;
+  return 2 * align_up(items * 4, 256) + 256 + scan_workspace_bytes(items);
 }
 
-int me_plan_build(const int32_t *tbl, int64_t n_tgt, int64_t volume, int32_t *plan_src, int32_t *plan_dst,
-                  int32_t *group_k, int32_t *tile_gptr, void *workspace, int64_t workspace_bytes,
-                  void *stream_) {
+int me_plan_build(const int32_t *tbl, int64_t n_tgt, int64_t volume, int32_t tile_rows, int32_t *plan_src,
+                  int32_t *plan_dst, int32_t *group_k, int32_t *group_nk, int32_t *tile_gptr,
+                  void *workspace, int64_t workspace_bytes, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   ME_CHECK(volume >= 1 && volume <= 65535, "kernel volume out of range");
-  ME_CHECK(workspace_bytes >= me_plan_workspace_bytes(n_tgt, volume), "workspace too small");
-  const int64_t n_tiles = me_plan_num_tiles(n_tgt);
+  ME_CHECK(tile_rows >= ME_GROUP_ROWS && tile_rows <= ME_MAX_TILE_ROWS, "tile_rows out of range");
+  ME_CHECK(workspace_bytes >= me_plan_workspace_bytes(n_tgt, volume, tile_rows), "workspace too small");
+  const int64_t n_tiles = me_plan_num_tiles(n_tgt, tile_rows);
   if (n_tiles == 0) {
     ME_HIP(hipMemsetAsync(tile_gptr, 0, 4, stream));
     return 0;
@@ -615,16 +635,18 @@ int me_plan_build(const int32_t *tbl, int64_t n_tgt, int64_t volume, int32_t *pl
   const int64_t items = n_tiles * volume;
   ME_CHECK(items < (1ll << 31), "too many (tile, offset) items");
   char *ws = reinterpret_cast<char *>(workspace);
+  const int64_t asz = align_up(items * 4, 256);
   uint32_t *gcount = reinterpret_cast<uint32_t *>(ws);
-  uint32_t *gtotal = reinterpret_cast<uint32_t *>(ws + align_up(items * 4, 256));
-  void *scan_ws = ws + align_up(items * 4, 256) + 256;
+  uint32_t *goffs = reinterpret_cast<uint32_t *>(ws + asz);
+  uint32_t *gtotal = reinterpret_cast<uint32_t *>(ws + 2 * asz);
+  void *scan_ws = ws + 2 * asz + 256;
   const dim3 grid((unsigned)ceil_div(items, 4)), block(256);
-  hipLaunchKernelGGL(k_plan_count, grid, block, 0, stream, tbl, n_tgt, volume, items, gcount);
+  hipLaunchKernelGGL(k_plan_count, grid, block, 0, stream, tbl, n_tgt, volume, items, (int)tile_rows, gcount);
   ME_LAUNCH_CHECK();
-  if (int rc = exclusive_scan_u32(gcount, gcount, items, gtotal, scan_ws, scan_workspace_bytes(items), stream))
+  if (int rc = exclusive_scan_u32(gcount, goffs, items, gtotal, scan_ws, scan_workspace_bytes(items), stream))
     return rc;
-  hipLaunchKernelGGL(k_plan_fill, grid, block, 0, stream, tbl, n_tgt, volume, items, gcount, gtotal,
-                     plan_src, plan_dst, group_k, tile_gptr, n_tiles);
+  hipLaunchKernelGGL(k_plan_fill, grid, block, 0, stream, tbl, n_tgt, volume, items, (int)tile_rows, gcount,
+                     goffs, gtotal, plan_src, plan_dst, group_k, group_nk, tile_gptr, n_tiles);
   ME_LAUNCH_CHECK();
   return 0;
 }

@@ -39,7 +39,7 @@ def test_host_only_entry_points():
     lib = _lib.load()
     assert lib.me_hash_capacity(0) == 64
     assert lib.me_hash_capacity(100000) == 262144
-    assert lib.me_plan_num_tiles(257) == 3
+    assert lib.me_plan_num_tiles(257, 128) == 3 and lib.me_plan_num_tiles(257, 131) == 2
     rg = _lib.make_region(4, 0, [3, 3, 3], [1, 1, 1], [1, 1, 1])
     assert lib.me_region_volume(ctypes.byref(rg)) == 27
     rg = _lib.make_region(4, 1, [3, 3, 5], [1, 1, 1], [1, 1, 1])
@@ -49,3 +49,16 @@ def test_host_only_entry_points():
     koffs = (ctypes.c_int64 * 4)(0, 10, 10, 5000)
     # chunks: ceil(10/2048) + 0 + ceil(4990/2048) = 1 + 3
     assert lib.me_conv_wgrad_workspace_bytes(koffs, 3, 8, 16) == 4 * 8 * 16 * 4
+
+
+def test_choose_tile_rows_fills_the_chip():
+    """Host-only heuristic: tiles x slabs should sit just below a multiple of the resident slots."""
+    from minkowskiengine_amd import _lib
+    lib = _lib.load()
+    t = lib.me_conv_choose_tile_rows(100000, 27, 834914, 64, 128)
+    assert 16 <= t <= 256
+    items = -(-100000 // t) * 2
+    slots = 256 * 3
+    assert items % slots == 0 or items % slots > 0.9 * slots, (t, items)
+    for args in [(1, 27, 1, 4, 4), (4977, 27, 52353, 256, 256), (200000, 125, 889332, 3, 32), (400000, 81, 1837616, 32, 64)]:
+        assert 16 <= lib.me_conv_choose_tile_rows(*args) <= 256

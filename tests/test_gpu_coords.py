@@ -139,18 +139,18 @@ def test_kernel_map_pair_sets_identical(device, n, extent, D, ks, stride, dil, r
     assert mgr._kernel_map(key, okey, ksl, [stride] * D, [dil] * D, MEB.RegionType(region), None, False, False) is km
 
 
-@pytest.mark.parametrize("target", ["out", "in"])
-def test_tile_plan_covers_every_pair_once(device, target):
+@pytest.mark.parametrize("target,T", [("out", 128), ("in", 128), ("out", 131), ("in", 37), ("out", 16), ("out", 256)])
+def test_tile_plan_covers_every_pair_once(device, target, T):
     from minkowskiengine_amd import _lib
     coords = make_cloud(5000, 16, 3, seed=21, batch=2, negative=True)
     MEB, mgr = _mgr()
     key, _ = mgr.insert_and_map(coords.to(device), [1, 1, 1], "")
     okey = mgr.stride(key, [2, 2, 2])
     km = mgr._kernel_map(key, okey, [3, 3, 3], [2, 2, 2], [1, 1, 1], MEB.RegionType.HYPER_CUBE, None, False, False)
-    plan_src, plan_dst, group_k, tile_gptr = [t.cpu().numpy() for t in km.plan(target)]
+    plan_src, plan_dst, group_k, group_nk, tile_gptr = [t.cpu().numpy() for t in km.plan(target, T)]
     tbl = km.table(target).cpu().numpy()
     n_tgt = km.n_out if target == "out" else km.n_in
-    T, G = _lib.ME_TILE_ROWS, _lib.ME_GROUP_ROWS
+    G = _lib.ME_GROUP_ROWS
     n_tiles = (n_tgt + T - 1) // T
     assert tile_gptr[0] == 0 and np.all(np.diff(tile_gptr[:n_tiles + 1]) >= 0)
     seen = set()
@@ -159,10 +159,12 @@ def test_tile_plan_covers_every_pair_once(device, target):
         assert np.all(np.diff(ks) >= 0), "groups of a tile must be sorted by offset"
         for g in range(tile_gptr[t], tile_gptr[t + 1]):
             k = int(group_k[g])
+            later = ks[ks > k]
+            assert int(group_nk[g]) == (int(later[0]) if later.size else -1), "next-offset hint wrong"
             for j in range(G):
                 s, d = int(plan_src[g * G + j]), int(plan_dst[g * G + j])
                 if s < 0:
-                    assert d < 0
+                    assert d == T, "padding slots must point at the dummy row"
                     continue
                 row = t * T + d
                 assert 0 <= d < T and row < n_tgt and tbl[k, row] == s
