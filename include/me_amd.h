@@ -158,6 +158,9 @@ int me_conv_target_f32(const float *src_feat_dev, int64_t n_src, int32_t c_src, 
 int32_t me_conv_choose_tile_rows(int64_t n_tgt, int64_t volume, int64_t n_pairs, int32_t c_src,
                                  int32_t c_dst);
 
+/* Tuning / ablation switch for me_conv_target_f32 (0 = shipped configuration; see conv.hip). */
+void me_debug_set_conv_variant(int variant);
+
 /* wt[k, j, i] = w[k, i, j] */
 int me_transpose_kernel_f32(const float *w_dev, int64_t volume, int32_t c_in, int32_t c_out,
                             float *wt_dev, void *stream);

@@ -32,20 +32,32 @@ constexpr int kGB = 4;            // groups (of 16 gathered rows) per LDS batch
 constexpr int kRows = kGB * 16;   // gathered rows per batch
 constexpr int kLdsBudget = 160 * 1024;
 
+constexpr int kAccPad = 4;  // accumulator row stride NC + 4 floats: spreads the row-scattered adds over banks
+
 // LDS bytes of one workgroup of k_conv_target_f32<NC, KC> with `tile_rows` target rows
 // (accumulator tile + one dummy row for padding slots, gathered-row tile, plan slice)
 __host__ __device__ constexpr int conv_lds_bytes(int NC, int KC, int tile_rows) {
-  return (tile_rows + 1) * NC * 4 + kRows * (KC + 4) * 4 + kRows * 4 + 2 * kGB * 4 + 32;
+  return (tile_rows + 1) * (NC + kAccPad) * 4 + kRows * (KC + 4) * 4 + kRows * 4 + 2 * kGB * 4 + 32;
 }
 
 // =================================================================================================
 // target-stationary convolution (forward and dgrad)
 // =================================================================================================
 // R groups of one offset at once: R independent accumulators share every B register, which covers
-// the 40-cycle dependent-accumulator latency of v_mfma_f32_16x16x4_f32 (issue interval 32).
-template <int R, int KQ, int A_LD>
+// the 40-cycle dependent-accumulator latency of v_mfma_f32_16x16x4_f32 (issue interval 32).  The
+// 16x16 result blocks are then added into the LDS accumulator rows named by the plan: all reads
+// first, then all writes (rows of one offset are distinct, padding slots share a dummy row), so the
+// R*4 LDS round trips overlap instead of forming a chain.
+template <int R, int KQ, int A_LD, int ACC_LD>
 __device__ __forceinline__ void mma_groups(const float *__restrict__ a0p, const float (&breg)[KQ],
-                                           f32x4 (&acc)[4]) {
+                                           const int32_t *__restrict__ dstp, float *__restrict__ accp) {
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  i32x4 d[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) d[r] = *reinterpret_cast<const i32x4 *>(dstp + r * 16);
+  f32x4 acc[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int s4 = 0; s4 < KQ / 4; ++s4) {
     f32x4 a[R];
@@ -58,9 +70,23 @@ __device__ __forceinline__ void mma_groups(const float *__restrict__ a0p, const 
         acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][j], breg[s4 * 4 + j], acc[r], 0, 0, 0);
     }
   }
+  float old[R][4];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) old[r][i] = accp[d[r][i] * ACC_LD];
+#pragma unroll
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) accp[d[r][i] * ACC_LD] = old[r][i] + acc[r][i];
 }
 
-template <int NC, int KC>
+// VAR bits (tuning / ablation; 0 is the shipped configuration — measured best on MI355X, see
+// profiles/r01_tune_conv.log):
+//   1: prefetch W_k of the next offset one run ahead (costs 16 VGPRs -> spills at 3 waves/SIMD)
+//   2: runs of up to 4 groups instead of 2 (more accumulators in flight, more registers)
+//   4: plan indices fetched one batch ahead only (dependent index -> row load chain per batch)
+template <int NC, int KC, int VAR>
 __global__ __launch_bounds__(NC * 4, (NC == 32 && KC == 64) ? 2 : 3) void k_conv_target_f32(
     const float *__restrict__ src, int c_src, const float *__restrict__ w, int c_dst,
     const int32_t *__restrict__ plan_src, const int32_t *__restrict__ plan_dst,
@@ -69,15 +95,18 @@ __global__ __launch_bounds__(NC * 4, (NC == 32 && KC == 64) ? 2 : 3) void k_conv
   constexpr int WAVES = NC / 16;
   constexpr int NT = WAVES * 64;
   constexpr int A_LD = KC + 4;         // floats; +16 B per row spreads ds_read_b128 over the banks
+  constexpr int ACC_LD = NC + kAccPad;
   constexpr int KQ = KC / 4;           // MFMA k-steps per chunk (= B registers per lane)
   constexpr int F4_PER_ROW = KC / 4;   // 16-byte pieces per gathered row
   constexpr int ITER = kRows * F4_PER_ROW / NT;
+  constexpr int MAXRUN = (VAR & 2) ? 4 : 2;
   static_assert(kRows * F4_PER_ROW % NT == 0, "gather work must divide evenly");
   static_assert(KC % 16 == 0, "KC must be a multiple of 16");
+  static_assert(kGB == 4, "the batch metadata is read as one int4");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float *s_acc = reinterpret_cast<float *>(smem);              // [(tile_rows + 1) x NC]
-  float *s_a = s_acc + (tile_rows + 1) * NC;                   // [kRows x A_LD]
+  float *s_acc = reinterpret_cast<float *>(smem);              // [(tile_rows + 1) x ACC_LD]
+  float *s_a = s_acc + (tile_rows + 1) * ACC_LD;               // [kRows x A_LD]
   int32_t *s_dst = reinterpret_cast<int32_t *>(s_a + kRows * A_LD);  // [kRows]
   int32_t *s_k = s_dst + kRows;                                // [kGB]
   int32_t *s_nk = s_k + kGB;                                   // [kGB]
@@ -93,14 +122,18 @@ __global__ __launch_bounds__(NC * 4, (NC == 32 && KC == 64) ? 2 : 3) void k_conv
   const int g_begin = tile_gptr[tile];
   const int g_end = tile_gptr[tile + 1];
   const bool vec_ok = (c_src % 4) == 0;
-  const int acc_f4 = (tile_rows + 1) * NC / 4;
 
-  for (int x = tid; x < acc_f4; x += NT) reinterpret_cast<f32x4 *>(s_acc)[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int x = tid; x < (tile_rows + 1) * ACC_LD / 4; x += NT)
+    reinterpret_cast<f32x4 *>(s_acc)[x] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   for (int c0 = 0; c0 < c_src; c0 += KC) {
     float breg[KQ], bnext[KQ];
     int cur_k = -1;
+    // software pipeline registers: gathered rows of the NEXT batch, its plan slice, and the source
+    // row indices of the batch after that (so no load in the loop waits for another load)
     f32x4 stage[ITER];
+    int32_t sidx[ITER];
+    int32_t dst_r = tile_rows, k_r = -1, nk_r = -1;
 
     // this wave's 16-column slice of W_k for the source channels of this chunk (K-permuted: MFMA
     // k-step s of lane group q reads channel c0 + q*KQ + s, so a lane's A values are contiguous)
@@ -111,16 +144,28 @@ __global__ __launch_bounds__(NC * 4, (NC == 32 && KC == 64) ? 2 : 3) void k_conv
         b[s] = (kidx < c_src && col < c_dst) ? w[((int64_t)k * c_src + kidx) * c_dst + col] : 0.f;
       }
     };
-    // issue the gather loads of batch `gb` (global -> registers)
-    auto gather_issue = [&](int gb) {
-      const int ng = min(kGB, g_end - gb);
+    auto load_idx = [&](int gb) {
+      const int nrows = (gb < g_end) ? min(kGB, g_end - gb) * 16 : 0;
 #pragma unroll
       for (int it = 0; it < ITER; ++it) {
-        const int idx = it * NT + tid;
-        const int r = idx / F4_PER_ROW;
-        const int ch = c0 + (idx % F4_PER_ROW) * 4;
-        int s = -1;
-        if (r < ng * 16) s = plan_src[(int64_t)gb * 16 + r];
+        const int r = (it * NT + tid) / F4_PER_ROW;
+        sidx[it] = (r < nrows) ? plan_src[(int64_t)gb * 16 + r] : -1;
+      }
+    };
+    auto load_meta = [&](int gb) {
+      const int ng = min(kGB, g_end - gb);
+      if (tid < kRows) dst_r = (tid < ng * 16) ? plan_dst[(int64_t)gb * 16 + tid] : tile_rows;
+      if (tid < kGB) {
+        k_r = (tid < ng) ? group_k[gb + tid] : -1;
+        nk_r = (tid < ng) ? group_nk[gb + tid] : -1;
+      }
+    };
+    // issue the gather loads of the batch whose indices sit in sidx (global -> registers)
+    auto gather_issue = [&]() {
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) {
+        const int ch = c0 + ((it * NT + tid) % F4_PER_ROW) * 4;
+        const int s = sidx[it];
         f32x4 t = {0.f, 0.f, 0.f, 0.f};
         if (s >= 0 && ch < c_src) {
           const float *rowp = src + (int64_t)s * c_src + ch;
@@ -138,8 +183,11 @@ __global__ __launch_bounds__(NC * 4, (NC == 32 && KC == 64) ? 2 : 3) void k_conv
     };
 
     if (g_begin < g_end) {
-      load_b(group_k[g_begin], bnext);  // weights of the first offset fly under the first gather
-      gather_issue(g_begin);
+      load_idx(g_begin);
+      if (VAR & 1) load_b(group_k[g_begin], bnext);  // weights of the first offset
+      load_meta(g_begin);
+      gather_issue();
+      if (!(VAR & 4)) load_idx(g_begin + kGB);
     }
 
     for (int gb = g_begin; gb < g_end; gb += kGB) {
@@ -148,53 +196,57 @@ __global__ __launch_bounds__(NC * 4, (NC == 32 && KC == 64) ? 2 : 3) void k_conv
 #pragma unroll
       for (int it = 0; it < ITER; ++it) {
         const int idx = it * NT + tid;
-        const int r = idx / F4_PER_ROW;
-        const int p = idx % F4_PER_ROW;
-        *reinterpret_cast<f32x4 *>(&s_a[r * A_LD + p * 4]) = stage[it];
+        *reinterpret_cast<f32x4 *>(&s_a[(idx / F4_PER_ROW) * A_LD + (idx % F4_PER_ROW) * 4]) = stage[it];
       }
-      if (tid < kRows) s_dst[tid] = (tid < ng * 16) ? plan_dst[(int64_t)gb * 16 + tid] : tile_rows;
+      if (tid < kRows) s_dst[tid] = dst_r;
       if (tid < kGB) {
-        s_k[tid] = (tid < ng) ? group_k[gb + tid] : -1;
-        s_nk[tid] = (tid < ng) ? group_nk[gb + tid] : -1;
+        s_k[tid] = k_r;
+        s_nk[tid] = nk_r;
       }
       __syncthreads();
-      // next batch's loads fly while this batch is multiplied
-      if (gb + kGB < g_end) gather_issue(gb + kGB);
+      // the next batch's rows fly while this batch is multiplied; its indices were fetched a batch ago
+      if (gb + kGB < g_end) {
+        if (VAR & 4) load_idx(gb + kGB);
+        load_meta(gb + kGB);
+        gather_issue();
+        if (!(VAR & 4)) load_idx(gb + 2 * kGB);
+      }
+
+      typedef int i32x4 __attribute__((ext_vector_type(4)));
+      const i32x4 kv = *reinterpret_cast<const i32x4 *>(s_k);
+      const i32x4 nkv = *reinterpret_cast<const i32x4 *>(s_nk);
+      const int kk0 = __builtin_amdgcn_readfirstlane(kv.x), kk1 = __builtin_amdgcn_readfirstlane(kv.y);
+      const int kk2 = __builtin_amdgcn_readfirstlane(kv.z), kk3 = __builtin_amdgcn_readfirstlane(kv.w);
+      const int nk0 = __builtin_amdgcn_readfirstlane(nkv.x), nk1 = __builtin_amdgcn_readfirstlane(nkv.y);
+      const int nk2 = __builtin_amdgcn_readfirstlane(nkv.z), nk3 = __builtin_amdgcn_readfirstlane(nkv.w);
+      auto ksel = [&](int g) { return g == 0 ? kk0 : (g == 1 ? kk1 : (g == 2 ? kk2 : kk3)); };
+      auto nksel = [&](int g) { return g == 0 ? nk0 : (g == 1 ? nk1 : (g == 2 ? nk2 : nk3)); };
 
       int g = 0;
       while (g < ng) {
-        const int k0 = s_k[g];
+        const int k0 = ksel(g);
         int run = 1;
-        while (g + run < ng && s_k[g + run] == k0) ++run;
+        while (run < MAXRUN && g + run < ng && ksel(g + run) == k0) ++run;
         if (k0 != cur_k) {
           cur_k = k0;
+          if (!(VAR & 1)) {
+            load_b(k0, breg);
+          } else {
 #pragma unroll
-          for (int s = 0; s < KQ; ++s) breg[s] = bnext[s];
-          const int nk = s_nk[g];
-          if (nk >= 0) load_b(nk, bnext);  // prefetch the next offset's weights under this run
-        }
-        f32x4 acc[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const float *a0p = &s_a[(g * 16 + i16) * A_LD + q * KQ];
-        if (run == 4) mma_groups<4, KQ, A_LD>(a0p, breg, acc);
-        else if (run == 3) mma_groups<3, KQ, A_LD>(a0p, breg, acc);
-        else if (run == 2) mma_groups<2, KQ, A_LD>(a0p, breg, acc);
-        else mma_groups<1, KQ, A_LD>(a0p, breg, acc);
-        // D[row = q*4 + i][col = i16] -> accumulator rows named by the plan.  The columns are private
-        // to this wave and a wave's LDS operations retire in order, so ds_add_f32 (no return) gives a
-        // fixed summation order; padding slots land in the dummy row `tile_rows`.
-        float *accp = &s_acc[wave * 16 + i16];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (r < run) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const int d = s_dst[(g + r) * 16 + q * 4 + i];
-              __hip_atomic_fetch_add(accp + d * NC, acc[r][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
+            for (int s = 0; s < KQ; ++s) breg[s] = bnext[s];
+            const int nk = nksel(g);
+            if (nk >= 0) load_b(nk, bnext);  // prefetch the next offset's weights under this run
           }
         }
+        const float *a0p = &s_a[(g * 16 + i16) * A_LD + q * KQ];
+        const int32_t *dstp = &s_dst[g * 16 + q * 4];
+        // D[row = q*4 + i][col = i16]: columns are private to this wave -> plain LDS read-add-write
+        // in a fixed order (bitwise reproducible); padding slots land in the dummy row `tile_rows`.
+        float *accp = &s_acc[wave * 16 + i16];
+        if (MAXRUN > 2 && run == 4) mma_groups<4, KQ, A_LD, ACC_LD>(a0p, breg, dstp, accp);
+        else if (MAXRUN > 2 && run == 3) mma_groups<3, KQ, A_LD, ACC_LD>(a0p, breg, dstp, accp);
+        else if (run == 2) mma_groups<2, KQ, A_LD, ACC_LD>(a0p, breg, dstp, accp);
+        else mma_groups<1, KQ, A_LD, ACC_LD>(a0p, breg, dstp, accp);
         g += run;
       }
     }
@@ -207,9 +259,10 @@ __global__ __launch_bounds__(NC * 4, (NC == 32 && KC == 64) ? 2 : 3) void k_conv
   const bool vec_out = (c_dst % 4) == 0;
   for (int x = tid; x < tile_rows * NC / 4; x += NT) {
     const int row = x / (NC / 4);
-    const int cc = col_base + (x % (NC / 4)) * 4;
+    const int c4 = x % (NC / 4);
+    const int cc = col_base + c4 * 4;
     if (row < rows_here && cc < c_dst) {
-      const f32x4 v = reinterpret_cast<const f32x4 *>(s_acc)[x];
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(&s_acc[row * ACC_LD + c4 * 4]);
       float *o = dst + (row0 + row) * c_dst + cc;
       if (vec_out) {
         *reinterpret_cast<f32x4 *>(o) = v;
@@ -488,7 +541,9 @@ static int device_cu_count() {
   return cus;
 }
 
-template <int NC, int KC>
+int g_conv_variant = 0;  // me_debug_set_conv_variant
+
+template <int NC, int KC, int VAR>
 static int launch_conv_target(const float *src, int c_src, const float *w, int c_dst,
                               const int32_t *plan_src, const int32_t *plan_dst, const int32_t *group_k,
                               const int32_t *group_nk, const int32_t *tile_gptr, float *dst, int64_t n_tgt,
@@ -497,12 +552,12 @@ static int launch_conv_target(const float *src, int c_src, const float *w, int c
   ME_CHECK(lds <= kLdsBudget, "tile_rows too large for the LDS of one workgroup");
   static int max_lds_set = 0;  // per instantiation
   if (lds > 64 * 1024 && lds > max_lds_set) {
-    ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_target_f32<NC, KC>),
+    ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_target_f32<NC, KC, VAR>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
     max_lds_set = kLdsBudget;
   }
   const dim3 grid((unsigned)ceil_div(n_tgt, tile_rows), (unsigned)ceil_div(c_dst, NC));
-  hipLaunchKernelGGL((k_conv_target_f32<NC, KC>), grid, dim3(NC * 4), (size_t)lds, stream, src, c_src, w,
+  hipLaunchKernelGGL((k_conv_target_f32<NC, KC, VAR>), grid, dim3(NC * 4), (size_t)lds, stream, src, c_src, w,
                      c_dst, plan_src, plan_dst, group_k, group_nk, tile_gptr, dst, n_tgt, tile_rows);
   ME_LAUNCH_CHECK();
   return 0;
@@ -572,9 +627,20 @@ int me_conv_target_f32(const float *src, int64_t n_src, int32_t c_src, const flo
   ME_CHECK((uintptr_t)src % 16 == 0 && (uintptr_t)dst % 16 == 0, "feature pointers must be 16-byte aligned");
   if (n_tgt == 0) return 0;
   const ConvVariant v = conv_variant(c_src, c_dst);
-#define ME_CONV_CASE(NCV, KCV)                                                                    \
-  return launch_conv_target<NCV, KCV>(src, c_src, w, c_dst, plan_src, plan_dst, group_k, group_nk, \
-                                      tile_gptr, dst, n_tgt, tile_rows, stream)
+#define ME_CONV_ARGS src, c_src, w, c_dst, plan_src, plan_dst, group_k, group_nk, tile_gptr, dst, n_tgt, tile_rows, stream
+  if (g_conv_variant != 0 && v.nc == 64 && v.kc == 64) {  // ablation builds exist for the headline shape only
+    switch (g_conv_variant) {
+      case 1: return launch_conv_target<64, 64, 1>(ME_CONV_ARGS);
+      case 2: return launch_conv_target<64, 64, 2>(ME_CONV_ARGS);
+      case 3: return launch_conv_target<64, 64, 3>(ME_CONV_ARGS);
+      case 4: return launch_conv_target<64, 64, 4>(ME_CONV_ARGS);
+      case 5: return launch_conv_target<64, 64, 5>(ME_CONV_ARGS);
+      case 6: return launch_conv_target<64, 64, 6>(ME_CONV_ARGS);
+      case 7: return launch_conv_target<64, 64, 7>(ME_CONV_ARGS);
+      default: break;
+    }
+  }
+#define ME_CONV_CASE(NCV, KCV) return launch_conv_target<NCV, KCV, 0>(ME_CONV_ARGS)
   if (v.nc == 32) {
     if (v.kc == 64) ME_CONV_CASE(32, 64);
     if (v.kc == 32) ME_CONV_CASE(32, 32);
@@ -585,7 +651,10 @@ int me_conv_target_f32(const float *src, int64_t n_src, int32_t c_src, const flo
     ME_CONV_CASE(64, 16);
   }
 #undef ME_CONV_CASE
+#undef ME_CONV_ARGS
 }
+
+void me_debug_set_conv_variant(int variant) { g_conv_variant = variant; }
 
 int me_transpose_kernel_f32(const float *w, int64_t volume, int32_t c_in, int32_t c_out, float *wt,
                             void *stream_) {
