@@ -141,15 +141,25 @@ int me_plan_build(const int32_t *tbl_dev, int64_t n_tgt, int64_t volume, int32_t
 /* ---- convolution feature kernels (replace ConvolutionForwardKernelGPU / BackwardKernelGPU,
  *      src/convolution_kernel.cu:320-496, 553-757; CPU twins src/convolution_kernel.hpp:33-144) -- */
 
+/* Weights are handed to the convolution kernel PACKED: the register image of the MFMA operand
+ * (one 16-byte element per lane and k-step quad, zero-padded to the kernel's channel tiling; layout
+ * documented at k_pack_weights in csrc/conv.hip).  Pack once per call (~1 us for 0.9 MB):
+ *   transposed = 0: w is [volume, c_src, c_dst]                     (forward: w = kernel)
+ *   transposed = 1: w is [volume, c_dst, c_src], i.e. the FORWARD kernel when computing dgrad with
+ *                   c_src = Cout, c_dst = Cin (so no separate transpose pass is needed). */
+int64_t me_conv_packed_weight_elems(int64_t volume, int32_t c_src, int32_t c_dst); /* floats */
+int me_conv_pack_weights_f32(const float *w_dev, int64_t volume, int32_t c_src, int32_t c_dst,
+                             int32_t transposed, float *packed_dev, void *stream);
+
 /* Target-stationary gather -> LDS -> MFMA(fp32 16x16x4) -> LDS accumulate -> one coalesced store.
  *   dst[t, :] = sum over plan entries (k, s) of tile(t):  src[s, :] @ w[k]      (w[k]: [c_src, c_dst])
- * Forward: src = in_feat, w = kernel, plan from nbr.  dgrad: src = grad_out, w = kernel^T (per k),
- * plan from nbrT.  Every target row is written (rows without entries get zeros). */
-int me_conv_target_f32(const float *src_feat_dev, int64_t n_src, int32_t c_src, const float *w_dev,
-                       int64_t volume, int32_t c_dst, const int32_t *plan_src_dev,
-                       const int32_t *plan_dst_dev, const int32_t *group_k_dev,
-                       const int32_t *group_nk_dev, const int32_t *tile_gptr_dev,
-                       float *dst_feat_dev, int64_t n_tgt, int32_t tile_rows, void *stream);
+ * Forward: src = in_feat, packed kernel, plan from nbr.  dgrad: src = grad_out, kernel packed with
+ * transposed = 1, plan from nbrT.  Every target row is written (rows without entries get zeros). */
+int me_conv_target_f32(const float *src_feat_dev, int64_t n_src, int32_t c_src,
+                       const float *packed_w_dev, int64_t volume, int32_t c_dst,
+                       const int32_t *plan_src_dev, const int32_t *plan_dst_dev,
+                       const int32_t *group_k_dev, const int32_t *tile_gptr_dev, float *dst_feat_dev,
+                       int64_t n_tgt, int32_t tile_rows, void *stream);
 
 /* Tile height for a (target rows, channels) problem: the largest tile that still fits the LDS budget
  * of the chosen kernel variant while tiles x column slabs is just below a multiple of the GPU's

@@ -55,8 +55,10 @@ SIGNATURES = {
     "me_plan_workspace_bytes": (c_i64, [c_i64, c_i64, c_i32]),
     "me_plan_build": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64,
                                      c_vp]),
+    "me_conv_packed_weight_elems": (c_i64, [c_i64, c_i32, c_i32]),
+    "me_conv_pack_weights_f32": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "me_conv_target_f32": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp,
-                                          c_vp, c_vp, c_i64, c_i32, c_vp]),
+                                          c_vp, c_i64, c_i32, c_vp]),
     "me_conv_choose_tile_rows": (c_i32, [c_i64, c_i64, c_i64, c_i32, c_i32]),
     "me_debug_set_conv_variant": (None, [ctypes.c_int]),
     "me_transpose_kernel_f32": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),

@@ -522,21 +522,26 @@ def _timed(name, device, launch):
     return r
 
 
-def _conv_target(src_feat, weights, km, target, n_tgt, name="conv_target"):
-    """dst[t] = sum over plan entries of src[s] @ weights[k]   (weights: [K, c_src, c_dst])."""
+def _conv_target(src_feat, kernel, km, target, n_tgt, name="conv_target", transposed=False):
+    """dst[t] = sum over plan entries of src[s] @ W[k].
+    transposed=False: W[k] = kernel[k] ([c_src, c_dst]);  transposed=True (dgrad): W[k] = kernel[k]^T."""
     lib = _lib.load()
     dev = src_feat.device
-    c_src, c_dst = int(weights.shape[1]), int(weights.shape[2])
+    volume = int(kernel.shape[0])
+    c_src, c_dst = (int(kernel.shape[2]), int(kernel.shape[1])) if transposed else \
+        (int(kernel.shape[1]), int(kernel.shape[2]))
     out = torch.empty((n_tgt, c_dst), dtype=torch.float32, device=dev)
     if n_tgt == 0:
         return out
     tile_rows = _TILE_ROWS or int(lib.me_conv_choose_tile_rows(n_tgt, km.volume, km.n_pairs, c_src, c_dst))
     plan_src, plan_dst, group_k, group_nk, tile_gptr = km.plan(target, tile_rows)
+    packed = torch.empty(int(lib.me_conv_packed_weight_elems(volume, c_src, c_dst)), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
+        _lib.check(lib.me_conv_pack_weights_f32(_ptr(kernel), volume, c_src, c_dst, 1 if transposed else 0,
+                                                _ptr(packed), _stream(dev)))
         _timed(name, dev, lambda: _lib.check(lib.me_conv_target_f32(
-            _ptr(src_feat), src_feat.shape[0], c_src, _ptr(weights), km.volume, c_dst, _ptr(plan_src),
-            _ptr(plan_dst), _ptr(group_k), _ptr(group_nk), _ptr(tile_gptr), _ptr(out), n_tgt, tile_rows,
-            _stream(dev))))
+            _ptr(src_feat), src_feat.shape[0], c_src, _ptr(packed), km.volume, c_dst, _ptr(plan_src),
+            _ptr(plan_dst), _ptr(group_k), _ptr(tile_gptr), _ptr(out), n_tgt, tile_rows, _stream(dev))))
     return out
 
 
@@ -568,11 +573,8 @@ def _conv_backward(in_feat, grad_out, kernel, km, algo=None):
                                                       km.volume, km.n_pairs, _ptr(grad_in), _ptr(grad_w),
                                                       _stream(dev)))
         return grad_in, grad_w
-    # dgrad: the same target-stationary kernel with the per-offset transposed weights
-    wt = torch.empty((volume, c_out, c_in), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
-        _lib.check(lib.me_transpose_kernel_f32(_ptr(kernel), volume, c_in, c_out, _ptr(wt), _stream(dev)))
-    grad_in = _conv_target(grad_out, wt, km, "in", km.n_in, name="conv_dgrad")
+    # dgrad: the same target-stationary kernel; the weights are packed transposed per offset
+    grad_in = _conv_target(grad_out, kernel, km, "in", km.n_in, name="conv_dgrad", transposed=True)
     # wgrad
     grad_w = torch.empty_like(kernel)
     koffs = (ctypes.c_int64 * (volume + 1))(*km.k_offsets)

@@ -37,24 +37,25 @@ constexpr int kAccPad = 4;  // accumulator row stride NC + 4 floats: spreads the
 // LDS bytes of one workgroup of k_conv_target_f32<NC, KC> with `tile_rows` target rows
 // (accumulator tile + one dummy row for padding slots, gathered-row tile, plan slice)
 __host__ __device__ constexpr int conv_lds_bytes(int NC, int KC, int tile_rows) {
-  return (tile_rows + 1) * (NC + kAccPad) * 4 + kRows * (KC + 4) * 4 + kRows * 4 + 2 * kGB * 4 + 32;
+  return (tile_rows + 1) * (NC + kAccPad) * 4 + kRows * (KC + 4) * 4 + kRows * 4 + kGB * 4 + 32;
 }
 
 // =================================================================================================
 // target-stationary convolution (forward and dgrad)
 // =================================================================================================
-// R groups of one offset at once: R independent accumulators share every B register, which covers
-// the 40-cycle dependent-accumulator latency of v_mfma_f32_16x16x4_f32 (issue interval 32).  The
-// 16x16 result blocks are then added into the LDS accumulator rows named by the plan: all reads
-// first, then all writes (rows of one offset are distinct, padding slots share a dummy row), so the
-// R*4 LDS round trips overlap instead of forming a chain.
+// R groups of one offset at once: R independent accumulators share every weight register, which
+// covers the 40-cycle dependent-accumulator latency of v_mfma_f32_16x16x4_f32 (issue interval 32).
+// The MFMA is issued "transposed" — A operand = weights (M = 16 output columns), B operand = gathered
+// rows (N = 16 rows) — so a lane ends up with 4 CONSECUTIVE output columns of ONE target row and the
+// accumulate into LDS is one 16-byte read + one 16-byte write per group.  All reads first, then all
+// writes (rows of one offset are distinct, padding slots share a dummy row), so the R LDS round
+// trips overlap instead of forming a chain.
 template <int R, int KQ, int A_LD, int ACC_LD>
-__device__ __forceinline__ void mma_groups(const float *__restrict__ a0p, const float (&breg)[KQ],
+__device__ __forceinline__ void mma_groups(const float *__restrict__ a0p, const float (&wreg)[KQ],
                                            const int32_t *__restrict__ dstp, float *__restrict__ accp) {
-  typedef int i32x4 __attribute__((ext_vector_type(4)));
-  i32x4 d[R];
+  int d[R];
 #pragma unroll
-  for (int r = 0; r < R; ++r) d[r] = *reinterpret_cast<const i32x4 *>(dstp + r * 16);
+  for (int r = 0; r < R; ++r) d[r] = dstp[r * 16];
   f32x4 acc[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -67,36 +68,68 @@ __device__ __forceinline__ void mma_groups(const float *__restrict__ a0p, const 
     for (int j = 0; j < 4; ++j) {
 #pragma unroll
       for (int r = 0; r < R; ++r)
-        acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][j], breg[s4 * 4 + j], acc[r], 0, 0, 0);
+        acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s4 * 4 + j], a[r][j], acc[r], 0, 0, 0);
     }
   }
-  float old[R][4];
+  f32x4 old[R];
 #pragma unroll
-  for (int r = 0; r < R; ++r)
+  for (int r = 0; r < R; ++r) old[r] = *reinterpret_cast<const f32x4 *>(accp + d[r] * ACC_LD);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) old[r][i] = accp[d[r][i] * ACC_LD];
-#pragma unroll
-  for (int r = 0; r < R; ++r)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) accp[d[r][i] * ACC_LD] = old[r][i] + acc[r][i];
+  for (int r = 0; r < R; ++r) *reinterpret_cast<f32x4 *>(accp + d[r] * ACC_LD) = old[r] + acc[r];
 }
 
-// VAR bits (tuning / ablation; 0 is the shipped configuration — measured best on MI355X, see
-// profiles/r01_tune_conv.log):
-//   1: prefetch W_k of the next offset one run ahead (costs 16 VGPRs -> spills at 3 waves/SIMD)
+// Packed weights: the exact register image of the kernel.  For offset k, source-channel chunk c,
+// 16-column block cb and k-step quad v, lane (q = lane >> 4, i16 = lane & 15) finds its four weights
+//   W[k][c*KC + q*KQ + v*4 + j][cb*16 + i16],  j = 0..3
+// as ONE 16-byte element at  ((((k*nchunks + c)*ncb + cb)*(KQ/4) + v)*64 + lane)  — zero beyond the
+// real channel counts, so the kernel needs no guards and a wave reads 1 KiB contiguous per load.
+template <int KC>
+__global__ __launch_bounds__(256) void k_pack_weights(const float *__restrict__ w, int c_src, int c_dst,
+                                                     int transposed, int nchunks, int ncb,
+                                                     f32x4 *__restrict__ wp, int64_t total) {
+  constexpr int KQ = KC / 4;
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int lane = (int)(e % 64);
+  int64_t r = e / 64;
+  const int v = (int)(r % (KQ / 4));
+  r /= (KQ / 4);
+  const int cb = (int)(r % ncb);
+  r /= ncb;
+  const int c = (int)(r % nchunks);
+  const int64_t k = r / nchunks;
+  const int q = lane >> 4, i16 = lane & 15;
+  const int col = cb * 16 + i16;
+  f32x4 out;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ch = c * KC + q * KQ + v * 4 + j;
+    float val = 0.f;
+    if (ch < c_src && col < c_dst) {
+      // plain: w is [K, c_src, c_dst]; transposed (dgrad): w is the forward kernel [K, c_dst, c_src]
+      val = transposed ? w[(k * c_dst + col) * c_src + ch] : w[(k * c_src + ch) * c_dst + col];
+    }
+    out[j] = val;
+  }
+  wp[e] = out;
+}
+
+// VAR bits (tuning / ablation; 0 is the shipped configuration):
 //   2: runs of up to 4 groups instead of 2 (more accumulators in flight, more registers)
 //   4: plan indices fetched one batch ahead only (dependent index -> row load chain per batch)
-template <int NC, int KC, int VAR>
-__global__ __launch_bounds__(NC * 4, (NC == 32 && KC == 64) ? 2 : 3) void k_conv_target_f32(
-    const float *__restrict__ src, int c_src, const float *__restrict__ w, int c_dst,
+// EXACT: c_src is a multiple of KC (and of 4): the gather needs no channel guards.
+template <int NC, int KC, int VAR, bool EXACT>
+__global__ __launch_bounds__(NC * 4, 3) void k_conv_target_f32(
+    const float *__restrict__ src, int c_src, const f32x4 *__restrict__ wp, int c_dst,
     const int32_t *__restrict__ plan_src, const int32_t *__restrict__ plan_dst,
-    const int32_t *__restrict__ group_k, const int32_t *__restrict__ group_nk,
-    const int32_t *__restrict__ tile_gptr, float *__restrict__ dst, int64_t n_tgt, int tile_rows) {
+    const int32_t *__restrict__ group_k, const int32_t *__restrict__ tile_gptr,
+    float *__restrict__ dst, int64_t n_tgt, int tile_rows) {
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
   constexpr int WAVES = NC / 16;
   constexpr int NT = WAVES * 64;
   constexpr int A_LD = KC + 4;         // floats; +16 B per row spreads ds_read_b128 over the banks
   constexpr int ACC_LD = NC + kAccPad;
-  constexpr int KQ = KC / 4;           // MFMA k-steps per chunk (= B registers per lane)
+  constexpr int KQ = KC / 4;           // MFMA k-steps per chunk (= weight registers per lane)
   constexpr int F4_PER_ROW = KC / 4;   // 16-byte pieces per gathered row
   constexpr int ITER = kRows * F4_PER_ROW / NT;
   constexpr int MAXRUN = (VAR & 2) ? 4 : 2;
@@ -109,39 +142,47 @@ __global__ __launch_bounds__(NC * 4, (NC == 32 && KC == 64) ? 2 : 3) void k_conv
   float *s_a = s_acc + (tile_rows + 1) * ACC_LD;               // [kRows x A_LD]
   int32_t *s_dst = reinterpret_cast<int32_t *>(s_a + kRows * A_LD);  // [kRows]
   int32_t *s_k = s_dst + kRows;                                // [kGB]
-  int32_t *s_nk = s_k + kGB;                                   // [kGB]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const int i16 = lane & 15;  // MFMA row (A) / column (B, D) index of this lane
-  const int q = lane >> 4;    // MFMA k index (A, B) / row block (D) of this lane
+  const int i16 = lane & 15;  // gathered row (MFMA B column) / weight column (MFMA A row) of this lane
+  const int q = lane >> 4;    // MFMA k index of this lane; after the MFMA: output columns q*4 .. q*4+3
   const int tile = blockIdx.x;
   const int col_base = blockIdx.y * NC;
-  const int col = col_base + wave * 16 + i16;
   const int g_begin = tile_gptr[tile];
   const int g_end = tile_gptr[tile + 1];
   const bool vec_ok = (c_src % 4) == 0;
+  const int nchunks = (c_src + KC - 1) / KC;
+  const int ncb = (c_dst + 15) / 16;
+  const int cb = col_base / 16 + wave;   // this wave's 16-column block (may lie beyond c_dst: zeros)
 
   for (int x = tid; x < (tile_rows + 1) * ACC_LD / 4; x += NT)
     reinterpret_cast<f32x4 *>(s_acc)[x] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int c0 = 0; c0 < c_src; c0 += KC) {
-    float breg[KQ], bnext[KQ];
+  for (int c0 = 0, chunk = 0; c0 < c_src; c0 += KC, ++chunk) {
+    float wreg[KQ];
     int cur_k = -1;
     // software pipeline registers: gathered rows of the NEXT batch, its plan slice, and the source
     // row indices of the batch after that (so no load in the loop waits for another load)
     f32x4 stage[ITER];
     int32_t sidx[ITER];
-    int32_t dst_r = tile_rows, k_r = -1, nk_r = -1;
+    int32_t dst_r = tile_rows, k_r = -1;
 
-    // this wave's 16-column slice of W_k for the source channels of this chunk (K-permuted: MFMA
-    // k-step s of lane group q reads channel c0 + q*KQ + s, so a lane's A values are contiguous)
-    auto load_b = [&](int k, float (&b)[KQ]) {
+    auto load_w = [&](int k) {
+      if (cb < ncb) {
+        const f32x4 *p = wp + ((((int64_t)k * nchunks + chunk) * ncb + cb) * (KQ / 4)) * 64 + lane;
 #pragma unroll
-      for (int s = 0; s < KQ; ++s) {
-        const int kidx = c0 + q * KQ + s;
-        b[s] = (kidx < c_src && col < c_dst) ? w[((int64_t)k * c_src + kidx) * c_dst + col] : 0.f;
+        for (int v = 0; v < KQ / 4; ++v) {
+          const f32x4 t = p[v * 64];
+          wreg[v * 4 + 0] = t.x;
+          wreg[v * 4 + 1] = t.y;
+          wreg[v * 4 + 2] = t.z;
+          wreg[v * 4 + 3] = t.w;
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < KQ; ++s) wreg[s] = 0.f;
       }
     };
     auto load_idx = [&](int gb) {
@@ -155,10 +196,7 @@ __global__ __launch_bounds__(NC * 4, (NC == 32 && KC == 64) ? 2 : 3) void k_conv
     auto load_meta = [&](int gb) {
       const int ng = min(kGB, g_end - gb);
       if (tid < kRows) dst_r = (tid < ng * 16) ? plan_dst[(int64_t)gb * 16 + tid] : tile_rows;
-      if (tid < kGB) {
-        k_r = (tid < ng) ? group_k[gb + tid] : -1;
-        nk_r = (tid < ng) ? group_nk[gb + tid] : -1;
-      }
+      if (tid < kGB) k_r = (tid < ng) ? group_k[gb + tid] : -1;
     };
     // issue the gather loads of the batch whose indices sit in sidx (global -> registers)
     auto gather_issue = [&]() {
@@ -167,7 +205,11 @@ __global__ __launch_bounds__(NC * 4, (NC == 32 && KC == 64) ? 2 : 3) void k_conv
         const int ch = c0 + ((it * NT + tid) % F4_PER_ROW) * 4;
         const int s = sidx[it];
         f32x4 t = {0.f, 0.f, 0.f, 0.f};
-        if (s >= 0 && ch < c_src) {
+        if (EXACT) {
+          // unconditional 16-byte load (padding slots read row 0 and are zeroed by a select)
+          const f32x4 ld = *reinterpret_cast<const f32x4 *>(src + (int64_t)max(s, 0) * c_src + ch);
+          t = (s >= 0) ? ld : t;
+        } else if (s >= 0 && ch < c_src) {
           const float *rowp = src + (int64_t)s * c_src + ch;
           if (vec_ok) {
             t = *reinterpret_cast<const f32x4 *>(rowp);
@@ -184,7 +226,6 @@ __global__ __launch_bounds__(NC * 4, (NC == 32 && KC == 64) ? 2 : 3) void k_conv
 
     if (g_begin < g_end) {
       load_idx(g_begin);
-      if (VAR & 1) load_b(group_k[g_begin], bnext);  // weights of the first offset
       load_meta(g_begin);
       gather_issue();
       if (!(VAR & 4)) load_idx(g_begin + kGB);
@@ -199,10 +240,7 @@ __global__ __launch_bounds__(NC * 4, (NC == 32 && KC == 64) ? 2 : 3) void k_conv
         *reinterpret_cast<f32x4 *>(&s_a[(idx / F4_PER_ROW) * A_LD + (idx % F4_PER_ROW) * 4]) = stage[it];
       }
       if (tid < kRows) s_dst[tid] = dst_r;
-      if (tid < kGB) {
-        s_k[tid] = k_r;
-        s_nk[tid] = nk_r;
-      }
+      if (tid < kGB) s_k[tid] = k_r;
       __syncthreads();
       // the next batch's rows fly while this batch is multiplied; its indices were fetched a batch ago
       if (gb + kGB < g_end) {
@@ -212,15 +250,10 @@ __global__ __launch_bounds__(NC * 4, (NC == 32 && KC == 64) ? 2 : 3) void k_conv
         if (!(VAR & 4)) load_idx(gb + 2 * kGB);
       }
 
-      typedef int i32x4 __attribute__((ext_vector_type(4)));
       const i32x4 kv = *reinterpret_cast<const i32x4 *>(s_k);
-      const i32x4 nkv = *reinterpret_cast<const i32x4 *>(s_nk);
       const int kk0 = __builtin_amdgcn_readfirstlane(kv.x), kk1 = __builtin_amdgcn_readfirstlane(kv.y);
       const int kk2 = __builtin_amdgcn_readfirstlane(kv.z), kk3 = __builtin_amdgcn_readfirstlane(kv.w);
-      const int nk0 = __builtin_amdgcn_readfirstlane(nkv.x), nk1 = __builtin_amdgcn_readfirstlane(nkv.y);
-      const int nk2 = __builtin_amdgcn_readfirstlane(nkv.z), nk3 = __builtin_amdgcn_readfirstlane(nkv.w);
       auto ksel = [&](int g) { return g == 0 ? kk0 : (g == 1 ? kk1 : (g == 2 ? kk2 : kk3)); };
-      auto nksel = [&](int g) { return g == 0 ? nk0 : (g == 1 ? nk1 : (g == 2 ? nk2 : nk3)); };
 
       int g = 0;
       while (g < ng) {
@@ -229,24 +262,18 @@ __global__ __launch_bounds__(NC * 4, (NC == 32 && KC == 64) ? 2 : 3) void k_conv
         while (run < MAXRUN && g + run < ng && ksel(g + run) == k0) ++run;
         if (k0 != cur_k) {
           cur_k = k0;
-          if (!(VAR & 1)) {
-            load_b(k0, breg);
-          } else {
-#pragma unroll
-            for (int s = 0; s < KQ; ++s) breg[s] = bnext[s];
-            const int nk = nksel(g);
-            if (nk >= 0) load_b(nk, bnext);  // prefetch the next offset's weights under this run
-          }
+          load_w(k0);
         }
         const float *a0p = &s_a[(g * 16 + i16) * A_LD + q * KQ];
-        const int32_t *dstp = &s_dst[g * 16 + q * 4];
-        // D[row = q*4 + i][col = i16]: columns are private to this wave -> plain LDS read-add-write
-        // in a fixed order (bitwise reproducible); padding slots land in the dummy row `tile_rows`.
-        float *accp = &s_acc[wave * 16 + i16];
-        if (MAXRUN > 2 && run == 4) mma_groups<4, KQ, A_LD, ACC_LD>(a0p, breg, dstp, accp);
-        else if (MAXRUN > 2 && run == 3) mma_groups<3, KQ, A_LD, ACC_LD>(a0p, breg, dstp, accp);
-        else if (run == 2) mma_groups<2, KQ, A_LD, ACC_LD>(a0p, breg, dstp, accp);
-        else mma_groups<1, KQ, A_LD, ACC_LD>(a0p, breg, dstp, accp);
+        const int32_t *dstp = &s_dst[g * 16 + i16];
+        // after the MFMA this lane holds columns wave*16 + q*4 .. +3 of target row s_dst[g*16 + i16];
+        // columns are private to this wave -> plain LDS read-add-write in a fixed order (bitwise
+        // reproducible); padding slots land in the dummy row `tile_rows`.
+        float *accp = &s_acc[wave * 16 + q * 4];
+        if (MAXRUN > 2 && run == 4) mma_groups<4, KQ, A_LD, ACC_LD>(a0p, wreg, dstp, accp);
+        else if (MAXRUN > 2 && run == 3) mma_groups<3, KQ, A_LD, ACC_LD>(a0p, wreg, dstp, accp);
+        else if (run == 2) mma_groups<2, KQ, A_LD, ACC_LD>(a0p, wreg, dstp, accp);
+        else mma_groups<1, KQ, A_LD, ACC_LD>(a0p, wreg, dstp, accp);
         g += run;
       }
     }
@@ -544,21 +571,28 @@ static int device_cu_count() {
 int g_conv_variant = 0;  // me_debug_set_conv_variant
 
 template <int NC, int KC, int VAR>
-static int launch_conv_target(const float *src, int c_src, const float *w, int c_dst,
+static int launch_conv_target(const float *src, int c_src, const float *wp, int c_dst,
                               const int32_t *plan_src, const int32_t *plan_dst, const int32_t *group_k,
-                              const int32_t *group_nk, const int32_t *tile_gptr, float *dst, int64_t n_tgt,
-                              int tile_rows, hipStream_t stream) {
+                              const int32_t *tile_gptr, float *dst, int64_t n_tgt, int tile_rows,
+                              hipStream_t stream) {
   const int lds = conv_lds_bytes(NC, KC, tile_rows);
   ME_CHECK(lds <= kLdsBudget, "tile_rows too large for the LDS of one workgroup");
-  static int max_lds_set = 0;  // per instantiation
-  if (lds > 64 * 1024 && lds > max_lds_set) {
-    ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_target_f32<NC, KC, VAR>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
-    max_lds_set = kLdsBudget;
+  const bool exact = (c_src % KC) == 0;
+  static int max_lds_set[2] = {0, 0};  // per instantiation
+  if (lds > 64 * 1024 && lds > max_lds_set[exact]) {
+    const void *fn = exact ? reinterpret_cast<const void *>(&k_conv_target_f32<NC, KC, VAR, true>)
+                           : reinterpret_cast<const void *>(&k_conv_target_f32<NC, KC, VAR, false>);
+    ME_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
+    max_lds_set[exact] = kLdsBudget;
   }
   const dim3 grid((unsigned)ceil_div(n_tgt, tile_rows), (unsigned)ceil_div(c_dst, NC));
-  hipLaunchKernelGGL((k_conv_target_f32<NC, KC, VAR>), grid, dim3(NC * 4), (size_t)lds, stream, src, c_src, w,
-                     c_dst, plan_src, plan_dst, group_k, group_nk, tile_gptr, dst, n_tgt, tile_rows);
+  const f32x4 *wp4 = reinterpret_cast<const f32x4 *>(wp);
+  if (exact)
+    hipLaunchKernelGGL((k_conv_target_f32<NC, KC, VAR, true>), grid, dim3(NC * 4), (size_t)lds, stream, src,
+                       c_src, wp4, c_dst, plan_src, plan_dst, group_k, tile_gptr, dst, n_tgt, tile_rows);
+  else
+    hipLaunchKernelGGL((k_conv_target_f32<NC, KC, VAR, false>), grid, dim3(NC * 4), (size_t)lds, stream, src,
+                       c_src, wp4, c_dst, plan_src, plan_dst, group_k, tile_gptr, dst, n_tgt, tile_rows);
   ME_LAUNCH_CHECK();
   return 0;
 }
@@ -582,8 +616,9 @@ int32_t me_conv_choose_tile_rows(int64_t n_tgt, int64_t volume, int64_t n_pairs,
   const int waves = v.nc / 16;
   const int64_t slabs = ceil_div(c_dst, v.nc);
   const int chunks = (int)ceil_div(c_src, v.kc);
-  // resident workgroups per CU: 3 waves per SIMD by registers, then whatever the LDS allows
-  const int occ_regs = 12 / waves;
+  // resident workgroups per CU: 4 waves per SIMD by registers (3 for the <32,64> variant), then
+  // whatever the LDS allows
+  const int occ_regs = ((v.nc == 32 && v.kc == 64) ? 12 : 16) / waves;
   const int cus = device_cu_count();
   // occupancy p of a neighbour offset (centre excluded) -> expected 16-row groups of a (tile, k)
   const double p = volume > 1 ? (double)(n_pairs > n_tgt ? n_pairs - n_tgt : 0) / ((double)(volume - 1) * n_tgt)
@@ -615,28 +650,51 @@ int32_t me_conv_choose_tile_rows(int64_t n_tgt, int64_t volume, int64_t n_pairs,
   return best_t > 0 ? best_t : 128;
 }
 
-int me_conv_target_f32(const float *src, int64_t n_src, int32_t c_src, const float *w, int64_t volume,
+int64_t me_conv_packed_weight_elems(int64_t volume, int32_t c_src, int32_t c_dst) {
+  if (volume <= 0 || c_src <= 0 || c_dst <= 0) return 0;
+  const ConvVariant v = conv_variant(c_src, c_dst);
+  return volume * align_up(c_src, v.kc) * align_up(c_dst, 16);
+}
+
+int me_conv_pack_weights_f32(const float *w, int64_t volume, int32_t c_src, int32_t c_dst, int32_t transposed,
+                             float *wp, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ME_CHECK(volume >= 1 && c_src > 0 && c_dst > 0, "invalid weight shape");
+  ME_CHECK((uintptr_t)wp % 16 == 0, "packed weights must be 16-byte aligned");
+  const ConvVariant v = conv_variant(c_src, c_dst);
+  const int nchunks = (int)ceil_div(c_src, v.kc), ncb = (int)ceil_div(c_dst, 16);
+  const int64_t total = volume * nchunks * ncb * (v.kc / 16) * 64;  // 16-byte elements
+  f32x4 *wp4 = reinterpret_cast<f32x4 *>(wp);
+  const dim3 grid((unsigned)ceil_div(total, 256)), block(256);
+  if (v.kc == 64)
+    hipLaunchKernelGGL(k_pack_weights<64>, grid, block, 0, stream, w, c_src, c_dst, transposed, nchunks, ncb, wp4, total);
+  else if (v.kc == 32)
+    hipLaunchKernelGGL(k_pack_weights<32>, grid, block, 0, stream, w, c_src, c_dst, transposed, nchunks, ncb, wp4, total);
+  else
+    hipLaunchKernelGGL(k_pack_weights<16>, grid, block, 0, stream, w, c_src, c_dst, transposed, nchunks, ncb, wp4, total);
+  ME_LAUNCH_CHECK();
+  return 0;
+}
+
+int me_conv_target_f32(const float *src, int64_t n_src, int32_t c_src, const float *wp, int64_t volume,
                        int32_t c_dst, const int32_t *plan_src, const int32_t *plan_dst,
-                       const int32_t *group_k, const int32_t *group_nk, const int32_t *tile_gptr, float *dst,
-                       int64_t n_tgt, int32_t tile_rows, void *stream_) {
+                       const int32_t *group_k, const int32_t *tile_gptr, float *dst, int64_t n_tgt,
+                       int32_t tile_rows, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   (void)n_src;
   (void)volume;
   ME_CHECK(c_src > 0 && c_dst > 0, "channel counts must be positive");
   ME_CHECK(tile_rows >= ME_GROUP_ROWS && tile_rows <= ME_MAX_TILE_ROWS, "tile_rows out of range");
-  ME_CHECK((uintptr_t)src % 16 == 0 && (uintptr_t)dst % 16 == 0, "feature pointers must be 16-byte aligned");
+  ME_CHECK((uintptr_t)src % 16 == 0 && (uintptr_t)dst % 16 == 0 && (uintptr_t)wp % 16 == 0,
+           "feature and weight pointers must be 16-byte aligned");
   if (n_tgt == 0) return 0;
   const ConvVariant v = conv_variant(c_src, c_dst);
-#define ME_CONV_ARGS src, c_src, w, c_dst, plan_src, plan_dst, group_k, group_nk, tile_gptr, dst, n_tgt, tile_rows, stream
+#define ME_CONV_ARGS src, c_src, wp, c_dst, plan_src, plan_dst, group_k, tile_gptr, dst, n_tgt, tile_rows, stream
   if (g_conv_variant != 0 && v.nc == 64 && v.kc == 64) {  // ablation builds exist for the headline shape only
     switch (g_conv_variant) {
-      case 1: return launch_conv_target<64, 64, 1>(ME_CONV_ARGS);
       case 2: return launch_conv_target<64, 64, 2>(ME_CONV_ARGS);
-      case 3: return launch_conv_target<64, 64, 3>(ME_CONV_ARGS);
       case 4: return launch_conv_target<64, 64, 4>(ME_CONV_ARGS);
-      case 5: return launch_conv_target<64, 64, 5>(ME_CONV_ARGS);
       case 6: return launch_conv_target<64, 64, 6>(ME_CONV_ARGS);
-      case 7: return launch_conv_target<64, 64, 7>(ME_CONV_ARGS);
       default: break;
     }
   }

@@ -11,6 +11,8 @@ from minkowskiengine_amd import backend as MEB, _lib
 from bench import make_scene
 
 dev = torch.device("cuda:0")
+VARIANTS = [int(v) for v in os.environ.get("VARIANTS", "0,16").split(",")]
+TILES = [int(v) for v in os.environ.get("TILES", "64,96,112,128,131,160,196,256").split(",")]
 lib = _lib.load()
 
 
@@ -35,14 +37,13 @@ for extent in (70, 215):
     x = torch.rand(100000, 64, device=dev)
     w = torch.rand(27, 64, 128, device=dev) - 0.5
     gy = torch.rand(100000, 128, device=dev)
-    wt = w.transpose(1, 2).contiguous()
     flops = 2.0 * km.n_pairs * 64 * 128
     print(f"== extent {extent}: pairs {km.n_pairs}, auto T fwd {lib.me_conv_choose_tile_rows(100000, 27, km.n_pairs, 64, 128)}"
           f" dgrad {lib.me_conv_choose_tile_rows(100000, 27, km.n_pairs, 128, 64)}")
     ref = None
-    for var in (0, 1, 2, 4, 3, 5, 7):
+    for var in VARIANTS:
         row = []
-        for T in (64, 96, 112, 128, 131, 160, 196, 256):
+        for T in TILES:
             MEB._TILE_ROWS = T
             lib.me_debug_set_conv_variant(var)
             try:
@@ -51,7 +52,7 @@ for extent in (70, 215):
                     ref = y.clone()
                 err = float((y - ref).abs().max())
                 t = time_it(lambda: MEB._conv_forward(x, w, km, "mfma"))
-                td = time_it(lambda: MEB._conv_target(gy, wt, km, "in", km.n_in))
+                td = time_it(lambda: MEB._conv_target(gy, w, km, "in", km.n_in, transposed=True))
                 row.append(f"T{T}: {t*1e3:.0f}us/{flops/t/1e9:.1f}TF d{td*1e3:.0f}us e{err:.0e}")
             except RuntimeError as ex:
                 row.append(f"T{T}: ERR {str(ex)[:40]}")
