@@ -25,9 +25,10 @@ timeout 300 python bench.py --steps 50 --warmup 10 --extent 215 --cpu-budget 5 >
 cat $OUT/bench_sparse.json
 echo "== rocprofv3"
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o trace -- python $OLDPWD/bench.py --steps 20 --warmup 5 --cpu-budget 0 > $OUT/prof.log 2>&1; echo "rocprof rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python $OLDPWD/bench.py --steps 20 --warmup 5 --cpu-budget 0 > $OUT/prof.log 2>&1; echo "rocprof rc=$?"
 cd $OLDPWD
 find $OUT/prof -name "*stats*" | head; find $OUT/prof -name "*kernel_stats*" -exec head -25 {} \;
+find $OUT/prof -name "*kernel_stats*.csv" -exec cp {} $OUT/kernel_stats.csv \;
 # keep only the small summaries (the raw trace can be large)
 find $OUT/prof -type f ! -name "*stats*" -size +2M -delete
 echo "== done"
