@@ -176,11 +176,11 @@ int me_transpose_kernel_f32(const float *w_dev, int64_t volume, int32_t c_in, in
                             float *wt_dev, void *stream);
 
 /* Weight gradient: grad_w[k] = sum over pairs e of offset k of  x[in[e], :]^T (outer) dy[out[e], :]
- * (src/convolution_kernel.hpp:128-142).  MFMA fp32 32x32x2 over chunks of ME_WGRAD_CHUNK pairs,
- * partial tiles to workspace, deterministic second-pass reduction.
+ * (src/convolution_kernel.hpp:128-142).  The pair list is cut into equal ranges (one per workgroup,
+ * regardless of offset boundaries); MFMA fp32 16x16x4 fed straight from global memory; partial
+ * register images to the workspace; deterministic second-pass reduction in range order.
  *   k_offsets: host int64 [volume+1] (sizes the grid), k_offsets_dev: the same values on the device;
  *   workspace bytes from me_conv_wgrad_workspace_bytes. */
-#define ME_WGRAD_CHUNK 2048
 int64_t me_conv_wgrad_workspace_bytes(const int64_t *k_offsets, int64_t volume, int32_t c_in,
                                       int32_t c_out);
 int me_conv_wgrad_f32(const float *x_dev, int32_t c_in, const float *dy_dev, int32_t c_out,
@@ -188,6 +188,9 @@ int me_conv_wgrad_f32(const float *x_dev, int32_t c_in, const float *dy_dev, int
                       const int64_t *k_offsets /* host */, const int64_t *k_offsets_dev,
                       int64_t volume, float *grad_w_dev, void *workspace_dev,
                       int64_t workspace_bytes, void *stream);
+/* Tuning switch for me_conv_wgrad_f32: prefetch ring depth (4 or 8 steps of 4 pairs) and resident
+ * workgroups per CU the ranges are sized for; 0 = shipped defaults. */
+void me_debug_set_wgrad_config(int depth, int wgs_per_cu);
 
 /* Plain VALU + atomics versions on the pair lists (debug cross-check only; never the default).
  * out / grad_in / grad_w must be zero-filled by the caller. */

@@ -14,7 +14,6 @@ LIB_PATH = os.path.join(_HERE, "libme_amd.so")
 ME_MAX_DIM = 7
 ME_MAX_TILE_ROWS = 256
 ME_GROUP_ROWS = 16
-ME_WGRAD_CHUNK = 2048
 
 c_i32, c_i64, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
 
@@ -65,6 +64,7 @@ SIGNATURES = {
     "me_conv_wgrad_workspace_bytes": (c_i64, [_P_I64, c_i64, c_i32, c_i32]),
     "me_conv_wgrad_f32": (ctypes.c_int, [c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, _P_I64, c_vp, c_i64, c_vp,
                                          c_vp, c_i64, c_vp]),
+    "me_debug_set_wgrad_config": (None, [ctypes.c_int, ctypes.c_int]),
     "me_conv_forward_naive_f32": (ctypes.c_int, [c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_i64,
                                                  c_vp, c_vp]),
     "me_conv_backward_naive_f32": (ctypes.c_int, [c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i64,

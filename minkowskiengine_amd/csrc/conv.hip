@@ -23,6 +23,8 @@
 // of the transposed neighbour table.  wgrad reduces over the per-offset pair lists in chunks.
 #include "common.hpp"
 
+#include <type_traits>
+
 namespace me {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -327,146 +329,249 @@ __global__ __launch_bounds__(256) void k_transpose_kernel(const float *__restric
 // =================================================================================================
 // wgrad: grad_w[k] = X_g^T (c_in x n_k) . dY_g (n_k x c_out), reduction over the pairs of offset k
 // =================================================================================================
-constexpr int kWgPB = 32;       // pairs per LDS batch
-constexpr int kWgLD = 64 + 16;  // floats per staged row (stride = 16 mod 32 banks)
+// Barrier-free and LDS-free.  The concatenated pair list (sorted by offset k) is cut into R equal
+// RANGES of pairs, one per workgroup, regardless of the offset boundaries, so every SIMD gets the
+// same number of MFMAs; a range that crosses an offset boundary simply flushes its accumulators and
+// starts the next offset ("segment").  A wave owns a 64 x (16*NB) block of grad_w[k] and feeds
+// v_mfma_f32_16x16x4_f32 straight from global memory: one step = 4 pairs; lane (i16 = lane & 15,
+// q = lane >> 4) loads ONE 16-byte piece of x[in[e + q]] (channels ci0 + 4*i16 .. +3) and one
+// 4*NB-byte piece of dy[out[e + q]] — 16 lanes x 16 B = the whole 256-byte x row, so every gathered
+// byte is loaded exactly once per wave — and that feeds 4*NB MFMAs on independent accumulators
+// (MFMA row i of block m <-> input channel ci0 + 4*i + m; column j of block n <-> output channel
+// co0 + NB*j + n).  Pair indices arrive 64 at a time with one coalesced load and reach the lanes
+// through ds_bpermute; operands are prefetched DEPTH steps ahead in a statically indexed register
+// ring.  The waves of a workgroup sit side by side along the output channels (same x rows -> L1).
+// Flushes go to workspace slot (range + k) — unique, because (range, k) only ever moves up a
+// staircase — as the raw register image (coalesced); k_wgrad_reduce sums the slots of each offset
+// in range order (fixed summation order -> bitwise reproducible) and undoes the channel interleave.
+constexpr int kWgMB = 4;  // 16-row MFMA blocks of input channels per wave (64 channels, one dwordx4 per lane)
 
-// chunk -> (k, first pair, last pair): chunks are ME_WGRAD_CHUNK pairs of one offset
-__device__ __forceinline__ void wgrad_locate_chunk(const int64_t *__restrict__ koffs, int volume,
-                                                   int chunk, int &k_out, int64_t &e0, int64_t &e1) {
-  int c = 0;
-  k_out = -1;
-  e0 = e1 = 0;
-  for (int k = 0; k < volume; ++k) {
-    const int64_t b = koffs[k], e = koffs[k + 1];
-    const int nck = (int)((e - b + ME_WGRAD_CHUNK - 1) / ME_WGRAD_CHUNK);
-    if (chunk < c + nck) {
-      k_out = k;
-      e0 = b + (int64_t)(chunk - c) * ME_WGRAD_CHUNK;
-      e1 = min(e, e0 + ME_WGRAD_CHUNK);
-      return;
+// largest k in [0, volume) with koffs[k] <= e
+__device__ __forceinline__ int wgrad_locate_offset(const int64_t *__restrict__ koffs, int volume, int64_t e) {
+  int lo = 0, hi = volume;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (koffs[mid] <= e) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__host__ __device__ __forceinline__ int64_t wgrad_range_begin(int64_t r, int64_t n_pairs, int64_t n_ranges) {
+  return r * n_pairs / n_ranges;
+}
+
+// the range r with range_begin(r) <= e < range_begin(r + 1)
+__device__ __forceinline__ int64_t wgrad_range_of_pair(int64_t e, int64_t n_pairs, int64_t n_ranges) {
+  int64_t r = e * n_ranges / n_pairs;
+  while (r > 0 && wgrad_range_begin(r, n_pairs, n_ranges) > e) --r;
+  while (r + 1 < n_ranges && wgrad_range_begin(r + 1, n_pairs, n_ranges) <= e) ++r;
+  return r;
+}
+
+// One lane's V consecutive channels of a gathered row, always as unconditional loads (loads inside
+// exec-masked branches make hipcc fall back to s_waitcnt vmcnt(0), which serialises the prefetch
+// ring).  `ch` is already clamped into the row (channels beyond the real count only feed outputs that
+// k_wgrad_reduce ignores).  CHECK: the pair may be a padding pair (row < 0) -> zeros.
+// VEC: c is a multiple of V (one V*4-byte load); otherwise V scalar loads with clamped channels.
+template <int V, bool VEC, bool CHECK>
+__device__ __forceinline__ void load_piece(const float *__restrict__ base, int32_t row, int c, int ch,
+                                           float (&out)[V]) {
+  const bool ok = !CHECK || row >= 0;
+  const uint32_t r0 = (uint32_t)(CHECK ? max(row, 0) : row) * (uint32_t)c;
+  if constexpr (VEC) {
+    const float *p = base + (r0 + (uint32_t)ch);
+    if constexpr (V == 4) {
+      const f32x4 t = *reinterpret_cast<const f32x4 *>(p);
+      out[0] = ok ? t.x : 0.f; out[1] = ok ? t.y : 0.f; out[2] = ok ? t.z : 0.f; out[3] = ok ? t.w : 0.f;
+    } else if constexpr (V == 2) {
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      const f32x2 t = *reinterpret_cast<const f32x2 *>(p);
+      out[0] = ok ? t.x : 0.f; out[1] = ok ? t.y : 0.f;
+    } else {
+      const float t = *p;
+      out[0] = ok ? t : 0.f;
     }
-    c += nck;
+  } else {
+#pragma unroll
+    for (int m = 0; m < V; ++m) {
+      const float t = base[r0 + (uint32_t)(ch + m < c ? ch + m : 0)];
+      out[m] = ok ? t : 0.f;
+    }
   }
 }
 
-__global__ __launch_bounds__(256) void k_wgrad_f32(const float *__restrict__ x, int c_in,
+template <int NB, int DEPTH, bool VEC>
+__global__ __launch_bounds__(256, (NB == 4 ? 2 : 3)) void k_wgrad_f32(const float *__restrict__ x, int c_in,
                                                   const float *__restrict__ dy, int c_out,
                                                   const int32_t *__restrict__ in_pairs,
                                                   const int32_t *__restrict__ out_pairs,
                                                   const int64_t *__restrict__ koffs, int volume,
+                                                  int64_t n_pairs, int n_ranges, int n_cob,
                                                   float *__restrict__ partial) {
-  __shared__ __attribute__((aligned(16))) float s_x[kWgPB * kWgLD];
-  __shared__ __attribute__((aligned(16))) float s_y[kWgPB * kWgLD];
-  __shared__ int s_k;
-  __shared__ int64_t s_e[2];
+  constexpr int MB = kWgMB;
+  static_assert(DEPTH <= 8 && 16 % DEPTH == 0, "ring depth must divide the 16 steps of a 64-pair block");
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int i16 = lane & 15, q = lane >> 4;
+  const int range = blockIdx.x;
+  const int ci0 = blockIdx.y * (16 * MB);
+  const int cob = blockIdx.z * (blockDim.x >> 6) + wave;  // block of 16*NB output channels
+  if (cob >= n_cob) return;  // whole wave idle (there are no barriers in this kernel)
+  const int co0 = cob * (16 * NB);
+  const int64_t e_lo = wgrad_range_begin(range, n_pairs, n_ranges);
+  const int64_t e_hi = wgrad_range_begin(range + 1, n_pairs, n_ranges);
+  if (e_lo >= e_hi) return;
+  // this lane's channels, clamped into the row (see load_piece)
+  const int cha = (ci0 + MB * i16 < c_in) ? ci0 + MB * i16 : 0;
+  const int chb = (co0 + NB * i16 < c_out) ? co0 + NB * i16 : 0;
+  // register image of one (slot, cin block, cout block): MB*NB*4 registers x 64 lanes
+  constexpr int kImage = MB * NB * 4 * 64;
+  const int64_t image_stride = (int64_t)gridDim.y * n_cob * kImage;  // floats per slot
+  float *const image0 = partial + ((int64_t)blockIdx.y * n_cob + cob) * kImage + lane;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int chunk = blockIdx.x;
-  const int ci0 = blockIdx.y * 64, co0 = blockIdx.z * 64;
-  if (tid == 0) {
-    int k;
-    int64_t e0, e1;
-    wgrad_locate_chunk(koffs, volume, chunk, k, e0, e1);
-    s_k = k;
-    s_e[0] = e0;
-    s_e[1] = e1;
-  }
-  __syncthreads();
-  const int64_t e0 = s_e[0], e1 = s_e[1];
-  const int wm = wave >> 1, wn = wave & 1;
-  const bool vx = (c_in % 4) == 0, vy = (c_out % 4) == 0;
+  f32x4 acc[MB][NB];
+  float ra[DEPTH][MB], rb[DEPTH][NB];
 
-  f32x16 acc;
+  int k = wgrad_locate_offset(koffs, volume, e_lo);
+  int64_t e0 = e_lo;
+  while (e0 < e_hi) {
+    const int64_t kend = koffs[k + 1];
+    if (kend <= e0) {  // offsets without pairs
+      ++k;
+      continue;
+    }
+    const int64_t e1 = min(e_hi, kend);
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-
-  // 32 rows x 16 float4 per operand = 512 float4; 256 threads -> 2 per thread per operand
-  f32x4 sx[2], sy[2];
-  auto issue = [&](int64_t eb) {
+    for (int m = 0; m < MB; ++m)
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int idx = it * 256 + tid;
-      const int r = idx >> 4;
-      const int p = idx & 15;
-      const int64_t e = eb + r;
-      f32x4 tx = {0.f, 0.f, 0.f, 0.f}, ty = {0.f, 0.f, 0.f, 0.f};
-      if (e < e1) {
-        const int ci = ci0 + p * 4, co = co0 + p * 4;
-        if (ci < c_in) {
-          const float *xp = x + (int64_t)in_pairs[e] * c_in + ci;
-          if (vx) {
-            tx = *reinterpret_cast<const f32x4 *>(xp);
-          } else {
-            tx.x = xp[0];
-            if (ci + 1 < c_in) tx.y = xp[1];
-            if (ci + 2 < c_in) tx.z = xp[2];
-            if (ci + 3 < c_in) tx.w = xp[3];
-          }
-        }
-        if (co < c_out) {
-          const float *yp = dy + (int64_t)out_pairs[e] * c_out + co;
-          if (vy) {
-            ty = *reinterpret_cast<const f32x4 *>(yp);
-          } else {
-            ty.x = yp[0];
-            if (co + 1 < c_out) ty.y = yp[1];
-            if (co + 2 < c_out) ty.z = yp[2];
-            if (co + 3 < c_out) ty.w = yp[3];
-          }
-        }
+      for (int n = 0; n < NB; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // pair indices of the current block of 64 pairs (lane l holds pair eb + l) and of the next one;
+    // pairs beyond the segment are -1 (padding)
+    int32_t pin, pout, pin_n, pout_n;
+    auto load_pairs = [&](int64_t eb, int32_t &pi, int32_t &po) {
+      const int64_t e = eb + lane;
+      const int64_t ec = min(e, e1 - 1);  // unconditional load from a valid address
+      const int32_t vi = in_pairs[ec], vo = out_pairs[ec];
+      pi = (e < e1) ? vi : -1;
+      po = (e < e1) ? vo : -1;
+    };
+    // hand the indices of step `pos` (counted from the current block; pos >= 16: next block) to the lanes
+    int32_t ri_nx, ro_nx;
+    auto permute = [&](int pos) {
+      const int src_lane = 4 * (pos & 15) + q;
+      ri_nx = __shfl(pos < 16 ? pin : pin_n, src_lane, 64);
+      ro_nx = __shfl(pos < 16 ? pout : pout_n, src_lane, 64);
+    };
+    auto mma_step = [&](const float (&a)[MB], const float (&b)[NB]) {
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[n], acc[m][n], 0, 0, 0);
+    };
+    load_pairs(e0, pin, pout);
+    load_pairs(e0 + 64, pin_n, pout_n);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      permute(d);
+      load_piece<MB, VEC, true>(x, ri_nx, c_in, cha, ra[d]);
+      load_piece<NB, VEC, true>(dy, ro_nx, c_out, chb, rb[d]);
+    }
+    permute(DEPTH);
+    // one block = 16 steps of 4 pairs.  At step st: multiply ring slot st % DEPTH, refill it with step
+    // st + DEPTH (indices permuted one step earlier), permute the indices of step st + DEPTH + 1.
+    auto block = [&](auto check, int nsteps) {
+      constexpr bool CHECK = decltype(check)::value;
+#pragma unroll
+      for (int st = 0; st < 16; ++st) {
+        if (CHECK && st >= nsteps) break;  // wave-uniform
+        const int d = st % DEPTH;
+        mma_step(ra[d], rb[d]);
+        load_piece<MB, VEC, CHECK>(x, ri_nx, c_in, cha, ra[d]);
+        load_piece<NB, VEC, CHECK>(dy, ro_nx, c_out, chb, rb[d]);
+        permute(st + DEPTH + 1);
+        // keep hipcc's scheduler from sinking the refill loads down to their use DEPTH steps later
+        // (it would trade the whole prefetch distance for a few registers)
+        __builtin_amdgcn_sched_barrier(0);
       }
-      sx[it] = tx;
-      sy[it] = ty;
+      pin = pin_n;
+      pout = pout_n;
+    };
+    int64_t eb = e0;
+    // blocks whose own pairs and the next block's pairs are all real: no padding checks
+    for (; eb + 128 <= e1; eb += 64) {
+      block(std::false_type{}, 16);
+      load_pairs(eb + 128, pin_n, pout_n);
     }
-  };
-
-  if (e0 < e1) issue(e0);
-  for (int64_t eb = e0; eb < e1; eb += kWgPB) {
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int idx = it * 256 + tid;
-      const int r = idx >> 4, p = idx & 15;
-      *reinterpret_cast<f32x4 *>(&s_x[r * kWgLD + p * 4]) = sx[it];
-      *reinterpret_cast<f32x4 *>(&s_y[r * kWgLD + p * 4]) = sy[it];
+    for (; eb < e1; eb += 64) {
+      block(std::true_type{}, (int)min((int64_t)16, (e1 - eb + 3) >> 2));
+      load_pairs(eb + 128, pin_n, pout_n);
     }
-    __syncthreads();
-    if (eb + kWgPB < e1) issue(eb + kWgPB);
-    const float *ap = &s_x[(lane >> 5) * kWgLD + wm * 32 + (lane & 31)];
-    const float *bp = &s_y[(lane >> 5) * kWgLD + wn * 32 + (lane & 31)];
+    float *img = image0 + (int64_t)(range + k) * image_stride;
 #pragma unroll
-    for (int s = 0; s < kWgPB / 2; ++s)
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[s * 2 * kWgLD], bp[s * 2 * kWgLD], acc, 0, 0, 0);
-  }
-
-  float *pp = partial + (int64_t)chunk * c_in * c_out;
-  const int colo = co0 + wn * 32 + (lane & 31);
+    for (int m = 0; m < MB; ++m)
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = ci0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    if (row < c_in && colo < c_out) pp[(int64_t)row * c_out + colo] = acc[r];
+      for (int n = 0; n < NB; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) img[((m * NB + n) * 4 + r) * 64] = acc[m][n][r];
+    e0 = e1;
   }
 }
 
-// grad_w[k][idx] = sum of the partial tiles of offset k's chunks, in chunk order (deterministic)
+// grad_w[k] = sum of the register images of the ranges that touch offset k, written back through the
+// channel interleave of k_wgrad_f32.  A block sums 64 consecutive image elements; its four waves take
+// the slots s = first + phase, + 4, ... (four independent loads in flight per thread: the loop is
+// latency-bound otherwise) and the four partial sums are combined in phase order, so the summation
+// order is fixed (bitwise reproducible).
+template <int NB>
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ partial,
                                                      const int64_t *__restrict__ koffs, int volume,
-                                                     int64_t cc, float *__restrict__ grad_w) {
-  __shared__ int s_c[2];
+                                                     int64_t n_pairs, int n_ranges, int n_cib, int n_cob,
+                                                     int c_in, int c_out, float *__restrict__ grad_w) {
+  constexpr int MB = kWgMB;
+  constexpr int kImage = MB * NB * 4 * 64;
+  __shared__ int64_t s_r[2];
+  __shared__ float s_part[4][64];
   const int k = blockIdx.y;
+  const int64_t b = koffs[k], e = koffs[k + 1];
   if (threadIdx.x == 0) {
-    int c = 0;
-    for (int kk = 0; kk < k; ++kk)
-      c += (int)((koffs[kk + 1] - koffs[kk] + ME_WGRAD_CHUNK - 1) / ME_WGRAD_CHUNK);
-    s_c[0] = c;
-    s_c[1] = c + (int)((koffs[k + 1] - koffs[k] + ME_WGRAD_CHUNK - 1) / ME_WGRAD_CHUNK);
+    s_r[0] = 0;
+    s_r[1] = -1;
+    if (e > b) {
+      s_r[0] = wgrad_range_of_pair(b, n_pairs, n_ranges) + k;
+      s_r[1] = wgrad_range_of_pair(e - 1, n_pairs, n_ranges) + k;
+    }
   }
   __syncthreads();
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= cc) return;
+  const int j = threadIdx.x & 63, phase = threadIdx.x >> 6;
+  const int64_t idx = (int64_t)blockIdx.x * 64 + j;
+  const int64_t per_slot = (int64_t)n_cib * n_cob * kImage;
   float s = 0.f;
-  for (int c = s_c[0]; c < s_c[1]; ++c) s += partial[(int64_t)c * cc + idx];
-  grad_w[(int64_t)k * cc + idx] = s;
+  if (idx < per_slot) {
+    const int64_t first = s_r[0], last = s_r[1];
+    const float *p = partial + idx;
+    int64_t slot = first + phase;
+    for (; slot + 12 <= last; slot += 16) {
+      const float v0 = p[slot * per_slot], v1 = p[(slot + 4) * per_slot];
+      const float v2 = p[(slot + 8) * per_slot], v3 = p[(slot + 12) * per_slot];
+      s = ((s + v0) + v1) + v2 + v3;
+    }
+    for (; slot <= last; slot += 4) s += p[slot * per_slot];
+  }
+  s_part[phase][j] = s;
+  __syncthreads();
+  if (phase != 0 || idx >= per_slot) return;
+  s = ((s_part[0][j] + s_part[1][j]) + s_part[2][j]) + s_part[3][j];
+  const int lane = (int)(idx % 64);
+  const int reg = (int)((idx / 64) % (MB * NB * 4));
+  const int cob = (int)((idx / kImage) % n_cob);
+  const int cib = (int)(idx / ((int64_t)kImage * n_cob));
+  const int r = reg % 4, n = (reg / 4) % NB, m = reg / (4 * NB);
+  const int i16 = lane & 15, q = lane >> 4;
+  const int ci = cib * (16 * MB) + MB * (4 * q + r) + m;
+  const int co = cob * (16 * NB) + NB * i16 + n;
+  if (ci < c_in && co < c_out) grad_w[((int64_t)k * c_in + ci) * c_out + co] = s;
 }
 
 // =================================================================================================
@@ -597,10 +702,35 @@ static int launch_conv_target(const float *src, int c_src, const float *wp, int 
   return 0;
 }
 
-static int64_t wgrad_num_chunks(const int64_t *k_offsets, int64_t volume) {
-  int64_t c = 0;
-  for (int64_t k = 0; k < volume; ++k) c += ceil_div(k_offsets[k + 1] - k_offsets[k], ME_WGRAD_CHUNK);
-  return c;
+int g_wgrad_depth = 0;         // me_debug_set_wgrad_config: 0 = default
+int g_wgrad_wgs_per_cu = 0;
+
+// launch geometry of the wgrad kernels for a (pairs, channels) problem
+struct WgradGeom {
+  int nb;        // 16-column MFMA blocks of output channels per wave (1, 2 or 4)
+  int n_cib;     // blocks of 64 input channels   (grid.y)
+  int n_cob;     // blocks of 16*nb output channels (waves along grid.z x waves per workgroup)
+  int waves;     // waves per workgroup (side by side along the output channels)
+  int gz;        // grid.z
+  int64_t ranges;  // grid.x: equal ranges of the pair list
+  int64_t slot_floats;
+};
+
+static WgradGeom wgrad_geom(int64_t n_pairs, int64_t volume, int c_in, int c_out) {
+  WgradGeom g;
+  g.nb = c_out <= 64 ? 1 : (c_out <= 128 ? 2 : 4);
+  g.n_cib = (int)ceil_div(c_in, 16 * kWgMB);
+  g.n_cob = (int)ceil_div(c_out, 16 * g.nb);
+  g.waves = g.n_cob < 4 ? g.n_cob : 4;
+  g.gz = (int)ceil_div(g.n_cob, g.waves);
+  const int wpc = g_wgrad_wgs_per_cu > 0 ? g_wgrad_wgs_per_cu : 3;
+  int64_t r = ceil_div((int64_t)device_cu_count() * wpc, (int64_t)g.n_cib * g.gz);
+  if (r > n_pairs / 64) r = n_pairs / 64;  // at least 64 pairs per range (and no empty ranges)
+  if (r < 1) r = 1;
+  g.ranges = r;
+  g.slot_floats = (int64_t)g.n_cib * g.n_cob * (kWgMB * g.nb * 4 * 64);
+  (void)volume;
+  return g;
 }
 
 }  // namespace me
@@ -725,9 +855,14 @@ int me_transpose_kernel_f32(const float *w, int64_t volume, int32_t c_in, int32_
 }
 
 int64_t me_conv_wgrad_workspace_bytes(const int64_t *k_offsets, int64_t volume, int32_t c_in, int32_t c_out) {
-  int64_t chunks = wgrad_num_chunks(k_offsets, volume);
-  if (chunks < 1) chunks = 1;
-  return align_up(chunks * (int64_t)c_in * c_out * 4, 256);
+  if (volume < 1 || c_in <= 0 || c_out <= 0) return 256;
+  const WgradGeom g = wgrad_geom(k_offsets[volume], volume, c_in, c_out);
+  return align_up((g.ranges + volume) * g.slot_floats * 4, 256);
+}
+
+void me_debug_set_wgrad_config(int depth, int wgs_per_cu) {
+  g_wgrad_depth = depth;
+  g_wgrad_wgs_per_cu = wgs_per_cu;
 }
 
 int me_conv_wgrad_f32(const float *x, int32_t c_in, const float *dy, int32_t c_out, const int32_t *in_pairs,
@@ -740,17 +875,37 @@ int me_conv_wgrad_f32(const float *x, int32_t c_in, const float *dy, int32_t c_o
   ME_CHECK((uintptr_t)x % 16 == 0 && (uintptr_t)dy % 16 == 0, "feature pointers must be 16-byte aligned");
   ME_CHECK(workspace_bytes >= me_conv_wgrad_workspace_bytes(k_offsets, volume, c_in, c_out),
            "workspace too small");
-  const int64_t chunks = wgrad_num_chunks(k_offsets, volume);
+  const int64_t n_pairs = k_offsets[volume];
+  const WgradGeom g = wgrad_geom(n_pairs, volume, c_in, c_out);
   float *partial = reinterpret_cast<float *>(workspace);
-  if (chunks > 0) {
-    const dim3 grid((unsigned)chunks, (unsigned)ceil_div(c_in, 64), (unsigned)ceil_div(c_out, 64));
-    hipLaunchKernelGGL(k_wgrad_f32, grid, dim3(256), 0, stream, x, c_in, dy, c_out, in_pairs, out_pairs,
-                       k_offsets_dev, (int)volume, partial);
+  const int depth = g_wgrad_depth > 0 ? g_wgrad_depth : (g.nb == 4 ? 8 : 4);  // measured: profiles/r01_tune_wgrad_v2.log
+  if (n_pairs > 0) {
+    const dim3 grid((unsigned)g.ranges, (unsigned)g.n_cib, (unsigned)g.gz);
+    const dim3 block(64 * g.waves);
+    const bool vec = (c_in % kWgMB) == 0 && (c_out % g.nb) == 0;
+#define ME_WGRAD_LAUNCH(NBV, DV)                                                                              \
+  do {                                                                                                        \
+    if (vec)                                                                                                  \
+      hipLaunchKernelGGL((k_wgrad_f32<NBV, DV, true>), grid, block, 0, stream, x, c_in, dy, c_out, in_pairs,  \
+                         out_pairs, k_offsets_dev, (int)volume, n_pairs, (int)g.ranges, g.n_cob, partial);    \
+    else                                                                                                      \
+      hipLaunchKernelGGL((k_wgrad_f32<NBV, 8, false>), grid, block, 0, stream, x, c_in, dy, c_out, in_pairs,  \
+                         out_pairs, k_offsets_dev, (int)volume, n_pairs, (int)g.ranges, g.n_cob, partial);    \
+  } while (0)
+    if (g.nb == 1) { if (depth == 4) ME_WGRAD_LAUNCH(1, 4); else ME_WGRAD_LAUNCH(1, 8); }
+    else if (g.nb == 2) { if (depth == 4) ME_WGRAD_LAUNCH(2, 4); else ME_WGRAD_LAUNCH(2, 8); }
+    else { if (depth == 4) ME_WGRAD_LAUNCH(4, 4); else ME_WGRAD_LAUNCH(4, 8); }
+#undef ME_WGRAD_LAUNCH
     ME_LAUNCH_CHECK();
   }
-  const int64_t cc = (int64_t)c_in * c_out;
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)ceil_div(cc, 256), (unsigned)volume), dim3(256), 0,
-                     stream, partial, k_offsets_dev, (int)volume, cc, grad_w);
+  const dim3 rgrid((unsigned)ceil_div(g.slot_floats, 64), (unsigned)volume);
+#define ME_WGRAD_REDUCE(NBV)                                                                               \
+  hipLaunchKernelGGL((k_wgrad_reduce<NBV>), rgrid, dim3(256), 0, stream, partial, k_offsets_dev, (int)volume, \
+                     n_pairs > 0 ? n_pairs : 1, (int)g.ranges, g.n_cib, g.n_cob, c_in, c_out, grad_w)
+  if (g.nb == 1) ME_WGRAD_REDUCE(1);
+  else if (g.nb == 2) ME_WGRAD_REDUCE(2);
+  else ME_WGRAD_REDUCE(4);
+#undef ME_WGRAD_REDUCE
   ME_LAUNCH_CHECK();
   return 0;
 }

@@ -27,6 +27,7 @@ def time_it(fn, iters=20, warm=3):
 
 
 shapes = [(64, 128), (128, 64), (32, 32), (96, 96), (3, 32), (256, 256)]
+CONFIGS = [tuple(int(v) for v in c.split(":")) for c in os.environ.get("CONFIGS", "0:0").split(",")]
 for extent in (70, 215):
     coords = make_scene(100000, extent, 0).to(dev)
     mgr = MEB.CoordinateMapManagerGPU_c10()
@@ -42,12 +43,18 @@ for extent in (70, 215):
         err = float((gw - gw_ref).abs().max() / gw_ref.abs().max())
         _, gw2 = MEB._conv_backward(x, gy, w, km, "mfma")
         rep = bool((gw == gw2).all())
-        MEB.KERNEL_TIMER = MEB.KernelTimer()
-        for _ in range(20):
-            MEB._conv_backward(x, gy, w, km, "mfma")
-        torch.cuda.synchronize()
-        tm = MEB.KERNEL_TIMER.summary()
-        MEB.KERNEL_TIMER = None
-        t = tm["conv_wgrad"][1]
-        print(f"extent {extent} {cin}->{cout}: wgrad {t*1e3:.0f} us {flops/t/1e9:.1f} TF relerr {err:.1e} bitwise-repro {rep}",
-              flush=True)
+        res = []
+        for depth, wpc in CONFIGS:
+            lib.me_debug_set_wgrad_config(depth, wpc)
+            for _ in range(3):
+                MEB._conv_backward(x, gy, w, km, "mfma")
+            MEB.KERNEL_TIMER = MEB.KernelTimer()
+            for _ in range(20):
+                MEB._conv_backward(x, gy, w, km, "mfma")
+            torch.cuda.synchronize()
+            tm = MEB.KERNEL_TIMER.summary()
+            MEB.KERNEL_TIMER = None
+            t = tm["conv_wgrad"][1]
+            res.append(f"d{depth}w{wpc}: {t*1e3:.0f}us/{flops/t/1e9:.1f}TF")
+        lib.me_debug_set_wgrad_config(0, 0)
+        print(f"extent {extent} {cin}->{cout}: relerr {err:.1e} repro {rep} | " + " | ".join(res), flush=True)

@@ -47,8 +47,8 @@ def test_host_only_entry_points():
     rg = _lib.make_region(5, 0, [3, 3, 3, 3], [1] * 4, [1] * 4)
     assert lib.me_region_volume(ctypes.byref(rg)) == 81
     koffs = (ctypes.c_int64 * 4)(0, 10, 10, 5000)
-    # chunks: ceil(10/2048) + 0 + ceil(4990/2048) = 1 + 3
-    assert lib.me_conv_wgrad_workspace_bytes(koffs, 3, 8, 16) == 4 * 8 * 16 * 4
+    # (ranges + volume) slots of one 64 x 16 register image each: 5000 pairs -> 78 ranges of >= 64 pairs
+    assert lib.me_conv_wgrad_workspace_bytes(koffs, 3, 8, 16) == (5000 // 64 + 3) * 64 * 16 * 4
 
 
 def test_choose_tile_rows_fills_the_chip():
