@@ -192,6 +192,45 @@ int me_conv_wgrad_f32(const float *x_dev, int32_t c_in, const float *dy_dev, int
  * workgroups per CU the ranges are sized for; 0 = shipped defaults. */
 void me_debug_set_wgrad_config(int depth, int wgs_per_cu);
 
+/* ---- pooling / broadcast (replace src/pooling_avg_kernel.cu, src/pooling_max_kernel.cu,
+ *      src/broadcast_kernel.cu; CPU twins src/pooling_avg_kernel.hpp:41-150,
+ *      src/pooling_max_kernel.hpp:36-117, src/broadcast_kernel.hpp:35-160) ------------------------
+ * All target-stationary on the dense neighbour tables of a kernel map (tbl[k, target row] -> source row
+ * or -1): no atomics, no zero-fill, summation in ascending k (the reference CPU order). */
+
+/* Local sum / average pooling, forward AND backward:
+ *   dst[t, :] = sum_k src[tbl[k, t], :]                              (src_count_dev == NULL)
+ *   dst[t, :] = sum_k src[s, :] / src_count[s],  s = tbl[k, t]       (average-pooling backward:
+ *               src = grad_out, tbl = transposed table, src_count = num_nonzero of the forward pass)
+ * `average` != 0 divides by the number of summed rows; that number is written to dst_count_dev (float
+ * [n_tgt], may be NULL) — the reference's num_nonzero (src/local_pooling_cpu.cpp:104-122). */
+int me_pool_sum_f32(const float *src_dev, int32_t c, const int32_t *tbl_dev, int64_t n_tgt, int64_t volume,
+                    const float *src_count_dev, int32_t average, float *dst_dev, float *dst_count_dev,
+                    void *stream);
+/* Local max pooling forward: dst = max over k, mask[t, c] = flat index (source row * c + channel) of the
+ * first maximum in k order; rows without neighbours get -FLT_MAX / -1 (src/pooling_max_kernel.hpp:73-96). */
+int me_pool_max_f32(const float *src_dev, int32_t c, const int32_t *tbl_dev, int64_t n_tgt, int64_t volume,
+                    float *dst_dev, int32_t *mask_dev, void *stream);
+/* Local max pooling backward: grad_in[i, c] = sum of grad_out[o, c] over the outputs o = tbl_in[k, i] whose
+ * mask names (i, c)  (src/pooling_max_kernel.hpp:98-117).  tbl_in: transposed table [volume, n_in]. */
+int me_pool_max_backward_f32(const float *grad_out_dev, int32_t c, const int32_t *tbl_in_dev, int64_t n_in,
+                             int64_t volume, const int32_t *mask_dev, float *grad_in_dev, void *stream);
+
+/* Global pooling over the rows of each batch index (src/global_pooling_cpu.cpp:43-238).
+ *   batch_row_dev int32 [n]: row of the origin map (output row) of every input row
+ *   mode 0 sum, 1 average, 2 max;  src2_dev (may be NULL): multiplied element-wise before the reduction
+ *   (the gradient of a broadcast multiplication);  dst [n_batch, c];  dst_arg int32 [n_batch, c] (max: flat
+ *   index row * c + channel);  dst_count float [n_batch] (sum / average; may be NULL). */
+int64_t me_global_pool_workspace_bytes(int64_t n, int32_t n_batch, int32_t c);
+int me_global_pool_f32(const float *src_dev, const float *src2_dev, int32_t c, const int32_t *batch_row_dev,
+                       int64_t n, int32_t n_batch, int32_t mode, float *dst_dev, int32_t *dst_arg_dev,
+                       float *dst_count_dev, void *workspace_dev, int64_t workspace_bytes, void *stream);
+
+/* Broadcast (src/broadcast_kernel.hpp:35-160): out[i, :] = in[i, :] (+ | *) glob[batch_row[i], :];
+ * in_dev == NULL: out[i, :] = glob[batch_row[i], :] (the gradient of global sum pooling). */
+int me_broadcast_f32(const float *in_dev, const float *glob_dev, const int32_t *batch_row_dev, int64_t n,
+                     int32_t c, int32_t multiply, float *out_dev, void *stream);
+
 /* Plain VALU + atomics versions on the pair lists (debug cross-check only; never the default).
  * out / grad_in / grad_w must be zero-filled by the caller. */
 int me_conv_forward_naive_f32(const float *in_feat_dev, int32_t c_in, const float *w_dev, int32_t c_out,

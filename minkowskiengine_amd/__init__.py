@@ -23,6 +23,13 @@ from .kernel_generator import KernelGenerator, get_kernel_volume  # noqa: F401
 from .layers import (  # noqa: F401
     MinkowskiBatchNorm, MinkowskiDropout, MinkowskiELU, MinkowskiLeakyReLU, MinkowskiLinear, MinkowskiReLU,
     MinkowskiSigmoid, MinkowskiSyncBatchNorm, MinkowskiTanh, cat)
+from .pooling import (  # noqa: F401
+    MinkowskiAvgPooling, MinkowskiGlobalAvgPooling, MinkowskiGlobalMaxPooling, MinkowskiGlobalPooling,
+    MinkowskiGlobalPoolingFunction, MinkowskiGlobalSumPooling, MinkowskiLocalPoolingFunction,
+    MinkowskiLocalPoolingTransposeFunction, MinkowskiMaxPooling, MinkowskiPoolingTranspose, MinkowskiSumPooling)
+from .broadcast import (  # noqa: F401
+    MinkowskiBroadcast, MinkowskiBroadcastAddition, MinkowskiBroadcastConcatenation, MinkowskiBroadcastFunction,
+    MinkowskiBroadcastMultiplication)
 from .sparse_tensor import (  # noqa: F401
     SparseTensor, SparseTensorOperationMode, SparseTensorQuantizationMode, clear_global_coordinate_manager,
     global_coordinate_manager, set_global_coordinate_manager, set_sparse_tensor_operation_mode,

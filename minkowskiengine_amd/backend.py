@@ -424,6 +424,55 @@ class CoordinateMapManagerGPU_c10:
     def get_coordinates(self, key):
         return self._get(key).coords
 
+    # ---- origin map (one row per batch index) --------------------------------------------------
+    def origin(self):
+        """CoordinateMapKey of the origin map: tensor stride all zeros, one row per batch index in
+        first-occurrence order of the finest map (src/coordinate_map_manager.cpp:470-508; the reference CPU
+        orders the rows by hash-table iteration, so rows are compared by their batch index)."""
+        _check(len(self._maps) > 0, "origin() needs at least one coordinate map")
+        any_key = next(iter(self._maps))
+        D = len(any_key[0])
+        okey = (tuple([0] * D), "")
+        if okey not in self._maps:
+            # the map with the smallest tensor stride holds every batch index
+            cands = [k for k in self._maps if all(t > 0 for t in k[0])]
+            base_key = min(cands, key=lambda k: (sum(k[0]), k[1]))
+            base = self._maps[base_key]
+            oc = torch.zeros_like(base.coords)
+            oc[:, 0] = base.coords[:, 0]
+            cmap, _, inverse = _insert(oc.contiguous(), okey[0])
+            self._maps[okey] = cmap
+            self._origin_maps[base_key] = inverse.to(torch.int32)
+        return CoordinateMapKey(list(okey[0]), okey[1])
+
+    def origin_map_size(self):
+        return self._get(self.origin()).n
+
+    def _origin_rows(self, in_key):
+        """int32 [n_in]: origin-map row (output row of a global pooling) of every row of `in_key`;
+        the kernel map of src/coordinate_map_cpu.hpp:1067-1100 with one offset, kept as a row table."""
+        ik = self._k(in_key)
+        self.origin()
+        rows = self._origin_maps.get(ik)
+        if rows is None:
+            in_map, omap = self._get(ik), self._get(self.origin())
+            lib = _lib.load()
+            dev = in_map.coords.device
+            q = torch.zeros_like(in_map.coords)
+            q[:, 0] = in_map.coords[:, 0]
+            rows = torch.empty(max(in_map.n, 1), dtype=torch.int32, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(lib.me_coords_find(_ptr(omap.table), omap.capacity, _ptr(omap.coords), q.shape[1],
+                                              _ptr(q), in_map.n, _ptr(rows), _stream(dev)))
+            rows = rows[:in_map.n]
+            self._origin_maps[ik] = rows
+        return rows
+
+    def origin_map(self, in_key):
+        """{0: int32 [2, n_in]} (row 0 = in rows, row 1 = origin rows), the reference's origin_map_th layout."""
+        rows = self._origin_rows(in_key)
+        return {0: torch.stack((torch.arange(rows.numel(), dtype=torch.int32, device=rows.device), rows))}
+
     def size(self, key):
         return self._get(key).n
 
@@ -661,3 +710,219 @@ def ConvolutionTransposeBackwardGPU(in_feat, grad_out_feat, kernel, kernel_size,
                              True, False)
     _check(grad_out_feat.shape[0] == km.n_out, "Invalid grad_out size")
     return _conv_backward(in_feat, grad_out_feat, kernel, km)
+
+
+# ------------------------------------------------------------------------------------------------
+# pooling / broadcast operators (src/local_pooling_cpu.cpp, src/local_pooling_transpose_cpu.cpp,
+# src/global_pooling_cpu.cpp, src/broadcast_cpu.cpp; signatures pybind/extern.hpp:187-392)
+# ------------------------------------------------------------------------------------------------
+def _pool_sum(src, tbl, n_tgt, volume, src_count=None, average=False, want_count=False):
+    lib = _lib.load()
+    dev = src.device
+    c = int(src.shape[1])
+    out = torch.empty((n_tgt, c), dtype=torch.float32, device=dev)
+    cnt = torch.empty(max(n_tgt, 1), dtype=torch.float32, device=dev)[:n_tgt] if want_count else None
+    with torch.cuda.device(dev):
+        _timed("pool_sum", dev, lambda: _lib.check(lib.me_pool_sum_f32(
+            _ptr(src), c, _ptr(tbl), n_tgt, volume, _ptr(src_count), 1 if average else 0, _ptr(out), _ptr(cnt),
+            _stream(dev))))
+    return out, cnt
+
+
+def _prepare_pool(in_feat, kernel_stride, in_key, out_key, manager, transpose):
+    _check_feat("in_feat", in_feat)
+    _check(in_feat.dim() == 2, "in_feat.dim():", in_feat.dim())
+    _check(manager.exists(in_key), "coordinate map not found")
+    _check(in_feat.shape[0] == manager.size(in_key), "Invalid in_feat size", in_feat.shape[0], "!=",
+           manager.size(in_key))
+    if not out_key.is_key_set():
+        if not transpose:
+            out_key.set_key(manager.stride(in_key, kernel_stride).get_key())
+        else:
+            ts = in_key.get_tensor_stride()
+            st = [int(s) for s in kernel_stride]
+            _check(all(t % s == 0 for t, s in zip(ts, st)), "Invalid up stride on tensor stride:", ts)
+            cand = ([t // s for t, s in zip(ts, st)], "")
+            _check(manager.exists(cand), "pooling transpose needs an existing output map")
+            out_key.set_key(cand)
+
+
+def LocalPoolingForwardGPU(in_feat, kernel_size, kernel_stride, kernel_dilation, region_type, offset,
+                           pooling_mode, in_key, out_key, manager):
+    """src/local_pooling_cpu.cpp:43-122 -> (out_feat, num_nonzero | max_index)."""
+    _prepare_pool(in_feat, kernel_stride, in_key, out_key, manager, False)
+    km = manager._kernel_map(in_key, out_key, kernel_size, kernel_stride, kernel_dilation, region_type, offset,
+                             False, True)
+    mode = PoolingMode(int(pooling_mode))
+    if mode == PoolingMode.LOCAL_MAX_POOLING:
+        lib = _lib.load()
+        dev = in_feat.device
+        c = int(in_feat.shape[1])
+        out = torch.empty((km.n_out, c), dtype=torch.float32, device=dev)
+        mask = torch.empty((km.n_out, c), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            _timed("pool_max", dev, lambda: _lib.check(lib.me_pool_max_f32(
+                _ptr(in_feat), c, _ptr(km.table("out")), km.n_out, km.volume, _ptr(out), _ptr(mask), _stream(dev))))
+        return out, mask
+    _check(mode in (PoolingMode.LOCAL_SUM_POOLING, PoolingMode.LOCAL_AVG_POOLING), "Invalid pooling mode")
+    avg = mode == PoolingMode.LOCAL_AVG_POOLING
+    out, cnt = _pool_sum(in_feat, km.table("out"), km.n_out, km.volume, average=avg, want_count=avg)
+    if cnt is None:
+        cnt = torch.empty(0, dtype=torch.float32, device=in_feat.device)
+    return out, cnt
+
+
+def LocalPoolingBackwardGPU(in_feat, grad_out_feat, num_nonzero, kernel_size, kernel_stride, kernel_dilation,
+                            region_type, offset, pooling_mode, in_key, out_key, manager):
+    """src/local_pooling_cpu.cpp:124-214 -> grad_in_feat."""
+    _check_feat("in_feat", in_feat)
+    if not grad_out_feat.is_contiguous():
+        grad_out_feat = grad_out_feat.contiguous()
+    _check_feat("grad_out_feat", grad_out_feat)
+    km = manager._kernel_map(in_key, out_key, kernel_size, kernel_stride, kernel_dilation, region_type, offset,
+                             False, True)
+    _check(grad_out_feat.shape[0] == km.n_out, "Invalid grad_out size")
+    mode = PoolingMode(int(pooling_mode))
+    if mode == PoolingMode.LOCAL_MAX_POOLING:
+        lib = _lib.load()
+        dev = in_feat.device
+        c = int(in_feat.shape[1])
+        grad_in = torch.empty((km.n_in, c), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.me_pool_max_backward_f32(_ptr(grad_out_feat), c, _ptr(km.table("in")), km.n_in, km.volume,
+                                                    _ptr(num_nonzero), _ptr(grad_in), _stream(dev)))
+        return grad_in
+    avg = mode == PoolingMode.LOCAL_AVG_POOLING
+    grad_in, _ = _pool_sum(grad_out_feat, km.table("in"), km.n_in, km.volume,
+                           src_count=num_nonzero if avg else None)
+    return grad_in
+
+
+def LocalPoolingTransposeForwardGPU(in_feat, kernel_size, kernel_stride, kernel_dilation, region_type, offset,
+                                    generate_new_coordinates, pooling_mode, in_key, out_key, manager):
+    """src/local_pooling_transpose_cpu.cpp:41-115: unpooling = sum over the transposed map -> (out, num_nonzero)."""
+    _check(not generate_new_coordinates, "generate_new_coordinates (stride_region) is not part of the hot path yet")
+    _prepare_pool(in_feat, kernel_stride, in_key, out_key, manager, True)
+    km = manager._kernel_map(in_key, out_key, kernel_size, kernel_stride, kernel_dilation, region_type, offset,
+                             True, True)
+    out, cnt = _pool_sum(in_feat, km.table("out"), km.n_out, km.volume, average=False, want_count=True)
+    return out, cnt
+
+
+def LocalPoolingTransposeBackwardGPU(in_feat, grad_out_feat, num_nonzero, kernel_size, kernel_stride,
+                                     kernel_dilation, region_type, offset, pooling_mode, in_key, out_key, manager):
+    """src/local_pooling_transpose_cpu.cpp:117-190 -> grad_in_feat."""
+    if not grad_out_feat.is_contiguous():
+        grad_out_feat = grad_out_feat.contiguous()
+    _check_feat("grad_out_feat", grad_out_feat)
+    km = manager._kernel_map(in_key, out_key, kernel_size, kernel_stride, kernel_dilation, region_type, offset,
+                             True, True)
+    grad_in, _ = _pool_sum(grad_out_feat, km.table("in"), km.n_in, km.volume)
+    return grad_in
+
+
+_GLOBAL_SUM = (PoolingMode.GLOBAL_SUM_POOLING_DEFAULT, PoolingMode.GLOBAL_SUM_POOLING_KERNEL,
+               PoolingMode.GLOBAL_SUM_POOLING_PYTORCH_INDEX)
+_GLOBAL_AVG = (PoolingMode.GLOBAL_AVG_POOLING_DEFAULT, PoolingMode.GLOBAL_AVG_POOLING_KERNEL,
+               PoolingMode.GLOBAL_AVG_POOLING_PYTORCH_INDEX)
+_GLOBAL_MAX = (PoolingMode.GLOBAL_MAX_POOLING_DEFAULT, PoolingMode.GLOBAL_MAX_POOLING_KERNEL,
+               PoolingMode.GLOBAL_MAX_POOLING_PYTORCH_INDEX)
+
+
+def _global_pool(src, src2, rows, n_batch, mode):
+    """mode 0 sum / 1 avg / 2 max over the rows of each origin row -> (out, argmax | None, count | None)."""
+    lib = _lib.load()
+    dev = src.device
+    n, c = int(src.shape[0]), int(src.shape[1])
+    out = torch.empty((n_batch, c), dtype=torch.float32, device=dev)
+    arg = torch.empty((n_batch, c), dtype=torch.int32, device=dev) if mode == 2 else None
+    cnt = torch.empty(n_batch, dtype=torch.float32, device=dev) if mode != 2 else None
+    ws = _workspace(lib.me_global_pool_workspace_bytes(n, n_batch, c), dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.me_global_pool_f32(_ptr(src), _ptr(src2), c, _ptr(rows), n, n_batch, mode, _ptr(out), _ptr(arg),
+                                          _ptr(cnt), _ptr(ws), ws.numel(), _stream(dev)))
+    return out, arg, cnt
+
+
+def GlobalPoolingForwardGPU(in_feat, pooling_mode, in_key, out_key, manager):
+    """src/global_pooling_cpu.cpp:43-238 -> (out_feat [batch, C], num_nonzero [batch] | max_index [batch, C]).
+    max_index holds flat indices row * C + channel for every batch size (the reference returns plain row
+    indices when the batch size is 1, global_pooling_cpu.cpp:99-101, and then mis-scatters them)."""
+    _check_feat("in_feat", in_feat)
+    _check(in_feat.dim() == 2, "Invalid in_feat.dim():", in_feat.dim())
+    _check(manager.exists(in_key), "coordinate map not found")
+    _check(in_feat.shape[0] == manager.size(in_key), "Invalid in_feat size")
+    mode = PoolingMode(int(pooling_mode))
+    _check(mode in _GLOBAL_SUM + _GLOBAL_AVG + _GLOBAL_MAX, "Invalid pooling mode")
+    if not out_key.is_key_set():
+        out_key.set_key(manager.origin().get_key())
+    rows = manager._origin_rows(in_key)
+    n_batch = manager.size(out_key)
+    m = 2 if mode in _GLOBAL_MAX else (1 if mode in _GLOBAL_AVG else 0)
+    out, arg, cnt = _global_pool(in_feat, None, rows, n_batch, m)
+    return out, (arg if m == 2 else cnt)
+
+
+def GlobalPoolingBackwardGPU(in_feat, grad_out_feat, num_nonzero, pooling_mode, in_key, out_key, manager):
+    """src/global_pooling_cpu.cpp:240-326 -> grad_in_feat."""
+    if not grad_out_feat.is_contiguous():
+        grad_out_feat = grad_out_feat.contiguous()
+    _check_feat("grad_out_feat", grad_out_feat)
+    mode = PoolingMode(int(pooling_mode))
+    n, c = int(in_feat.shape[0]), int(in_feat.shape[1])
+    dev = in_feat.device
+    if mode in _GLOBAL_MAX:
+        grad_in = torch.zeros((n, c), dtype=torch.float32, device=dev)
+        valid = num_nonzero.reshape(-1) >= 0
+        grad_in.view(-1)[num_nonzero.reshape(-1)[valid].long()] = grad_out_feat.reshape(-1)[valid]
+        return grad_in
+    g = grad_out_feat
+    if mode in _GLOBAL_AVG:
+        g = (g / num_nonzero.clamp_min(1.0)[:, None]).contiguous()
+    rows = manager._origin_rows(in_key)
+    lib = _lib.load()
+    grad_in = torch.empty((n, c), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.me_broadcast_f32(None, _ptr(g), _ptr(rows), n, c, 0, _ptr(grad_in), _stream(dev)))
+    return grad_in
+
+
+def BroadcastForwardGPU(in_feat, in_feat_glob, broadcast_mode, in_key, glob_key, manager):
+    """src/broadcast_cpu.cpp:38-97: out[i] = in[i] (+ | *) glob[batch of i]."""
+    _check_feat("in_feat", in_feat)
+    _check_feat("in_feat_glob", in_feat_glob)
+    _check(in_feat.shape[1] == in_feat_glob.shape[1], "feature sizes must match")
+    _check(in_feat.shape[0] == manager.size(in_key), "Invalid in_feat size")
+    _check(in_feat_glob.shape[0] == manager.size(glob_key), "Invalid in_feat_glob size")
+    op = BroadcastMode(int(broadcast_mode))
+    rows = manager._origin_rows(in_key)
+    lib = _lib.load()
+    dev = in_feat.device
+    out = torch.empty_like(in_feat)
+    with torch.cuda.device(dev):
+        _lib.check(lib.me_broadcast_f32(_ptr(in_feat), _ptr(in_feat_glob), _ptr(rows), in_feat.shape[0],
+                                        in_feat.shape[1], 1 if op == BroadcastMode.ELEMENTWISE_MULTIPLICATION else 0,
+                                        _ptr(out), _stream(dev)))
+    return out
+
+
+def BroadcastBackwardGPU(in_feat, in_feat_glob, grad_out_feat, broadcast_mode, in_key, glob_key, manager):
+    """src/broadcast_cpu.cpp:99-160 -> (grad_in_feat, grad_in_feat_glob)."""
+    if not grad_out_feat.is_contiguous():
+        grad_out_feat = grad_out_feat.contiguous()
+    _check_feat("grad_out_feat", grad_out_feat)
+    op = BroadcastMode(int(broadcast_mode))
+    rows = manager._origin_rows(in_key)
+    n_batch = int(in_feat_glob.shape[0])
+    lib = _lib.load()
+    dev = in_feat.device
+    if op == BroadcastMode.ELEMENTWISE_ADDITON:
+        grad_in = grad_out_feat.clone()
+        grad_glob, _, _ = _global_pool(grad_out_feat, None, rows, n_batch, 0)
+    else:
+        grad_in = torch.empty_like(in_feat)
+        with torch.cuda.device(dev):
+            _lib.check(lib.me_broadcast_f32(_ptr(grad_out_feat), _ptr(in_feat_glob), _ptr(rows), in_feat.shape[0],
+                                            in_feat.shape[1], 1, _ptr(grad_in), _stream(dev)))
+        grad_glob, _, _ = _global_pool(grad_out_feat, in_feat, rows, n_batch, 0)
+    return grad_in, grad_glob

@@ -75,6 +75,16 @@ class CoordinateManager:
             key = CoordinateMapKey(convert_to_int_list(key, self.D), "")
         return self._manager.get_coordinates(key)
 
+    def origin(self):
+        """Key of the origin map: one row per batch index (MinkowskiCoordinateManager.py:224-226)."""
+        return self._manager.origin()
+
+    def origin_map(self, key):
+        return self._manager.origin_map(key)
+
+    def origin_map_size(self):
+        return self._manager.origin_map_size()
+
     def get_unique_coordinate_map_key(self, tensor_stride):
         ts = convert_to_int_list(tensor_stride, self.D)
         sid = self._manager.get_random_string_id(ts, "")

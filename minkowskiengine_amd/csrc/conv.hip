@@ -485,15 +485,16 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 3)) void k_wgrad_f32(const floa
       constexpr bool CHECK = decltype(check)::value;
 #pragma unroll
       for (int st = 0; st < 16; ++st) {
-        if (CHECK && st >= nsteps) break;  // wave-uniform
-        const int d = st % DEPTH;
-        mma_step(ra[d], rb[d]);
-        load_piece<MB, VEC, CHECK>(x, ri_nx, c_in, cha, ra[d]);
-        load_piece<NB, VEC, CHECK>(dy, ro_nx, c_out, chb, rb[d]);
-        permute(st + DEPTH + 1);
-        // keep hipcc's scheduler from sinking the refill loads down to their use DEPTH steps later
-        // (it would trade the whole prefetch distance for a few registers)
-        __builtin_amdgcn_sched_barrier(0);
+        if (!CHECK || st < nsteps) {  // wave-uniform
+          const int d = st % DEPTH;
+          mma_step(ra[d], rb[d]);
+          load_piece<MB, VEC, CHECK>(x, ri_nx, c_in, cha, ra[d]);
+          load_piece<NB, VEC, CHECK>(dy, ro_nx, c_out, chb, rb[d]);
+          permute(st + DEPTH + 1);
+          // keep hipcc's scheduler from sinking the refill loads down to their use DEPTH steps later
+          // (it would trade the whole prefetch distance for a few registers)
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
       pin = pin_n;
       pout = pout_n;

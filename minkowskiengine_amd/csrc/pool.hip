@@ -1,0 +1,382 @@
+// Pooling and broadcast kernels for gfx950 (MI355X): local sum / average / max pooling, global pooling
+// over the rows of each batch index, and broadcast of one feature row per batch index.
+//
+// Replace NonzeroAvgPooling{Forward,Backward}KernelGPU, MaxPooling{Forward,Backward}KernelGPU and the
+// broadcast kernels (src/pooling_avg_kernel.cu, src/pooling_max_kernel.cu, src/broadcast_kernel.cu; CPU
+// twins src/pooling_avg_kernel.hpp:41-150, src/pooling_max_kernel.hpp:36-117,
+// src/broadcast_kernel.hpp:35-160).  The reference scatters over the pair lists (cuSPARSE SpMM for the
+// sums, one atomic per element otherwise); here every kernel is TARGET-stationary on the dense
+// neighbour tables the convolution already uses (nbr[k][target row] -> source row or -1): a thread owns
+// a (target row, 16-byte channel piece), walks the kernel offsets in ascending k and writes its result
+// once — no atomics, no zero-fill pass, and the summation order is the reference CPU order (k ascending),
+// so sums and averages are bitwise reproducible.  All of them are HBM-bound gathers:
+// bytes = 4*C*(pairs + targets) + 4*K*targets of table.
+#include "common.hpp"
+
+#include <float.h>
+
+namespace me {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// V consecutive channels (V = 4: one 16-byte access; V = 1 when C is not a multiple of 4)
+template <int V>
+struct Piece {
+  float v[V];
+};
+template <int V>
+__device__ __forceinline__ Piece<V> load_piece(const float *p) {
+  Piece<V> r;
+  if constexpr (V == 4) {
+    const f32x4 t = *reinterpret_cast<const f32x4 *>(p);
+    r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+  } else {
+    r.v[0] = *p;
+  }
+  return r;
+}
+template <int V>
+__device__ __forceinline__ void store_piece(float *p, const Piece<V> &r) {
+  if constexpr (V == 4) *reinterpret_cast<f32x4 *>(p) = f32x4{r.v[0], r.v[1], r.v[2], r.v[3]};
+  else *p = r.v[0];
+}
+
+// dst[t] = sum over k of src[tbl[k][t]]            (src_count == nullptr)
+//        = sum over k of src[s] / src_count[s]      (src_count != nullptr: average-pooling backward,
+//                                                    src/pooling_avg_kernel.hpp:118-127)
+// then divided by the number of summed rows when `average` (forward, :96-108); that number is written to
+// dst_count when given.
+template <int V>
+__global__ __launch_bounds__(256) void k_pool_sum(const float *__restrict__ src, int c,
+                                                 const int32_t *__restrict__ tbl, int64_t n_tgt, int volume,
+                                                 const float *__restrict__ src_count, int average,
+                                                 float *__restrict__ dst, float *__restrict__ dst_count) {
+  const int pieces = c / V;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_tgt * pieces) return;
+  const int64_t t = idx / pieces;
+  const int ch = (int)(idx % pieces) * V;
+  Piece<V> acc;
+#pragma unroll
+  for (int j = 0; j < V; ++j) acc.v[j] = 0.f;
+  float cnt = 0.f;
+  for (int k = 0; k < volume; ++k) {
+    const int32_t s = tbl[(int64_t)k * n_tgt + t];
+    if (s < 0) continue;
+    const Piece<V> x = load_piece<V>(src + (int64_t)s * c + ch);
+    if (src_count) {
+      const float d = src_count[s];
+      if (d > 0.f) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) acc.v[j] += x.v[j] / d;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < V; ++j) acc.v[j] += x.v[j];
+    }
+    cnt += 1.f;
+  }
+  if (average && cnt > 0.f) {
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc.v[j] /= cnt;
+  }
+  store_piece<V>(dst + t * c + ch, acc);
+  if (dst_count && ch == 0) dst_count[t] = cnt;
+}
+
+// dst[t][c] = max over k of src[tbl[k][t]][c], mask[t][c] = flat index (source row * C + c) of the
+// first maximum in k order, -FLT_MAX / -1 for rows without neighbours (src/pooling_max_kernel.hpp:36-96)
+template <int V>
+__global__ __launch_bounds__(256) void k_pool_max(const float *__restrict__ src, int c,
+                                                 const int32_t *__restrict__ tbl, int64_t n_tgt, int volume,
+                                                 float *__restrict__ dst, int32_t *__restrict__ mask) {
+  const int pieces = c / V;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_tgt * pieces) return;
+  const int64_t t = idx / pieces;
+  const int ch = (int)(idx % pieces) * V;
+  Piece<V> best;
+  int32_t arg[V];
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    best.v[j] = -FLT_MAX;
+    arg[j] = -1;
+  }
+  for (int k = 0; k < volume; ++k) {
+    const int32_t s = tbl[(int64_t)k * n_tgt + t];
+    if (s < 0) continue;
+    const Piece<V> x = load_piece<V>(src + (int64_t)s * c + ch);
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      if (best.v[j] < x.v[j]) {
+        best.v[j] = x.v[j];
+        arg[j] = s * c + ch + j;
+      }
+    }
+  }
+  store_piece<V>(dst + t * c + ch, best);
+#pragma unroll
+  for (int j = 0; j < V; ++j) mask[t * c + ch + j] = arg[j];
+}
+
+// grad_in[i][c] = sum over k of grad_out[o][c] for the output rows o = tblT[k][i] whose maximum came
+// from (i, c)  (src/pooling_max_kernel.hpp:98-117, without its scatter)
+template <int V>
+__global__ __launch_bounds__(256) void k_pool_max_backward(const float *__restrict__ grad_out, int c,
+                                                          const int32_t *__restrict__ tbl_in, int64_t n_in,
+                                                          int volume, const int32_t *__restrict__ mask,
+                                                          float *__restrict__ grad_in) {
+  const int pieces = c / V;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_in * pieces) return;
+  const int64_t i = idx / pieces;
+  const int ch = (int)(idx % pieces) * V;
+  Piece<V> acc;
+#pragma unroll
+  for (int j = 0; j < V; ++j) acc.v[j] = 0.f;
+  for (int k = 0; k < volume; ++k) {
+    const int32_t o = tbl_in[(int64_t)k * n_in + i];
+    if (o < 0) continue;
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      if (mask[(int64_t)o * c + ch + j] == (int32_t)(i * c + ch + j)) acc.v[j] += grad_out[(int64_t)o * c + ch + j];
+    }
+  }
+  store_piece<V>(grad_in + i * c + ch, acc);
+}
+
+// ---- global pooling: reduce the rows of each batch index (origin map row) -------------------------
+// Stage 1: a workgroup walks kGlobalChunk consecutive rows, one thread per channel, and keeps a running
+// value for the batch row of the current run of rows; runs are added into partial[chunk][b][c] by the
+// same thread every time (deterministic).  Stage 2 combines the chunks in order.
+constexpr int kGlobalChunk = 256;
+
+template <bool MAX>
+__global__ __launch_bounds__(256) void k_global_partial(const float *__restrict__ src,
+                                                       const float *__restrict__ src2, int c,
+                                                       const int32_t *__restrict__ batch_row, int64_t n,
+                                                       int n_batch, float *__restrict__ partial,
+                                                       int32_t *__restrict__ partial_arg,
+                                                       float *__restrict__ partial_cnt) {
+  const int64_t chunk = blockIdx.x;
+  const int64_t r0 = chunk * kGlobalChunk;
+  const int64_t r1 = min(n, r0 + kGlobalChunk);
+  float *pp = partial + chunk * n_batch * c;
+  int32_t *pa = MAX ? partial_arg + chunk * n_batch * c : nullptr;
+  for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
+    int cur = -1;
+    float acc = 0.f;
+    int32_t arg = -1;
+    float cnt = 0.f;
+    auto flush = [&]() {
+      if (cur < 0) return;
+      if (MAX) {
+        if (pp[(int64_t)cur * c + ch] < acc) {
+          pp[(int64_t)cur * c + ch] = acc;
+          pa[(int64_t)cur * c + ch] = arg;
+        }
+      } else {
+        pp[(int64_t)cur * c + ch] += acc;
+        if (ch == 0 && partial_cnt) partial_cnt[chunk * n_batch + cur] += cnt;
+      }
+    };
+    for (int64_t r = r0; r < r1; ++r) {
+      const int b = batch_row[r];
+      if (b != cur) {
+        flush();
+        cur = b;
+        acc = MAX ? -FLT_MAX : 0.f;
+        arg = -1;
+        cnt = 0.f;
+      }
+      float x = src[r * c + ch];
+      if (src2) x *= src2[r * c + ch];
+      if (MAX) {
+        if (acc < x) {
+          acc = x;
+          arg = (int32_t)(r * c + ch);
+        }
+      } else {
+        acc += x;
+        cnt += 1.f;
+      }
+    }
+    flush();
+  }
+}
+
+template <bool MAX>
+__global__ __launch_bounds__(256) void k_global_final(const float *__restrict__ partial,
+                                                     const int32_t *__restrict__ partial_arg,
+                                                     const float *__restrict__ partial_cnt, int64_t chunks,
+                                                     int n_batch, int c, int average,
+                                                     float *__restrict__ dst, int32_t *__restrict__ dst_arg,
+                                                     float *__restrict__ dst_cnt) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)n_batch * c) return;
+  const int b = (int)(idx / c);
+  if (MAX) {
+    float best = -FLT_MAX;
+    int32_t arg = -1;
+    for (int64_t q = 0; q < chunks; ++q) {
+      const float v = partial[q * n_batch * c + idx];
+      if (best < v) {
+        best = v;
+        arg = partial_arg[q * n_batch * c + idx];
+      }
+    }
+    dst[idx] = best;
+    dst_arg[idx] = arg;
+  } else {
+    float s = 0.f, cnt = 0.f;
+    for (int64_t q = 0; q < chunks; ++q) {
+      s += partial[q * n_batch * c + idx];
+      if (partial_cnt) cnt += partial_cnt[q * n_batch + b];
+    }
+    if (average && cnt > 0.f) s /= cnt;
+    dst[idx] = s;
+    if (dst_cnt && idx % c == 0) dst_cnt[b] = cnt;
+  }
+}
+
+// out[i][c] = in[i][c] (+ | *) glob[batch_row[i]][c]; with in == nullptr: out[i][c] = glob[...][c]
+template <int V>
+__global__ __launch_bounds__(256) void k_broadcast(const float *__restrict__ in, const float *__restrict__ glob,
+                                                  const int32_t *__restrict__ batch_row, int64_t n, int c,
+                                                  int multiply, float *__restrict__ out) {
+  const int pieces = c / V;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * pieces) return;
+  const int64_t i = idx / pieces;
+  const int ch = (int)(idx % pieces) * V;
+  const Piece<V> g = load_piece<V>(glob + (int64_t)batch_row[i] * c + ch);
+  Piece<V> r = g;
+  if (in) {
+    const Piece<V> x = load_piece<V>(in + i * c + ch);
+#pragma unroll
+    for (int j = 0; j < V; ++j) r.v[j] = multiply ? x.v[j] * g.v[j] : x.v[j] + g.v[j];
+  }
+  store_piece<V>(out + i * c + ch, r);
+}
+
+}  // namespace me
+
+using namespace me;
+
+extern "C" {
+
+int me_pool_sum_f32(const float *src, int32_t c, const int32_t *tbl, int64_t n_tgt, int64_t volume,
+                    const float *src_count, int32_t average, float *dst, float *dst_count, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ME_CHECK(c > 0 && volume >= 1 && volume <= 65535, "invalid channel count or kernel volume");
+  if (n_tgt == 0) return 0;
+  const bool vec = (c % 4) == 0 && (uintptr_t)src % 16 == 0 && (uintptr_t)dst % 16 == 0;
+  const int64_t total = n_tgt * (vec ? c / 4 : c);
+  const dim3 grid((unsigned)ceil_div(total, 256)), block(256);
+  if (vec)
+    hipLaunchKernelGGL(k_pool_sum<4>, grid, block, 0, stream, src, c, tbl, n_tgt, (int)volume, src_count, average,
+                       dst, dst_count);
+  else
+    hipLaunchKernelGGL(k_pool_sum<1>, grid, block, 0, stream, src, c, tbl, n_tgt, (int)volume, src_count, average,
+                       dst, dst_count);
+  ME_LAUNCH_CHECK();
+  return 0;
+}
+
+int me_pool_max_f32(const float *src, int32_t c, const int32_t *tbl, int64_t n_tgt, int64_t volume, float *dst,
+                    int32_t *mask, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ME_CHECK(c > 0 && volume >= 1 && volume <= 65535, "invalid channel count or kernel volume");
+  if (n_tgt == 0) return 0;
+  const bool vec = (c % 4) == 0 && (uintptr_t)src % 16 == 0 && (uintptr_t)dst % 16 == 0;
+  const int64_t total = n_tgt * (vec ? c / 4 : c);
+  const dim3 grid((unsigned)ceil_div(total, 256)), block(256);
+  if (vec) hipLaunchKernelGGL(k_pool_max<4>, grid, block, 0, stream, src, c, tbl, n_tgt, (int)volume, dst, mask);
+  else hipLaunchKernelGGL(k_pool_max<1>, grid, block, 0, stream, src, c, tbl, n_tgt, (int)volume, dst, mask);
+  ME_LAUNCH_CHECK();
+  return 0;
+}
+
+int me_pool_max_backward_f32(const float *grad_out, int32_t c, const int32_t *tbl_in, int64_t n_in,
+                             int64_t volume, const int32_t *mask, float *grad_in, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ME_CHECK(c > 0 && volume >= 1 && volume <= 65535, "invalid channel count or kernel volume");
+  if (n_in == 0) return 0;
+  const bool vec = (c % 4) == 0 && (uintptr_t)grad_in % 16 == 0;
+  const int64_t total = n_in * (vec ? c / 4 : c);
+  const dim3 grid((unsigned)ceil_div(total, 256)), block(256);
+  if (vec)
+    hipLaunchKernelGGL(k_pool_max_backward<4>, grid, block, 0, stream, grad_out, c, tbl_in, n_in, (int)volume, mask,
+                       grad_in);
+  else
+    hipLaunchKernelGGL(k_pool_max_backward<1>, grid, block, 0, stream, grad_out, c, tbl_in, n_in, (int)volume, mask,
+                       grad_in);
+  ME_LAUNCH_CHECK();
+  return 0;
+}
+
+int64_t me_global_pool_workspace_bytes(int64_t n, int32_t n_batch, int32_t c) {
+  const int64_t chunks = ceil_div(n < 1 ? 1 : n, kGlobalChunk);
+  // partial values | partial argmax | partial counts
+  return align_up(chunks * n_batch * c * 4, 256) * 2 + align_up(chunks * n_batch * 4, 256);
+}
+
+int me_global_pool_f32(const float *src, const float *src2, int32_t c, const int32_t *batch_row, int64_t n,
+                       int32_t n_batch, int32_t mode, float *dst, int32_t *dst_arg, float *dst_count,
+                       void *workspace, int64_t workspace_bytes, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ME_CHECK(c > 0 && n_batch > 0, "invalid channel count or batch size");
+  ME_CHECK(mode >= 0 && mode <= 2, "mode must be 0 (sum), 1 (average) or 2 (max)");
+  ME_CHECK(mode != 2 || dst_arg != nullptr, "max pooling needs the argmax output");
+  ME_CHECK(workspace_bytes >= me_global_pool_workspace_bytes(n, n_batch, c), "workspace too small");
+  const int64_t chunks = ceil_div(n < 1 ? 1 : n, kGlobalChunk);
+  const int64_t vsz = align_up(chunks * n_batch * c * 4, 256);
+  float *partial = reinterpret_cast<float *>(workspace);
+  int32_t *partial_arg = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(workspace) + vsz);
+  float *partial_cnt = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + 2 * vsz);
+  const int64_t total = (int64_t)n_batch * c;
+  if (mode == 2) {
+    // -FLT_MAX / -1 start values
+    const dim3 fgrid((unsigned)ceil_div(chunks * total, 256));
+    (void)fgrid;
+    ME_HIP(hipMemsetAsync(partial_arg, 0xff, (size_t)chunks * total * 4, stream));
+    // 0xff7fffff = -FLT_MAX: fill with a 32-bit pattern
+    ME_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(partial), (int)0xff7fffff, (size_t)chunks * total, stream));
+    if (n > 0) {
+      hipLaunchKernelGGL(k_global_partial<true>, dim3((unsigned)chunks), dim3(256), 0, stream, src, src2, c,
+                         batch_row, n, n_batch, partial, partial_arg, partial_cnt);
+      ME_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_global_final<true>, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream, partial,
+                       partial_arg, partial_cnt, chunks, n_batch, c, 0, dst, dst_arg, dst_count);
+  } else {
+    ME_HIP(hipMemsetAsync(partial, 0, (size_t)chunks * total * 4, stream));
+    ME_HIP(hipMemsetAsync(partial_cnt, 0, (size_t)chunks * n_batch * 4, stream));
+    if (n > 0) {
+      hipLaunchKernelGGL(k_global_partial<false>, dim3((unsigned)chunks), dim3(256), 0, stream, src, src2, c,
+                         batch_row, n, n_batch, partial, partial_arg, partial_cnt);
+      ME_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_global_final<false>, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream, partial,
+                       partial_arg, partial_cnt, chunks, n_batch, c, mode == 1, dst, dst_arg, dst_count);
+  }
+  ME_LAUNCH_CHECK();
+  return 0;
+}
+
+int me_broadcast_f32(const float *in, const float *glob, const int32_t *batch_row, int64_t n, int32_t c,
+                     int32_t multiply, float *out, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ME_CHECK(c > 0, "invalid channel count");
+  if (n == 0) return 0;
+  const bool vec = (c % 4) == 0 && (uintptr_t)glob % 16 == 0 && (uintptr_t)out % 16 == 0 &&
+                   (in == nullptr || (uintptr_t)in % 16 == 0);
+  const int64_t total = n * (vec ? c / 4 : c);
+  const dim3 grid((unsigned)ceil_div(total, 256)), block(256);
+  if (vec) hipLaunchKernelGGL(k_broadcast<4>, grid, block, 0, stream, in, glob, batch_row, n, c, multiply, out);
+  else hipLaunchKernelGGL(k_broadcast<1>, grid, block, 0, stream, in, glob, batch_row, n, c, multiply, out);
+  ME_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

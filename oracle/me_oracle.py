@@ -188,6 +188,81 @@ def conv_backward(in_feat, grad_out, kernel, kmap, dtype=np.float64):
     return grad_in, grad_kernel
 
 
+# ---- pooling / broadcast (numpy restatement; float32 by default to follow the reference's arithmetic) --------
+def pool_forward(in_feat, kmap, n_out, mode, dtype=np.float32):
+    """mode "sum" | "avg" | "max" -> (out, num_nonzero | max_index).
+    NonzeroAvgPoolingForwardKernelCPU (pooling_avg_kernel.hpp:41-108) / MaxPoolingForwardKernelCPU
+    (pooling_max_kernel.hpp:36-96): offsets in ascending k, rows in list order."""
+    x = np.asarray(in_feat, dtype=dtype)
+    c = x.shape[1]
+    if mode == "max":
+        out = np.full((n_out, c), -np.finfo(dtype).max, dtype)
+        idx = np.full((n_out, c), -1, np.int32)
+        for k in sorted(kmap):
+            for i, o in zip(*[np.asarray(a) for a in kmap[k]]):
+                better = out[o] < x[i]
+                out[o] = np.where(better, x[i], out[o])
+                idx[o] = np.where(better, i * c + np.arange(c), idx[o])
+        return out, idx
+    out = np.zeros((n_out, c), dtype)
+    cnt = np.zeros(n_out, dtype)
+    for k in sorted(kmap):
+        for i, o in zip(*[np.asarray(a) for a in kmap[k]]):
+            out[o] += x[i]
+            cnt[o] += 1
+    if mode == "avg":
+        nz = cnt > 0
+        out[nz] = out[nz] / cnt[nz, None]
+    return out, cnt
+
+
+def pool_backward(grad_out, kmap, n_in, mode, aux, dtype=np.float32):
+    """aux = num_nonzero (avg) / max_index (max).  pooling_avg_kernel.hpp:110-150,
+    pooling_max_kernel.hpp:98-117."""
+    g = np.asarray(grad_out, dtype=dtype)
+    c = g.shape[1]
+    grad_in = np.zeros((n_in, c), dtype)
+    if mode == "max":
+        flat = grad_in.reshape(-1)
+        m = np.asarray(aux).reshape(-1)
+        np.add.at(flat, m[m >= 0], g.reshape(-1)[m >= 0])
+        return grad_in
+    for k in sorted(kmap):
+        for i, o in zip(*[np.asarray(a) for a in kmap[k]]):
+            if mode == "avg":
+                if aux[o] > 0:
+                    grad_in[i] += g[o] / dtype(aux[o])
+            else:
+                grad_in[i] += g[o]
+    return grad_in
+
+
+def global_pool_forward(in_feat, batch_rows, n_batch, mode, dtype=np.float32):
+    """Rows of every batch index reduced in row order (global_pooling_cpu.cpp:43-238)."""
+    x = np.asarray(in_feat, dtype=dtype)
+    rows = np.asarray(batch_rows)
+    c = x.shape[1]
+    if mode == "max":
+        out = np.full((n_batch, c), -np.finfo(dtype).max, dtype)
+        idx = np.full((n_batch, c), -1, np.int32)
+        for i, b in enumerate(rows):
+            better = out[b] < x[i]
+            out[b] = np.where(better, x[i], out[b])
+            idx[b] = np.where(better, i * c + np.arange(c), idx[b])
+        return out, idx
+    out = np.zeros((n_batch, c), np.float64)
+    np.add.at(out, rows, x.astype(np.float64))
+    cnt = np.bincount(rows, minlength=n_batch).astype(dtype)
+    if mode == "avg":
+        out = out / np.maximum(cnt, 1)[:, None]
+    return out.astype(dtype), cnt
+
+
+def broadcast_forward(in_feat, glob, batch_rows, multiply):
+    x, g = np.asarray(in_feat), np.asarray(glob)[np.asarray(batch_rows)]
+    return x * g if multiply else x + g
+
+
 # ---- canonicalisers (SURVEY.md §0.3: how "bit-exact index maps" is defined) ----------------------
 def pairs_by_offset(kmap):
     """{k: [2, n_k] array-like} -> {k: sorted int64 [n_k, 2] of (in, out)}; empty offsets dropped."""

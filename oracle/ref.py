@@ -74,3 +74,53 @@ class RefConv:
 
     def out_coordinates(self):
         return self.manager.get_coordinates(self.out_key)
+
+
+class RefPool(RefConv):
+    """Reference CPU pooling / broadcast operators on fixed coordinates (src/local_pooling_cpu.cpp,
+    src/global_pooling_cpu.cpp, src/broadcast_cpu.cpp)."""
+
+    def _mode(self, name):
+        PM = self.C.PoolingMode
+        return {"sum": PM.LOCAL_SUM_POOLING, "avg": PM.LOCAL_AVG_POOLING, "max": PM.LOCAL_MAX_POOLING,
+                "gsum": PM.GLOBAL_SUM_POOLING_KERNEL, "gavg": PM.GLOBAL_AVG_POOLING_KERNEL,
+                "gmax": PM.GLOBAL_MAX_POOLING_KERNEL}[name]
+
+    def pool_forward(self, feats, mode):
+        C = self.C
+        return C.LocalPoolingForwardCPU(feats, self.kernel_size, self.stride, self.dilation, C.RegionType.HYPER_CUBE,
+                                        self.empty_offset, self._mode(mode), self.in_key, self.out_key, self.manager)
+
+    def pool_backward(self, feats, grad_out, aux, mode):
+        C = self.C
+        return C.LocalPoolingBackwardCPU(feats, grad_out, aux, self.kernel_size, self.stride, self.dilation,
+                                         C.RegionType.HYPER_CUBE, self.empty_offset, self._mode(mode), self.in_key,
+                                         self.out_key, self.manager)
+
+    def pool_kernel_map(self):
+        C = self.C
+        return self.manager.kernel_map(self.in_key, self.out_key, self.kernel_size, self.stride, self.dilation,
+                                       C.RegionType.HYPER_CUBE, self.empty_offset, False, True)
+
+    def global_forward(self, feats, mode):
+        C = self.C
+        self.glob_key = C.CoordinateMapKey(self.D + 1)
+        return C.GlobalPoolingForwardCPU(feats, self._mode("g" + mode), self.in_key, self.glob_key, self.manager)
+
+    def global_backward(self, feats, grad_out, aux, mode):
+        C = self.C
+        return C.GlobalPoolingBackwardCPU(feats, grad_out, aux, self._mode("g" + mode), self.in_key, self.glob_key,
+                                          self.manager)
+
+    def glob_coordinates(self):
+        return self.manager.get_coordinates(self.glob_key)
+
+    def broadcast_forward(self, feats, glob, multiply):
+        C = self.C
+        op = C.BroadcastMode.ELEMENTWISE_MULTIPLICATION if multiply else C.BroadcastMode.ELEMENTWISE_ADDITON
+        return C.BroadcastForwardCPU(feats, glob, op, self.in_key, self.glob_key, self.manager)
+
+    def broadcast_backward(self, feats, glob, grad_out, multiply):
+        C = self.C
+        op = C.BroadcastMode.ELEMENTWISE_MULTIPLICATION if multiply else C.BroadcastMode.ELEMENTWISE_ADDITON
+        return C.BroadcastBackwardCPU(feats, glob, grad_out, op, self.in_key, self.glob_key, self.manager)

@@ -67,6 +67,42 @@ def conv_case(name, coords, cin, cout, kernel_size, stride=1, dilation=1, seed=0
     print(name, "n_in", n_in, "n_out", out.shape[0], "pairs", int(kn.sum()))
 
 
+def pool_case(name, coords, c, kernel_size, stride, seed=0):
+    """Local sum / avg / max pooling, global pooling and broadcast through the reference's CPU operators
+    (src/local_pooling_cpu.cpp, src/global_pooling_cpu.cpp, src/broadcast_cpu.cpp)."""
+    g = torch.Generator().manual_seed(seed)
+    rp = ref.RefPool(coords, kernel_size, stride)
+    n_in = rp.in_coordinates().shape[0]
+    n_out = rp.out_coordinates().shape[0]
+    feats = torch.rand(n_in, c, generator=g) - 0.5
+    grad_out = torch.rand(n_out, c, generator=g) - 0.5
+    kk, kn, kp = kmap_to_arrays(rp.pool_kernel_map())
+    data = dict(coords=coords.numpy().astype(np.int32), in_coords=rp.in_coordinates().numpy(),
+                out_coords=rp.out_coordinates().numpy(), kernel_size=np.array(rp.kernel_size, np.int32),
+                stride=np.array(rp.stride, np.int32), feats=feats.numpy(), grad_out=grad_out.numpy(),
+                kmap_k=kk, kmap_n=kn, kmap_pairs=kp)
+    for mode in ("sum", "avg", "max"):
+        out, aux = rp.pool_forward(feats, mode)
+        gin = rp.pool_backward(feats, grad_out, aux, mode)
+        data.update({mode + "_out": out.numpy(), mode + "_aux": aux.numpy(), mode + "_grad_in": gin.numpy()})
+    for mode in ("sum", "avg", "max"):
+        out, aux = rp.global_forward(feats, mode)
+        gglob = torch.rand(out.shape, generator=g) - 0.5
+        gin = rp.global_backward(feats, gglob, aux, mode)
+        data.update({"g" + mode + "_out": out.numpy(), "g" + mode + "_aux": aux.numpy(),
+                     "g" + mode + "_grad_out": gglob.numpy(), "g" + mode + "_grad_in": gin.numpy()})
+    data["glob_coords"] = rp.glob_coordinates().numpy()
+    glob = torch.rand(data["gsum_out"].shape, generator=g) - 0.5
+    gb = torch.rand(n_in, c, generator=g) - 0.5
+    for nm, mul in (("badd", False), ("bmul", True)):
+        out = rp.broadcast_forward(feats, glob, mul)
+        gi, gg = rp.broadcast_backward(feats, glob, gb, mul)
+        data.update({nm + "_out": out.numpy(), nm + "_grad_in": gi.numpy(), nm + "_grad_glob": gg.numpy()})
+    data.update(bglob=glob.numpy(), bgrad_out=gb.numpy())
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **data)
+    print(name, "n_in", n_in, "n_out", n_out, "pairs", int(kn.sum()))
+
+
 def cloud(n, extent, D, seed, batch=1, dup=0):
     g = torch.Generator().manual_seed(seed)
     parts = []
@@ -92,7 +128,16 @@ def data_loader_fixture(batch_size=2):
     return torch.IntTensor(coords)
 
 
+def make_pool_cases():
+    pool_case("pool_3d_k2s2_c16", cloud(700, 12, 3, 11, batch=3), 16, 2, 2)
+    pool_case("pool_3d_k3s1_c8", cloud(500, 10, 3, 12, batch=2), 8, 3, 1)
+    pool_case("pool_3d_k3s2_c5", cloud(500, 10, 3, 13, batch=2), 5, 3, 2)
+
+
 if __name__ == "__main__":
+    make_pool_cases()
+    if "--pool-only" in sys.argv:
+        sys.exit(0)
     # the reference's own fixture: conv k=3 s=2 -> 26 pairs / 10 output voxels (probe in SURVEY.md §8c)
     conv_case("ref_fixture2d_k3s2", data_loader_fixture(), 2, 3, 3, stride=2)
     # 1-D analytic case of tests/python/convolution.py:226-245
