@@ -68,7 +68,7 @@ def cold_path(ME, MEB, feats, coords, dev, n, D=3, K=27):
                                                  None, False, False))
         def plans():
             for tgt, (cs, cd) in (("out", (64, 128)), ("in", (128, 64))):
-                km.plan(tgt, MEB._lib.load().me_conv_choose_tile_rows(n, K, km.n_pairs, cs, cd))
+                km.plan(tgt, *MEB.plan_config(n, K, km.n_pairs, cs, cd))
         _, t_plan = timed(plans)
         for name, t in (("insert_ms", t_ins), ("kernel_map_ms", t_km), ("plans_ms", t_plan)):
             best[name] = min(best.get(name, 1e9), t)
@@ -221,10 +221,10 @@ def main():
                                    "(BASELINE configs[1])",
                        "points_per_gpu": n, "pairs_per_gpu": n_pairs, "pairs_total": int(pairs_all),
                        "parallelism": f"scene-sharded dp{world}, RCCL all-reduce of the weight gradient"},
-            "roofline": {"bound": "mfma", "kernel": "k_conv_target_f32<64,64> (forward)", "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": "k_conv_tile_f32<64,64> (forward)", "achieved": achieved,
                          "peak": PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / PEAK_F32_MATRIX_TFLOPS, 4),
-                         "traffic": pmc_traffic("k_conv_target_f32", n, args.extent, cin, cout),
+                         "traffic": pmc_traffic("k_conv_tile_f32", n, args.extent, cin, cout),
                          "traffic_note": "HBM-side bytes per launch (FETCH_SIZE x2 + WRITE_SIZE), rocprofv3 --pmc, "
                                          "profiles/pmc_traffic.json; compulsory bytes of the forward launch: "
                                          f"{int(4 * (n * cin + n * cout + 27 * cin * cout) + 8 * n_pairs)}",

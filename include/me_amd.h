@@ -79,6 +79,13 @@ int me_coords_stride(const int32_t *coords_dev, int64_t n, int32_t ncol,
                      const int32_t *out_tensor_stride /* host [ncol-1] */, int32_t *out_coords_dev,
                      void *stream);
 
+/* keys[i] = Z-order (Morton) key of coordinate row i: batch index on top, then the bit-interleaved
+ * spatial coordinates in units of the tensor stride.  Sorting target rows by this key gives the tile
+ * plan spatially compact tiles (their gathers then hit the L2 instead of HBM).  No reference
+ * counterpart (the reference never reorders work); the row order of the maps is NOT changed. */
+int me_coords_spatial_keys(const int32_t *coords_dev, int64_t n, int32_t ncol,
+                           const int32_t *tensor_stride /* host [ncol-1] */, int64_t *keys_dev, void *stream);
+
 /* rows[q] = row of query q in the map, or -1.  Replaces CoordinateMapGPU::find
  * (src/coordinate_map_gpu.cu:284-361). */
 int me_coords_find(const uint64_t *table_dev, int64_t capacity, const int32_t *map_coords_dev,
@@ -116,27 +123,34 @@ int me_kernel_map_transpose(const int32_t *in_pairs_dev, const int32_t *out_pair
 
 /* ---- tile plan for the target-stationary convolution ----------------------------------------- */
 /* A plan cuts the target rows into tiles of `tile_rows` consecutive rows (any value in
- * [ME_GROUP_ROWS, ME_MAX_TILE_ROWS]; me_conv_choose_tile_rows picks it so that tiles x column slabs
- * fill the GPU's workgroup slots evenly).  Per tile the valid (offset k, source row) entries are
- * grouped by k and padded to groups of 16 (one MFMA 16x16x4 M-tile per group). */
+ * [ME_GROUP_ROWS, ME_MAX_TILE_ROWS]; me_conv_plan_config picks it so that tiles x column slabs
+ * fill the GPU's workgroup slots evenly).  Per tile and kernel offset k ("item") the valid
+ * (k, source row) entries are padded to groups of 16 (one MFMA tile) and the groups are cut into
+ * batches of at most `batch_groups` groups; a batch is what the convolution kernel stages in LDS at
+ * once and never mixes offsets. */
 #define ME_GROUP_ROWS 16
 #define ME_MAX_TILE_ROWS 256
+#define ME_MAX_BATCH_GROUPS 4
 int64_t me_plan_num_tiles(int64_t n_tgt, int32_t tile_rows);
-/* upper bound on the number of groups for a table with n_pairs valid entries */
+/* upper bound on the number of groups (and of batches) for a table with n_pairs valid entries */
 int64_t me_plan_max_groups(int64_t n_tgt, int64_t volume, int64_t n_pairs, int32_t tile_rows);
 int64_t me_plan_workspace_bytes(int64_t n_tgt, int64_t volume, int32_t tile_rows);
 /*   tbl_dev        int32 [volume, n_tgt]  neighbour table (nbr for forward, nbrT for dgrad)
+ *   order_dev      int32 [n_tgt] or NULL   target rows in tile order: tile t owns the rows
+ *                                          order[t*tile_rows .. (t+1)*tile_rows)  (NULL = identity;
+ *                                          pass the argsort of me_coords_spatial_keys for compact tiles)
  *   plan_src_dev   int32 [16 * max_groups] (out) source row per slot, -1 = padding
  *   plan_dst_dev   int32 [16 * max_groups] (out) target row local to its tile; padding slots point at
- *                                                the dummy row `tile_rows`
- *   group_k_dev    int32 [max_groups]      (out) kernel offset of each group
- *   group_nk_dev   int32 [max_groups]      (out) next offset of the same tile that has groups, or -1
- *   tile_gptr_dev  int32 [num_tiles + 1]   (out) group range of each tile
+ *                                                the dummy row `tile_rows`; the global target row of
+ *                                                (tile t, local row d) is order[t * tile_rows + d]
+ *   batch_desc_dev int32 [2 * max_groups]  (out) per batch {first group, (k << 8) | number of groups}
+ *   tile_bptr_dev  int32 [num_tiles + 1]   (out) batch range of each tile
+ *   item_gptr_dev  int32 [num_tiles * volume + 1] (out) first group of each (tile, k) item
  */
-int me_plan_build(const int32_t *tbl_dev, int64_t n_tgt, int64_t volume, int32_t tile_rows,
-                  int32_t *plan_src_dev, int32_t *plan_dst_dev, int32_t *group_k_dev,
-                  int32_t *group_nk_dev, int32_t *tile_gptr_dev, void *workspace_dev,
-                  int64_t workspace_bytes, void *stream);
+int me_plan_build(const int32_t *tbl_dev, const int32_t *order_dev, int64_t n_tgt, int64_t volume,
+                  int32_t tile_rows, int32_t batch_groups, int32_t *plan_src_dev, int32_t *plan_dst_dev,
+                  int32_t *batch_desc_dev, int32_t *tile_bptr_dev, int32_t *item_gptr_dev,
+                  void *workspace_dev, int64_t workspace_bytes, void *stream);
 
 /* ---- convolution feature kernels (replace ConvolutionForwardKernelGPU / BackwardKernelGPU,
  *      src/convolution_kernel.cu:320-496, 553-757; CPU twins src/convolution_kernel.hpp:33-144) -- */
@@ -154,23 +168,25 @@ int me_conv_pack_weights_f32(const float *w_dev, int64_t volume, int32_t c_src, 
 /* Target-stationary gather -> LDS -> MFMA(fp32 16x16x4) -> LDS accumulate -> one coalesced store.
  *   dst[t, :] = sum over plan entries (k, s) of tile(t):  src[s, :] @ w[k]      (w[k]: [c_src, c_dst])
  * Forward: src = in_feat, packed kernel, plan from nbr.  dgrad: src = grad_out, kernel packed with
- * transposed = 1, plan from nbrT.  Every target row is written (rows without entries get zeros). */
+ * transposed = 1, plan from nbrT.  Every target row is written (rows without entries get zeros).
+ * The plan must have been built with the same tile_rows / batch_groups. */
 int me_conv_target_f32(const float *src_feat_dev, int64_t n_src, int32_t c_src,
                        const float *packed_w_dev, int64_t volume, int32_t c_dst,
                        const int32_t *plan_src_dev, const int32_t *plan_dst_dev,
-                       const int32_t *group_k_dev, const int32_t *tile_gptr_dev, float *dst_feat_dev,
-                       int64_t n_tgt, int32_t tile_rows, void *stream);
+                       const int32_t *batch_desc_dev, const int32_t *tile_bptr_dev,
+                       const int32_t *order_dev /* as given to me_plan_build, or NULL */, float *dst_feat_dev,
+                       int64_t n_tgt, int32_t tile_rows, int32_t batch_groups, void *stream);
 
-/* Tile height for a (target rows, channels) problem: the largest tile that still fits the LDS budget
- * of the chosen kernel variant while tiles x column slabs is just below a multiple of the GPU's
- * resident-workgroup slots (a 100k-voxel layer is only ~2 workgroup rounds long, so an unlucky tile
- * count can idle a third of the chip).  n_pairs steers the trade-off against 16-row group padding. */
-int32_t me_conv_choose_tile_rows(int64_t n_tgt, int64_t volume, int64_t n_pairs, int32_t c_src,
-                                 int32_t c_dst);
+/* Plan geometry for a (target rows, channels) problem: the tile height is chosen so that tiles x column
+ * slabs is just below a multiple of the GPU's resident-workgroup slots (a 100k-voxel layer is only
+ * ~2 workgroup rounds long, so an unlucky tile count can idle a third of the chip) while the
+ * accumulator tile + two stage buffers of batch_groups groups fit the 160 KiB LDS; n_pairs (density)
+ * steers the trade-off against the 16-row group padding and sizes the batch. */
+int me_conv_plan_config(int64_t n_tgt, int64_t volume, int64_t n_pairs, int32_t c_src, int32_t c_dst,
+                        int32_t *tile_rows, int32_t *batch_groups);
 
 /* Tuning / ablation switch for me_conv_target_f32 (0 = shipped configuration; see conv.hip). */
 void me_debug_set_conv_variant(int variant);
-
 /* wt[k, j, i] = w[k, i, j] */
 int me_transpose_kernel_f32(const float *w_dev, int64_t volume, int32_t c_in, int32_t c_out,
                             float *wt_dev, void *stream);

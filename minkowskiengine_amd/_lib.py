@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libme_amd.so")
 ME_MAX_DIM = 7
 ME_MAX_TILE_ROWS = 256
 ME_GROUP_ROWS = 16
+ME_MAX_BATCH_GROUPS = 4
 
 c_i32, c_i64, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
 
@@ -43,6 +44,7 @@ SIGNATURES = {
     "me_coords_insert_and_map": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp, c_vp, _P_I64,
                                                 c_vp, c_i64, c_vp]),
     "me_coords_stride": (ctypes.c_int, [c_vp, c_i64, c_i32, _P_I32, c_vp, c_vp]),
+    "me_coords_spatial_keys": (ctypes.c_int, [c_vp, c_i64, c_i32, _P_I32, c_vp, c_vp]),
     "me_coords_find": (ctypes.c_int, [c_vp, c_i64, c_vp, c_i32, c_vp, c_i64, c_vp, c_vp]),
     "me_kernel_map_workspace_bytes": (c_i64, [c_i64, c_i64]),
     "me_kernel_map_probe": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, _P_REGION, c_vp, _P_I64, c_vp,
@@ -52,13 +54,13 @@ SIGNATURES = {
     "me_plan_num_tiles": (c_i64, [c_i64, c_i32]),
     "me_plan_max_groups": (c_i64, [c_i64, c_i64, c_i64, c_i32]),
     "me_plan_workspace_bytes": (c_i64, [c_i64, c_i64, c_i32]),
-    "me_plan_build": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64,
-                                     c_vp]),
+    "me_plan_build": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                     c_i64, c_vp]),
     "me_conv_packed_weight_elems": (c_i64, [c_i64, c_i32, c_i32]),
     "me_conv_pack_weights_f32": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
-    "me_conv_target_f32": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp,
-                                          c_vp, c_i64, c_i32, c_vp]),
-    "me_conv_choose_tile_rows": (c_i32, [c_i64, c_i64, c_i64, c_i32, c_i32]),
+    "me_conv_target_f32": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                          c_vp, c_i64, c_i32, c_i32, c_vp]),
+    "me_conv_plan_config": (ctypes.c_int, [c_i64, c_i64, c_i64, c_i32, c_i32, _P_I32, _P_I32]),
     "me_debug_set_conv_variant": (None, [ctypes.c_int]),
     "me_transpose_kernel_f32": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
     "me_conv_wgrad_workspace_bytes": (c_i64, [_P_I64, c_i64, c_i32, c_i32]),

@@ -229,8 +229,9 @@ class KernelMapGPU:
     """
 
     def __init__(self, volume, n_in, n_out, k_offsets, k_offsets_dev, in_pairs, out_pairs, store=None,
-                 flip=False):
+                 flip=False, in_map=None, out_map=None):
         self.volume, self.n_in, self.n_out = int(volume), int(n_in), int(n_out)
+        self.in_map, self.out_map = in_map, out_map   # _CoordinateMapGPU of either side (spatial tile order)
         self.k_offsets = k_offsets            # host list of volume+1 ints
         self.k_offsets_dev = k_offsets_dev    # int64 [volume+1] on the device
         self.in_pairs, self.out_pairs = in_pairs, out_pairs
@@ -252,7 +253,8 @@ class KernelMapGPU:
 
     def swapped(self):
         return KernelMapGPU(self.volume, self.n_out, self.n_in, self.k_offsets, self.k_offsets_dev,
-                            self.out_pairs, self.in_pairs, store=self._store, flip=not self._flip)
+                            self.out_pairs, self.in_pairs, store=self._store, flip=not self._flip,
+                            in_map=self.out_map, out_map=self.in_map)
 
     def table(self, target):
         """target 'out': [volume, n_out] -> in row; target 'in': [volume, n_in] -> out row."""
@@ -271,10 +273,33 @@ class KernelMapGPU:
             self._store[name] = tbl
         return self._store[name]
 
-    def plan(self, target, tile_rows):
-        """Tile plan with `target` rows stationary and tiles of `tile_rows` rows:
-        (plan_src, plan_dst, group_k, group_nk, tile_gptr); built once per (target, tile_rows)."""
-        name = self._name("plan", target) + f"_{int(tile_rows)}"
+    def order(self, target):
+        """Target rows in tile order: the argsort of the Z-order keys of the target map's coordinates
+        (int32 [n_tgt]); None when disabled (ME_AMD_SPATIAL_TILES=0).  Tiles of spatially close rows
+        gather (almost) the same source rows for all kernel offsets -> L2 hits instead of HBM."""
+        if not _SPATIAL_TILES:
+            return None
+        name = self._name("order", target)
+        if name not in self._store:
+            cmap = self.out_map if target == "out" else self.in_map
+            if cmap is None or cmap.n == 0:
+                self._store[name] = None
+            else:
+                lib = _lib.load()
+                dev = self.device
+                keys = torch.empty(cmap.n, dtype=torch.int64, device=dev)
+                ts = (ctypes.c_int32 * len(cmap.tensor_stride))(*cmap.tensor_stride)
+                with torch.cuda.device(dev):
+                    _lib.check(lib.me_coords_spatial_keys(_ptr(cmap.coords), cmap.n, cmap.coords.shape[1], ts,
+                                                          _ptr(keys), _stream(dev)))
+                self._store[name] = torch.argsort(keys, stable=True).to(torch.int32)
+        return self._store[name]
+
+    def plan(self, target, tile_rows, batch_groups):
+        """Tile plan with `target` rows stationary, tiles of `tile_rows` rows and batches of at most
+        `batch_groups` groups: (plan_src, plan_dst, batch_desc, tile_bptr, item_gptr); built once per
+        (target, tile_rows, batch_groups)."""
+        name = self._name("plan", target) + f"_{int(tile_rows)}_{int(batch_groups)}"
         if name not in self._store:
             lib = _lib.load()
             dev = self.device
@@ -284,15 +309,16 @@ class KernelMapGPU:
             n_tiles = int(lib.me_plan_num_tiles(n_tgt, tile_rows))
             plan_src = torch.empty(max_groups * _lib.ME_GROUP_ROWS, dtype=torch.int32, device=dev)
             plan_dst = torch.empty(max_groups * _lib.ME_GROUP_ROWS, dtype=torch.int32, device=dev)
-            group_k = torch.empty(max_groups, dtype=torch.int32, device=dev)
-            group_nk = torch.empty(max_groups, dtype=torch.int32, device=dev)
-            tile_gptr = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
+            batch_desc = torch.empty(2 * max_groups, dtype=torch.int32, device=dev)
+            tile_bptr = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
+            item_gptr = torch.empty(n_tiles * self.volume + 1, dtype=torch.int32, device=dev)
             ws = _workspace(lib.me_plan_workspace_bytes(n_tgt, self.volume, tile_rows), dev)
+            order = self.order(target)
             with torch.cuda.device(dev):
-                _lib.check(lib.me_plan_build(_ptr(tbl), n_tgt, self.volume, tile_rows, _ptr(plan_src),
-                                             _ptr(plan_dst), _ptr(group_k), _ptr(group_nk), _ptr(tile_gptr),
-                                             _ptr(ws), ws.numel(), _stream(dev)))
-            self._store[name] = (plan_src, plan_dst, group_k, group_nk, tile_gptr)
+                _lib.check(lib.me_plan_build(_ptr(tbl), _ptr(order), n_tgt, self.volume, tile_rows, batch_groups,
+                                             _ptr(plan_src), _ptr(plan_dst), _ptr(batch_desc), _ptr(tile_bptr),
+                                             _ptr(item_gptr), _ptr(ws), ws.numel(), _stream(dev)))
+            self._store[name] = (plan_src, plan_dst, batch_desc, tile_bptr, item_gptr)
         return self._store[name]
 
     def to_dict(self):
@@ -328,7 +354,7 @@ def _build_kernel_map(in_map, out_map, region):
                                              ws.numel(), _stream(dev)))
     k_offsets_dev = torch.tensor(k_offsets, dtype=torch.int64, device=dev)
     return KernelMapGPU(volume, n_in, n_out, k_offsets, k_offsets_dev, in_pairs[:max(n_pairs, 0)],
-                        out_pairs[:max(n_pairs, 0)], store={"nbr_out": nbr})
+                        out_pairs[:max(n_pairs, 0)], store={"nbr_out": nbr}, in_map=in_map, out_map=out_map)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -529,7 +555,9 @@ CoordinateMapManagerGPU_default = CoordinateMapManagerGPU_c10
 # convolution operators (src/convolution_gpu.cu:45-244, src/convolution_transpose_gpu.cu)
 # ------------------------------------------------------------------------------------------------
 _ALGO = os.environ.get("ME_AMD_CONV_ALGO", "mfma")  # "naive" = VALU/atomics cross-check kernels
-_TILE_ROWS = int(os.environ.get("ME_AMD_TILE_ROWS", "0"))  # 0 = me_conv_choose_tile_rows (tuning override)
+_TILE_ROWS = int(os.environ.get("ME_AMD_TILE_ROWS", "0"))        # 0 = me_conv_plan_config (tuning overrides)
+_BATCH_GROUPS = int(os.environ.get("ME_AMD_BATCH_GROUPS", "0"))
+_SPATIAL_TILES = os.environ.get("ME_AMD_SPATIAL_TILES", "0") != "0"  # tiles of Z-order-sorted target rows (off: no gain measured while the gather is latency-hidden)
 
 
 def _check_feat(name, t):
@@ -571,6 +599,14 @@ def _timed(name, device, launch):
     return r
 
 
+def plan_config(n_tgt, volume, n_pairs, c_src, c_dst):
+    """(tile_rows, batch_groups) of the tile plan for a (target rows, channels) problem."""
+    lib = _lib.load()
+    t, g = ctypes.c_int32(0), ctypes.c_int32(0)
+    _lib.check(lib.me_conv_plan_config(n_tgt, volume, n_pairs, c_src, c_dst, ctypes.byref(t), ctypes.byref(g)))
+    return _TILE_ROWS or int(t.value), _BATCH_GROUPS or int(g.value)
+
+
 def _conv_target(src_feat, kernel, km, target, n_tgt, name="conv_target", transposed=False):
     """dst[t] = sum over plan entries of src[s] @ W[k].
     transposed=False: W[k] = kernel[k] ([c_src, c_dst]);  transposed=True (dgrad): W[k] = kernel[k]^T."""
@@ -582,15 +618,16 @@ def _conv_target(src_feat, kernel, km, target, n_tgt, name="conv_target", transp
     out = torch.empty((n_tgt, c_dst), dtype=torch.float32, device=dev)
     if n_tgt == 0:
         return out
-    tile_rows = _TILE_ROWS or int(lib.me_conv_choose_tile_rows(n_tgt, km.volume, km.n_pairs, c_src, c_dst))
-    plan_src, plan_dst, group_k, group_nk, tile_gptr = km.plan(target, tile_rows)
+    tile_rows, batch_groups = plan_config(n_tgt, km.volume, km.n_pairs, c_src, c_dst)
+    plan_src, plan_dst, batch_desc, tile_bptr, _ = km.plan(target, tile_rows, batch_groups)
     packed = torch.empty(int(lib.me_conv_packed_weight_elems(volume, c_src, c_dst)), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         _lib.check(lib.me_conv_pack_weights_f32(_ptr(kernel), volume, c_src, c_dst, 1 if transposed else 0,
                                                 _ptr(packed), _stream(dev)))
         _timed(name, dev, lambda: _lib.check(lib.me_conv_target_f32(
             _ptr(src_feat), src_feat.shape[0], c_src, _ptr(packed), km.volume, c_dst, _ptr(plan_src),
-            _ptr(plan_dst), _ptr(group_k), _ptr(tile_gptr), _ptr(out), n_tgt, tile_rows, _stream(dev))))
+            _ptr(plan_dst), _ptr(batch_desc), _ptr(tile_bptr), _ptr(km.order(target)), _ptr(out), n_tgt, tile_rows,
+            batch_groups, _stream(dev))))
     return out
 
 

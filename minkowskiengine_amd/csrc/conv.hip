@@ -30,16 +30,13 @@ namespace me {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kGB = 4;            // groups (of 16 gathered rows) per LDS batch
-constexpr int kRows = kGB * 16;   // gathered rows per batch
 constexpr int kLdsBudget = 160 * 1024;
-
 constexpr int kAccPad = 4;  // accumulator row stride NC + 4 floats: spreads the row-scattered adds over banks
 
-// LDS bytes of one workgroup of k_conv_target_f32<NC, KC> with `tile_rows` target rows
-// (accumulator tile + one dummy row for padding slots, gathered-row tile, plan slice)
-__host__ __device__ constexpr int conv_lds_bytes(int NC, int KC, int tile_rows) {
-  return (tile_rows + 1) * (NC + kAccPad) * 4 + kRows * (KC + 4) * 4 + kRows * 4 + kGB * 4 + 32;
+// LDS bytes of one workgroup of k_conv_tile_f32<NC, KC>: accumulator tile (+ one dummy row for padding
+// slots), one stage buffer of gathered rows and the target-row indices of the batch
+__host__ __device__ constexpr int conv_lds_bytes(int nc, int kc, int tile_rows, int batch_groups) {
+  return (tile_rows + 1) * (nc + kAccPad) * 4 + batch_groups * 16 * ((kc + 4) * 4 + 4);
 }
 
 // =================================================================================================
@@ -116,173 +113,208 @@ __global__ __launch_bounds__(256) void k_pack_weights(const float *__restrict__ 
   wp[e] = out;
 }
 
-// VAR bits (tuning / ablation; 0 is the shipped configuration):
-//   2: runs of up to 4 groups instead of 2 (more accumulators in flight, more registers)
-//   4: plan indices fetched one batch ahead only (dependent index -> row load chain per batch)
+// One workgroup of NC/16 waves owns `tile_rows` target rows x NC output columns (one column slab); its
+// fp32 accumulator tile lives in LDS (e.g. 131 x 68 x 4 B = 36 KiB: three workgroups share a CU and
+// hide each other's barriers and memory latencies).  The work of a tile is a list of BATCHES (plan,
+// coords.hip): up to `batch_groups` (<= 4) groups of 16 (source row, target row) entries of ONE kernel
+// offset.  Per batch, software-pipelined over three batches:
+//   * batch b+2: its plan indices are fetched;
+//   * batch b+1: this wave's slice of W_k (register image, 16-byte loads) and the source rows (16-byte
+//     gather, global -> registers) are requested right after the barrier that publishes batch b, and are
+//     not touched again before the top of the next iteration — a whole batch of MFMAs later;
+//   * batch b: after a barrier the rows gathered during batch b-1 are written to the LDS stage buffer
+//     (padding slots zeroed here, not at the load), after a second barrier every wave multiplies its 16
+//     output columns of all groups on the matrix cores (mma_groups) and adds the 16x16 blocks into the
+//     LDS accumulator.  The target rows of a batch are distinct: plain read-add-write, no atomics, fixed
+//     summation order (bitwise reproducible).
+// EVERY vector load of the loop is unconditional (indices clamped, redundant loads of the last batch at
+// the end of a tile): hipcc's s_waitcnt insertion counts loads per basic block, and a load behind a
+// branch, a select next to its load or a register spill turned into s_waitcnt vmcnt(0) in the middle of
+// the iteration — the whole gather latency exposed per batch (measured, profiles/r01_tune_conv_v6b*).
+// After the last batch every target row is written exactly once with coalesced 16-byte stores (rows
+// without entries get zeros: no zero-fill pass, no global atomics).
+// VAR bits (timing ablations only; 0 is the shipped configuration): 16: no gather traffic (constant rows)
 // EXACT: c_src is a multiple of KC (and of 4): the gather needs no channel guards.
-template <int NC, int KC, int VAR, bool EXACT>
-__global__ __launch_bounds__(NC * 4, 3) void k_conv_target_f32(
+template <int NC, int KC, bool EXACT, int VAR>
+__global__ __launch_bounds__(NC * 4, 3) void k_conv_tile_f32(
     const float *__restrict__ src, int c_src, const f32x4 *__restrict__ wp, int c_dst,
     const int32_t *__restrict__ plan_src, const int32_t *__restrict__ plan_dst,
-    const int32_t *__restrict__ group_k, const int32_t *__restrict__ tile_gptr,
-    float *__restrict__ dst, int64_t n_tgt, int tile_rows) {
-  typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const int32_t *__restrict__ batch_desc, const int32_t *__restrict__ tile_bptr,
+    const int32_t *__restrict__ order, float *__restrict__ dst, int64_t n_tgt, int tile_rows, int batch_groups) {
+  typedef int i32x2 __attribute__((ext_vector_type(2)));
   constexpr int WAVES = NC / 16;
   constexpr int NT = WAVES * 64;
   constexpr int A_LD = KC + 4;         // floats; +16 B per row spreads ds_read_b128 over the banks
   constexpr int ACC_LD = NC + kAccPad;
   constexpr int KQ = KC / 4;           // MFMA k-steps per chunk (= weight registers per lane)
-  constexpr int F4_PER_ROW = KC / 4;   // 16-byte pieces per gathered row
-  constexpr int ITER = kRows * F4_PER_ROW / NT;
-  constexpr int MAXRUN = (VAR & 2) ? 4 : 2;
-  static_assert(kRows * F4_PER_ROW % NT == 0, "gather work must divide evenly");
+  constexpr int F4 = KC / 4;           // 16-byte pieces per gathered row
+  constexpr int ITER = (ME_MAX_BATCH_GROUPS * 16 * F4 + NT - 1) / NT;
   static_assert(KC % 16 == 0, "KC must be a multiple of 16");
-  static_assert(kGB == 4, "the batch metadata is read as one int4");
+  static_assert(ME_MAX_BATCH_GROUPS == 4, "mma_groups runs cover at most 4 groups");
 
+  const int cap_rows = batch_groups * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float *s_acc = reinterpret_cast<float *>(smem);              // [(tile_rows + 1) x ACC_LD]
-  float *s_a = s_acc + (tile_rows + 1) * ACC_LD;               // [kRows x A_LD]
-  int32_t *s_dst = reinterpret_cast<int32_t *>(s_a + kRows * A_LD);  // [kRows]
-  int32_t *s_k = s_dst + kRows;                                // [kGB]
+  float *s_acc = reinterpret_cast<float *>(smem);                      // [(tile_rows + 1) x ACC_LD]
+  float *s_a = s_acc + (tile_rows + 1) * ACC_LD;                       // [cap_rows x A_LD]
+  int32_t *s_dst = reinterpret_cast<int32_t *>(s_a + cap_rows * A_LD);  // [cap_rows]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i16 = lane & 15;  // gathered row (MFMA B column) / weight column (MFMA A row) of this lane
   const int q = lane >> 4;    // MFMA k index of this lane; after the MFMA: output columns q*4 .. q*4+3
   const int tile = blockIdx.x;
   const int col_base = blockIdx.y * NC;
-  const int g_begin = tile_gptr[tile];
-  const int g_end = tile_gptr[tile + 1];
   const bool vec_ok = (c_src % 4) == 0;
   const int nchunks = (c_src + KC - 1) / KC;
   const int ncb = (c_dst + 15) / 16;
-  const int cb = col_base / 16 + wave;   // this wave's 16-column block (may lie beyond c_dst: zeros)
+  // this wave's 16-column block; a block beyond c_dst (last slab) multiplies the last real block again
+  // and its columns are simply not stored
+  const int cb = min(col_base / 16 + wave, ncb - 1);
 
   for (int x = tid; x < (tile_rows + 1) * ACC_LD / 4; x += NT)
     reinterpret_cast<f32x4 *>(s_acc)[x] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int c0 = 0, chunk = 0; c0 < c_src; c0 += KC, ++chunk) {
-    float wreg[KQ];
-    int cur_k = -1;
-    // software pipeline registers: gathered rows of the NEXT batch, its plan slice, and the source
-    // row indices of the batch after that (so no load in the loop waits for another load)
-    f32x4 stage[ITER];
-    int32_t sidx[ITER];
-    int32_t dst_r = tile_rows, k_r = -1;
+  const int b0 = tile_bptr[tile];
+  const int nb = tile_bptr[tile + 1] - b0;
+  const int n_it = nb * nchunks;  // iterations: chunk-major, then the batches of the tile
 
-    auto load_w = [&](int k) {
-      if (cb < ncb) {
-        const f32x4 *p = wp + ((((int64_t)k * nchunks + chunk) * ncb + cb) * (KQ / 4)) * 64 + lane;
+  // batch `it` (clamped to the last one): chunk, first group, groups, offset — scalar loads (the address is
+  // wave-uniform), fetched three iterations ahead
+  auto locate = [&](int it, int &chunk, int &g0, int &ng, int &k) {
+    int r = min(it, n_it - 1);
+    chunk = 0;
+    while (r >= nb) {
+      r -= nb;
+      ++chunk;
+    }
+    const i32x2 d = *reinterpret_cast<const i32x2 *>(batch_desc + 2 * (int64_t)(b0 + r));
+    g0 = d.x;
+    ng = d.y & 255;
+    k = (int)((uint32_t)d.y >> 8);
+  };
+
+  // software pipeline registers
+  f32x4 stage[ITER];    // gathered rows of the batch that is written to LDS next
+  int32_t dstv = tile_rows;
+  int32_t sidx[ITER];   // plan indices of the batch that is gathered next (rows beyond the batch repeat its
+                        // last row: they are staged into slots nobody reads)
+  int32_t sprev[ITER];  // the indices the rows in `stage` were gathered with (padding slots: -1 -> zeros)
+  float wreg[KQ], wnxt[KQ];
+
+  auto load_sidx = [&](int g0, int ng) {
+    const int last = ng * 16 - 1;
 #pragma unroll
-        for (int v = 0; v < KQ / 4; ++v) {
-          const f32x4 t = p[v * 64];
-          wreg[v * 4 + 0] = t.x;
-          wreg[v * 4 + 1] = t.y;
-          wreg[v * 4 + 2] = t.z;
-          wreg[v * 4 + 3] = t.w;
-        }
+    for (int j = 0; j < ITER; ++j) sidx[j] = plan_src[(int64_t)g0 * 16 + min((j * NT + tid) / F4, last)];
+  };
+  // issue the gather of the batch whose indices sit in sidx (global -> registers); nothing here consumes
+  // the result
+  auto gather = [&](int chunk, int g0, int ng) {
+    const int c0 = chunk * KC;
+    dstv = plan_dst[(int64_t)g0 * 16 + min(tid, ng * 16 - 1)];
+#pragma unroll
+    for (int j = 0; j < ITER; ++j) {
+      const int ch = c0 + ((j * NT + tid) % F4) * 4;
+      const int sr = sidx[j];
+      sprev[j] = sr;
+      if (VAR & 16) {  // timing ablation only: no gather traffic
+        stage[j] = f32x4{1.f, 1.f, 1.f, 1.f};
+      } else if (EXACT) {
+        stage[j] = *reinterpret_cast<const f32x4 *>(src + (int64_t)max(sr, 0) * c_src + ch);
       } else {
-#pragma unroll
-        for (int s = 0; s < KQ; ++s) wreg[s] = 0.f;
-      }
-    };
-    auto load_idx = [&](int gb) {
-      const int nrows = (gb < g_end) ? min(kGB, g_end - gb) * 16 : 0;
-#pragma unroll
-      for (int it = 0; it < ITER; ++it) {
-        const int r = (it * NT + tid) / F4_PER_ROW;
-        sidx[it] = (r < nrows) ? plan_src[(int64_t)gb * 16 + r] : -1;
-      }
-    };
-    auto load_meta = [&](int gb) {
-      const int ng = min(kGB, g_end - gb);
-      if (tid < kRows) dst_r = (tid < ng * 16) ? plan_dst[(int64_t)gb * 16 + tid] : tile_rows;
-      if (tid < kGB) k_r = (tid < ng) ? group_k[gb + tid] : -1;
-    };
-    // issue the gather loads of the batch whose indices sit in sidx (global -> registers)
-    auto gather_issue = [&]() {
-#pragma unroll
-      for (int it = 0; it < ITER; ++it) {
-        const int ch = c0 + ((it * NT + tid) % F4_PER_ROW) * 4;
-        const int s = sidx[it];
-        f32x4 t = {0.f, 0.f, 0.f, 0.f};
-        if (EXACT) {
-          // unconditional 16-byte load (padding slots read row 0 and are zeroed by a select)
-          const f32x4 ld = *reinterpret_cast<const f32x4 *>(src + (int64_t)max(s, 0) * c_src + ch);
-          t = (s >= 0) ? ld : t;
-        } else if (s >= 0 && ch < c_src) {
-          const float *rowp = src + (int64_t)s * c_src + ch;
-          if (vec_ok) {
-            t = *reinterpret_cast<const f32x4 *>(rowp);
-          } else {
-            t.x = rowp[0];
-            if (ch + 1 < c_src) t.y = rowp[1];
-            if (ch + 2 < c_src) t.z = rowp[2];
-            if (ch + 3 < c_src) t.w = rowp[3];
-          }
+        // clamped scalar / vector loads; channels beyond c_src are zeroed at the stage write
+        const float *rowp = src + (int64_t)max(sr, 0) * c_src;
+        if (vec_ok) {
+          stage[j] = *reinterpret_cast<const f32x4 *>(rowp + min(ch, c_src - 4));
+        } else {
+          stage[j] = f32x4{rowp[min(ch, c_src - 1)], rowp[min(ch + 1, c_src - 1)], rowp[min(ch + 2, c_src - 1)],
+                           rowp[min(ch + 3, c_src - 1)]};
         }
-        stage[it] = t;
       }
-    };
-
-    if (g_begin < g_end) {
-      load_idx(g_begin);
-      load_meta(g_begin);
-      gather_issue();
-      if (!(VAR & 4)) load_idx(g_begin + kGB);
     }
-
-    for (int gb = g_begin; gb < g_end; gb += kGB) {
-      const int ng = min(kGB, g_end - gb);
-      __syncthreads();  // consumers of the previous batch are done with s_a / s_dst / s_k
+  };
+  auto write_stage = [&](int chunk) {
+    const int c0 = chunk * KC;
 #pragma unroll
-      for (int it = 0; it < ITER; ++it) {
-        const int idx = it * NT + tid;
-        *reinterpret_cast<f32x4 *>(&s_a[(idx / F4_PER_ROW) * A_LD + (idx % F4_PER_ROW) * 4]) = stage[it];
+    for (int j = 0; j < ITER; ++j) {
+      const int idx = j * NT + tid;
+      const int r = idx / F4;
+      const int ch = c0 + (idx % F4) * 4;
+      f32x4 t = stage[j];
+      if (!EXACT) {
+        if (ch >= c_src) t.x = 0.f;
+        if (ch + 1 >= c_src) t.y = 0.f;
+        if (ch + 2 >= c_src) t.z = 0.f;
+        if (ch + 3 >= c_src) t.w = 0.f;
       }
-      if (tid < kRows) s_dst[tid] = dst_r;
-      if (tid < kGB) s_k[tid] = k_r;
+      if (sprev[j] < 0) t = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (r < cap_rows) *reinterpret_cast<f32x4 *>(&s_a[r * A_LD + (idx % F4) * 4]) = t;
+    }
+    if (tid < cap_rows) s_dst[tid] = dstv;
+  };
+  auto load_w = [&](int chunk, int k) {
+    const f32x4 *p = wp + ((((int64_t)k * nchunks + chunk) * ncb + cb) * (KQ / 4)) * 64 + lane;
+#pragma unroll
+    for (int v = 0; v < KQ / 4; ++v) {
+      const f32x4 t = p[v * 64];
+      wnxt[v * 4 + 0] = t.x;
+      wnxt[v * 4 + 1] = t.y;
+      wnxt[v * 4 + 2] = t.z;
+      wnxt[v * 4 + 3] = t.w;
+    }
+  };
+
+  if (n_it > 0) {
+    // batch cursors: A = it, B = it + 1, C = it + 2 (clamped to the last batch: the tail of a tile repeats
+    // its last loads instead of branching around them)
+    int chA, gA, nA, kA, chB, gB, nB, kB, chC, gC, nC, kC;
+    locate(0, chA, gA, nA, kA);
+    locate(1, chB, gB, nB, kB);
+    locate(2, chC, gC, nC, kC);
+    load_w(chA, kA);
+    load_sidx(gA, nA);
+    gather(chA, gA, nA);
+    load_sidx(gB, nB);
+
+    for (int it = 0; it < n_it; ++it) {
+      __syncthreads();  // everybody is done reading the previous batch from s_a / s_dst
+      write_stage(chA);  // rows of batch it (gathered during the previous iteration)
+#pragma unroll
+      for (int sx = 0; sx < KQ; ++sx) wreg[sx] = wnxt[sx];  // its weights were requested before its rows
       __syncthreads();
-      // the next batch's rows fly while this batch is multiplied; its indices were fetched a batch ago
-      if (gb + kGB < g_end) {
-        if (VAR & 4) load_idx(gb + kGB);
-        load_meta(gb + kGB);
-        gather_issue();
-        if (!(VAR & 4)) load_idx(gb + 2 * kGB);
-      }
+      // next batch: its weights, its rows, and the indices of the one after
+      load_w(chB, kB);
+      gather(chB, gB, nB);
+      load_sidx(gC, nC);
 
-      const i32x4 kv = *reinterpret_cast<const i32x4 *>(s_k);
-      const int kk0 = __builtin_amdgcn_readfirstlane(kv.x), kk1 = __builtin_amdgcn_readfirstlane(kv.y);
-      const int kk2 = __builtin_amdgcn_readfirstlane(kv.z), kk3 = __builtin_amdgcn_readfirstlane(kv.w);
-      auto ksel = [&](int g) { return g == 0 ? kk0 : (g == 1 ? kk1 : (g == 2 ? kk2 : kk3)); };
-
-      int g = 0;
-      while (g < ng) {
-        const int k0 = ksel(g);
-        int run = 1;
-        while (run < MAXRUN && g + run < ng && ksel(g + run) == k0) ++run;
-        if (k0 != cur_k) {
-          cur_k = k0;
-          load_w(k0);
-        }
-        const float *a0p = &s_a[(g * 16 + i16) * A_LD + q * KQ];
-        const int32_t *dstp = &s_dst[g * 16 + i16];
-        // after the MFMA this lane holds columns wave*16 + q*4 .. +3 of target row s_dst[g*16 + i16];
-        // columns are private to this wave -> plain LDS read-add-write in a fixed order (bitwise
-        // reproducible); padding slots land in the dummy row `tile_rows`.
+      // multiply batch it.  After the MFMA this lane holds columns wave*16 + q*4 .. +3 of target row
+      // s_dst[g*16 + i16]; columns are private to this wave -> plain LDS read-add-write in a fixed order;
+      // padding slots land in the dummy row `tile_rows`.
+      {
+        const float *a0p = &s_a[i16 * A_LD + q * KQ];
+        const int32_t *dstp = &s_dst[i16];
         float *accp = &s_acc[wave * 16 + q * 4];
-        if (MAXRUN > 2 && run == 4) mma_groups<4, KQ, A_LD, ACC_LD>(a0p, wreg, dstp, accp);
-        else if (MAXRUN > 2 && run == 3) mma_groups<3, KQ, A_LD, ACC_LD>(a0p, wreg, dstp, accp);
-        else if (run == 2) mma_groups<2, KQ, A_LD, ACC_LD>(a0p, wreg, dstp, accp);
-        else mma_groups<1, KQ, A_LD, ACC_LD>(a0p, wreg, dstp, accp);
-        g += run;
+        if (nA == 4) {
+          mma_groups<2, KQ, A_LD, ACC_LD>(a0p, wreg, dstp, accp);
+          mma_groups<2, KQ, A_LD, ACC_LD>(a0p + 32 * A_LD, wreg, dstp + 32, accp);
+        } else if (nA == 3) {
+          mma_groups<2, KQ, A_LD, ACC_LD>(a0p, wreg, dstp, accp);
+          mma_groups<1, KQ, A_LD, ACC_LD>(a0p + 32 * A_LD, wreg, dstp + 32, accp);
+        } else if (nA == 2) {
+          mma_groups<2, KQ, A_LD, ACC_LD>(a0p, wreg, dstp, accp);
+        } else {
+          mma_groups<1, KQ, A_LD, ACC_LD>(a0p, wreg, dstp, accp);
+        }
       }
+      chA = chB; gA = gB; nA = nB; kA = kB;
+      chB = chC; gB = gC; nB = nC; kB = kC;
+      locate(it + 3, chC, gC, nC, kC);
     }
-    __syncthreads();  // all reads of s_a done before the next chunk restages it
   }
-
   __syncthreads();
+
+  // every target row of the tile is written exactly once; local row r is target row order[row0 + r]
+  // (row0 + r without an order)
   const int64_t row0 = (int64_t)tile * tile_rows;
   const int rows_here = (int)min((int64_t)tile_rows, n_tgt - row0);
   const bool vec_out = (c_dst % 4) == 0;
@@ -292,7 +324,8 @@ __global__ __launch_bounds__(NC * 4, 3) void k_conv_target_f32(
     const int cc = col_base + c4 * 4;
     if (row < rows_here && cc < c_dst) {
       const f32x4 v = *reinterpret_cast<const f32x4 *>(&s_acc[row * ACC_LD + c4 * 4]);
-      float *o = dst + (row0 + row) * c_dst + cc;
+      const int64_t grow = order ? (int64_t)order[row0 + row] : row0 + row;
+      float *o = dst + grow * c_dst + cc;
       if (vec_out) {
         *reinterpret_cast<f32x4 *>(o) = v;
       } else {
@@ -642,8 +675,9 @@ __global__ __launch_bounds__(256) void k_naive_wgrad(const float *__restrict__ i
 
 // kernel variant for a (c_src, c_dst) problem
 struct ConvVariant {
-  int nc;  // output columns per workgroup (64 or 32); waves per workgroup = nc / 16
-  int kc;  // source-channel chunk (64, 32 or 16)
+  int nc;     // output columns per workgroup (64 or 32); waves per workgroup = nc / 16
+  int slabs;  // column slabs (grid.y)
+  int kc;     // source-channel chunk (64, 32 or 16)
 };
 
 static ConvVariant conv_variant(int c_src, int c_dst) {
@@ -651,6 +685,7 @@ static ConvVariant conv_variant(int c_src, int c_dst) {
   // columns per workgroup: 64 unless the last 64-column slab would be at most half full
   const int rem = c_dst % 64;
   v.nc = (rem != 0 && rem <= 32) ? 32 : 64;
+  v.slabs = (int)ceil_div(c_dst, v.nc);
   // source-channel chunk: the largest of {64, 32, 16} that adds at most 16 channels of padding
   if (c_src % 64 == 0) v.kc = 64;
   else if (c_src % 32 == 0) v.kc = 32;
@@ -677,28 +712,28 @@ static int device_cu_count() {
 int g_conv_variant = 0;  // me_debug_set_conv_variant
 
 template <int NC, int KC, int VAR>
-static int launch_conv_target(const float *src, int c_src, const float *wp, int c_dst,
-                              const int32_t *plan_src, const int32_t *plan_dst, const int32_t *group_k,
-                              const int32_t *tile_gptr, float *dst, int64_t n_tgt, int tile_rows,
-                              hipStream_t stream) {
-  const int lds = conv_lds_bytes(NC, KC, tile_rows);
-  ME_CHECK(lds <= kLdsBudget, "tile_rows too large for the LDS of one workgroup");
+static int launch_conv_tile(const float *src, int c_src, const float *wp, int c_dst, int slabs,
+                            const int32_t *plan_src, const int32_t *plan_dst, const int32_t *batch_desc,
+                            const int32_t *tile_bptr, const int32_t *order, float *dst, int64_t n_tgt,
+                            int tile_rows, int batch_groups, hipStream_t stream) {
+  const int lds = conv_lds_bytes(NC, KC, tile_rows, batch_groups);
+  ME_CHECK(lds <= kLdsBudget, "tile_rows / batch_groups too large for the LDS of one workgroup");
   const bool exact = (c_src % KC) == 0;
-  static int max_lds_set[2] = {0, 0};  // per instantiation
-  if (lds > 64 * 1024 && lds > max_lds_set[exact]) {
-    const void *fn = exact ? reinterpret_cast<const void *>(&k_conv_target_f32<NC, KC, VAR, true>)
-                           : reinterpret_cast<const void *>(&k_conv_target_f32<NC, KC, VAR, false>);
+  static bool attr_set[2] = {false, false};  // per instantiation
+  if (lds > 48 * 1024 && !attr_set[exact]) {
+    const void *fn = exact ? reinterpret_cast<const void *>(&k_conv_tile_f32<NC, KC, true, VAR>)
+                           : reinterpret_cast<const void *>(&k_conv_tile_f32<NC, KC, false, VAR>);
     ME_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
-    max_lds_set[exact] = kLdsBudget;
+    attr_set[exact] = true;
   }
-  const dim3 grid((unsigned)ceil_div(n_tgt, tile_rows), (unsigned)ceil_div(c_dst, NC));
+  const dim3 grid((unsigned)ceil_div(n_tgt, tile_rows), (unsigned)slabs);
   const f32x4 *wp4 = reinterpret_cast<const f32x4 *>(wp);
   if (exact)
-    hipLaunchKernelGGL((k_conv_target_f32<NC, KC, VAR, true>), grid, dim3(NC * 4), (size_t)lds, stream, src,
-                       c_src, wp4, c_dst, plan_src, plan_dst, group_k, tile_gptr, dst, n_tgt, tile_rows);
+    hipLaunchKernelGGL((k_conv_tile_f32<NC, KC, true, VAR>), grid, dim3(NC * 4), (size_t)lds, stream, src, c_src, wp4,
+                       c_dst, plan_src, plan_dst, batch_desc, tile_bptr, order, dst, n_tgt, tile_rows, batch_groups);
   else
-    hipLaunchKernelGGL((k_conv_target_f32<NC, KC, VAR, false>), grid, dim3(NC * 4), (size_t)lds, stream, src,
-                       c_src, wp4, c_dst, plan_src, plan_dst, group_k, tile_gptr, dst, n_tgt, tile_rows);
+    hipLaunchKernelGGL((k_conv_tile_f32<NC, KC, false, VAR>), grid, dim3(NC * 4), (size_t)lds, stream, src, c_src, wp4,
+                       c_dst, plan_src, plan_dst, batch_desc, tile_bptr, order, dst, n_tgt, tile_rows, batch_groups);
   ME_LAUNCH_CHECK();
   return 0;
 }
@@ -740,45 +775,50 @@ using namespace me;
 
 extern "C" {
 
-int32_t me_conv_choose_tile_rows(int64_t n_tgt, int64_t volume, int64_t n_pairs, int32_t c_src,
-                                 int32_t c_dst) {
-  if (n_tgt <= 0 || volume <= 0 || c_src <= 0 || c_dst <= 0) return 128;
+int me_conv_plan_config(int64_t n_tgt, int64_t volume, int64_t n_pairs, int32_t c_src, int32_t c_dst,
+                        int32_t *tile_rows, int32_t *batch_groups) {
+  ME_CHECK(tile_rows != nullptr && batch_groups != nullptr, "output pointers must not be null");
+  *tile_rows = 128;
+  *batch_groups = ME_MAX_BATCH_GROUPS;
+  if (n_tgt <= 0 || volume <= 0 || c_src <= 0 || c_dst <= 0) return 0;
   const ConvVariant v = conv_variant(c_src, c_dst);
   const int waves = v.nc / 16;
-  const int64_t slabs = ceil_div(c_dst, v.nc);
+  const int kq = v.kc / 4;
   const int chunks = (int)ceil_div(c_src, v.kc);
-  // resident workgroups per CU: 4 waves per SIMD by registers (3 for the <32,64> variant), then
-  // whatever the LDS allows
-  const int occ_regs = ((v.nc == 32 && v.kc == 64) ? 12 : 16) / waves;
   const int cus = device_cu_count();
-  // occupancy p of a neighbour offset (centre excluded) -> expected 16-row groups of a (tile, k)
+  // occupancy p of a neighbour offset (centre excluded) -> expected 16-row groups of a (tile, k) item
   const double p = volume > 1 ? (double)(n_pairs > n_tgt ? n_pairs - n_tgt : 0) / ((double)(volume - 1) * n_tgt)
                               : 0.0;
+  const int cap = ME_MAX_BATCH_GROUPS;
   double best_cost = 1e300;
-  int best_t = 0;
-  for (int occ = occ_regs; occ >= 1; --occ) {
+  // resident workgroups per CU: 3 waves per SIMD by registers (__launch_bounds__(NC * 4, 3)), then the LDS
+  for (int occ = 12 / waves; occ >= 1; --occ) {
     const int64_t slots = (int64_t)cus * occ;
     for (int rounds = 1; rounds <= 64; ++rounds) {
-      int64_t t = ceil_div(n_tgt * slabs, slots * rounds);
+      int64_t t = ceil_div(n_tgt * v.slabs, slots * rounds);
       if (t < ME_GROUP_ROWS) t = ME_GROUP_ROWS;
       if (t > ME_MAX_TILE_ROWS) continue;
-      if ((int64_t)conv_lds_bytes(v.nc, v.kc, (int)t) * occ > kLdsBudget) continue;
-      const double m = (double)t * p;
+      if ((int64_t)conv_lds_bytes(v.nc, v.kc, (int)t, cap) * occ > kLdsBudget) continue;
+      const double m = (double)t * p;  // expected entries of an off-centre item
       const double g_side = m < 6.0 ? (m <= 0 ? 0.0 : (1.0 - exp(-m)) * (1.0 + m / 16.0)) : m / 16.0 + 0.5;
       const double groups = (double)ceil_div(t, 16) + (double)(volume - 1) * g_side;
-      const int64_t items = ceil_div(n_tgt, t) * slabs;
+      const double batches = (double)ceil_div(ceil_div(t, 16), cap) +
+                             (double)(volume - 1) * (m <= 0 ? 0.0 : (m < 3.0 ? 1.0 - exp(-m) : ceil(g_side / cap)));
+      const int64_t items = ceil_div(n_tgt, t) * v.slabs;
       const double real_rounds = (double)ceil_div(items, slots);
-      // time ~ rounds x groups of one item x waves sharing a SIMD (+ a per-batch overhead term)
-      const double cost = real_rounds * (groups * chunks) * (double)(occ * waves) / 4.0 *
+      // cycles of one tile if its waves had their SIMDs alone: MFMAs (32 cycles each) + per-batch barrier /
+      // pipeline overhead + store / pipeline fill per tile; occ * waves / 4 waves share a SIMD
+      const double tile_cycles = chunks * (groups * kq * 32.0 + batches * 400.0) + (double)t * v.nc * 0.4 + 3000.0;
+      const double cost = real_rounds * tile_cycles * (double)(occ * waves) / 4.0 *
                           (1.0 + 0.15 * 12.0 / (occ * waves));
       if (cost < best_cost) {
         best_cost = cost;
-        best_t = (int)t;
+        *tile_rows = (int32_t)t;
       }
       if (t == ME_GROUP_ROWS) break;
     }
   }
-  return best_t > 0 ? best_t : 128;
+  return 0;
 }
 
 int64_t me_conv_packed_weight_elems(int64_t volume, int32_t c_src, int32_t c_dst) {
@@ -809,27 +849,28 @@ int me_conv_pack_weights_f32(const float *w, int64_t volume, int32_t c_src, int3
 
 int me_conv_target_f32(const float *src, int64_t n_src, int32_t c_src, const float *wp, int64_t volume,
                        int32_t c_dst, const int32_t *plan_src, const int32_t *plan_dst,
-                       const int32_t *group_k, const int32_t *tile_gptr, float *dst, int64_t n_tgt,
-                       int32_t tile_rows, void *stream_) {
+                       const int32_t *batch_desc, const int32_t *tile_bptr, const int32_t *order, float *dst,
+                       int64_t n_tgt, int32_t tile_rows, int32_t batch_groups, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   (void)n_src;
   (void)volume;
   ME_CHECK(c_src > 0 && c_dst > 0, "channel counts must be positive");
   ME_CHECK(tile_rows >= ME_GROUP_ROWS && tile_rows <= ME_MAX_TILE_ROWS, "tile_rows out of range");
+  ME_CHECK(batch_groups >= 1 && batch_groups <= ME_MAX_BATCH_GROUPS, "batch_groups out of range");
   ME_CHECK((uintptr_t)src % 16 == 0 && (uintptr_t)dst % 16 == 0 && (uintptr_t)wp % 16 == 0,
            "feature and weight pointers must be 16-byte aligned");
   if (n_tgt == 0) return 0;
   const ConvVariant v = conv_variant(c_src, c_dst);
-#define ME_CONV_ARGS src, c_src, wp, c_dst, plan_src, plan_dst, group_k, tile_gptr, dst, n_tgt, tile_rows, stream
+#define ME_CONV_ARGS                                                                                         \
+  src, c_src, wp, c_dst, v.slabs, plan_src, plan_dst, batch_desc, tile_bptr, order, dst, n_tgt, tile_rows, \
+      batch_groups, stream
   if (g_conv_variant != 0 && v.nc == 64 && v.kc == 64) {  // ablation builds exist for the headline shape only
     switch (g_conv_variant) {
-      case 2: return launch_conv_target<64, 64, 2>(ME_CONV_ARGS);
-      case 4: return launch_conv_target<64, 64, 4>(ME_CONV_ARGS);
-      case 6: return launch_conv_target<64, 64, 6>(ME_CONV_ARGS);
+      case 16: return launch_conv_tile<64, 64, 16>(ME_CONV_ARGS);
       default: break;
     }
   }
-#define ME_CONV_CASE(NCV, KCV) return launch_conv_target<NCV, KCV, 0>(ME_CONV_ARGS)
+#define ME_CONV_CASE(NCV, KCV) return launch_conv_tile<NCV, KCV, 0>(ME_CONV_ARGS)
   if (v.nc == 32) {
     if (v.kc == 64) ME_CONV_CASE(32, 64);
     if (v.kc == 32) ME_CONV_CASE(32, 32);
@@ -844,6 +885,7 @@ int me_conv_target_f32(const float *src, int64_t n_src, int32_t c_src, const flo
 }
 
 void me_debug_set_conv_variant(int variant) { g_conv_variant = variant; }
+
 
 int me_transpose_kernel_f32(const float *w, int64_t volume, int32_t c_in, int32_t c_out, float *wt,
                             void *stream_) {

@@ -225,6 +225,34 @@ __global__ __launch_bounds__(256) void k_find(const uint64_t *__restrict__ table
 }
 
 // =================================================================================================
+// spatial keys
+// =================================================================================================
+// Z-order (Morton) key of a coordinate row: batch index in the top bits, then the bit-interleaved
+// spatial coordinates in units of the tensor stride (biased to be non-negative, truncated to `bits`
+// bits per axis — the key only has to give locality, not identity).  Rows sorted by this key form the
+// tiles of the convolution plan: a tile's 27 offsets then gather (almost) the same ~3x tile-size source
+// rows, which stay in the XCD's L2 instead of being fetched 27 times from HBM / Infinity Cache.
+template <int NCOL>
+__global__ __launch_bounds__(256) void k_spatial_keys(const int32_t *__restrict__ coords, int64_t n,
+                                                     StrideArg ts, int bits, int64_t *__restrict__ keys) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int32_t c[NCOL];
+  load_coords<NCOL>(coords, i, c);
+  uint64_t key = 0;
+  const uint32_t bias = 1u << (bits - 1), mask = (1u << bits) - 1u;
+  uint32_t v[NCOL - 1];
+#pragma unroll
+  for (int d = 0; d < NCOL - 1; ++d) v[d] = ((uint32_t)(floor_to_multiple(c[d + 1], ts.ts[d]) / ts.ts[d]) + bias) & mask;
+  for (int b = 0; b < bits; ++b) {
+#pragma unroll
+    for (int d = 0; d < NCOL - 1; ++d) key |= (uint64_t)((v[d] >> b) & 1u) << (b * (NCOL - 1) + d);
+  }
+  key |= (uint64_t)((uint32_t)c[0] & 0x7fu) << 56;
+  keys[i] = (int64_t)key;
+}
+
+// =================================================================================================
 // kernel map
 // =================================================================================================
 // neighbour coordinate of offset k: src/kernel_region.hpp:198-247
@@ -325,10 +353,15 @@ __global__ __launch_bounds__(256) void k_kmap_transpose(const int32_t *__restric
 // =================================================================================================
 // tile plan
 // =================================================================================================
-// one wavefront per (tile, offset); tiles hold `tile_rows` consecutive target rows
-__global__ __launch_bounds__(256) void k_plan_count(const int32_t *__restrict__ tbl, int64_t n_tgt,
+// one wavefront per (tile, offset) item; tiles hold `tile_rows` consecutive target rows.  An item's
+// valid entries are padded to groups of 16 (one MFMA N-tile) and its groups are cut into BATCHES of at
+// most `batch_groups` groups: a batch is what the convolution kernel stages in LDS at once, and it
+// never mixes offsets (one weight slice per batch).
+__global__ __launch_bounds__(256) void k_plan_count(const int32_t *__restrict__ tbl,
+                                                   const int32_t *__restrict__ order, int64_t n_tgt,
                                                    int64_t volume, int64_t n_items, int tile_rows,
-                                                   uint32_t *__restrict__ gcount) {
+                                                   int batch_groups, uint32_t *__restrict__ gcount,
+                                                   uint32_t *__restrict__ bcount) {
   const int64_t item = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (item >= n_items) return;  // wave-uniform
   const int64_t t = item / volume, k = item % volume;
@@ -336,23 +369,38 @@ __global__ __launch_bounds__(256) void k_plan_count(const int32_t *__restrict__ 
   uint32_t count = 0;
   for (int c = 0; c < tile_rows; c += 64) {
     const int local = c + lane_id();
-    const int64_t u = row0 + local;
-    const int32_t r = (local < tile_rows && u < n_tgt) ? tbl[k * n_tgt + u] : -1;
+    const int64_t pos = row0 + local;
+    int32_t r = -1;
+    if (local < tile_rows && pos < n_tgt) r = tbl[k * n_tgt + (order ? (int64_t)order[pos] : pos)];
     count += (uint32_t)__popcll(__ballot(r >= 0));
   }
-  if (lane_id() == 0) gcount[item] = (count + ME_GROUP_ROWS - 1) / ME_GROUP_ROWS;
+  if (lane_id() == 0) {
+    const uint32_t groups = (count + ME_GROUP_ROWS - 1) / ME_GROUP_ROWS;
+    gcount[item] = groups;
+    bcount[item] = (groups + batch_groups - 1) / batch_groups;
+  }
 }
 
-__global__ __launch_bounds__(256) void k_plan_fill(const int32_t *__restrict__ tbl, int64_t n_tgt,
+// The valid entries of an item are not stored in row order: they are DEALT to the item's groups and
+// slots by the residue of their target row.  The convolution kernel adds the 16x16 result of a group
+// into its LDS accumulator with one 16-byte access per lane at the lane's target row; the LDS serves a
+// 16-byte store in passes of 8 consecutive lanes, and two rows whose indices are congruent mod 8 fall
+// into the same banks (the accumulator row stride is an odd number of 16-byte units).  Entries are
+// therefore ordered by (row mod 8) — position p —, entry p goes to group p % groups, step s = p / groups,
+// and even steps fill slots 0-7, odd steps slots 8-15: each half of a group then holds (close to) one
+// row of every residue, instead of ~3 rows in the fullest residue for 8 random rows.
+__global__ __launch_bounds__(256) void k_plan_fill(const int32_t *__restrict__ tbl,
+                                                  const int32_t *__restrict__ order, int64_t n_tgt,
                                                   int64_t volume, int64_t n_items, int tile_rows,
-                                                  const uint32_t *__restrict__ gcount,
-                                                  const uint32_t *__restrict__ goffs,
+                                                  int batch_groups, const uint32_t *__restrict__ goffs,
                                                   const uint32_t *__restrict__ gtotal,
+                                                  const uint32_t *__restrict__ boffs,
+                                                  const uint32_t *__restrict__ btotal,
                                                   int32_t *__restrict__ plan_src,
                                                   int32_t *__restrict__ plan_dst,
-                                                  int32_t *__restrict__ group_k,
-                                                  int32_t *__restrict__ group_nk,
-                                                  int32_t *__restrict__ tile_gptr, int64_t n_tiles) {
+                                                  int32_t *__restrict__ batch_desc,
+                                                  int32_t *__restrict__ tile_bptr,
+                                                  int32_t *__restrict__ item_gptr, int64_t n_tiles) {
   const int64_t item = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (item >= n_items) return;  // wave-uniform
   const int lane = lane_id();
@@ -360,45 +408,66 @@ __global__ __launch_bounds__(256) void k_plan_fill(const int32_t *__restrict__ t
   const int64_t row0 = t * tile_rows;
   const uint32_t g0 = goffs[item];
   const int64_t slot0 = (int64_t)g0 * ME_GROUP_ROWS;
-  uint32_t running = 0;
-  for (int c = 0; c < tile_rows; c += 64) {
-    const int local = c + lane;
-    const int64_t u = row0 + local;
-    const int32_t r = (local < tile_rows && u < n_tgt) ? tbl[k * n_tgt + u] : -1;
-    const unsigned long long m = __ballot(r >= 0);
-    if (r >= 0) {
-      const int64_t s = slot0 + running + mask_prefix(m);
-      plan_src[s] = r;
-      plan_dst[s] = local;
-    }
-    running += (uint32_t)__popcll(m);
+  constexpr int kChunks = ME_MAX_TILE_ROWS / 64;
+  // local row = c * 64 + lane, so its residue mod 8 is lane & 7 in every chunk
+  const unsigned long long class_mask = 0x0101010101010101ull << (lane & 7);
+  int32_t r[kChunks];
+  uint32_t my_class_count = 0, total = 0;
+#pragma unroll
+  for (int c = 0; c < kChunks; ++c) {
+    const int local = c * 64 + lane;
+    const int64_t pos = row0 + local;
+    r[c] = -1;
+    if (local < tile_rows && pos < n_tgt) r[c] = tbl[k * n_tgt + (order ? (int64_t)order[pos] : pos)];
+    const unsigned long long m = __ballot(r[c] >= 0);
+    my_class_count += (uint32_t)__popcll(m & class_mask);
+    total += (uint32_t)__popcll(m);
   }
-  const uint32_t groups = (running + ME_GROUP_ROWS - 1) / ME_GROUP_ROWS;
+  const uint32_t groups = (total + ME_GROUP_ROWS - 1) / ME_GROUP_ROWS;
   const uint32_t padded = groups * ME_GROUP_ROWS;
-  // padding slots of the last group (fewer than 16): no source row, dummy accumulator row
-  if (running + lane < padded) {
-    plan_src[slot0 + running + lane] = -1;
-    plan_dst[slot0 + running + lane] = tile_rows;
+  // entries of smaller residues come first (lanes 0-7 hold the counts of residues 0-7)
+  uint32_t run = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const uint32_t cj = __shfl(my_class_count, j, 64);
+    if (j < (lane & 7)) run += cj;
   }
-  if (groups > 0) {
-    // next offset of this tile that has any group (for the weight prefetch), or -1
-    int32_t nk = -1;
-    for (int64_t base = k + 1; base < volume; base += 64) {
-      const int64_t kk = base + lane;
-      const bool has = kk < volume && gcount[t * volume + kk] > 0;
-      const unsigned long long m = __ballot(has);
-      if (m) {
-        nk = (int32_t)(base + __builtin_ctzll(m));
-        break;
-      }
+  auto place = [&](uint32_t p) {  // position in residue order -> slot of the plan
+    const uint32_t gi = p % groups, s = p / groups;
+    return slot0 + (int64_t)gi * ME_GROUP_ROWS + (((s & 1u) << 3) | (s >> 1));
+  };
+#pragma unroll
+  for (int c = 0; c < kChunks; ++c) {
+    const unsigned long long mine = __ballot(r[c] >= 0) & class_mask;
+    if (r[c] >= 0) {
+      const int64_t s = place(run + mask_prefix(mine));
+      plan_src[s] = r[c];
+      plan_dst[s] = c * 64 + lane;
     }
-    for (uint32_t j = lane; j < groups; j += 64) {
-      group_k[g0 + j] = (int32_t)k;
-      group_nk[g0 + j] = nk;
+    run += (uint32_t)__popcll(mine);
+  }
+  // padding positions (fewer than 16): no source row, dummy accumulator row
+  if (total + lane < padded) {
+    const int64_t s = place(total + lane);
+    plan_src[s] = -1;
+    plan_dst[s] = tile_rows;
+  }
+  const uint32_t b0 = boffs[item];
+  const uint32_t nb = (groups + batch_groups - 1) / batch_groups;
+  for (uint32_t j = lane; j < nb; j += 64) {
+    const uint32_t first = j * batch_groups;
+    const uint32_t ng = min((uint32_t)batch_groups, groups - first);
+    batch_desc[2 * (int64_t)(b0 + j)] = (int32_t)(g0 + first);
+    batch_desc[2 * (int64_t)(b0 + j) + 1] = (int32_t)(((uint32_t)k << 8) | ng);
+  }
+  if (lane == 0) {
+    item_gptr[item] = (int32_t)g0;
+    if (k == 0) tile_bptr[t] = (int32_t)b0;
+    if (item == 0) {
+      tile_bptr[n_tiles] = (int32_t)(*btotal);
+      item_gptr[n_items] = (int32_t)(*gtotal);
     }
   }
-  if (k == 0 && lane == 0) tile_gptr[t] = (int32_t)g0;
-  if (item == 0 && lane == 0) tile_gptr[n_tiles] = (int32_t)(*gtotal);
 }
 
 }  // namespace me
@@ -500,6 +569,26 @@ int me_coords_stride(const int32_t *coords, int64_t n, int32_t ncol, const int32
            "coordinates with 4 columns must be 16-byte aligned");
   const dim3 grid((unsigned)ceil_div(n, 256)), block(256);
   ME_DISPATCH_NCOL(ncol, hipLaunchKernelGGL(k_stride<NCOL>, grid, block, 0, stream, coords, n, arg, out_coords));
+  ME_LAUNCH_CHECK();
+  return 0;
+}
+
+int me_coords_spatial_keys(const int32_t *coords, int64_t n, int32_t ncol, const int32_t *tensor_stride,
+                           int64_t *keys, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ME_CHECK(ncol >= 2 && ncol <= ME_MAX_DIM + 1, "invalid coordinate size");
+  StrideArg arg;
+  for (int d = 0; d < ME_MAX_DIM; ++d) arg.ts[d] = 1;
+  for (int d = 0; d < ncol - 1; ++d) {
+    ME_CHECK(tensor_stride[d] > 0, "tensor stride must be positive");
+    arg.ts[d] = tensor_stride[d];
+  }
+  if (n == 0) return 0;
+  ME_CHECK(ncol != 4 || (uintptr_t)coords % 16 == 0, "coordinates with 4 columns must be 16-byte aligned");
+  int bits = 56 / (ncol - 1);
+  if (bits > 21) bits = 21;
+  const dim3 grid((unsigned)ceil_div(n, 256)), block(256);
+  ME_DISPATCH_NCOL(ncol, hipLaunchKernelGGL(k_spatial_keys<NCOL>, grid, block, 0, stream, coords, n, arg, bits, keys));
   ME_LAUNCH_CHECK();
   return 0;
 }
@@ -615,21 +704,24 @@ int64_t me_plan_max_groups(int64_t n_tgt, int64_t volume, int64_t n_pairs, int32
   const int64_t nonempty = items < n_pairs ? items : n_pairs;
   return n_pairs / ME_GROUP_ROWS + nonempty + 1;
 }
+// plan workspace: gcount | goffs | bcount | boffs [items each] | totals | scan ws
 int64_t me_plan_workspace_bytes(int64_t n_tgt, int64_t volume, int32_t tile_rows) {
   const int64_t items = me_plan_num_tiles(n_tgt < 1 ? 1 : n_tgt, tile_rows) * volume;
-  return 2 * align_up(items * 4, 256) + 256 + scan_workspace_bytes(items);
+  return 4 * align_up(items * 4, 256) + 256 + scan_workspace_bytes(items);
 }
 
-int me_plan_build(const int32_t *tbl, int64_t n_tgt, int64_t volume, int32_t tile_rows, int32_t *plan_src,
-                  int32_t *plan_dst, int32_t *group_k, int32_t *group_nk, int32_t *tile_gptr,
-                  void *workspace, int64_t workspace_bytes, void *stream_) {
+int me_plan_build(const int32_t *tbl, const int32_t *order, int64_t n_tgt, int64_t volume, int32_t tile_rows,
+                  int32_t batch_groups, int32_t *plan_src, int32_t *plan_dst, int32_t *batch_desc, int32_t *tile_bptr,
+                  int32_t *item_gptr, void *workspace, int64_t workspace_bytes, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   ME_CHECK(volume >= 1 && volume <= 65535, "kernel volume out of range");
   ME_CHECK(tile_rows >= ME_GROUP_ROWS && tile_rows <= ME_MAX_TILE_ROWS, "tile_rows out of range");
+  ME_CHECK(batch_groups >= 1 && batch_groups <= ME_MAX_BATCH_GROUPS, "batch_groups out of range");
   ME_CHECK(workspace_bytes >= me_plan_workspace_bytes(n_tgt, volume, tile_rows), "workspace too small");
   const int64_t n_tiles = me_plan_num_tiles(n_tgt, tile_rows);
   if (n_tiles == 0) {
-    ME_HIP(hipMemsetAsync(tile_gptr, 0, 4, stream));
+    ME_HIP(hipMemsetAsync(tile_bptr, 0, 4, stream));
+    ME_HIP(hipMemsetAsync(item_gptr, 0, 4, stream));
     return 0;
   }
   const int64_t items = n_tiles * volume;
@@ -638,15 +730,22 @@ int me_plan_build(const int32_t *tbl, int64_t n_tgt, int64_t volume, int32_t til
   const int64_t asz = align_up(items * 4, 256);
   uint32_t *gcount = reinterpret_cast<uint32_t *>(ws);
   uint32_t *goffs = reinterpret_cast<uint32_t *>(ws + asz);
-  uint32_t *gtotal = reinterpret_cast<uint32_t *>(ws + 2 * asz);
-  void *scan_ws = ws + 2 * asz + 256;
+  uint32_t *bcount = reinterpret_cast<uint32_t *>(ws + 2 * asz);
+  uint32_t *boffs = reinterpret_cast<uint32_t *>(ws + 3 * asz);
+  uint32_t *gtotal = reinterpret_cast<uint32_t *>(ws + 4 * asz);
+  uint32_t *btotal = gtotal + 1;
+  void *scan_ws = ws + 4 * asz + 256;
   const dim3 grid((unsigned)ceil_div(items, 4)), block(256);
-  hipLaunchKernelGGL(k_plan_count, grid, block, 0, stream, tbl, n_tgt, volume, items, (int)tile_rows, gcount);
+  hipLaunchKernelGGL(k_plan_count, grid, block, 0, stream, tbl, order, n_tgt, volume, items, (int)tile_rows,
+                     (int)batch_groups, gcount, bcount);
   ME_LAUNCH_CHECK();
   if (int rc = exclusive_scan_u32(gcount, goffs, items, gtotal, scan_ws, scan_workspace_bytes(items), stream))
     return rc;
-  hipLaunchKernelGGL(k_plan_fill, grid, block, 0, stream, tbl, n_tgt, volume, items, (int)tile_rows, gcount,
-                     goffs, gtotal, plan_src, plan_dst, group_k, group_nk, tile_gptr, n_tiles);
+  if (int rc = exclusive_scan_u32(bcount, boffs, items, btotal, scan_ws, scan_workspace_bytes(items), stream))
+    return rc;
+  hipLaunchKernelGGL(k_plan_fill, grid, block, 0, stream, tbl, order, n_tgt, volume, items, (int)tile_rows,
+                     (int)batch_groups, goffs, gtotal, boffs, btotal, plan_src, plan_dst, batch_desc, tile_bptr,
+                     item_gptr, n_tiles);
   ME_LAUNCH_CHECK();
   return 0;
 }

@@ -51,14 +51,26 @@ def test_host_only_entry_points():
     assert lib.me_conv_wgrad_workspace_bytes(koffs, 3, 8, 16) == (5000 // 64 + 3) * 64 * 16 * 4
 
 
-def test_choose_tile_rows_fills_the_chip():
-    """Host-only heuristic: tiles x slabs should sit just below a multiple of the resident slots."""
+def test_plan_config_fills_the_chip():
+    """Host-only heuristic: tiles x slabs should sit just below a multiple of the resident slots and the
+    workgroup must fit the 160 KiB LDS."""
     from minkowskiengine_amd import _lib
     lib = _lib.load()
-    t = lib.me_conv_choose_tile_rows(100000, 27, 834914, 64, 128)
-    assert 16 <= t <= 256
+
+    def cfg(*args):
+        t, g = ctypes.c_int32(0), ctypes.c_int32(0)
+        assert lib.me_conv_plan_config(*args, ctypes.byref(t), ctypes.byref(g)) == 0
+        return t.value, g.value
+
+    t, g = cfg(100000, 27, 834914, 64, 128)
+    assert 16 <= t <= 256 and 1 <= g <= 4
+    lds = (t + 1) * (64 + 4) * 4 + g * 16 * (68 * 4 + 4)
+    occ = min(3, (160 * 1024) // lds)
+    assert occ >= 1
     items = -(-100000 // t) * 2
-    slots = 256 * 3
+    slots = 256 * occ
     assert items % slots == 0 or items % slots > 0.9 * slots, (t, items)
-    for args in [(1, 27, 1, 4, 4), (4977, 27, 52353, 256, 256), (200000, 125, 889332, 3, 32), (400000, 81, 1837616, 32, 64)]:
-        assert 16 <= lib.me_conv_choose_tile_rows(*args) <= 256
+    for args in [(1, 27, 1, 4, 4), (4977, 27, 52353, 256, 256), (200000, 125, 889332, 3, 32),
+                 (400000, 81, 1837616, 32, 64), (100000, 27, 834914, 128, 64), (20000, 8, 20000, 96, 96)]:
+        t, g = cfg(*args)
+        assert 16 <= t <= 256 and 1 <= g <= 4

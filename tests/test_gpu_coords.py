@@ -139,37 +139,50 @@ def test_kernel_map_pair_sets_identical(device, n, extent, D, ks, stride, dil, r
     assert mgr._kernel_map(key, okey, ksl, [stride] * D, [dil] * D, MEB.RegionType(region), None, False, False) is km
 
 
-@pytest.mark.parametrize("target,T", [("out", 128), ("in", 128), ("out", 131), ("in", 37), ("out", 16), ("out", 256)])
-def test_tile_plan_covers_every_pair_once(device, target, T):
+@pytest.mark.parametrize("target,T,CAP", [("out", 128, 4), ("in", 128, 4), ("out", 131, 3), ("in", 37, 1),
+                                          ("out", 16, 2), ("out", 256, 4)])
+def test_tile_plan_covers_every_pair_once(device, target, T, CAP):
     from minkowskiengine_amd import _lib
     coords = make_cloud(5000, 16, 3, seed=21, batch=2, negative=True)
     MEB, mgr = _mgr()
     key, _ = mgr.insert_and_map(coords.to(device), [1, 1, 1], "")
     okey = mgr.stride(key, [2, 2, 2])
     km = mgr._kernel_map(key, okey, [3, 3, 3], [2, 2, 2], [1, 1, 1], MEB.RegionType.HYPER_CUBE, None, False, False)
-    plan_src, plan_dst, group_k, group_nk, tile_gptr = [t.cpu().numpy() for t in km.plan(target, T)]
+    plan_src, plan_dst, batch_desc, tile_bptr, item_gptr = [t.cpu().numpy() for t in km.plan(target, T, CAP)]
     tbl = km.table(target).cpu().numpy()
     n_tgt = km.n_out if target == "out" else km.n_in
+    order = km.order(target)
+    order = order.cpu().numpy() if order is not None else np.arange(n_tgt)
+    assert sorted(order.tolist()) == list(range(n_tgt)), "the tile order is a permutation of the target rows"
     G = _lib.ME_GROUP_ROWS
+    K = km.volume
     n_tiles = (n_tgt + T - 1) // T
-    assert tile_gptr[0] == 0 and np.all(np.diff(tile_gptr[:n_tiles + 1]) >= 0)
+    assert tile_bptr[0] == 0 and np.all(np.diff(tile_bptr[:n_tiles + 1]) >= 0)
+    assert item_gptr[0] == 0 and np.all(np.diff(item_gptr[:n_tiles * K + 1]) >= 0)
     seen = set()
+    next_group = 0
     for t in range(n_tiles):
-        ks = group_k[tile_gptr[t]:tile_gptr[t + 1]]
-        assert np.all(np.diff(ks) >= 0), "groups of a tile must be sorted by offset"
-        for g in range(tile_gptr[t], tile_gptr[t + 1]):
-            k = int(group_k[g])
-            later = ks[ks > k]
-            assert int(group_nk[g]) == (int(later[0]) if later.size else -1), "next-offset hint wrong"
-            for j in range(G):
-                s, d = int(plan_src[g * G + j]), int(plan_dst[g * G + j])
-                if s < 0:
-                    assert d == T, "padding slots must point at the dummy row"
-                    continue
-                row = t * T + d
-                assert 0 <= d < T and row < n_tgt and tbl[k, row] == s
-                assert (k, row) not in seen
-                seen.add((k, row))
+        last_k = -1
+        for b in range(tile_bptr[t], tile_bptr[t + 1]):
+            g0, y = int(batch_desc[2 * b]), int(batch_desc[2 * b + 1])
+            ng, k = y & 255, y >> 8
+            assert 1 <= ng <= CAP and k >= last_k, "batches of a tile are sorted by offset, one offset each"
+            assert g0 == next_group, "batches tile the group list without gaps"
+            assert item_gptr[t * K + k] <= g0 and g0 + ng <= item_gptr[t * K + k + 1]
+            next_group = g0 + ng
+            last_k = k
+            for g in range(g0, g0 + ng):
+                for j in range(G):
+                    s, d = int(plan_src[g * G + j]), int(plan_dst[g * G + j])
+                    if s < 0:
+                        assert d == T, "padding slots must point at the dummy row"
+                        continue
+                    assert 0 <= d < T and t * T + d < n_tgt
+                    row = int(order[t * T + d])
+                    assert tbl[k, row] == s
+                    assert (k, row) not in seen
+                    seen.add((k, row))
+    assert next_group == item_gptr[n_tiles * K]
     assert len(seen) == int((tbl[:, :n_tgt] >= 0).sum()) == km.n_pairs
 
 
