@@ -208,6 +208,31 @@ int me_conv_wgrad_f32(const float *x_dev, int32_t c_in, const float *dy_dev, int
  * workgroups per CU the ranges are sized for; 0 = shipped defaults. */
 void me_debug_set_wgrad_config(int depth, int wgs_per_cu);
 
+/* ---- bf16 features (fp32 accumulation) --------------------------------------------------------------
+ * The reference computes in float / double only (AT_DISPATCH_FLOATING_TYPES, src/convolution_gpu.cu:137-155);
+ * BASELINE configs[2] (MinkUNet34C, bf16) asks for a reduced-precision path.  Feature matrices are bf16
+ * (uint16_t bit patterns, torch.bfloat16), [n, c] row-major; the SAME tile plans / pair lists are used.
+ * Semantics: weights rounded to bf16 (RNE) at pack time, exact products, fp32 sums in the plan's fixed
+ * order, one rounding of the result to bf16 — i.e. the fp32 convolution of the rounded operands.
+ *   me_conv_pack_weights_bf16: w_is_f32 != 0: w_dev holds fp32 master weights, else bf16; layouts and
+ *                              `transposed` as for me_conv_pack_weights_f32.
+ *   me_conv_target_bf16:       forward / dgrad on v_mfma_f32_16x16x32_bf16 (arguments as me_conv_target_f32).
+ *   me_conv_wgrad_bf16:        grad_w (fp32 out) from bf16 x / dy; workspace as for me_conv_wgrad_f32. */
+int64_t me_conv_packed_weight_elems_bf16(int64_t volume, int32_t c_src, int32_t c_dst); /* bf16 elements */
+int me_conv_pack_weights_bf16(const void *w_dev, int32_t w_is_f32, int64_t volume, int32_t c_src, int32_t c_dst,
+                              int32_t transposed, uint16_t *packed_dev, void *stream);
+int me_conv_target_bf16(const uint16_t *src_feat_dev, int64_t n_src, int32_t c_src,
+                        const uint16_t *packed_w_dev, int64_t volume, int32_t c_dst,
+                        const int32_t *plan_src_dev, const int32_t *plan_dst_dev,
+                        const int32_t *batch_desc_dev, const int32_t *tile_bptr_dev,
+                        const int32_t *order_dev, uint16_t *dst_feat_dev,
+                        int64_t n_tgt, int32_t tile_rows, int32_t batch_groups, void *stream);
+int me_conv_wgrad_bf16(const uint16_t *x_dev, int32_t c_in, const uint16_t *dy_dev, int32_t c_out,
+                       const int32_t *in_pairs_dev, const int32_t *out_pairs_dev,
+                       const int64_t *k_offsets /* host */, const int64_t *k_offsets_dev,
+                       int64_t volume, float *grad_w_dev, void *workspace_dev,
+                       int64_t workspace_bytes, void *stream);
+
 /* ---- pooling / broadcast (replace src/pooling_avg_kernel.cu, src/pooling_max_kernel.cu,
  *      src/broadcast_kernel.cu; CPU twins src/pooling_avg_kernel.hpp:41-150,
  *      src/pooling_max_kernel.hpp:36-117, src/broadcast_kernel.hpp:35-160) ------------------------

@@ -563,7 +563,7 @@ _SPATIAL_TILES = os.environ.get("ME_AMD_SPATIAL_TILES", "0") != "0"  # tiles of 
 def _check_feat(name, t):
     _check(t.is_contiguous(), name, "must be contiguous")
     _check(t.is_cuda, name, "must be CUDA (ROCm) — the MI355X path has no CPU implementation")
-    _check(t.dtype == torch.float32, name, "must be float32 (this round implements the fp32 path)")
+    _check(t.dtype in (torch.float32, torch.bfloat16), name, "must be float32 or bfloat16, got", t.dtype)
 
 
 class KernelTimer:
@@ -573,29 +573,36 @@ class KernelTimer:
 
     def __init__(self):
         self.events = {}
+        self.flops = {}
 
     def record(self, name, device):
         ev = torch.cuda.Event(enable_timing=True)
         ev.record(torch.cuda.current_stream(device))
         return ev
 
-    def add(self, name, start, end):
+    def add(self, name, start, end, flops=0.0):
         self.events.setdefault(name, []).append((start, end))
+        self.flops[name] = self.flops.get(name, 0.0) + flops
 
     def summary(self):
         """{name: (launches, mean ms)} — call after torch.cuda.synchronize()."""
         return {k: (len(v), sum(s.elapsed_time(e) for s, e in v) / len(v)) for k, v in self.events.items()}
 
+    def totals(self):
+        """{name: (launches, total ms, total algorithmic flops)} — call after torch.cuda.synchronize()."""
+        return {k: (len(v), sum(s.elapsed_time(e) for s, e in v), self.flops.get(k, 0.0))
+                for k, v in self.events.items()}
+
 
 KERNEL_TIMER = None  # set to a KernelTimer() to time launches
 
 
-def _timed(name, device, launch):
+def _timed(name, device, launch, flops=0.0):
     if KERNEL_TIMER is None:
         return launch()
     s = KERNEL_TIMER.record(name, device)
     r = launch()
-    KERNEL_TIMER.add(name, s, KERNEL_TIMER.record(name, device))
+    KERNEL_TIMER.add(name, s, KERNEL_TIMER.record(name, device), flops)
     return r
 
 
@@ -615,25 +622,43 @@ def _conv_target(src_feat, kernel, km, target, n_tgt, name="conv_target", transp
     volume = int(kernel.shape[0])
     c_src, c_dst = (int(kernel.shape[2]), int(kernel.shape[1])) if transposed else \
         (int(kernel.shape[1]), int(kernel.shape[2]))
-    out = torch.empty((n_tgt, c_dst), dtype=torch.float32, device=dev)
+    bf16 = src_feat.dtype == torch.bfloat16
+    out = torch.empty((n_tgt, c_dst), dtype=src_feat.dtype, device=dev)
     if n_tgt == 0:
         return out
     tile_rows, batch_groups = plan_config(n_tgt, km.volume, km.n_pairs, c_src, c_dst)
     plan_src, plan_dst, batch_desc, tile_bptr, _ = km.plan(target, tile_rows, batch_groups)
-    packed = torch.empty(int(lib.me_conv_packed_weight_elems(volume, c_src, c_dst)), dtype=torch.float32, device=dev)
+    flops = 2.0 * km.n_pairs * c_src * c_dst
     with torch.cuda.device(dev):
+        if bf16:
+            # bf16 features: weights (fp32 master copy or bf16) are rounded to bf16 while being packed
+            _check(kernel.dtype in (torch.float32, torch.bfloat16), "kernel must be float32 or bfloat16")
+            packed = torch.empty(int(lib.me_conv_packed_weight_elems_bf16(volume, c_src, c_dst)),
+                                 dtype=torch.bfloat16, device=dev)
+            _lib.check(lib.me_conv_pack_weights_bf16(_ptr(kernel), 1 if kernel.dtype == torch.float32 else 0, volume,
+                                                     c_src, c_dst, 1 if transposed else 0, _ptr(packed),
+                                                     _stream(dev)))
+            _timed(name, dev, lambda: _lib.check(lib.me_conv_target_bf16(
+                _ptr(src_feat), src_feat.shape[0], c_src, _ptr(packed), km.volume, c_dst, _ptr(plan_src),
+                _ptr(plan_dst), _ptr(batch_desc), _ptr(tile_bptr), _ptr(km.order(target)), _ptr(out), n_tgt,
+                tile_rows, batch_groups, _stream(dev))), flops=flops)
+            return out
+        _check(kernel.dtype == torch.float32, "float32 features need a float32 kernel, got", kernel.dtype)
+        packed = torch.empty(int(lib.me_conv_packed_weight_elems(volume, c_src, c_dst)), dtype=torch.float32,
+                             device=dev)
         _lib.check(lib.me_conv_pack_weights_f32(_ptr(kernel), volume, c_src, c_dst, 1 if transposed else 0,
                                                 _ptr(packed), _stream(dev)))
         _timed(name, dev, lambda: _lib.check(lib.me_conv_target_f32(
             _ptr(src_feat), src_feat.shape[0], c_src, _ptr(packed), km.volume, c_dst, _ptr(plan_src),
             _ptr(plan_dst), _ptr(batch_desc), _ptr(tile_bptr), _ptr(km.order(target)), _ptr(out), n_tgt, tile_rows,
-            batch_groups, _stream(dev))))
+            batch_groups, _stream(dev))), flops=flops)
     return out
 
 
 def _conv_forward(in_feat, kernel, km, algo=None):
     algo = algo or _ALGO
     if algo == "naive":
+        _check(in_feat.dtype == torch.float32, "the cross-check kernels are float32 only")
         lib = _lib.load()
         dev = in_feat.device
         out = torch.zeros((km.n_out, kernel.shape[2]), dtype=torch.float32, device=dev)
@@ -650,7 +675,11 @@ def _conv_backward(in_feat, grad_out, kernel, km, algo=None):
     lib = _lib.load()
     dev = in_feat.device
     volume, c_in, c_out = int(kernel.shape[0]), int(kernel.shape[1]), int(kernel.shape[2])
+    if grad_out.dtype != in_feat.dtype:
+        grad_out = grad_out.to(in_feat.dtype)
+    bf16 = in_feat.dtype == torch.bfloat16
     if algo == "naive":
+        _check(not bf16, "the cross-check kernels are float32 only")
         grad_in = torch.zeros((km.n_in, c_in), dtype=torch.float32, device=dev)
         grad_w = torch.zeros_like(kernel)
         with torch.cuda.device(dev):
@@ -661,16 +690,18 @@ def _conv_backward(in_feat, grad_out, kernel, km, algo=None):
         return grad_in, grad_w
     # dgrad: the same target-stationary kernel; the weights are packed transposed per offset
     grad_in = _conv_target(grad_out, kernel, km, "in", km.n_in, name="conv_dgrad", transposed=True)
-    # wgrad
-    grad_w = torch.empty_like(kernel)
+    # wgrad: always accumulated and reduced in fp32; handed back in the kernel's dtype
+    grad_w = torch.empty(kernel.shape, dtype=torch.float32, device=dev)
     koffs = (ctypes.c_int64 * (volume + 1))(*km.k_offsets)
     wsb = int(lib.me_conv_wgrad_workspace_bytes(koffs, volume, c_in, c_out))
     ws = _workspace(wsb, dev)
+    fn = lib.me_conv_wgrad_bf16 if bf16 else lib.me_conv_wgrad_f32
     with torch.cuda.device(dev):
-        _timed("conv_wgrad", dev, lambda: _lib.check(lib.me_conv_wgrad_f32(
+        _timed("conv_wgrad", dev, lambda: _lib.check(fn(
             _ptr(in_feat), c_in, _ptr(grad_out), c_out, _ptr(km.in_pairs), _ptr(km.out_pairs), koffs,
-            _ptr(km.k_offsets_dev), volume, _ptr(grad_w), _ptr(ws), ws.numel(), _stream(dev))))
-    return grad_in, grad_w
+            _ptr(km.k_offsets_dev), volume, _ptr(grad_w), _ptr(ws), ws.numel(), _stream(dev))),
+            flops=2.0 * km.n_pairs * c_in * c_out)
+    return grad_in, grad_w if kernel.dtype == torch.float32 else grad_w.to(kernel.dtype)
 
 
 def _prepare_conv(in_feat, kernel, kernel_stride, expand_coordinates, in_key, out_key, manager, transpose):

@@ -110,7 +110,8 @@ class MinkowskiConvolutionBase(MinkowskiModuleBase):
         assert input.D == self.dimension
         if self.use_mm:
             out_coordinate_map_key = input.coordinate_map_key
-            outfeat = input.F.mm(self.kernel)
+            # bf16 features with fp32 master weights: the product runs in the feature dtype
+            outfeat = input.F.mm(self.kernel if self.kernel.dtype == input.F.dtype else self.kernel.to(input.F.dtype))
         else:
             # (the reference passes expand_coordinates positionally into the tensor_stride slot,
             # MinkowskiConvolution.py:311-313; passed by keyword here)
@@ -119,7 +120,7 @@ class MinkowskiConvolutionBase(MinkowskiModuleBase):
             outfeat = self.conv.apply(input.F, self.kernel, self.kernel_generator, self.convolution_mode,
                                       input.coordinate_map_key, out_coordinate_map_key, input._manager)
         if self.bias is not None:
-            outfeat = outfeat + self.bias
+            outfeat = outfeat + (self.bias if self.bias.dtype == outfeat.dtype else self.bias.to(outfeat.dtype))
         return SparseTensor(outfeat, coordinate_map_key=out_coordinate_map_key, coordinate_manager=input._manager)
 
     def reset_parameters(self, is_transpose=False):

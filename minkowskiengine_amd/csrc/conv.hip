@@ -21,17 +21,11 @@
 //     no global atomics.
 // dgrad is the same kernel with source = grad_out, W = per-offset transposed kernel and the plan
 // of the transposed neighbour table.  wgrad reduces over the per-offset pair lists in chunks.
-#include "common.hpp"
+#include "conv_common.hpp"
 
 #include <type_traits>
 
 namespace me {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int kLdsBudget = 160 * 1024;
-constexpr int kAccPad = 4;  // accumulator row stride NC + 4 floats: spreads the row-scattered adds over banks
 
 // LDS bytes of one workgroup of k_conv_tile_f32<NC, KC>: accumulator tile (+ one dummy row for padding
 // slots), one stage buffer of gathered rows and the target-row indices of the batch
@@ -406,36 +400,36 @@ __device__ __forceinline__ int64_t wgrad_range_of_pair(int64_t e, int64_t n_pair
 // ring).  `ch` is already clamped into the row (channels beyond the real count only feed outputs that
 // k_wgrad_reduce ignores).  CHECK: the pair may be a padding pair (row < 0) -> zeros.
 // VEC: c is a multiple of V (one V*4-byte load); otherwise V scalar loads with clamped channels.
-template <int V, bool VEC, bool CHECK>
-__device__ __forceinline__ void load_piece(const float *__restrict__ base, int32_t row, int c, int ch,
+template <typename T, int V, bool VEC, bool CHECK>
+__device__ __forceinline__ void load_piece(const T *__restrict__ base, int32_t row, int c, int ch,
                                            float (&out)[V]) {
+  typedef T tvec __attribute__((ext_vector_type(V)));
   const bool ok = !CHECK || row >= 0;
   const uint32_t r0 = (uint32_t)(CHECK ? max(row, 0) : row) * (uint32_t)c;
   if constexpr (VEC) {
-    const float *p = base + (r0 + (uint32_t)ch);
-    if constexpr (V == 4) {
-      const f32x4 t = *reinterpret_cast<const f32x4 *>(p);
-      out[0] = ok ? t.x : 0.f; out[1] = ok ? t.y : 0.f; out[2] = ok ? t.z : 0.f; out[3] = ok ? t.w : 0.f;
-    } else if constexpr (V == 2) {
-      typedef float f32x2 __attribute__((ext_vector_type(2)));
-      const f32x2 t = *reinterpret_cast<const f32x2 *>(p);
-      out[0] = ok ? t.x : 0.f; out[1] = ok ? t.y : 0.f;
+    const T *p = base + (r0 + (uint32_t)ch);
+    if constexpr (V == 1) {
+      const T t = *p;
+      out[0] = ok ? (float)t : 0.f;
     } else {
-      const float t = *p;
-      out[0] = ok ? t : 0.f;
+      const tvec t = *reinterpret_cast<const tvec *>(p);  // one V * sizeof(T)-byte load
+#pragma unroll
+      for (int m = 0; m < V; ++m) out[m] = ok ? (float)t[m] : 0.f;
     }
   } else {
 #pragma unroll
     for (int m = 0; m < V; ++m) {
-      const float t = base[r0 + (uint32_t)(ch + m < c ? ch + m : 0)];
-      out[m] = ok ? t : 0.f;
+      const T t = base[r0 + (uint32_t)(ch + m < c ? ch + m : 0)];
+      out[m] = ok ? (float)t : 0.f;
     }
   }
 }
 
-template <int NB, int DEPTH, bool VEC>
-__global__ __launch_bounds__(256, (NB == 4 ? 2 : 3)) void k_wgrad_f32(const float *__restrict__ x, int c_in,
-                                                  const float *__restrict__ dy, int c_out,
+// T: element type of the gathered rows (float, or __bf16 converted on load: the products of bf16 values are
+// exact in fp32, so the bf16 path computes the same sums as an fp32 convolution of the rounded inputs).
+template <typename T, int NB, int DEPTH, bool VEC>
+__global__ __launch_bounds__(256, (NB == 4 ? 2 : 3)) void k_wgrad_f32(const T *__restrict__ x, int c_in,
+                                                  const T *__restrict__ dy, int c_out,
                                                   const int32_t *__restrict__ in_pairs,
                                                   const int32_t *__restrict__ out_pairs,
                                                   const int64_t *__restrict__ koffs, int volume,
@@ -508,8 +502,8 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 3)) void k_wgrad_f32(const floa
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
       permute(d);
-      load_piece<MB, VEC, true>(x, ri_nx, c_in, cha, ra[d]);
-      load_piece<NB, VEC, true>(dy, ro_nx, c_out, chb, rb[d]);
+      load_piece<T, MB, VEC, true>(x, ri_nx, c_in, cha, ra[d]);
+      load_piece<T, NB, VEC, true>(dy, ro_nx, c_out, chb, rb[d]);
     }
     permute(DEPTH);
     // one block = 16 steps of 4 pairs.  At step st: multiply ring slot st % DEPTH, refill it with step
@@ -521,8 +515,8 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 3)) void k_wgrad_f32(const floa
         if (!CHECK || st < nsteps) {  // wave-uniform
           const int d = st % DEPTH;
           mma_step(ra[d], rb[d]);
-          load_piece<MB, VEC, CHECK>(x, ri_nx, c_in, cha, ra[d]);
-          load_piece<NB, VEC, CHECK>(dy, ro_nx, c_out, chb, rb[d]);
+          load_piece<T, MB, VEC, CHECK>(x, ri_nx, c_in, cha, ra[d]);
+          load_piece<T, NB, VEC, CHECK>(dy, ro_nx, c_out, chb, rb[d]);
           permute(st + DEPTH + 1);
           // keep hipcc's scheduler from sinking the refill loads down to their use DEPTH steps later
           // (it would trade the whole prefetch distance for a few registers)
@@ -695,20 +689,6 @@ static ConvVariant conv_variant(int c_src, int c_dst) {
   return v;
 }
 
-static int device_cu_count() {
-  static int cus = 0;
-  if (cus == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-        prop.multiProcessorCount > 0)
-      cus = prop.multiProcessorCount;
-    else
-      cus = 256;  // MI355X
-  }
-  return cus;
-}
-
 int g_conv_variant = 0;  // me_debug_set_conv_variant
 
 template <int NC, int KC, int VAR>
@@ -772,6 +752,51 @@ static WgradGeom wgrad_geom(int64_t n_pairs, int64_t volume, int c_in, int c_out
 }  // namespace me
 
 using namespace me;
+
+template <typename T>
+static int wgrad_launch(const T *x, int32_t c_in, const T *dy, int32_t c_out, const int32_t *in_pairs,
+                        const int32_t *out_pairs, const int64_t *k_offsets, const int64_t *k_offsets_dev,
+                        int64_t volume, float *grad_w, void *workspace, int64_t workspace_bytes,
+                        hipStream_t stream) {
+  ME_CHECK(volume >= 1 && volume <= 65535, "kernel volume out of range");
+  ME_CHECK(c_in > 0 && c_out > 0, "channel counts must be positive");
+  ME_CHECK((uintptr_t)x % 16 == 0 && (uintptr_t)dy % 16 == 0, "feature pointers must be 16-byte aligned");
+  ME_CHECK(workspace_bytes >= me_conv_wgrad_workspace_bytes(k_offsets, volume, c_in, c_out),
+           "workspace too small");
+  const int64_t n_pairs = k_offsets[volume];
+  const WgradGeom g = wgrad_geom(n_pairs, volume, c_in, c_out);
+  float *partial = reinterpret_cast<float *>(workspace);
+  const int depth = g_wgrad_depth > 0 ? g_wgrad_depth : (g.nb == 4 ? 8 : 4);  // measured: profiles/r01_tune_wgrad_v2.log
+  if (n_pairs > 0) {
+    const dim3 grid((unsigned)g.ranges, (unsigned)g.n_cib, (unsigned)g.gz);
+    const dim3 block(64 * g.waves);
+    const bool vec = (c_in % kWgMB) == 0 && (c_out % g.nb) == 0;
+#define ME_WGRAD_LAUNCH(NBV, DV)                                                                                 \
+  do {                                                                                                           \
+    if (vec)                                                                                                     \
+      hipLaunchKernelGGL((k_wgrad_f32<T, NBV, DV, true>), grid, block, 0, stream, x, c_in, dy, c_out, in_pairs,  \
+                         out_pairs, k_offsets_dev, (int)volume, n_pairs, (int)g.ranges, g.n_cob, partial);       \
+    else                                                                                                         \
+      hipLaunchKernelGGL((k_wgrad_f32<T, NBV, 8, false>), grid, block, 0, stream, x, c_in, dy, c_out, in_pairs,  \
+                         out_pairs, k_offsets_dev, (int)volume, n_pairs, (int)g.ranges, g.n_cob, partial);       \
+  } while (0)
+    if (g.nb == 1) { if (depth == 4) ME_WGRAD_LAUNCH(1, 4); else ME_WGRAD_LAUNCH(1, 8); }
+    else if (g.nb == 2) { if (depth == 4) ME_WGRAD_LAUNCH(2, 4); else ME_WGRAD_LAUNCH(2, 8); }
+    else { if (depth == 4) ME_WGRAD_LAUNCH(4, 4); else ME_WGRAD_LAUNCH(4, 8); }
+#undef ME_WGRAD_LAUNCH
+    ME_LAUNCH_CHECK();
+  }
+  const dim3 rgrid((unsigned)ceil_div(g.slot_floats, 64), (unsigned)volume);
+#define ME_WGRAD_REDUCE(NBV)                                                                               \
+  hipLaunchKernelGGL((k_wgrad_reduce<NBV>), rgrid, dim3(256), 0, stream, partial, k_offsets_dev, (int)volume, \
+                     n_pairs > 0 ? n_pairs : 1, (int)g.ranges, g.n_cib, g.n_cob, c_in, c_out, grad_w)
+  if (g.nb == 1) ME_WGRAD_REDUCE(1);
+  else if (g.nb == 2) ME_WGRAD_REDUCE(2);
+  else ME_WGRAD_REDUCE(4);
+#undef ME_WGRAD_REDUCE
+  ME_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" {
 
@@ -912,45 +937,17 @@ int me_conv_wgrad_f32(const float *x, int32_t c_in, const float *dy, int32_t c_o
                       const int32_t *out_pairs, const int64_t *k_offsets, const int64_t *k_offsets_dev,
                       int64_t volume, float *grad_w, void *workspace, int64_t workspace_bytes,
                       void *stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  ME_CHECK(volume >= 1 && volume <= 65535, "kernel volume out of range");
-  ME_CHECK(c_in > 0 && c_out > 0, "channel counts must be positive");
-  ME_CHECK((uintptr_t)x % 16 == 0 && (uintptr_t)dy % 16 == 0, "feature pointers must be 16-byte aligned");
-  ME_CHECK(workspace_bytes >= me_conv_wgrad_workspace_bytes(k_offsets, volume, c_in, c_out),
-           "workspace too small");
-  const int64_t n_pairs = k_offsets[volume];
-  const WgradGeom g = wgrad_geom(n_pairs, volume, c_in, c_out);
-  float *partial = reinterpret_cast<float *>(workspace);
-  const int depth = g_wgrad_depth > 0 ? g_wgrad_depth : (g.nb == 4 ? 8 : 4);  // measured: profiles/r01_tune_wgrad_v2.log
-  if (n_pairs > 0) {
-    const dim3 grid((unsigned)g.ranges, (unsigned)g.n_cib, (unsigned)g.gz);
-    const dim3 block(64 * g.waves);
-    const bool vec = (c_in % kWgMB) == 0 && (c_out % g.nb) == 0;
-#define ME_WGRAD_LAUNCH(NBV, DV)                                                                              \
-  do {                                                                                                        \
-    if (vec)                                                                                                  \
-      hipLaunchKernelGGL((k_wgrad_f32<NBV, DV, true>), grid, block, 0, stream, x, c_in, dy, c_out, in_pairs,  \
-                         out_pairs, k_offsets_dev, (int)volume, n_pairs, (int)g.ranges, g.n_cob, partial);    \
-    else                                                                                                      \
-      hipLaunchKernelGGL((k_wgrad_f32<NBV, 8, false>), grid, block, 0, stream, x, c_in, dy, c_out, in_pairs,  \
-                         out_pairs, k_offsets_dev, (int)volume, n_pairs, (int)g.ranges, g.n_cob, partial);    \
-  } while (0)
-    if (g.nb == 1) { if (depth == 4) ME_WGRAD_LAUNCH(1, 4); else ME_WGRAD_LAUNCH(1, 8); }
-    else if (g.nb == 2) { if (depth == 4) ME_WGRAD_LAUNCH(2, 4); else ME_WGRAD_LAUNCH(2, 8); }
-    else { if (depth == 4) ME_WGRAD_LAUNCH(4, 4); else ME_WGRAD_LAUNCH(4, 8); }
-#undef ME_WGRAD_LAUNCH
-    ME_LAUNCH_CHECK();
-  }
-  const dim3 rgrid((unsigned)ceil_div(g.slot_floats, 64), (unsigned)volume);
-#define ME_WGRAD_REDUCE(NBV)                                                                               \
-  hipLaunchKernelGGL((k_wgrad_reduce<NBV>), rgrid, dim3(256), 0, stream, partial, k_offsets_dev, (int)volume, \
-                     n_pairs > 0 ? n_pairs : 1, (int)g.ranges, g.n_cib, g.n_cob, c_in, c_out, grad_w)
-  if (g.nb == 1) ME_WGRAD_REDUCE(1);
-  else if (g.nb == 2) ME_WGRAD_REDUCE(2);
-  else ME_WGRAD_REDUCE(4);
-#undef ME_WGRAD_REDUCE
-  ME_LAUNCH_CHECK();
-  return 0;
+  return wgrad_launch<float>(x, c_in, dy, c_out, in_pairs, out_pairs, k_offsets, k_offsets_dev, volume, grad_w,
+                             workspace, workspace_bytes, (hipStream_t)stream_);
+}
+
+int me_conv_wgrad_bf16(const uint16_t *x, int32_t c_in, const uint16_t *dy, int32_t c_out, const int32_t *in_pairs,
+                       const int32_t *out_pairs, const int64_t *k_offsets, const int64_t *k_offsets_dev,
+                       int64_t volume, float *grad_w, void *workspace, int64_t workspace_bytes,
+                       void *stream_) {
+  return wgrad_launch<__bf16>(reinterpret_cast<const __bf16 *>(x), c_in, reinterpret_cast<const __bf16 *>(dy),
+                              c_out, in_pairs, out_pairs, k_offsets, k_offsets_dev, volume, grad_w, workspace,
+                              workspace_bytes, (hipStream_t)stream_);
 }
 
 int me_conv_forward_naive_f32(const float *in_feat, int32_t c_in, const float *w, int32_t c_out,

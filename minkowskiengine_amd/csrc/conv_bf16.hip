@@ -1,0 +1,385 @@
+// Sparse convolution on bf16 features for gfx950 (MI355X): forward / dgrad on v_mfma_f32_16x16x32_bf16
+// with fp32 accumulation, weight gradient on the fp32 matrix pipe fed with bf16 rows (conv.hip).
+//
+// The reference has no reduced-precision path (AT_DISPATCH_FLOATING_TYPES: float / double only,
+// src/convolution_gpu.cu:137-155); BASELINE config 3 (MinkUNet34C, bf16) and the north_star's
+// "MFMA bf16/fp32 tiles" ask for one.  Semantics: features and weights are rounded to bf16 (RNE),
+// products are exact, sums are fp32 in the plan's fixed order, the result is rounded to bf16 once.
+//
+// Same target-stationary structure and the SAME tile plan as k_conv_tile_f32 (conv.hip) — a workgroup
+// owns tile_rows target rows x NC output columns with an fp32 accumulator tile in LDS, walks the
+// single-offset batches of its tile, gathers rows one batch ahead into registers, stages them in LDS —
+// but a gathered row is half as many bytes, one MFMA covers 32 source channels (8 per lane: ONE
+// ds_read_b128 per operand), and a 16-group costs 2 MFMAs per 64 channels instead of 16.  The matrix pipe
+// is nearly idle here; the kernel is bound by the LDS traffic of the operand reads + the accumulator
+// read-add-write and by the gather, so source-channel chunks are as wide as possible (up to 128: one pass
+// over the plan per 128 channels).
+#include "conv_common.hpp"
+
+namespace me {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// stage row stride in elements: KC + 8 (16 bytes of padding: 16 rows x one 16-byte piece hit 64 distinct banks)
+__host__ __device__ constexpr int conv_bf16_lds_bytes(int nc, int kc, int tile_rows, int batch_groups) {
+  return (tile_rows + 1) * (nc + kAccPad) * 4 + batch_groups * 16 * ((kc + 8) * 2 + 4);
+}
+
+// R groups of one offset: per 32-channel step one ds_read_b128 per group and one MFMA, issued
+// "transposed" (A = weights, B = gathered rows) so a lane ends with 4 consecutive output columns of one
+// target row; then all accumulator reads, then all writes (distinct rows within a batch).
+template <int R, int KS, int A_LD, int ACC_LD>
+__device__ __forceinline__ void mma_groups_bf16(const __bf16 *__restrict__ a0p, const bf16x8 (&wreg)[KS],
+                                                const int32_t *__restrict__ dstp, float *__restrict__ accp) {
+  int d[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) d[r] = dstp[r * 16];
+  f32x4 acc[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    bf16x8 a[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) a[r] = *reinterpret_cast<const bf16x8 *>(a0p + r * 16 * A_LD + s * 32);
+#pragma unroll
+    for (int r = 0; r < R; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[s], a[r], acc[r], 0, 0, 0);
+  }
+  f32x4 old[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) old[r] = *reinterpret_cast<const f32x4 *>(accp + d[r] * ACC_LD);
+#pragma unroll
+  for (int r = 0; r < R; ++r) *reinterpret_cast<f32x4 *>(accp + d[r] * ACC_LD) = old[r] + acc[r];
+}
+
+// Packed weights: the register image of the MFMA A operand.  For offset k, source-channel chunk c,
+// 16-column block cb and 32-channel step v, lane (q = lane >> 4, i16 = lane & 15) finds its eight weights
+//   W[k][c*KC + v*32 + q*8 + j][cb*16 + i16],  j = 0..7
+// as ONE 16-byte element at ((((k*nchunks + c)*ncb + cb)*(KC/32) + v)*64 + lane), zero beyond the real
+// channel counts.  W_F32: the weights are given in fp32 (master weights) and rounded here.
+template <int KC, bool W_F32>
+__global__ __launch_bounds__(256) void k_pack_weights_bf16(const void *__restrict__ w_, int c_src, int c_dst,
+                                                          int transposed, int nchunks, int ncb,
+                                                          bf16x8 *__restrict__ wp, int64_t total) {
+  constexpr int KS = KC / 32;
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int lane = (int)(e % 64);
+  int64_t r = e / 64;
+  const int v = (int)(r % KS);
+  r /= KS;
+  const int cb = (int)(r % ncb);
+  r /= ncb;
+  const int c = (int)(r % nchunks);
+  const int64_t k = r / nchunks;
+  const int q = lane >> 4, i16 = lane & 15;
+  const int col = cb * 16 + i16;
+  bf16x8 out;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int ch = c * KC + v * 32 + q * 8 + j;
+    __bf16 val = (__bf16)0.f;
+    if (ch < c_src && col < c_dst) {
+      // plain: w is [K, c_src, c_dst]; transposed (dgrad): w is the forward kernel [K, c_dst, c_src]
+      const int64_t idx = transposed ? (k * c_dst + col) * c_src + ch : (k * c_src + ch) * c_dst + col;
+      if (W_F32) val = (__bf16) reinterpret_cast<const float *>(w_)[idx];
+      else val = reinterpret_cast<const __bf16 *>(w_)[idx];
+    }
+    out[j] = val;
+  }
+  wp[e] = out;
+}
+
+// See k_conv_tile_f32 (conv.hip) for the pipeline; differences are the element type and the MFMA shape.
+// EXACT: c_src is a multiple of KC (rows need no channel guards).
+template <int NC, int KC, bool EXACT>
+__global__ __launch_bounds__(NC * 4, 3) void k_conv_tile_bf16(
+    const __bf16 *__restrict__ src, int c_src, const bf16x8 *__restrict__ wp, int c_dst,
+    const int32_t *__restrict__ plan_src, const int32_t *__restrict__ plan_dst,
+    const int32_t *__restrict__ batch_desc, const int32_t *__restrict__ tile_bptr,
+    const int32_t *__restrict__ order, __bf16 *__restrict__ dst, int64_t n_tgt, int tile_rows, int batch_groups) {
+  typedef int i32x2 __attribute__((ext_vector_type(2)));
+  constexpr int WAVES = NC / 16;
+  constexpr int NT = WAVES * 64;
+  constexpr int A_LD = KC + 8;         // bf16 elements
+  constexpr int ACC_LD = NC + kAccPad;
+  constexpr int KS = KC / 32;          // MFMA steps per chunk (= 16-byte weight registers per lane)
+  constexpr int F8 = KC / 8;           // 16-byte pieces per gathered row
+  constexpr int ITER = (ME_MAX_BATCH_GROUPS * 16 * F8 + NT - 1) / NT;
+  static_assert(KC % 32 == 0, "KC must be a multiple of 32");
+  static_assert(ME_MAX_BATCH_GROUPS == 4, "mma_groups runs cover at most 4 groups");
+
+  const int cap_rows = batch_groups * 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *s_acc = reinterpret_cast<float *>(smem);                           // [(tile_rows + 1) x ACC_LD]
+  __bf16 *s_a = reinterpret_cast<__bf16 *>(s_acc + (tile_rows + 1) * ACC_LD);  // [cap_rows x A_LD]
+  int32_t *s_dst = reinterpret_cast<int32_t *>(s_a + cap_rows * A_LD);      // [cap_rows]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15;
+  const int q = lane >> 4;
+  const int tile = blockIdx.x;
+  const int col_base = blockIdx.y * NC;
+  const bool vec_ok = (c_src % 8) == 0;
+  const int nchunks = (c_src + KC - 1) / KC;
+  const int ncb = (c_dst + 15) / 16;
+  const int cb = min(col_base / 16 + wave, ncb - 1);
+
+  for (int x = tid; x < (tile_rows + 1) * ACC_LD / 4; x += NT)
+    reinterpret_cast<f32x4 *>(s_acc)[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int b0 = tile_bptr[tile];
+  const int nb = tile_bptr[tile + 1] - b0;
+  const int n_it = nb * nchunks;
+
+  auto locate = [&](int it, int &chunk, int &g0, int &ng, int &k) {
+    int r = min(it, n_it - 1);
+    chunk = 0;
+    while (r >= nb) {
+      r -= nb;
+      ++chunk;
+    }
+    const i32x2 d = *reinterpret_cast<const i32x2 *>(batch_desc + 2 * (int64_t)(b0 + r));
+    g0 = d.x;
+    ng = d.y & 255;
+    k = (int)((uint32_t)d.y >> 8);
+  };
+
+  bf16x8 stage[ITER];
+  int32_t dstv = tile_rows;
+  int32_t sidx[ITER];
+  int32_t sprev[ITER];
+  bf16x8 wreg[KS], wnxt[KS];
+
+  auto load_sidx = [&](int g0, int ng) {
+    const int last = ng * 16 - 1;
+#pragma unroll
+    for (int j = 0; j < ITER; ++j) sidx[j] = plan_src[(int64_t)g0 * 16 + min((j * NT + tid) / F8, last)];
+  };
+  auto gather = [&](int chunk, int g0, int ng) {
+    const int c0 = chunk * KC;
+    dstv = plan_dst[(int64_t)g0 * 16 + min(tid, ng * 16 - 1)];
+#pragma unroll
+    for (int j = 0; j < ITER; ++j) {
+      const int ch = c0 + ((j * NT + tid) % F8) * 8;
+      const int sr = sidx[j];
+      sprev[j] = sr;
+      const __bf16 *rowp = src + (int64_t)max(sr, 0) * c_src;
+      if (EXACT) {
+        stage[j] = *reinterpret_cast<const bf16x8 *>(rowp + ch);
+      } else if (vec_ok) {
+        // a piece is either wholly inside the row or wholly beyond it (zeroed at the stage write)
+        stage[j] = *reinterpret_cast<const bf16x8 *>(rowp + min(ch, c_src - 8));
+      } else {
+        bf16x8 t;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = rowp[min(ch + e, c_src - 1)];
+        stage[j] = t;
+      }
+    }
+  };
+  auto write_stage = [&](int chunk) {
+    const int c0 = chunk * KC;
+#pragma unroll
+    for (int j = 0; j < ITER; ++j) {
+      const int idx = j * NT + tid;
+      const int r = idx / F8;
+      const int ch = c0 + (idx % F8) * 8;
+      bf16x8 t = stage[j];
+      if (!EXACT) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (ch + e >= c_src) t[e] = (__bf16)0.f;
+      }
+      if (sprev[j] < 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = (__bf16)0.f;
+      }
+      if (r < cap_rows) *reinterpret_cast<bf16x8 *>(&s_a[r * A_LD + (idx % F8) * 8]) = t;
+    }
+    if (tid < cap_rows) s_dst[tid] = dstv;
+  };
+  auto load_w = [&](int chunk, int k) {
+    const bf16x8 *p = wp + ((((int64_t)k * nchunks + chunk) * ncb + cb) * KS) * 64 + lane;
+#pragma unroll
+    for (int v = 0; v < KS; ++v) wnxt[v] = p[v * 64];
+  };
+
+  if (n_it > 0) {
+    int chA, gA, nA, kA, chB, gB, nB, kB, chC, gC, nC, kC;
+    locate(0, chA, gA, nA, kA);
+    locate(1, chB, gB, nB, kB);
+    locate(2, chC, gC, nC, kC);
+    load_w(chA, kA);
+    load_sidx(gA, nA);
+    gather(chA, gA, nA);
+    load_sidx(gB, nB);
+
+    for (int it = 0; it < n_it; ++it) {
+      __syncthreads();
+      write_stage(chA);
+#pragma unroll
+      for (int sx = 0; sx < KS; ++sx) wreg[sx] = wnxt[sx];
+      __syncthreads();
+      load_w(chB, kB);
+      gather(chB, gB, nB);
+      load_sidx(gC, nC);
+      {
+        const __bf16 *a0p = &s_a[i16 * A_LD + q * 8];
+        const int32_t *dstp = &s_dst[i16];
+        float *accp = &s_acc[wave * 16 + q * 4];
+        if (nA == 4) {
+          mma_groups_bf16<4, KS, A_LD, ACC_LD>(a0p, wreg, dstp, accp);
+        } else if (nA == 3) {
+          mma_groups_bf16<3, KS, A_LD, ACC_LD>(a0p, wreg, dstp, accp);
+        } else if (nA == 2) {
+          mma_groups_bf16<2, KS, A_LD, ACC_LD>(a0p, wreg, dstp, accp);
+        } else {
+          mma_groups_bf16<1, KS, A_LD, ACC_LD>(a0p, wreg, dstp, accp);
+        }
+      }
+      chA = chB; gA = gB; nA = nB; kA = kB;
+      chB = chC; gB = gC; nB = nC; kB = kC;
+      locate(it + 3, chC, gC, nC, kC);
+    }
+  }
+  __syncthreads();
+
+  // every target row of the tile is written exactly once, rounded to bf16 (RNE)
+  const int64_t row0 = (int64_t)tile * tile_rows;
+  const int rows_here = (int)min((int64_t)tile_rows, n_tgt - row0);
+  const bool vec_out = (c_dst % 4) == 0;
+  for (int x = tid; x < tile_rows * NC / 4; x += NT) {
+    const int row = x / (NC / 4);
+    const int c4 = x % (NC / 4);
+    const int cc = col_base + c4 * 4;
+    if (row < rows_here && cc < c_dst) {
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(&s_acc[row * ACC_LD + c4 * 4]);
+      const int64_t grow = order ? (int64_t)order[row0 + row] : row0 + row;
+      __bf16 *o = dst + grow * c_dst + cc;
+      if (vec_out) {
+        *reinterpret_cast<bf16x4 *>(o) = bf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+      } else {
+        o[0] = (__bf16)v.x;
+        if (cc + 1 < c_dst) o[1] = (__bf16)v.y;
+        if (cc + 2 < c_dst) o[2] = (__bf16)v.z;
+        if (cc + 3 < c_dst) o[3] = (__bf16)v.w;
+      }
+    }
+  }
+}
+
+struct ConvVariantBf16 {
+  int nc, slabs, kc;
+};
+
+static ConvVariantBf16 conv_variant_bf16(int c_src, int c_dst) {
+  ConvVariantBf16 v;
+  const int rem = c_dst % 64;
+  v.nc = (rem != 0 && rem <= 32) ? 32 : 64;
+  v.slabs = (int)ceil_div(c_dst, v.nc);
+  v.kc = c_src <= 32 ? 32 : (c_src <= 64 ? 64 : 128);
+  return v;
+}
+
+template <int NC, int KC>
+static int launch_conv_tile_bf16(const __bf16 *src, int c_src, const bf16x8 *wp, int c_dst, int slabs,
+                                 const int32_t *plan_src, const int32_t *plan_dst, const int32_t *batch_desc,
+                                 const int32_t *tile_bptr, const int32_t *order, __bf16 *dst, int64_t n_tgt,
+                                 int tile_rows, int batch_groups, hipStream_t stream) {
+  const int lds = conv_bf16_lds_bytes(NC, KC, tile_rows, batch_groups);
+  ME_CHECK(lds <= kLdsBudget, "tile_rows / batch_groups too large for the LDS of one workgroup");
+  const bool exact = (c_src % KC) == 0;
+  static bool attr_set[2] = {false, false};  // per instantiation
+  if (lds > 48 * 1024 && !attr_set[exact]) {
+    const void *fn = exact ? reinterpret_cast<const void *>(&k_conv_tile_bf16<NC, KC, true>)
+                           : reinterpret_cast<const void *>(&k_conv_tile_bf16<NC, KC, false>);
+    ME_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
+    attr_set[exact] = true;
+  }
+  const dim3 grid((unsigned)ceil_div(n_tgt, tile_rows), (unsigned)slabs);
+  if (exact)
+    hipLaunchKernelGGL((k_conv_tile_bf16<NC, KC, true>), grid, dim3(NC * 4), (size_t)lds, stream, src, c_src, wp, c_dst,
+                       plan_src, plan_dst, batch_desc, tile_bptr, order, dst, n_tgt, tile_rows, batch_groups);
+  else
+    hipLaunchKernelGGL((k_conv_tile_bf16<NC, KC, false>), grid, dim3(NC * 4), (size_t)lds, stream, src, c_src, wp, c_dst,
+                       plan_src, plan_dst, batch_desc, tile_bptr, order, dst, n_tgt, tile_rows, batch_groups);
+  ME_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace me
+
+using namespace me;
+
+extern "C" {
+
+int64_t me_conv_packed_weight_elems_bf16(int64_t volume, int32_t c_src, int32_t c_dst) {
+  if (volume <= 0 || c_src <= 0 || c_dst <= 0) return 0;
+  const ConvVariantBf16 v = conv_variant_bf16(c_src, c_dst);
+  return volume * align_up(c_src, v.kc) * align_up(c_dst, 16);
+}
+
+int me_conv_pack_weights_bf16(const void *w, int32_t w_is_f32, int64_t volume, int32_t c_src, int32_t c_dst,
+                              int32_t transposed, uint16_t *wp, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ME_CHECK(volume >= 1 && c_src > 0 && c_dst > 0, "invalid weight shape");
+  ME_CHECK((uintptr_t)wp % 16 == 0, "packed weights must be 16-byte aligned");
+  const ConvVariantBf16 v = conv_variant_bf16(c_src, c_dst);
+  const int nchunks = (int)ceil_div(c_src, v.kc), ncb = (int)ceil_div(c_dst, 16);
+  const int64_t total = volume * nchunks * ncb * (v.kc / 32) * 64;  // 16-byte elements
+  bf16x8 *wp8 = reinterpret_cast<bf16x8 *>(wp);
+  const dim3 grid((unsigned)ceil_div(total, 256)), block(256);
+#define ME_PACK(KCV)                                                                                            \
+  do {                                                                                                          \
+    if (w_is_f32)                                                                                               \
+      hipLaunchKernelGGL((k_pack_weights_bf16<KCV, true>), grid, block, 0, stream, w, c_src, c_dst, transposed, \
+                         nchunks, ncb, wp8, total);                                                             \
+    else                                                                                                        \
+      hipLaunchKernelGGL((k_pack_weights_bf16<KCV, false>), grid, block, 0, stream, w, c_src, c_dst, transposed, \
+                         nchunks, ncb, wp8, total);                                                             \
+  } while (0)
+  if (v.kc == 128) ME_PACK(128);
+  else if (v.kc == 64) ME_PACK(64);
+  else ME_PACK(32);
+#undef ME_PACK
+  ME_LAUNCH_CHECK();
+  return 0;
+}
+
+int me_conv_target_bf16(const uint16_t *src_, int64_t n_src, int32_t c_src, const uint16_t *wp_, int64_t volume,
+                        int32_t c_dst, const int32_t *plan_src, const int32_t *plan_dst,
+                        const int32_t *batch_desc, const int32_t *tile_bptr, const int32_t *order, uint16_t *dst_,
+                        int64_t n_tgt, int32_t tile_rows, int32_t batch_groups, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  (void)n_src;
+  (void)volume;
+  ME_CHECK(c_src > 0 && c_dst > 0, "channel counts must be positive");
+  ME_CHECK(tile_rows >= ME_GROUP_ROWS && tile_rows <= ME_MAX_TILE_ROWS, "tile_rows out of range");
+  ME_CHECK(batch_groups >= 1 && batch_groups <= ME_MAX_BATCH_GROUPS, "batch_groups out of range");
+  ME_CHECK((uintptr_t)src_ % 16 == 0 && (uintptr_t)dst_ % 16 == 0 && (uintptr_t)wp_ % 16 == 0,
+           "feature and weight pointers must be 16-byte aligned");
+  if (n_tgt == 0) return 0;
+  const __bf16 *src = reinterpret_cast<const __bf16 *>(src_);
+  const bf16x8 *wp = reinterpret_cast<const bf16x8 *>(wp_);
+  __bf16 *dst = reinterpret_cast<__bf16 *>(dst_);
+  const ConvVariantBf16 v = conv_variant_bf16(c_src, c_dst);
+#define ME_CONV_CASE(NCV, KCV)                                                                                   \
+  return launch_conv_tile_bf16<NCV, KCV>(src, c_src, wp, c_dst, v.slabs, plan_src, plan_dst, batch_desc, tile_bptr, \
+                                         order, dst, n_tgt, tile_rows, batch_groups, stream)
+  if (v.nc == 32) {
+    if (v.kc == 128) ME_CONV_CASE(32, 128);
+    if (v.kc == 64) ME_CONV_CASE(32, 64);
+    ME_CONV_CASE(32, 32);
+  } else {
+    if (v.kc == 128) ME_CONV_CASE(64, 128);
+    if (v.kc == 64) ME_CONV_CASE(64, 64);
+    ME_CONV_CASE(64, 32);
+  }
+#undef ME_CONV_CASE
+}
+
+}  // extern "C"

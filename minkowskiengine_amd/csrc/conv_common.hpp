@@ -1,0 +1,26 @@
+// Shared by the convolution translation units (conv.hip: fp32, conv_bf16.hip: bf16 features).
+#pragma once
+#include "common.hpp"
+
+namespace me {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kLdsBudget = 160 * 1024;
+constexpr int kAccPad = 4;  // accumulator row stride NC + 4 floats: spreads the row-scattered adds over banks
+
+static inline int device_cu_count() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+        prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
+    else
+      cus = 256;  // MI355X
+  }
+  return cus;
+}
+
+}  // namespace me

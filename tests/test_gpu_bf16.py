@@ -1,0 +1,157 @@
+"""GPU parity of the bf16 feature path (BASELINE configs[2]: MinkUNet34C in bf16).
+
+The reference has no reduced-precision path, so the oracle is the fp32 reference algorithm applied to the
+bf16-ROUNDED operands (features, weights, upstream gradient): products of bf16 values are exact in fp32, so
+the only differences are the fp32 summation order and ONE final rounding to bf16 (relative 2^-9 per
+element).  Tolerances written below: element-wise |err| <= 2^-8 |ref| + 1e-3 max|ref| for bf16 outputs
+(one ulp of slack on top of the half-ulp rounding), 1e-4 relative for the fp32 weight gradient."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import me_oracle as O
+from helpers import make_cloud, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def assert_bf16_close(got, ref, what):
+    got = np.asarray(got, np.float64)
+    ref = np.asarray(ref, np.float64)
+    tol = 2.0 ** -8 * np.abs(ref) + 1e-3 * max(1.0, np.abs(ref).max())
+    bad = np.abs(got - ref) > tol
+    assert not bad.any(), f"{what}: {int(bad.sum())} of {bad.size} elements off, max err {np.abs(got - ref).max():.4g}"
+
+
+def _run_layer(device, coords, cin, cout, ks, stride=1, dil=1, seed=0, kernel_dtype=torch.float32, transpose=False):
+    import minkowskiengine_amd as ME
+    D = coords.shape[1] - 1
+    g = torch.Generator().manual_seed(seed)
+    feats = bf16_round(torch.rand(coords.shape[0], cin, generator=g) - 0.3)
+    conv = ME.MinkowskiConvolution(cin, cout, kernel_size=ks, stride=stride, dilation=dil, dimension=D)
+    with torch.no_grad():
+        conv.kernel.copy_(bf16_round(torch.rand(conv.kernel.shape, generator=g) - 0.5))
+    conv = conv.to(device)
+    if kernel_dtype != torch.float32:
+        conv = conv.to(kernel_dtype)
+    x = ME.SparseTensor(feats.to(device).to(torch.bfloat16), coords.to(device), requires_grad=True)
+    y = conv(x)
+    assert y.F.dtype == torch.bfloat16
+    gy = bf16_round(torch.rand(y.F.shape, generator=g) - 0.5)
+    y.F.backward(gy.to(device).to(torch.bfloat16))
+    return conv, x, y, feats, gy
+
+
+BF16_CASES = [
+    # n, extent, D, cin, cout, ks, stride, dil
+    (3000, 14, 3, 64, 128, 3, 1, 1),      # config-2 channel shape: KC = 64, two 64-column slabs
+    (3000, 40, 3, 64, 128, 3, 1, 1),      # sparse map: nearly empty groups
+    (3000, 14, 3, 32, 32, 3, 1, 1),       # MinkUNet full-resolution layers: KC = 32, NC = 32
+    (2500, 14, 3, 3, 32, 5, 1, 1),        # MinkUNet stem: cin = 3 (scalar gather), K = 125
+    (2500, 14, 3, 32, 96, 3, 1, 1),       # cout = 64 + 32
+    (2500, 14, 3, 96, 32, 3, 1, 1),       # cin = 96 inside one 128-channel chunk
+    (2000, 12, 3, 192, 128, 3, 1, 1),     # cin = 128 + 64: two chunks, the second half empty
+    (1500, 10, 3, 256, 256, 3, 1, 1),     # two full 128-channel chunks, four slabs
+    (2500, 14, 3, 20, 24, 3, 1, 1),       # channels not multiples of 8
+    (2500, 14, 3, 5, 7, 3, 1, 1),         # odd channel counts: scalar loads and stores
+    (2500, 14, 3, 32, 32, 2, 2, 1),       # down conv k=2 s=2
+    (2500, 14, 3, 16, 16, 3, 2, 1),
+    (2000, 8, 4, 32, 64, 3, 1, 1),        # 4-D, K = 81
+    (1, 2, 3, 8, 8, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("n,extent,D,cin,cout,ks,stride,dil", BF16_CASES)
+def test_bf16_conv_forward_backward_vs_oracle(device, n, extent, D, cin, cout, ks, stride, dil):
+    coords = make_cloud(n, extent, D, seed=n + cin, batch=2 if n > 100 else 1, negative=True)
+    conv, x, y, feats, gy = _run_layer(device, coords, cin, cout, ks, stride, dil)
+    in_c = coords.numpy()
+    out_c = y.C.cpu().numpy()
+    _, km = O.kernel_map(in_c, out_c, O.make_region(D, ks, dil, 1))
+    w = conv.kernel.detach().float().cpu().numpy()
+    ref = O.conv_forward(feats.numpy(), w, km, len(out_c))
+    assert_bf16_close(y.F.detach().float().cpu().numpy(), ref, "forward")
+    gi, gw = O.conv_backward(feats.numpy(), gy.numpy(), w, km)
+    assert x.F.grad.dtype == torch.bfloat16 and conv.kernel.grad.dtype == torch.float32
+    assert_bf16_close(x.F.grad.float().cpu().numpy(), gi, "grad_in")
+    assert rel_err(conv.kernel.grad.cpu().numpy(), gw) < 1e-4          # fp32 accumulation of exact products
+
+
+def test_bf16_kernel_parameter(device):
+    """Weights stored in bf16 (net.to(torch.bfloat16)) give the same forward bits as fp32 master weights that
+    hold bf16-representable values; the weight gradient comes back in the parameter's dtype."""
+    coords = make_cloud(3000, 14, 3, seed=3)
+    a = _run_layer(device, coords, 64, 64, 3, seed=5)
+    b = _run_layer(device, coords, 64, 64, 3, seed=5, kernel_dtype=torch.bfloat16)
+    assert torch.equal(a[2].F, b[2].F) and torch.equal(a[1].F.grad, b[1].F.grad)
+    assert b[0].kernel.grad.dtype == torch.bfloat16
+    assert torch.equal(a[0].kernel.grad.to(torch.bfloat16), b[0].kernel.grad)
+
+
+def test_bf16_bitwise_reproducible(device):
+    coords = make_cloud(4000, 14, 3, seed=9)
+    r1 = _run_layer(device, coords, 32, 64, 3)
+    r2 = _run_layer(device, coords, 32, 64, 3)
+    assert torch.equal(r1[2].F, r2[2].F) and torch.equal(r1[1].F.grad, r2[1].F.grad)
+    assert torch.equal(r1[0].kernel.grad, r2[0].kernel.grad)
+
+
+def test_bf16_transposed_conv_and_bias(device):
+    """Down conv then transposed conv back onto the input map, bias and the 1x1 `use_mm` path in bf16."""
+    import minkowskiengine_amd as ME
+    coords = make_cloud(3000, 14, 3, seed=11)
+    g = torch.Generator().manual_seed(0)
+    feats = bf16_round(torch.rand(3000, 32, generator=g))
+    down = ME.MinkowskiConvolution(32, 64, kernel_size=2, stride=2, dimension=3)
+    up = ME.MinkowskiConvolutionTranspose(64, 32, kernel_size=2, stride=2, dimension=3)
+    head = ME.MinkowskiConvolution(32, 20, kernel_size=1, bias=True, dimension=3)
+    with torch.no_grad():
+        for m in (down, up):
+            m.kernel.copy_(bf16_round(torch.rand(m.kernel.shape, generator=g) - 0.5))
+    down, up, head = down.to(device), up.to(device), head.to(device)
+    x = ME.SparseTensor(feats.to(device).to(torch.bfloat16), coords.to(device))
+    d = down(x)
+    u = up(d)
+    h = head(u)
+    assert u.coordinate_map_key == x.coordinate_map_key and h.F.dtype == torch.bfloat16 and h.F.shape == (3000, 20)
+    in_c, mid_c = coords.numpy(), d.C.cpu().numpy()
+    _, km = O.kernel_map(in_c, mid_c, O.make_region(3, 2, 1, 1))
+    ref_d = O.conv_forward(feats.numpy(), down.kernel.detach().cpu().numpy(), km, len(mid_c))
+    assert_bf16_close(d.F.float().cpu().numpy(), ref_d, "down")
+    # transposed conv = the same pair lists with the roles swapped (coordinate_map_manager.cpp:763-774)
+    kmt = {k: v[::-1].copy() for k, v in km.items()}
+    ref_u = O.conv_forward(d.F.float().cpu().numpy(), up.kernel.detach().cpu().numpy(), kmt, len(in_c))
+    assert_bf16_close(u.F.float().cpu().numpy(), ref_u, "up")
+
+
+def test_bf16_config2_full_size(device):
+    """BASELINE config 2 shape at full size in bf16 + linearity in exact arithmetic: features that are small
+    integers keep every product and partial sum exactly representable, so conv(a + b) == conv(a) + conv(b)
+    bit for bit once the outputs are integers below 2^8."""
+    import minkowskiengine_amd as ME
+    coords = make_cloud(100000, 70, 3, seed=0)
+    conv, x, y, feats, gy = _run_layer(device, coords, 64, 128, 3)
+    _, km = O.kernel_map(coords.numpy(), coords.numpy(), O.make_region(3, 3))
+    w = conv.kernel.detach().cpu().numpy()
+    ref = O.conv_forward(feats.numpy(), w, km, 100000, dtype=np.float32)
+    assert_bf16_close(y.F.detach().float().cpu().numpy(), ref, "forward")
+    gi, gw = O.conv_backward(feats.numpy(), gy.numpy(), w, km, dtype=np.float32)
+    assert_bf16_close(x.F.grad.float().cpu().numpy(), gi, "grad_in")
+    assert rel_err(conv.kernel.grad.cpu().numpy(), gw) < 1e-4
+    g = torch.Generator().manual_seed(1)
+    conv1 = ME.MinkowskiConvolution(64, 128, kernel_size=3, dimension=3)
+    with torch.no_grad():   # weights in {-1, 0, 1}, sparse enough that |out| stays far below 256
+        conv1.kernel.copy_((torch.rand(conv1.kernel.shape, generator=g) < 0.01).float()
+                           * torch.sign(torch.rand(conv1.kernel.shape, generator=g) - 0.5))
+    conv1 = conv1.to(device)
+    a = torch.randint(0, 3, (100000, 64), generator=g).to(device).to(torch.bfloat16)
+    b = torch.randint(0, 3, (100000, 64), generator=g).to(device).to(torch.bfloat16)
+    mk = lambda f: ME.SparseTensor(f, coordinate_map_key=x.coordinate_map_key, coordinate_manager=x.coordinate_manager)
+    with torch.no_grad():
+        lhs, ra, rb = conv1(mk(a + b)).F, conv1(mk(a)).F, conv1(mk(b)).F
+    assert float(lhs.float().abs().max()) < 256
+    assert torch.equal(lhs, ra + rb)

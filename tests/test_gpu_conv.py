@@ -165,3 +165,30 @@ def test_config2_full_size(device):
         lhs = conv(mk(2 * a - 3 * b)).F
         rhs = 2 * conv(mk(a)).F - 3 * conv(mk(b)).F
     assert float((lhs - rhs).abs().max()) < 1e-4
+
+
+def test_config5_full_size(device):
+    """BASELINE config 5 at full size: 4-D (3-D + time) k = 3 (K = 81), 8 frames x 50k voxels in
+    [0,100)^3 x [0,8), 32 -> 64 — the high-D coordinate-hash stress.  Kernel map pair sets identical to the
+    oracle's per offset, features within 1e-4, plus mirror symmetry of the pair counts
+    (|map[k]| == |map[K-1-k]| for a stride-1 map onto itself)."""
+    import minkowskiengine_amd as ME
+    g = torch.Generator().manual_seed(5)
+    n = 400000
+    pts = torch.stack([torch.randint(0, e, (int(1.6 * n),), generator=g) for e in (100, 100, 100, 8)], 1)
+    pts = torch.unique(pts, dim=0)
+    pts = pts[torch.randperm(pts.shape[0], generator=g)][:n]
+    coords = torch.cat([torch.zeros(n, 1, dtype=torch.long), pts], 1).int().contiguous()
+    conv, x, y, feats, gy = _run_layer(device, coords, 32, 64, 3)
+    assert np.array_equal(y.C.cpu().numpy(), coords.numpy())
+    _, km = O.kernel_map(coords.numpy(), coords.numpy(), O.make_region(4, 3))
+    d = x.coordinate_manager.kernel_map(x.coordinate_map_key, y.coordinate_map_key, kernel_size=3)
+    O.assert_same_kernel_map({k: v.cpu().numpy().astype(np.int64) for k, v in d.items()}, km)
+    sizes = {k: v.shape[1] for k, v in d.items()}
+    assert all(sizes.get(k, 0) == sizes.get(80 - k, 0) for k in range(81)) and sizes[40] == n
+    w = conv.kernel.detach().cpu().numpy()
+    ref = O.conv_forward(feats.numpy(), w, km, n, dtype=np.float32)
+    assert rel_err(y.F.detach().cpu().numpy(), ref) < TOL
+    gi, gw = O.conv_backward(feats.numpy(), gy.numpy(), w, km, dtype=np.float32)
+    assert rel_err(x.F.grad.cpu().numpy(), gi) < TOL
+    assert rel_err(conv.kernel.grad.cpu().numpy(), gw) < TOL
