@@ -272,6 +272,21 @@ int me_global_pool_f32(const float *src_dev, const float *src2_dev, int32_t c, c
 int me_broadcast_f32(const float *in_dev, const float *glob_dev, const int32_t *batch_row_dev, int64_t n,
                      int32_t c, int32_t multiply, float *out_dev, void *stream);
 
+/* ---- input pipeline on the device --------------------------------------------------
+ * Voxelisation = me_coords_insert_and_map (unique_map / inverse_map) plus these two reductions.
+ * Labels (src/quantization.cpp:140-196, quantize_label): colabels[u] = label of the voxel's first point,
+ * or ignore_label if any point of the voxel carries a different label.  (The reference writes the
+ * ignore label to colabels[inverse_mapping[u]] instead of colabels[u] — src/quantization.cpp:189 — which
+ * marks the wrong voxel whenever duplicates precede row u; the intended semantics are implemented.) */
+int me_coords_quantize_labels(const int64_t *unique_map_dev, int64_t n_unique, const int64_t *inverse_map_dev,
+                              const int32_t *labels_dev, int64_t n, int32_t ignore_label,
+                              int32_t *colabels_dev, void *stream);
+/* Features of duplicate coordinates (SparseTensorQuantizationMode UNWEIGHTED_SUM / UNWEIGHTED_AVERAGE,
+ * MinkowskiSparseTensor.py:317-341; the reference goes through cuSPARSE coo_spmm, src/spmm.cu):
+ * dst[s, :] = sum (or mean) of src[perm[i], :] for i in [seg_offsets[s], seg_offsets[s+1]) in that order. */
+int me_segment_sum_f32(const float *src_dev, int32_t c, const int64_t *perm_dev, const int64_t *seg_offsets_dev,
+                       int64_t n_seg, int32_t average, float *dst_dev, void *stream);
+
 /* Plain VALU + atomics versions on the pair lists (debug cross-check only; never the default).
  * out / grad_in / grad_w must be zero-filled by the caller. */
 int me_conv_forward_naive_f32(const float *in_feat_dev, int32_t c_in, const float *w_dev, int32_t c_out,

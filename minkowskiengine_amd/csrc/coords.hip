@@ -470,6 +470,27 @@ __global__ __launch_bounds__(256) void k_plan_fill(const int32_t *__restrict__ t
   }
 }
 
+// Voxel labels (the reference's quantize_label, src/quantization.cpp:140-196): a voxel keeps the label of
+// its first point unless another point of the voxel disagrees -> ignore_label.  Every writer of a voxel
+// writes the same value and the comparison reads the INPUT labels, so the result does not depend on the
+// schedule.
+__global__ __launch_bounds__(256) void k_quantize_labels_init(const int64_t *__restrict__ unique_map, int64_t n_unique,
+                                                             const int32_t *__restrict__ labels,
+                                                             int32_t *__restrict__ colabels) {
+  const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u < n_unique) colabels[u] = labels[unique_map[u]];
+}
+
+__global__ __launch_bounds__(256) void k_quantize_labels_mark(const int64_t *__restrict__ unique_map,
+                                                             const int64_t *__restrict__ inverse_map,
+                                                             const int32_t *__restrict__ labels, int64_t n,
+                                                             int32_t ignore_label, int32_t *__restrict__ colabels) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n) return;
+  const int64_t u = inverse_map[row];
+  if (labels[row] != labels[unique_map[u]]) colabels[u] = ignore_label;
+}
+
 }  // namespace me
 
 // =================================================================================================
@@ -569,6 +590,19 @@ int me_coords_stride(const int32_t *coords, int64_t n, int32_t ncol, const int32
            "coordinates with 4 columns must be 16-byte aligned");
   const dim3 grid((unsigned)ceil_div(n, 256)), block(256);
   ME_DISPATCH_NCOL(ncol, hipLaunchKernelGGL(k_stride<NCOL>, grid, block, 0, stream, coords, n, arg, out_coords));
+  ME_LAUNCH_CHECK();
+  return 0;
+}
+
+int me_coords_quantize_labels(const int64_t *unique_map, int64_t n_unique, const int64_t *inverse_map,
+                              const int32_t *labels, int64_t n, int32_t ignore_label, int32_t *colabels,
+                              void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_unique == 0 || n == 0) return 0;
+  hipLaunchKernelGGL(k_quantize_labels_init, dim3((unsigned)ceil_div(n_unique, 256)), dim3(256), 0, stream,
+                     unique_map, n_unique, labels, colabels);
+  hipLaunchKernelGGL(k_quantize_labels_mark, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, stream, unique_map,
+                     inverse_map, labels, n, ignore_label, colabels);
   ME_LAUNCH_CHECK();
   return 0;
 }

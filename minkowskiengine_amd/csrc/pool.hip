@@ -259,6 +259,38 @@ __global__ __launch_bounds__(256) void k_broadcast(const float *__restrict__ in,
   store_piece<V>(out + i * c + ch, r);
 }
 
+// Segmented sum / mean of feature rows (voxelisation of duplicate coordinates, the reference's
+// UNWEIGHTED_SUM / UNWEIGHTED_AVERAGE quantisation modes: MinkowskiSparseTensor.py:317-341 via
+// MinkowskiSPMMFunction -> cuSPARSE coo_spmm).  Segment s owns the rows perm[seg[s] .. seg[s+1]) — the
+// input rows of one voxel in input order — so the summation order is fixed (no atomics, bitwise
+// reproducible).  A thread owns one 16-byte channel piece of one segment.
+template <int V>
+__global__ __launch_bounds__(256) void k_segment_sum(const float *__restrict__ src, int c,
+                                                    const int64_t *__restrict__ perm,
+                                                    const int64_t *__restrict__ seg, int64_t n_seg, int average,
+                                                    float *__restrict__ dst) {
+  const int pieces = c / V;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_seg * pieces) return;
+  const int64_t s = idx / pieces;
+  const int ch = (int)(idx % pieces) * V;
+  const int64_t b = seg[s], e = seg[s + 1];
+  Piece<V> acc;
+#pragma unroll
+  for (int j = 0; j < V; ++j) acc.v[j] = 0.f;
+  for (int64_t i = b; i < e; ++i) {
+    const Piece<V> x = load_piece<V>(src + perm[i] * c + ch);
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc.v[j] += x.v[j];
+  }
+  if (average && e > b) {
+    const float inv = (float)(e - b);
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc.v[j] /= inv;
+  }
+  store_piece<V>(dst + s * c + ch, acc);
+}
+
 }  // namespace me
 
 using namespace me;
@@ -375,6 +407,20 @@ int me_broadcast_f32(const float *in, const float *glob, const int32_t *batch_ro
   const dim3 grid((unsigned)ceil_div(total, 256)), block(256);
   if (vec) hipLaunchKernelGGL(k_broadcast<4>, grid, block, 0, stream, in, glob, batch_row, n, c, multiply, out);
   else hipLaunchKernelGGL(k_broadcast<1>, grid, block, 0, stream, in, glob, batch_row, n, c, multiply, out);
+  ME_LAUNCH_CHECK();
+  return 0;
+}
+
+int me_segment_sum_f32(const float *src, int32_t c, const int64_t *perm, const int64_t *seg_offsets, int64_t n_seg,
+                       int32_t average, float *dst, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ME_CHECK(c > 0, "invalid channel count");
+  if (n_seg == 0) return 0;
+  const bool vec = (c % 4) == 0 && (uintptr_t)src % 16 == 0 && (uintptr_t)dst % 16 == 0;
+  const int64_t total = n_seg * (vec ? c / 4 : c);
+  const dim3 grid((unsigned)ceil_div(total, 256)), block(256);
+  if (vec) hipLaunchKernelGGL(k_segment_sum<4>, grid, block, 0, stream, src, c, perm, seg_offsets, n_seg, average, dst);
+  else hipLaunchKernelGGL(k_segment_sum<1>, grid, block, 0, stream, src, c, perm, seg_offsets, n_seg, average, dst);
   ME_LAUNCH_CHECK();
   return 0;
 }

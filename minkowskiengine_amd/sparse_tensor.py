@@ -125,13 +125,11 @@ class SparseTensor:
         coordinates = coordinates[self.unique_index]
         mode = self.quantization_mode
         if mode in (SparseTensorQuantizationMode.UNWEIGHTED_SUM, SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE):
-            summed = torch.zeros((n_unique, features.shape[1]), dtype=features.dtype, device=features.device)
-            summed.index_add_(0, inverse_mapping, features)
-            if mode == SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE:
-                counts = torch.zeros(n_unique, dtype=features.dtype, device=features.device)
-                counts.index_add_(0, inverse_mapping, torch.ones_like(inverse_mapping, dtype=features.dtype))
-                summed = summed / counts.unsqueeze(1)
-            features = summed
+            # duplicate coordinates: rows of a voxel are summed in input order by one HIP kernel (deterministic;
+            # the reference goes through cuSPARSE coo_spmm, MinkowskiSparseTensor.py:317-341)
+            from .utils.quantization import segment_reduce
+            features = segment_reduce(features, inverse_mapping, n_unique,
+                                      average=(mode == SparseTensorQuantizationMode.UNWEIGHTED_AVERAGE))
         elif mode == SparseTensorQuantizationMode.RANDOM_SUBSAMPLE:
             features = features[self.unique_index]
         return coordinates, features, coordinate_map_key

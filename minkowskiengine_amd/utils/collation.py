@@ -38,3 +38,36 @@ def sparse_collate(coords, feats, labels=None, dtype=torch.int32, device=None):
     if device is not None:
         blabels = blabels.to(device)
     return bcoords, bfeats, blabels
+
+
+def batch_sparse_collate(data, dtype=torch.int32, device=None):
+    """collate_fn for torch.utils.data.DataLoader: list of (coords, feats[, labels]) tuples
+    (collation.py:191-206)."""
+    return sparse_collate(*list(zip(*data)), dtype=dtype, device=device)
+
+
+class SparseCollation:
+    """Callable collate_fn that caps the batch at `limit_numpoints` points and optionally returns the lists
+    un-concatenated (collation.py:209-288)."""
+
+    def __init__(self, limit_numpoints=-1, dtype=torch.int32, device=None):
+        self.limit_numpoints = limit_numpoints
+        self.dtype = dtype
+        self.device = device
+
+    def __call__(self, list_data):
+        coords, feats, labels = list(zip(*list_data))
+        keep_c, keep_f, keep_l = [], [], []
+        total = 0
+        for batch_id, _ in enumerate(coords):
+            n = coords[batch_id].shape[0]
+            total += n
+            if 0 < self.limit_numpoints < total:
+                import logging
+                logging.warning("Cannot fit %d points into %d points limit. Truncating batch size at %d out of %d.",
+                                sum(len(c) for c in coords), self.limit_numpoints, batch_id, len(coords))
+                break
+            keep_c.append(coords[batch_id])
+            keep_f.append(feats[batch_id])
+            keep_l.append(labels[batch_id])
+        return sparse_collate(keep_c, keep_f, keep_l, dtype=self.dtype, device=self.device)

@@ -305,3 +305,39 @@ def relabel_kernel_map(kmap, in_coords_a, in_coords_b, out_coords_a, out_coords_
         a = np.asarray(io if not hasattr(io, "cpu") else io.cpu().numpy()).astype(np.int64)
         out[k] = np.stack((mi[a[0]], mo[a[1]]))
     return out
+
+
+# ---- voxelisation (input pipeline) ------------------------------------------------------------------
+def quantize_label(coords, labels, ignore_label):
+    """-> (unique_map, inverse_map, colabels): first-occurrence dedup; a voxel keeps its first point's label
+    unless a later point of the voxel disagrees -> ignore_label (src/quantization.cpp:140-196, with the
+    ignore label written to colabels[u]; the reference's line 189 indexes colabels[inverse_mapping[u]])."""
+    coords = _i32(coords)
+    labels = np.asarray(labels, np.int32)
+    unique_map, inverse_map = [], np.empty(len(coords), np.int64)
+    colabels, seen = [], {}
+    for row in range(len(coords)):
+        key = coords[row].tobytes()
+        u = seen.get(key)
+        if u is None:
+            seen[key] = len(unique_map)
+            inverse_map[row] = len(unique_map)
+            unique_map.append(row)
+            colabels.append(int(labels[row]))
+        else:
+            if colabels[u] != labels[row] and colabels[u] != ignore_label:
+                colabels[u] = ignore_label
+            inverse_map[row] = u
+    return np.asarray(unique_map, np.int64), inverse_map, np.asarray(colabels, np.int32)
+
+
+def segment_mean(features, inverse_map, n_unique, average=True):
+    """Voxel features of duplicate coordinates: sum / mean of the rows of each voxel in input order
+    (MinkowskiSparseTensor.py:317-341: spmm with a [n_unique, N] COO matrix of ones, then / row count)."""
+    f = np.asarray(features, np.float64)
+    out = np.zeros((n_unique, f.shape[1]), np.float64)
+    cnt = np.zeros(n_unique, np.float64)
+    for row, u in enumerate(np.asarray(inverse_map)):
+        out[u] += f[row]
+        cnt[u] += 1
+    return out / cnt[:, None] if average else out

@@ -103,7 +103,7 @@ def test_bf16_bitwise_reproducible(device):
 def test_bf16_transposed_conv_and_bias(device):
     """Down conv then transposed conv back onto the input map, bias and the 1x1 `use_mm` path in bf16."""
     import minkowskiengine_amd as ME
-    coords = make_cloud(3000, 14, 3, seed=11)
+    coords = make_cloud(3000, 20, 3, seed=11)
     g = torch.Generator().manual_seed(0)
     feats = bf16_round(torch.rand(3000, 32, generator=g))
     down = ME.MinkowskiConvolution(32, 64, kernel_size=2, stride=2, dimension=3)
