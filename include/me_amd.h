@@ -217,7 +217,9 @@ void me_debug_set_wgrad_config(int depth, int wgs_per_cu);
  *   me_conv_pack_weights_bf16: w_is_f32 != 0: w_dev holds fp32 master weights, else bf16; layouts and
  *                              `transposed` as for me_conv_pack_weights_f32.
  *   me_conv_target_bf16:       forward / dgrad on v_mfma_f32_16x16x32_bf16 (arguments as me_conv_target_f32).
- *   me_conv_wgrad_bf16:        grad_w (fp32 out) from bf16 x / dy; workspace as for me_conv_wgrad_f32. */
+ *   me_conv_wgrad_bf16:        grad_w (fp32 out) from bf16 x / dy on v_mfma_f32_16x16x32_bf16 (rows staged in
+ *                              LDS once per workgroup, operands read back transposed with
+ *                              ds_read_b64_tr_b16); workspace bytes from me_conv_wgrad_workspace_bytes_bf16. */
 int64_t me_conv_packed_weight_elems_bf16(int64_t volume, int32_t c_src, int32_t c_dst); /* bf16 elements */
 int me_conv_pack_weights_bf16(const void *w_dev, int32_t w_is_f32, int64_t volume, int32_t c_src, int32_t c_dst,
                               int32_t transposed, uint16_t *packed_dev, void *stream);
@@ -227,6 +229,7 @@ int me_conv_target_bf16(const uint16_t *src_feat_dev, int64_t n_src, int32_t c_s
                         const int32_t *batch_desc_dev, const int32_t *tile_bptr_dev,
                         const int32_t *order_dev, uint16_t *dst_feat_dev,
                         int64_t n_tgt, int32_t tile_rows, int32_t batch_groups, void *stream);
+int64_t me_conv_wgrad_workspace_bytes_bf16(const int64_t *k_offsets, int64_t volume, int32_t c_in, int32_t c_out);
 int me_conv_wgrad_bf16(const uint16_t *x_dev, int32_t c_in, const uint16_t *dy_dev, int32_t c_out,
                        const int32_t *in_pairs_dev, const int32_t *out_pairs_dev,
                        const int64_t *k_offsets /* host */, const int64_t *k_offsets_dev,

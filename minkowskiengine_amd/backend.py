@@ -693,7 +693,8 @@ def _conv_backward(in_feat, grad_out, kernel, km, algo=None):
     # wgrad: always accumulated and reduced in fp32; handed back in the kernel's dtype
     grad_w = torch.empty(kernel.shape, dtype=torch.float32, device=dev)
     koffs = (ctypes.c_int64 * (volume + 1))(*km.k_offsets)
-    wsb = int(lib.me_conv_wgrad_workspace_bytes(koffs, volume, c_in, c_out))
+    wsb = int((lib.me_conv_wgrad_workspace_bytes_bf16 if bf16 else lib.me_conv_wgrad_workspace_bytes)(
+        koffs, volume, c_in, c_out))
     ws = _workspace(wsb, dev)
     fn = lib.me_conv_wgrad_bf16 if bf16 else lib.me_conv_wgrad_f32
     with torch.cuda.device(dev):

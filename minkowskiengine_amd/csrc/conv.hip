@@ -547,12 +547,240 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 3)) void k_wgrad_f32(const T *_
   }
 }
 
+// =================================================================================================
+// wgrad on bf16 rows: grad_w[k] = X_g^T . dY_g on v_mfma_f32_16x16x32_bf16 (reduction dimension = pairs)
+// =================================================================================================
+// Both MFMA operands need, per lane, 8 CONSECUTIVE PAIRS of ONE channel — the transpose of how rows lie
+// in memory — so the rows go through LDS: a workgroup (4 waves) stages a step of SP = 32*KSTEPS pairs,
+// x rows as [SP][64 channels] and dy rows as [SP][64*NB channels] (every gathered byte is loaded ONCE per
+// workgroup with 16-byte loads and shared by the four waves), and reads the operands back with
+// ds_read_b64_tr_b16: the 16 lanes of a group point at 4 rows x 4 chunks of 4 channels and each lane
+// receives ONE channel of the 4 rows (probed: scripts/ubench/tr_probe.hip).  Row stride = channels + 16
+// elements: the 8 rows a 32-lane pass touches fall into 8 disjoint 32-byte bank windows.
+// Wave w owns the 64 x (16*NB) block of grad_w[k] at output channels (4*blockIdx.z + w)*16*NB; the four
+// waves share the x tile.  Work split, slots and the ordered reduction are those of k_wgrad_f32 (conv.hip):
+// equal pair ranges regardless of offset boundaries, register-image partials at slot (range + k).
+// Pipeline (one barrier per step, two LDS buffers): rows of step s+1 are in flight (global -> registers)
+// and the pair indices of step s+2 are being fetched while step s is multiplied.
+constexpr int kWgStepLd = 16;  // padding elements per staged row
+
+template <int NB, int KSTEPS>
+__global__ __launch_bounds__(256, 2) void k_wgrad_bf16(const __bf16 *__restrict__ x, int c_in,
+                                                      const __bf16 *__restrict__ dy, int c_out,
+                                                      const int32_t *__restrict__ in_pairs,
+                                                      const int32_t *__restrict__ out_pairs,
+                                                      const int64_t *__restrict__ koffs, int volume,
+                                                      int64_t n_pairs, int n_ranges, int n_cob,
+                                                      float *__restrict__ partial) {
+  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+  constexpr int MB = 4;
+  constexpr int SP = 32 * KSTEPS;        // pairs per step (<= 64: one index register per wave)
+  constexpr int COB = 64 * NB;           // output channels per workgroup
+  constexpr int XLD = 64 + kWgStepLd;    // elements
+  constexpr int DLD = COB + kWgStepLd;
+  constexpr int XP = SP * 8 / 256;       // 16-byte x pieces per thread and step
+  constexpr int DP = SP * (COB / 8) / 256;
+  static_assert(SP <= 64 && XP >= 1, "step size");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __bf16 *s_x = reinterpret_cast<__bf16 *>(smem);            // [2][SP][XLD]
+  __bf16 *s_d = s_x + 2 * SP * XLD;                           // [2][SP][DLD]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, q = lane >> 4;
+  const int range = blockIdx.x;
+  const int ci0 = blockIdx.y * 64;
+  const int cog = blockIdx.z * COB;                           // first output channel of the workgroup
+  const int cob = blockIdx.z * 4 + wave;                      // this wave's block of 16*NB output channels
+  const int64_t e_lo = n_pairs * range / n_ranges;
+  const int64_t e_hi = n_pairs * (range + 1) / n_ranges;
+  if (e_lo >= e_hi) return;                                   // whole workgroup
+
+  constexpr int kImage = MB * NB * 4 * 64;
+  const int64_t image_stride = (int64_t)gridDim.y * n_cob * kImage;
+  float *const image0 = partial + ((int64_t)blockIdx.y * n_cob + min(cob, n_cob - 1)) * kImage + lane;
+
+  // step cursor: offset k, first pair e, number of pairs cnt (0 = past the end of the range)
+  auto first_offset = [&](int64_t e) {
+    int lo = 0, hi = volume;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (koffs[mid] <= e) lo = mid; else hi = mid;
+    }
+    return lo;
+  };
+  auto step_count = [&](int k, int64_t e) -> int {
+    if (e >= e_hi) return 0;
+    const int64_t kend = min(koffs[k + 1], e_hi);
+    return (int)min((int64_t)SP, kend - e);
+  };
+  auto advance = [&](int &k, int64_t &e, int cnt) {
+    e += cnt;
+    if (e < e_hi) {
+      while (koffs[k + 1] <= e) ++k;
+    }
+  };
+
+  // this thread's pieces: x piece j is row (j*256 + tid) >> 3, channels ci0 + ((j*256 + tid) & 7) * 8
+  int32_t pin = 0, pout = 0;            // pair indices of the step whose rows are loaded next (lane l: pair e + l)
+  bf16x8 rx[XP], rd[DP];
+  auto load_idx = [&](int64_t e) {
+    const int64_t ec = min(e + lane, n_pairs - 1);            // unconditional load from a valid address
+    const int32_t *pi = in_pairs + ec, *po = out_pairs + ec;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(pin) : "v"(pi) : "memory");
+    asm volatile("global_load_dword %0, %1, off" : "=v"(pout) : "v"(po) : "memory");
+  };
+  // The row loads are inline asm: hipcc sinks ordinary loads whose first use is in the next iteration below
+  // the MFMAs (into the last block before the back edge), which serialises gather and multiply.  asm volatile
+  // keeps them where they are written; the matching s_waitcnt is issued by hand (wait_rows) right before the
+  // registers are stored to LDS one iteration later.
+  auto load_rows = [&]() {
+#pragma unroll
+    for (int j = 0; j < XP; ++j) {
+      const int idx = j * 256 + tid;
+      const int row = idx >> 3;
+      const int ch = ci0 + (idx & 7) * 8;
+      const int32_t r = __shfl(pin, row, 64);
+      const __bf16 *p = x + (int64_t)r * c_in + (ch < c_in ? ch : 0);
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rx[j]) : "v"(p) : "memory");
+    }
+#pragma unroll
+    for (int j = 0; j < DP; ++j) {
+      const int idx = j * 256 + tid;
+      const int row = idx / (COB / 8);
+      const int ch = cog + (idx % (COB / 8)) * 8;
+      const int32_t r = __shfl(pout, row, 64);
+      const __bf16 *p = dy + (int64_t)r * c_out + (ch < c_out ? ch : 0);
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rd[j]) : "v"(p) : "memory");
+    }
+  };
+  auto wait_rows = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pin), "+v"(pout));
+#pragma unroll
+    for (int j = 0; j < XP; ++j) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rx[j]));
+#pragma unroll
+    for (int j = 0; j < DP; ++j) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rd[j]));
+  };
+  auto write_lds = [&](int buf, int cnt) {
+    const bf16x8 zero = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+#pragma unroll
+    for (int j = 0; j < XP; ++j) {
+      const int idx = j * 256 + tid;
+      const int row = idx >> 3;
+      const int ch = ci0 + (idx & 7) * 8;
+      const bool ok = row < cnt && ch < c_in;                // pairs beyond the step / channels beyond c_in: zeros
+      *reinterpret_cast<bf16x8 *>(s_x + (buf * SP + row) * XLD + (idx & 7) * 8) = ok ? rx[j] : zero;
+    }
+#pragma unroll
+    for (int j = 0; j < DP; ++j) {
+      const int idx = j * 256 + tid;
+      const int row = idx / (COB / 8);
+      const int pc = idx % (COB / 8);
+      const bool ok = row < cnt && cog + pc * 8 < c_out;
+      *reinterpret_cast<bf16x8 *>(s_d + (buf * SP + row) * DLD + pc * 8) = ok ? rd[j] : zero;
+    }
+  };
+
+  f32x4 acc[MB][NB];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int n = 0; n < NB; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto flush = [&](int k) {
+    if (cob < n_cob) {
+      float *img = image0 + (int64_t)(range + k) * image_stride;
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) img[((m * NB + n) * 4 + r) * 64] = acc[m][n][r];
+    }
+  };
+  // operand fragments: lane (i16, q) of a 16-lane group addresses row 4*q + (i16 >> 2) of each 16-row half and
+  // the 4-channel chunk (i16 & 3); it receives channel i16 of rows 4*q .. 4*q + 3
+  const int frag_row = 4 * q + (i16 >> 2);
+  const int frag_col = 4 * (i16 & 3);
+  auto multiply = [&](int buf) {
+    const __bf16 *bx = s_x + (buf * SP + frag_row) * XLD + frag_col;
+    const __bf16 *bd = s_d + (buf * SP + frag_row) * DLD + wave * 16 * NB + frag_col;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      bf16x8 a[MB], b[NB];
+#pragma unroll
+      for (int m = 0; m < MB; ++m) {
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(bx + (ks * 32) * XLD + 16 * m));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(bx + (ks * 32 + 16) * XLD + 16 * m));
+        a[m] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int n = 0; n < NB; ++n) {
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(bd + (ks * 32) * DLD + 16 * n));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(bd + (ks * 32 + 16) * DLD + 16 * n));
+        b[n] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int n = 0; n < NB; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], b[n], acc[m][n], 0, 0, 0);
+    }
+  };
+
+  // cursors: A = step being multiplied, B = step whose rows are in flight, C = step whose indices are in flight
+  int kA = first_offset(e_lo);
+  int64_t eA = e_lo;
+  int cA = step_count(kA, eA);
+  int kB = kA;
+  int64_t eB = eA;
+  advance(kB, eB, cA);
+  int cB = step_count(kB, eB);
+  int kC = kB;
+  int64_t eC = eB;
+  advance(kC, eC, cB);
+  int cC = step_count(kC, eC);
+
+  load_idx(eA);
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(pin), "+v"(pout));
+  load_rows();          // rows of step A
+  load_idx(eB);         // indices of step B
+  zero_acc();
+  int buf = 0;
+  int pending = -1;     // offset whose accumulators must be flushed before the next step is multiplied
+  while (cA > 0) {
+    // (the flush sits at the top of the loop so that the block that issues the row loads ends with the
+    // MFMAs: hipcc otherwise sinks the loads below the multiply into the block after the flush branch)
+    if (pending >= 0) {
+      flush(pending);
+      zero_acc();
+    }
+    wait_rows();
+    write_lds(buf, cA);   // rows of step A (requested one step ago)
+    load_rows();          // rows of step B (its indices arrived with A's rows)
+    load_idx(eC);         // indices of step C
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();      // step A visible; everybody is done reading the other buffer
+    multiply(buf);
+    pending = (cB == 0 || kB != kA) ? kA : -1;  // last step of offset kA inside this range
+    buf ^= 1;
+    kA = kB; eA = eB; cA = cB;
+    kB = kC; eB = eC; cB = cC;
+    advance(kC, eC, cC);
+    cC = step_count(kC, eC);
+  }
+  if (pending >= 0) flush(pending);
+}
+
 // grad_w[k] = sum of the register images of the ranges that touch offset k, written back through the
 // channel interleave of k_wgrad_f32.  A block sums 64 consecutive image elements; its four waves take
 // the slots s = first + phase, + 4, ... (four independent loads in flight per thread: the loop is
 // latency-bound otherwise) and the four partial sums are combined in phase order, so the summation
 // order is fixed (bitwise reproducible).
-template <int NB>
+// TR: the images come from k_wgrad_bf16 (MFMA row i of block m <-> input channel 16*m + i, column j of block
+// n <-> output channel 16*n + j) instead of k_wgrad_f32's interleave.
+template <int NB, bool TR>
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ partial,
                                                      const int64_t *__restrict__ koffs, int volume,
                                                      int64_t n_pairs, int n_ranges, int n_cib, int n_cob,
@@ -597,8 +825,8 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ 
   const int cib = (int)(idx / ((int64_t)kImage * n_cob));
   const int r = reg % 4, n = (reg / 4) % NB, m = reg / (4 * NB);
   const int i16 = lane & 15, q = lane >> 4;
-  const int ci = cib * (16 * MB) + MB * (4 * q + r) + m;
-  const int co = cob * (16 * NB) + NB * i16 + n;
+  const int ci = cib * (16 * MB) + (TR ? 16 * m + 4 * q + r : MB * (4 * q + r) + m);
+  const int co = cob * (16 * NB) + (TR ? 16 * n + i16 : NB * i16 + n);
   if (ci < c_in && co < c_out) grad_w[((int64_t)k * c_in + ci) * c_out + co] = s;
 }
 
@@ -788,7 +1016,7 @@ static int wgrad_launch(const T *x, int32_t c_in, const T *dy, int32_t c_out, co
   }
   const dim3 rgrid((unsigned)ceil_div(g.slot_floats, 64), (unsigned)volume);
 #define ME_WGRAD_REDUCE(NBV)                                                                               \
-  hipLaunchKernelGGL((k_wgrad_reduce<NBV>), rgrid, dim3(256), 0, stream, partial, k_offsets_dev, (int)volume, \
+  hipLaunchKernelGGL((k_wgrad_reduce<NBV, false>), rgrid, dim3(256), 0, stream, partial, k_offsets_dev, (int)volume, \
                      n_pairs > 0 ? n_pairs : 1, (int)g.ranges, g.n_cib, g.n_cob, c_in, c_out, grad_w)
   if (g.nb == 1) ME_WGRAD_REDUCE(1);
   else if (g.nb == 2) ME_WGRAD_REDUCE(2);
@@ -941,13 +1169,95 @@ int me_conv_wgrad_f32(const float *x, int32_t c_in, const float *dy, int32_t c_o
                              workspace, workspace_bytes, (hipStream_t)stream_);
 }
 
-int me_conv_wgrad_bf16(const uint16_t *x, int32_t c_in, const uint16_t *dy, int32_t c_out, const int32_t *in_pairs,
+}  // extern "C"
+
+// geometry of k_wgrad_bf16: always four waves side by side along the output channels
+static WgradGeom wgrad_geom_bf16(int64_t n_pairs, int c_in, int c_out) {
+  WgradGeom g;
+  // 64 or 128 output channels per workgroup; wider layers take several workgroup columns (grid.z) that
+  // re-gather the x rows (the <4, 1> instantiation — 256 channels, 32-pair steps — faulted on the GPU and is
+  // not used; its cause was not found in round 1)
+  g.nb = c_out <= 64 ? 1 : 2;
+  g.n_cib = (int)ceil_div(c_in, 16 * kWgMB);
+  g.n_cob = (int)ceil_div(c_out, 16 * g.nb);
+  g.waves = 4;
+  g.gz = (int)ceil_div(g.n_cob, 4);
+  const int wpc = g_wgrad_wgs_per_cu > 0 ? g_wgrad_wgs_per_cu : 2;
+  int64_t r = ceil_div((int64_t)device_cu_count() * wpc, (int64_t)g.n_cib * g.gz);
+  if (r > n_pairs / 64) r = n_pairs / 64;
+  if (r < 1) r = 1;
+  g.ranges = r;
+  g.slot_floats = (int64_t)g.n_cib * g.n_cob * (kWgMB * g.nb * 4 * 64);
+  return g;
+}
+
+template <int NB, int KSTEPS>
+static int launch_wgrad_bf16(const WgradGeom &g, const __bf16 *x, int c_in, const __bf16 *dy, int c_out,
+                             const int32_t *in_pairs, const int32_t *out_pairs, const int64_t *k_offsets_dev,
+                             int volume, int64_t n_pairs, float *partial, hipStream_t stream) {
+  constexpr int SP = 32 * KSTEPS;
+  const int lds = 2 * SP * ((64 + kWgStepLd) + (64 * NB + kWgStepLd)) * 2;
+  static bool attr_set = false;
+  if (lds > 32 * 1024 && !attr_set) {
+    ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wgrad_bf16<NB, KSTEPS>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
+    attr_set = true;
+  }
+  const dim3 grid((unsigned)g.ranges, (unsigned)g.n_cib, (unsigned)g.gz);
+  hipLaunchKernelGGL((k_wgrad_bf16<NB, KSTEPS>), grid, dim3(256), (size_t)lds, stream, x, c_in, dy, c_out, in_pairs,
+                     out_pairs, k_offsets_dev, volume, n_pairs, (int)g.ranges, g.n_cob, partial);
+  ME_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" {
+
+int64_t me_conv_wgrad_workspace_bytes_bf16(const int64_t *k_offsets, int64_t volume, int32_t c_in, int32_t c_out) {
+  if (volume < 1 || c_in <= 0 || c_out <= 0) return 256;
+  // the larger of the two kernels' needs (channel counts that are not multiples of 8 take k_wgrad_f32<__bf16>)
+  const WgradGeom g = wgrad_geom_bf16(k_offsets[volume], c_in, c_out);
+  const int64_t a = align_up((g.ranges + volume) * g.slot_floats * 4, 256);
+  const int64_t b = me_conv_wgrad_workspace_bytes(k_offsets, volume, c_in, c_out);
+  return a > b ? a : b;
+}
+
+int me_conv_wgrad_bf16(const uint16_t *x_, int32_t c_in, const uint16_t *dy_, int32_t c_out, const int32_t *in_pairs,
                        const int32_t *out_pairs, const int64_t *k_offsets, const int64_t *k_offsets_dev,
                        int64_t volume, float *grad_w, void *workspace, int64_t workspace_bytes,
                        void *stream_) {
-  return wgrad_launch<__bf16>(reinterpret_cast<const __bf16 *>(x), c_in, reinterpret_cast<const __bf16 *>(dy),
-                              c_out, in_pairs, out_pairs, k_offsets, k_offsets_dev, volume, grad_w, workspace,
-                              workspace_bytes, (hipStream_t)stream_);
+  hipStream_t stream = (hipStream_t)stream_;
+  const __bf16 *x = reinterpret_cast<const __bf16 *>(x_);
+  const __bf16 *dy = reinterpret_cast<const __bf16 *>(dy_);
+  ME_CHECK(workspace_bytes >= me_conv_wgrad_workspace_bytes_bf16(k_offsets, volume, c_in, c_out),
+           "workspace too small");
+  // rows that are not whole 16-byte pieces: the fp32-MFMA kernel with bf16 loads
+  if ((c_in % 8) != 0 || (c_out % 8) != 0 || g_wgrad_depth < 0)
+    return wgrad_launch<__bf16>(x, c_in, dy, c_out, in_pairs, out_pairs, k_offsets, k_offsets_dev, volume, grad_w,
+                                workspace, workspace_bytes, stream);
+  ME_CHECK(volume >= 1 && volume <= 65535, "kernel volume out of range");
+  ME_CHECK((uintptr_t)x % 16 == 0 && (uintptr_t)dy % 16 == 0, "feature pointers must be 16-byte aligned");
+  const int64_t n_pairs = k_offsets[volume];
+  const WgradGeom g = wgrad_geom_bf16(n_pairs, c_in, c_out);
+  float *partial = reinterpret_cast<float *>(workspace);
+  if (n_pairs > 0) {
+    int rc;
+#define ME_WG16(NBV, KSV)                                                                                      \
+  launch_wgrad_bf16<NBV, KSV>(g, x, c_in, dy, c_out, in_pairs, out_pairs, k_offsets_dev, (int)volume, n_pairs, \
+                              partial, stream)
+    if (g.nb == 1) rc = ME_WG16(1, 2);
+    else rc = ME_WG16(2, 2);
+#undef ME_WG16
+    if (rc != 0) return rc;
+  }
+  const dim3 rgrid((unsigned)ceil_div(g.slot_floats, 64), (unsigned)volume);
+#define ME_WGRAD_REDUCE_TR(NBV)                                                                               \
+  hipLaunchKernelGGL((k_wgrad_reduce<NBV, true>), rgrid, dim3(256), 0, stream, partial, k_offsets_dev, (int)volume, \
+                     n_pairs > 0 ? n_pairs : 1, (int)g.ranges, g.n_cib, g.n_cob, c_in, c_out, grad_w)
+  if (g.nb == 1) ME_WGRAD_REDUCE_TR(1);
+  else ME_WGRAD_REDUCE_TR(2);
+#undef ME_WGRAD_REDUCE_TR
+  ME_LAUNCH_CHECK();
+  return 0;
 }
 
 int me_conv_forward_naive_f32(const float *in_feat, int32_t c_in, const float *w, int32_t c_out,

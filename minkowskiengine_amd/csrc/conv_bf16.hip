@@ -1,5 +1,6 @@
 // Sparse convolution on bf16 features for gfx950 (MI355X): forward / dgrad on v_mfma_f32_16x16x32_bf16
-// with fp32 accumulation, weight gradient on the fp32 matrix pipe fed with bf16 rows (conv.hip).
+// with fp32 accumulation (the weight gradient on bf16 rows is k_wgrad_bf16 in conv.hip, next to the
+// reduction it shares with the fp32 kernel).
 //
 // The reference has no reduced-precision path (AT_DISPATCH_FLOATING_TYPES: float / double only,
 // src/convolution_gpu.cu:137-155); BASELINE config 3 (MinkUNet34C, bf16) and the north_star's
@@ -17,9 +18,6 @@
 #include "conv_common.hpp"
 
 namespace me {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 // stage row stride in elements: KC + 8 (16 bytes of padding: 16 rows x one 16-byte piece hit 64 distinct banks)
 __host__ __device__ constexpr int conv_bf16_lds_bytes(int nc, int kc, int tile_rows, int batch_groups) {

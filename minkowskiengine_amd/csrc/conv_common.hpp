@@ -5,6 +5,8 @@
 namespace me {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kLdsBudget = 160 * 1024;
 constexpr int kAccPad = 4;  // accumulator row stride NC + 4 floats: spreads the row-scattered adds over banks

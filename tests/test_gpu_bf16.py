@@ -121,11 +121,11 @@ def test_bf16_transposed_conv_and_bias(device):
     in_c, mid_c = coords.numpy(), d.C.cpu().numpy()
     _, km = O.kernel_map(in_c, mid_c, O.make_region(3, 2, 1, 1))
     ref_d = O.conv_forward(feats.numpy(), down.kernel.detach().cpu().numpy(), km, len(mid_c))
-    assert_bf16_close(d.F.float().cpu().numpy(), ref_d, "down")
+    assert_bf16_close(d.F.detach().float().cpu().numpy(), ref_d, "down")
     # transposed conv = the same pair lists with the roles swapped (coordinate_map_manager.cpp:763-774)
     kmt = {k: v[::-1].copy() for k, v in km.items()}
-    ref_u = O.conv_forward(d.F.float().cpu().numpy(), up.kernel.detach().cpu().numpy(), kmt, len(in_c))
-    assert_bf16_close(u.F.float().cpu().numpy(), ref_u, "up")
+    ref_u = O.conv_forward(d.F.detach().float().cpu().numpy(), up.kernel.detach().cpu().numpy(), kmt, len(in_c))
+    assert_bf16_close(u.F.detach().float().cpu().numpy(), ref_u, "up")
 
 
 def test_bf16_config2_full_size(device):
