@@ -204,8 +204,9 @@ int me_conv_wgrad_f32(const float *x_dev, int32_t c_in, const float *dy_dev, int
                       const int64_t *k_offsets /* host */, const int64_t *k_offsets_dev,
                       int64_t volume, float *grad_w_dev, void *workspace_dev,
                       int64_t workspace_bytes, void *stream);
-/* Tuning switch for me_conv_wgrad_f32: prefetch ring depth (4 or 8 steps of 4 pairs) and resident
- * workgroups per CU the ranges are sized for; 0 = shipped defaults. */
+/* Tuning switch for the weight-gradient kernels: depth 4 / 8 = prefetch ring depth of k_wgrad_f32 (steps of 4
+ * pairs); depth -1 = bf16 rows through the fp32-MFMA kernel instead of k_wgrad_bf16; depth -2 = fp32 rows through
+ * the LDS-staged kernel; wgs_per_cu = resident workgroups per CU the ranges are sized for; 0 = shipped defaults. */
 void me_debug_set_wgrad_config(int depth, int wgs_per_cu);
 
 /* ---- bf16 features (fp32 accumulation) --------------------------------------------------------------

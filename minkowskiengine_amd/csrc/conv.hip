@@ -773,6 +773,215 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_bf16(const __bf16 *__restrict_
   if (pending >= 0) flush(pending);
 }
 
+// The same staged design in fp32 (v_mfma_f32_16x16x4_f32, exact fp32): rows are gathered ONCE per workgroup with
+// 16-byte loads and shared by the four waves through LDS, so the matrix pipe is fed by one conflict-free
+// ds_read_b32 per operand instead of one global gather per wave — k_wgrad_f32 above re-gathers every x row in
+// each of its waves and tops out at 54 % of the fp32 MFMA peak.  Used when both channel counts are multiples
+// of 4; register images in the layout of k_wgrad_bf16 (k_wgrad_reduce<NB, true>).
+template <int NB, int KSTEPS>
+__global__ __launch_bounds__(256, 2) void k_wgrad_lds_f32(const float *__restrict__ x, int c_in,
+                                                         const float *__restrict__ dy, int c_out,
+                                                      const int32_t *__restrict__ in_pairs,
+                                                      const int32_t *__restrict__ out_pairs,
+                                                      const int64_t *__restrict__ koffs, int volume,
+                                                      int64_t n_pairs, int n_ranges, int n_cob,
+                                                      float *__restrict__ partial) {
+  constexpr int MB = 4;
+  constexpr int SP = 16 * KSTEPS;        // pairs per step (<= 64: one index register per wave)
+  constexpr int COB = 64 * NB;           // output channels per workgroup
+  constexpr int XLD = 64 + kWgStepLd;    // elements
+  constexpr int DLD = COB + kWgStepLd;
+  constexpr int XP = SP * 16 / 256;      // 16-byte x pieces per thread and step
+  constexpr int DP = SP * (COB / 4) / 256;
+  static_assert(SP <= 64 && XP >= 1, "step size");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *s_x = reinterpret_cast<float *>(smem);              // [2][SP][XLD]
+  float *s_d = s_x + 2 * SP * XLD;                            // [2][SP][DLD]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, q = lane >> 4;
+  const int range = blockIdx.x;
+  const int ci0 = blockIdx.y * 64;
+  const int cog = blockIdx.z * COB;                           // first output channel of the workgroup
+  const int cob = blockIdx.z * 4 + wave;                      // this wave's block of 16*NB output channels
+  const int64_t e_lo = n_pairs * range / n_ranges;
+  const int64_t e_hi = n_pairs * (range + 1) / n_ranges;
+  if (e_lo >= e_hi) return;                                   // whole workgroup
+
+  constexpr int kImage = MB * NB * 4 * 64;
+  const int64_t image_stride = (int64_t)gridDim.y * n_cob * kImage;
+  float *const image0 = partial + ((int64_t)blockIdx.y * n_cob + min(cob, n_cob - 1)) * kImage + lane;
+
+  // step cursor: offset k, first pair e, number of pairs cnt (0 = past the end of the range)
+  auto first_offset = [&](int64_t e) {
+    int lo = 0, hi = volume;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (koffs[mid] <= e) lo = mid; else hi = mid;
+    }
+    return lo;
+  };
+  auto step_count = [&](int k, int64_t e) -> int {
+    if (e >= e_hi) return 0;
+    const int64_t kend = min(koffs[k + 1], e_hi);
+    return (int)min((int64_t)SP, kend - e);
+  };
+  auto advance = [&](int &k, int64_t &e, int cnt) {
+    e += cnt;
+    if (e < e_hi) {
+      while (koffs[k + 1] <= e) ++k;
+    }
+  };
+
+  // this thread's pieces: x piece j is row (j*256 + tid) >> 3, channels ci0 + ((j*256 + tid) & 7) * 8
+  int32_t pin = 0, pout = 0;            // pair indices of the step whose rows are loaded next (lane l: pair e + l)
+  f32x4 rx[XP], rd[DP];
+  auto load_idx = [&](int64_t e) {
+    const int64_t ec = min(e + lane, n_pairs - 1);            // unconditional load from a valid address
+    const int32_t *pi = in_pairs + ec, *po = out_pairs + ec;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(pin) : "v"(pi) : "memory");
+    asm volatile("global_load_dword %0, %1, off" : "=v"(pout) : "v"(po) : "memory");
+  };
+  // The row loads are inline asm: hipcc sinks ordinary loads whose first use is in the next iteration below
+  // the MFMAs (into the last block before the back edge), which serialises gather and multiply.  asm volatile
+  // keeps them where they are written; the matching s_waitcnt is issued by hand (wait_rows) right before the
+  // registers are stored to LDS one iteration later.
+  auto load_rows = [&]() {
+#pragma unroll
+    for (int j = 0; j < XP; ++j) {
+      const int idx = j * 256 + tid;
+      const int row = idx >> 4;
+      const int ch = ci0 + (idx & 15) * 4;
+      const int32_t r = __shfl(pin, row, 64);
+      const float *p = x + (int64_t)r * c_in + (ch < c_in ? ch : 0);
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rx[j]) : "v"(p) : "memory");
+    }
+#pragma unroll
+    for (int j = 0; j < DP; ++j) {
+      const int idx = j * 256 + tid;
+      const int row = idx / (COB / 4);
+      const int ch = cog + (idx % (COB / 4)) * 4;
+      const int32_t r = __shfl(pout, row, 64);
+      const float *p = dy + (int64_t)r * c_out + (ch < c_out ? ch : 0);
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rd[j]) : "v"(p) : "memory");
+    }
+  };
+  auto wait_rows = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pin), "+v"(pout));
+#pragma unroll
+    for (int j = 0; j < XP; ++j) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rx[j]));
+#pragma unroll
+    for (int j = 0; j < DP; ++j) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rd[j]));
+  };
+  auto write_lds = [&](int buf, int cnt) {
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < XP; ++j) {
+      const int idx = j * 256 + tid;
+      const int row = idx >> 4;
+      const int ch = ci0 + (idx & 15) * 4;
+      const bool ok = row < cnt && ch < c_in;                // pairs beyond the step / channels beyond c_in: zeros
+      *reinterpret_cast<f32x4 *>(s_x + (buf * SP + row) * XLD + (idx & 15) * 4) = ok ? rx[j] : zero;
+    }
+#pragma unroll
+    for (int j = 0; j < DP; ++j) {
+      const int idx = j * 256 + tid;
+      const int row = idx / (COB / 4);
+      const int pc = idx % (COB / 4);
+      const bool ok = row < cnt && cog + pc * 4 < c_out;
+      *reinterpret_cast<f32x4 *>(s_d + (buf * SP + row) * DLD + pc * 4) = ok ? rd[j] : zero;
+    }
+  };
+
+  f32x4 acc[MB][NB];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int n = 0; n < NB; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto flush = [&](int k) {
+    if (cob < n_cob) {
+      float *img = image0 + (int64_t)(range + k) * image_stride;
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) img[((m * NB + n) * 4 + r) * 64] = acc[m][n][r];
+    }
+  };
+  // v_mfma_f32_16x16x4_f32: lane (i16, q) supplies x[pair 4*s + q][16*m + i16] and dy[pair 4*s + q][16*n + i16]:
+  // one ds_read_b32 per operand, 16 consecutive floats per 16-lane group, row stride = 16 mod 32 banks
+  auto multiply = [&](int buf) {
+    const float *bx = s_x + (buf * SP + q) * XLD + i16;
+    const float *bd = s_d + (buf * SP + q) * DLD + wave * 16 * NB + i16;
+#pragma unroll
+    for (int s = 0; s < SP / 4; ++s) {
+      float a[MB], b[NB];
+#pragma unroll
+      for (int m = 0; m < MB; ++m) a[m] = bx[(4 * s) * XLD + 16 * m];
+#pragma unroll
+      for (int n = 0; n < NB; ++n) b[n] = bd[(4 * s) * DLD + 16 * n];
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int n = 0; n < NB; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[n], acc[m][n], 0, 0, 0);
+    }
+  };
+
+  // cursors: A = step being multiplied, B = step whose rows are in flight, C = step whose indices are in flight
+  int kA = first_offset(e_lo);
+  int64_t eA = e_lo;
+  int cA = step_count(kA, eA);
+  int kB = kA;
+  int64_t eB = eA;
+  advance(kB, eB, cA);
+  int cB = step_count(kB, eB);
+  int kC = kB;
+  int64_t eC = eB;
+  advance(kC, eC, cB);
+  int cC = step_count(kC, eC);
+
+  load_idx(eA);
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(pin), "+v"(pout));
+  load_rows();          // rows of step A
+  load_idx(eB);         // indices of step B
+  zero_acc();
+  int buf = 0;
+  int pending = -1;     // offset whose accumulators must be flushed before the next step is multiplied
+  while (cA > 0) {
+    // (the flush sits at the top of the loop so that the block that issues the row loads ends with the
+    // MFMAs: hipcc otherwise sinks the loads below the multiply into the block after the flush branch)
+    if (pending >= 0) {
+      flush(pending);
+      zero_acc();
+    }
+    wait_rows();
+    write_lds(buf, cA);   // rows of step A (requested one step ago)
+    load_rows();          // rows of step B (its indices arrived with A's rows)
+    load_idx(eC);         // indices of step C
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();      // step A visible; everybody is done reading the other buffer
+    multiply(buf);
+    pending = (cB == 0 || kB != kA) ? kA : -1;  // last step of offset kA inside this range
+    buf ^= 1;
+    kA = kB; eA = eB; cA = cB;
+    kB = kC; eB = eC; cB = cC;
+    advance(kC, eC, cC);
+    cC = step_count(kC, eC);
+  }
+  if (pending >= 0) flush(pending);
+}
+
+// grad_w[k] = sum of the register images of the ranges that touch offset k, written back through the
+// channel interleave of k_wgrad_f32.  A block sums 64 consecutive image elements; its four waves take
+// the slots s = first + phase, + 4, ... (four independent loads in flight per thread: the loop is
+// latency-bound otherwise) and the four partial sums are combined in phase order, so the summation
+// order is fixed (bitwise reproducible).
+
 // grad_w[k] = sum of the register images of the ranges that touch offset k, written back through the
 // channel interleave of k_wgrad_f32.  A block sums 64 consecutive image elements; its four waves take
 // the slots s = first + phase, + 4, ... (four independent loads in flight per thread: the loop is
@@ -977,6 +1186,65 @@ static WgradGeom wgrad_geom(int64_t n_pairs, int64_t volume, int c_in, int c_out
   return g;
 }
 
+// geometry of the LDS-staged kernels (k_wgrad_bf16, k_wgrad_lds_f32): always four waves side by side along the
+// output channels
+static WgradGeom wgrad_geom_staged(int64_t n_pairs, int c_in, int c_out) {
+  WgradGeom g;
+  // 64 or 128 output channels per workgroup; wider layers take several workgroup columns (grid.z) that
+  // re-gather the x rows (the <4, 1> instantiation — 256 channels, 32-pair steps — faulted on the GPU and is
+  // not used; its cause was not found in round 1)
+  g.nb = c_out <= 64 ? 1 : 2;
+  g.n_cib = (int)ceil_div(c_in, 16 * kWgMB);
+  g.n_cob = (int)ceil_div(c_out, 16 * g.nb);
+  g.waves = 4;
+  g.gz = (int)ceil_div(g.n_cob, 4);
+  const int wpc = g_wgrad_wgs_per_cu > 0 ? g_wgrad_wgs_per_cu : 2;
+  int64_t r = ceil_div((int64_t)device_cu_count() * wpc, (int64_t)g.n_cib * g.gz);
+  if (r > n_pairs / 64) r = n_pairs / 64;
+  if (r < 1) r = 1;
+  g.ranges = r;
+  g.slot_floats = (int64_t)g.n_cib * g.n_cob * (kWgMB * g.nb * 4 * 64);
+  return g;
+}
+
+template <int NB, int KSTEPS>
+static int launch_wgrad_bf16(const WgradGeom &g, const __bf16 *x, int c_in, const __bf16 *dy, int c_out,
+                             const int32_t *in_pairs, const int32_t *out_pairs, const int64_t *k_offsets_dev,
+                             int volume, int64_t n_pairs, float *partial, hipStream_t stream) {
+  constexpr int SP = 32 * KSTEPS;
+  const int lds = 2 * SP * ((64 + kWgStepLd) + (64 * NB + kWgStepLd)) * 2;
+  static bool attr_set = false;
+  if (lds > 32 * 1024 && !attr_set) {
+    ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wgrad_bf16<NB, KSTEPS>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
+    attr_set = true;
+  }
+  const dim3 grid((unsigned)g.ranges, (unsigned)g.n_cib, (unsigned)g.gz);
+  hipLaunchKernelGGL((k_wgrad_bf16<NB, KSTEPS>), grid, dim3(256), (size_t)lds, stream, x, c_in, dy, c_out, in_pairs,
+                     out_pairs, k_offsets_dev, volume, n_pairs, (int)g.ranges, g.n_cob, partial);
+  ME_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int NB, int KSTEPS>
+static int launch_wgrad_lds_f32(const WgradGeom &g, const float *x, int c_in, const float *dy, int c_out,
+                                const int32_t *in_pairs, const int32_t *out_pairs, const int64_t *k_offsets_dev,
+                                int volume, int64_t n_pairs, float *partial, hipStream_t stream) {
+  constexpr int SP = 16 * KSTEPS;
+  const int lds = 2 * SP * ((64 + kWgStepLd) + (64 * NB + kWgStepLd)) * 4;
+  static bool attr_set = false;
+  if (lds > 32 * 1024 && !attr_set) {
+    ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wgrad_lds_f32<NB, KSTEPS>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
+    attr_set = true;
+  }
+  const dim3 grid((unsigned)g.ranges, (unsigned)g.n_cib, (unsigned)g.gz);
+  hipLaunchKernelGGL((k_wgrad_lds_f32<NB, KSTEPS>), grid, dim3(256), (size_t)lds, stream, x, c_in, dy, c_out,
+                     in_pairs, out_pairs, k_offsets_dev, volume, n_pairs, (int)g.ranges, g.n_cob, partial);
+  ME_LAUNCH_CHECK();
+  return 0;
+}
+
 }  // namespace me
 
 using namespace me;
@@ -1152,8 +1420,11 @@ int me_transpose_kernel_f32(const float *w, int64_t volume, int32_t c_in, int32_
 
 int64_t me_conv_wgrad_workspace_bytes(const int64_t *k_offsets, int64_t volume, int32_t c_in, int32_t c_out) {
   if (volume < 1 || c_in <= 0 || c_out <= 0) return 256;
+  // the larger need of the two kernels (k_wgrad_lds_f32 / k_wgrad_f32)
   const WgradGeom g = wgrad_geom(k_offsets[volume], volume, c_in, c_out);
-  return align_up((g.ranges + volume) * g.slot_floats * 4, 256);
+  const WgradGeom h = wgrad_geom_staged(k_offsets[volume], c_in, c_out);
+  const int64_t a = (g.ranges + volume) * g.slot_floats, b = (h.ranges + volume) * h.slot_floats;
+  return align_up((a > b ? a : b) * 4, 256);
 }
 
 void me_debug_set_wgrad_config(int depth, int wgs_per_cu) {
@@ -1165,57 +1436,50 @@ int me_conv_wgrad_f32(const float *x, int32_t c_in, const float *dy, int32_t c_o
                       const int32_t *out_pairs, const int64_t *k_offsets, const int64_t *k_offsets_dev,
                       int64_t volume, float *grad_w, void *workspace, int64_t workspace_bytes,
                       void *stream_) {
-  return wgrad_launch<float>(x, c_in, dy, c_out, in_pairs, out_pairs, k_offsets, k_offsets_dev, volume, grad_w,
-                             workspace, workspace_bytes, (hipStream_t)stream_);
-}
-
-}  // extern "C"
-
-// geometry of k_wgrad_bf16: always four waves side by side along the output channels
-static WgradGeom wgrad_geom_bf16(int64_t n_pairs, int c_in, int c_out) {
-  WgradGeom g;
-  // 64 or 128 output channels per workgroup; wider layers take several workgroup columns (grid.z) that
-  // re-gather the x rows (the <4, 1> instantiation — 256 channels, 32-pair steps — faulted on the GPU and is
-  // not used; its cause was not found in round 1)
-  g.nb = c_out <= 64 ? 1 : 2;
-  g.n_cib = (int)ceil_div(c_in, 16 * kWgMB);
-  g.n_cob = (int)ceil_div(c_out, 16 * g.nb);
-  g.waves = 4;
-  g.gz = (int)ceil_div(g.n_cob, 4);
-  const int wpc = g_wgrad_wgs_per_cu > 0 ? g_wgrad_wgs_per_cu : 2;
-  int64_t r = ceil_div((int64_t)device_cu_count() * wpc, (int64_t)g.n_cib * g.gz);
-  if (r > n_pairs / 64) r = n_pairs / 64;
-  if (r < 1) r = 1;
-  g.ranges = r;
-  g.slot_floats = (int64_t)g.n_cib * g.n_cob * (kWgMB * g.nb * 4 * 64);
-  return g;
-}
-
-template <int NB, int KSTEPS>
-static int launch_wgrad_bf16(const WgradGeom &g, const __bf16 *x, int c_in, const __bf16 *dy, int c_out,
-                             const int32_t *in_pairs, const int32_t *out_pairs, const int64_t *k_offsets_dev,
-                             int volume, int64_t n_pairs, float *partial, hipStream_t stream) {
-  constexpr int SP = 32 * KSTEPS;
-  const int lds = 2 * SP * ((64 + kWgStepLd) + (64 * NB + kWgStepLd)) * 2;
-  static bool attr_set = false;
-  if (lds > 32 * 1024 && !attr_set) {
-    ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wgrad_bf16<NB, KSTEPS>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
-    attr_set = true;
+  hipStream_t stream = (hipStream_t)stream_;
+  // Default: the direct-from-global kernel.  The LDS-staged fp32 kernel (me_debug_set_wgrad_config(-2, 0)) measured
+  // the same 82 TF on config 2 (profiles/r01_tune_wgrad_f32_staged.log): in fp32 the weight gradient is bound by
+  // the ~4 TB/s at which 640 MB of random rows arrive from beyond the L2s, not by how the matrix pipe is fed
+  // (it is 13 % faster on sparse maps and 40 % slower on 32 -> 32, so it is not the default).
+  if ((c_in % 4) != 0 || (c_out % 4) != 0 || g_wgrad_depth != -2)
+    return wgrad_launch<float>(x, c_in, dy, c_out, in_pairs, out_pairs, k_offsets, k_offsets_dev, volume, grad_w,
+                               workspace, workspace_bytes, stream);
+  ME_CHECK(volume >= 1 && volume <= 65535, "kernel volume out of range");
+  ME_CHECK(c_in > 0 && c_out > 0, "channel counts must be positive");
+  ME_CHECK((uintptr_t)x % 16 == 0 && (uintptr_t)dy % 16 == 0, "feature pointers must be 16-byte aligned");
+  ME_CHECK(workspace_bytes >= me_conv_wgrad_workspace_bytes(k_offsets, volume, c_in, c_out), "workspace too small");
+  const int64_t n_pairs = k_offsets[volume];
+  const WgradGeom g = wgrad_geom_staged(n_pairs, c_in, c_out);
+  float *partial = reinterpret_cast<float *>(workspace);
+  if (n_pairs > 0) {
+    int rc;
+    if (g.nb == 1)
+      rc = launch_wgrad_lds_f32<1, 2>(g, x, c_in, dy, c_out, in_pairs, out_pairs, k_offsets_dev, (int)volume, n_pairs,
+                                      partial, stream);
+    else
+      rc = launch_wgrad_lds_f32<2, 2>(g, x, c_in, dy, c_out, in_pairs, out_pairs, k_offsets_dev, (int)volume, n_pairs,
+                                      partial, stream);
+    if (rc != 0) return rc;
   }
-  const dim3 grid((unsigned)g.ranges, (unsigned)g.n_cib, (unsigned)g.gz);
-  hipLaunchKernelGGL((k_wgrad_bf16<NB, KSTEPS>), grid, dim3(256), (size_t)lds, stream, x, c_in, dy, c_out, in_pairs,
-                     out_pairs, k_offsets_dev, volume, n_pairs, (int)g.ranges, g.n_cob, partial);
+  const dim3 rgrid((unsigned)ceil_div(g.slot_floats, 64), (unsigned)volume);
+  if (g.nb == 1)
+    hipLaunchKernelGGL((k_wgrad_reduce<1, true>), rgrid, dim3(256), 0, stream, partial, k_offsets_dev, (int)volume,
+                       n_pairs > 0 ? n_pairs : 1, (int)g.ranges, g.n_cib, g.n_cob, c_in, c_out, grad_w);
+  else
+    hipLaunchKernelGGL((k_wgrad_reduce<2, true>), rgrid, dim3(256), 0, stream, partial, k_offsets_dev, (int)volume,
+                       n_pairs > 0 ? n_pairs : 1, (int)g.ranges, g.n_cib, g.n_cob, c_in, c_out, grad_w);
   ME_LAUNCH_CHECK();
   return 0;
 }
+
+}  // extern "C"
 
 extern "C" {
 
 int64_t me_conv_wgrad_workspace_bytes_bf16(const int64_t *k_offsets, int64_t volume, int32_t c_in, int32_t c_out) {
   if (volume < 1 || c_in <= 0 || c_out <= 0) return 256;
   // the larger of the two kernels' needs (channel counts that are not multiples of 8 take k_wgrad_f32<__bf16>)
-  const WgradGeom g = wgrad_geom_bf16(k_offsets[volume], c_in, c_out);
+  const WgradGeom g = wgrad_geom_staged(k_offsets[volume], c_in, c_out);
   const int64_t a = align_up((g.ranges + volume) * g.slot_floats * 4, 256);
   const int64_t b = me_conv_wgrad_workspace_bytes(k_offsets, volume, c_in, c_out);
   return a > b ? a : b;
@@ -1237,7 +1501,7 @@ int me_conv_wgrad_bf16(const uint16_t *x_, int32_t c_in, const uint16_t *dy_, in
   ME_CHECK(volume >= 1 && volume <= 65535, "kernel volume out of range");
   ME_CHECK((uintptr_t)x % 16 == 0 && (uintptr_t)dy % 16 == 0, "feature pointers must be 16-byte aligned");
   const int64_t n_pairs = k_offsets[volume];
-  const WgradGeom g = wgrad_geom_bf16(n_pairs, c_in, c_out);
+  const WgradGeom g = wgrad_geom_staged(n_pairs, c_in, c_out);
   float *partial = reinterpret_cast<float *>(workspace);
   if (n_pairs > 0) {
     int rc;
