@@ -995,3 +995,60 @@ def BroadcastBackwardGPU(in_feat, in_feat_glob, grad_out_feat, broadcast_mode, i
                                             in_feat.shape[1], 1, _ptr(grad_in), _stream(dev)))
         grad_glob, _, _ = _global_pool(grad_out_feat, in_feat, rows, n_batch, 0)
     return grad_in, grad_glob
+
+
+# ------------------------------------------------------------------------------------------------
+# batch normalisation over feature rows (csrc/norm.hip; the reference applies torch.nn.BatchNorm1d to the
+# feature matrix, MinkowskiNormalization.py:35-82)
+# ------------------------------------------------------------------------------------------------
+def _bn_check(x):
+    _check(x.is_cuda and x.is_contiguous() and x.dim() == 2, "batch norm input must be a contiguous GPU matrix")
+    _check(x.dtype in (torch.float32, torch.bfloat16), "batch norm input must be float32 or bfloat16, got", x.dtype)
+    _check(x.shape[0] > 0, "batch norm needs at least one row")
+
+
+def bn_stats(x, eps, momentum, running_mean=None, running_var=None):
+    """-> (mean, rstd) float32 [c] of the batch; running statistics updated in place when given."""
+    _bn_check(x)
+    lib = _lib.load()
+    dev = x.device
+    n, c = int(x.shape[0]), int(x.shape[1])
+    mean = torch.empty(c, dtype=torch.float32, device=dev)
+    rstd = torch.empty(c, dtype=torch.float32, device=dev)
+    ws = _workspace(int(lib.me_bn_workspace_bytes(n, c)), dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.me_bn_stats(_ptr(x), 1 if x.dtype == torch.bfloat16 else 0, n, c, float(eps),
+                                   float(momentum), _ptr(mean), _ptr(rstd), _ptr(running_mean), _ptr(running_var),
+                                   _ptr(ws), ws.numel(), _stream(dev)))
+    return mean, rstd
+
+
+def bn_apply(x, mean, rstd, gamma, beta):
+    _bn_check(x)
+    lib = _lib.load()
+    dev = x.device
+    y = torch.empty_like(x)
+    with torch.cuda.device(dev):
+        _lib.check(lib.me_bn_apply(_ptr(x), 1 if x.dtype == torch.bfloat16 else 0, int(x.shape[0]), int(x.shape[1]),
+                                   _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(y), _stream(dev)))
+    return y
+
+
+def bn_backward(x, dy, mean, rstd, gamma):
+    """-> (dx, grad_gamma, grad_beta) of training-mode batch norm."""
+    _bn_check(x)
+    lib = _lib.load()
+    dev = x.device
+    n, c = int(x.shape[0]), int(x.shape[1])
+    if dy.dtype != x.dtype:
+        dy = dy.to(x.dtype)
+    dy = dy.contiguous()
+    dx = torch.empty_like(x)
+    gg = torch.empty(c, dtype=torch.float32, device=dev)
+    gb = torch.empty(c, dtype=torch.float32, device=dev)
+    ws = _workspace(int(lib.me_bn_workspace_bytes(n, c)), dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.me_bn_backward(_ptr(x), _ptr(dy), 1 if x.dtype == torch.bfloat16 else 0, n, c, _ptr(mean),
+                                      _ptr(rstd), _ptr(gamma), _ptr(dx), _ptr(gg), _ptr(gb), _ptr(ws), ws.numel(),
+                                      _stream(dev)))
+    return dx, gg, gb

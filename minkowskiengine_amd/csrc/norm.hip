@@ -1,0 +1,407 @@
+// Batch normalisation over the rows of a sparse tensor's feature matrix [n, c] for gfx950 (MI355X).
+//
+// The reference's MinkowskiBatchNorm is torch.nn.BatchNorm1d applied to the feature matrix
+// (MinkowskiEngine/MinkowskiNormalization.py:35-82); MinkUNet34C runs 62 of them per forward pass (SURVEY 8f
+// rank 1).  torch's channels-last statistics kernels take ~70 us per call on a 200k x 32..256 matrix (29 %
+// of a bf16 MinkUNet34C step, profiles/r01_rocprof_kernel_stats_minkunet34c_bf16_first.csv), far from the
+// HBM time of a 13..100 MB read, so the layer gets its own kernels here.  All of it is HBM-bound streaming:
+//
+//   statistics  k_bn_partial   one workgroup per chunk of rows; a thread owns a 16-byte channel piece and
+//                              strides over the rows of the chunk (coalesced rows), shifted sums
+//                              (shift = first row of the chunk) -> (mean, M2) of the chunk and channel
+//               k_bn_final     chunks combined per channel with Chan's formula in a FIXED order (bitwise
+//                              reproducible), mean / rstd written, running statistics updated
+//   forward     k_bn_apply     y = x * a[c] + b[c]   (a = gamma * rstd, b = beta - mean * a)
+//   backward    k_bn_bwd_partial / k_bn_bwd_final   sum dy, sum dy * xhat per channel (two levels, fixed order)
+//               k_bn_bwd_apply dx = a * (dy - sum_dy / n - xhat * sum_dy_xhat / n)
+// T = float or __bf16 rows; statistics and parameters are fp32.
+#include "conv_common.hpp"
+
+namespace me {
+
+constexpr int kBnMaxChunks = 1024;
+
+template <typename T, int V>
+struct Row {
+  float v[V];
+};
+template <typename T, int V>
+__device__ __forceinline__ Row<T, V> load_row(const T *p) {
+  Row<T, V> r;
+  if constexpr (V == 1) {
+    r.v[0] = (float)p[0];
+  } else {
+    typedef T tvec __attribute__((ext_vector_type(V)));
+    const tvec t = *reinterpret_cast<const tvec *>(p);
+#pragma unroll
+    for (int j = 0; j < V; ++j) r.v[j] = (float)t[j];
+  }
+  return r;
+}
+template <typename T, int V>
+__device__ __forceinline__ void store_row(T *p, const Row<T, V> &r) {
+  if constexpr (V == 1) {
+    p[0] = (T)r.v[0];
+  } else {
+    typedef T tvec __attribute__((ext_vector_type(V)));
+    tvec t;
+#pragma unroll
+    for (int j = 0; j < V; ++j) t[j] = (T)r.v[j];
+    *reinterpret_cast<tvec *>(p) = t;
+  }
+}
+
+// rows of chunk g: [g * n / G, (g + 1) * n / G)
+__device__ __forceinline__ int64_t chunk_begin(int64_t g, int64_t n, int64_t G) { return g * n / G; }
+
+// Per chunk and channel: mean and M2 = sum (x - mean)^2, from sums shifted by the chunk's first row.
+// Block layout: P = c / V pieces per row, R = blockDim / P row lanes; thread (lane rl, piece p) takes rows
+// r0 + rl, r0 + rl + R, ...; the R lanes are combined through LDS in lane order.
+template <typename T, int V>
+__global__ __launch_bounds__(256) void k_bn_partial(const T *__restrict__ x, int64_t n, int c, int chunks,
+                                                   float *__restrict__ part_mean, float *__restrict__ part_m2) {
+  extern __shared__ float s_red[];  // [R][2][c]
+  const int P = c / V;
+  const int R = max(1, (int)blockDim.x / P);
+  const int64_t r0 = chunk_begin(blockIdx.x, n, chunks), r1 = chunk_begin(blockIdx.x + 1, n, chunks);
+  for (int p0 = 0; p0 < P; p0 += blockDim.x) {  // one pass unless c / V > blockDim
+    const int p = p0 + (int)threadIdx.x % min(P, (int)blockDim.x);
+    const int rl = (int)threadIdx.x / min(P, (int)blockDim.x);
+    const bool active = rl < R && p < P;
+    float s1[V], s2[V], shift[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) s1[j] = s2[j] = shift[j] = 0.f;
+    if (active && r0 < r1) {
+      const Row<T, V> k = load_row<T, V>(x + r0 * c + p * V);
+#pragma unroll
+      for (int j = 0; j < V; ++j) shift[j] = k.v[j];
+      for (int64_t r = r0 + rl; r < r1; r += R) {
+        const Row<T, V> t = load_row<T, V>(x + r * c + p * V);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          const float d = t.v[j] - shift[j];
+          s1[j] += d;
+          s2[j] += d * d;
+        }
+      }
+    }
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        s_red[(rl * 2 + 0) * c + p * V + j] = s1[j];
+        s_red[(rl * 2 + 1) * c + p * V + j] = s2[j];
+      }
+    }
+    __syncthreads();
+    if (active && rl == 0) {
+      const float cnt = (float)(r1 - r0);
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        float a = 0.f, b = 0.f;
+        for (int l = 0; l < R; ++l) {  // fixed order
+          a += s_red[(l * 2 + 0) * c + p * V + j];
+          b += s_red[(l * 2 + 1) * c + p * V + j];
+        }
+        const float m = cnt > 0.f ? a / cnt : 0.f;
+        part_mean[(int64_t)blockIdx.x * c + p * V + j] = shift[j] + m;
+        part_m2[(int64_t)blockIdx.x * c + p * V + j] = cnt > 0.f ? fmaxf(b - a * m, 0.f) : 0.f;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// Combine the chunks of each channel (Chan et al.): block = 32 channels x 8 lanes; lane l takes chunks
+// l, l + 8, ... in order, the 8 lane results are combined in lane order.  Writes mean, rstd (biased
+// variance + eps) and updates the running statistics (unbiased variance, torch's convention).
+__global__ __launch_bounds__(256) void k_bn_final(const float *__restrict__ part_mean,
+                                                 const float *__restrict__ part_m2, int64_t n, int c, int chunks,
+                                                 float eps, float momentum, float *__restrict__ mean_out,
+                                                 float *__restrict__ rstd_out, float *__restrict__ running_mean,
+                                                 float *__restrict__ running_var) {
+  __shared__ float s_n[8][32], s_m[8][32], s_q[8][32];
+  const int ch = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int l = threadIdx.x >> 5;
+  float cn = 0.f, cm = 0.f, cq = 0.f;
+  if (ch < c) {
+    for (int g = l; g < chunks; g += 8) {
+      const float bn = (float)(chunk_begin(g + 1, n, chunks) - chunk_begin(g, n, chunks));
+      if (bn <= 0.f) continue;
+      const float bm = part_mean[(int64_t)g * c + ch], bq = part_m2[(int64_t)g * c + ch];
+      const float tot = cn + bn, d = bm - cm;
+      cm += d * (bn / tot);
+      cq += bq + d * d * (cn * bn / tot);
+      cn = tot;
+    }
+  }
+  s_n[l][threadIdx.x & 31] = cn;
+  s_m[l][threadIdx.x & 31] = cm;
+  s_q[l][threadIdx.x & 31] = cq;
+  __syncthreads();
+  if (l != 0 || ch >= c) return;
+  for (int j = 1; j < 8; ++j) {
+    const float bn = s_n[j][threadIdx.x], bm = s_m[j][threadIdx.x], bq = s_q[j][threadIdx.x];
+    if (bn <= 0.f) continue;
+    const float tot = cn + bn, d = bm - cm;
+    cm += d * (bn / tot);
+    cq += bq + d * d * (cn * bn / tot);
+    cn = tot;
+  }
+  const float var = cn > 0.f ? cq / cn : 0.f;
+  mean_out[ch] = cm;
+  rstd_out[ch] = rsqrtf(var + eps);
+  if (running_mean != nullptr) {
+    const float unbiased = cn > 1.f ? cq / (cn - 1.f) : var;
+    running_mean[ch] = (1.f - momentum) * running_mean[ch] + momentum * cm;
+    running_var[ch] = (1.f - momentum) * running_var[ch] + momentum * unbiased;
+  }
+}
+
+// y = x * a[c] + b[c] with a = gamma * rstd, b = beta - mean * a (gamma / beta may be NULL: 1 / 0)
+template <typename T, int V>
+__global__ __launch_bounds__(256) void k_bn_apply(const T *__restrict__ x, int64_t n, int c,
+                                                 const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                 const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                 T *__restrict__ y) {
+  const int P = c / V;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * P) return;
+  const int ch = (int)(idx % P) * V;
+  Row<T, V> t = load_row<T, V>(x + idx * V);
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    const float a = (gamma ? gamma[ch + j] : 1.f) * rstd[ch + j];
+    const float b = (beta ? beta[ch + j] : 0.f) - mean[ch + j] * a;
+    t.v[j] = t.v[j] * a + b;
+  }
+  store_row<T, V>(y + idx * V, t);
+}
+
+// per chunk and channel: sum dy and sum dy * xhat (xhat = (x - mean) * rstd); same layout as k_bn_partial
+template <typename T, int V>
+__global__ __launch_bounds__(256) void k_bn_bwd_partial(const T *__restrict__ x, const T *__restrict__ dy,
+                                                       int64_t n, int c, int chunks,
+                                                       const float *__restrict__ mean,
+                                                       const float *__restrict__ rstd,
+                                                       float *__restrict__ part_dy,
+                                                       float *__restrict__ part_dyx) {
+  extern __shared__ float s_red[];  // [R][2][c]
+  const int P = c / V;
+  const int R = max(1, (int)blockDim.x / P);
+  const int64_t r0 = chunk_begin(blockIdx.x, n, chunks), r1 = chunk_begin(blockIdx.x + 1, n, chunks);
+  for (int p0 = 0; p0 < P; p0 += blockDim.x) {
+    const int p = p0 + (int)threadIdx.x % min(P, (int)blockDim.x);
+    const int rl = (int)threadIdx.x / min(P, (int)blockDim.x);
+    const bool active = rl < R && p < P;
+    float s1[V], s2[V], m[V], rs[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) s1[j] = s2[j] = m[j] = rs[j] = 0.f;
+    if (active) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        m[j] = mean[p * V + j];
+        rs[j] = rstd[p * V + j];
+      }
+      for (int64_t r = r0 + rl; r < r1; r += R) {
+        const Row<T, V> tx = load_row<T, V>(x + r * c + p * V);
+        const Row<T, V> tg = load_row<T, V>(dy + r * c + p * V);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          s1[j] += tg.v[j];
+          s2[j] += tg.v[j] * ((tx.v[j] - m[j]) * rs[j]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        s_red[(rl * 2 + 0) * c + p * V + j] = s1[j];
+        s_red[(rl * 2 + 1) * c + p * V + j] = s2[j];
+      }
+    }
+    __syncthreads();
+    if (active && rl == 0) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        float a = 0.f, b = 0.f;
+        for (int l = 0; l < R; ++l) {
+          a += s_red[(l * 2 + 0) * c + p * V + j];
+          b += s_red[(l * 2 + 1) * c + p * V + j];
+        }
+        part_dy[(int64_t)blockIdx.x * c + p * V + j] = a;
+        part_dyx[(int64_t)blockIdx.x * c + p * V + j] = b;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// sums of the chunks per channel in a fixed order: grad_beta = sum dy, grad_gamma = sum dy * xhat
+__global__ __launch_bounds__(256) void k_bn_bwd_final(const float *__restrict__ part_dy,
+                                                     const float *__restrict__ part_dyx, int c, int chunks,
+                                                     float *__restrict__ sum_dy, float *__restrict__ sum_dyx) {
+  __shared__ float s_a[8][32], s_b[8][32];
+  const int ch = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int l = threadIdx.x >> 5;
+  float a = 0.f, b = 0.f;
+  if (ch < c) {
+    for (int g = l; g < chunks; g += 8) {
+      a += part_dy[(int64_t)g * c + ch];
+      b += part_dyx[(int64_t)g * c + ch];
+    }
+  }
+  s_a[l][threadIdx.x & 31] = a;
+  s_b[l][threadIdx.x & 31] = b;
+  __syncthreads();
+  if (l != 0 || ch >= c) return;
+  for (int j = 1; j < 8; ++j) {
+    a += s_a[j][threadIdx.x];
+    b += s_b[j][threadIdx.x];
+  }
+  sum_dy[ch] = a;
+  sum_dyx[ch] = b;
+}
+
+// dx = gamma * rstd * (dy - sum_dy / n - xhat * sum_dyx / n)
+template <typename T, int V>
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const T *__restrict__ x, const T *__restrict__ dy,
+                                                     int64_t n, int c, const float *__restrict__ mean,
+                                                     const float *__restrict__ rstd,
+                                                     const float *__restrict__ gamma,
+                                                     const float *__restrict__ sum_dy,
+                                                     const float *__restrict__ sum_dyx, T *__restrict__ dx) {
+  const int P = c / V;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * P) return;
+  const int ch = (int)(idx % P) * V;
+  const Row<T, V> tx = load_row<T, V>(x + idx * V);
+  const Row<T, V> tg = load_row<T, V>(dy + idx * V);
+  Row<T, V> out;
+  const float inv_n = 1.f / (float)n;
+#pragma unroll
+  for (int j = 0; j < V; ++j) {
+    const float rs = rstd[ch + j];
+    const float xh = (tx.v[j] - mean[ch + j]) * rs;
+    const float a = (gamma ? gamma[ch + j] : 1.f) * rs;
+    out.v[j] = a * (tg.v[j] - sum_dy[ch + j] * inv_n - xh * (sum_dyx[ch + j] * inv_n));
+  }
+  store_row<T, V>(dx + idx * V, out);
+}
+
+static int bn_chunks(int64_t n) {
+  int64_t g = ceil_div(n, 128);  // at least ~128 rows per chunk
+  if (g > kBnMaxChunks) g = kBnMaxChunks;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+template <typename T>
+static int bn_stats(const T *x, int64_t n, int c, float eps, float momentum, float *mean, float *rstd,
+                    float *running_mean, float *running_var, float *ws, hipStream_t stream) {
+  const int chunks = bn_chunks(n);
+  float *pm = ws, *pq = ws + (int64_t)chunks * c;
+  const bool vec = (c % 4) == 0 && (uintptr_t)x % 16 == 0;
+  const int P = vec ? c / 4 : c;
+  const int R = P >= 256 ? 1 : 256 / P;
+  const size_t lds = (size_t)R * 2 * c * sizeof(float);
+  ME_CHECK(lds <= 64 * 1024, "channel count too large for the batch-norm kernels");
+  if (vec) hipLaunchKernelGGL((k_bn_partial<T, 4>), dim3(chunks), dim3(256), lds, stream, x, n, c, chunks, pm, pq);
+  else hipLaunchKernelGGL((k_bn_partial<T, 1>), dim3(chunks), dim3(256), lds, stream, x, n, c, chunks, pm, pq);
+  hipLaunchKernelGGL(k_bn_final, dim3((unsigned)ceil_div(c, 32)), dim3(256), 0, stream, pm, pq, n, c, chunks, eps,
+                     momentum, mean, rstd, running_mean, running_var);
+  ME_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T>
+static int bn_apply(const T *x, int64_t n, int c, const float *mean, const float *rstd, const float *gamma,
+                    const float *beta, T *y, hipStream_t stream) {
+  const bool vec = (c % 4) == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0;
+  const int64_t total = n * (vec ? c / 4 : c);
+  const dim3 grid((unsigned)ceil_div(total, 256));
+  if (vec) hipLaunchKernelGGL((k_bn_apply<T, 4>), grid, dim3(256), 0, stream, x, n, c, mean, rstd, gamma, beta, y);
+  else hipLaunchKernelGGL((k_bn_apply<T, 1>), grid, dim3(256), 0, stream, x, n, c, mean, rstd, gamma, beta, y);
+  ME_LAUNCH_CHECK();
+  return 0;
+}
+
+template <typename T>
+static int bn_backward(const T *x, const T *dy, int64_t n, int c, const float *mean, const float *rstd,
+                       const float *gamma, T *dx, float *grad_gamma, float *grad_beta, float *ws,
+                       hipStream_t stream) {
+  const int chunks = bn_chunks(n);
+  float *pa = ws, *pb = ws + (int64_t)chunks * c;
+  const bool vec = (c % 4) == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)dy % 16 == 0 && (uintptr_t)dx % 16 == 0;
+  const int P = vec ? c / 4 : c;
+  const int R = P >= 256 ? 1 : 256 / P;
+  const size_t lds = (size_t)R * 2 * c * sizeof(float);
+  ME_CHECK(lds <= 64 * 1024, "channel count too large for the batch-norm kernels");
+  if (vec)
+    hipLaunchKernelGGL((k_bn_bwd_partial<T, 4>), dim3(chunks), dim3(256), lds, stream, x, dy, n, c, chunks, mean, rstd,
+                       pa, pb);
+  else
+    hipLaunchKernelGGL((k_bn_bwd_partial<T, 1>), dim3(chunks), dim3(256), lds, stream, x, dy, n, c, chunks, mean, rstd,
+                       pa, pb);
+  hipLaunchKernelGGL(k_bn_bwd_final, dim3((unsigned)ceil_div(c, 32)), dim3(256), 0, stream, pa, pb, c, chunks,
+                     grad_beta, grad_gamma);
+  const int64_t total = n * (vec ? c / 4 : c);
+  const dim3 grid((unsigned)ceil_div(total, 256));
+  if (vec)
+    hipLaunchKernelGGL((k_bn_bwd_apply<T, 4>), grid, dim3(256), 0, stream, x, dy, n, c, mean, rstd, gamma, grad_beta,
+                       grad_gamma, dx);
+  else
+    hipLaunchKernelGGL((k_bn_bwd_apply<T, 1>), grid, dim3(256), 0, stream, x, dy, n, c, mean, rstd, gamma, grad_beta,
+                       grad_gamma, dx);
+  ME_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace me
+
+using namespace me;
+
+extern "C" {
+
+int64_t me_bn_workspace_bytes(int64_t n, int32_t c) {
+  return align_up((int64_t)bn_chunks(n) * c * 2 * 4, 256);
+}
+
+int me_bn_stats(const void *x, int32_t is_bf16, int64_t n, int32_t c, float eps, float momentum, float *mean,
+                float *rstd, float *running_mean, float *running_var, void *workspace, int64_t workspace_bytes,
+                void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ME_CHECK(n > 0 && c > 0, "batch norm needs at least one row and one channel");
+  ME_CHECK(workspace_bytes >= me_bn_workspace_bytes(n, c), "workspace too small");
+  float *ws = reinterpret_cast<float *>(workspace);
+  if (is_bf16)
+    return bn_stats<__bf16>(reinterpret_cast<const __bf16 *>(x), n, c, eps, momentum, mean, rstd, running_mean,
+                            running_var, ws, stream);
+  return bn_stats<float>(reinterpret_cast<const float *>(x), n, c, eps, momentum, mean, rstd, running_mean,
+                         running_var, ws, stream);
+}
+
+int me_bn_apply(const void *x, int32_t is_bf16, int64_t n, int32_t c, const float *mean, const float *rstd,
+                const float *gamma, const float *beta, void *y, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ME_CHECK(c > 0, "invalid channel count");
+  if (n == 0) return 0;
+  if (is_bf16)
+    return bn_apply<__bf16>(reinterpret_cast<const __bf16 *>(x), n, c, mean, rstd, gamma, beta,
+                            reinterpret_cast<__bf16 *>(y), stream);
+  return bn_apply<float>(reinterpret_cast<const float *>(x), n, c, mean, rstd, gamma, beta,
+                         reinterpret_cast<float *>(y), stream);
+}
+
+int me_bn_backward(const void *x, const void *dy, int32_t is_bf16, int64_t n, int32_t c, const float *mean,
+                   const float *rstd, const float *gamma, void *dx, float *grad_gamma, float *grad_beta,
+                   void *workspace, int64_t workspace_bytes, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ME_CHECK(n > 0 && c > 0, "batch norm needs at least one row and one channel");
+  ME_CHECK(workspace_bytes >= me_bn_workspace_bytes(n, c), "workspace too small");
+  float *ws = reinterpret_cast<float *>(workspace);
+  if (is_bf16)
+    return bn_backward<__bf16>(reinterpret_cast<const __bf16 *>(x), reinterpret_cast<const __bf16 *>(dy), n, c, mean,
+                               rstd, gamma, reinterpret_cast<__bf16 *>(dx), grad_gamma, grad_beta, ws, stream);
+  return bn_backward<float>(reinterpret_cast<const float *>(x), reinterpret_cast<const float *>(dy), n, c, mean, rstd,
+                            gamma, reinterpret_cast<float *>(dx), grad_gamma, grad_beta, ws, stream);
+}
+
+}  // extern "C"

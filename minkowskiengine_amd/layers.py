@@ -1,24 +1,84 @@
 """Feature-only layers that MinkUNet-style networks need around the convolutions.  In the reference
 these contain no native code: they apply torch modules to `.F` and re-wrap
 (MinkowskiNormalization.py:51-140, MinkowskiNonlinearity.py, MinkowskiOps.py:141-158)."""
+import os
+
 import torch
 import torch.nn as nn
+from torch.autograd import Function
 
+from . import backend as MEB
 from .sparse_tensor import SparseTensor
+
+_TORCH_BN = os.environ.get("ME_AMD_TORCH_BN", "0") != "0"   # 1: torch's batch-norm kernels (A/B timing)
 
 
 def _rewrap(x, feats):
     return SparseTensor(feats, coordinate_map_key=x.coordinate_map_key, coordinate_manager=x._manager)
 
 
+class _BatchNormTrainFunction(Function):
+    """Training-mode batch norm of a feature matrix on the HIP kernels of csrc/norm.hip (statistics in fp32,
+    fixed summation order).  weight / bias may be None."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps):
+        x = x.contiguous()
+        w32 = weight.float() if weight is not None else None
+        b32 = bias.float() if bias is not None else None
+        mean, rstd = MEB.bn_stats(x, eps, momentum, running_mean, running_var)
+        y = MEB.bn_apply(x, mean, rstd, w32, b32)
+        ctx.save_for_backward(x, mean, rstd, w32)
+        ctx.param_dtype = weight.dtype if weight is not None else None
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, w32 = ctx.saved_tensors
+        dx, gg, gb = MEB.bn_backward(x, dy, mean, rstd, w32)
+        gw = gg.to(ctx.param_dtype) if ctx.param_dtype is not None else None
+        gbias = gb.to(ctx.param_dtype) if ctx.has_bias else None
+        return dx, gw, gbias, None, None, None, None
+
+
 class MinkowskiBatchNorm(nn.Module):
+    """torch.nn.BatchNorm1d semantics on the feature matrix (MinkowskiNormalization.py:35-82).  The parameters
+    and running statistics live in `self.bn` (same state-dict names as the reference); on the GPU the arithmetic
+    runs on this package's kernels."""
+
     def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True):
         super().__init__()
         self.bn = nn.BatchNorm1d(num_features, eps=eps, momentum=momentum, affine=affine,
                                  track_running_stats=track_running_stats)
 
+    def _native(self, f):
+        bn = self.bn
+        return (not _TORCH_BN and type(bn) is nn.BatchNorm1d and f.is_cuda and f.dim() == 2 and f.shape[0] > 1
+                and f.dtype in (torch.float32, torch.bfloat16) and bn.momentum is not None
+                and f.shape[1] <= 2048)
+
     def forward(self, input):
-        return _rewrap(input, self.bn(input.F))
+        f = input.F
+        bn = self.bn
+        if not self._native(f):
+            return _rewrap(input, bn(f))
+        use_batch_stats = bn.training or not bn.track_running_stats
+        if use_batch_stats:
+            rm = bn.running_mean if (bn.training and bn.track_running_stats) else None
+            rv = bn.running_var if (bn.training and bn.track_running_stats) else None
+            if rm is not None:
+                bn.num_batches_tracked.add_(1)
+            y = _BatchNormTrainFunction.apply(f, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps)
+        else:
+            # evaluation: an affine map per channel, differentiable through torch (cheap: two fused passes)
+            rstd = torch.rsqrt(bn.running_var + bn.eps)
+            a = rstd * bn.weight.float() if bn.weight is not None else rstd
+            b = (bn.bias.float() if bn.bias is not None else 0.0) - bn.running_mean * a
+            y = (f * a.to(f.dtype) + b.to(f.dtype)) if f.requires_grad else \
+                MEB.bn_apply(f.contiguous(), bn.running_mean, rstd, bn.weight.float() if bn.weight is not None else None,
+                             bn.bias.float() if bn.bias is not None else None)
+        return _rewrap(input, y)
 
     def __repr__(self):
         b = self.bn

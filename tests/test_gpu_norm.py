@@ -1,0 +1,89 @@
+"""MinkowskiBatchNorm on the HIP kernels (csrc/norm.hip) against torch.nn.BatchNorm1d evaluated in float64 on
+the CPU — the reference's MinkowskiBatchNorm IS BatchNorm1d on the feature matrix
+(MinkowskiNormalization.py:35-82).  Tolerance 1e-5 (abs + rel) in fp32; for bf16 rows the output is compared
+after one bf16 rounding (2^-8 relative + 1e-3 of the range)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import make_cloud
+
+pytestmark = pytest.mark.gpu
+
+
+def _reference(x64, w, b, gy64, eps=1e-5, momentum=0.1):
+    bn = torch.nn.BatchNorm1d(x64.shape[1], eps=eps, momentum=momentum).double()
+    with torch.no_grad():
+        bn.weight.copy_(w.double())
+        bn.bias.copy_(b.double())
+    x = x64.clone().requires_grad_(True)
+    y = bn(x)
+    y.backward(gy64)
+    return y.detach(), x.grad, bn.weight.grad, bn.bias.grad, bn.running_mean, bn.running_var
+
+
+def _ours(device, x, w, b, gy, coords):
+    import minkowskiengine_amd as ME
+    bn = ME.MinkowskiBatchNorm(x.shape[1]).to(device)
+    with torch.no_grad():
+        bn.bn.weight.copy_(w)
+        bn.bn.bias.copy_(b)
+    f = x.to(device).requires_grad_(True)
+    st = ME.SparseTensor(f, coords.to(device))
+    y = bn(st)
+    y.F.backward(gy.to(device))
+    return y.F.detach(), f.grad, bn.bn.weight.grad, bn.bn.bias.grad, bn.bn.running_mean, bn.bn.running_var, bn
+
+
+def close(a, b, tol=1e-5):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max()) <= tol * (1.0 + float(b.abs().max()))
+
+
+@pytest.mark.parametrize("n,c,offset", [(5000, 32, 0.0), (1000, 96, 0.0), (3000, 7, 0.0), (2, 4, 0.0),
+                                        (4000, 256, 0.0), (3000, 384, 0.0), (20000, 64, 300.0)])
+def test_batch_norm_matches_torch_float64(device, n, c, offset):
+    g = torch.Generator().manual_seed(n + c)
+    coords = make_cloud(n, 40, 3, seed=c)
+    x = torch.randn(n, c, generator=g) * (1.0 + torch.arange(c) % 5) + offset   # offset: mean >> std
+    w, b = torch.rand(c, generator=g) + 0.5, torch.rand(c, generator=g) - 0.5
+    gy = torch.randn(n, c, generator=g)
+    ry, rdx, rdw, rdb, rrm, rrv = _reference(x.double(), w, b, gy.double())
+    y, dx, dw, db, rm, rv, _ = _ours(device, x, w, b, gy, coords)
+    tol = 1e-5 if offset == 0.0 else 2e-4      # fp32 input with mean 300, std ~1: 1e-7 * 300 relative to std
+    assert close(y, ry, tol) and close(dx, rdx, tol) and close(dw, rdw, tol * 10) and close(db, rdb, tol * 10)
+    assert close(rm, rrm, 1e-5) and close(rv, rrv, 1e-4)
+
+
+def test_batch_norm_bf16_rows(device):
+    n, c = 50000, 64
+    g = torch.Generator().manual_seed(1)
+    coords = make_cloud(n, 60, 3, seed=1)
+    x = (torch.randn(n, c, generator=g) * 2 + 1).bfloat16()
+    w, b = torch.rand(c, generator=g) + 0.5, torch.rand(c, generator=g) - 0.5
+    gy = torch.randn(n, c, generator=g).bfloat16()
+    ry, rdx, rdw, rdb, _, _ = _reference(x.double(), w, b, gy.double())
+    y, dx, dw, db, _, _, _ = _ours(device, x, w, b, gy, coords)
+    assert y.dtype == torch.bfloat16 and dx.dtype == torch.bfloat16 and dw.dtype == torch.float32
+    for got, ref in ((y, ry), (dx, rdx)):
+        err = (got.double().cpu() - ref).abs()
+        assert bool((err <= 2.0 ** -8 * ref.abs() + 1e-3 * ref.abs().max()).all())
+    assert close(dw, rdw, 1e-4) and close(db, rdb, 1e-4)
+
+
+def test_batch_norm_reproducible_and_eval(device):
+    import minkowskiengine_amd as ME
+    n, c = 30000, 32
+    g = torch.Generator().manual_seed(2)
+    coords = make_cloud(n, 50, 3, seed=2)
+    x, gy = torch.randn(n, c, generator=g), torch.randn(n, c, generator=g)
+    w, b = torch.rand(c, generator=g) + 0.5, torch.rand(c, generator=g)
+    a = _ours(device, x, w, b, gy, coords)
+    b2 = _ours(device, x, w, b, gy, coords)
+    assert all(torch.equal(p, q) for p, q in zip(a[:6], b2[:6]))
+    bn = a[6].eval()
+    st = ME.SparseTensor(x.to(device), coords.to(device))
+    ref = torch.nn.functional.batch_norm(x.double(), bn.bn.running_mean.double().cpu(), bn.bn.running_var.double().cpu(),
+                                         w.double(), b.double(), False, 0.1, 1e-5)
+    assert close(bn(st).F, ref, 1e-5)
+    assert int(bn.bn.num_batches_tracked) == 1
