@@ -221,6 +221,8 @@ void me_debug_set_wgrad_config(int depth, int wgs_per_cu);
  *   me_conv_wgrad_bf16:        grad_w (fp32 out) from bf16 x / dy on v_mfma_f32_16x16x32_bf16 (rows staged in
  *                              LDS once per workgroup, operands read back transposed with
  *                              ds_read_b64_tr_b16); workspace bytes from me_conv_wgrad_workspace_bytes_bf16. */
+int me_conv_plan_config_bf16(int64_t n_tgt, int64_t volume, int64_t n_pairs, int32_t c_src, int32_t c_dst,
+                             int32_t *tile_rows, int32_t *batch_groups);  /* plan geometry of the bf16 kernel */
 int64_t me_conv_packed_weight_elems_bf16(int64_t volume, int32_t c_src, int32_t c_dst); /* bf16 elements */
 int me_conv_pack_weights_bf16(const void *w_dev, int32_t w_is_f32, int64_t volume, int32_t c_src, int32_t c_dst,
                               int32_t transposed, uint16_t *packed_dev, void *stream);

@@ -606,11 +606,12 @@ def _timed(name, device, launch, flops=0.0):
     return r
 
 
-def plan_config(n_tgt, volume, n_pairs, c_src, c_dst):
+def plan_config(n_tgt, volume, n_pairs, c_src, c_dst, bf16=False):
     """(tile_rows, batch_groups) of the tile plan for a (target rows, channels) problem."""
     lib = _lib.load()
     t, g = ctypes.c_int32(0), ctypes.c_int32(0)
-    _lib.check(lib.me_conv_plan_config(n_tgt, volume, n_pairs, c_src, c_dst, ctypes.byref(t), ctypes.byref(g)))
+    fn = lib.me_conv_plan_config_bf16 if bf16 else lib.me_conv_plan_config
+    _lib.check(fn(n_tgt, volume, n_pairs, c_src, c_dst, ctypes.byref(t), ctypes.byref(g)))
     return _TILE_ROWS or int(t.value), _BATCH_GROUPS or int(g.value)
 
 
@@ -626,7 +627,7 @@ def _conv_target(src_feat, kernel, km, target, n_tgt, name="conv_target", transp
     out = torch.empty((n_tgt, c_dst), dtype=src_feat.dtype, device=dev)
     if n_tgt == 0:
         return out
-    tile_rows, batch_groups = plan_config(n_tgt, km.volume, km.n_pairs, c_src, c_dst)
+    tile_rows, batch_groups = plan_config(n_tgt, km.volume, km.n_pairs, c_src, c_dst, bf16)
     plan_src, plan_dst, batch_desc, tile_bptr, _ = km.plan(target, tile_rows, batch_groups)
     flops = 2.0 * km.n_pairs * c_src * c_dst
     with torch.cuda.device(dev):

@@ -1126,6 +1126,50 @@ static ConvVariant conv_variant(int c_src, int c_dst) {
   return v;
 }
 
+// Tile height for a (target rows, kernel shape) problem, shared by the fp32 and bf16 kernels: tiles x column
+// slabs just below a multiple of the GPU's resident-workgroup slots, the accumulator tile + stage buffer within
+// the LDS of `occ` resident workgroups, density steering the trade-off against the 16-row group padding.
+int plan_tile_rows(const PlanShape &s, int64_t n_tgt, int64_t volume, int64_t n_pairs) {
+  const int waves = s.nc / 16;
+  const int cus = device_cu_count();
+  // occupancy p of a neighbour offset (centre excluded) -> expected 16-row groups of a (tile, k) item
+  const double p = volume > 1 ? (double)(n_pairs > n_tgt ? n_pairs - n_tgt : 0) / ((double)(volume - 1) * n_tgt)
+                              : 0.0;
+  const int cap = ME_MAX_BATCH_GROUPS;
+  double best_cost = 1e300;
+  int best_t = 128;
+  // resident workgroups per CU: 3 waves per SIMD by registers (__launch_bounds__(NC * 4, 3)), then the LDS
+  for (int occ = 12 / waves; occ >= 1; --occ) {
+    const int64_t slots = (int64_t)cus * occ;
+    for (int rounds = 1; rounds <= 64; ++rounds) {
+      int64_t t = ceil_div(n_tgt * s.slabs, slots * rounds);
+      if (t < ME_GROUP_ROWS) t = ME_GROUP_ROWS;
+      if (t > ME_MAX_TILE_ROWS) continue;
+      const int64_t lds = (t + 1) * (s.nc + kAccPad) * 4 + (int64_t)cap * 16 * s.stage_row_bytes;
+      if (lds * occ > kLdsBudget) continue;
+      const double m = (double)t * p;  // expected entries of an off-centre item
+      const double g_side = m < 6.0 ? (m <= 0 ? 0.0 : (1.0 - exp(-m)) * (1.0 + m / 16.0)) : m / 16.0 + 0.5;
+      const double groups = (double)ceil_div(t, 16) + (double)(volume - 1) * g_side;
+      const double batches = (double)ceil_div(ceil_div(t, 16), cap) +
+                             (double)(volume - 1) * (m <= 0 ? 0.0 : (m < 3.0 ? 1.0 - exp(-m) : ceil(g_side / cap)));
+      const int64_t items = ceil_div(n_tgt, t) * s.slabs;
+      const double real_rounds = (double)ceil_div(items, slots);
+      // cycles of one tile if its waves had their SIMDs alone: per-group work + per-batch barrier / pipeline
+      // overhead + store / pipeline fill per tile; occ * waves / 4 waves share a SIMD
+      const double tile_cycles =
+          s.chunks * (groups * s.group_cycles + batches * 400.0) + (double)t * s.nc * 0.4 + 3000.0;
+      const double cost = real_rounds * tile_cycles * (double)(occ * waves) / 4.0 *
+                          (1.0 + 0.15 * 12.0 / (occ * waves));
+      if (cost < best_cost) {
+        best_cost = cost;
+        best_t = (int)t;
+      }
+      if (t == ME_GROUP_ROWS) break;
+    }
+  }
+  return best_t;
+}
+
 int g_conv_variant = 0;  // me_debug_set_conv_variant
 
 template <int NC, int KC, int VAR>
@@ -1303,42 +1347,13 @@ int me_conv_plan_config(int64_t n_tgt, int64_t volume, int64_t n_pairs, int32_t 
   *batch_groups = ME_MAX_BATCH_GROUPS;
   if (n_tgt <= 0 || volume <= 0 || c_src <= 0 || c_dst <= 0) return 0;
   const ConvVariant v = conv_variant(c_src, c_dst);
-  const int waves = v.nc / 16;
-  const int kq = v.kc / 4;
-  const int chunks = (int)ceil_div(c_src, v.kc);
-  const int cus = device_cu_count();
-  // occupancy p of a neighbour offset (centre excluded) -> expected 16-row groups of a (tile, k) item
-  const double p = volume > 1 ? (double)(n_pairs > n_tgt ? n_pairs - n_tgt : 0) / ((double)(volume - 1) * n_tgt)
-                              : 0.0;
-  const int cap = ME_MAX_BATCH_GROUPS;
-  double best_cost = 1e300;
-  // resident workgroups per CU: 3 waves per SIMD by registers (__launch_bounds__(NC * 4, 3)), then the LDS
-  for (int occ = 12 / waves; occ >= 1; --occ) {
-    const int64_t slots = (int64_t)cus * occ;
-    for (int rounds = 1; rounds <= 64; ++rounds) {
-      int64_t t = ceil_div(n_tgt * v.slabs, slots * rounds);
-      if (t < ME_GROUP_ROWS) t = ME_GROUP_ROWS;
-      if (t > ME_MAX_TILE_ROWS) continue;
-      if ((int64_t)conv_lds_bytes(v.nc, v.kc, (int)t, cap) * occ > kLdsBudget) continue;
-      const double m = (double)t * p;  // expected entries of an off-centre item
-      const double g_side = m < 6.0 ? (m <= 0 ? 0.0 : (1.0 - exp(-m)) * (1.0 + m / 16.0)) : m / 16.0 + 0.5;
-      const double groups = (double)ceil_div(t, 16) + (double)(volume - 1) * g_side;
-      const double batches = (double)ceil_div(ceil_div(t, 16), cap) +
-                             (double)(volume - 1) * (m <= 0 ? 0.0 : (m < 3.0 ? 1.0 - exp(-m) : ceil(g_side / cap)));
-      const int64_t items = ceil_div(n_tgt, t) * v.slabs;
-      const double real_rounds = (double)ceil_div(items, slots);
-      // cycles of one tile if its waves had their SIMDs alone: MFMAs (32 cycles each) + per-batch barrier /
-      // pipeline overhead + store / pipeline fill per tile; occ * waves / 4 waves share a SIMD
-      const double tile_cycles = chunks * (groups * kq * 32.0 + batches * 400.0) + (double)t * v.nc * 0.4 + 3000.0;
-      const double cost = real_rounds * tile_cycles * (double)(occ * waves) / 4.0 *
-                          (1.0 + 0.15 * 12.0 / (occ * waves));
-      if (cost < best_cost) {
-        best_cost = cost;
-        *tile_rows = (int32_t)t;
-      }
-      if (t == ME_GROUP_ROWS) break;
-    }
-  }
+  PlanShape s;
+  s.nc = v.nc;
+  s.slabs = v.slabs;
+  s.chunks = (int)ceil_div(c_src, v.kc);
+  s.group_cycles = (v.kc / 4) * 32.0;  // fp32 MFMAs of one 16-row group and chunk
+  s.stage_row_bytes = (v.kc + 4) * 4 + 4;
+  *tile_rows = plan_tile_rows(s, n_tgt, volume, n_pairs);
   return 0;
 }
 

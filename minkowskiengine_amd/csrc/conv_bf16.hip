@@ -276,8 +276,9 @@ struct ConvVariantBf16 {
 
 static ConvVariantBf16 conv_variant_bf16(int c_src, int c_dst) {
   ConvVariantBf16 v;
-  const int rem = c_dst % 64;
-  v.nc = (rem != 0 && rem <= 32) ? 32 : 64;
+  // 64 columns per workgroup whenever there are more than 32: the matrix pipe is nearly idle in bf16, so a
+  // half-empty last slab costs nothing, while every extra slab re-gathers all source rows
+  v.nc = c_dst <= 32 ? 32 : 64;
   v.slabs = (int)ceil_div(c_dst, v.nc);
   v.kc = c_src <= 32 ? 32 : (c_src <= 64 ? 64 : 128);
   return v;
@@ -314,6 +315,23 @@ static int launch_conv_tile_bf16(const __bf16 *src, int c_src, const bf16x8 *wp,
 using namespace me;
 
 extern "C" {
+
+int me_conv_plan_config_bf16(int64_t n_tgt, int64_t volume, int64_t n_pairs, int32_t c_src, int32_t c_dst,
+                             int32_t *tile_rows, int32_t *batch_groups) {
+  ME_CHECK(tile_rows != nullptr && batch_groups != nullptr, "output pointers must not be null");
+  *tile_rows = 128;
+  *batch_groups = ME_MAX_BATCH_GROUPS;
+  if (n_tgt <= 0 || volume <= 0 || c_src <= 0 || c_dst <= 0) return 0;
+  const ConvVariantBf16 v = conv_variant_bf16(c_src, c_dst);
+  PlanShape s;
+  s.nc = v.nc;
+  s.slabs = v.slabs;
+  s.chunks = (int)ceil_div(c_src, v.kc);
+  s.group_cycles = 64.0 + (v.kc / 32) * 24.0;  // LDS-bound: accumulator read-add-write + operand reads
+  s.stage_row_bytes = (v.kc + 8) * 2 + 4;
+  *tile_rows = plan_tile_rows(s, n_tgt, volume, n_pairs);
+  return 0;
+}
 
 int64_t me_conv_packed_weight_elems_bf16(int64_t volume, int32_t c_src, int32_t c_dst) {
   if (volume <= 0 || c_src <= 0 || c_dst <= 0) return 0;

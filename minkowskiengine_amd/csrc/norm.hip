@@ -19,7 +19,7 @@
 
 namespace me {
 
-constexpr int kBnMaxChunks = 1024;
+constexpr int kBnMaxChunks = 512;
 
 template <typename T, int V>
 struct Row {
@@ -111,20 +111,21 @@ __global__ __launch_bounds__(256) void k_bn_partial(const T *__restrict__ x, int
   }
 }
 
-// Combine the chunks of each channel (Chan et al.): block = 32 channels x 8 lanes; lane l takes chunks
-// l, l + 8, ... in order, the 8 lane results are combined in lane order.  Writes mean, rstd (biased
+// Combine the chunks of each channel (Chan et al.): block = 8 channels x 32 lanes; lane l takes chunks
+// l, l + 32, ... in order, the 32 lane results are combined in lane order.  Writes mean, rstd (biased
 // variance + eps) and updates the running statistics (unbiased variance, torch's convention).
 __global__ __launch_bounds__(256) void k_bn_final(const float *__restrict__ part_mean,
                                                  const float *__restrict__ part_m2, int64_t n, int c, int chunks,
                                                  float eps, float momentum, float *__restrict__ mean_out,
                                                  float *__restrict__ rstd_out, float *__restrict__ running_mean,
                                                  float *__restrict__ running_var) {
-  __shared__ float s_n[8][32], s_m[8][32], s_q[8][32];
-  const int ch = blockIdx.x * 32 + (threadIdx.x & 31);
-  const int l = threadIdx.x >> 5;
+  __shared__ float s_n[32][8], s_m[32][8], s_q[32][8];
+  const int cl = threadIdx.x & 7;
+  const int ch = blockIdx.x * 8 + cl;
+  const int l = threadIdx.x >> 3;
   float cn = 0.f, cm = 0.f, cq = 0.f;
   if (ch < c) {
-    for (int g = l; g < chunks; g += 8) {
+    for (int g = l; g < chunks; g += 32) {
       const float bn = (float)(chunk_begin(g + 1, n, chunks) - chunk_begin(g, n, chunks));
       if (bn <= 0.f) continue;
       const float bm = part_mean[(int64_t)g * c + ch], bq = part_m2[(int64_t)g * c + ch];
@@ -134,13 +135,13 @@ __global__ __launch_bounds__(256) void k_bn_final(const float *__restrict__ part
       cn = tot;
     }
   }
-  s_n[l][threadIdx.x & 31] = cn;
-  s_m[l][threadIdx.x & 31] = cm;
-  s_q[l][threadIdx.x & 31] = cq;
+  s_n[l][cl] = cn;
+  s_m[l][cl] = cm;
+  s_q[l][cl] = cq;
   __syncthreads();
   if (l != 0 || ch >= c) return;
-  for (int j = 1; j < 8; ++j) {
-    const float bn = s_n[j][threadIdx.x], bm = s_m[j][threadIdx.x], bq = s_q[j][threadIdx.x];
+  for (int j = 1; j < 32; ++j) {
+    const float bn = s_n[j][cl], bm = s_m[j][cl], bq = s_q[j][cl];
     if (bn <= 0.f) continue;
     const float tot = cn + bn, d = bm - cm;
     cm += d * (bn / tot);
@@ -157,24 +158,40 @@ __global__ __launch_bounds__(256) void k_bn_final(const float *__restrict__ part
   }
 }
 
-// y = x * a[c] + b[c] with a = gamma * rstd, b = beta - mean * a (gamma / beta may be NULL: 1 / 0)
+// y = x * a[c] + b[c] with a = gamma * rstd, b = beta - mean * a (gamma / beta may be NULL: 1 / 0).
+// Same thread layout as k_bn_partial — a thread owns one channel piece, keeps its a / b in registers and walks
+// kBnRowsPerThread rows of the block's row range (no per-element index arithmetic, coalesced rows).
+constexpr int kBnRowsPerThread = 8;
+
 template <typename T, int V>
 __global__ __launch_bounds__(256) void k_bn_apply(const T *__restrict__ x, int64_t n, int c,
                                                  const float *__restrict__ mean, const float *__restrict__ rstd,
                                                  const float *__restrict__ gamma, const float *__restrict__ beta,
                                                  T *__restrict__ y) {
   const int P = c / V;
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= n * P) return;
-  const int ch = (int)(idx % P) * V;
-  Row<T, V> t = load_row<T, V>(x + idx * V);
+  const int W = min(P, (int)blockDim.x);
+  const int R = max(1, (int)blockDim.x / P);
+  const int rl = (int)threadIdx.x / W;
+  const int64_t r0 = (int64_t)blockIdx.x * R * kBnRowsPerThread;
+  if (rl >= R) return;
+  for (int p = (int)threadIdx.x % W; p < P; p += W) {
+    float a[V], b[V];
 #pragma unroll
-  for (int j = 0; j < V; ++j) {
-    const float a = (gamma ? gamma[ch + j] : 1.f) * rstd[ch + j];
-    const float b = (beta ? beta[ch + j] : 0.f) - mean[ch + j] * a;
-    t.v[j] = t.v[j] * a + b;
+    for (int j = 0; j < V; ++j) {
+      a[j] = (gamma ? gamma[p * V + j] : 1.f) * rstd[p * V + j];
+      b[j] = (beta ? beta[p * V + j] : 0.f) - mean[p * V + j] * a[j];
+    }
+#pragma unroll
+    for (int i = 0; i < kBnRowsPerThread; ++i) {
+      const int64_t r = r0 + rl + (int64_t)i * R;
+      if (r < n) {
+        Row<T, V> t = load_row<T, V>(x + r * c + p * V);
+#pragma unroll
+        for (int j = 0; j < V; ++j) t.v[j] = t.v[j] * a[j] + b[j];
+        store_row<T, V>(y + r * c + p * V, t);
+      }
+    }
   }
-  store_row<T, V>(y + idx * V, t);
 }
 
 // per chunk and channel: sum dy and sum dy * xhat (xhat = (x - mean) * rstd); same layout as k_bn_partial
@@ -235,32 +252,35 @@ __global__ __launch_bounds__(256) void k_bn_bwd_partial(const T *__restrict__ x,
 }
 
 // sums of the chunks per channel in a fixed order: grad_beta = sum dy, grad_gamma = sum dy * xhat
+// (block = 8 channels x 32 lanes, as k_bn_final)
 __global__ __launch_bounds__(256) void k_bn_bwd_final(const float *__restrict__ part_dy,
                                                      const float *__restrict__ part_dyx, int c, int chunks,
                                                      float *__restrict__ sum_dy, float *__restrict__ sum_dyx) {
-  __shared__ float s_a[8][32], s_b[8][32];
-  const int ch = blockIdx.x * 32 + (threadIdx.x & 31);
-  const int l = threadIdx.x >> 5;
+  __shared__ float s_a[32][8], s_b[32][8];
+  const int cl = threadIdx.x & 7;
+  const int ch = blockIdx.x * 8 + cl;
+  const int l = threadIdx.x >> 3;
   float a = 0.f, b = 0.f;
   if (ch < c) {
-    for (int g = l; g < chunks; g += 8) {
+    for (int g = l; g < chunks; g += 32) {
       a += part_dy[(int64_t)g * c + ch];
       b += part_dyx[(int64_t)g * c + ch];
     }
   }
-  s_a[l][threadIdx.x & 31] = a;
-  s_b[l][threadIdx.x & 31] = b;
+  s_a[l][cl] = a;
+  s_b[l][cl] = b;
   __syncthreads();
   if (l != 0 || ch >= c) return;
-  for (int j = 1; j < 8; ++j) {
-    a += s_a[j][threadIdx.x];
-    b += s_b[j][threadIdx.x];
+  for (int j = 1; j < 32; ++j) {
+    a += s_a[j][cl];
+    b += s_b[j][cl];
   }
   sum_dy[ch] = a;
   sum_dyx[ch] = b;
 }
 
-// dx = gamma * rstd * (dy - sum_dy / n - xhat * sum_dyx / n)
+// dx = gamma * rstd * (dy - sum_dy / n - xhat * sum_dyx / n) = dy * ca + x * cb + cc per channel
+// (thread layout of k_bn_apply)
 template <typename T, int V>
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T *__restrict__ x, const T *__restrict__ dy,
                                                      int64_t n, int c, const float *__restrict__ mean,
@@ -269,21 +289,37 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T *__restrict__ x, c
                                                      const float *__restrict__ sum_dy,
                                                      const float *__restrict__ sum_dyx, T *__restrict__ dx) {
   const int P = c / V;
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= n * P) return;
-  const int ch = (int)(idx % P) * V;
-  const Row<T, V> tx = load_row<T, V>(x + idx * V);
-  const Row<T, V> tg = load_row<T, V>(dy + idx * V);
-  Row<T, V> out;
+  const int W = min(P, (int)blockDim.x);
+  const int R = max(1, (int)blockDim.x / P);
+  const int rl = (int)threadIdx.x / W;
+  const int64_t r0 = (int64_t)blockIdx.x * R * kBnRowsPerThread;
+  if (rl >= R) return;
   const float inv_n = 1.f / (float)n;
+  for (int p = (int)threadIdx.x % W; p < P; p += W) {
+    float ca[V], cb[V], cc[V];
 #pragma unroll
-  for (int j = 0; j < V; ++j) {
-    const float rs = rstd[ch + j];
-    const float xh = (tx.v[j] - mean[ch + j]) * rs;
-    const float a = (gamma ? gamma[ch + j] : 1.f) * rs;
-    out.v[j] = a * (tg.v[j] - sum_dy[ch + j] * inv_n - xh * (sum_dyx[ch + j] * inv_n));
+    for (int j = 0; j < V; ++j) {
+      const int ch = p * V + j;
+      const float rs = rstd[ch];
+      const float a = (gamma ? gamma[ch] : 1.f) * rs;
+      const float k = sum_dyx[ch] * inv_n * rs;   // xhat * sum_dyx / n = (x - mean) * k
+      ca[j] = a;
+      cb[j] = -a * k;
+      cc[j] = a * (mean[ch] * k - sum_dy[ch] * inv_n);
+    }
+#pragma unroll
+    for (int i = 0; i < kBnRowsPerThread; ++i) {
+      const int64_t r = r0 + rl + (int64_t)i * R;
+      if (r < n) {
+        const Row<T, V> tx = load_row<T, V>(x + r * c + p * V);
+        const Row<T, V> tg = load_row<T, V>(dy + r * c + p * V);
+        Row<T, V> out;
+#pragma unroll
+        for (int j = 0; j < V; ++j) out.v[j] = tg.v[j] * ca[j] + tx.v[j] * cb[j] + cc[j];
+        store_row<T, V>(dx + r * c + p * V, out);
+      }
+    }
   }
-  store_row<T, V>(dx + idx * V, out);
 }
 
 static int bn_chunks(int64_t n) {
@@ -305,7 +341,7 @@ static int bn_stats(const T *x, int64_t n, int c, float eps, float momentum, flo
   ME_CHECK(lds <= 64 * 1024, "channel count too large for the batch-norm kernels");
   if (vec) hipLaunchKernelGGL((k_bn_partial<T, 4>), dim3(chunks), dim3(256), lds, stream, x, n, c, chunks, pm, pq);
   else hipLaunchKernelGGL((k_bn_partial<T, 1>), dim3(chunks), dim3(256), lds, stream, x, n, c, chunks, pm, pq);
-  hipLaunchKernelGGL(k_bn_final, dim3((unsigned)ceil_div(c, 32)), dim3(256), 0, stream, pm, pq, n, c, chunks, eps,
+  hipLaunchKernelGGL(k_bn_final, dim3((unsigned)ceil_div(c, 8)), dim3(256), 0, stream, pm, pq, n, c, chunks, eps,
                      momentum, mean, rstd, running_mean, running_var);
   ME_LAUNCH_CHECK();
   return 0;
@@ -314,10 +350,13 @@ static int bn_stats(const T *x, int64_t n, int c, float eps, float momentum, flo
 template <typename T>
 static int bn_apply(const T *x, int64_t n, int c, const float *mean, const float *rstd, const float *gamma,
                     const float *beta, T *y, hipStream_t stream) {
-  const bool vec = (c % 4) == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0;
-  const int64_t total = n * (vec ? c / 4 : c);
-  const dim3 grid((unsigned)ceil_div(total, 256));
-  if (vec) hipLaunchKernelGGL((k_bn_apply<T, 4>), grid, dim3(256), 0, stream, x, n, c, mean, rstd, gamma, beta, y);
+  constexpr int W = 16 / (int)sizeof(T);  // channels per 16-byte access
+  const bool aligned = (uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0;
+  const int v = (aligned && c % W == 0) ? W : ((aligned && c % 4 == 0) ? 4 : 1);
+  const int pieces = c / v;
+  const dim3 grid((unsigned)ceil_div(n, (int64_t)(pieces >= 256 ? 1 : 256 / pieces) * kBnRowsPerThread));
+  if (v == W) hipLaunchKernelGGL((k_bn_apply<T, W>), grid, dim3(256), 0, stream, x, n, c, mean, rstd, gamma, beta, y);
+  else if (v == 4) hipLaunchKernelGGL((k_bn_apply<T, 4>), grid, dim3(256), 0, stream, x, n, c, mean, rstd, gamma, beta, y);
   else hipLaunchKernelGGL((k_bn_apply<T, 1>), grid, dim3(256), 0, stream, x, n, c, mean, rstd, gamma, beta, y);
   ME_LAUNCH_CHECK();
   return 0;
@@ -340,11 +379,16 @@ static int bn_backward(const T *x, const T *dy, int64_t n, int c, const float *m
   else
     hipLaunchKernelGGL((k_bn_bwd_partial<T, 1>), dim3(chunks), dim3(256), lds, stream, x, dy, n, c, chunks, mean, rstd,
                        pa, pb);
-  hipLaunchKernelGGL(k_bn_bwd_final, dim3((unsigned)ceil_div(c, 32)), dim3(256), 0, stream, pa, pb, c, chunks,
+  hipLaunchKernelGGL(k_bn_bwd_final, dim3((unsigned)ceil_div(c, 8)), dim3(256), 0, stream, pa, pb, c, chunks,
                      grad_beta, grad_gamma);
-  const int64_t total = n * (vec ? c / 4 : c);
-  const dim3 grid((unsigned)ceil_div(total, 256));
-  if (vec)
+  constexpr int W = 16 / (int)sizeof(T);
+  const int v = (vec && c % W == 0) ? W : (vec ? 4 : 1);
+  const int pieces = c / v;
+  const dim3 grid((unsigned)ceil_div(n, (int64_t)(pieces >= 256 ? 1 : 256 / pieces) * kBnRowsPerThread));
+  if (v == W)
+    hipLaunchKernelGGL((k_bn_bwd_apply<T, W>), grid, dim3(256), 0, stream, x, dy, n, c, mean, rstd, gamma, grad_beta,
+                       grad_gamma, dx);
+  else if (v == 4)
     hipLaunchKernelGGL((k_bn_bwd_apply<T, 4>), grid, dim3(256), 0, stream, x, dy, n, c, mean, rstd, gamma, grad_beta,
                        grad_gamma, dx);
   else
