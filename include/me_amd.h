@@ -187,6 +187,9 @@ int me_conv_plan_config(int64_t n_tgt, int64_t volume, int64_t n_pairs, int32_t 
 
 /* Tuning / ablation switch for me_conv_target_f32 (0 = shipped configuration; see conv.hip). */
 void me_debug_set_conv_variant(int variant);
+/* Phase cycle counters of the instrumented build (variant 256): barrier A, stage write + wait, barrier B, load
+ * issue, multiply, prologue, epilogue (s_memtime cycles summed over wave 0 of every workgroup), batches. */
+int me_debug_conv_timing(uint64_t *out8, int32_t reset);
 /* wt[k, j, i] = w[k, i, j] */
 int me_transpose_kernel_f32(const float *w_dev, int64_t volume, int32_t c_in, int32_t c_out,
                             float *wt_dev, void *stream);

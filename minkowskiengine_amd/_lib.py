@@ -62,6 +62,7 @@ SIGNATURES = {
                                           c_vp, c_i64, c_i32, c_i32, c_vp]),
     "me_conv_plan_config": (ctypes.c_int, [c_i64, c_i64, c_i64, c_i32, c_i32, _P_I32, _P_I32]),
     "me_debug_set_conv_variant": (None, [ctypes.c_int]),
+    "me_debug_conv_timing": (ctypes.c_int, [c_vp, c_i32]),
     "me_transpose_kernel_f32": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
     "me_conv_wgrad_workspace_bytes": (c_i64, [_P_I64, c_i64, c_i32, c_i32]),
     "me_conv_wgrad_f32": (ctypes.c_int, [c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, _P_I64, c_vp, c_i64, c_vp,
