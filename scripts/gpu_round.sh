@@ -22,7 +22,13 @@ echo "== bench"
 timeout 600 python bench.py --steps 50 --warmup 10 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"
 cat $OUT/bench.json; tail -3 $OUT/bench.err
 timeout 300 python bench.py --steps 50 --warmup 10 --extent 215 --cpu-budget 5 > $OUT/bench_sparse.json 2> $OUT/bench_sparse.err
-cat $OUT/bench_sparse.json
+cut -c1-400 $OUT/bench_sparse.json
+timeout 300 python bench.py --steps 50 --warmup 10 --dtype bf16 --cpu-budget 0 > $OUT/bench_bf16.json 2> $OUT/bench_bf16.err
+cut -c1-400 $OUT/bench_bf16.json
+for dt in f32 bf16; do
+  timeout 400 python bench.py --workload conv4d --steps 30 --warmup 5 --dtype $dt --cpu-budget 5 > $OUT/bench_conv4d_$dt.json 2> $OUT/bench_conv4d_$dt.err
+  cut -c1-300 $OUT/bench_conv4d_$dt.json; echo
+done
 echo "== rocprofv3"
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python $OLDPWD/bench.py --steps 20 --warmup 5 --cpu-budget 0 > $OUT/prof.log 2>&1; echo "rocprof rc=$?"
