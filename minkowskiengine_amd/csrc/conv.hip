@@ -161,12 +161,17 @@ __global__ __launch_bounds__(256) void k_pack_weights(const float *__restrict__ 
 // After the last batch every target row is written exactly once with coalesced 16-byte stores (rows
 // without entries get zeros: no zero-fill pass, no global atomics).
 // VAR bits (timing ablations only; 0 is the shipped configuration): 16: no gather traffic (constant rows);
-// 32: no MFMA operand reads from LDS; 64: no read-add-write of the LDS accumulator; 128: no stage writes
+// 2: no per-batch weight loads; 32: no MFMA operand reads from LDS (INVALID: hipcc folds the MFMAs);
+// 64: no read-add-write of the LDS accumulator; 128: no stage writes; 256: s_memtime phase counters;
+// 512: two stage buffers, one barrier per batch; 1024 + n: stagger; 2048 + n: n KiB of LDS padding
 // EXACT: c_src is a multiple of KC (and of 4): the gather needs no channel guards.
 // phase cycle counters of the VAR & 256 instrumentation build (summed over wave 0 of every workgroup):
 // 0 barrier A, 1 stage write (incl. the wait for the gathered rows), 2 barrier B, 3 load issue, 4 multiply,
 // 5 prologue (accumulator clear + first loads), 6 epilogue, 7 batches
 __device__ unsigned long long d_conv_timing[8];
+// VAR & 1024 (experiment): the workgroup that sits in the odd wave slot of its SIMDs sleeps d_conv_stagger x 64
+// cycles before it starts, so that the two co-resident workgroups of a CU do not run their phases in lockstep
+__device__ int d_conv_stagger;
 
 template <int NC, int KC, bool EXACT, int VAR>
 __global__ __launch_bounds__(NC * 4, 3) void k_conv_tile_f32(
@@ -211,6 +216,14 @@ __global__ __launch_bounds__(NC * 4, 3) void k_conv_tile_f32(
 #pragma unroll
   for (int s4 = 0; s4 < KQ / 4; ++s4) pofs[s4] = ((4 * s4 + q) ^ stage_swz(KC, i16)) * 4;
 
+  if (VAR & 1024) {
+    // HW_REG_HW_ID (id 4), bits [3:0] = wave slot within the SIMD
+    const unsigned slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11));
+    if (slot & 1u) {
+      const int n = d_conv_stagger;
+      for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
+    }
+  }
   unsigned long long tm[7] = {0, 0, 0, 0, 0, 0, 0};
   unsigned long long t_prev = (VAR & 256) ? __builtin_amdgcn_s_memtime() : 0ull;
   auto tick = [&](int slot) {
@@ -306,7 +319,10 @@ __global__ __launch_bounds__(NC * 4, 3) void k_conv_tile_f32(
     }
     if (tid < cap_rows) s_dst[buf * cap_rows + tid] = dstv;
   };
+  bool w_loaded = false;
   auto load_w = [&](int chunk, int k) {
+    if ((VAR & 2) && w_loaded) return;  // ablation: the weights of the first batch are reused
+    w_loaded = true;
     const f32x4 *p = wp + ((((int64_t)k * nchunks + chunk) * ncb + cb) * (KQ / 4)) * 64 + lane;
 #pragma unroll
     for (int v = 0; v < KQ / 4; ++v) {
@@ -1281,8 +1297,10 @@ static int launch_conv_tile(const float *src, int c_src, const float *wp, int c_
                             const int32_t *plan_src, const int32_t *plan_dst, const int32_t *batch_desc,
                             const int32_t *tile_bptr, const int32_t *order, float *dst, int64_t n_tgt,
                             int tile_rows, int batch_groups, hipStream_t stream) {
+  // variants 2048 + n (experiment): n KiB of unused LDS, to cap the resident workgroups per CU
   const int lds = conv_lds_bytes(NC, KC, tile_rows, batch_groups) +
-                  ((VAR & 512) ? batch_groups * 16 * (stage_ld(KC) * 4 + 4) : 0);
+                  ((VAR & 512) ? batch_groups * 16 * (stage_ld(KC) * 4 + 4) : 0) +
+                  (g_conv_variant >= 2048 ? (g_conv_variant - 2048) * 1024 : 0);
   ME_CHECK(lds <= kLdsBudget, "tile_rows / batch_groups too large for the LDS of one workgroup");
   const bool exact = (c_src % KC) == 0;
   static bool attr_set[2] = {false, false};  // per instantiation
@@ -1505,9 +1523,17 @@ int me_conv_target_f32(const float *src, int64_t n_src, int32_t c_src, const flo
 #define ME_CONV_ARGS                                                                                         \
   src, c_src, wp, c_dst, v.slabs, plan_src, plan_dst, batch_desc, tile_bptr, order, dst, n_tgt, tile_rows, \
       batch_groups, stream
+  if (g_conv_variant >= 1024 && g_conv_variant < 2048 && v.nc == 64 && v.kc == 64)
+    return launch_conv_tile<64, 64, 1024>(ME_CONV_ARGS);
+  if (g_conv_variant >= 2048 && v.nc == 64 && v.kc == 64) return launch_conv_tile<64, 64, 0>(ME_CONV_ARGS);
   if (g_conv_variant != 0 && v.nc == 64 && v.kc == 64) {  // ablation builds exist for the headline shape only
     switch (g_conv_variant) {
       case 16: return launch_conv_tile<64, 64, 16>(ME_CONV_ARGS);
+      case 18: return launch_conv_tile<64, 64, 18>(ME_CONV_ARGS);
+      case 144: return launch_conv_tile<64, 64, 144>(ME_CONV_ARGS);
+      case 146: return launch_conv_tile<64, 64, 146>(ME_CONV_ARGS);
+      case 210: return launch_conv_tile<64, 64, 210>(ME_CONV_ARGS);
+      case 80: return launch_conv_tile<64, 64, 80>(ME_CONV_ARGS);
       case 256: return launch_conv_tile<64, 64, 256>(ME_CONV_ARGS);
       case 512: return launch_conv_tile<64, 64, 512>(ME_CONV_ARGS);
       case 528: return launch_conv_tile<64, 64, 528>(ME_CONV_ARGS);
@@ -1534,7 +1560,13 @@ int me_conv_target_f32(const float *src, int64_t n_src, int32_t c_src, const flo
 #undef ME_CONV_ARGS
 }
 
-void me_debug_set_conv_variant(int variant) { g_conv_variant = variant; }
+void me_debug_set_conv_variant(int variant) {
+  g_conv_variant = variant;
+  if (variant >= 1024 && variant < 2048) {  // stagger experiment: 1024 + sleep units of 64 cycles
+    const int units = variant - 1024;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(d_conv_stagger), &units, sizeof(units));
+  }
+}
 
 int me_debug_conv_timing(uint64_t *out8, int32_t reset) {
   unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
