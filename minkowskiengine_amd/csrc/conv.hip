@@ -393,14 +393,14 @@ __global__ __launch_bounds__(NC * 4, 3) void k_conv_tile_f32(
       }
     } else
     for (int it = 0; it < n_it; ++it) {
-      __syncthreads();  // everybody is done reading the previous batch from s_a / s_dst
+      if (!(VAR & 4)) __syncthreads();  // everybody is done reading the previous batch from s_a / s_dst
       tick(0);
       write_stage(chA);  // rows of batch it (gathered during the previous iteration)
 #pragma unroll
       for (int sx = 0; sx < KQ; ++sx) wreg[sx] = wnxt[sx];  // its weights were requested before its rows
       if (VAR & 256) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       tick(1);
-      __syncthreads();
+      if (!(VAR & 4)) __syncthreads();  // (VAR & 4: timing-only ablation without barriers; results are garbage)
       tick(2);
       // next batch: its weights, its rows, and the indices of the one after
       load_w(chB, kB);
@@ -1533,6 +1533,9 @@ int me_conv_target_f32(const float *src, int64_t n_src, int32_t c_src, const flo
       case 144: return launch_conv_tile<64, 64, 144>(ME_CONV_ARGS);
       case 146: return launch_conv_tile<64, 64, 146>(ME_CONV_ARGS);
       case 210: return launch_conv_tile<64, 64, 210>(ME_CONV_ARGS);
+      case 214: return launch_conv_tile<64, 64, 214>(ME_CONV_ARGS);
+      case 20: return launch_conv_tile<64, 64, 20>(ME_CONV_ARGS);
+      case 4: return launch_conv_tile<64, 64, 4>(ME_CONV_ARGS);
       case 80: return launch_conv_tile<64, 64, 80>(ME_CONV_ARGS);
       case 256: return launch_conv_tile<64, 64, 256>(ME_CONV_ARGS);
       case 512: return launch_conv_tile<64, 64, 512>(ME_CONV_ARGS);
