@@ -3,6 +3,7 @@
 `Convolution{Forward,Backward}GPU` in the backend by name, exactly as the reference does through
 get_minkowski_function (MinkowskiCommon.py:110-120)."""
 import math
+import os
 
 import torch
 from torch.autograd import Function
@@ -12,6 +13,9 @@ from .backend import ConvolutionMode, CoordinateMapKey, RegionType
 from .common import get_minkowski_function
 from .kernel_generator import KernelGenerator
 from .sparse_tensor import SparseTensor, _get_coordinate_map_key
+
+
+_MM_AS_CONV = os.environ.get("ME_AMD_MM_AS_CONV", "1") != "0"   # 1x1 convolutions on the conv kernels
 
 
 class MinkowskiConvolutionFunction(Function):
@@ -109,9 +113,18 @@ class MinkowskiConvolutionBase(MinkowskiModuleBase):
         assert isinstance(input, SparseTensor)
         assert input.D == self.dimension
         if self.use_mm:
+            # kernel volume 1, stride 1: out = F @ W on the same coordinate map (MinkowskiConvolution.py:304-308).
             out_coordinate_map_key = input.coordinate_map_key
-            # bf16 features with fp32 master weights: the product runs in the feature dtype
-            outfeat = input.F.mm(self.kernel if self.kernel.dtype == input.F.dtype else self.kernel.to(input.F.dtype))
+            if _MM_AS_CONV and not self.is_transpose and input.F.is_cuda and input.F.shape[0] > 0:
+                # run it as a one-offset convolution on this package's kernels: rocBLAS / hipBLASLt pick slow
+                # kernels for the skinny products of a segmentation head (200k x 96 @ 96 x 20 took 325 us)
+                outfeat = self.conv.apply(input.F, self.kernel.unsqueeze(0), self.kernel_generator,
+                                          self.convolution_mode, input.coordinate_map_key, out_coordinate_map_key,
+                                          input._manager)
+            else:
+                # bf16 features with fp32 master weights: the product runs in the feature dtype
+                outfeat = input.F.mm(self.kernel if self.kernel.dtype == input.F.dtype
+                                     else self.kernel.to(input.F.dtype))
         else:
             # (the reference passes expand_coordinates positionally into the tensor_stride slot,
             # MinkowskiConvolution.py:311-313; passed by keyword here)

@@ -174,7 +174,7 @@ __device__ unsigned long long d_conv_timing[8];
 __device__ int d_conv_stagger;
 
 template <int NC, int KC, bool EXACT, int VAR>
-__global__ __launch_bounds__(NC * 4, 3) void k_conv_tile_f32(
+__global__ __launch_bounds__(NC * 4, (NC == 128 ? 2 : 3)) void k_conv_tile_f32(
     const float *__restrict__ src, int c_src, const f32x4 *__restrict__ wp, int c_dst,
     const int32_t *__restrict__ plan_src, const int32_t *__restrict__ plan_dst,
     const int32_t *__restrict__ batch_desc, const int32_t *__restrict__ tile_bptr,
@@ -1526,26 +1526,20 @@ int me_conv_target_f32(const float *src, int64_t n_src, int32_t c_src, const flo
   if (g_conv_variant >= 1024 && g_conv_variant < 2048 && v.nc == 64 && v.kc == 64)
     return launch_conv_tile<64, 64, 1024>(ME_CONV_ARGS);
   if (g_conv_variant >= 2048 && v.nc == 64 && v.kc == 64) return launch_conv_tile<64, 64, 0>(ME_CONV_ARGS);
+  if (g_conv_variant == 1000 && v.kc == 64 && c_dst >= 128 && c_dst % 128 == 0)  // experiment: 128-column workgroups
+    return launch_conv_tile<128, 64, 0>(src, c_src, wp, c_dst, c_dst / 128, plan_src, plan_dst, batch_desc, tile_bptr,
+                                        order, dst, n_tgt, tile_rows, batch_groups, stream);
   if (g_conv_variant != 0 && v.nc == 64 && v.kc == 64) {  // ablation builds exist for the headline shape only
     switch (g_conv_variant) {
       case 16: return launch_conv_tile<64, 64, 16>(ME_CONV_ARGS);
       case 18: return launch_conv_tile<64, 64, 18>(ME_CONV_ARGS);
-      case 144: return launch_conv_tile<64, 64, 144>(ME_CONV_ARGS);
-      case 146: return launch_conv_tile<64, 64, 146>(ME_CONV_ARGS);
       case 210: return launch_conv_tile<64, 64, 210>(ME_CONV_ARGS);
       case 214: return launch_conv_tile<64, 64, 214>(ME_CONV_ARGS);
-      case 20: return launch_conv_tile<64, 64, 20>(ME_CONV_ARGS);
       case 4: return launch_conv_tile<64, 64, 4>(ME_CONV_ARGS);
       case 80: return launch_conv_tile<64, 64, 80>(ME_CONV_ARGS);
       case 256: return launch_conv_tile<64, 64, 256>(ME_CONV_ARGS);
       case 512: return launch_conv_tile<64, 64, 512>(ME_CONV_ARGS);
-      case 528: return launch_conv_tile<64, 64, 528>(ME_CONV_ARGS);
       case 272: return launch_conv_tile<64, 64, 272>(ME_CONV_ARGS);
-      case 32: return launch_conv_tile<64, 64, 32>(ME_CONV_ARGS);
-      case 48: return launch_conv_tile<64, 64, 48>(ME_CONV_ARGS);
-      case 64: return launch_conv_tile<64, 64, 64>(ME_CONV_ARGS);
-      case 112: return launch_conv_tile<64, 64, 112>(ME_CONV_ARGS);
-      case 240: return launch_conv_tile<64, 64, 240>(ME_CONV_ARGS);
       default: break;
     }
   }
