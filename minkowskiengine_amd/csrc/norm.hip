@@ -75,6 +75,7 @@ __global__ __launch_bounds__(256) void k_bn_partial(const T *__restrict__ x, int
       const Row<T, V> k = load_row<T, V>(x + r0 * c + p * V);
 #pragma unroll
       for (int j = 0; j < V; ++j) shift[j] = k.v[j];
+#pragma unroll 4
       for (int64_t r = r0 + rl; r < r1; r += R) {
         const Row<T, V> t = load_row<T, V>(x + r * c + p * V);
 #pragma unroll
@@ -111,43 +112,38 @@ __global__ __launch_bounds__(256) void k_bn_partial(const T *__restrict__ x, int
   }
 }
 
-// Combine the chunks of each channel (Chan et al.): block = 8 channels x 32 lanes; lane l takes chunks
-// l, l + 32, ... in order, the 32 lane results are combined in lane order.  Writes mean, rstd (biased
-// variance + eps) and updates the running statistics (unbiased variance, torch's convention).
-__global__ __launch_bounds__(256) void k_bn_final(const float *__restrict__ part_mean,
-                                                 const float *__restrict__ part_m2, int64_t n, int c, int chunks,
-                                                 float eps, float momentum, float *__restrict__ mean_out,
-                                                 float *__restrict__ rstd_out, float *__restrict__ running_mean,
-                                                 float *__restrict__ running_var) {
-  __shared__ float s_n[32][8], s_m[32][8], s_q[32][8];
-  const int cl = threadIdx.x & 7;
-  const int ch = blockIdx.x * 8 + cl;
-  const int l = threadIdx.x >> 3;
-  float cn = 0.f, cm = 0.f, cq = 0.f;
-  if (ch < c) {
-    for (int g = l; g < chunks; g += 32) {
-      const float bn = (float)(chunk_begin(g + 1, n, chunks) - chunk_begin(g, n, chunks));
-      if (bn <= 0.f) continue;
-      const float bm = part_mean[(int64_t)g * c + ch], bq = part_m2[(int64_t)g * c + ch];
-      const float tot = cn + bn, d = bm - cm;
-      cm += d * (bn / tot);
-      cq += bq + d * d * (cn * bn / tot);
-      cn = tot;
-    }
-  }
-  s_n[l][cl] = cn;
-  s_m[l][cl] = cm;
-  s_q[l][cl] = cq;
-  __syncthreads();
-  if (l != 0 || ch >= c) return;
-  for (int j = 1; j < 32; ++j) {
-    const float bn = s_n[j][cl], bm = s_m[j][cl], bq = s_q[j][cl];
-    if (bn <= 0.f) continue;
+// Combine the chunks of each channel (Chan et al.): ONE WAVE per channel (4 channels per block); lane l merges
+// chunks l, l + 64, ... in order, then the 64 lane results are merged in a fixed shuffle tree (the formula is
+// associative, the tree is the same every run: bitwise reproducible).  Writes mean, rstd (biased variance +
+// eps) and updates the running statistics (unbiased variance, torch's convention).
+__device__ __forceinline__ void chan_merge(float &cn, float &cm, float &cq, float bn, float bm, float bq) {
+  if (bn > 0.f) {
     const float tot = cn + bn, d = bm - cm;
     cm += d * (bn / tot);
     cq += bq + d * d * (cn * bn / tot);
     cn = tot;
   }
+}
+
+__global__ __launch_bounds__(256) void k_bn_final(const float *__restrict__ part_mean,
+                                                 const float *__restrict__ part_m2, int64_t n, int c, int chunks,
+                                                 float eps, float momentum, float *__restrict__ mean_out,
+                                                 float *__restrict__ rstd_out, float *__restrict__ running_mean,
+                                                 float *__restrict__ running_var) {
+  const int lane = threadIdx.x & 63;
+  const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ch >= c) return;  // whole wave
+  float cn = 0.f, cm = 0.f, cq = 0.f;
+  for (int g = lane; g < chunks; g += 64) {
+    const float bn = (float)(chunk_begin(g + 1, n, chunks) - chunk_begin(g, n, chunks));
+    chan_merge(cn, cm, cq, bn, part_mean[(int64_t)g * c + ch], part_m2[(int64_t)g * c + ch]);
+  }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {  // lane l absorbs lane l + off: chunk order is preserved
+    const float bn = __shfl_down(cn, off, 64), bm = __shfl_down(cm, off, 64), bq = __shfl_down(cq, off, 64);
+    if ((lane & (2 * off - 1)) == 0) chan_merge(cn, cm, cq, bn, bm, bq);
+  }
+  if (lane != 0) return;
   const float var = cn > 0.f ? cq / cn : 0.f;
   mean_out[ch] = cm;
   rstd_out[ch] = rsqrtf(var + eps);
@@ -219,6 +215,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_partial(const T *__restrict__ x,
         m[j] = mean[p * V + j];
         rs[j] = rstd[p * V + j];
       }
+#pragma unroll 4
       for (int64_t r = r0 + rl; r < r1; r += R) {
         const Row<T, V> tx = load_row<T, V>(x + r * c + p * V);
         const Row<T, V> tg = load_row<T, V>(dy + r * c + p * V);
@@ -252,31 +249,30 @@ __global__ __launch_bounds__(256) void k_bn_bwd_partial(const T *__restrict__ x,
 }
 
 // sums of the chunks per channel in a fixed order: grad_beta = sum dy, grad_gamma = sum dy * xhat
-// (block = 8 channels x 32 lanes, as k_bn_final)
+// (one wave per channel and a fixed shuffle tree, as k_bn_final)
 __global__ __launch_bounds__(256) void k_bn_bwd_final(const float *__restrict__ part_dy,
                                                      const float *__restrict__ part_dyx, int c, int chunks,
                                                      float *__restrict__ sum_dy, float *__restrict__ sum_dyx) {
-  __shared__ float s_a[32][8], s_b[32][8];
-  const int cl = threadIdx.x & 7;
-  const int ch = blockIdx.x * 8 + cl;
-  const int l = threadIdx.x >> 3;
+  const int lane = threadIdx.x & 63;
+  const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ch >= c) return;  // whole wave
   float a = 0.f, b = 0.f;
-  if (ch < c) {
-    for (int g = l; g < chunks; g += 32) {
-      a += part_dy[(int64_t)g * c + ch];
-      b += part_dyx[(int64_t)g * c + ch];
+  for (int g = lane; g < chunks; g += 64) {
+    a += part_dy[(int64_t)g * c + ch];
+    b += part_dyx[(int64_t)g * c + ch];
+  }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const float ta = __shfl_down(a, off, 64), tb = __shfl_down(b, off, 64);
+    if ((lane & (2 * off - 1)) == 0) {
+      a += ta;
+      b += tb;
     }
   }
-  s_a[l][cl] = a;
-  s_b[l][cl] = b;
-  __syncthreads();
-  if (l != 0 || ch >= c) return;
-  for (int j = 1; j < 32; ++j) {
-    a += s_a[j][cl];
-    b += s_b[j][cl];
+  if (lane == 0) {
+    sum_dy[ch] = a;
+    sum_dyx[ch] = b;
   }
-  sum_dy[ch] = a;
-  sum_dyx[ch] = b;
 }
 
 // dx = gamma * rstd * (dy - sum_dy / n - xhat * sum_dyx / n) = dy * ca + x * cb + cc per channel
@@ -334,14 +330,17 @@ static int bn_stats(const T *x, int64_t n, int c, float eps, float momentum, flo
                     float *running_mean, float *running_var, float *ws, hipStream_t stream) {
   const int chunks = bn_chunks(n);
   float *pm = ws, *pq = ws + (int64_t)chunks * c;
-  const bool vec = (c % 4) == 0 && (uintptr_t)x % 16 == 0;
-  const int P = vec ? c / 4 : c;
+  constexpr int W = 16 / (int)sizeof(T);  // channels per 16-byte access
+  const bool aligned = (uintptr_t)x % 16 == 0;
+  const int v = (aligned && c % W == 0) ? W : ((aligned && c % 4 == 0) ? 4 : 1);
+  const int P = c / v;
   const int R = P >= 256 ? 1 : 256 / P;
   const size_t lds = (size_t)R * 2 * c * sizeof(float);
   ME_CHECK(lds <= 64 * 1024, "channel count too large for the batch-norm kernels");
-  if (vec) hipLaunchKernelGGL((k_bn_partial<T, 4>), dim3(chunks), dim3(256), lds, stream, x, n, c, chunks, pm, pq);
+  if (v == W) hipLaunchKernelGGL((k_bn_partial<T, W>), dim3(chunks), dim3(256), lds, stream, x, n, c, chunks, pm, pq);
+  else if (v == 4) hipLaunchKernelGGL((k_bn_partial<T, 4>), dim3(chunks), dim3(256), lds, stream, x, n, c, chunks, pm, pq);
   else hipLaunchKernelGGL((k_bn_partial<T, 1>), dim3(chunks), dim3(256), lds, stream, x, n, c, chunks, pm, pq);
-  hipLaunchKernelGGL(k_bn_final, dim3((unsigned)ceil_div(c, 8)), dim3(256), 0, stream, pm, pq, n, c, chunks, eps,
+  hipLaunchKernelGGL(k_bn_final, dim3((unsigned)ceil_div(c, 4)), dim3(256), 0, stream, pm, pq, n, c, chunks, eps,
                      momentum, mean, rstd, running_mean, running_var);
   ME_LAUNCH_CHECK();
   return 0;
@@ -368,21 +367,24 @@ static int bn_backward(const T *x, const T *dy, int64_t n, int c, const float *m
                        hipStream_t stream) {
   const int chunks = bn_chunks(n);
   float *pa = ws, *pb = ws + (int64_t)chunks * c;
+  constexpr int W = 16 / (int)sizeof(T);
   const bool vec = (c % 4) == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)dy % 16 == 0 && (uintptr_t)dx % 16 == 0;
-  const int P = vec ? c / 4 : c;
+  const int v = (vec && c % W == 0) ? W : (vec ? 4 : 1);
+  const int P = c / v;
   const int R = P >= 256 ? 1 : 256 / P;
   const size_t lds = (size_t)R * 2 * c * sizeof(float);
   ME_CHECK(lds <= 64 * 1024, "channel count too large for the batch-norm kernels");
-  if (vec)
+  if (v == W)
+    hipLaunchKernelGGL((k_bn_bwd_partial<T, W>), dim3(chunks), dim3(256), lds, stream, x, dy, n, c, chunks, mean, rstd,
+                       pa, pb);
+  else if (v == 4)
     hipLaunchKernelGGL((k_bn_bwd_partial<T, 4>), dim3(chunks), dim3(256), lds, stream, x, dy, n, c, chunks, mean, rstd,
                        pa, pb);
   else
     hipLaunchKernelGGL((k_bn_bwd_partial<T, 1>), dim3(chunks), dim3(256), lds, stream, x, dy, n, c, chunks, mean, rstd,
                        pa, pb);
-  hipLaunchKernelGGL(k_bn_bwd_final, dim3((unsigned)ceil_div(c, 8)), dim3(256), 0, stream, pa, pb, c, chunks,
+  hipLaunchKernelGGL(k_bn_bwd_final, dim3((unsigned)ceil_div(c, 4)), dim3(256), 0, stream, pa, pb, c, chunks,
                      grad_beta, grad_gamma);
-  constexpr int W = 16 / (int)sizeof(T);
-  const int v = (vec && c % W == 0) ? W : (vec ? 4 : 1);
   const int pieces = c / v;
   const dim3 grid((unsigned)ceil_div(n, (int64_t)(pieces >= 256 ? 1 : 256 / pieces) * kBnRowsPerThread));
   if (v == W)
