@@ -220,7 +220,8 @@ def bench_conv(args, ME, MEB, dist_utils, rank, world, dev):
     kc = 64 if cin % 64 == 0 else 32 if cin % 32 == 0 else 16
     bf16 = args.dtype == "bf16"
     if bf16:
-        kc = 32 if cin <= 32 else 64 if cin <= 64 else 128     # conv_variant_bf16() of csrc/conv_bf16.hip
+        # conv_variant_bf16() of csrc/conv_bf16.hip
+        kc = 128 if cin % 128 == 0 else 96 if cin % 96 == 0 else 32 if cin <= 32 else 64 if cin <= 64 else 128
     peak = PEAK_BF16_MATRIX_TFLOPS if bf16 else PEAK_F32_MATRIX_TFLOPS
     esz = 2 if bf16 else 4
     line = {

@@ -280,7 +280,11 @@ static ConvVariantBf16 conv_variant_bf16(int c_src, int c_dst) {
   // half-empty last slab costs nothing, while every extra slab re-gathers all source rows
   v.nc = c_dst <= 32 ? 32 : 64;
   v.slabs = (int)ceil_div(c_dst, v.nc);
-  v.kc = c_src <= 32 ? 32 : (c_src <= 64 ? 64 : 128);
+  // widest chunk that tiles the source channels exactly (MinkUNet's 96 / 192-channel layers sit on its largest
+  // maps); otherwise the smallest chunk that covers them, or 128
+  if (c_src % 128 == 0) v.kc = 128;
+  else if (c_src % 96 == 0) v.kc = 96;
+  else v.kc = c_src <= 32 ? 32 : (c_src <= 64 ? 64 : 128);
   return v;
 }
 
@@ -359,6 +363,7 @@ int me_conv_pack_weights_bf16(const void *w, int32_t w_is_f32, int64_t volume, i
                          nchunks, ncb, wp8, total);                                                             \
   } while (0)
   if (v.kc == 128) ME_PACK(128);
+  else if (v.kc == 96) ME_PACK(96);
   else if (v.kc == 64) ME_PACK(64);
   else ME_PACK(32);
 #undef ME_PACK
@@ -388,10 +393,12 @@ int me_conv_target_bf16(const uint16_t *src_, int64_t n_src, int32_t c_src, cons
                                          order, dst, n_tgt, tile_rows, batch_groups, stream)
   if (v.nc == 32) {
     if (v.kc == 128) ME_CONV_CASE(32, 128);
+    if (v.kc == 96) ME_CONV_CASE(32, 96);
     if (v.kc == 64) ME_CONV_CASE(32, 64);
     ME_CONV_CASE(32, 32);
   } else {
     if (v.kc == 128) ME_CONV_CASE(64, 128);
+    if (v.kc == 96) ME_CONV_CASE(64, 96);
     if (v.kc == 64) ME_CONV_CASE(64, 64);
     ME_CONV_CASE(64, 32);
   }
