@@ -281,6 +281,17 @@ int me_global_pool_f32(const float *src_dev, const float *src2_dev, int32_t c, c
 int me_broadcast_f32(const float *in_dev, const float *glob_dev, const int32_t *batch_row_dev, int64_t n,
                      int32_t c, int32_t multiply, float *out_dev, void *stream);
 
+/* Generative / expanding convolutions (CoordinateMapCPU::stride_region, src/coordinate_map_cpu.hpp:446-487;
+ * manager: src/coordinate_map_manager.cpp:436-466): candidate output coordinates = every kernel offset of the
+ * region around every input coordinate, candidate (row, k) at out[row * volume + k]; a following
+ * me_coords_insert_and_map removes the duplicates (first occurrence wins).  region->tensor_stride holds the
+ * OUTPUT tensor stride, as the reference's kernel region does.  align_stride (may be NULL) with `aligned`
+ * (uint8 [n * volume]): marks the candidates whose spatial coordinates are multiples of align_stride (the
+ * non-transposed expand_coordinates case keeps only those, :478-483). */
+int me_coords_expand_region(const int32_t *coords_dev, int64_t n, int32_t ncol, const me_region *region,
+                            const int32_t *align_stride, int32_t *out_coords_dev, uint8_t *aligned_dev,
+                            void *stream);
+
 /* ---- input pipeline on the device --------------------------------------------------
  * Voxelisation = me_coords_insert_and_map (unique_map / inverse_map) plus these two reductions.
  * Labels (src/quantization.cpp:140-196, quantize_label): colabels[u] = label of the voxel's first point,

@@ -16,7 +16,9 @@ from .backend import (  # noqa: F401
 from .common import convert_to_int_list, get_minkowski_function  # noqa: F401
 from .convolution import (  # noqa: F401
     MinkowskiConvolution, MinkowskiConvolutionFunction, MinkowskiConvolutionTranspose,
-    MinkowskiConvolutionTransposeFunction)
+    MinkowskiConvolutionTransposeFunction, MinkowskiGenerativeConvolutionTranspose)
+from .pruning import MinkowskiPruning, MinkowskiPruningFunction  # noqa: F401
+from .union import MinkowskiUnion, MinkowskiUnionFunction  # noqa: F401
 from .coordinate_manager import (  # noqa: F401
     CoordinateManager, set_gpu_allocator, set_memory_manager_backend)
 from .kernel_generator import KernelGenerator, get_kernel_volume  # noqa: F401

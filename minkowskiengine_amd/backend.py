@@ -374,6 +374,7 @@ class CoordinateMapManagerGPU_c10:
         self._maps = {}          # (tensor_stride tuple, string_id) -> _CoordinateMapGPU
         self._kernel_maps = {}   # kernel_map_key (src/types.hpp:183-192) -> KernelMapGPU
         self._origin_maps = {}
+        self._prune_rows = {}
 
     # ---- keys -----------------------------------------------------------------------------------
     @staticmethod
@@ -446,6 +447,109 @@ class CoordinateMapManagerGPU_c10:
             cmap, _, inverse = _insert(strided[:in_map.n], out_ts)
             self._maps[ok] = cmap
         return CoordinateMapKey(list(ok[0]), ok[1])
+
+    def _register(self, ts, cmap, string_id=""):
+        """insert under (ts, string_id), with a random suffix if that key is taken -> key tuple"""
+        key = (tuple(ts), str(string_id))
+        if key in self._maps:
+            k = self.get_random_string_id(ts, string_id)
+            key = (tuple(k[0]), k[1])
+        self._maps[key] = cmap
+        return key
+
+    def stride_region(self, in_key, kernel_size, kernel_dilation, region_type, out_tensor_stride,
+                      expand_coordinates, is_transpose, region_tensor_stride=None):
+        """src/coordinate_map_manager.cpp:436-466 -> (CoordinateMapKey, created): the map with
+        `out_tensor_stride`; it is reused when it exists and `expand_coordinates` is false, otherwise generated
+        from the kernel region around every input coordinate (CoordinateMapCPU::stride_region,
+        src/coordinate_map_cpu.hpp:446-487): all of them for a transposed kernel, only those aligned to the out
+        tensor stride otherwise.  New rows are ordered by input row, then kernel offset."""
+        ik = self._k(in_key)
+        _check(ik in self._maps, "coordinate map not found", ik)
+        _check(int(region_type) != int(RegionType.CUSTOM), "Not implemented yet.")
+        out_ts = tuple(int(t) for t in out_tensor_stride)
+        ok = (out_ts, "")
+        exists = ok in self._maps
+        if exists and not expand_coordinates:
+            return CoordinateMapKey(list(ok[0]), ok[1]), False
+        in_map = self._maps[ik]
+        lib = _lib.load()
+        dev = in_map.coords.device
+        ncol = len(out_ts) + 1
+        # the offsets of a transposed kernel step by the OUT tensor stride (convolution_transpose_cpu.cpp:81-91),
+        # those of a regular kernel by the IN tensor stride (convolution_cpu.cpp:88-98)
+        rts = out_ts if region_tensor_stride is None else tuple(int(t) for t in region_tensor_stride)
+        region = _lib.make_region(ncol, int(region_type), [int(v) for v in kernel_size],
+                                  [int(v) for v in kernel_dilation], rts)
+        volume = int(lib.me_region_volume(ctypes.byref(region)))
+        cand = torch.empty((max(in_map.n * volume, 1), ncol), dtype=torch.int32, device=dev)
+        aligned = None if is_transpose else torch.empty(max(in_map.n * volume, 1), dtype=torch.uint8, device=dev)
+        ts_arr = (ctypes.c_int32 * len(out_ts))(*out_ts)
+        with torch.cuda.device(dev):
+            _lib.check(lib.me_coords_expand_region(_ptr(in_map.coords), in_map.n, ncol, ctypes.byref(region),
+                                                   None if is_transpose else ts_arr, _ptr(cand), _ptr(aligned),
+                                                   _stream(dev)))
+        cand = cand[:in_map.n * volume]
+        if aligned is not None:
+            cand = cand[aligned[:in_map.n * volume].bool()].contiguous()
+        cmap, _, _ = _insert(cand, out_ts)
+        key = self._register(out_ts, cmap)
+        return CoordinateMapKey(list(key[0]), key[1]), True
+
+    def prune(self, in_key, keep):
+        """src/coordinate_map_manager.cpp:558-576: new map (tensor stride of `in_key`, string id "pruned") with the
+        rows of `in_key` where `keep` is true, in row order."""
+        ik = self._k(in_key)
+        _check(ik in self._maps, "coordinate map not found", ik)
+        in_map = self._maps[ik]
+        _check(keep.dim() == 1 and keep.numel() == in_map.n, "Invalid range for pruning")
+        rows = torch.nonzero(keep.to(in_map.coords.device).bool(), as_tuple=False).squeeze(1)
+        cmap, _, _ = _insert(in_map.coords[rows].contiguous(), ik[0])
+        key = self._register(ik[0], cmap, "pruned")
+        self._prune_rows[(ik, key)] = rows.to(torch.int32)
+        return CoordinateMapKey(list(key[0]), key[1])
+
+    def _pruning_rows(self, in_key, out_key):
+        """int32 [n_out]: the row of `in_key` every row of the pruned map `out_key` came from (the one-offset
+        kernel map the reference builds for PruningForward, src/pruning_cpu.cpp:82)."""
+        rows = self._prune_rows.get((self._k(in_key), self._k(out_key)))
+        if rows is None:   # maps that were not produced by prune(): look the coordinates up
+            in_map, out_map = self._get(in_key), self._get(out_key)
+            lib = _lib.load()
+            dev = in_map.coords.device
+            rows = torch.empty(max(out_map.n, 1), dtype=torch.int32, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(lib.me_coords_find(_ptr(in_map.table), in_map.capacity, _ptr(in_map.coords),
+                                              in_map.coords.shape[1], _ptr(out_map.coords), out_map.n, _ptr(rows),
+                                              _stream(dev)))
+            rows = rows[:out_map.n]
+            _check(bool((rows >= 0).all()), "the pruned map is not a subset of the input map")
+            self._prune_rows[(self._k(in_key), self._k(out_key))] = rows
+        return rows
+
+    def union_map(self, in_keys, out_key):
+        """src/coordinate_map_manager.cpp (union_map): the union of the maps `in_keys` (same tensor stride) is
+        created under `out_key`; returns one int64 [2, n_i] tensor per input (row 0 = its rows, row 1 = rows of
+        the union).  Union rows are ordered by first occurrence over the concatenated inputs."""
+        _check(len(in_keys) > 1, "Number of input coordinate keys must be > 1")
+        iks = [self._k(k) for k in in_keys]
+        for ik in iks:
+            _check(ik in self._maps, "coordinate map not found", ik)
+            _check(ik[0] == iks[0][0], "Invalid tensor stride", ik[0], iks[0][0])
+        maps = [self._maps[ik] for ik in iks]
+        allc = torch.cat([m.coords for m in maps], 0).contiguous()
+        cmap, _, inverse = _insert(allc, iks[0][0])
+        if not out_key.is_key_set():
+            key = self._register(iks[0][0], cmap, "union")
+            out_key.set_key((list(key[0]), key[1]))
+        else:
+            self._maps[self._k(out_key)] = cmap
+        out, s0 = [], 0
+        for m in maps:
+            rows = torch.arange(m.n, dtype=torch.int64, device=allc.device)
+            out.append(torch.stack((rows, inverse[s0:s0 + m.n])))
+            s0 += m.n
+        return out
 
     def get_coordinates(self, key):
         return self._get(key).coords
@@ -706,7 +810,8 @@ def _conv_backward(in_feat, grad_out, kernel, km, algo=None):
     return grad_in, grad_w if kernel.dtype == torch.float32 else grad_w.to(kernel.dtype)
 
 
-def _prepare_conv(in_feat, kernel, kernel_stride, expand_coordinates, in_key, out_key, manager, transpose):
+def _prepare_conv(in_feat, kernel, kernel_size, kernel_stride, kernel_dilation, region_type, expand_coordinates,
+                  in_key, out_key, manager, transpose):
     _check_feat("in_feat", in_feat)
     _check_feat("kernel", kernel)
     _check(in_feat.dim() == 2, "in_feat.dim():", in_feat.dim())
@@ -715,28 +820,36 @@ def _prepare_conv(in_feat, kernel, kernel_stride, expand_coordinates, in_key, ou
     _check(manager.exists(in_key), "coordinate map not found")
     _check(in_feat.shape[0] == manager.size(in_key), "Invalid in_feat size", in_feat.shape[0], "!=",
            manager.size(in_key))
-    if not out_key.is_key_set():
-        _check(not expand_coordinates, "expand_coordinates (stride_region) is not part of the hot path yet")
-        if not transpose:
-            out_key.set_key(manager.stride(in_key, kernel_stride).get_key())
+    if out_key.is_key_set():
+        return
+    ts = in_key.get_tensor_stride()
+    st = [int(s) for s in kernel_stride]
+    if not transpose:
+        if expand_coordinates:
+            # src/convolution_cpu.cpp:79-103: every kernel offset around every input voxel that falls on the
+            # output grid becomes an output voxel
+            out_ts = [t * s for t, s in zip(ts, st)]
+            key, _ = manager.stride_region(in_key, kernel_size, kernel_dilation, region_type, out_ts, True, False,
+                                           region_tensor_stride=ts)
+            out_key.set_key(key.get_key())
         else:
-            # src/convolution_transpose_cpu.cpp:76-97: out tensor stride = in / stride; the map must exist
-            ts = in_key.get_tensor_stride()
-            st = [int(s) for s in kernel_stride]
-            _check(all(t % s == 0 for t, s in zip(ts, st)), "Invalid up stride on tensor stride:", ts,
-                   "kernel stride:", st)
-            out_ts = [t // s for t, s in zip(ts, st)]
-            cand = (out_ts, "")
-            _check(manager.exists(cand),
-                   "transposed convolution without an existing output map needs stride_region "
-                   "(generative; not part of the hot path yet)")
-            out_key.set_key(cand)
+            out_key.set_key(manager.stride(in_key, kernel_stride).get_key())
+    else:
+        # src/convolution_transpose_cpu.cpp:76-97: out tensor stride = in / stride; the existing map of that
+        # stride is reused unless new coordinates are to be generated
+        _check(all(t % s == 0 for t, s in zip(ts, st)), "Invalid up stride on tensor stride:", ts,
+               "kernel stride:", st)
+        out_ts = [t // s for t, s in zip(ts, st)]
+        key, _ = manager.stride_region(in_key, kernel_size, kernel_dilation, region_type, out_ts,
+                                       bool(expand_coordinates), True)
+        out_key.set_key(key.get_key())
 
 
 def ConvolutionForwardGPU(in_feat, kernel, kernel_size, kernel_stride, kernel_dilation, region_type, offset,
                           expand_coordinates, convolution_mode, in_key, out_key, manager):
     """src/convolution_gpu.cu:45-159 (CPU twin src/convolution_cpu.cpp:42-135)."""
-    _prepare_conv(in_feat, kernel, kernel_stride, expand_coordinates, in_key, out_key, manager, False)
+    _prepare_conv(in_feat, kernel, kernel_size, kernel_stride, kernel_dilation, region_type, expand_coordinates, in_key,
+                  out_key, manager, False)
     km = manager._kernel_map(in_key, out_key, kernel_size, kernel_stride, kernel_dilation, region_type, offset,
                              False, False)
     return _conv_forward(in_feat, kernel, km)
@@ -761,7 +874,8 @@ def ConvolutionBackwardGPU(in_feat, grad_out_feat, kernel, kernel_size, kernel_s
 def ConvolutionTransposeForwardGPU(in_feat, kernel, kernel_size, kernel_stride, kernel_dilation, region_type,
                                    offset, expand_coordinates, convolution_mode, in_key, out_key, manager):
     """src/convolution_transpose_gpu.cu (CPU twin src/convolution_transpose_cpu.cpp:41-125)."""
-    _prepare_conv(in_feat, kernel, kernel_stride, expand_coordinates, in_key, out_key, manager, True)
+    _prepare_conv(in_feat, kernel, kernel_size, kernel_stride, kernel_dilation, region_type, expand_coordinates, in_key,
+                  out_key, manager, True)
     km = manager._kernel_map(in_key, out_key, kernel_size, kernel_stride, kernel_dilation, region_type, offset,
                              True, False)
     return _conv_forward(in_feat, kernel, km)
@@ -1053,3 +1167,30 @@ def bn_backward(x, dy, mean, rstd, gamma):
                                       _ptr(rstd), _ptr(gamma), _ptr(dx), _ptr(gg), _ptr(gb), _ptr(ws), ws.numel(),
                                       _stream(dev)))
     return dx, gg, gb
+
+
+# ------------------------------------------------------------------------------------------------
+# pruning (src/pruning_cpu.cpp:40-150, src/pruning_gpu.cu)
+# ------------------------------------------------------------------------------------------------
+def PruningForwardGPU(in_feat, keep, in_key, out_key, manager):
+    """Rows of `in_feat` where `keep` is true, on a new coordinate map (created here unless `out_key` is set)."""
+    _check_feat("in_feat", in_feat)
+    _check(keep.dtype in (torch.bool, torch.uint8), "keep must be a boolean tensor")
+    _check(in_feat.dim() == 2 and keep.dim() == 1, "in_feat.dim():", in_feat.dim(), "keep.dim():", keep.dim())
+    _check(in_feat.shape[0] == keep.shape[0], "Input feature size and keep size mismatch")
+    _check(manager.exists(in_key), "coordinate map not found")
+    _check(in_feat.shape[0] == manager.size(in_key), "Invalid in_feat size", in_feat.shape[0], "!=",
+           manager.size(in_key))
+    if not out_key.is_key_set():
+        out_key.set_key(manager.prune(in_key, keep).get_key())
+    rows = manager._pruning_rows(in_key, out_key)
+    return in_feat.index_select(0, rows.long())
+
+
+def PruningBackwardGPU(grad_out_feat, in_key, out_key, manager):
+    _check_feat("grad_out_feat", grad_out_feat)
+    rows = manager._pruning_rows(in_key, out_key)
+    grad_in = torch.zeros((manager.size(in_key), grad_out_feat.shape[1]), dtype=grad_out_feat.dtype,
+                          device=grad_out_feat.device)
+    grad_in.index_copy_(0, rows.long(), grad_out_feat)
+    return grad_in

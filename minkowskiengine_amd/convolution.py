@@ -180,3 +180,21 @@ class MinkowskiConvolutionTranspose(MinkowskiConvolutionBase):
                          is_transpose=True, expand_coordinates=expand_coordinates,
                          convolution_mode=convolution_mode, dimension=dimension)
         self.reset_parameters(True)
+
+
+class MinkowskiGenerativeConvolutionTranspose(MinkowskiConvolutionBase):
+    """Transposed convolution that GENERATES its output coordinates: every kernel offset around every input
+    voxel becomes an output voxel (MinkowskiConvolution.py:539-634; coordinate generation
+    src/coordinate_map_cpu.hpp:446-487)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=-1, stride=1, dilation=1, bias=False,
+                 kernel_generator=None, convolution_mode=ConvolutionMode.DEFAULT, dimension=None):
+        if kernel_generator is None:
+            kernel_generator = KernelGenerator(kernel_size=kernel_size, stride=stride, dilation=dilation,
+                                               expand_coordinates=True, dimension=dimension)
+        else:
+            kernel_generator.expand_coordinates = True
+        super().__init__(in_channels, out_channels, kernel_size, stride, dilation, bias, kernel_generator,
+                         is_transpose=True, expand_coordinates=True, convolution_mode=convolution_mode,
+                         dimension=dimension)
+        self.reset_parameters(True)

@@ -85,6 +85,10 @@ class CoordinateManager:
     def origin_map_size(self):
         return self._manager.origin_map_size()
 
+    def union_map(self, in_keys, out_key):
+        """one int64 [2, n_i] tensor per input key: (its rows, rows of the union map created under out_key)"""
+        return self._manager.union_map(in_keys, out_key)
+
     def get_unique_coordinate_map_key(self, tensor_stride):
         ts = convert_to_int_list(tensor_stride, self.D)
         sid = self._manager.get_random_string_id(ts, "")

@@ -292,6 +292,31 @@ __device__ __forceinline__ void region_coordinate_at(const me_region &rg, int32_
   }
 }
 
+// Coordinates of a kernel region around every input coordinate (generative / transposed convolution with
+// expand_coordinates: CoordinateMapCPU::stride_region, src/coordinate_map_cpu.hpp:446-487).  Candidate
+// (row, k) is written at row * volume + k, so a first-occurrence dedup orders the new map by input row, then
+// kernel offset.  `aligned` (may be NULL): 1 where every spatial coordinate is a multiple of the region's
+// tensor stride times `align` (the non-transposed expand_coordinates case keeps only those).
+template <int NCOL>
+__global__ __launch_bounds__(256) void k_expand_region(const int32_t *__restrict__ coords, int64_t n,
+                                                      me_region rg, int32_t volume, StrideArg align,
+                                                      int32_t *__restrict__ out, uint8_t *__restrict__ aligned) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * volume) return;
+  const int64_t row = idx / volume;
+  const int32_t k = (int32_t)(idx % volume);
+  int32_t src[NCOL], dst[NCOL];
+  load_coords<NCOL>(coords, row, src);
+  region_coordinate_at<NCOL>(rg, k, src, dst);
+  store_coords<NCOL>(out, idx, dst);
+  if (aligned != nullptr) {
+    bool ok = true;
+#pragma unroll
+    for (int d = 0; d < NCOL - 1; ++d) ok = ok && (dst[d + 1] % align.ts[d] == 0);
+    aligned[idx] = ok ? 1 : 0;
+  }
+}
+
 // one thread per (output row u, offset k = blockIdx.y); lanes = consecutive u
 template <int NCOL>
 __global__ __launch_bounds__(256) void k_kmap_probe(const uint64_t *__restrict__ in_table,
@@ -590,6 +615,32 @@ int me_coords_stride(const int32_t *coords, int64_t n, int32_t ncol, const int32
            "coordinates with 4 columns must be 16-byte aligned");
   const dim3 grid((unsigned)ceil_div(n, 256)), block(256);
   ME_DISPATCH_NCOL(ncol, hipLaunchKernelGGL(k_stride<NCOL>, grid, block, 0, stream, coords, n, arg, out_coords));
+  ME_LAUNCH_CHECK();
+  return 0;
+}
+
+int me_coords_expand_region(const int32_t *coords, int64_t n, int32_t ncol, const me_region *region,
+                            const int32_t *align_stride, int32_t *out_coords, uint8_t *aligned, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ME_CHECK(region != nullptr && region->ncol == ncol, "region / coordinate size mismatch");
+  ME_CHECK(ncol >= 2 && ncol <= ME_MAX_DIM + 1, "invalid coordinate size");
+  const int64_t volume = me_region_volume(region);
+  ME_CHECK(volume >= 1 && volume <= 65535, "kernel volume out of range");
+  if (n == 0) return 0;
+  ME_CHECK(ncol != 4 || ((uintptr_t)coords % 16 == 0 && (uintptr_t)out_coords % 16 == 0),
+           "coordinates with 4 columns must be 16-byte aligned");
+  StrideArg arg;
+  for (int d = 0; d < ME_MAX_DIM; ++d) arg.ts[d] = 1;
+  if (align_stride != nullptr)
+    for (int d = 0; d < ncol - 1; ++d) {
+      ME_CHECK(align_stride[d] > 0, "alignment stride must be positive");
+      arg.ts[d] = align_stride[d];
+    }
+  const me_region rg = *region;
+  const dim3 grid((unsigned)ceil_div(n * volume, 256)), block(256);
+  ME_DISPATCH_NCOL(ncol, hipLaunchKernelGGL(k_expand_region<NCOL>, grid, block, 0, stream, coords, n, rg,
+                                            (int32_t)volume, arg, out_coords,
+                                            align_stride != nullptr ? aligned : nullptr));
   ME_LAUNCH_CHECK();
   return 0;
 }

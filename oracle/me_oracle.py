@@ -341,3 +341,34 @@ def segment_mean(features, inverse_map, n_unique, average=True):
         out[u] += f[row]
         cnt[u] += 1
     return out / cnt[:, None] if average else out
+
+
+# ---- generative maps, pruning, union ------------------------------------------------
+def stride_region(coords, region, out_tensor_stride=None):
+    """CoordinateMapCPU::stride_region (src/coordinate_map_cpu.hpp:446-487): the coordinates of the kernel region
+    around every input coordinate, deduplicated in first-occurrence order (input row, then offset).
+    `out_tensor_stride` given = the non-transposed branch (:470-484): only coordinates aligned to it are kept."""
+    cand = region_coordinates(coords, region)
+    if out_tensor_stride is not None:
+        ts = np.asarray(_as_list(out_tensor_stride, cand.shape[1] - 1), np.int64)
+        cand = cand[(cand[:, 1:] % ts == 0).all(1)]
+    um, _ = insert_and_map(cand)
+    return cand[um]
+
+
+def prune(coords, feats, keep):
+    """CoordinateMapCPU::prune + PruningForwardKernelCPU (src/coordinate_map_cpu.hpp:519-536,
+    src/pruning_cpu.cpp:40-105): kept rows in row order."""
+    keep = np.asarray(keep, bool)
+    return _i32(coords)[keep], np.asarray(feats)[keep]
+
+
+def union(coord_sets, feat_sets):
+    """union_map + MinkowskiUnionFunction.forward (MinkowskiUnion.py:41-60): union coordinates in first-occurrence
+    order over the concatenated inputs, features of coinciding coordinates added."""
+    allc = np.concatenate([_i32(c) for c in coord_sets], 0)
+    allf = np.concatenate([np.asarray(f, np.float64) for f in feat_sets], 0)
+    um, inv = insert_and_map(allc)
+    out = np.zeros((len(um), allf.shape[1]), np.float64)
+    np.add.at(out, inv, allf)
+    return allc[um], out
