@@ -146,23 +146,100 @@ __global__ __launch_bounds__(256) void k_pool_max_backward(const float *__restri
 }
 
 // ---- global pooling: reduce the rows of each batch index (origin map row) -------------------------
-// Stage 1: a workgroup walks kGlobalChunk consecutive rows, one thread per channel, and keeps a running
-// value for the batch row of the current run of rows; runs are added into partial[chunk][b][c] by the
-// same thread every time (deterministic).  Stage 2 combines the chunks in order.
-constexpr int kGlobalChunk = 256;
+// Stage 1: a workgroup reduces one chunk of consecutive rows into partial[chunk][b][c].  Rows of a scene are
+// normally consecutive, so nearly every chunk holds ONE batch index: then a thread owns a 16-byte channel piece
+// and every (256 / pieces)-th row, and the row lanes are combined through LDS in lane order.  A chunk that
+// mixes batch indices takes the general path: one thread per channel walks the rows and adds every run of
+// equal batch indices.  Either way the summation order is fixed (deterministic); the argmax is the first row
+// that attains the maximum.  Stage 2: one wave per (batch index, channel) merges the chunks in a fixed
+// shuffle tree.
+static inline int64_t global_chunk_rows(int64_t n) {
+  const int64_t l = ceil_div(n < 1 ? 1 : n, 512);
+  return l < 256 ? 256 : l;
+}
 
-template <bool MAX>
+template <bool MAX, int V>
 __global__ __launch_bounds__(256) void k_global_partial(const float *__restrict__ src,
                                                        const float *__restrict__ src2, int c,
                                                        const int32_t *__restrict__ batch_row, int64_t n,
-                                                       int n_batch, float *__restrict__ partial,
+                                                       int64_t chunk_rows, int n_batch,
+                                                       float *__restrict__ partial,
                                                        int32_t *__restrict__ partial_arg,
                                                        float *__restrict__ partial_cnt) {
+  extern __shared__ float s_red[];  // [R][c] values (+ [R][c] argmax as int)
   const int64_t chunk = blockIdx.x;
-  const int64_t r0 = chunk * kGlobalChunk;
-  const int64_t r1 = min(n, r0 + kGlobalChunk);
+  const int64_t r0 = chunk * chunk_rows;
+  const int64_t r1 = min(n, r0 + chunk_rows);
   float *pp = partial + chunk * n_batch * c;
   int32_t *pa = MAX ? partial_arg + chunk * n_batch * c : nullptr;
+  const int b0 = batch_row[r0];
+  int mixed = 0;
+  for (int64_t r = r0 + threadIdx.x; r < r1; r += blockDim.x) mixed |= (batch_row[r] != b0);
+  if (!__syncthreads_or(mixed)) {
+    const int P = c / V;                      // the host launches V = 4 only when P <= 256
+    const int R = max(1, (int)blockDim.x / P);
+    const int p = (int)threadIdx.x % P, rl = (int)threadIdx.x / P;
+    const bool active = rl < R;
+    float acc[V];
+    int32_t arg[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      acc[j] = MAX ? -FLT_MAX : 0.f;
+      arg[j] = -1;
+    }
+    if (active) {
+#pragma unroll 4
+      for (int64_t r = r0 + rl; r < r1; r += R) {
+        Piece<V> x = load_piece<V>(src + r * c + p * V);
+        if (src2) {
+          const Piece<V> y = load_piece<V>(src2 + r * c + p * V);
+#pragma unroll
+          for (int j = 0; j < V; ++j) x.v[j] *= y.v[j];
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          if (MAX) {
+            if (acc[j] < x.v[j]) {
+              acc[j] = x.v[j];
+              arg[j] = (int32_t)(r * c + p * V + j);
+            }
+          } else {
+            acc[j] += x.v[j];
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        s_red[rl * c + p * V + j] = acc[j];
+        if (MAX) reinterpret_cast<int32_t *>(s_red)[(R + rl) * c + p * V + j] = arg[j];
+      }
+    }
+    __syncthreads();
+    if (active && rl == 0) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        float a = MAX ? -FLT_MAX : 0.f;
+        int32_t g = -1;
+        for (int l = 0; l < R; ++l) {  // fixed order; ties keep the smaller flat index = the earlier row
+          const float v = s_red[l * c + p * V + j];
+          if (MAX) {
+            const int32_t vg = reinterpret_cast<const int32_t *>(s_red)[(R + l) * c + p * V + j];
+            if (a < v || (a == v && vg >= 0 && (g < 0 || vg < g))) {
+              a = v;
+              g = vg;
+            }
+          } else {
+            a += v;
+          }
+        }
+        pp[(int64_t)b0 * c + p * V + j] = a;
+        if (MAX) pa[(int64_t)b0 * c + p * V + j] = g;
+      }
+      if (!MAX && p == 0 && partial_cnt) partial_cnt[chunk * n_batch + b0] = (float)(r1 - r0);
+    }
+    return;
+  }
+  // general path: runs of equal batch indices, one thread per channel
   for (int ch = threadIdx.x; ch < c; ch += blockDim.x) {
     int cur = -1;
     float acc = 0.f;
@@ -205,6 +282,7 @@ __global__ __launch_bounds__(256) void k_global_partial(const float *__restrict_
   }
 }
 
+// one wave per (batch index, channel): lane l merges chunks l, l + 64, ... in order, then a fixed shuffle tree
 template <bool MAX>
 __global__ __launch_bounds__(256) void k_global_final(const float *__restrict__ partial,
                                                      const int32_t *__restrict__ partial_arg,
@@ -212,29 +290,42 @@ __global__ __launch_bounds__(256) void k_global_final(const float *__restrict__ 
                                                      int n_batch, int c, int average,
                                                      float *__restrict__ dst, int32_t *__restrict__ dst_arg,
                                                      float *__restrict__ dst_cnt) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (int64_t)n_batch * c) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t idx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // (b, channel)
+  if (idx >= (int64_t)n_batch * c) return;                              // whole wave
   const int b = (int)(idx / c);
-  if (MAX) {
-    float best = -FLT_MAX;
-    int32_t arg = -1;
-    for (int64_t q = 0; q < chunks; ++q) {
-      const float v = partial[q * n_batch * c + idx];
-      if (best < v) {
-        best = v;
-        arg = partial_arg[q * n_batch * c + idx];
+  float a = MAX ? -FLT_MAX : 0.f, cnt = 0.f;
+  int32_t g = -1;
+  auto merge = [&](float v, int32_t vg) {
+    if (MAX) {
+      if (a < v || (a == v && vg >= 0 && (g < 0 || vg < g))) {
+        a = v;
+        g = vg;
       }
+    } else {
+      a += v;
     }
-    dst[idx] = best;
-    dst_arg[idx] = arg;
+  };
+  for (int64_t q = lane; q < chunks; q += 64) {
+    merge(partial[q * n_batch * c + idx], MAX ? partial_arg[q * n_batch * c + idx] : -1);
+    if (!MAX && partial_cnt) cnt += partial_cnt[q * n_batch + b];
+  }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const float v = __shfl_down(a, off, 64), vc = __shfl_down(cnt, off, 64);
+    const int32_t vg = __shfl_down(g, off, 64);
+    if ((lane & (2 * off - 1)) == 0) {
+      merge(v, vg);
+      cnt += vc;
+    }
+  }
+  if (lane != 0) return;
+  if (MAX) {
+    dst[idx] = a;
+    dst_arg[idx] = g;
   } else {
-    float s = 0.f, cnt = 0.f;
-    for (int64_t q = 0; q < chunks; ++q) {
-      s += partial[q * n_batch * c + idx];
-      if (partial_cnt) cnt += partial_cnt[q * n_batch + b];
-    }
-    if (average && cnt > 0.f) s /= cnt;
-    dst[idx] = s;
+    if (average && cnt > 0.f) a /= cnt;
+    dst[idx] = a;
     if (dst_cnt && idx % c == 0) dst_cnt[b] = cnt;
   }
 }
@@ -348,7 +439,7 @@ int me_pool_max_backward_f32(const float *grad_out, int32_t c, const int32_t *tb
 }
 
 int64_t me_global_pool_workspace_bytes(int64_t n, int32_t n_batch, int32_t c) {
-  const int64_t chunks = ceil_div(n < 1 ? 1 : n, kGlobalChunk);
+  const int64_t chunks = ceil_div(n < 1 ? 1 : n, global_chunk_rows(n));
   // partial values | partial argmax | partial counts
   return align_up(chunks * n_batch * c * 4, 256) * 2 + align_up(chunks * n_batch * 4, 256);
 }
@@ -361,35 +452,48 @@ int me_global_pool_f32(const float *src, const float *src2, int32_t c, const int
   ME_CHECK(mode >= 0 && mode <= 2, "mode must be 0 (sum), 1 (average) or 2 (max)");
   ME_CHECK(mode != 2 || dst_arg != nullptr, "max pooling needs the argmax output");
   ME_CHECK(workspace_bytes >= me_global_pool_workspace_bytes(n, n_batch, c), "workspace too small");
-  const int64_t chunks = ceil_div(n < 1 ? 1 : n, kGlobalChunk);
+  const int64_t chunk_rows = global_chunk_rows(n);
+  const int64_t chunks = ceil_div(n < 1 ? 1 : n, chunk_rows);
   const int64_t vsz = align_up(chunks * n_batch * c * 4, 256);
   float *partial = reinterpret_cast<float *>(workspace);
   int32_t *partial_arg = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(workspace) + vsz);
   float *partial_cnt = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + 2 * vsz);
   const int64_t total = (int64_t)n_batch * c;
+  const bool vec = (c % 4) == 0 && c / 4 <= 256 && (uintptr_t)src % 16 == 0 &&
+                   (src2 == nullptr || (uintptr_t)src2 % 16 == 0);
+  const int P = vec ? c / 4 : (c < 256 ? c : 256);
+  const int R = 256 / P < 1 ? 1 : 256 / P;
+  const size_t lds = (size_t)R * c * 4 * (mode == 2 ? 2 : 1);
+  ME_CHECK(vec || c <= 256, "global pooling of more than 256 channels needs a channel count that is a multiple of 4");
+  ME_CHECK(lds <= 64 * 1024, "channel count too large for global pooling");
   if (mode == 2) {
-    // -FLT_MAX / -1 start values
-    const dim3 fgrid((unsigned)ceil_div(chunks * total, 256));
-    (void)fgrid;
+    // -FLT_MAX / -1 start values (0xff7fffff = -FLT_MAX as a 32-bit pattern)
     ME_HIP(hipMemsetAsync(partial_arg, 0xff, (size_t)chunks * total * 4, stream));
-    // 0xff7fffff = -FLT_MAX: fill with a 32-bit pattern
     ME_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(partial), (int)0xff7fffff, (size_t)chunks * total, stream));
     if (n > 0) {
-      hipLaunchKernelGGL(k_global_partial<true>, dim3((unsigned)chunks), dim3(256), 0, stream, src, src2, c,
-                         batch_row, n, n_batch, partial, partial_arg, partial_cnt);
+      if (vec)
+        hipLaunchKernelGGL((k_global_partial<true, 4>), dim3((unsigned)chunks), dim3(256), lds, stream, src, src2, c,
+                           batch_row, n, chunk_rows, n_batch, partial, partial_arg, partial_cnt);
+      else
+        hipLaunchKernelGGL((k_global_partial<true, 1>), dim3((unsigned)chunks), dim3(256), lds, stream, src, src2, c,
+                           batch_row, n, chunk_rows, n_batch, partial, partial_arg, partial_cnt);
       ME_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_global_final<true>, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream, partial,
+    hipLaunchKernelGGL(k_global_final<true>, dim3((unsigned)ceil_div(total, 4)), dim3(256), 0, stream, partial,
                        partial_arg, partial_cnt, chunks, n_batch, c, 0, dst, dst_arg, dst_count);
   } else {
     ME_HIP(hipMemsetAsync(partial, 0, (size_t)chunks * total * 4, stream));
     ME_HIP(hipMemsetAsync(partial_cnt, 0, (size_t)chunks * n_batch * 4, stream));
     if (n > 0) {
-      hipLaunchKernelGGL(k_global_partial<false>, dim3((unsigned)chunks), dim3(256), 0, stream, src, src2, c,
-                         batch_row, n, n_batch, partial, partial_arg, partial_cnt);
+      if (vec)
+        hipLaunchKernelGGL((k_global_partial<false, 4>), dim3((unsigned)chunks), dim3(256), lds, stream, src, src2, c,
+                           batch_row, n, chunk_rows, n_batch, partial, partial_arg, partial_cnt);
+      else
+        hipLaunchKernelGGL((k_global_partial<false, 1>), dim3((unsigned)chunks), dim3(256), lds, stream, src, src2, c,
+                           batch_row, n, chunk_rows, n_batch, partial, partial_arg, partial_cnt);
       ME_LAUNCH_CHECK();
     }
-    hipLaunchKernelGGL(k_global_final<false>, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream, partial,
+    hipLaunchKernelGGL(k_global_final<false>, dim3((unsigned)ceil_div(total, 4)), dim3(256), 0, stream, partial,
                        partial_arg, partial_cnt, chunks, n_batch, c, mode == 1, dst, dst_arg, dst_count);
   }
   ME_LAUNCH_CHECK();
