@@ -239,7 +239,8 @@ def bench_conv(args, ME, MEB, dist_utils, rank, world, dev):
                    "parallelism": f"scene-sharded dp{world}, RCCL all-reduce of the weight gradient"},
         "roofline": {"bound": "mfma", "kernel": f"k_conv_tile_{'bf16' if bf16 else 'f32'}<{nc},{kc}> (forward)",
                      "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                     "traffic": pmc_traffic("k_conv_tile_f32", n, extent, cin, cout) if D == 3 and not bf16 else None,
+                     "traffic": pmc_traffic("k_conv_tile_bf16_forward" if bf16 else "k_conv_tile_f32", n, extent, cin,
+                                            cout) if D == 3 else None,
                      "traffic_note": "HBM-side bytes per launch (FETCH_SIZE x2 + WRITE_SIZE), rocprofv3 --pmc, "
                                      "profiles/pmc_traffic.json; compulsory bytes of the forward launch: "
                                      f"{int(esz * (n * cin + n * cout + K * cin * cout) + 8 * n_pairs)}",

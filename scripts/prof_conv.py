@@ -17,9 +17,10 @@ coords = make_scene(100000, extent, 0).to(dev)
 mgr = MEB.CoordinateMapManagerGPU_c10()
 key, _ = mgr.insert_and_map(coords, [1, 1, 1], "")
 km = mgr._kernel_map(key, key, [3] * 3, [1] * 3, [1] * 3, MEB.RegionType.HYPER_CUBE, None, False, False)
-x = torch.rand(100000, 64, device=dev)
+tdt = torch.bfloat16 if os.environ.get("DTYPE", "f32") == "bf16" else torch.float32
+x = torch.rand(100000, 64, device=dev).to(tdt)
 w = torch.rand(27, 64, 128, device=dev) - 0.5
-gy = torch.rand(100000, 128, device=dev)
+gy = torch.rand(100000, 128, device=dev).to(tdt)
 MEB._TILE_ROWS = T
 lib.me_debug_set_conv_variant(var)
 for _ in range(iters):
