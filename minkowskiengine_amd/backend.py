@@ -172,11 +172,34 @@ class CoordinateMapKey:
 # device objects
 # ------------------------------------------------------------------------------------------------
 def _ptr(t):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+    """device address for a c_void_p argument (plain int / None: ctypes converts them without an object)"""
+    return t.data_ptr() if t is not None else None
 
 
 def _stream(device):
-    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class _on:
+    """`with _on(dev):` = torch.cuda.device(dev) without the switch when `dev` is already current (the
+    per-layer host time matters: a bf16 MinkUNet34C step is as long on the host as on the GPU)."""
+    __slots__ = ("dev", "guard")
+
+    def __init__(self, dev):
+        self.dev = dev
+        self.guard = None
+
+    def __enter__(self):
+        idx = self.dev.index
+        if idx is not None and idx != torch.cuda.current_device():
+            self.guard = torch.cuda.device(self.dev)
+            self.guard.__enter__()
+
+    def __exit__(self, *exc):
+        if self.guard is not None:
+            self.guard.__exit__(*exc)
+            self.guard = None
+        return False
 
 
 def _workspace(nbytes, device):
@@ -208,7 +231,7 @@ def _insert(coords, tensor_stride):
     wsb = int(lib.me_insert_workspace_bytes(n))
     ws = _workspace(wsb, dev)
     n_unique = ctypes.c_int64(0)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(lib.me_coords_insert_and_map(_ptr(coords), n, ncol, _ptr(table), cap, _ptr(coords_unique),
                                                 _ptr(unique_map), _ptr(inverse_map), ctypes.byref(n_unique),
                                                 _ptr(ws), ws.numel(), _stream(dev)))
@@ -237,6 +260,7 @@ class KernelMapGPU:
         self.in_pairs, self.out_pairs = in_pairs, out_pairs
         self._store = store if store is not None else {}
         self._flip = flip
+        self._launch_cache = {}               # per view: launch geometry and device addresses of the plans
 
     @property
     def n_pairs(self):
@@ -267,7 +291,7 @@ class KernelMapGPU:
             src_pairs = self.in_pairs if target == "out" else self.out_pairs   # values stored
             tgt_pairs = self.out_pairs if target == "out" else self.in_pairs   # rows indexed
             tbl = torch.empty((self.volume, max(n_tgt, 1)), dtype=torch.int32, device=dev)
-            with torch.cuda.device(dev):
+            with _on(dev):
                 _lib.check(lib.me_kernel_map_transpose(_ptr(tgt_pairs), _ptr(src_pairs), _ptr(self.k_offsets_dev),
                                                        self.volume, self.n_pairs, n_tgt, _ptr(tbl), _stream(dev)))
             self._store[name] = tbl
@@ -289,7 +313,7 @@ class KernelMapGPU:
                 dev = self.device
                 keys = torch.empty(cmap.n, dtype=torch.int64, device=dev)
                 ts = (ctypes.c_int32 * len(cmap.tensor_stride))(*cmap.tensor_stride)
-                with torch.cuda.device(dev):
+                with _on(dev):
                     _lib.check(lib.me_coords_spatial_keys(_ptr(cmap.coords), cmap.n, cmap.coords.shape[1], ts,
                                                           _ptr(keys), _stream(dev)))
                 self._store[name] = torch.argsort(keys, stable=True).to(torch.int32)
@@ -314,7 +338,7 @@ class KernelMapGPU:
             item_gptr = torch.empty(n_tiles * self.volume + 1, dtype=torch.int32, device=dev)
             ws = _workspace(lib.me_plan_workspace_bytes(n_tgt, self.volume, tile_rows), dev)
             order = self.order(target)
-            with torch.cuda.device(dev):
+            with _on(dev):
                 _lib.check(lib.me_plan_build(_ptr(tbl), _ptr(order), n_tgt, self.volume, tile_rows, batch_groups,
                                              _ptr(plan_src), _ptr(plan_dst), _ptr(batch_desc), _ptr(tile_bptr),
                                              _ptr(item_gptr), _ptr(ws), ws.numel(), _stream(dev)))
@@ -342,7 +366,7 @@ def _build_kernel_map(in_map, out_map, region):
     nbr = torch.empty((volume, max(n_out, 1)), dtype=torch.int32, device=dev)
     ws = _workspace(lib.me_kernel_map_workspace_bytes(n_out, volume), dev)
     koffs = (ctypes.c_int64 * (volume + 1))()
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(lib.me_kernel_map_probe(_ptr(in_map.table), in_map.capacity, _ptr(in_map.coords),
                                            _ptr(out_map.coords), n_out, ctypes.byref(region), _ptr(nbr), koffs,
                                            _ptr(ws), ws.numel(), _stream(dev)))
@@ -441,7 +465,7 @@ class CoordinateMapManagerGPU_c10:
             ncol = len(out_ts) + 1
             strided = torch.empty((max(in_map.n, 1), ncol), dtype=torch.int32, device=dev)
             ts_arr = (ctypes.c_int32 * len(out_ts))(*out_ts)
-            with torch.cuda.device(dev):
+            with _on(dev):
                 _lib.check(lib.me_coords_stride(_ptr(in_map.coords), in_map.n, ncol, ts_arr, _ptr(strided),
                                                 _stream(dev)))
             cmap, _, inverse = _insert(strided[:in_map.n], out_ts)
@@ -485,7 +509,7 @@ class CoordinateMapManagerGPU_c10:
         cand = torch.empty((max(in_map.n * volume, 1), ncol), dtype=torch.int32, device=dev)
         aligned = None if is_transpose else torch.empty(max(in_map.n * volume, 1), dtype=torch.uint8, device=dev)
         ts_arr = (ctypes.c_int32 * len(out_ts))(*out_ts)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.check(lib.me_coords_expand_region(_ptr(in_map.coords), in_map.n, ncol, ctypes.byref(region),
                                                    None if is_transpose else ts_arr, _ptr(cand), _ptr(aligned),
                                                    _stream(dev)))
@@ -518,7 +542,7 @@ class CoordinateMapManagerGPU_c10:
             lib = _lib.load()
             dev = in_map.coords.device
             rows = torch.empty(max(out_map.n, 1), dtype=torch.int32, device=dev)
-            with torch.cuda.device(dev):
+            with _on(dev):
                 _lib.check(lib.me_coords_find(_ptr(in_map.table), in_map.capacity, _ptr(in_map.coords),
                                               in_map.coords.shape[1], _ptr(out_map.coords), out_map.n, _ptr(rows),
                                               _stream(dev)))
@@ -591,7 +615,7 @@ class CoordinateMapManagerGPU_c10:
             q = torch.zeros_like(in_map.coords)
             q[:, 0] = in_map.coords[:, 0]
             rows = torch.empty(max(in_map.n, 1), dtype=torch.int32, device=dev)
-            with torch.cuda.device(dev):
+            with _on(dev):
                 _lib.check(lib.me_coords_find(_ptr(omap.table), omap.capacity, _ptr(omap.coords), q.shape[1],
                                               _ptr(q), in_map.n, _ptr(rows), _stream(dev)))
             rows = rows[:in_map.n]
@@ -659,6 +683,8 @@ CoordinateMapManagerGPU_default = CoordinateMapManagerGPU_c10
 # convolution operators (src/convolution_gpu.cu:45-244, src/convolution_transpose_gpu.cu)
 # ------------------------------------------------------------------------------------------------
 _ALGO = os.environ.get("ME_AMD_CONV_ALGO", "mfma")  # "naive" = VALU/atomics cross-check kernels
+_WGRAD_TUNING = False  # set by the tuning scripts, which flip the wgrad debug switches between calls: the
+                       # workspace size is then re-queried on every call instead of cached per kernel map
 _TILE_ROWS = int(os.environ.get("ME_AMD_TILE_ROWS", "0"))        # 0 = me_conv_plan_config (tuning overrides)
 _BATCH_GROUPS = int(os.environ.get("ME_AMD_BATCH_GROUPS", "0"))
 _SPATIAL_TILES = os.environ.get("ME_AMD_SPATIAL_TILES", "0") != "0"  # tiles of Z-order-sorted target rows (off: no gain measured while the gather is latency-hidden)
@@ -731,32 +757,40 @@ def _conv_target(src_feat, kernel, km, target, n_tgt, name="conv_target", transp
     out = torch.empty((n_tgt, c_dst), dtype=src_feat.dtype, device=dev)
     if n_tgt == 0:
         return out
-    tile_rows, batch_groups = plan_config(n_tgt, km.volume, km.n_pairs, c_src, c_dst, bf16)
-    plan_src, plan_dst, batch_desc, tile_bptr, _ = km.plan(target, tile_rows, batch_groups)
+    # launch geometry of this (map side, channel shape, dtype): computed once per kernel map
+    ck = (target, c_src, c_dst, bf16, _TILE_ROWS, _BATCH_GROUPS, _SPATIAL_TILES)
+    cfg = km._launch_cache.get(ck)
+    if cfg is None:
+        tile_rows, batch_groups = plan_config(n_tgt, km.volume, km.n_pairs, c_src, c_dst, bf16)
+        plan_src, plan_dst, batch_desc, tile_bptr, _ = km.plan(target, tile_rows, batch_groups)
+        elems = int((lib.me_conv_packed_weight_elems_bf16 if bf16 else lib.me_conv_packed_weight_elems)(
+            volume, c_src, c_dst))
+        order = km.order(target)
+        cfg = (tile_rows, batch_groups, plan_src, plan_dst, batch_desc, tile_bptr, order, elems,
+               _ptr(plan_src), _ptr(plan_dst), _ptr(batch_desc), _ptr(tile_bptr), _ptr(order))
+        km._launch_cache[ck] = cfg
+    tile_rows, batch_groups, _, _, _, _, _, elems, p_src, p_dst, p_desc, p_bptr, p_order = cfg
     flops = 2.0 * km.n_pairs * c_src * c_dst
-    with torch.cuda.device(dev):
+    stream = _stream(dev)
+    with _on(dev):
         if bf16:
             # bf16 features: weights (fp32 master copy or bf16) are rounded to bf16 while being packed
             _check(kernel.dtype in (torch.float32, torch.bfloat16), "kernel must be float32 or bfloat16")
-            packed = torch.empty(int(lib.me_conv_packed_weight_elems_bf16(volume, c_src, c_dst)),
-                                 dtype=torch.bfloat16, device=dev)
-            _lib.check(lib.me_conv_pack_weights_bf16(_ptr(kernel), 1 if kernel.dtype == torch.float32 else 0, volume,
-                                                     c_src, c_dst, 1 if transposed else 0, _ptr(packed),
-                                                     _stream(dev)))
+            packed = torch.empty(elems, dtype=torch.bfloat16, device=dev)
+            _lib.check(lib.me_conv_pack_weights_bf16(kernel.data_ptr(), 1 if kernel.dtype == torch.float32 else 0,
+                                                     volume, c_src, c_dst, 1 if transposed else 0,
+                                                     packed.data_ptr(), stream))
             _timed(name, dev, lambda: _lib.check(lib.me_conv_target_bf16(
-                _ptr(src_feat), src_feat.shape[0], c_src, _ptr(packed), km.volume, c_dst, _ptr(plan_src),
-                _ptr(plan_dst), _ptr(batch_desc), _ptr(tile_bptr), _ptr(km.order(target)), _ptr(out), n_tgt,
-                tile_rows, batch_groups, _stream(dev))), flops=flops)
+                src_feat.data_ptr(), src_feat.shape[0], c_src, packed.data_ptr(), km.volume, c_dst, p_src, p_dst,
+                p_desc, p_bptr, p_order, out.data_ptr(), n_tgt, tile_rows, batch_groups, stream)), flops=flops)
             return out
         _check(kernel.dtype == torch.float32, "float32 features need a float32 kernel, got", kernel.dtype)
-        packed = torch.empty(int(lib.me_conv_packed_weight_elems(volume, c_src, c_dst)), dtype=torch.float32,
-                             device=dev)
-        _lib.check(lib.me_conv_pack_weights_f32(_ptr(kernel), volume, c_src, c_dst, 1 if transposed else 0,
-                                                _ptr(packed), _stream(dev)))
+        packed = torch.empty(elems, dtype=torch.float32, device=dev)
+        _lib.check(lib.me_conv_pack_weights_f32(kernel.data_ptr(), volume, c_src, c_dst, 1 if transposed else 0,
+                                                packed.data_ptr(), stream))
         _timed(name, dev, lambda: _lib.check(lib.me_conv_target_f32(
-            _ptr(src_feat), src_feat.shape[0], c_src, _ptr(packed), km.volume, c_dst, _ptr(plan_src),
-            _ptr(plan_dst), _ptr(batch_desc), _ptr(tile_bptr), _ptr(km.order(target)), _ptr(out), n_tgt, tile_rows,
-            batch_groups, _stream(dev))), flops=flops)
+            src_feat.data_ptr(), src_feat.shape[0], c_src, packed.data_ptr(), km.volume, c_dst, p_src, p_dst, p_desc,
+            p_bptr, p_order, out.data_ptr(), n_tgt, tile_rows, batch_groups, stream)), flops=flops)
     return out
 
 
@@ -767,7 +801,7 @@ def _conv_forward(in_feat, kernel, km, algo=None):
         lib = _lib.load()
         dev = in_feat.device
         out = torch.zeros((km.n_out, kernel.shape[2]), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.check(lib.me_conv_forward_naive_f32(_ptr(in_feat), kernel.shape[1], _ptr(kernel), kernel.shape[2],
                                                      _ptr(km.in_pairs), _ptr(km.out_pairs), _ptr(km.k_offsets_dev),
                                                      km.volume, km.n_pairs, _ptr(out), _stream(dev)))
@@ -787,7 +821,7 @@ def _conv_backward(in_feat, grad_out, kernel, km, algo=None):
         _check(not bf16, "the cross-check kernels are float32 only")
         grad_in = torch.zeros((km.n_in, c_in), dtype=torch.float32, device=dev)
         grad_w = torch.zeros_like(kernel)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.check(lib.me_conv_backward_naive_f32(_ptr(in_feat), c_in, _ptr(grad_out), c_out, _ptr(kernel),
                                                       _ptr(km.in_pairs), _ptr(km.out_pairs), _ptr(km.k_offsets_dev),
                                                       km.volume, km.n_pairs, _ptr(grad_in), _ptr(grad_w),
@@ -797,16 +831,25 @@ def _conv_backward(in_feat, grad_out, kernel, km, algo=None):
     grad_in = _conv_target(grad_out, kernel, km, "in", km.n_in, name="conv_dgrad", transposed=True)
     # wgrad: always accumulated and reduced in fp32; handed back in the kernel's dtype
     grad_w = torch.empty(kernel.shape, dtype=torch.float32, device=dev)
-    koffs = (ctypes.c_int64 * (volume + 1))(*km.k_offsets)
-    wsb = int((lib.me_conv_wgrad_workspace_bytes_bf16 if bf16 else lib.me_conv_wgrad_workspace_bytes)(
-        koffs, volume, c_in, c_out))
+    ck = ("wgrad", c_in, c_out, bf16)
+    cfg = km._launch_cache.get(ck)
+    if cfg is None:
+        koffs = (ctypes.c_int64 * (volume + 1))(*km.k_offsets)
+        wsb = int((lib.me_conv_wgrad_workspace_bytes_bf16 if bf16 else lib.me_conv_wgrad_workspace_bytes)(
+            koffs, volume, c_in, c_out))
+        cfg = (koffs, wsb, _ptr(km.in_pairs), _ptr(km.out_pairs), _ptr(km.k_offsets_dev))
+        km._launch_cache[ck] = cfg
+    koffs, wsb, p_in, p_out, p_koffs = cfg
+    if _WGRAD_TUNING:   # the debug switches change the workspace need
+        wsb = int((lib.me_conv_wgrad_workspace_bytes_bf16 if bf16 else lib.me_conv_wgrad_workspace_bytes)(
+            koffs, volume, c_in, c_out))
     ws = _workspace(wsb, dev)
     fn = lib.me_conv_wgrad_bf16 if bf16 else lib.me_conv_wgrad_f32
-    with torch.cuda.device(dev):
+    stream = _stream(dev)
+    with _on(dev):
         _timed("conv_wgrad", dev, lambda: _lib.check(fn(
-            _ptr(in_feat), c_in, _ptr(grad_out), c_out, _ptr(km.in_pairs), _ptr(km.out_pairs), koffs,
-            _ptr(km.k_offsets_dev), volume, _ptr(grad_w), _ptr(ws), ws.numel(), _stream(dev))),
-            flops=2.0 * km.n_pairs * c_in * c_out)
+            in_feat.data_ptr(), c_in, grad_out.data_ptr(), c_out, p_in, p_out, koffs, p_koffs, volume,
+            grad_w.data_ptr(), ws.data_ptr(), ws.numel(), stream)), flops=2.0 * km.n_pairs * c_in * c_out)
     return grad_in, grad_w if kernel.dtype == torch.float32 else grad_w.to(kernel.dtype)
 
 
@@ -906,7 +949,7 @@ def _pool_sum(src, tbl, n_tgt, volume, src_count=None, average=False, want_count
     c = int(src.shape[1])
     out = torch.empty((n_tgt, c), dtype=torch.float32, device=dev)
     cnt = torch.empty(max(n_tgt, 1), dtype=torch.float32, device=dev)[:n_tgt] if want_count else None
-    with torch.cuda.device(dev):
+    with _on(dev):
         _timed("pool_sum", dev, lambda: _lib.check(lib.me_pool_sum_f32(
             _ptr(src), c, _ptr(tbl), n_tgt, volume, _ptr(src_count), 1 if average else 0, _ptr(out), _ptr(cnt),
             _stream(dev))))
@@ -944,7 +987,7 @@ def LocalPoolingForwardGPU(in_feat, kernel_size, kernel_stride, kernel_dilation,
         c = int(in_feat.shape[1])
         out = torch.empty((km.n_out, c), dtype=torch.float32, device=dev)
         mask = torch.empty((km.n_out, c), dtype=torch.int32, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _timed("pool_max", dev, lambda: _lib.check(lib.me_pool_max_f32(
                 _ptr(in_feat), c, _ptr(km.table("out")), km.n_out, km.volume, _ptr(out), _ptr(mask), _stream(dev))))
         return out, mask
@@ -972,7 +1015,7 @@ def LocalPoolingBackwardGPU(in_feat, grad_out_feat, num_nonzero, kernel_size, ke
         dev = in_feat.device
         c = int(in_feat.shape[1])
         grad_in = torch.empty((km.n_in, c), dtype=torch.float32, device=dev)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.check(lib.me_pool_max_backward_f32(_ptr(grad_out_feat), c, _ptr(km.table("in")), km.n_in, km.volume,
                                                     _ptr(num_nonzero), _ptr(grad_in), _stream(dev)))
         return grad_in
@@ -1022,7 +1065,7 @@ def _global_pool(src, src2, rows, n_batch, mode):
     arg = torch.empty((n_batch, c), dtype=torch.int32, device=dev) if mode == 2 else None
     cnt = torch.empty(n_batch, dtype=torch.float32, device=dev) if mode != 2 else None
     ws = _workspace(lib.me_global_pool_workspace_bytes(n, n_batch, c), dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(lib.me_global_pool_f32(_ptr(src), _ptr(src2), c, _ptr(rows), n, n_batch, mode, _ptr(out), _ptr(arg),
                                           _ptr(cnt), _ptr(ws), ws.numel(), _stream(dev)))
     return out, arg, cnt
@@ -1066,7 +1109,7 @@ def GlobalPoolingBackwardGPU(in_feat, grad_out_feat, num_nonzero, pooling_mode, 
     rows = manager._origin_rows(in_key)
     lib = _lib.load()
     grad_in = torch.empty((n, c), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(lib.me_broadcast_f32(None, _ptr(g), _ptr(rows), n, c, 0, _ptr(grad_in), _stream(dev)))
     return grad_in
 
@@ -1083,7 +1126,7 @@ def BroadcastForwardGPU(in_feat, in_feat_glob, broadcast_mode, in_key, glob_key,
     lib = _lib.load()
     dev = in_feat.device
     out = torch.empty_like(in_feat)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(lib.me_broadcast_f32(_ptr(in_feat), _ptr(in_feat_glob), _ptr(rows), in_feat.shape[0],
                                         in_feat.shape[1], 1 if op == BroadcastMode.ELEMENTWISE_MULTIPLICATION else 0,
                                         _ptr(out), _stream(dev)))
@@ -1105,7 +1148,7 @@ def BroadcastBackwardGPU(in_feat, in_feat_glob, grad_out_feat, broadcast_mode, i
         grad_glob, _, _ = _global_pool(grad_out_feat, None, rows, n_batch, 0)
     else:
         grad_in = torch.empty_like(in_feat)
-        with torch.cuda.device(dev):
+        with _on(dev):
             _lib.check(lib.me_broadcast_f32(_ptr(grad_out_feat), _ptr(in_feat_glob), _ptr(rows), in_feat.shape[0],
                                             in_feat.shape[1], 1, _ptr(grad_in), _stream(dev)))
         grad_glob, _, _ = _global_pool(grad_out_feat, in_feat, rows, n_batch, 0)
@@ -1131,7 +1174,7 @@ def bn_stats(x, eps, momentum, running_mean=None, running_var=None):
     mean = torch.empty(c, dtype=torch.float32, device=dev)
     rstd = torch.empty(c, dtype=torch.float32, device=dev)
     ws = _workspace(int(lib.me_bn_workspace_bytes(n, c)), dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(lib.me_bn_stats(_ptr(x), 1 if x.dtype == torch.bfloat16 else 0, n, c, float(eps),
                                    float(momentum), _ptr(mean), _ptr(rstd), _ptr(running_mean), _ptr(running_var),
                                    _ptr(ws), ws.numel(), _stream(dev)))
@@ -1143,7 +1186,7 @@ def bn_apply(x, mean, rstd, gamma, beta):
     lib = _lib.load()
     dev = x.device
     y = torch.empty_like(x)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(lib.me_bn_apply(_ptr(x), 1 if x.dtype == torch.bfloat16 else 0, int(x.shape[0]), int(x.shape[1]),
                                    _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(y), _stream(dev)))
     return y
@@ -1162,7 +1205,7 @@ def bn_backward(x, dy, mean, rstd, gamma):
     gg = torch.empty(c, dtype=torch.float32, device=dev)
     gb = torch.empty(c, dtype=torch.float32, device=dev)
     ws = _workspace(int(lib.me_bn_workspace_bytes(n, c)), dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(lib.me_bn_backward(_ptr(x), _ptr(dy), 1 if x.dtype == torch.bfloat16 else 0, n, c, _ptr(mean),
                                       _ptr(rstd), _ptr(gamma), _ptr(dx), _ptr(gg), _ptr(gb), _ptr(ws), ws.numel(),
                                       _stream(dev)))

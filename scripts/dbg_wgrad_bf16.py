@@ -5,6 +5,7 @@ from minkowskiengine_amd import backend as MEB, _lib
 from bench import make_scene
 dev = torch.device("cuda:0")
 lib = _lib.load()
+MEB._WGRAD_TUNING = True
 coords = make_scene(20000, 40, 0).to(dev)
 mgr = MEB.CoordinateMapManagerGPU_c10()
 key, _ = mgr.insert_and_map(coords, [1, 1, 1], "")

@@ -11,6 +11,7 @@ from bench import make_scene
 
 dev = torch.device("cuda:0")
 lib = _lib.load()
+MEB._WGRAD_TUNING = True
 
 
 def time_it(fn, iters=20, warm=3):

@@ -11,6 +11,7 @@ from bench import make_scene
 
 dev = torch.device("cuda:0")
 lib = _lib.load()
+MEB._WGRAD_TUNING = True
 shapes = [(64, 128), (128, 64), (32, 32), (32, 64), (96, 96), (256, 256), (64, 64)]
 CONFIGS = [tuple(int(v) for v in c.split(":")) for c in os.environ.get("CONFIGS", "0:0,0:3,-1:0").split(",")]
 for extent in (70, 215):
