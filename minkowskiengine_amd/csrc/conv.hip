@@ -76,8 +76,7 @@ __device__ __forceinline__ void mma_groups(const float *__restrict__ a0p, const 
   for (int s4 = 0; s4 < KQ / 4; ++s4) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      if (VAR & 32) a[s4][r] = f32x4{wreg[s4], wreg[s4 + 1], 1.f, 2.f};  // ablation: no operand reads from LDS
-      else a[s4][r] = *reinterpret_cast<const f32x4 *>(a0p + r * 16 * A_LD + pofs[s4]);
+      a[s4][r] = *reinterpret_cast<const f32x4 *>(a0p + r * 16 * A_LD + pofs[s4]);
     }
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -161,17 +160,16 @@ __global__ __launch_bounds__(256) void k_pack_weights(const float *__restrict__ 
 // After the last batch every target row is written exactly once with coalesced 16-byte stores (rows
 // without entries get zeros: no zero-fill pass, no global atomics).
 // VAR bits (timing ablations only; 0 is the shipped configuration): 16: no gather traffic (constant rows);
-// 2: no per-batch weight loads; 32: no MFMA operand reads from LDS (INVALID: hipcc folds the MFMAs);
-// 64: no read-add-write of the LDS accumulator; 128: no stage writes; 256: s_memtime phase counters;
-// 512: two stage buffers, one barrier per batch; 1024 + n: stagger; 2048 + n: n KiB of LDS padding
+// 2: no per-batch weight loads; 4: no barriers (timing only); 64: no read-add-write of the LDS accumulator;
+// 128: no stage writes; 256: s_memtime phase counters; 2048 + n: n KiB of LDS padding (caps the resident
+// workgroups).  Restructurings that were measured and removed again (logs under profiles/): two stage buffers
+// with one barrier per batch, gathering two batches ahead, staggered start of the co-resident workgroups,
+// 128-column workgroups.
 // EXACT: c_src is a multiple of KC (and of 4): the gather needs no channel guards.
 // phase cycle counters of the VAR & 256 instrumentation build (summed over wave 0 of every workgroup):
 // 0 barrier A, 1 stage write (incl. the wait for the gathered rows), 2 barrier B, 3 load issue, 4 multiply,
 // 5 prologue (accumulator clear + first loads), 6 epilogue, 7 batches
 __device__ unsigned long long d_conv_timing[8];
-// VAR & 1024 (experiment): the workgroup that sits in the odd wave slot of its SIMDs sleeps d_conv_stagger x 64
-// cycles before it starts, so that the two co-resident workgroups of a CU do not run their phases in lockstep
-__device__ int d_conv_stagger;
 
 template <int NC, int KC, bool EXACT, int VAR>
 __global__ __launch_bounds__(NC * 4, (NC == 128 ? 2 : 3)) void k_conv_tile_f32(
@@ -192,10 +190,9 @@ __global__ __launch_bounds__(NC * 4, (NC == 128 ? 2 : 3)) void k_conv_tile_f32(
 
   const int cap_rows = batch_groups * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NBUF = (VAR & 512) ? 2 : 1;  // 512: double-buffered stage, one barrier per batch (experiment)
   float *s_acc = reinterpret_cast<float *>(smem);                      // [(tile_rows + 1) x ACC_LD]
-  float *s_a = s_acc + (tile_rows + 1) * ACC_LD;                       // [NBUF][cap_rows x A_LD]
-  int32_t *s_dst = reinterpret_cast<int32_t *>(s_a + NBUF * cap_rows * A_LD);  // [NBUF][cap_rows]
+  float *s_a = s_acc + (tile_rows + 1) * ACC_LD;                       // [cap_rows x A_LD]
+  int32_t *s_dst = reinterpret_cast<int32_t *>(s_a + cap_rows * A_LD);  // [cap_rows]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -216,14 +213,6 @@ __global__ __launch_bounds__(NC * 4, (NC == 128 ? 2 : 3)) void k_conv_tile_f32(
 #pragma unroll
   for (int s4 = 0; s4 < KQ / 4; ++s4) pofs[s4] = ((4 * s4 + q) ^ stage_swz(KC, i16)) * 4;
 
-  if (VAR & 1024) {
-    // HW_REG_HW_ID (id 4), bits [3:0] = wave slot within the SIMD
-    const unsigned slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11));
-    if (slot & 1u) {
-      const int n = d_conv_stagger;
-      for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
-    }
-  }
   unsigned long long tm[7] = {0, 0, 0, 0, 0, 0, 0};
   unsigned long long t_prev = (VAR & 256) ? __builtin_amdgcn_s_memtime() : 0ull;
   auto tick = [&](int slot) {
@@ -256,11 +245,15 @@ __global__ __launch_bounds__(NC * 4, (NC == 128 ? 2 : 3)) void k_conv_tile_f32(
   };
 
   // software pipeline registers
-  f32x4 stage[ITER];    // gathered rows of the batch that is written to LDS next
-  int32_t dstv = tile_rows;
+  struct GatherSet {
+    f32x4 stage[ITER];    // gathered rows of a batch on their way to the LDS stage buffer
+    int32_t sprev[ITER];  // the plan indices they were gathered with (padding slots: -1 -> zeros)
+    int32_t dstv;         // this thread's target-row entry of the batch
+  };
+  GatherSet G0;
+  G0.dstv = tile_rows;
   int32_t sidx[ITER];   // plan indices of the batch that is gathered next (rows beyond the batch repeat its
                         // last row: they are staged into slots nobody reads)
-  int32_t sprev[ITER];  // the indices the rows in `stage` were gathered with (padding slots: -1 -> zeros)
   float wreg[KQ], wnxt[KQ];
 
   auto load_sidx = [&](int g0, int ng) {
@@ -270,9 +263,11 @@ __global__ __launch_bounds__(NC * 4, (NC == 128 ? 2 : 3)) void k_conv_tile_f32(
   };
   // issue the gather of the batch whose indices sit in sidx (global -> registers); nothing here consumes
   // the result
-  auto gather = [&](int chunk, int g0, int ng) {
+  auto gather = [&](GatherSet &G, int chunk, int g0, int ng) {
+    f32x4 (&stage)[ITER] = G.stage;
+    int32_t (&sprev)[ITER] = G.sprev;
     const int c0 = chunk * KC;
-    dstv = plan_dst[(int64_t)g0 * 16 + min(tid, ng * 16 - 1)];
+    G.dstv = plan_dst[(int64_t)g0 * 16 + min(tid, ng * 16 - 1)];
 #pragma unroll
     for (int j = 0; j < ITER; ++j) {
       const int ch = c0 + ((j * NT + tid) % F4) * 4;
@@ -294,9 +289,12 @@ __global__ __launch_bounds__(NC * 4, (NC == 128 ? 2 : 3)) void k_conv_tile_f32(
       }
     }
   };
-  auto write_stage = [&](int chunk, int buf = 0) {
+  auto write_stage = [&](GatherSet &G, int chunk) {
+    f32x4 (&stage)[ITER] = G.stage;
+    int32_t (&sprev)[ITER] = G.sprev;
+    const int32_t dstv = G.dstv;
     const int c0 = chunk * KC;
-    float *s_ab = s_a + buf * cap_rows * A_LD;
+    float *s_ab = s_a;
 #pragma unroll
     for (int j = 0; j < ITER; ++j) {
       const int idx = j * NT + tid;
@@ -317,7 +315,7 @@ __global__ __launch_bounds__(NC * 4, (NC == 128 ? 2 : 3)) void k_conv_tile_f32(
         *reinterpret_cast<f32x4 *>(&s_ab[r * A_LD + slot * 4]) = t;
       }
     }
-    if (tid < cap_rows) s_dst[buf * cap_rows + tid] = dstv;
+    if (tid < cap_rows) s_dst[tid] = dstv;
   };
   bool w_loaded = false;
   auto load_w = [&](int chunk, int k) {
@@ -343,15 +341,15 @@ __global__ __launch_bounds__(NC * 4, (NC == 128 ? 2 : 3)) void k_conv_tile_f32(
     locate(2, chC, gC, nC, kC);
     load_w(chA, kA);
     load_sidx(gA, nA);
-    gather(chA, gA, nA);
+    gather(G0, chA, gA, nA);
     load_sidx(gB, nB);
 
-    auto multiply = [&](int n_groups, int buf) {
+    auto multiply = [&](int n_groups) {
       // After the MFMA this lane holds columns wave*16 + q*4 .. +3 of target row s_dst[g*16 + i16]; columns are
       // private to this wave -> plain LDS read-add-write in a fixed order; padding slots land in the dummy row
       // `tile_rows`.
-      const float *a0p = &s_a[buf * cap_rows * A_LD + i16 * A_LD];
-      const int32_t *dstp = &s_dst[buf * cap_rows + i16];
+      const float *a0p = &s_a[i16 * A_LD];
+      const int32_t *dstp = &s_dst[i16];
       float *accp = &s_acc[wave * 16 + q * 4];
       if (n_groups == 4) {
         mma_groups<2, KQ, A_LD, ACC_LD, VAR>(a0p, pofs, wreg, dstp, accp);
@@ -366,36 +364,10 @@ __global__ __launch_bounds__(NC * 4, (NC == 128 ? 2 : 3)) void k_conv_tile_f32(
       }
     };
     tick(5);
-    if (VAR & 512) {
-      // EXPERIMENT: two stage buffers, ONE barrier per batch.  Batch it is multiplied out of buffer it & 1; right
-      // after its own multiply a wave writes the rows of batch it + 1 (gathered meanwhile) into the other buffer
-      // and requests batch it + 2; the barrier at the end of the iteration publishes the buffer and retires the
-      // readers of the one that is overwritten next.
-      write_stage(chA, 0);
-#pragma unroll
-      for (int sx = 0; sx < KQ; ++sx) wreg[sx] = wnxt[sx];
-      load_w(chB, kB);
-      gather(chB, gB, nB);
-      load_sidx(gC, nC);
-      __syncthreads();
-      for (int it = 0; it < n_it; ++it) {
-        multiply(nA, it & 1);
-        chA = chB; gA = gB; nA = nB; kA = kB;
-        chB = chC; gB = gC; nB = nC; kB = kC;
-        locate(it + 3, chC, gC, nC, kC);
-        write_stage(chA, (it + 1) & 1);  // rows of batch it + 1
-#pragma unroll
-        for (int sx = 0; sx < KQ; ++sx) wreg[sx] = wnxt[sx];
-        load_w(chB, kB);                 // batch it + 2
-        gather(chB, gB, nB);
-        load_sidx(gC, nC);
-        __syncthreads();
-      }
-    } else
     for (int it = 0; it < n_it; ++it) {
       if (!(VAR & 4)) __syncthreads();  // everybody is done reading the previous batch from s_a / s_dst
       tick(0);
-      write_stage(chA);  // rows of batch it (gathered during the previous iteration)
+      write_stage(G0, chA);  // rows of batch it (gathered during the previous iteration)
 #pragma unroll
       for (int sx = 0; sx < KQ; ++sx) wreg[sx] = wnxt[sx];  // its weights were requested before its rows
       if (VAR & 256) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -404,10 +376,10 @@ __global__ __launch_bounds__(NC * 4, (NC == 128 ? 2 : 3)) void k_conv_tile_f32(
       tick(2);
       // next batch: its weights, its rows, and the indices of the one after
       load_w(chB, kB);
-      gather(chB, gB, nB);
+      gather(G0, chB, gB, nB);
       load_sidx(gC, nC);
       tick(3);
-      multiply(nA, 0);
+      multiply(nA);
       if (VAR & 256) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       tick(4);
       chA = chB; gA = gB; nA = nB; kA = kB;
@@ -1299,7 +1271,6 @@ static int launch_conv_tile(const float *src, int c_src, const float *wp, int c_
                             int tile_rows, int batch_groups, hipStream_t stream) {
   // variants 2048 + n (experiment): n KiB of unused LDS, to cap the resident workgroups per CU
   const int lds = conv_lds_bytes(NC, KC, tile_rows, batch_groups) +
-                  ((VAR & 512) ? batch_groups * 16 * (stage_ld(KC) * 4 + 4) : 0) +
                   (g_conv_variant >= 2048 ? (g_conv_variant - 2048) * 1024 : 0);
   ME_CHECK(lds <= kLdsBudget, "tile_rows / batch_groups too large for the LDS of one workgroup");
   const bool exact = (c_src % KC) == 0;
@@ -1523,8 +1494,6 @@ int me_conv_target_f32(const float *src, int64_t n_src, int32_t c_src, const flo
 #define ME_CONV_ARGS                                                                                         \
   src, c_src, wp, c_dst, v.slabs, plan_src, plan_dst, batch_desc, tile_bptr, order, dst, n_tgt, tile_rows, \
       batch_groups, stream
-  if (g_conv_variant >= 1024 && g_conv_variant < 2048 && v.nc == 64 && v.kc == 64)
-    return launch_conv_tile<64, 64, 1024>(ME_CONV_ARGS);
   if (g_conv_variant >= 2048 && v.nc == 64 && v.kc == 64) return launch_conv_tile<64, 64, 0>(ME_CONV_ARGS);
   if (g_conv_variant == 1000 && v.kc == 64 && c_dst >= 128 && c_dst % 128 == 0)  // experiment: 128-column workgroups
     return launch_conv_tile<128, 64, 0>(src, c_src, wp, c_dst, c_dst / 128, plan_src, plan_dst, batch_desc, tile_bptr,
@@ -1538,7 +1507,6 @@ int me_conv_target_f32(const float *src, int64_t n_src, int32_t c_src, const flo
       case 4: return launch_conv_tile<64, 64, 4>(ME_CONV_ARGS);
       case 80: return launch_conv_tile<64, 64, 80>(ME_CONV_ARGS);
       case 256: return launch_conv_tile<64, 64, 256>(ME_CONV_ARGS);
-      case 512: return launch_conv_tile<64, 64, 512>(ME_CONV_ARGS);
       case 272: return launch_conv_tile<64, 64, 272>(ME_CONV_ARGS);
       default: break;
     }
@@ -1557,13 +1525,7 @@ int me_conv_target_f32(const float *src, int64_t n_src, int32_t c_src, const flo
 #undef ME_CONV_ARGS
 }
 
-void me_debug_set_conv_variant(int variant) {
-  g_conv_variant = variant;
-  if (variant >= 1024 && variant < 2048) {  // stagger experiment: 1024 + sleep units of 64 cycles
-    const int units = variant - 1024;
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(d_conv_stagger), &units, sizeof(units));
-  }
-}
+void me_debug_set_conv_variant(int variant) { g_conv_variant = variant; }
 
 int me_debug_conv_timing(uint64_t *out8, int32_t reset) {
   unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
