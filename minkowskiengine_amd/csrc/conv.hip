@@ -1220,6 +1220,11 @@ static ConvVariant conv_variant(int c_src, int c_dst) {
 // Tile height for a (target rows, kernel shape) problem, shared by the fp32 and bf16 kernels: tiles x column
 // slabs just below a multiple of the GPU's resident-workgroup slots, the accumulator tile + stage buffer within
 // the LDS of `occ` resident workgroups, density steering the trade-off against the 16-row group padding.
+// two barriers, the stage write and the exposed part of the loads of one batch (phase timing,
+// profiles/r01_phase_timing_conv_v7.log: ~2150 cycles); with 400 the model preferred many small tiles on
+// sparse maps, where T = 256 measured 12-21 % faster at config 5
+constexpr double kBatchOverheadCycles = 2000.0;
+
 int plan_tile_rows(const PlanShape &s, int64_t n_tgt, int64_t volume, int64_t n_pairs) {
   const int waves = s.nc / 16;
   const int cus = device_cu_count();
@@ -1235,7 +1240,9 @@ int plan_tile_rows(const PlanShape &s, int64_t n_tgt, int64_t volume, int64_t n_
     for (int rounds = 1; rounds <= 64; ++rounds) {
       int64_t t = ceil_div(n_tgt * s.slabs, slots * rounds);
       if (t < ME_GROUP_ROWS) t = ME_GROUP_ROWS;
-      if (t > ME_MAX_TILE_ROWS) continue;
+      // (the tallest tile is a candidate of its own: on sparse maps the per-offset cost of a tile hardly grows
+      // with its height, so fewer, taller tiles win even when they do not fill the last round)
+      if (t > ME_MAX_TILE_ROWS) t = ME_MAX_TILE_ROWS;
       const int64_t lds = (t + 1) * (s.nc + kAccPad) * 4 + (int64_t)cap * 16 * s.stage_row_bytes;
       if (lds * occ > kLdsBudget) continue;
       const double m = (double)t * p;  // expected entries of an off-centre item
@@ -1244,11 +1251,12 @@ int plan_tile_rows(const PlanShape &s, int64_t n_tgt, int64_t volume, int64_t n_
       const double batches = (double)ceil_div(ceil_div(t, 16), cap) +
                              (double)(volume - 1) * (m <= 0 ? 0.0 : (m < 3.0 ? 1.0 - exp(-m) : ceil(g_side / cap)));
       const int64_t items = ceil_div(n_tgt, t) * s.slabs;
-      const double real_rounds = (double)ceil_div(items, slots);
+      // workgroups are dispatched as slots free up: half way between whole rounds and perfect packing
+      const double real_rounds = 0.5 * (double)ceil_div(items, slots) + 0.5 * (double)items / (double)slots;
       // cycles of one tile if its waves had their SIMDs alone: per-group work + per-batch barrier / pipeline
       // overhead + store / pipeline fill per tile; occ * waves / 4 waves share a SIMD
       const double tile_cycles =
-          s.chunks * (groups * s.group_cycles + batches * 400.0) + (double)t * s.nc * 0.4 + 3000.0;
+          s.chunks * (groups * s.group_cycles + batches * kBatchOverheadCycles) + (double)t * s.nc * 0.4 + 3000.0;
       const double cost = real_rounds * tile_cycles * (double)(occ * waves) / 4.0 *
                           (1.0 + 0.15 * 12.0 / (occ * waves));
       if (cost < best_cost) {
