@@ -53,6 +53,9 @@ class MinkUNetBase(nn.Module):
             self.dec.append(self._make_layer(P[4 + level], L[4 + level]))
         self.final = ME.MinkowskiConvolution(P[7] * E, out_channels, kernel_size=1, bias=True, dimension=D)
         self.relu = ME.MinkowskiReLU(inplace=True)
+        # every one of these batch norms feeds self.relu directly in forward(): let the batch-norm kernels rectify
+        for bn in [self.bn0, *self.down_bn, *self.up_bn]:
+            bn.fuse_relu = True
         self._init_weights()
 
     def _init_weights(self):

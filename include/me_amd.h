@@ -314,20 +314,23 @@ int me_segment_sum_f32(const float *src_dev, int32_t c, const int64_t *perm_dev,
  *                   running_var are given they are updated as torch does (momentum, unbiased variance).
  *                   Two-level reduction in a fixed order (Chan's combination of per-chunk mean / M2): bitwise
  *                   reproducible.
- *   me_bn_apply:    y = (x - mean) * rstd * gamma + beta        (gamma / beta may be NULL)
+ *   me_bn_apply:    y = (x - mean) * rstd * gamma + beta        (gamma / beta may be NULL); relu != 0: y = max(y, 0)
  *   me_bn_backward: grad_beta = sum dy, grad_gamma = sum dy * xhat,
- *                   dx = gamma * rstd * (dy - grad_beta / n - xhat * grad_gamma / n)   (training-mode gradient)
+ *                   dx = gamma * rstd * (dy - grad_beta / n - xhat * grad_gamma / n)   (training-mode gradient);
+ *                   relu != 0: dy is first masked where the forward output (recomputed from x) was not positive
+ *                   (batch norm + ReLU fused: MinkowskiBatchNorm followed by MinkowskiReLU in the reference)
  * workspace bytes for stats and backward: me_bn_workspace_bytes(n, c). */
 int64_t me_bn_workspace_bytes(int64_t n, int32_t c);
 int me_bn_stats(const void *x_dev, int32_t is_bf16, int64_t n, int32_t c, float eps, float momentum,
                 float *mean_dev, float *rstd_dev, float *running_mean_dev, float *running_var_dev,
                 void *workspace_dev, int64_t workspace_bytes, void *stream);
 int me_bn_apply(const void *x_dev, int32_t is_bf16, int64_t n, int32_t c, const float *mean_dev,
-                const float *rstd_dev, const float *gamma_dev, const float *beta_dev, void *y_dev, void *stream);
+                const float *rstd_dev, const float *gamma_dev, const float *beta_dev, int32_t relu, void *y_dev,
+                void *stream);
 int me_bn_backward(const void *x_dev, const void *dy_dev, int32_t is_bf16, int64_t n, int32_t c,
-                   const float *mean_dev, const float *rstd_dev, const float *gamma_dev, void *dx_dev,
-                   float *grad_gamma_dev, float *grad_beta_dev, void *workspace_dev, int64_t workspace_bytes,
-                   void *stream);
+                   const float *mean_dev, const float *rstd_dev, const float *gamma_dev, const float *beta_dev,
+                   int32_t relu, void *dx_dev, float *grad_gamma_dev, float *grad_beta_dev, void *workspace_dev,
+                   int64_t workspace_bytes, void *stream);
 
 /* Plain VALU + atomics versions on the pair lists (debug cross-check only; never the default).
  * out / grad_in / grad_w must be zero-filled by the caller. */

@@ -71,9 +71,9 @@ SIGNATURES = {
     "me_bn_workspace_bytes": (c_i64, [c_i64, c_i32]),
     "me_bn_stats": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i32, ctypes.c_float, ctypes.c_float, c_vp, c_vp, c_vp, c_vp,
                                    c_vp, c_i64, c_vp]),
-    "me_bn_apply": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "me_bn_backward": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
-                                      c_i64, c_vp]),
+    "me_bn_apply": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
+    "me_bn_backward": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp,
+                                      c_vp, c_i64, c_vp]),
     "me_coords_expand_region": (ctypes.c_int, [c_vp, c_i64, c_i32, _P_REGION, _P_I32, c_vp, c_vp, c_vp]),
     "me_coords_quantize_labels": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp]),
     "me_segment_sum_f32": (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp]),

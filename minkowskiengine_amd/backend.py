@@ -1181,19 +1181,20 @@ def bn_stats(x, eps, momentum, running_mean=None, running_var=None):
     return mean, rstd
 
 
-def bn_apply(x, mean, rstd, gamma, beta):
+def bn_apply(x, mean, rstd, gamma, beta, relu=False):
     _bn_check(x)
     lib = _lib.load()
     dev = x.device
     y = torch.empty_like(x)
     with _on(dev):
         _lib.check(lib.me_bn_apply(_ptr(x), 1 if x.dtype == torch.bfloat16 else 0, int(x.shape[0]), int(x.shape[1]),
-                                   _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), _ptr(y), _stream(dev)))
+                                   _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), 1 if relu else 0, _ptr(y),
+                                   _stream(dev)))
     return y
 
 
-def bn_backward(x, dy, mean, rstd, gamma):
-    """-> (dx, grad_gamma, grad_beta) of training-mode batch norm."""
+def bn_backward(x, dy, mean, rstd, gamma, beta=None, relu=False):
+    """-> (dx, grad_gamma, grad_beta) of training-mode batch norm (followed by a fused ReLU when `relu`)."""
     _bn_check(x)
     lib = _lib.load()
     dev = x.device
@@ -1207,8 +1208,8 @@ def bn_backward(x, dy, mean, rstd, gamma):
     ws = _workspace(int(lib.me_bn_workspace_bytes(n, c)), dev)
     with _on(dev):
         _lib.check(lib.me_bn_backward(_ptr(x), _ptr(dy), 1 if x.dtype == torch.bfloat16 else 0, n, c, _ptr(mean),
-                                      _ptr(rstd), _ptr(gamma), _ptr(dx), _ptr(gg), _ptr(gb), _ptr(ws), ws.numel(),
-                                      _stream(dev)))
+                                      _ptr(rstd), _ptr(gamma), _ptr(beta), 1 if relu else 0, _ptr(dx), _ptr(gg),
+                                      _ptr(gb), _ptr(ws), ws.numel(), _stream(dev)))
     return dx, gg, gb
 
 

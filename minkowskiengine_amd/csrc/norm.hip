@@ -164,7 +164,7 @@ template <typename T, int V>
 __global__ __launch_bounds__(256) void k_bn_apply(const T *__restrict__ x, int64_t n, int c,
                                                  const float *__restrict__ mean, const float *__restrict__ rstd,
                                                  const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                 T *__restrict__ y) {
+                                                 T *__restrict__ y, int relu) {
   const int P = c / V;
   const int W = min(P, (int)blockDim.x);
   const int R = max(1, (int)blockDim.x / P);
@@ -184,7 +184,10 @@ __global__ __launch_bounds__(256) void k_bn_apply(const T *__restrict__ x, int64
       if (r < n) {
         Row<T, V> t = load_row<T, V>(x + r * c + p * V);
 #pragma unroll
-        for (int j = 0; j < V; ++j) t.v[j] = t.v[j] * a[j] + b[j];
+        for (int j = 0; j < V; ++j) {
+          t.v[j] = t.v[j] * a[j] + b[j];
+          if (relu) t.v[j] = fmaxf(t.v[j], 0.f);
+        }
         store_row<T, V>(y + r * c + p * V, t);
       }
     }
@@ -197,6 +200,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_partial(const T *__restrict__ x,
                                                        int64_t n, int c, int chunks,
                                                        const float *__restrict__ mean,
                                                        const float *__restrict__ rstd,
+                                                       const float *__restrict__ gamma,
+                                                       const float *__restrict__ beta, int relu,
                                                        float *__restrict__ part_dy,
                                                        float *__restrict__ part_dyx) {
   extern __shared__ float s_red[];  // [R][2][c]
@@ -207,14 +212,16 @@ __global__ __launch_bounds__(256) void k_bn_bwd_partial(const T *__restrict__ x,
     const int p = p0 + (int)threadIdx.x % min(P, (int)blockDim.x);
     const int rl = (int)threadIdx.x / min(P, (int)blockDim.x);
     const bool active = rl < R && p < P;
-    float s1[V], s2[V], m[V], rs[V];
+    float s1[V], s2[V], m[V], rs[V], ga[V], be[V];
 #pragma unroll
-    for (int j = 0; j < V; ++j) s1[j] = s2[j] = m[j] = rs[j] = 0.f;
+    for (int j = 0; j < V; ++j) s1[j] = s2[j] = m[j] = rs[j] = ga[j] = be[j] = 0.f;
     if (active) {
 #pragma unroll
       for (int j = 0; j < V; ++j) {
         m[j] = mean[p * V + j];
         rs[j] = rstd[p * V + j];
+        ga[j] = gamma ? gamma[p * V + j] : 1.f;
+        be[j] = beta ? beta[p * V + j] : 0.f;
       }
 #pragma unroll 4
       for (int64_t r = r0 + rl; r < r1; r += R) {
@@ -222,8 +229,11 @@ __global__ __launch_bounds__(256) void k_bn_bwd_partial(const T *__restrict__ x,
         const Row<T, V> tg = load_row<T, V>(dy + r * c + p * V);
 #pragma unroll
         for (int j = 0; j < V; ++j) {
-          s1[j] += tg.v[j];
-          s2[j] += tg.v[j] * ((tx.v[j] - m[j]) * rs[j]);
+          const float xh = (tx.v[j] - m[j]) * rs[j];
+          // fused ReLU: the gradient passes where the forward output xh * gamma + beta was positive
+          const float g = (relu && !(xh * ga[j] + be[j] > 0.f)) ? 0.f : tg.v[j];
+          s1[j] += g;
+          s2[j] += g * xh;
         }
       }
 #pragma unroll
@@ -284,7 +294,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T *__restrict__ x, c
                                                      const float *__restrict__ rstd,
                                                      const float *__restrict__ gamma,
                                                      const float *__restrict__ sum_dy,
-                                                     const float *__restrict__ sum_dyx, T *__restrict__ dx) {
+                                                     const float *__restrict__ sum_dyx, T *__restrict__ dx,
+                                                     const float *__restrict__ beta, int relu) {
   const int P = c / V;
   const int W = min(P, (int)blockDim.x);
   const int R = max(1, (int)blockDim.x / P);
@@ -293,7 +304,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T *__restrict__ x, c
   if (rl >= R) return;
   const float inv_n = 1.f / (float)n;
   for (int p = (int)threadIdx.x % W; p < P; p += W) {
-    float ca[V], cb[V], cc[V];
+    float ca[V], cb[V], cc[V], za[V], zb[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) {
       const int ch = p * V + j;
@@ -303,6 +314,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T *__restrict__ x, c
       ca[j] = a;
       cb[j] = -a * k;
       cc[j] = a * (mean[ch] * k - sum_dy[ch] * inv_n);
+      za[j] = a;                                    // forward output z = x * za + zb (fused-ReLU mask)
+      zb[j] = (beta ? beta[ch] : 0.f) - mean[ch] * a;
     }
 #pragma unroll
     for (int i = 0; i < kBnRowsPerThread; ++i) {
@@ -312,7 +325,10 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T *__restrict__ x, c
         const Row<T, V> tg = load_row<T, V>(dy + r * c + p * V);
         Row<T, V> out;
 #pragma unroll
-        for (int j = 0; j < V; ++j) out.v[j] = tg.v[j] * ca[j] + tx.v[j] * cb[j] + cc[j];
+        for (int j = 0; j < V; ++j) {
+          const float g = (relu && !(tx.v[j] * za[j] + zb[j] > 0.f)) ? 0.f : tg.v[j];
+          out.v[j] = g * ca[j] + tx.v[j] * cb[j] + cc[j];
+        }
         store_row<T, V>(dx + r * c + p * V, out);
       }
     }
@@ -349,23 +365,23 @@ static int bn_stats(const T *x, int64_t n, int c, float eps, float momentum, flo
 
 template <typename T>
 static int bn_apply(const T *x, int64_t n, int c, const float *mean, const float *rstd, const float *gamma,
-                    const float *beta, T *y, hipStream_t stream) {
+                    const float *beta, T *y, int relu, hipStream_t stream) {
   constexpr int W = 16 / (int)sizeof(T);  // channels per 16-byte access
   const bool aligned = (uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0;
   const int v = (aligned && c % W == 0) ? W : ((aligned && c % 4 == 0) ? 4 : 1);
   const int pieces = c / v;
   const dim3 grid((unsigned)ceil_div(n, (int64_t)(pieces >= 256 ? 1 : 256 / pieces) * kBnRowsPerThread));
-  if (v == W) hipLaunchKernelGGL((k_bn_apply<T, W>), grid, dim3(256), 0, stream, x, n, c, mean, rstd, gamma, beta, y);
-  else if (v == 4) hipLaunchKernelGGL((k_bn_apply<T, 4>), grid, dim3(256), 0, stream, x, n, c, mean, rstd, gamma, beta, y);
-  else hipLaunchKernelGGL((k_bn_apply<T, 1>), grid, dim3(256), 0, stream, x, n, c, mean, rstd, gamma, beta, y);
+  if (v == W) hipLaunchKernelGGL((k_bn_apply<T, W>), grid, dim3(256), 0, stream, x, n, c, mean, rstd, gamma, beta, y, relu);
+  else if (v == 4) hipLaunchKernelGGL((k_bn_apply<T, 4>), grid, dim3(256), 0, stream, x, n, c, mean, rstd, gamma, beta, y, relu);
+  else hipLaunchKernelGGL((k_bn_apply<T, 1>), grid, dim3(256), 0, stream, x, n, c, mean, rstd, gamma, beta, y, relu);
   ME_LAUNCH_CHECK();
   return 0;
 }
 
 template <typename T>
 static int bn_backward(const T *x, const T *dy, int64_t n, int c, const float *mean, const float *rstd,
-                       const float *gamma, T *dx, float *grad_gamma, float *grad_beta, float *ws,
-                       hipStream_t stream) {
+                       const float *gamma, const float *beta, int relu, T *dx, float *grad_gamma, float *grad_beta,
+                       float *ws, hipStream_t stream) {
   const int chunks = bn_chunks(n);
   float *pa = ws, *pb = ws + (int64_t)chunks * c;
   constexpr int W = 16 / (int)sizeof(T);
@@ -377,26 +393,26 @@ static int bn_backward(const T *x, const T *dy, int64_t n, int c, const float *m
   ME_CHECK(lds <= 64 * 1024, "channel count too large for the batch-norm kernels");
   if (v == W)
     hipLaunchKernelGGL((k_bn_bwd_partial<T, W>), dim3(chunks), dim3(256), lds, stream, x, dy, n, c, chunks, mean, rstd,
-                       pa, pb);
+                       gamma, beta, relu, pa, pb);
   else if (v == 4)
     hipLaunchKernelGGL((k_bn_bwd_partial<T, 4>), dim3(chunks), dim3(256), lds, stream, x, dy, n, c, chunks, mean, rstd,
-                       pa, pb);
+                       gamma, beta, relu, pa, pb);
   else
     hipLaunchKernelGGL((k_bn_bwd_partial<T, 1>), dim3(chunks), dim3(256), lds, stream, x, dy, n, c, chunks, mean, rstd,
-                       pa, pb);
+                       gamma, beta, relu, pa, pb);
   hipLaunchKernelGGL(k_bn_bwd_final, dim3((unsigned)ceil_div(c, 4)), dim3(256), 0, stream, pa, pb, c, chunks,
                      grad_beta, grad_gamma);
   const int pieces = c / v;
   const dim3 grid((unsigned)ceil_div(n, (int64_t)(pieces >= 256 ? 1 : 256 / pieces) * kBnRowsPerThread));
   if (v == W)
     hipLaunchKernelGGL((k_bn_bwd_apply<T, W>), grid, dim3(256), 0, stream, x, dy, n, c, mean, rstd, gamma, grad_beta,
-                       grad_gamma, dx);
+                       grad_gamma, dx, beta, relu);
   else if (v == 4)
     hipLaunchKernelGGL((k_bn_bwd_apply<T, 4>), grid, dim3(256), 0, stream, x, dy, n, c, mean, rstd, gamma, grad_beta,
-                       grad_gamma, dx);
+                       grad_gamma, dx, beta, relu);
   else
     hipLaunchKernelGGL((k_bn_bwd_apply<T, 1>), grid, dim3(256), 0, stream, x, dy, n, c, mean, rstd, gamma, grad_beta,
-                       grad_gamma, dx);
+                       grad_gamma, dx, beta, relu);
   ME_LAUNCH_CHECK();
   return 0;
 }
@@ -426,29 +442,30 @@ int me_bn_stats(const void *x, int32_t is_bf16, int64_t n, int32_t c, float eps,
 }
 
 int me_bn_apply(const void *x, int32_t is_bf16, int64_t n, int32_t c, const float *mean, const float *rstd,
-                const float *gamma, const float *beta, void *y, void *stream_) {
+                const float *gamma, const float *beta, int32_t relu, void *y, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   ME_CHECK(c > 0, "invalid channel count");
   if (n == 0) return 0;
   if (is_bf16)
     return bn_apply<__bf16>(reinterpret_cast<const __bf16 *>(x), n, c, mean, rstd, gamma, beta,
-                            reinterpret_cast<__bf16 *>(y), stream);
+                            reinterpret_cast<__bf16 *>(y), relu, stream);
   return bn_apply<float>(reinterpret_cast<const float *>(x), n, c, mean, rstd, gamma, beta,
-                         reinterpret_cast<float *>(y), stream);
+                         reinterpret_cast<float *>(y), relu, stream);
 }
 
 int me_bn_backward(const void *x, const void *dy, int32_t is_bf16, int64_t n, int32_t c, const float *mean,
-                   const float *rstd, const float *gamma, void *dx, float *grad_gamma, float *grad_beta,
-                   void *workspace, int64_t workspace_bytes, void *stream_) {
+                   const float *rstd, const float *gamma, const float *beta, int32_t relu, void *dx,
+                   float *grad_gamma, float *grad_beta, void *workspace, int64_t workspace_bytes, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   ME_CHECK(n > 0 && c > 0, "batch norm needs at least one row and one channel");
   ME_CHECK(workspace_bytes >= me_bn_workspace_bytes(n, c), "workspace too small");
   float *ws = reinterpret_cast<float *>(workspace);
   if (is_bf16)
     return bn_backward<__bf16>(reinterpret_cast<const __bf16 *>(x), reinterpret_cast<const __bf16 *>(dy), n, c, mean,
-                               rstd, gamma, reinterpret_cast<__bf16 *>(dx), grad_gamma, grad_beta, ws, stream);
+                               rstd, gamma, beta, relu, reinterpret_cast<__bf16 *>(dx), grad_gamma, grad_beta, ws,
+                               stream);
   return bn_backward<float>(reinterpret_cast<const float *>(x), reinterpret_cast<const float *>(dy), n, c, mean, rstd,
-                            gamma, reinterpret_cast<float *>(dx), grad_gamma, grad_beta, ws, stream);
+                            gamma, beta, relu, reinterpret_cast<float *>(dx), grad_gamma, grad_beta, ws, stream);
 }
 
 }  // extern "C"

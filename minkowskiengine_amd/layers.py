@@ -22,24 +22,25 @@ class _BatchNormTrainFunction(Function):
     fixed summation order).  weight / bias may be None."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps):
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu=False):
         x = x.contiguous()
         w32 = weight.float() if weight is not None else None
         b32 = bias.float() if bias is not None else None
         mean, rstd = MEB.bn_stats(x, eps, momentum, running_mean, running_var)
-        y = MEB.bn_apply(x, mean, rstd, w32, b32)
-        ctx.save_for_backward(x, mean, rstd, w32)
+        y = MEB.bn_apply(x, mean, rstd, w32, b32, relu)
+        ctx.save_for_backward(x, mean, rstd, w32, b32)
         ctx.param_dtype = weight.dtype if weight is not None else None
         ctx.has_bias = bias is not None
+        ctx.relu = relu
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, mean, rstd, w32 = ctx.saved_tensors
-        dx, gg, gb = MEB.bn_backward(x, dy, mean, rstd, w32)
+        x, mean, rstd, w32, b32 = ctx.saved_tensors
+        dx, gg, gb = MEB.bn_backward(x, dy, mean, rstd, w32, b32, ctx.relu)
         gw = gg.to(ctx.param_dtype) if ctx.param_dtype is not None else None
         gbias = gb.to(ctx.param_dtype) if ctx.has_bias else None
-        return dx, gw, gbias, None, None, None, None
+        return dx, gw, gbias, None, None, None, None, None
 
 
 class MinkowskiBatchNorm(nn.Module):
@@ -51,6 +52,10 @@ class MinkowskiBatchNorm(nn.Module):
         super().__init__()
         self.bn = nn.BatchNorm1d(num_features, eps=eps, momentum=momentum, affine=affine,
                                  track_running_stats=track_running_stats)
+        # Not in the reference: set by a model whose next layer is ALWAYS a MinkowskiReLU.  The rectification is
+        # then done by the batch-norm kernels (forward clamp, backward mask) and the output tensor is marked so
+        # that the following MinkowskiReLU passes it through; the results are those of the two separate layers.
+        self.fuse_relu = False
 
     def _native(self, f):
         bn = self.bn
@@ -69,7 +74,10 @@ class MinkowskiBatchNorm(nn.Module):
             rv = bn.running_var if (bn.training and bn.track_running_stats) else None
             if rm is not None:
                 bn.num_batches_tracked.add_(1)
-            y = _BatchNormTrainFunction.apply(f, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps)
+            y = _BatchNormTrainFunction.apply(f, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps, self.fuse_relu)
+            out = _rewrap(input, y)
+            out._rectified = self.fuse_relu
+            return out
         else:
             # evaluation: an affine map per channel, differentiable through torch (cheap: two fused passes)
             rstd = torch.rsqrt(bn.running_var + bn.eps)
@@ -129,6 +137,12 @@ class _Elementwise(nn.Module):
 
 class MinkowskiReLU(_Elementwise):
     MODULE = nn.ReLU
+
+    def forward(self, input):
+        # the output of a MinkowskiBatchNorm with fuse_relu is already rectified
+        if getattr(input, "_rectified", False):
+            return input
+        return _rewrap(input, self.module(input.F))
 
 
 class MinkowskiLeakyReLU(_Elementwise):

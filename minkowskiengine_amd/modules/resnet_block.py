@@ -23,6 +23,7 @@ class BasicBlock(nn.Module):
         self.conv1 = MinkowskiConvolution(inplanes, planes, kernel_size=3, stride=stride, dilation=dilation,
                                           dimension=dimension)
         self.norm1 = MinkowskiBatchNorm(planes, momentum=bn_momentum)
+        self.norm1.fuse_relu = True   # forward() rectifies norm1's output directly
         self.conv2 = MinkowskiConvolution(planes, planes, kernel_size=3, stride=1, dilation=dilation,
                                           dimension=dimension)
         self.norm2 = MinkowskiBatchNorm(planes, momentum=bn_momentum)
@@ -49,6 +50,7 @@ class Bottleneck(nn.Module):
         self.norm2 = MinkowskiBatchNorm(planes, momentum=bn_momentum)
         self.conv3 = MinkowskiConvolution(planes, planes * self.expansion, kernel_size=1, dimension=dimension)
         self.norm3 = MinkowskiBatchNorm(planes * self.expansion, momentum=bn_momentum)
+        self.norm1.fuse_relu = self.norm2.fuse_relu = True   # forward() rectifies their outputs directly
         self.relu = MinkowskiReLU(inplace=True)
         self.downsample = downsample
 

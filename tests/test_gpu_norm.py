@@ -87,3 +87,46 @@ def test_batch_norm_reproducible_and_eval(device):
                                          w.double(), b.double(), False, 0.1, 1e-5)
     assert close(bn(st).F, ref, 1e-5)
     assert int(bn.bn.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_fused_batch_norm_relu(device, dtype):
+    """MinkowskiBatchNorm(fuse_relu) + MinkowskiReLU = the two separate layers (forward clamp, backward mask
+    recomputed from x), against relu(BatchNorm1d(x)) in float64."""
+    import minkowskiengine_amd as ME
+    n, c = 20000, 48
+    g = torch.Generator().manual_seed(5)
+    coords = make_cloud(n, 50, 3, seed=5)
+    x = torch.randn(n, c, generator=g).to(dtype)
+    w, b = torch.rand(c, generator=g) + 0.5, torch.rand(c, generator=g) - 0.5
+    gy = torch.randn(n, c, generator=g).to(dtype)
+    ref_bn = torch.nn.BatchNorm1d(c).double()
+    with torch.no_grad():
+        ref_bn.weight.copy_(w.double())
+        ref_bn.bias.copy_(b.double())
+    xr = x.double().clone().requires_grad_(True)
+    yr = torch.relu(ref_bn(xr))
+    yr.backward(gy.double())
+    bn, relu = ME.MinkowskiBatchNorm(c).to(device), ME.MinkowskiReLU()
+    bn.fuse_relu = True
+    with torch.no_grad():
+        bn.bn.weight.copy_(w)
+        bn.bn.bias.copy_(b)
+    f = x.to(device).requires_grad_(True)
+    mid = bn(ME.SparseTensor(f, coords.to(device)))
+    y = relu(mid)
+    assert y is mid and float(y.F.detach().min()) >= 0.0        # the ReLU module passed the rectified tensor through
+    y.F.backward(gy.to(device))
+    if dtype == torch.float32:
+        assert close(y.F.detach(), yr.detach(), 1e-5) and close(f.grad, xr.grad, 1e-5)
+        assert close(bn.bn.weight.grad, ref_bn.weight.grad, 1e-4) and close(bn.bn.bias.grad, ref_bn.bias.grad, 1e-4)
+    else:
+        for got, ref in ((y.F.detach(), yr.detach()), (f.grad, xr.grad)):
+            err = (got.double().cpu() - ref).abs()
+            # (an element within rounding of the ReLU threshold may flip its mask: allow a handful)
+            assert int((err > 2.0 ** -7 * ref.abs() + 2e-3 * ref.abs().max()).sum()) <= 5
+        assert close(bn.bn.weight.grad, ref_bn.weight.grad, 2e-3) and close(bn.bn.bias.grad, ref_bn.bias.grad, 2e-3)
+    # evaluation mode: not fused, the ReLU module does its work
+    bn.eval()
+    out = relu(bn(ME.SparseTensor(x.to(device), coords.to(device))))
+    assert float(out.F.min()) >= 0.0
