@@ -169,13 +169,17 @@ int me_conv_pack_weights_f32(const float *w_dev, int64_t volume, int32_t c_src, 
  *   dst[t, :] = sum over plan entries (k, s) of tile(t):  src[s, :] @ w[k]      (w[k]: [c_src, c_dst])
  * Forward: src = in_feat, packed kernel, plan from nbr.  dgrad: src = grad_out, kernel packed with
  * transposed = 1, plan from nbrT.  Every target row is written (rows without entries get zeros).
- * The plan must have been built with the same tile_rows / batch_groups. */
+ * The plan must have been built with the same tile_rows / batch_groups (me_conv_plan_config).  n_pairs is the
+ * number of pairs of the kernel map (k_offsets[volume]): like me_conv_plan_config, the launch uses the density
+ * n_pairs / (n_tgt * volume) to choose between its two kernels (k_conv_tile_f32 and, for c_src == 64 on maps that
+ * fill at least two 16-row groups per tile and offset, k_conv_tile_f32_lean); the results do not depend on it
+ * beyond fp32 summation order. */
 int me_conv_target_f32(const float *src_feat_dev, int64_t n_src, int32_t c_src,
                        const float *packed_w_dev, int64_t volume, int32_t c_dst,
                        const int32_t *plan_src_dev, const int32_t *plan_dst_dev,
                        const int32_t *batch_desc_dev, const int32_t *tile_bptr_dev,
                        const int32_t *order_dev /* as given to me_plan_build, or NULL */, float *dst_feat_dev,
-                       int64_t n_tgt, int32_t tile_rows, int32_t batch_groups, void *stream);
+                       int64_t n_tgt, int64_t n_pairs, int32_t tile_rows, int32_t batch_groups, void *stream);
 
 /* Plan geometry for a (target rows, channels) problem: the tile height is chosen so that tiles x column
  * slabs is just below a multiple of the GPU's resident-workgroup slots (a 100k-voxel layer is only
@@ -202,7 +206,8 @@ int me_transpose_kernel_f32(const float *w_dev, int64_t volume, int32_t c_in, in
  *   workspace bytes from me_conv_wgrad_workspace_bytes. */
 int64_t me_conv_wgrad_workspace_bytes(const int64_t *k_offsets, int64_t volume, int32_t c_in,
                                       int32_t c_out);
-int me_conv_wgrad_f32(const float *x_dev, int32_t c_in, const float *dy_dev, int32_t c_out,
+int me_conv_wgrad_f32(const float *x_dev, int64_t n_in /* rows of x */, int32_t c_in, const float *dy_dev,
+                      int64_t n_out /* rows of dy */, int32_t c_out,
                       const int32_t *in_pairs_dev, const int32_t *out_pairs_dev,
                       const int64_t *k_offsets /* host */, const int64_t *k_offsets_dev,
                       int64_t volume, float *grad_w_dev, void *workspace_dev,
@@ -236,7 +241,8 @@ int me_conv_target_bf16(const uint16_t *src_feat_dev, int64_t n_src, int32_t c_s
                         const int32_t *order_dev, uint16_t *dst_feat_dev,
                         int64_t n_tgt, int32_t tile_rows, int32_t batch_groups, void *stream);
 int64_t me_conv_wgrad_workspace_bytes_bf16(const int64_t *k_offsets, int64_t volume, int32_t c_in, int32_t c_out);
-int me_conv_wgrad_bf16(const uint16_t *x_dev, int32_t c_in, const uint16_t *dy_dev, int32_t c_out,
+int me_conv_wgrad_bf16(const uint16_t *x_dev, int64_t n_in, int32_t c_in, const uint16_t *dy_dev, int64_t n_out,
+                       int32_t c_out,
                        const int32_t *in_pairs_dev, const int32_t *out_pairs_dev,
                        const int64_t *k_offsets /* host */, const int64_t *k_offsets_dev,
                        int64_t volume, float *grad_w_dev, void *workspace_dev,

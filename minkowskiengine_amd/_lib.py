@@ -59,13 +59,13 @@ SIGNATURES = {
     "me_conv_packed_weight_elems": (c_i64, [c_i64, c_i32, c_i32]),
     "me_conv_pack_weights_f32": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "me_conv_target_f32": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp,
-                                          c_vp, c_i64, c_i32, c_i32, c_vp]),
+                                          c_vp, c_i64, c_i64, c_i32, c_i32, c_vp]),
     "me_conv_plan_config": (ctypes.c_int, [c_i64, c_i64, c_i64, c_i32, c_i32, _P_I32, _P_I32]),
     "me_debug_set_conv_variant": (None, [ctypes.c_int]),
     "me_debug_conv_timing": (ctypes.c_int, [c_vp, c_i32]),
     "me_transpose_kernel_f32": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
     "me_conv_wgrad_workspace_bytes": (c_i64, [_P_I64, c_i64, c_i32, c_i32]),
-    "me_conv_wgrad_f32": (ctypes.c_int, [c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, _P_I64, c_vp, c_i64, c_vp,
+    "me_conv_wgrad_f32": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, _P_I64, c_vp, c_i64, c_vp,
                                          c_vp, c_i64, c_vp]),
     "me_debug_set_wgrad_config": (None, [ctypes.c_int, ctypes.c_int]),
     "me_bn_workspace_bytes": (c_i64, [c_i64, c_i32]),
@@ -83,7 +83,7 @@ SIGNATURES = {
     "me_conv_target_bf16": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp,
                                            c_vp, c_i64, c_i32, c_i32, c_vp]),
     "me_conv_wgrad_workspace_bytes_bf16": (c_i64, [_P_I64, c_i64, c_i32, c_i32]),
-    "me_conv_wgrad_bf16": (ctypes.c_int, [c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, _P_I64, c_vp, c_i64, c_vp,
+    "me_conv_wgrad_bf16": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, _P_I64, c_vp, c_i64, c_vp,
                                           c_vp, c_i64, c_vp]),
     "me_pool_sum_f32": (ctypes.c_int, [c_vp, c_i32, c_vp, c_i64, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "me_pool_max_f32": (ctypes.c_int, [c_vp, c_i32, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp]),

@@ -790,7 +790,7 @@ def _conv_target(src_feat, kernel, km, target, n_tgt, name="conv_target", transp
                                                 packed.data_ptr(), stream))
         _timed(name, dev, lambda: _lib.check(lib.me_conv_target_f32(
             src_feat.data_ptr(), src_feat.shape[0], c_src, packed.data_ptr(), km.volume, c_dst, p_src, p_dst, p_desc,
-            p_bptr, p_order, out.data_ptr(), n_tgt, tile_rows, batch_groups, stream)), flops=flops)
+            p_bptr, p_order, out.data_ptr(), n_tgt, km.n_pairs, tile_rows, batch_groups, stream)), flops=flops)
     return out
 
 
@@ -848,7 +848,8 @@ def _conv_backward(in_feat, grad_out, kernel, km, algo=None):
     stream = _stream(dev)
     with _on(dev):
         _timed("conv_wgrad", dev, lambda: _lib.check(fn(
-            in_feat.data_ptr(), c_in, grad_out.data_ptr(), c_out, p_in, p_out, koffs, p_koffs, volume,
+            in_feat.data_ptr(), in_feat.shape[0], c_in, grad_out.data_ptr(), grad_out.shape[0], c_out, p_in, p_out,
+            koffs, p_koffs, volume,
             grad_w.data_ptr(), ws.data_ptr(), ws.numel(), stream)), flops=2.0 * km.n_pairs * c_in * c_out)
     return grad_in, grad_w if kernel.dtype == torch.float32 else grad_w.to(kernel.dtype)
 

@@ -480,10 +480,19 @@ __global__ __launch_bounds__(256) void k_plan_fill(const int32_t *__restrict__ t
   const uint32_t b0 = boffs[item];
   const uint32_t nb = (groups + batch_groups - 1) / batch_groups;
   for (uint32_t j = lane; j < nb; j += 64) {
-    const uint32_t first = j * batch_groups;
-    const uint32_t ng = min((uint32_t)batch_groups, groups - first);
+    // the groups are dealt evenly over the nb batches (5 groups -> 3 + 2, not 4 + 1): no one-group stragglers
+    const uint32_t base = groups / nb, rem = groups % nb;
+    const uint32_t first = j * base + min(j, rem);
+    const uint32_t ng = base + (j < rem ? 1u : 0u);
     batch_desc[2 * (int64_t)(b0 + j)] = (int32_t)(g0 + first);
     batch_desc[2 * (int64_t)(b0 + j) + 1] = (int32_t)(((uint32_t)k << 8) | ng);
+  }
+  // The convolution kernels read the index window of a batch (ME_MAX_BATCH_GROUPS * 16 entries from its first
+  // group) unconditionally: behind the last group of the plan follow 64 entries that gather row 0 into the dummy
+  // row (me_plan_max_groups reserves them).
+  if (item == n_items - 1) {
+    plan_src[slot0 + (int64_t)padded + lane] = 0;
+    plan_dst[slot0 + (int64_t)padded + lane] = tile_rows;
   }
   if (lane == 0) {
     item_gptr[item] = (int32_t)g0;
@@ -787,7 +796,8 @@ int64_t me_plan_num_tiles(int64_t n_tgt, int32_t tile_rows) {
 int64_t me_plan_max_groups(int64_t n_tgt, int64_t volume, int64_t n_pairs, int32_t tile_rows) {
   const int64_t items = me_plan_num_tiles(n_tgt, tile_rows) * volume;
   const int64_t nonempty = items < n_pairs ? items : n_pairs;
-  return n_pairs / ME_GROUP_ROWS + nonempty + 1;
+  // (+ 4 groups: the zero-filled over-read window behind the last batch, see k_plan_fill)
+  return n_pairs / ME_GROUP_ROWS + nonempty + 1 + ME_MAX_BATCH_GROUPS;
 }
 // plan workspace: gcount | goffs | bcount | boffs [items each] | totals | scan ws
 int64_t me_plan_workspace_bytes(int64_t n_tgt, int64_t volume, int32_t tile_rows) {
