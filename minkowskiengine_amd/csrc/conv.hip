@@ -74,7 +74,8 @@ __device__ __forceinline__ void mma_groups(const float *__restrict__ a0p, const 
                                            float *__restrict__ accp, Hook hook = Hook()) {
   int d[R];  // accumulator row of this lane's entry, as a float offset (PREMUL: already multiplied by ACC_LD)
 #pragma unroll
-  for (int r = 0; r < R; ++r) d[r] = PREMUL ? dstp[r * 16] : dstp[r * 16] * ACC_LD;
+  for (int r = 0; r < R; ++r)
+    d[r] = PREMUL ? dstp[r * 16] : (int)__umul24((unsigned)dstp[r * 16], (unsigned)ACC_LD);
   f32x4 acc[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -212,7 +213,10 @@ __global__ __launch_bounds__(256) void k_pack_weights(const float *__restrict__ 
 // 5 prologue (accumulator clear + first loads), 6 epilogue, 7 batches
 __device__ unsigned long long d_conv_timing[8];
 
-template <int NC, int KC, bool EXACT, int VAR>
+// SMALL: source rows < 2^24, row bytes < 2^24, source matrix < 4 GiB (host-checked): gather addresses are the scalar
+// base + one v_mad_u32_u24 instead of 64-bit per-lane arithmetic (an fp32 MFMA blocks the VALU of its SIMD, see
+// k_conv_tile_f32_lean).
+template <int NC, int KC, bool EXACT, int VAR, bool SMALL = false>
 __global__ __launch_bounds__(NC * 4, (NC == 128 ? 2 : 3)) void k_conv_tile_f32(
     const float *__restrict__ src, int c_src, const f32x4 *__restrict__ wp, int c_dst,
     const int32_t *__restrict__ plan_src, const int32_t *__restrict__ plan_dst,
@@ -288,39 +292,50 @@ __global__ __launch_bounds__(NC * 4, (NC == 128 ? 2 : 3)) void k_conv_tile_f32(
   // software pipeline registers
   struct GatherSet {
     f32x4 stage[ITER];    // gathered rows of a batch on their way to the LDS stage buffer
-    int32_t sprev[ITER];  // the plan indices they were gathered with (padding slots: -1 -> zeros)
     int32_t dstv;         // this thread's target-row entry of the batch
   };
+  // Padding slots (plan index -1) gather row 0 and are NOT zeroed: their target row is the dummy accumulator row,
+  // which is never stored.
   GatherSet G0;
   G0.dstv = tile_rows;
   int32_t sidx[ITER];   // plan indices of the batch that is gathered next (rows beyond the batch repeat its
                         // last row: they are staged into slots nobody reads)
   float wreg[KQ], wnxt[KQ];
 
+  // (the index window of a batch is read to its end unconditionally: the plan is followed by 64 valid entries,
+  // k_plan_fill; rows beyond the batch are staged into slots nobody reads)
   auto load_sidx = [&](int g0, int ng) {
-    const int last = ng * 16 - 1;
+    (void)ng;
+    const char *pb = reinterpret_cast<const char *>(plan_src + (int64_t)g0 * 16);
 #pragma unroll
-    for (int j = 0; j < ITER; ++j) sidx[j] = plan_src[(int64_t)g0 * 16 + min((j * NT + tid) / F4, last)];
+    for (int j = 0; j < ITER; ++j)
+      sidx[j] = *reinterpret_cast<const int32_t *>(pb + (unsigned)(((j * NT + tid) / F4) * 4));
   };
   // issue the gather of the batch whose indices sit in sidx (global -> registers); nothing here consumes
   // the result
+  const char *srcb = reinterpret_cast<const char *>(src);
+  const unsigned row_bytes = (unsigned)c_src * 4u;
   auto gather = [&](GatherSet &G, int chunk, int g0, int ng) {
     f32x4 (&stage)[ITER] = G.stage;
-    int32_t (&sprev)[ITER] = G.sprev;
     const int c0 = chunk * KC;
-    G.dstv = plan_dst[(int64_t)g0 * 16 + min(tid, ng * 16 - 1)];
+    (void)ng;
+    G.dstv = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(plan_dst + (int64_t)g0 * 16) +
+                                               (unsigned)(min(tid, ME_MAX_BATCH_GROUPS * 16 - 1) * 4));
 #pragma unroll
     for (int j = 0; j < ITER; ++j) {
       const int ch = c0 + ((j * NT + tid) % F4) * 4;
-      const int sr = sidx[j];
-      sprev[j] = sr;
+      const int sr = max(sidx[j], 0);
       if (VAR & 16) {  // timing ablation only: no gather traffic
         stage[j] = f32x4{1.f, 1.f, 1.f, 1.f};
+      } else if (SMALL && (EXACT || vec_ok)) {
+        // channels beyond c_src (not EXACT) are zeroed at the stage write
+        const unsigned off = __umul24((unsigned)sr, row_bytes) + (unsigned)(EXACT ? ch : min(ch, c_src - 4)) * 4u;
+        stage[j] = *reinterpret_cast<const f32x4 *>(srcb + off);
       } else if (EXACT) {
-        stage[j] = *reinterpret_cast<const f32x4 *>(src + (int64_t)max(sr, 0) * c_src + ch);
+        stage[j] = *reinterpret_cast<const f32x4 *>(src + (int64_t)sr * c_src + ch);
       } else {
         // clamped scalar / vector loads; channels beyond c_src are zeroed at the stage write
-        const float *rowp = src + (int64_t)max(sr, 0) * c_src;
+        const float *rowp = src + (int64_t)sr * c_src;
         if (vec_ok) {
           stage[j] = *reinterpret_cast<const f32x4 *>(rowp + min(ch, c_src - 4));
         } else {
@@ -332,7 +347,6 @@ __global__ __launch_bounds__(NC * 4, (NC == 128 ? 2 : 3)) void k_conv_tile_f32(
   };
   auto write_stage = [&](GatherSet &G, int chunk) {
     f32x4 (&stage)[ITER] = G.stage;
-    int32_t (&sprev)[ITER] = G.sprev;
     const int32_t dstv = G.dstv;
     const int c0 = chunk * KC;
     float *s_ab = s_a;
@@ -348,7 +362,6 @@ __global__ __launch_bounds__(NC * 4, (NC == 128 ? 2 : 3)) void k_conv_tile_f32(
         if (ch + 2 >= c_src) t.z = 0.f;
         if (ch + 3 >= c_src) t.w = 0.f;
       }
-      if (sprev[j] < 0) t = f32x4{0.f, 0.f, 0.f, 0.f};
       const int slot = (idx % F4) ^ stage_swz(KC, r);
       if (VAR & 128) {  // ablation: no stage writes (the registers are kept alive through a never-taken store)
         if (t.x == 12345.678f) *reinterpret_cast<f32x4 *>(&s_ab[r * A_LD + slot * 4]) = t;
@@ -1566,27 +1579,31 @@ template <int NC, int KC, int VAR>
 static int launch_conv_tile(const float *src, int c_src, const float *wp, int c_dst, int slabs,
                             const int32_t *plan_src, const int32_t *plan_dst, const int32_t *batch_desc,
                             const int32_t *tile_bptr, const int32_t *order, float *dst, int64_t n_tgt,
-                            int tile_rows, int batch_groups, hipStream_t stream) {
+                            int tile_rows, int batch_groups, hipStream_t stream, bool small = false) {
   // variants 2048 + n (experiment): n KiB of unused LDS, to cap the resident workgroups per CU
   const int lds = conv_lds_bytes(NC, KC, tile_rows, batch_groups) +
                   (g_conv_variant >= 2048 ? (g_conv_variant - 2048) * 1024 : 0);
   ME_CHECK(lds <= kLdsBudget, "tile_rows / batch_groups too large for the LDS of one workgroup");
   const bool exact = (c_src % KC) == 0;
-  static bool attr_set[2] = {false, false};  // per instantiation
-  if (lds > 48 * 1024 && !attr_set[exact]) {
-    const void *fn = exact ? reinterpret_cast<const void *>(&k_conv_tile_f32<NC, KC, true, VAR>)
-                           : reinterpret_cast<const void *>(&k_conv_tile_f32<NC, KC, false, VAR>);
-    ME_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
-    attr_set[exact] = true;
+  // the timing ablations (VAR != 0) exist with 64-bit addresses only
+  constexpr bool kHasSmall = VAR == 0;
+  small = small && kHasSmall;
+  typedef void (*kernel_t)(const float *, int, const f32x4 *, int, const int32_t *, const int32_t *, const int32_t *,
+                           const int32_t *, const int32_t *, float *, int64_t, int, int);
+  const kernel_t fn = small ? (exact ? &k_conv_tile_f32<NC, KC, true, VAR, kHasSmall>
+                                     : &k_conv_tile_f32<NC, KC, false, VAR, kHasSmall>)
+                            : (exact ? &k_conv_tile_f32<NC, KC, true, VAR, false>
+                                     : &k_conv_tile_f32<NC, KC, false, VAR, false>);
+  static bool attr_set[4] = {false, false, false, false};  // per instantiation
+  const int which = (small ? 2 : 0) + (exact ? 1 : 0);
+  if (lds > 48 * 1024 && !attr_set[which]) {
+    ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               kLdsBudget));
+    attr_set[which] = true;
   }
   const dim3 grid((unsigned)ceil_div(n_tgt, tile_rows), (unsigned)slabs);
-  const f32x4 *wp4 = reinterpret_cast<const f32x4 *>(wp);
-  if (exact)
-    hipLaunchKernelGGL((k_conv_tile_f32<NC, KC, true, VAR>), grid, dim3(NC * 4), (size_t)lds, stream, src, c_src, wp4,
-                       c_dst, plan_src, plan_dst, batch_desc, tile_bptr, order, dst, n_tgt, tile_rows, batch_groups);
-  else
-    hipLaunchKernelGGL((k_conv_tile_f32<NC, KC, false, VAR>), grid, dim3(NC * 4), (size_t)lds, stream, src, c_src, wp4,
-                       c_dst, plan_src, plan_dst, batch_desc, tile_bptr, order, dst, n_tgt, tile_rows, batch_groups);
+  hipLaunchKernelGGL(fn, grid, dim3(NC * 4), (size_t)lds, stream, src, c_src, reinterpret_cast<const f32x4 *>(wp), c_dst,
+                     plan_src, plan_dst, batch_desc, tile_bptr, order, dst, n_tgt, tile_rows, batch_groups);
   ME_LAUNCH_CHECK();
   return 0;
 }
@@ -1830,9 +1847,11 @@ int me_conv_target_f32(const float *src, int64_t n_src, int32_t c_src, const flo
 #define ME_CONV_ARGS                                                                                         \
   src, c_src, wp, c_dst, v.slabs, plan_src, plan_dst, batch_desc, tile_bptr, order, dst, n_tgt, tile_rows, \
       batch_groups, stream
-  // the lean kernel (variant 7 forces the general one); its 32-bit offsets need a feature matrix below 4 GiB
-  const bool lean_ok = conv_use_lean(n_tgt, volume, n_pairs, c_src, v.nc, tile_rows) && n_src > 0 &&
-                       n_src < (1ll << 24) && n_src * c_src * 4 < (1ll << 32) && batch_groups == ME_MAX_BATCH_GROUPS;
+  // 32-bit byte offsets with a 24-bit row multiply (both kernels) need a source matrix below 4 GiB
+  const bool small = n_src > 0 && n_src < (1ll << 24) && n_src * c_src * 4 < (1ll << 32) && g_conv_variant != 6;
+  // the lean kernel (variant 7 forces the general one)
+  const bool lean_ok = conv_use_lean(n_tgt, volume, n_pairs, c_src, v.nc, tile_rows) && small &&
+                       batch_groups == ME_MAX_BATCH_GROUPS;
   if (lean_ok && (g_conv_variant == 0 || g_conv_variant >= 2048)) {
     if (v.nc == 64) return launch_conv_tile_lean<64>(ME_CONV_ARGS);
     return launch_conv_tile_lean<32>(ME_CONV_ARGS);
@@ -1853,7 +1872,7 @@ int me_conv_target_f32(const float *src, int64_t n_src, int32_t c_src, const flo
       default: break;
     }
   }
-#define ME_CONV_CASE(NCV, KCV) return launch_conv_tile<NCV, KCV, 0>(ME_CONV_ARGS)
+#define ME_CONV_CASE(NCV, KCV) return launch_conv_tile<NCV, KCV, 0>(ME_CONV_ARGS, small)
   if (v.nc == 32) {
     if (v.kc == 64) ME_CONV_CASE(32, 64);
     if (v.kc == 32) ME_CONV_CASE(32, 32);
