@@ -101,11 +101,13 @@ int64_t me_kernel_map_workspace_bytes(int64_t n_out, int64_t volume);
 /* Pass 1: neighbour table + per-offset pair counts.
  *   nbr_dev   int32 [volume, n_out] (out): in-map row of (out row u, offset k) or -1
  *   k_offsets host int64 [volume + 1] (out): exclusive prefix of pair counts — SYNC
+ *   k_offsets_dev int64 [volume + 1] on the device (out, may be NULL): the same prefix, for the kernels that
+ *             take it as a device array (transpose, wgrad) — saves the caller a host-to-device copy
  * The iteration direction is the reference's: iterate OUTPUT coordinates, look up the INPUT map
  * (src/coordinate_map_cpu.hpp:626-649). */
 int me_kernel_map_probe(const uint64_t *in_table_dev, int64_t in_capacity,
                         const int32_t *in_coords_dev, const int32_t *out_coords_dev, int64_t n_out,
-                        const me_region *region, int32_t *nbr_dev, int64_t *k_offsets,
+                        const me_region *region, int32_t *nbr_dev, int64_t *k_offsets, int64_t *k_offsets_dev,
                         void *workspace_dev, int64_t workspace_bytes, void *stream);
 
 /* Pass 2: wavefront ballot/prefix-sum compaction of the table into the reference's per-offset
@@ -169,17 +171,13 @@ int me_conv_pack_weights_f32(const float *w_dev, int64_t volume, int32_t c_src, 
  *   dst[t, :] = sum over plan entries (k, s) of tile(t):  src[s, :] @ w[k]      (w[k]: [c_src, c_dst])
  * Forward: src = in_feat, packed kernel, plan from nbr.  dgrad: src = grad_out, kernel packed with
  * transposed = 1, plan from nbrT.  Every target row is written (rows without entries get zeros).
- * The plan must have been built with the same tile_rows / batch_groups (me_conv_plan_config).  n_pairs is the
- * number of pairs of the kernel map (k_offsets[volume]): like me_conv_plan_config, the launch uses the density
- * n_pairs / (n_tgt * volume) to choose between its two kernels (k_conv_tile_f32 and, for c_src == 64 on maps that
- * fill at least two 16-row groups per tile and offset, k_conv_tile_f32_lean); the results do not depend on it
- * beyond fp32 summation order. */
+ * The plan must have been built with the same tile_rows / batch_groups (me_conv_plan_config). */
 int me_conv_target_f32(const float *src_feat_dev, int64_t n_src, int32_t c_src,
                        const float *packed_w_dev, int64_t volume, int32_t c_dst,
                        const int32_t *plan_src_dev, const int32_t *plan_dst_dev,
                        const int32_t *batch_desc_dev, const int32_t *tile_bptr_dev,
                        const int32_t *order_dev /* as given to me_plan_build, or NULL */, float *dst_feat_dev,
-                       int64_t n_tgt, int64_t n_pairs, int32_t tile_rows, int32_t batch_groups, void *stream);
+                       int64_t n_tgt, int32_t tile_rows, int32_t batch_groups, void *stream);
 
 /* Plan geometry for a (target rows, channels) problem: the tile height is chosen so that tiles x column
  * slabs is just below a multiple of the GPU's resident-workgroup slots (a 100k-voxel layer is only

@@ -47,7 +47,7 @@ SIGNATURES = {
     "me_coords_spatial_keys": (ctypes.c_int, [c_vp, c_i64, c_i32, _P_I32, c_vp, c_vp]),
     "me_coords_find": (ctypes.c_int, [c_vp, c_i64, c_vp, c_i32, c_vp, c_i64, c_vp, c_vp]),
     "me_kernel_map_workspace_bytes": (c_i64, [c_i64, c_i64]),
-    "me_kernel_map_probe": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, _P_REGION, c_vp, _P_I64, c_vp,
+    "me_kernel_map_probe": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, _P_REGION, c_vp, _P_I64, c_vp, c_vp,
                                            c_i64, c_vp]),
     "me_kernel_map_compact": (ctypes.c_int, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "me_kernel_map_transpose": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp]),
@@ -59,7 +59,7 @@ SIGNATURES = {
     "me_conv_packed_weight_elems": (c_i64, [c_i64, c_i32, c_i32]),
     "me_conv_pack_weights_f32": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "me_conv_target_f32": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp,
-                                          c_vp, c_i64, c_i64, c_i32, c_i32, c_vp]),
+                                          c_vp, c_i64, c_i32, c_i32, c_vp]),
     "me_conv_plan_config": (ctypes.c_int, [c_i64, c_i64, c_i64, c_i32, c_i32, _P_I32, _P_I32]),
     "me_debug_set_conv_variant": (None, [ctypes.c_int]),
     "me_debug_conv_timing": (ctypes.c_int, [c_vp, c_i32]),

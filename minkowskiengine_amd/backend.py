@@ -366,17 +366,17 @@ def _build_kernel_map(in_map, out_map, region):
     nbr = torch.empty((volume, max(n_out, 1)), dtype=torch.int32, device=dev)
     ws = _workspace(lib.me_kernel_map_workspace_bytes(n_out, volume), dev)
     koffs = (ctypes.c_int64 * (volume + 1))()
+    k_offsets_dev = torch.empty(volume + 1, dtype=torch.int64, device=dev)
     with _on(dev):
         _lib.check(lib.me_kernel_map_probe(_ptr(in_map.table), in_map.capacity, _ptr(in_map.coords),
                                            _ptr(out_map.coords), n_out, ctypes.byref(region), _ptr(nbr), koffs,
-                                           _ptr(ws), ws.numel(), _stream(dev)))
+                                           _ptr(k_offsets_dev), _ptr(ws), ws.numel(), _stream(dev)))
         k_offsets = [int(v) for v in koffs]
         n_pairs = k_offsets[-1]
         in_pairs = torch.empty(max(n_pairs, 1), dtype=torch.int32, device=dev)
         out_pairs = torch.empty(max(n_pairs, 1), dtype=torch.int32, device=dev)
         _lib.check(lib.me_kernel_map_compact(_ptr(nbr), n_out, volume, _ptr(in_pairs), _ptr(out_pairs), _ptr(ws),
                                              ws.numel(), _stream(dev)))
-    k_offsets_dev = torch.tensor(k_offsets, dtype=torch.int64, device=dev)
     return KernelMapGPU(volume, n_in, n_out, k_offsets, k_offsets_dev, in_pairs[:max(n_pairs, 0)],
                         out_pairs[:max(n_pairs, 0)], store={"nbr_out": nbr}, in_map=in_map, out_map=out_map)
 
@@ -646,6 +646,16 @@ class CoordinateMapManagerGPU_c10:
             return km
         in_map, out_map = self._get(ik), self._get(ok)
         _check(len(ks) + 1 == in_map.coords.shape[1], "kernel size mismatch")
+        if ik == ok and all(k == 1 for k in ks):
+            # a 1x1 kernel on one map: every row is paired with itself (volume-1 shortcut of
+            # src/coordinate_map_cpu.hpp:605-616) — no probe, no host synchronisation
+            n = in_map.n
+            rows = torch.arange(n, dtype=torch.int32, device=in_map.coords.device)
+            km = KernelMapGPU(1, n, n, [0, n], torch.tensor([0, n], dtype=torch.int64, device=rows.device), rows, rows,
+                              store={"nbr_out": rows.view(1, n) if n else rows.new_empty((1, 1))},
+                              in_map=in_map, out_map=out_map)
+            self._kernel_maps[key] = km
+            return km
         if not is_transpose:
             # (pooling with stride == kernel uses the same generic path: the result is identical)
             region = _lib.make_region(len(ks) + 1, int(region_type), ks, dl, in_map.tensor_stride)
@@ -790,7 +800,7 @@ def _conv_target(src_feat, kernel, km, target, n_tgt, name="conv_target", transp
                                                 packed.data_ptr(), stream))
         _timed(name, dev, lambda: _lib.check(lib.me_conv_target_f32(
             src_feat.data_ptr(), src_feat.shape[0], c_src, packed.data_ptr(), km.volume, c_dst, p_src, p_dst, p_desc,
-            p_bptr, p_order, out.data_ptr(), n_tgt, km.n_pairs, tile_rows, batch_groups, stream)), flops=flops)
+            p_bptr, p_order, out.data_ptr(), n_tgt, tile_rows, batch_groups, stream)), flops=flops)
     return out
 
 

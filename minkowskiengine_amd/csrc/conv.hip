@@ -45,11 +45,6 @@ __host__ __device__ constexpr int conv_lds_bytes(int nc, int kc, int tile_rows, 
   return (tile_rows + 1) * (nc + kAccPad) * 4 + batch_groups * 16 * (stage_ld(kc) * 4 + 4);
 }
 
-// the lean kernel (c_src % 64 == 0): accumulator tile + TWO full-size stage buffers
-__host__ __device__ constexpr int conv_lean_lds_bytes(int nc, int tile_rows) {
-  return (tile_rows + 1) * (nc + kAccPad) * 4 + 2 * ME_MAX_BATCH_GROUPS * 16 * (stage_ld(64) * 4 + 4);
-}
-
 // =================================================================================================
 // target-stationary convolution (forward and dgrad)
 // =================================================================================================
@@ -62,20 +57,15 @@ __host__ __device__ constexpr int conv_lean_lds_bytes(int nc, int tile_rows) {
 // trips overlap instead of forming a chain.
 // a0p: this lane's row of the first group (s_a + i16 * A_LD); pofs[s4]: float offset of the piece it reads at
 // quad-step s4 (swizzled, see stage_swz).
-struct NoHook {
-  __device__ __forceinline__ void operator()(int) const {}
-};
-
-// hook(s4) is called after the MFMAs of quad-step s4, pinned in place: the lean kernel issues the next batch's
-// vector loads there, inside its own MFMA stream (see k_conv_tile_f32_lean).
-template <int R, int KQ, int A_LD, int ACC_LD, int VAR = 0, bool PREMUL = false, typename Hook = NoHook>
+template <int R, int KQ, int A_LD, int ACC_LD, int VAR = 0>
 __device__ __forceinline__ void mma_groups(const float *__restrict__ a0p, const int (&pofs)[KQ / 4],
                                            const float (&wreg)[KQ], const int32_t *__restrict__ dstp,
-                                           float *__restrict__ accp, Hook hook = Hook()) {
-  int d[R];  // accumulator row of this lane's entry, as a float offset (PREMUL: already multiplied by ACC_LD)
+                                           float *__restrict__ accp) {
+  // accumulator row of this lane's entry as a float offset (24-bit multiply: a 64-bit mad here picked up an
+  // undefined high half from a register with a load in flight and waited for the whole gather)
+  int d[R];
 #pragma unroll
-  for (int r = 0; r < R; ++r)
-    d[r] = PREMUL ? dstp[r * 16] : (int)__umul24((unsigned)dstp[r * 16], (unsigned)ACC_LD);
+  for (int r = 0; r < R; ++r) d[r] = (int)__umul24((unsigned)dstp[r * 16], (unsigned)ACC_LD);
   f32x4 acc[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -100,11 +90,6 @@ __device__ __forceinline__ void mma_groups(const float *__restrict__ a0p, const 
       for (int r = 0; r < R; ++r)
         acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s4 * 4 + j], a[s4][r][j], acc[r], 0, 0, 0);
     }
-    if (!std::is_same<Hook, NoHook>::value) {
-      __builtin_amdgcn_sched_barrier(0);
-      hook(s4);
-      __builtin_amdgcn_sched_barrier(0);
-    }
   }
   if (VAR & 64) {  // ablation: no read-add-write of the LDS accumulator (results kept alive through one write)
     f32x4 s = acc[0];
@@ -118,31 +103,6 @@ __device__ __forceinline__ void mma_groups(const float *__restrict__ a0p, const 
   for (int r = 0; r < R; ++r) old[r] = *reinterpret_cast<const f32x4 *>(accp + d[r]);
 #pragma unroll
   for (int r = 0; r < R; ++r) *reinterpret_cast<f32x4 *>(accp + d[r]) = old[r] + acc[r];
-}
-
-// One group with its k range split over two accumulators (two independent MFMA chains instead of one dependent
-// chain of KQ; their sum is added to the accumulator row): the odd group of a batch in the lean kernel.
-template <int KQ, int A_LD>
-__device__ __forceinline__ void mma_group_split(const float *__restrict__ a0p, const int (&pofs)[KQ / 4],
-                                                const float (&wreg)[KQ], const int32_t *__restrict__ dstp,
-                                                float *__restrict__ accp) {
-  const int d = dstp[0];
-  f32x4 a[KQ / 4];
-#pragma unroll
-  for (int s4 = 0; s4 < KQ / 4; ++s4) a[s4] = *reinterpret_cast<const f32x4 *>(a0p + pofs[s4]);
-  __builtin_amdgcn_sched_barrier(0);
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-  constexpr int H = KQ / 8;  // quad-steps per half
-#pragma unroll
-  for (int s4 = 0; s4 < H; ++s4) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s4 * 4 + j], a[s4][j], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[(s4 + H) * 4 + j], a[s4 + H][j], acc1, 0, 0, 0);
-    }
-  }
-  const f32x4 old = *reinterpret_cast<const f32x4 *>(accp + d);
-  *reinterpret_cast<f32x4 *>(accp + d) = old + (acc0 + acc1);
 }
 
 // Packed weights: the exact register image of the kernel.  For offset k, source-channel chunk c,
@@ -214,8 +174,12 @@ __global__ __launch_bounds__(256) void k_pack_weights(const float *__restrict__ 
 __device__ unsigned long long d_conv_timing[8];
 
 // SMALL: source rows < 2^24, row bytes < 2^24, source matrix < 4 GiB (host-checked): gather addresses are the scalar
-// base + one v_mad_u32_u24 instead of 64-bit per-lane arithmetic (an fp32 MFMA blocks the VALU of its SIMD, see
-// k_conv_tile_f32_lean).
+// base + one v_mad_u32_u24 instead of 64-bit per-lane arithmetic.  On gfx950 an fp32 MFMA occupies the SIMD
+// exclusively: while v_mfma_f32_16x16x4_f32 executes, no VALU and no vector-memory instruction of ANY wave of that
+// SIMD issues, only LDS and scalar instructions do (scripts/ubench/coissue*.hip, profiles/r01_ubench_coissue*.log:
+// a v_add_u32 costs ~5 cycles and a global_load_dwordx4 ~17 cycles of matrix time, in the same wave or in a
+// neighbour).  Occupancy hides latencies but not instruction issue, so every VALU / VMEM instruction of the loop is
+// paid for in matrix time.
 template <int NC, int KC, bool EXACT, int VAR, bool SMALL = false>
 __global__ __launch_bounds__(NC * 4, (NC == 128 ? 2 : 3)) void k_conv_tile_f32(
     const float *__restrict__ src, int c_src, const f32x4 *__restrict__ wp, int c_dst,
@@ -477,233 +441,6 @@ __global__ __launch_bounds__(NC * 4, (NC == 128 ? 2 : 3)) void k_conv_tile_f32(
   }
 }
 
-// ---- "lean" variant for c_src % 64 == 0 ------------------------------------------------------------------------
-// On gfx950 an fp32 MFMA occupies the SIMD exclusively: while v_mfma_f32_16x16x4_f32 executes, no VALU and no
-// vector-memory instruction of ANY wave of that SIMD issues (only LDS and scalar instructions do; measured with
-// scripts/ubench/coissue*.hip, profiles/r01_ubench_coissue*.log: a v_add_u32 costs ~5 cycles and a
-// global_load_dwordx4 ~17 cycles of matrix time, in the same wave or in a neighbour).  Occupancy therefore hides
-// latencies but not instruction issue, and the fp32 rate of this kernel is
-//     MFMA cycles / (MFMA cycles + VALU + VMEM issue cycles of all resident waves).
-// k_conv_tile_f32 spends ~100 VALU and 13 VMEM instructions per batch of 64 MFMAs (57 % matrix time).  This
-// variant does the same work — same plan, same LDS layout, same summation order, bitwise identical results —
-// with ~25 VALU and 10 VMEM instructions per batch:
-//   * 32-bit byte offsets against scalar base pointers (global_load ... v_off, s[base]) instead of 64-bit
-//     per-lane addresses: one v_mad_u32_u24 per gathered row piece (host side guarantees rows < 2^24, row bytes
-//     < 2^24, feature matrix < 4 GiB);
-//   * a thread gathers the same 16-byte piece of ITER CONSECUTIVE plan rows, so its plan indices are one 16-byte
-//     load (a row of KC = 64 channels is exactly one 16-lane LDS service group, any row assignment is
-//     conflict-free);
-//   * padding slots are not zeroed: they gather row 0 (indices clamped) and their products land in the dummy
-//     accumulator row, which is never stored;
-//   * two weight register sets used alternately by a loop unrolled by two: no register copies;
-//   * the target rows are staged as float offsets into the accumulator tile (one multiply in wave 0 instead of one
-//     per lane and group in every wave);
-//   * index loads run to the end of the 64-entry batch window unconditionally (the plan arrays are zero-filled
-//     and 64 entries longer than the plan: no clamping arithmetic).
-template <int NC>
-__global__ __launch_bounds__(NC * 4, 3) void k_conv_tile_f32_lean(
-    const float *__restrict__ src, int c_src, const f32x4 *__restrict__ wp, int c_dst,
-    const int32_t *__restrict__ plan_src, const int32_t *__restrict__ plan_dst,
-    const int32_t *__restrict__ batch_desc, const int32_t *__restrict__ tile_bptr,
-    const int32_t *__restrict__ order, float *__restrict__ dst, int64_t n_tgt, int tile_rows, int batch_groups) {
-  typedef int i32x2 __attribute__((ext_vector_type(2)));
-  constexpr int KC = 64;
-  constexpr int WAVES = NC / 16;
-  constexpr int NT = WAVES * 64;
-  constexpr int A_LD = stage_ld(KC);
-  constexpr int ACC_LD = NC + kAccPad;
-  constexpr int KQ = KC / 4;
-  constexpr int F4 = KC / 4;                                       // 16-byte pieces per gathered row
-  constexpr int ITER = ME_MAX_BATCH_GROUPS * 16 * F4 / NT;          // consecutive plan rows per thread (4 or 8)
-  typedef int ivec __attribute__((ext_vector_type(ITER)));
-  static_assert(ME_MAX_BATCH_GROUPS == 4 && (ITER == 4 || ITER == 8), "row assignment of the lean kernel");
-
-  (void)batch_groups;
-  constexpr int CAP_ROWS = ME_MAX_BATCH_GROUPS * 16;
-  constexpr int STAGE_FLOATS = CAP_ROWS * A_LD + CAP_ROWS;  // one stage buffer: gathered rows + their target offsets
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float *s_acc = reinterpret_cast<float *>(smem);   // [(tile_rows + 1) x ACC_LD]
-  float *s_stage = s_acc + (tile_rows + 1) * ACC_LD;  // 2 x { [CAP_ROWS x A_LD] rows, [CAP_ROWS] float offsets of the target rows }
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int i16 = lane & 15, q = lane >> 4;
-  const int tile = blockIdx.x;
-  const int col_base = blockIdx.y * NC;
-  const int nchunks = c_src / KC;
-  const int ncb = (c_dst + 15) / 16;
-  const int cb = min(col_base / 16 + wave, ncb - 1);
-  int pofs[KQ / 4];
-#pragma unroll
-  for (int s4 = 0; s4 < KQ / 4; ++s4) pofs[s4] = ((4 * s4 + q) ^ stage_swz(KC, i16)) * 4;
-
-  for (int x = tid; x < (tile_rows + 1) * ACC_LD / 4; x += NT)
-    reinterpret_cast<f32x4 *>(s_acc)[x] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int b0 = tile_bptr[tile];
-  const int nb = tile_bptr[tile + 1] - b0;
-  const int n_it = nb * nchunks;
-  auto locate = [&](int it, int &chunk, int &g0, int &k) {
-    int r = min(it, n_it - 1);
-    chunk = 0;
-    while (r >= nb) {
-      r -= nb;
-      ++chunk;
-    }
-    const i32x2 d = *reinterpret_cast<const i32x2 *>(batch_desc + 2 * (int64_t)(b0 + r));
-    g0 = d.x;
-    k = (int)((uint32_t)d.y >> 8);
-    return d.y & 255;
-  };
-
-  // per-thread constants of the gather: plan rows r0 .. r0 + ITER - 1 of the batch window, piece `piece`
-  const int r0 = (tid / F4) * ITER, piece = tid % F4;
-  const unsigned row_bytes = (unsigned)c_src * 4u;
-  const unsigned piece_bytes = (unsigned)piece * 16u;
-  const unsigned idx_bytes = (unsigned)r0 * 4u;         // offset of this thread's indices inside the window
-  const unsigned dst_bytes = (unsigned)min(tid, 63) * 4u;
-  const unsigned w_bytes = (unsigned)lane * 16u;
-  int sofs[ITER];                                        // float offsets of this thread's stage slots
-#pragma unroll
-  for (int j = 0; j < ITER; ++j) sofs[j] = (r0 + j) * A_LD + ((piece ^ stage_swz(KC, r0 + j)) * 4);
-  const char *srcb = reinterpret_cast<const char *>(src);
-
-  f32x4 stage[ITER];
-  ivec sidx;
-  int32_t dstv = 0;
-  float wA[KQ], wB[KQ];
-
-  auto load_sidx = [&](int g0) {
-    sidx = *reinterpret_cast<const ivec *>(reinterpret_cast<const char *>(plan_src + (int64_t)g0 * 16) + idx_bytes);
-  };
-  auto load_dst = [&](int g0) {
-    dstv = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(plan_dst + (int64_t)g0 * 16) + dst_bytes);
-  };
-  auto gather_part = [&](int chunk, int part) {   // half of this thread's rows
-    const char *base = srcb + chunk * (KC * 4);
-#pragma unroll
-    for (int j = part * (ITER / 2); j < (part + 1) * (ITER / 2); ++j) {
-      const unsigned off = __umul24((unsigned)max(sidx[j], 0), row_bytes) + piece_bytes;
-      stage[j] = *reinterpret_cast<const f32x4 *>(base + off);
-    }
-  };
-  auto write_stage = [&](float *buf, int n_groups) {
-#pragma unroll
-    for (int j = 0; j < ITER; ++j) *reinterpret_cast<f32x4 *>(&buf[sofs[j]]) = stage[j];
-    // entries behind the batch (over-read window) point at the dummy row
-    if (tid < 64)
-      reinterpret_cast<int32_t *>(buf + CAP_ROWS * A_LD)[tid] =
-          (int32_t)__umul24((unsigned)(tid < n_groups * 16 ? dstv : tile_rows), (unsigned)ACC_LD);
-  };
-  auto load_w = [&](float (&w)[KQ], int chunk, int k) {
-    const char *p = reinterpret_cast<const char *>(wp + ((((int64_t)k * nchunks + chunk) * ncb + cb) * (KQ / 4)) * 64);
-#pragma unroll
-    for (int v = 0; v < KQ / 4; ++v) {
-      const f32x4 t = *reinterpret_cast<const f32x4 *>(p + w_bytes + v * 1024);
-      w[v * 4 + 0] = t.x;
-      w[v * 4 + 1] = t.y;
-      w[v * 4 + 2] = t.z;
-      w[v * 4 + 3] = t.w;
-    }
-  };
-  // Everything except the MFMAs of a batch rides INSIDE the MFMA stream of its last pair of groups (an fp32 MFMA
-  // blocks the VALU / VMEM issue of the whole SIMD: work issued in a phase of its own waits for the MFMAs of the
-  // co-resident workgroup and the matrix pipe idles meanwhile).  That pair is groups 0 and 1 and runs for every
-  // batch — group 1 of a one-group batch is a dummy whose target rows are the dummy row (write_stage) — so the loads
-  // have ONE site at the end of the iteration: with copies of them in several branches hipcc sinks them below the
-  // branches, behind all MFMAs.  Groups 2 and 3 come first (rows of one offset are distinct: the order of the
-  // groups does not matter).
-  auto multiply = [&](const float *buf, const float (&w)[KQ], int n_groups, auto hook) {
-    const float *a0p = &buf[i16 * A_LD];
-    const int32_t *dstp = reinterpret_cast<const int32_t *>(buf + CAP_ROWS * A_LD) + i16;
-    float *accp = &s_acc[wave * 16 + q * 4];
-    if (n_groups == 4) {
-      mma_groups<2, KQ, A_LD, ACC_LD, 0, true>(a0p + 32 * A_LD, pofs, w, dstp + 32, accp);
-    } else if (n_groups == 3) {
-      mma_group_split<KQ, A_LD>(a0p + 32 * A_LD, pofs, w, dstp + 32, accp);
-    }
-    mma_groups<2, KQ, A_LD, ACC_LD, 0, true>(a0p, pofs, w, dstp, accp, hook);
-  };
-
-  if (n_it > 0) {
-    // cursors: A = the batch that is multiplied (it), B = it + 1 (its rows are in registers, its weights and its
-    // stage write go out during A), C = it + 2 (gathered during A), D = it + 3 (indices fetched during A); batches
-    // beyond the tile repeat its last one (redundant loads instead of branches)
-    int chA, gA, nA, kA, chB, gB, nB, kB, chC, gC, nC, kC, chD, gD, nD, kD;
-    nA = locate(0, chA, gA, kA);
-    nB = locate(1, chB, gB, kB);
-    nC = locate(2, chC, gC, kC);
-    nD = locate(3, chD, gD, kD);
-    load_w(wA, chA, kA);
-    load_sidx(gA);
-    load_dst(gA);
-    gather_part(chA, 0);
-    gather_part(chA, 1);
-    load_sidx(gB);
-    write_stage(s_stage, nA);  // batch 0 -> buffer 0 (waits for its rows)
-    load_dst(gB);
-    gather_part(chB, 0);
-    gather_part(chB, 1);
-    load_sidx(gC);
-    __syncthreads();
-    int it = 0;
-    // One batch, ONE barrier: while batch `it` is multiplied out of buffer it & 1, the rows of batch it + 1 (gathered
-    // during the previous batch) are written to the other buffer, the rows of batch it + 2 are requested into the
-    // registers that just became free, and the indices of batch it + 3 are fetched.
-    auto step = [&](const float (&wcur)[KQ], float (&wnext)[KQ], float *cur, float *nxt) {
-      multiply(cur, wcur, nA, [&](int s4) {
-        if (s4 == 0) {
-          load_w(wnext, chB, kB);
-          write_stage(nxt, nB);
-        } else if (s4 == 1) {
-          load_dst(gC);
-          gather_part(chC, 0);
-        } else if (s4 == 2) {
-          gather_part(chC, 1);
-        } else {
-          load_sidx(gD);
-        }
-      });
-      __syncthreads();  // buffer `cur` is free again, buffer `nxt` is complete
-      chA = chB; gA = gB; nA = nB; kA = kB;
-      chB = chC; gB = gC; nB = nC; kB = kC;
-      chC = chD; gC = gD; nC = nD; kC = kD;
-      nD = locate(it + 4, chD, gD, kD);
-      ++it;
-    };
-    // (unrolled by two: the buffers and the weight register sets alternate without address arithmetic or copies)
-    while (it + 1 < n_it) {
-      step(wA, wB, s_stage, s_stage + STAGE_FLOATS);
-      step(wB, wA, s_stage + STAGE_FLOATS, s_stage);
-    }
-    if (it < n_it) step(wA, wB, s_stage, s_stage + STAGE_FLOATS);
-  }
-  __syncthreads();
-
-  const int64_t row0 = (int64_t)tile * tile_rows;
-  const int rows_here = (int)min((int64_t)tile_rows, n_tgt - row0);
-  const bool vec_out = (c_dst % 4) == 0;
-  for (int x = tid; x < tile_rows * NC / 4; x += NT) {
-    const int row = x / (NC / 4);
-    const int c4 = x % (NC / 4);
-    const int cc = col_base + c4 * 4;
-    if (row < rows_here && cc < c_dst) {
-      const f32x4 v = *reinterpret_cast<const f32x4 *>(&s_acc[row * ACC_LD + c4 * 4]);
-      const int64_t grow = order ? (int64_t)order[row0 + row] : row0 + row;
-      float *o = dst + grow * c_dst + cc;
-      if (vec_out) {
-        *reinterpret_cast<f32x4 *>(o) = v;
-      } else {
-        o[0] = v.x;
-        if (cc + 1 < c_dst) o[1] = v.y;
-        if (cc + 2 < c_dst) o[2] = v.z;
-        if (cc + 3 < c_dst) o[3] = v.w;
-      }
-    }
-  }
-}
-
 
 __global__ __launch_bounds__(256) void k_transpose_kernel(const float *__restrict__ w, int64_t volume,
                                                          int c_in, int c_out,
@@ -775,7 +512,7 @@ __device__ __forceinline__ int64_t wgrad_range_of_pair(int64_t e, int64_t n_pair
 // VEC: c is a multiple of V (one V*4-byte load); otherwise V scalar loads with clamped channels.
 // SMALL: rows < 2^24, row bytes < 2^24 and the matrix below 4 GiB (checked by the host): the address is the scalar
 // base plus ONE v_mad_u32_u24 — an fp32 MFMA blocks the VALU of its SIMD, so the 64-bit multiply-add, the 64-bit
-// add and the register copies of the general address cost matrix time (see k_conv_tile_f32_lean).
+// add and the register copies of the general address cost matrix time (see k_conv_tile_f32).
 template <typename T, int V, bool VEC, bool CHECK, bool SMALL = false>
 __device__ __forceinline__ void load_piece(const T *__restrict__ base, int32_t row, int c, int ch,
                                            float (&out)[V]) {
@@ -1528,7 +1265,7 @@ int plan_tile_rows(const PlanShape &s, int64_t n_tgt, int64_t volume, int64_t n_
   double best_cost = 1e300;
   int best_t = 128;
   // resident workgroups per CU: 3 waves per SIMD by registers (__launch_bounds__(NC * 4, 3)), then the LDS
-  for (int occ = 12 / waves; occ >= s.min_occ; --occ) {
+  for (int occ = 12 / waves; occ >= 1; --occ) {
     const int64_t slots = (int64_t)cus * occ;
     for (int rounds = 1; rounds <= 64; ++rounds) {
       int64_t t = ceil_div(n_tgt * s.slabs, slots * rounds);
@@ -1560,16 +1297,6 @@ int plan_tile_rows(const PlanShape &s, int64_t n_tgt, int64_t volume, int64_t n_
     }
   }
   return best_t;
-}
-
-// k_conv_tile_f32_lean instead of k_conv_tile_f32: c_src == 64, room for two workgroups per CU with two stage
-// buffers each, and a map dense enough that a (tile, offset) item fills at least two 16-row groups (the lean kernel
-// always multiplies groups in pairs).  Used by me_conv_plan_config and me_conv_target_f32 alike.
-static bool conv_use_lean(int64_t n_tgt, int64_t volume, int64_t n_pairs, int c_src, int nc, int tile_rows) {
-  if (c_src != 64 || volume <= 1 || n_tgt <= 0) return false;
-  if (2 * conv_lean_lds_bytes(nc, tile_rows) > kLdsBudget) return false;
-  const double p = (double)(n_pairs > n_tgt ? n_pairs - n_tgt : 0) / ((double)(volume - 1) * n_tgt);
-  return p * tile_rows >= 32.0;
 }
 
 int g_conv_variant = 0;  // me_debug_set_conv_variant
@@ -1604,27 +1331,6 @@ static int launch_conv_tile(const float *src, int c_src, const float *wp, int c_
   const dim3 grid((unsigned)ceil_div(n_tgt, tile_rows), (unsigned)slabs);
   hipLaunchKernelGGL(fn, grid, dim3(NC * 4), (size_t)lds, stream, src, c_src, reinterpret_cast<const f32x4 *>(wp), c_dst,
                      plan_src, plan_dst, batch_desc, tile_bptr, order, dst, n_tgt, tile_rows, batch_groups);
-  ME_LAUNCH_CHECK();
-  return 0;
-}
-
-template <int NC>
-static int launch_conv_tile_lean(const float *src, int c_src, const float *wp, int c_dst, int slabs,
-                                 const int32_t *plan_src, const int32_t *plan_dst, const int32_t *batch_desc,
-                                 const int32_t *tile_bptr, const int32_t *order, float *dst, int64_t n_tgt,
-                                 int tile_rows, int batch_groups, hipStream_t stream) {
-  const int lds = conv_lean_lds_bytes(NC, tile_rows) + (g_conv_variant >= 2048 ? (g_conv_variant - 2048) * 1024 : 0);
-  ME_CHECK(lds <= kLdsBudget, "tile_rows too large for the LDS of one workgroup");
-  static bool attr_set = false;  // per instantiation
-  if (lds > 48 * 1024 && !attr_set) {
-    ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_tile_f32_lean<NC>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
-    attr_set = true;
-  }
-  const dim3 grid((unsigned)ceil_div(n_tgt, tile_rows), (unsigned)slabs);
-  hipLaunchKernelGGL((k_conv_tile_f32_lean<NC>), grid, dim3(NC * 4), (size_t)lds, stream, src, c_src,
-                     reinterpret_cast<const f32x4 *>(wp), c_dst, plan_src, plan_dst, batch_desc, tile_bptr, order, dst,
-                     n_tgt, tile_rows, batch_groups);
   ME_LAUNCH_CHECK();
   return 0;
 }
@@ -1791,17 +1497,6 @@ int me_conv_plan_config(int64_t n_tgt, int64_t volume, int64_t n_pairs, int32_t 
   s.chunks = (int)ceil_div(c_src, v.kc);
   s.group_cycles = (v.kc / 4) * 32.0;  // fp32 MFMAs of one 16-row group and chunk
   s.stage_row_bytes = stage_ld(v.kc) * 4 + 4;
-  if (c_src == 64 && volume > 1) {
-    // the lean kernel (two stage buffers, two workgroups per CU) where it pays off, see conv_use_lean
-    PlanShape l = s;
-    l.stage_row_bytes *= 2;
-    l.min_occ = 2;
-    const int t = plan_tile_rows(l, n_tgt, volume, n_pairs);
-    if (conv_use_lean(n_tgt, volume, n_pairs, c_src, v.nc, t)) {
-      *tile_rows = t;
-      return 0;
-    }
-  }
   *tile_rows = plan_tile_rows(s, n_tgt, volume, n_pairs);
   return 0;
 }
@@ -1835,8 +1530,9 @@ int me_conv_pack_weights_f32(const float *w, int64_t volume, int32_t c_src, int3
 int me_conv_target_f32(const float *src, int64_t n_src, int32_t c_src, const float *wp, int64_t volume,
                        int32_t c_dst, const int32_t *plan_src, const int32_t *plan_dst,
                        const int32_t *batch_desc, const int32_t *tile_bptr, const int32_t *order, float *dst,
-                       int64_t n_tgt, int64_t n_pairs, int32_t tile_rows, int32_t batch_groups, void *stream_) {
+                       int64_t n_tgt, int32_t tile_rows, int32_t batch_groups, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  (void)volume;
   ME_CHECK(c_src > 0 && c_dst > 0, "channel counts must be positive");
   ME_CHECK(tile_rows >= ME_GROUP_ROWS && tile_rows <= ME_MAX_TILE_ROWS, "tile_rows out of range");
   ME_CHECK(batch_groups >= 1 && batch_groups <= ME_MAX_BATCH_GROUPS, "batch_groups out of range");
@@ -1847,15 +1543,9 @@ int me_conv_target_f32(const float *src, int64_t n_src, int32_t c_src, const flo
 #define ME_CONV_ARGS                                                                                         \
   src, c_src, wp, c_dst, v.slabs, plan_src, plan_dst, batch_desc, tile_bptr, order, dst, n_tgt, tile_rows, \
       batch_groups, stream
-  // 32-bit byte offsets with a 24-bit row multiply (both kernels) need a source matrix below 4 GiB
+  // 32-bit byte offsets with a 24-bit row multiply need a source matrix below 4 GiB (variant 6: 64-bit addresses)
   const bool small = n_src > 0 && n_src < (1ll << 24) && n_src * c_src * 4 < (1ll << 32) && g_conv_variant != 6;
-  // the lean kernel (variant 7 forces the general one)
-  const bool lean_ok = conv_use_lean(n_tgt, volume, n_pairs, c_src, v.nc, tile_rows) && small &&
-                       batch_groups == ME_MAX_BATCH_GROUPS;
-  if (lean_ok && (g_conv_variant == 0 || g_conv_variant >= 2048)) {
-    if (v.nc == 64) return launch_conv_tile_lean<64>(ME_CONV_ARGS);
-    return launch_conv_tile_lean<32>(ME_CONV_ARGS);
-  }
+  if (g_conv_variant >= 2048 && v.nc == 64 && v.kc == 64) return launch_conv_tile<64, 64, 0>(ME_CONV_ARGS, small);
   if (g_conv_variant == 1000 && v.kc == 64 && c_dst >= 128 && c_dst % 128 == 0)  // experiment: 128-column workgroups
     return launch_conv_tile<128, 64, 0>(src, c_src, wp, c_dst, c_dst / 128, plan_src, plan_dst, batch_desc, tile_bptr,
                                         order, dst, n_tgt, tile_rows, batch_groups, stream);

@@ -20,17 +20,29 @@ thread_local char g_last_error[512] = "";
 // =================================================================================================
 // scan
 // =================================================================================================
-__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s_wave /*[4+1]*/,
-                                                         uint32_t &block_total) {
+// T = uint32_t, or uint64_t for two 32-bit counters scanned at once (high and low word: me_plan_build)
+template <typename T>
+__device__ __forceinline__ T wave_inclusive_scan_t(T v) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const T t = __shfl_up(v, d, 64);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+template <typename T>
+__device__ __forceinline__ T block_exclusive_scan(T v, T *s_wave /*[kScanThreads / 64]*/, T &block_total) {
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
-  const uint32_t incl = wave_inclusive_scan(v);
+  const T incl = wave_inclusive_scan_t(v);
   if (lane == 63) s_wave[wave] = incl;
   __syncthreads();
-  uint32_t wave_off = 0, total = 0;
+  T wave_off = 0, total = 0;
 #pragma unroll
   for (int w = 0; w < kScanThreads / 64; ++w) {
-    const uint32_t t = s_wave[w];
+    const T t = s_wave[w];
     if (w < wave) wave_off += t;
     total += t;
   }
@@ -39,51 +51,51 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t *s
   return wave_off + incl - v;
 }
 
-__global__ __launch_bounds__(kScanThreads) void k_scan_block_sums(const uint32_t *__restrict__ in,
-                                                                 int64_t n,
-                                                                 uint32_t *__restrict__ bsums) {
-  __shared__ uint32_t s_wave[8];
+template <typename T>
+__global__ __launch_bounds__(kScanThreads) void k_scan_block_sums(const T *__restrict__ in, int64_t n,
+                                                                 T *__restrict__ bsums) {
+  __shared__ T s_wave[8];
   const int64_t base = (int64_t)blockIdx.x * kScanBlock + (int64_t)threadIdx.x * kScanItems;
-  uint32_t s = 0;
+  T s = 0;
 #pragma unroll
   for (int j = 0; j < kScanItems; ++j)
     if (base + j < n) s += in[base + j];
-  uint32_t total;
+  T total;
   (void)block_exclusive_scan(s, s_wave, total);
   if (threadIdx.x == 0) bsums[blockIdx.x] = total;
 }
 
 // single block: exclusive scan of the block sums in place, grand total to *total_dev
-__global__ __launch_bounds__(kScanThreads) void k_scan_of_sums(uint32_t *__restrict__ bsums,
-                                                              int64_t nb,
-                                                              uint32_t *__restrict__ total_dev) {
-  __shared__ uint32_t s_wave[8];
-  uint32_t carry = 0;
+template <typename T>
+__global__ __launch_bounds__(kScanThreads) void k_scan_of_sums(T *__restrict__ bsums, int64_t nb,
+                                                              T *__restrict__ total_dev) {
+  __shared__ T s_wave[8];
+  T carry = 0;
   for (int64_t base = 0; base < nb; base += kScanThreads) {
     const int64_t i = base + threadIdx.x;
-    const uint32_t v = (i < nb) ? bsums[i] : 0u;
-    uint32_t total;
-    const uint32_t ex = block_exclusive_scan(v, s_wave, total);
+    const T v = (i < nb) ? bsums[i] : (T)0;
+    T total;
+    const T ex = block_exclusive_scan(v, s_wave, total);
     if (i < nb) bsums[i] = carry + ex;
     carry += total;
   }
   if (threadIdx.x == 0 && total_dev) *total_dev = carry;
 }
 
-__global__ __launch_bounds__(kScanThreads) void k_scan_apply(const uint32_t *__restrict__ in,
-                                                            uint32_t *__restrict__ out, int64_t n,
-                                                            const uint32_t *__restrict__ bsums) {
-  __shared__ uint32_t s_wave[8];
+template <typename T>
+__global__ __launch_bounds__(kScanThreads) void k_scan_apply(const T *__restrict__ in, T *__restrict__ out,
+                                                            int64_t n, const T *__restrict__ bsums) {
+  __shared__ T s_wave[8];
   const int64_t base = (int64_t)blockIdx.x * kScanBlock + (int64_t)threadIdx.x * kScanItems;
-  uint32_t v[kScanItems];
-  uint32_t s = 0;
+  T v[kScanItems];
+  T s = 0;
 #pragma unroll
   for (int j = 0; j < kScanItems; ++j) {
-    v[j] = (base + j < n) ? in[base + j] : 0u;
+    v[j] = (base + j < n) ? in[base + j] : (T)0;
     s += v[j];
   }
-  uint32_t total;
-  uint32_t ex = block_exclusive_scan(s, s_wave, total) + bsums[blockIdx.x];
+  T total;
+  T ex = block_exclusive_scan(s, s_wave, total) + bsums[blockIdx.x];
 #pragma unroll
   for (int j = 0; j < kScanItems; ++j) {
     if (base + j < n) out[base + j] = ex;
@@ -91,24 +103,65 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(const uint32_t *__r
   }
 }
 
-int64_t scan_workspace_bytes(int64_t n) { return align_up((ceil_div(n, kScanBlock) + 1) * 4, 256); }
+// short inputs: ONE workgroup walks the array with a running carry (one launch instead of three; the map
+// builders of a network issue ~100 scans per step, most of them a few thousand items long)
+template <typename T>
+__global__ __launch_bounds__(kScanThreads) void k_scan_single(const T *__restrict__ in, T *__restrict__ out,
+                                                             int64_t n, T *__restrict__ total_dev) {
+  __shared__ T s_wave[8];
+  T carry = 0;
+  for (int64_t blk = 0; blk < n; blk += kScanBlock) {
+    const int64_t base = blk + (int64_t)threadIdx.x * kScanItems;
+    T v[kScanItems];
+    T s = 0;
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j) {
+      v[j] = (base + j < n) ? in[base + j] : (T)0;
+      s += v[j];
+    }
+    T total;
+    T ex = block_exclusive_scan(s, s_wave, total) + carry;
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j) {
+      if (base + j < n) out[base + j] = ex;
+      ex += v[j];
+    }
+    carry += total;
+  }
+  if (threadIdx.x == 0 && total_dev) *total_dev = carry;
+}
 
-int exclusive_scan_u32(const uint32_t *in, uint32_t *out, int64_t n, uint32_t *total_dev, void *ws,
-                       int64_t ws_bytes, hipStream_t stream) {
+constexpr int64_t kScanSingleMax = 16 * kScanBlock;
+
+int64_t scan_workspace_bytes(int64_t n) { return align_up((ceil_div(n, kScanBlock) + 1) * 8, 256); }
+
+template <typename T>
+static int exclusive_scan(const T *in, T *out, int64_t n, T *total_dev, void *ws, int64_t ws_bytes,
+                          hipStream_t stream) {
   if (n <= 0) {
-    if (total_dev) ME_HIP(hipMemsetAsync(total_dev, 0, 4, stream));
+    if (total_dev) ME_HIP(hipMemsetAsync(total_dev, 0, sizeof(T), stream));
+    return 0;
+  }
+  if (n <= kScanSingleMax) {
+    hipLaunchKernelGGL(k_scan_single<T>, dim3(1), dim3(kScanThreads), 0, stream, in, out, n, total_dev);
+    ME_LAUNCH_CHECK();
     return 0;
   }
   ME_CHECK(ws_bytes >= scan_workspace_bytes(n), "scan workspace too small");
-  uint32_t *bsums = reinterpret_cast<uint32_t *>(ws);
+  T *bsums = reinterpret_cast<T *>(ws);
   const int64_t nb = ceil_div(n, kScanBlock);
-  hipLaunchKernelGGL(k_scan_block_sums, dim3((unsigned)nb), dim3(kScanThreads), 0, stream, in, n, bsums);
+  hipLaunchKernelGGL(k_scan_block_sums<T>, dim3((unsigned)nb), dim3(kScanThreads), 0, stream, in, n, bsums);
   ME_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_scan_of_sums, dim3(1), dim3(kScanThreads), 0, stream, bsums, nb, total_dev);
+  hipLaunchKernelGGL(k_scan_of_sums<T>, dim3(1), dim3(kScanThreads), 0, stream, bsums, nb, total_dev);
   ME_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(kScanThreads), 0, stream, in, out, n, bsums);
+  hipLaunchKernelGGL(k_scan_apply<T>, dim3((unsigned)nb), dim3(kScanThreads), 0, stream, in, out, n, bsums);
   ME_LAUNCH_CHECK();
   return 0;
+}
+
+int exclusive_scan_u32(const uint32_t *in, uint32_t *out, int64_t n, uint32_t *total_dev, void *ws,
+                       int64_t ws_bytes, hipStream_t stream) {
+  return exclusive_scan<uint32_t>(in, out, n, total_dev, ws, ws_bytes, stream);
 }
 
 // =================================================================================================
@@ -385,8 +438,7 @@ __global__ __launch_bounds__(256) void k_kmap_transpose(const int32_t *__restric
 __global__ __launch_bounds__(256) void k_plan_count(const int32_t *__restrict__ tbl,
                                                    const int32_t *__restrict__ order, int64_t n_tgt,
                                                    int64_t volume, int64_t n_items, int tile_rows,
-                                                   int batch_groups, uint32_t *__restrict__ gcount,
-                                                   uint32_t *__restrict__ bcount) {
+                                                   int batch_groups, uint64_t *__restrict__ count_gb) {
   const int64_t item = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (item >= n_items) return;  // wave-uniform
   const int64_t t = item / volume, k = item % volume;
@@ -401,8 +453,8 @@ __global__ __launch_bounds__(256) void k_plan_count(const int32_t *__restrict__ 
   }
   if (lane_id() == 0) {
     const uint32_t groups = (count + ME_GROUP_ROWS - 1) / ME_GROUP_ROWS;
-    gcount[item] = groups;
-    bcount[item] = (groups + batch_groups - 1) / batch_groups;
+    // groups in the low word, batches in the high word: ONE scan yields both offsets
+    count_gb[item] = ((uint64_t)((groups + batch_groups - 1) / batch_groups) << 32) | groups;
   }
 }
 
@@ -417,10 +469,8 @@ __global__ __launch_bounds__(256) void k_plan_count(const int32_t *__restrict__ 
 __global__ __launch_bounds__(256) void k_plan_fill(const int32_t *__restrict__ tbl,
                                                   const int32_t *__restrict__ order, int64_t n_tgt,
                                                   int64_t volume, int64_t n_items, int tile_rows,
-                                                  int batch_groups, const uint32_t *__restrict__ goffs,
-                                                  const uint32_t *__restrict__ gtotal,
-                                                  const uint32_t *__restrict__ boffs,
-                                                  const uint32_t *__restrict__ btotal,
+                                                  int batch_groups, const uint64_t *__restrict__ offs_gb,
+                                                  const uint64_t *__restrict__ total_gb,
                                                   int32_t *__restrict__ plan_src,
                                                   int32_t *__restrict__ plan_dst,
                                                   int32_t *__restrict__ batch_desc,
@@ -431,7 +481,8 @@ __global__ __launch_bounds__(256) void k_plan_fill(const int32_t *__restrict__ t
   const int lane = lane_id();
   const int64_t t = item / volume, k = item % volume;
   const int64_t row0 = t * tile_rows;
-  const uint32_t g0 = goffs[item];
+  const uint64_t off_gb = offs_gb[item];  // first group (low word) and first batch (high word) of the item
+  const uint32_t g0 = (uint32_t)off_gb;
   const int64_t slot0 = (int64_t)g0 * ME_GROUP_ROWS;
   constexpr int kChunks = ME_MAX_TILE_ROWS / 64;
   // local row = c * 64 + lane, so its residue mod 8 is lane & 7 in every chunk
@@ -477,7 +528,7 @@ __global__ __launch_bounds__(256) void k_plan_fill(const int32_t *__restrict__ t
     plan_src[s] = -1;
     plan_dst[s] = tile_rows;
   }
-  const uint32_t b0 = boffs[item];
+  const uint32_t b0 = (uint32_t)(off_gb >> 32);
   const uint32_t nb = (groups + batch_groups - 1) / batch_groups;
   for (uint32_t j = lane; j < nb; j += 64) {
     // the groups are dealt evenly over the nb batches (5 groups -> 3 + 2, not 4 + 1): no one-group stragglers
@@ -498,8 +549,8 @@ __global__ __launch_bounds__(256) void k_plan_fill(const int32_t *__restrict__ t
     item_gptr[item] = (int32_t)g0;
     if (k == 0) tile_bptr[t] = (int32_t)b0;
     if (item == 0) {
-      tile_bptr[n_tiles] = (int32_t)(*btotal);
-      item_gptr[n_items] = (int32_t)(*gtotal);
+      tile_bptr[n_tiles] = (int32_t)(*total_gb >> 32);
+      item_gptr[n_items] = (int32_t)(uint32_t)(*total_gb);
     }
   }
 }
@@ -715,8 +766,8 @@ int64_t me_kernel_map_workspace_bytes(int64_t n_out, int64_t volume) {
 
 int me_kernel_map_probe(const uint64_t *in_table, int64_t in_capacity, const int32_t *in_coords,
                         const int32_t *out_coords, int64_t n_out, const me_region *region,
-                        int32_t *nbr, int64_t *k_offsets, void *workspace, int64_t workspace_bytes,
-                        void *stream_) {
+                        int32_t *nbr, int64_t *k_offsets, int64_t *k_offsets_dev, void *workspace,
+                        int64_t workspace_bytes, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   ME_CHECK(region != nullptr, "region must not be null");
   const int64_t volume = me_region_volume(region);
@@ -732,6 +783,7 @@ int me_kernel_map_probe(const uint64_t *in_table, int64_t in_capacity, const int
   ME_CHECK(workspace_bytes >= me_kernel_map_workspace_bytes(n_out, volume), "workspace too small");
   if (n_out == 0) {
     for (int64_t k = 0; k <= volume; ++k) k_offsets[k] = 0;
+    if (k_offsets_dev) ME_HIP(hipMemsetAsync(k_offsets_dev, 0, (size_t)(volume + 1) * 8, stream));
     return 0;
   }
   const int ncol = region->ncol;
@@ -741,7 +793,8 @@ int me_kernel_map_probe(const uint64_t *in_table, int64_t in_capacity, const int
   const int64_t nw = kmap_nw(n_out);
   uint32_t *wcount = reinterpret_cast<uint32_t *>(ws);
   uint32_t *total = reinterpret_cast<uint32_t *>(ws + kmap_counts_bytes(n_out, volume));
-  int64_t *koffs = reinterpret_cast<int64_t *>(ws + kmap_counts_bytes(n_out, volume) + 256);
+  int64_t *koffs = k_offsets_dev ? k_offsets_dev
+                                 : reinterpret_cast<int64_t *>(ws + kmap_counts_bytes(n_out, volume) + 256);
   void *scan_ws = ws + kmap_counts_bytes(n_out, volume) + 256 + align_up((volume + 1) * 8, 256);
   const dim3 grid((unsigned)ceil_div(n_out, 256), (unsigned)volume), block(256);
   const uint32_t mask = (uint32_t)(in_capacity - 1);
@@ -802,7 +855,7 @@ int64_t me_plan_max_groups(int64_t n_tgt, int64_t volume, int64_t n_pairs, int32
 // plan workspace: gcount | goffs | bcount | boffs [items each] | totals | scan ws
 int64_t me_plan_workspace_bytes(int64_t n_tgt, int64_t volume, int32_t tile_rows) {
   const int64_t items = me_plan_num_tiles(n_tgt < 1 ? 1 : n_tgt, tile_rows) * volume;
-  return 4 * align_up(items * 4, 256) + 256 + scan_workspace_bytes(items);
+  return 2 * align_up(items * 8, 256) + 256 + scan_workspace_bytes(items);
 }
 
 int me_plan_build(const int32_t *tbl, const int32_t *order, int64_t n_tgt, int64_t volume, int32_t tile_rows,
@@ -822,25 +875,21 @@ int me_plan_build(const int32_t *tbl, const int32_t *order, int64_t n_tgt, int64
   const int64_t items = n_tiles * volume;
   ME_CHECK(items < (1ll << 31), "too many (tile, offset) items");
   char *ws = reinterpret_cast<char *>(workspace);
-  const int64_t asz = align_up(items * 4, 256);
-  uint32_t *gcount = reinterpret_cast<uint32_t *>(ws);
-  uint32_t *goffs = reinterpret_cast<uint32_t *>(ws + asz);
-  uint32_t *bcount = reinterpret_cast<uint32_t *>(ws + 2 * asz);
-  uint32_t *boffs = reinterpret_cast<uint32_t *>(ws + 3 * asz);
-  uint32_t *gtotal = reinterpret_cast<uint32_t *>(ws + 4 * asz);
-  uint32_t *btotal = gtotal + 1;
-  void *scan_ws = ws + 4 * asz + 256;
+  const int64_t asz = align_up(items * 8, 256);
+  uint64_t *count_gb = reinterpret_cast<uint64_t *>(ws);
+  uint64_t *offs_gb = reinterpret_cast<uint64_t *>(ws + asz);
+  uint64_t *total_gb = reinterpret_cast<uint64_t *>(ws + 2 * asz);
+  void *scan_ws = ws + 2 * asz + 256;
   const dim3 grid((unsigned)ceil_div(items, 4)), block(256);
   hipLaunchKernelGGL(k_plan_count, grid, block, 0, stream, tbl, order, n_tgt, volume, items, (int)tile_rows,
-                     (int)batch_groups, gcount, bcount);
+                     (int)batch_groups, count_gb);
   ME_LAUNCH_CHECK();
-  if (int rc = exclusive_scan_u32(gcount, goffs, items, gtotal, scan_ws, scan_workspace_bytes(items), stream))
-    return rc;
-  if (int rc = exclusive_scan_u32(bcount, boffs, items, btotal, scan_ws, scan_workspace_bytes(items), stream))
+  if (int rc = exclusive_scan<uint64_t>(count_gb, offs_gb, items, total_gb, scan_ws, scan_workspace_bytes(items),
+                                        stream))
     return rc;
   hipLaunchKernelGGL(k_plan_fill, grid, block, 0, stream, tbl, order, n_tgt, volume, items, (int)tile_rows,
-                     (int)batch_groups, goffs, gtotal, boffs, btotal, plan_src, plan_dst, batch_desc, tile_bptr,
-                     item_gptr, n_tiles);
+                     (int)batch_groups, offs_gb, total_gb, plan_src, plan_dst, batch_desc, tile_bptr, item_gptr,
+                     n_tiles);
   ME_LAUNCH_CHECK();
   return 0;
 }
