@@ -1352,6 +1352,7 @@ struct WgradGeom {
 static WgradGeom wgrad_geom(int64_t n_pairs, int64_t volume, int c_in, int c_out) {
   WgradGeom g;
   g.nb = c_out <= 64 ? 1 : (c_out <= 128 ? 2 : 4);
+  if (g_wgrad_depth >= 100) g.nb = g_wgrad_depth / 100;  // tuning: depth = 100 * nb + ring depth
   g.n_cib = (int)ceil_div(c_in, 16 * kWgMB);
   g.n_cob = (int)ceil_div(c_out, 16 * g.nb);
   g.waves = g.n_cob < 4 ? g.n_cob : 4;
@@ -1442,7 +1443,7 @@ static int wgrad_launch(const T *x, int64_t n_in, int32_t c_in, const T *dy, int
   const int64_t n_pairs = k_offsets[volume];
   const WgradGeom g = wgrad_geom(n_pairs, volume, c_in, c_out);
   float *partial = reinterpret_cast<float *>(workspace);
-  const int depth = g_wgrad_depth > 0 ? g_wgrad_depth : (g.nb == 4 ? 8 : 4);  // measured: profiles/r01_tune_wgrad_v2.log
+  const int depth = (g_wgrad_depth > 0 && g_wgrad_depth % 100 > 0) ? g_wgrad_depth % 100 : (g.nb == 4 ? 8 : 4);  // measured: profiles/r01_tune_wgrad_v2.log
   if (n_pairs > 0) {
     const dim3 grid((unsigned)g.ranges, (unsigned)g.n_cib, (unsigned)g.gz);
     const dim3 block(64 * g.waves);
