@@ -32,7 +32,7 @@ __device__ __forceinline__ void mma_groups_bf16(const __bf16 *__restrict__ a0p, 
                                                 const int32_t *__restrict__ dstp, float *__restrict__ accp) {
   int d[R];
 #pragma unroll
-  for (int r = 0; r < R; ++r) d[r] = dstp[r * 16];
+  for (int r = 0; r < R; ++r) d[r] = (int)__umul24((unsigned)dstp[r * 16], (unsigned)ACC_LD);  // see mma_groups
   f32x4 acc[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -46,9 +46,9 @@ __device__ __forceinline__ void mma_groups_bf16(const __bf16 *__restrict__ a0p, 
   }
   f32x4 old[R];
 #pragma unroll
-  for (int r = 0; r < R; ++r) old[r] = *reinterpret_cast<const f32x4 *>(accp + d[r] * ACC_LD);
+  for (int r = 0; r < R; ++r) old[r] = *reinterpret_cast<const f32x4 *>(accp + d[r]);
 #pragma unroll
-  for (int r = 0; r < R; ++r) *reinterpret_cast<f32x4 *>(accp + d[r] * ACC_LD) = old[r] + acc[r];
+  for (int r = 0; r < R; ++r) *reinterpret_cast<f32x4 *>(accp + d[r]) = old[r] + acc[r];
 }
 
 // Packed weights: the register image of the MFMA A operand.  For offset k, source-channel chunk c,
@@ -91,7 +91,8 @@ __global__ __launch_bounds__(256) void k_pack_weights_bf16(const void *__restric
 
 // See k_conv_tile_f32 (conv.hip) for the pipeline; differences are the element type and the MFMA shape.
 // EXACT: c_src is a multiple of KC (rows need no channel guards).
-template <int NC, int KC, bool EXACT>
+// SMALL: 32-bit gather offsets with a 24-bit row multiply (host-checked: < 2^24 rows, source matrix < 4 GiB).
+template <int NC, int KC, bool EXACT, bool SMALL>
 __global__ __launch_bounds__(NC * 4, 3) void k_conv_tile_bf16(
     const __bf16 *__restrict__ src, int c_src, const bf16x8 *__restrict__ wp, int c_dst,
     const int32_t *__restrict__ plan_src, const int32_t *__restrict__ plan_dst,
@@ -149,23 +150,35 @@ __global__ __launch_bounds__(NC * 4, 3) void k_conv_tile_bf16(
   bf16x8 stage[ITER];
   int32_t dstv = tile_rows;
   int32_t sidx[ITER];
-  int32_t sprev[ITER];
   bf16x8 wreg[KS], wnxt[KS];
 
+  // As in k_conv_tile_f32: the 64-entry index window of a batch is read to its end unconditionally (the plan is
+  // followed by 64 valid entries), and padding slots (index -1) gather row 0 without being zeroed — their
+  // products land in the dummy accumulator row.
   auto load_sidx = [&](int g0, int ng) {
-    const int last = ng * 16 - 1;
+    (void)ng;
+    const char *pb = reinterpret_cast<const char *>(plan_src + (int64_t)g0 * 16);
 #pragma unroll
-    for (int j = 0; j < ITER; ++j) sidx[j] = plan_src[(int64_t)g0 * 16 + min((j * NT + tid) / F8, last)];
+    for (int j = 0; j < ITER; ++j)
+      sidx[j] = *reinterpret_cast<const int32_t *>(pb + (unsigned)(((j * NT + tid) / F8) * 4));
   };
+  const char *srcb = reinterpret_cast<const char *>(src);
+  const unsigned row_bytes = (unsigned)c_src * 2u;
   auto gather = [&](int chunk, int g0, int ng) {
     const int c0 = chunk * KC;
-    dstv = plan_dst[(int64_t)g0 * 16 + min(tid, ng * 16 - 1)];
+    (void)ng;
+    dstv = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(plan_dst + (int64_t)g0 * 16) +
+                                             (unsigned)(min(tid, ME_MAX_BATCH_GROUPS * 16 - 1) * 4));
 #pragma unroll
     for (int j = 0; j < ITER; ++j) {
       const int ch = c0 + ((j * NT + tid) % F8) * 8;
-      const int sr = sidx[j];
-      sprev[j] = sr;
-      const __bf16 *rowp = src + (int64_t)max(sr, 0) * c_src;
+      const int sr = max(sidx[j], 0);
+      if (SMALL && (EXACT || vec_ok)) {
+        const unsigned off = __umul24((unsigned)sr, row_bytes) + (unsigned)(EXACT ? ch : min(ch, c_src - 8)) * 2u;
+        stage[j] = *reinterpret_cast<const bf16x8 *>(srcb + off);
+        continue;
+      }
+      const __bf16 *rowp = src + (int64_t)sr * c_src;
       if (EXACT) {
         stage[j] = *reinterpret_cast<const bf16x8 *>(rowp + ch);
       } else if (vec_ok) {
@@ -191,10 +204,6 @@ __global__ __launch_bounds__(NC * 4, 3) void k_conv_tile_bf16(
 #pragma unroll
         for (int e = 0; e < 8; ++e)
           if (ch + e >= c_src) t[e] = (__bf16)0.f;
-      }
-      if (sprev[j] < 0) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) t[e] = (__bf16)0.f;
       }
       if (r < cap_rows) *reinterpret_cast<bf16x8 *>(&s_a[r * A_LD + (idx % F8) * 8]) = t;
     }
@@ -292,24 +301,24 @@ template <int NC, int KC>
 static int launch_conv_tile_bf16(const __bf16 *src, int c_src, const bf16x8 *wp, int c_dst, int slabs,
                                  const int32_t *plan_src, const int32_t *plan_dst, const int32_t *batch_desc,
                                  const int32_t *tile_bptr, const int32_t *order, __bf16 *dst, int64_t n_tgt,
-                                 int tile_rows, int batch_groups, hipStream_t stream) {
+                                 int tile_rows, int batch_groups, hipStream_t stream, bool small) {
   const int lds = conv_bf16_lds_bytes(NC, KC, tile_rows, batch_groups);
   ME_CHECK(lds <= kLdsBudget, "tile_rows / batch_groups too large for the LDS of one workgroup");
   const bool exact = (c_src % KC) == 0;
-  static bool attr_set[2] = {false, false};  // per instantiation
-  if (lds > 48 * 1024 && !attr_set[exact]) {
-    const void *fn = exact ? reinterpret_cast<const void *>(&k_conv_tile_bf16<NC, KC, true>)
-                           : reinterpret_cast<const void *>(&k_conv_tile_bf16<NC, KC, false>);
-    ME_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
-    attr_set[exact] = true;
+  typedef void (*kernel_t)(const __bf16 *, int, const bf16x8 *, int, const int32_t *, const int32_t *, const int32_t *,
+                           const int32_t *, const int32_t *, __bf16 *, int64_t, int, int);
+  const kernel_t fn = small ? (exact ? &k_conv_tile_bf16<NC, KC, true, true> : &k_conv_tile_bf16<NC, KC, false, true>)
+                            : (exact ? &k_conv_tile_bf16<NC, KC, true, false> : &k_conv_tile_bf16<NC, KC, false, false>);
+  static bool attr_set[4] = {false, false, false, false};  // per instantiation
+  const int which = (small ? 2 : 0) + (exact ? 1 : 0);
+  if (lds > 48 * 1024 && !attr_set[which]) {
+    ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               kLdsBudget));
+    attr_set[which] = true;
   }
   const dim3 grid((unsigned)ceil_div(n_tgt, tile_rows), (unsigned)slabs);
-  if (exact)
-    hipLaunchKernelGGL((k_conv_tile_bf16<NC, KC, true>), grid, dim3(NC * 4), (size_t)lds, stream, src, c_src, wp, c_dst,
-                       plan_src, plan_dst, batch_desc, tile_bptr, order, dst, n_tgt, tile_rows, batch_groups);
-  else
-    hipLaunchKernelGGL((k_conv_tile_bf16<NC, KC, false>), grid, dim3(NC * 4), (size_t)lds, stream, src, c_src, wp, c_dst,
-                       plan_src, plan_dst, batch_desc, tile_bptr, order, dst, n_tgt, tile_rows, batch_groups);
+  hipLaunchKernelGGL(fn, grid, dim3(NC * 4), (size_t)lds, stream, src, c_src, wp, c_dst, plan_src, plan_dst, batch_desc,
+                     tile_bptr, order, dst, n_tgt, tile_rows, batch_groups);
   ME_LAUNCH_CHECK();
   return 0;
 }
@@ -376,8 +385,9 @@ int me_conv_target_bf16(const uint16_t *src_, int64_t n_src, int32_t c_src, cons
                         const int32_t *batch_desc, const int32_t *tile_bptr, const int32_t *order, uint16_t *dst_,
                         int64_t n_tgt, int32_t tile_rows, int32_t batch_groups, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  (void)n_src;
   (void)volume;
+  // 32-bit byte offsets with a 24-bit row multiply need a source matrix below 4 GiB
+  const bool small = n_src > 0 && n_src < (1ll << 24) && n_src * c_src * 2 < (1ll << 32);
   ME_CHECK(c_src > 0 && c_dst > 0, "channel counts must be positive");
   ME_CHECK(tile_rows >= ME_GROUP_ROWS && tile_rows <= ME_MAX_TILE_ROWS, "tile_rows out of range");
   ME_CHECK(batch_groups >= 1 && batch_groups <= ME_MAX_BATCH_GROUPS, "batch_groups out of range");
@@ -390,7 +400,7 @@ int me_conv_target_bf16(const uint16_t *src_, int64_t n_src, int32_t c_src, cons
   const ConvVariantBf16 v = conv_variant_bf16(c_src, c_dst);
 #define ME_CONV_CASE(NCV, KCV)                                                                                   \
   return launch_conv_tile_bf16<NCV, KCV>(src, c_src, wp, c_dst, v.slabs, plan_src, plan_dst, batch_desc, tile_bptr, \
-                                         order, dst, n_tgt, tile_rows, batch_groups, stream)
+                                         order, dst, n_tgt, tile_rows, batch_groups, stream, small)
   if (v.nc == 32) {
     if (v.kc == 128) ME_CONV_CASE(32, 128);
     if (v.kc == 96) ME_CONV_CASE(32, 96);
