@@ -34,9 +34,13 @@ namespace me {
 // profiles/r01_ablation_conv_v6c.log puts the operand reads at 78 of 192 us).  Instead lane q reads the pieces
 // q, 4 + q, 8 + q, ... (the weights are packed in the same channel order) and piece p of row r is stored at
 // slot p ^ swz(r) of an UNPADDED row: every 16-lane service group then touches 16 distinct 16-byte bank slots.
-__host__ __device__ constexpr int stage_ld(int kc) { return kc >= 32 ? kc : kc + 4; }  // floats per staged row
+// (KC = 96: 24 pieces per row, an XOR swizzle would leave the row; rows padded to 100 floats = 25 pieces instead,
+// an odd stride, so the 16 rows of a group start in 16 different bank slots)
+__host__ __device__ constexpr int stage_ld(int kc) {  // floats per staged row
+  return kc == 96 ? 100 : (kc >= 32 ? kc : kc + 4);
+}
 __device__ __forceinline__ int stage_swz(int kc, int row) {
-  return kc >= 64 ? (row & 15) : (kc == 32 ? ((row >> 1) & 7) : 0);
+  return kc == 96 ? 0 : (kc >= 64 ? (row & 15) : (kc == 32 ? ((row >> 1) & 7) : 0));
 }
 
 // LDS bytes of one workgroup of k_conv_tile_f32<NC, KC>: accumulator tile (+ one dummy row for padding
@@ -181,7 +185,7 @@ __device__ unsigned long long d_conv_timing[8];
 // neighbour).  Occupancy hides latencies but not instruction issue, so every VALU / VMEM instruction of the loop is
 // paid for in matrix time.
 template <int NC, int KC, bool EXACT, int VAR, bool SMALL = false>
-__global__ __launch_bounds__(NC * 4, (NC == 128 ? 2 : 3)) void k_conv_tile_f32(
+__global__ __launch_bounds__(NC * 4, ((NC >= 96 || KC == 96) ? 2 : 3)) void k_conv_tile_f32(
     const float *__restrict__ src, int c_src, const f32x4 *__restrict__ wp, int c_dst,
     const int32_t *__restrict__ plan_src, const int32_t *__restrict__ plan_dst,
     const int32_t *__restrict__ batch_desc, const int32_t *__restrict__ tile_bptr,
@@ -273,7 +277,8 @@ __global__ __launch_bounds__(NC * 4, (NC == 128 ? 2 : 3)) void k_conv_tile_f32(
     const char *pb = reinterpret_cast<const char *>(plan_src + (int64_t)g0 * 16);
 #pragma unroll
     for (int j = 0; j < ITER; ++j)
-      sidx[j] = *reinterpret_cast<const int32_t *>(pb + (unsigned)(((j * NT + tid) / F4) * 4));
+      sidx[j] = *reinterpret_cast<const int32_t *>(
+          pb + (unsigned)(min((j * NT + tid) / F4, ME_MAX_BATCH_GROUPS * 16 - 1) * 4));
   };
   // issue the gather of the batch whose indices sit in sidx (global -> registers); nothing here consumes
   // the result
@@ -1232,14 +1237,19 @@ struct ConvVariant {
   int kc;     // source-channel chunk (64, 32 or 16)
 };
 
+extern int g_conv_variant;
+
 static ConvVariant conv_variant(int c_src, int c_dst) {
   ConvVariant v;
-  // columns per workgroup: 64 unless the last 64-column slab would be at most half full
+  const bool allow96 = g_conv_variant != 9;  // (variant 9: the 32-wide passes that 96 channels used to take)
+  // columns per workgroup: 64 unless the last 64-column slab would be at most half full; 96-channel layers
+  // (MinkUNet's decoder) get ONE 96-column slab of six waves instead of three 32-column passes over the same rows
   const int rem = c_dst % 64;
-  v.nc = (rem != 0 && rem <= 32) ? 32 : 64;
+  v.nc = (allow96 && c_dst % 96 == 0 && rem != 0) ? 96 : ((rem != 0 && rem <= 32) ? 32 : 64);
   v.slabs = (int)ceil_div(c_dst, v.nc);
-  // source-channel chunk: the largest of {64, 32, 16} that adds at most 16 channels of padding
-  if (c_src % 64 == 0) v.kc = 64;
+  // source-channel chunk: the largest of {96, 64, 32, 16} that adds at most 16 channels of padding
+  if (allow96 && c_src % 96 == 0 && c_src % 64 != 0) v.kc = 96;
+  else if (c_src % 64 == 0) v.kc = 64;
   else if (c_src % 32 == 0) v.kc = 32;
   else if (c_src <= 16) v.kc = 16;
   else if (c_src <= 32) v.kc = 32;
@@ -1518,7 +1528,9 @@ int me_conv_pack_weights_f32(const float *w, int64_t volume, int32_t c_src, int3
   const int64_t total = volume * nchunks * ncb * (v.kc / 16) * 64;  // 16-byte elements
   f32x4 *wp4 = reinterpret_cast<f32x4 *>(wp);
   const dim3 grid((unsigned)ceil_div(total, 256)), block(256);
-  if (v.kc == 64)
+  if (v.kc == 96)
+    hipLaunchKernelGGL(k_pack_weights<96>, grid, block, 0, stream, w, c_src, c_dst, transposed, nchunks, ncb, wp4, total);
+  else if (v.kc == 64)
     hipLaunchKernelGGL(k_pack_weights<64>, grid, block, 0, stream, w, c_src, c_dst, transposed, nchunks, ncb, wp4, total);
   else if (v.kc == 32)
     hipLaunchKernelGGL(k_pack_weights<32>, grid, block, 0, stream, w, c_src, c_dst, transposed, nchunks, ncb, wp4, total);
@@ -1564,11 +1576,18 @@ int me_conv_target_f32(const float *src, int64_t n_src, int32_t c_src, const flo
     }
   }
 #define ME_CONV_CASE(NCV, KCV) return launch_conv_tile<NCV, KCV, 0>(ME_CONV_ARGS, small)
-  if (v.nc == 32) {
+  if (v.nc == 96) {
+    if (v.kc == 96) ME_CONV_CASE(96, 96);
+    if (v.kc == 64) ME_CONV_CASE(96, 64);
+    if (v.kc == 32) ME_CONV_CASE(96, 32);
+    ME_CONV_CASE(96, 16);
+  } else if (v.nc == 32) {
+    if (v.kc == 96) ME_CONV_CASE(32, 96);
     if (v.kc == 64) ME_CONV_CASE(32, 64);
     if (v.kc == 32) ME_CONV_CASE(32, 32);
     ME_CONV_CASE(32, 16);
   } else {
+    if (v.kc == 96) ME_CONV_CASE(64, 96);
     if (v.kc == 64) ME_CONV_CASE(64, 64);
     if (v.kc == 32) ME_CONV_CASE(64, 32);
     ME_CONV_CASE(64, 16);
