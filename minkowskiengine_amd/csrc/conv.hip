@@ -1461,7 +1461,8 @@ static int wgrad_launch(const T *x, int64_t n_in, int32_t c_in, const T *dy, int
     // 32-bit byte offsets with a 24-bit row multiply (load_piece<SMALL>)
     const int64_t lim = 1ll << 32;
     const bool small = n_in > 0 && n_out > 0 && n_in < (1 << 24) && n_out < (1 << 24) &&
-                       n_in * c_in * (int64_t)sizeof(T) < lim && n_out * c_out * (int64_t)sizeof(T) < lim;
+                       n_in * c_in * (int64_t)sizeof(T) < lim && n_out * c_out * (int64_t)sizeof(T) < lim &&
+                       g_conv_variant != 6;  // (variant 6: the 64-bit address path, tests/test_gpu_conv.py)
 #define ME_WGRAD_LAUNCH(NBV, DV)                                                                                 \
   do {                                                                                                           \
     if (vec && small)                                                                                            \

@@ -325,6 +325,10 @@ static int launch_conv_tile_bf16(const __bf16 *src, int c_src, const bf16x8 *wp,
 
 }  // namespace me
 
+namespace me {
+extern int g_conv_variant;  // conv.hip: variant 6 = 64-bit gather addresses
+}
+
 using namespace me;
 
 extern "C" {
@@ -387,7 +391,7 @@ int me_conv_target_bf16(const uint16_t *src_, int64_t n_src, int32_t c_src, cons
   hipStream_t stream = (hipStream_t)stream_;
   (void)volume;
   // 32-bit byte offsets with a 24-bit row multiply need a source matrix below 4 GiB
-  const bool small = n_src > 0 && n_src < (1ll << 24) && n_src * c_src * 2 < (1ll << 32);
+  const bool small = n_src > 0 && n_src < (1ll << 24) && n_src * c_src * 2 < (1ll << 32) && g_conv_variant != 6;
   ME_CHECK(c_src > 0 && c_dst > 0, "channel counts must be positive");
   ME_CHECK(tile_rows >= ME_GROUP_ROWS && tile_rows <= ME_MAX_TILE_ROWS, "tile_rows out of range");
   ME_CHECK(batch_groups >= 1 && batch_groups <= ME_MAX_BATCH_GROUPS, "batch_groups out of range");

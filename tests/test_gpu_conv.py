@@ -66,6 +66,39 @@ def test_conv_forward_backward_vs_oracle(device, n, extent, D, cin, cout, ks, st
     assert rel_err(conv.kernel.grad.cpu().numpy(), gw) < TOL
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("n,extent,D,cin,cout,ks,stride,dil", [CONV_CASES[1], CONV_CASES[5], CONV_CASES[7]])
+def test_wide_address_kernels_match_the_default(device, dtype, n, extent, D, cin, cout, ks, stride, dil):
+    """Feature matrices of 4 GiB and more (or 2^24 rows) take kernels with 64-bit gather addresses instead of the
+    32-bit offsets every other test exercises; debug variant 6 forces them.  Same plan, same summation order:
+    forward, grad_in and grad_kernel must be bit-identical to the default kernels."""
+    from minkowskiengine_amd import _lib
+    import minkowskiengine_amd as ME
+    lib = _lib.load()
+    coords = make_cloud(n, extent, D, seed=n + cin, batch=2, negative=True)
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    g = torch.Generator().manual_seed(3)
+    feats = torch.rand(coords.shape[0], cin, generator=g)
+    kernel = torch.rand(ks ** D, cin, cout, generator=g) - 0.5
+    results = []
+    for variant in (0, 6):
+        lib.me_debug_set_conv_variant(variant)
+        try:
+            conv = ME.MinkowskiConvolution(cin, cout, kernel_size=ks, stride=stride, dilation=dil, dimension=D)
+            with torch.no_grad():
+                conv.kernel.copy_(kernel)
+            conv = conv.to(device)
+            x = ME.SparseTensor(feats.to(device).to(tdt), coords.to(device), requires_grad=True)
+            y = conv(x)
+            y.F.backward(torch.ones_like(y.F))
+            torch.cuda.synchronize()
+            results.append((y.F.detach().clone(), x.F.grad.clone(), conv.kernel.grad.clone()))
+        finally:
+            lib.me_debug_set_conv_variant(0)
+    for a, b in zip(*results):
+        assert torch.equal(a, b)
+
+
 def test_mfma_and_naive_kernels_agree(device):
     from minkowskiengine_amd import backend as MEB
     coords = make_cloud(3000, 14, 3, seed=4, negative=True).to(device)
