@@ -103,26 +103,40 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(const T *__restrict
   }
 }
 
-// short inputs: ONE workgroup walks the array with a running carry (one launch instead of three; the map
-// builders of a network issue ~100 scans per step, most of them a few thousand items long)
+// short inputs: ONE workgroup of 1024 threads walks the array 8192 items at a time with a running carry (one launch
+// instead of three; the map builders of a network issue ~100 scans per step, most of them a few thousand to a few
+// ten thousand items long)
+constexpr int kScanSingleThreads = 1024, kScanSingleItems = 8;
 template <typename T>
-__global__ __launch_bounds__(kScanThreads) void k_scan_single(const T *__restrict__ in, T *__restrict__ out,
-                                                             int64_t n, T *__restrict__ total_dev) {
-  __shared__ T s_wave[8];
+__global__ __launch_bounds__(kScanSingleThreads) void k_scan_single(const T *__restrict__ in, T *__restrict__ out,
+                                                                   int64_t n, T *__restrict__ total_dev) {
+  constexpr int kWaves = kScanSingleThreads / 64;
+  __shared__ T s_wave[kWaves];
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
   T carry = 0;
-  for (int64_t blk = 0; blk < n; blk += kScanBlock) {
-    const int64_t base = blk + (int64_t)threadIdx.x * kScanItems;
-    T v[kScanItems];
+  for (int64_t blk = 0; blk < n; blk += kScanSingleThreads * kScanSingleItems) {
+    const int64_t base = blk + (int64_t)threadIdx.x * kScanSingleItems;
+    T v[kScanSingleItems];
     T s = 0;
 #pragma unroll
-    for (int j = 0; j < kScanItems; ++j) {
+    for (int j = 0; j < kScanSingleItems; ++j) {
       v[j] = (base + j < n) ? in[base + j] : (T)0;
       s += v[j];
     }
-    T total;
-    T ex = block_exclusive_scan(s, s_wave, total) + carry;
+    const T incl = wave_inclusive_scan_t(s);
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    T wave_off = 0, total = 0;
 #pragma unroll
-    for (int j = 0; j < kScanItems; ++j) {
+    for (int w = 0; w < kWaves; ++w) {
+      const T t = s_wave[w];
+      if (w < wave) wave_off += t;
+      total += t;
+    }
+    __syncthreads();
+    T ex = carry + wave_off + incl - s;
+#pragma unroll
+    for (int j = 0; j < kScanSingleItems; ++j) {
       if (base + j < n) out[base + j] = ex;
       ex += v[j];
     }
@@ -131,7 +145,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_single(const T *__restric
   if (threadIdx.x == 0 && total_dev) *total_dev = carry;
 }
 
-constexpr int64_t kScanSingleMax = 16 * kScanBlock;
+constexpr int64_t kScanSingleMax = 4 * kScanSingleThreads * kScanSingleItems;  // 32768 items
 
 int64_t scan_workspace_bytes(int64_t n) { return align_up((ceil_div(n, kScanBlock) + 1) * 8, 256); }
 
@@ -143,7 +157,7 @@ static int exclusive_scan(const T *in, T *out, int64_t n, T *total_dev, void *ws
     return 0;
   }
   if (n <= kScanSingleMax) {
-    hipLaunchKernelGGL(k_scan_single<T>, dim3(1), dim3(kScanThreads), 0, stream, in, out, n, total_dev);
+    hipLaunchKernelGGL(k_scan_single<T>, dim3(1), dim3(kScanSingleThreads), 0, stream, in, out, n, total_dev);
     ME_LAUNCH_CHECK();
     return 0;
   }
