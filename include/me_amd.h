@@ -128,20 +128,24 @@ int me_kernel_map_transpose(const int32_t *in_pairs_dev, const int32_t *out_pair
  * [ME_GROUP_ROWS, ME_MAX_TILE_ROWS]; me_conv_plan_config picks it so that tiles x column slabs
  * fill the GPU's workgroup slots evenly).  Per tile and kernel offset k ("item") the valid
  * (k, source row) entries are padded to groups of 16 (one MFMA tile) and the groups are cut into
- * batches of at most `batch_groups` groups; a batch is what the convolution kernel stages in LDS at
- * once and never mixes offsets. */
+ * batches of at most `batch_groups` groups (dealt evenly: 5 groups -> 3 + 2); a batch is what the convolution
+ * kernel stages in LDS at once and never mixes offsets. */
 #define ME_GROUP_ROWS 16
 #define ME_MAX_TILE_ROWS 256
 #define ME_MAX_BATCH_GROUPS 4
 int64_t me_plan_num_tiles(int64_t n_tgt, int32_t tile_rows);
-/* upper bound on the number of groups (and of batches) for a table with n_pairs valid entries */
+/* upper bound on the number of groups (and of batches) for a table with n_pairs valid entries; includes the four
+ * groups (64 slots) that me_plan_build fills BEHIND the last group of the plan with {source row 0, dummy target row}:
+ * the convolution kernels read the 64-slot index window of a batch to its end without clamping.  plan_src_dev /
+ * plan_dst_dev must therefore really hold 16 * me_plan_max_groups entries. */
 int64_t me_plan_max_groups(int64_t n_tgt, int64_t volume, int64_t n_pairs, int32_t tile_rows);
 int64_t me_plan_workspace_bytes(int64_t n_tgt, int64_t volume, int32_t tile_rows);
 /*   tbl_dev        int32 [volume, n_tgt]  neighbour table (nbr for forward, nbrT for dgrad)
  *   order_dev      int32 [n_tgt] or NULL   target rows in tile order: tile t owns the rows
  *                                          order[t*tile_rows .. (t+1)*tile_rows)  (NULL = identity;
  *                                          pass the argsort of me_coords_spatial_keys for compact tiles)
- *   plan_src_dev   int32 [16 * max_groups] (out) source row per slot, -1 = padding
+ *   plan_src_dev   int32 [16 * max_groups] (out) source row per slot, -1 = padding (the kernels gather row 0 for it;
+ *                                                its products land in the dummy accumulator row)
  *   plan_dst_dev   int32 [16 * max_groups] (out) target row local to its tile; padding slots point at
  *                                                the dummy row `tile_rows`; the global target row of
  *                                                (tile t, local row d) is order[t * tile_rows + d]
@@ -182,7 +186,7 @@ int me_conv_target_f32(const float *src_feat_dev, int64_t n_src, int32_t c_src,
 /* Plan geometry for a (target rows, channels) problem: the tile height is chosen so that tiles x column
  * slabs is just below a multiple of the GPU's resident-workgroup slots (a 100k-voxel layer is only
  * ~2 workgroup rounds long, so an unlucky tile count can idle a third of the chip) while the
- * accumulator tile + two stage buffers of batch_groups groups fit the 160 KiB LDS; n_pairs (density)
+ * accumulator tile + the stage buffer of batch_groups groups fit the 160 KiB LDS; n_pairs (density)
  * steers the trade-off against the 16-row group padding and sizes the batch. */
 int me_conv_plan_config(int64_t n_tgt, int64_t volume, int64_t n_pairs, int32_t c_src, int32_t c_dst,
                         int32_t *tile_rows, int32_t *batch_groups);
