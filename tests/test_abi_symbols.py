@@ -46,6 +46,10 @@ def test_host_only_entry_points():
     assert lib.me_region_volume(ctypes.byref(rg)) == 9
     rg = _lib.make_region(5, 0, [3, 3, 3, 3], [1] * 4, [1] * 4)
     assert lib.me_region_volume(ctypes.byref(rg)) == 81
+    # groups: one per 16 pairs + one partial group per non-empty item + 1, + the 4 groups (64 slots) of the index
+    # window that the convolution kernels read past the last batch without clamping
+    assert lib.me_plan_max_groups(1000, 27, 8000, 128) == 8000 // 16 + 8 * 27 + 1 + 4
+    assert lib.me_plan_max_groups(1000, 27, 50, 128) == 50 // 16 + 50 + 1 + 4
     koffs = (ctypes.c_int64 * 4)(0, 10, 10, 5000)
     # (ranges + volume) slots of one 64 x 16 register image each: 5000 pairs -> 78 ranges of >= 64 pairs
     assert lib.me_conv_wgrad_workspace_bytes(koffs, 3, 8, 16) == (5000 // 64 + 3) * 64 * 16 * 4
