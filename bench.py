@@ -7,23 +7,34 @@
 A step = one pass of the hot path over one batch of synthetic input: forward + backward of ONE
 MinkowskiConvolution (3-D, k = 3, s = 1, 64 -> 128 channels, fp32, no bias) on a 100k-voxel scene per
 GPU (BASELINE.json configs[1]), kernel map cached (steady-state training layer), inputs resident in
-HBM.  With N > 1 every rank owns its own scene (weak scaling, no data-path collective) and the
-0.88 MB weight gradient is all-reduced over RCCL each step.  value = total voxels of all ranks /
-max-over-ranks step time.
+HBM.  With N > 1 every rank owns its own scene (weak scaling, no data-path collective) and the gradients
+are averaged by torch DistributedDataParallel over RCCL (bucketed, overlapped with the backward pass).
+value = total voxels of all ranks / max-over-ranks step time.
+
+Launch: under torch.distributed.run the ranks come from the environment (RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_*).  A plain `python bench.py --gpus N` with N > 1 starts the N ranks itself (one process per GPU,
+127.0.0.1 rendezvous).  When the box has fewer GPUs than ranks (a 1-GPU test box), the ranks share the
+GPUs and talk over gloo instead of RCCL; the line then says "oversubscribed": true and is a functional
+check of the N > 1 path, not a scaling number.
+
+Timing: W warm-up steps, then blocks of EXACTLY K steps, each bracketed by barrier + synchronize on both
+sides and reduced with max over ranks; blocks are repeated until at least --min-time seconds have been
+timed (a 20-step block of the headline workload is 10 ms) and the FASTEST block is reported (`ms_per_step`,
+`value`); every block is listed under `blocks_ms_per_step`.
 
 Other workloads (never the default; parity-test configurations timed for DESIGN.md):
     --workload conv4d     BASELINE configs[4]: 4-D k = 3 (K = 81), 400k voxels in 100^3 x 8 frames, 32 -> 64
-    --workload minkunet   BASELINE configs[2]/[3]: MinkUNet34C forward + backward + SGD step on the 200k-voxel
-                          plane-union scene of SURVEY 8(d); with N > 1 one scene per rank, all gradients
-                          all-reduced in flat buckets over RCCL
+    --workload minkunet   BASELINE configs[2]/[3]: MinkUNet34C forward + loss + backward + SGD step on the
+                          200k-voxel plane-union scene of SURVEY 8(d); one scene per rank, DDP
 
-Rank 0 prints ONE JSON line carrying `roofline` (dominant kernel: the target-stationary MFMA
-convolution kernel, HIP-event timed inside the timed region) and `cpu_baseline` (the reference's own
-CPU operators, oracle/_ref, timed on this box's host cores at N = 1).
+Rank 0 prints ONE JSON line carrying `roofline` (dominant kernel, HIP-event timed inside the timed region
+on the launch stream) and `cpu_baseline` (the reference's own CPU operators, oracle/_ref, timed on this
+box's host cores at N = 1 on a bounded sample).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -31,52 +42,80 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
 PEAK_F32_MATRIX_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 PEAK_BF16_MATRIX_TFLOPS = 2500.0  # dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0
+RIDGE_F32 = PEAK_F32_MATRIX_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)    # ~19.7 flop/B
+RIDGE_BF16 = PEAK_BF16_MATRIX_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)  # ~312 flop/B
+
+
+# ------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` without torch.distributed.run
+# ------------------------------------------------------------------------------------------------------
+def spawn_ranks(n, argv):
+    """Start one process per rank of this same script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+    environment, 127.0.0.1 rendezvous) and wait for them; rank 0 prints the JSON line on our stdout."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    return rc
+
+
+import torch  # noqa: E402
 
 
 def pmc_traffic(kernel, n, extent, cin, cout):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc passes
-    (profiles/pmc_traffic.json; collected with scripts/gpu_pmc.sh on this exact workload), or None."""
+    """HBM-side bytes per launch of `kernel`: a CITED constant from the committed rocprofv3 --pmc passes
+    (profiles/pmc_traffic.json, collected with scripts/gpu_pmc_traffic.sh on this exact workload in their own
+    runs — PMC passes cannot share a run with the timed region), or None for any other workload."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             t = json.load(f)
         w = t["workload"]
         if (w["points"], w["extent"], w["cin"], w["cout"]) != (n, extent, cin, cout):
-            return None
+            return None, None
         k = t["kernels"][kernel]
-        return int(k["fetch_bytes"] + k["write_bytes"])
+        return int(k["fetch_bytes"] + k["write_bytes"]), t.get("source", "profiles/pmc_traffic.json")
     except Exception:  # noqa: BLE001
-        return None
+        return None, None
+
+
+def hip_timed(fn):
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    r = fn()
+    e.record()
+    torch.cuda.synchronize()
+    return r, s.elapsed_time(e)
 
 
 def cold_path(ME, MEB, feats, coords, dev, n, D=3, K=27, cin=64, cout=128):
-    """Coordinate insertion + kernel-map build + tile plans of one scene, each timed with HIP events,
-    with the achieved rate on SURVEY 8(d)'s algorithmic bytes (probes N*K x key bytes; insert N x key
-    bytes + table)."""
-    def timed(fn):
-        torch.cuda.synchronize()
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        r = fn()
-        e.record()
-        torch.cuda.synchronize()
-        return r, s.elapsed_time(e)
-
-    out = {}
-    best = {}
-    for rep in range(3):   # first repetition includes allocator warm-up; report the best
+    """Coordinate insertion + kernel-map build + tile plans of one scene, each timed with HIP events (best of
+    three: the first repetition pays the allocator), with the achieved rate on SURVEY 8(d)'s algorithmic bytes
+    (probes N*K x key bytes + 8 B per pair written; insert N x key bytes + table + maps)."""
+    out, best = {}, {}
+    km = None
+    for rep in range(3):
         mgr = MEB.CoordinateMapManagerGPU_c10()
-        (key, _), t_ins = timed(lambda: mgr.insert_and_map(coords, [1] * D, ""))
-        km, t_km = timed(lambda: mgr._kernel_map(key, key, [3] * D, [1] * D, [1] * D, ME.RegionType.HYPER_CUBE,
-                                                 None, False, False))
+        (key, _), t_ins = hip_timed(lambda: mgr.insert_and_map(coords, [1] * D, ""))
+        km, t_km = hip_timed(lambda: mgr._kernel_map(key, key, [3] * D, [1] * D, [1] * D, ME.RegionType.HYPER_CUBE,
+                                                     None, False, False))
+
         def plans():
             for tgt, (cs, cd) in (("out", (cin, cout)), ("in", (cout, cin))):
                 km.plan(tgt, *MEB.plan_config(n, K, km.n_pairs, cs, cd))
-        _, t_plan = timed(plans)
+        _, t_plan = hip_timed(plans)
         for name, t in (("insert_ms", t_ins), ("kernel_map_ms", t_km), ("plans_ms", t_plan)):
             best[name] = min(best.get(name, 1e9), t)
     key_bytes = 4 * (D + 1)
@@ -85,8 +124,8 @@ def cold_path(ME, MEB, feats, coords, dev, n, D=3, K=27, cin=64, cout=128):
     out["kernel_map_GBs"] = round(probe_bytes / (best["kernel_map_ms"] * 1e-3) / 1e9, 1)
     out["insert_GBs"] = round((n * key_bytes + 8 * 2 * n + 20 * n) / (best["insert_ms"] * 1e-3) / 1e9, 1)
     out["kernel_map_frac_of_hbm_peak"] = round(out["kernel_map_GBs"] / PEAK_HBM_GBS, 4)
-    out["note"] = ("kernel_map_ms covers probe + scan + compaction incl. one host sync; bytes = N*K*4(D+1) probes + "
-                   "8 B per pair written (SURVEY 8d); the map is built once per layer geometry and cached")
+    out["note"] = ("kernel_map_ms = end-to-end build (probe + offsets + compaction) as one stream of launches; bytes = "
+                   "N*K*4(D+1) probes + 8 B per pair written (SURVEY 8d); built once per layer geometry and cached")
     return out
 
 
@@ -144,6 +183,34 @@ def cpu_baseline(coords, feats, kernel, budget_s):
                 "sample": f"first {m} voxels of the workload, one fwd+bwd, numpy port ({e})"}
 
 
+def cpu_baseline_minkunet(coords, layer_specs, budget_s):
+    """The convolution layers of the network (recorded from the GPU run) on the reference's own CPU operators on
+    the same scene (oracle/ref.py RefConvStack); batch norm / ReLU are not replayed, so this is a LOWER bound of
+    the reference's step time — bounded to about `budget_s` seconds."""
+    from oracle import ref
+    if not ref.available():
+        return None
+    n = coords.shape[0]
+    cores = torch.get_num_threads()
+    t0 = time.perf_counter()
+    stack = ref.RefConvStack(coords, layer_specs)
+    stack.run()                                    # builds the coordinate and kernel maps (cached afterwards)
+    t_first = time.perf_counter() - t0
+    times = []
+    t_end = time.perf_counter() + budget_s
+    while not times or (time.perf_counter() + min(times) < t_end and len(times) < 5):
+        t0 = time.perf_counter()
+        stack.run()
+        times.append(time.perf_counter() - t0)
+    best = min(times)
+    return {"value": round(n / best / 1e6, 5), "unit": "Mpoints/s", "cores": cores, "kind": "reference",
+            "ms_per_step": round(best * 1e3, 1), "first_pass_ms": round(t_first * 1e3, 1),
+            "sample": f"the {len(layer_specs)} convolution layers of MinkUNet34C (forward + backward, maps cached) on "
+                      f"the same {n}-voxel scene through the reference's ConvolutionForward/BackwardCPU (+ transposed "
+                      f"twins; 1x1 layers as its use_mm matmuls), min of {len(times)} passes, {cores} threads; batch "
+                      "norm / ReLU / loss / optimizer NOT included (a lower bound of the reference's step)"}
+
+
 def kernel_table(timer, steps):
     """Per hot kernel: launches per step, mean ms per launch, algorithmic TFLOP/s over all its launches."""
     out = {}
@@ -155,23 +222,58 @@ def kernel_table(timer, steps):
 
 
 def run_timed(step, args, dist_utils, MEB, dev):
+    """-> (seconds of the fastest K-step block [max over ranks], every block's seconds, KernelTimer of ALL timed
+    blocks, number of timed steps).  Each block: barrier + synchronize | K steps | synchronize + barrier."""
     for _ in range(args.warmup):
         step()
     timer = MEB.KernelTimer()
-    dist_utils.barrier()
-    torch.cuda.synchronize()
-    MEB.KERNEL_TIMER = timer
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    dist_utils.barrier()
-    elapsed = time.perf_counter() - t0
-    MEB.KERNEL_TIMER = None
-    return dist_utils.max_over_ranks(elapsed, dev), timer
+    blocks = []
+    total = 0.0
+    while True:
+        dist_utils.barrier()
+        torch.cuda.synchronize()
+        MEB.KERNEL_TIMER = timer
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        dist_utils.barrier()
+        elapsed = time.perf_counter() - t0
+        MEB.KERNEL_TIMER = None
+        elapsed = dist_utils.max_over_ranks(elapsed, dev)      # the same value on every rank: same loop exit
+        blocks.append(elapsed)
+        total += elapsed
+        if (total >= args.min_time and len(blocks) >= args.min_blocks) or len(blocks) >= args.max_blocks:
+            break
+    return min(blocks), blocks, timer, args.steps * len(blocks)
 
 
-def bench_conv(args, ME, MEB, dist_utils, rank, world, dev):
+def roofline_entry(kernel, flops, compulsory_bytes, avg_ms, bf16, traffic, traffic_src):
+    """the roof is chosen by the launch's arithmetic intensity on its COMPULSORY bytes"""
+    peak_t = PEAK_BF16_MATRIX_TFLOPS if bf16 else PEAK_F32_MATRIX_TFLOPS
+    ridge = RIDGE_BF16 if bf16 else RIDGE_F32
+    intensity = flops / compulsory_bytes
+    tflops = flops / (avg_ms * 1e-3) / 1e12
+    gbs = compulsory_bytes / (avg_ms * 1e-3) / 1e9
+    r = {"kernel": kernel, "flops_per_launch": flops, "compulsory_bytes_per_launch": int(compulsory_bytes),
+         "intensity_flop_per_byte": round(intensity, 1), "ridge_flop_per_byte": round(ridge, 1),
+         "avg_ms": round(avg_ms, 4), "tflops": round(tflops, 2), "frac_of_mfma_peak": round(tflops / peak_t, 4),
+         "compulsory_GBs": round(gbs, 1), "frac_of_hbm_peak": round(gbs / PEAK_HBM_GBS, 4)}
+    if intensity >= ridge:
+        r.update({"bound": "mfma", "achieved": round(tflops, 2), "peak": peak_t, "unit": "TFLOP/s",
+                  "frac": round(tflops / peak_t, 4)})
+    else:
+        r.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                  "frac": round(gbs / PEAK_HBM_GBS, 4)})
+    r["traffic"] = traffic
+    r["traffic_note"] = ("HBM-side bytes per launch (FETCH_SIZE x2 + WRITE_SIZE) — a CITED constant from the committed "
+                         f"rocprofv3 --pmc passes ({traffic_src}; average of the forward and dgrad launches of the "
+                         "kernel), not measured in this run" if traffic is not None else
+                         "no committed PMC pass for this workload")
+    return r
+
+
+def bench_conv(args, ME, MEB, dist_utils, rank, world, dev, startup):
     if args.workload == "conv4d":
         D, n, extent, cin, cout = 4, args.points or 400000, (100, 100, 100, 8), args.cin or 32, args.cout or 64
         cfg, ext_s = "BASELINE configs[4]", "[0,100)^3 x [0,8)"
@@ -184,17 +286,22 @@ def bench_conv(args, ME, MEB, dist_utils, rank, world, dev):
     feats = torch.rand(n, cin, generator=g)
     torch.manual_seed(0)
     conv = ME.MinkowskiConvolution(cin, cout, kernel_size=3, stride=1, dimension=D, bias=False).to(dev)
-    dist_utils.broadcast_parameters(conv)
+    net = dist_utils.data_parallel(conv, dev)                 # DDP when world > 1 (broadcasts rank 0's weights)
 
-    # cold path: coordinate insertion + kernel map + tile plans + first forward/backward
+    # cold path: coordinate insertion + kernel map + tile plans + first forward/backward, in pieces
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     tdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     x = ME.SparseTensor(feats.to(dev).to(tdt), coords.to(dev), requires_grad=True)
-    y = conv(x)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    y = net(x)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
     y.F.sum().backward()
     torch.cuda.synchronize()
-    cold_ms = (time.perf_counter() - t0) * 1e3
+    t3 = time.perf_counter()
+    cold_ms = (t3 - t0) * 1e3
     km = x.coordinate_manager._manager._kernel_map(x.coordinate_map_key, y.coordinate_map_key, [3] * D, [1] * D,
                                                    [1] * D, ME.RegionType.HYPER_CUBE, None, False, False)
     n_pairs = km.n_pairs
@@ -203,50 +310,61 @@ def bench_conv(args, ME, MEB, dist_utils, rank, world, dev):
     def step():
         conv.kernel.grad = None
         x.F.grad = None
-        out = conv(x)
+        out = net(x)
         out.F.backward(grad_seed)
-        dist_utils.allreduce_gradients(conv)
 
-    elapsed, timer = run_timed(step, args, dist_utils, MEB, dev)
+    best, blocks, timer, timed_steps = run_timed(step, args, dist_utils, MEB, dev)
     total_points = dist_utils.sum_over_ranks(n, dev)
     pairs_all = dist_utils.sum_over_ranks(n_pairs, dev)
     cold = cold_path(ME, MEB, feats, coords.to(dev), dev, n, D, K, cin, cout) if rank == 0 else None
     if rank != 0:
         return None
-    kernels = kernel_table(timer, args.steps)
+    kernels = kernel_table(timer, timed_steps)
     flops_per_launch = 2.0 * n_pairs * cin * cout     # each of forward / dgrad / wgrad
-    achieved = kernels["conv_forward"]["tflops"]
     nc = 32 if 0 < cout % 64 <= 32 else 64                     # conv_variant() of csrc/conv.hip
     kc = 64 if cin % 64 == 0 else 32 if cin % 32 == 0 else 16
     bf16 = args.dtype == "bf16"
     if bf16:
         # conv_variant_bf16() of csrc/conv_bf16.hip
         kc = 128 if cin % 128 == 0 else 96 if cin % 96 == 0 else 32 if cin <= 32 else 64 if cin <= 64 else 128
-    peak = PEAK_BF16_MATRIX_TFLOPS if bf16 else PEAK_F32_MATRIX_TFLOPS
     esz = 2 if bf16 else 4
+    compulsory = esz * (n * cin + n * cout + K * cin * cout) + 8 * n_pairs   # SURVEY 8d, forward
+    traffic, traffic_src = pmc_traffic("k_conv_tile_bf16_forward" if bf16 else "k_conv_tile_f32", n, extent, cin,
+                                       cout) if D == 3 else (None, None)
+    ms_step = best / args.steps * 1e3
     line = {
         "metric": f"MinkowskiConvolution fwd+bwd Mpoints/sec ({n // 1000}k-pt {D}D, k=3)",
-        "value": round(total_points / (elapsed / args.steps) / 1e6, 3),
+        "value": round(total_points / (best / args.steps) / 1e6, 3),
         "unit": "Mpoints/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "ms_per_step": round(ms_step, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
         "data": "synthetic",
         "config": {"workload": f"single MinkowskiConvolution {D}D k=3 s=1, {n} voxels/GPU uniform in "
                                f"{ext_s}, {cin}->{cout} ch, {'bf16 features / fp32 accumulate' if bf16 else 'fp32'}, "
                                f"kernel map cached ({cfg})",
                    "points_per_gpu": n, "pairs_per_gpu": n_pairs, "pairs_total": int(pairs_all),
-                   "parallelism": f"scene-sharded dp{world}, RCCL all-reduce of the weight gradient"},
-        "roofline": {"bound": "mfma", "kernel": f"k_conv_tile_{'bf16' if bf16 else 'f32'}<{nc},{kc}> (forward)",
-                     "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                     "traffic": pmc_traffic("k_conv_tile_bf16_forward" if bf16 else "k_conv_tile_f32", n, extent, cin,
-                                            cout) if D == 3 else None,
-                     "traffic_note": "HBM-side bytes per launch (FETCH_SIZE x2 + WRITE_SIZE), rocprofv3 --pmc, "
-                                     "profiles/pmc_traffic.json; compulsory bytes of the forward launch: "
-                                     f"{int(esz * (n * cin + n * cout + K * cin * cout) + 8 * n_pairs)}",
-                     "flops_per_launch": flops_per_launch},
+                   "parallelism": f"scene-sharded dp{world}" + (
+                       f", torch DDP over {dist_utils.backend_name()} (gradient buckets overlapped with backward)"
+                       if world > 1 else ""),
+                   "oversubscribed": world > max(1, dist_utils.visible_gpus())},
+        "timing": {"blocks": len(blocks), "steps_per_block": args.steps,
+                   "blocks_ms_per_step": [round(b / args.steps * 1e3, 4) for b in blocks],
+                   "timed_region_s": round(sum(blocks), 4),
+                   "reported": "fastest block (max over ranks inside each block)"},
+        "roofline": roofline_entry(f"k_conv_tile_{'bf16' if bf16 else 'f32'}<{nc},{kc}> (forward)", flops_per_launch,
+                                   compulsory, kernels["conv_forward"]["avg_ms"], bf16, traffic, traffic_src),
         "kernels": kernels,
         "cold_ms": round(cold_ms, 2),
+        "cold_breakdown_ms": {"process_startup_to_first_launch": startup,
+                              "sparse_tensor_insert": round((t1 - t0) * 1e3, 2),
+                              "first_forward_kernel_map_plan": round((t2 - t1) * 1e3, 2),
+                              "first_backward_plans": round((t3 - t2) * 1e3, 2),
+                              "note": "cold_ms = sparse tensor + first forward + first backward on this process' FIRST "
+                                      "use of the library; it contains the one-time load of the code object's kernels "
+                                      "(hipModule lazy loading, reported under process_startup_to_first_launch."
+                                      "first_kernel_ms for one trivial kernel), the allocator's first hipMallocs and the "
+                                      "host synchronisations of the build; the warm build is under `cold`"},
         "cold": cold,
     }
     if world == 1 and args.cpu_budget > 0:      # the reference CPU path is fp32 whatever our feature dtype
@@ -257,7 +375,7 @@ def bench_conv(args, ME, MEB, dist_utils, rank, world, dev):
     return line
 
 
-def bench_minkunet(args, ME, MEB, dist_utils, rank, world, dev):
+def bench_minkunet(args, ME, MEB, dist_utils, rank, world, dev, startup):
     sys.path.insert(0, os.path.join(ROOT, "examples"))
     import minkunet as MU
     n = args.points or 200000
@@ -266,8 +384,9 @@ def bench_minkunet(args, ME, MEB, dist_utils, rank, world, dev):
     g = torch.Generator().manual_seed(1000 + rank)
     feats = torch.rand(n, 3, generator=g)
     torch.manual_seed(0)
-    net = MU.MinkUNet34C(3, 20, D=3).to(dev)
-    dist_utils.broadcast_parameters(net)
+    model = MU.MinkUNet34C(3, 20, D=3).to(dev)
+    n_params = sum(p.numel() for p in model.parameters())
+    net = dist_utils.data_parallel(model, dev, sync_batchnorm=args.sync_bn)
     opt = torch.optim.SGD(net.parameters(), lr=1e-3, momentum=0.9)
     labels = torch.randint(0, 20, (n,), generator=g).to(dev)
     crit = torch.nn.CrossEntropyLoss()
@@ -275,11 +394,20 @@ def bench_minkunet(args, ME, MEB, dist_utils, rank, world, dev):
     tdt = torch.bfloat16 if bf16 else torch.float32
     x = ME.SparseTensor(feats.to(dev).to(tdt), coords.to(dev))   # coordinate + kernel maps cached in x's manager
 
+    # layer census for the CPU baseline, recorded by forward hooks during the first step
+    specs, hooks = [], []
+    if rank == 0 and world == 1 and args.cpu_budget > 0:
+        def record(mod, inp, out):
+            kg = mod.kernel_generator
+            specs.append((bool(mod.is_transpose), list(kg.kernel_size), list(kg.kernel_stride), mod.in_channels,
+                          mod.out_channels, list(inp[0].tensor_stride)))
+        hooks = [m.register_forward_hook(record) for m in model.modules()
+                 if isinstance(m, (ME.MinkowskiConvolution, ME.MinkowskiConvolutionTranspose))]
+
     def step():
         opt.zero_grad(set_to_none=True)
         loss = crit(net(x).F.float(), labels)
         loss.backward()
-        dist_utils.allreduce_gradients(net)
         opt.step()
 
     torch.cuda.synchronize()
@@ -287,40 +415,80 @@ def bench_minkunet(args, ME, MEB, dist_utils, rank, world, dev):
     step()
     torch.cuda.synchronize()
     cold_ms = (time.perf_counter() - t0) * 1e3
-    elapsed, timer = run_timed(step, args, dist_utils, MEB, dev)
+    for h in hooks:
+        h.remove()
+    graphed = False
+    if args.graph:
+        step, graphed = capture_step(step), True
+    best, blocks, timer, timed_steps = run_timed(step, args, dist_utils, MEB, dev)
     total_points = dist_utils.sum_over_ranks(n, dev)
     if rank != 0:
         return None
-    kernels = kernel_table(timer, args.steps)
+    kernels = kernel_table(timer, timed_steps)
     tot_ms = sum(k["ms_per_step"] for k in kernels.values())
-    tot_flops = sum(f for _, _, f in timer.totals().values()) / args.steps
-    achieved = round(tot_flops / (tot_ms * 1e-3) / 1e12, 2)
-    return {
+    tot_flops = sum(f for _, _, f in timer.totals().values()) / max(timed_steps, 1)
+    peak = PEAK_BF16_MATRIX_TFLOPS if bf16 else PEAK_F32_MATRIX_TFLOPS
+    ms_step = best / args.steps * 1e3
+    achieved = round(tot_flops / (tot_ms * 1e-3) / 1e12, 2) if tot_ms > 0 else None
+    whole = round(1567e9 / (ms_step * 1e-3) / 1e12, 2)
+    line = {
         "metric": "MinkUNet34C fwd+bwd+SGD Mpoints/sec (200k-pt synthetic scene)",
-        "value": round(total_points / (elapsed / args.steps) / 1e6, 3),
+        "value": round(total_points / (best / args.steps) / 1e6, 3),
         "unit": "Mpoints/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "ms_per_step": round(ms_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
         "data": "synthetic",
-        "config": {"workload": f"MinkUNet34C (3 -> 20 classes, {sum(p.numel() for p in net.parameters())} parameters) "
+        "config": {"workload": f"MinkUNet34C (3 -> 20 classes, {n_params} parameters) "
                                f"forward + cross-entropy + backward + SGD step, {n} voxels/GPU on a union of 9 planes "
                                f"in 400^3 (SURVEY 8d), {'bf16 activations / fp32 master weights and accumulation' if bf16 else 'fp32'}, "
                                "maps cached (BASELINE configs[2]; configs[3] with N = 8)",
                    "points_per_gpu": n,
-                   "parallelism": f"scene-sharded dp{world}, RCCL all-reduce of all gradients in flat 25 MB buckets"},
-        "roofline": {"bound": "mfma", "kernel": "all convolution launches of a step (k_conv_tile_f32 forward + dgrad, "
-                                                "k_wgrad_f32)", "achieved": achieved,
-                     "peak": PEAK_BF16_MATRIX_TFLOPS if bf16 else PEAK_F32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / (PEAK_BF16_MATRIX_TFLOPS if bf16 else PEAK_F32_MATRIX_TFLOPS), 4),
+                   "parallelism": f"scene-sharded dp{world}" + (
+                       f", torch DDP over {dist_utils.backend_name()} (25 MB gradient buckets overlapped with backward)"
+                       + (", MinkowskiSyncBatchNorm" if args.sync_bn else ", per-rank batch norm") if world > 1 else ""),
+                   "hip_graph": graphed,
+                   "oversubscribed": world > max(1, dist_utils.visible_gpus())},
+        "timing": {"blocks": len(blocks), "steps_per_block": args.steps,
+                   "blocks_ms_per_step": [round(b / args.steps * 1e3, 3) for b in blocks],
+                   "timed_region_s": round(sum(blocks), 4),
+                   "reported": "fastest block (max over ranks inside each block)"},
+        "roofline": {"bound": "mfma", "kernel": "all convolution launches of a step (k_conv_tile_* forward + dgrad, "
+                                                "k_wgrad_*); HIP-event timed" + (" in a separate eager pass: the timed "
+                                                "region replays a hipGraph" if graphed else ""),
+                     "achieved": achieved if achieved is not None else whole,
+                     "peak": peak, "unit": "TFLOP/s",
+                     "frac": round((achieved if achieved is not None else whole) / peak, 4),
+                     "whole_step_tflops": whole, "whole_step_frac": round(whole / peak, 4),
                      "traffic": None,
                      "flops_per_step": tot_flops, "conv_kernel_ms_per_step": round(tot_ms, 3)},
         "kernels": kernels,
         "cold_ms": round(cold_ms, 2),
-        "cpu_baseline": None,
-        "cpu_baseline_note": "the reference network needs the reference's Python package, which does not travel to "
-                             "the GPU box; BASELINE.md §3: 21.7 s per iteration on the 8 survey-container cores",
     }
+    if world == 1 and args.cpu_budget > 0 and specs:
+        line["cpu_baseline"] = cpu_baseline_minkunet(coords, specs, args.cpu_budget)
+        if line["cpu_baseline"]:
+            line["speedup_vs_cpu_baseline"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
+    else:
+        line["cpu_baseline"] = None
+    return line
+
+
+def capture_step(step):
+    """Capture one training step (cached maps: no allocation-size read-backs, no host synchronisation) into a
+    hipGraph on a side stream and return a replay function — the whole step becomes ONE host call
+    (MI355X-first: HIP graphs for launch-bound loops; a bf16 MinkUNet34C step is ~700 launches)."""
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            step()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    return graph.replay
 
 
 def main():
@@ -336,21 +504,47 @@ def main():
     ap.add_argument("--cin", type=int, default=0)
     ap.add_argument("--cout", type=int, default=0)
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline timing (0 = skip)")
+    ap.add_argument("--min-time", type=float, default=0.2, help="keep timing K-step blocks until this many seconds")
+    ap.add_argument("--min-blocks", type=int, default=3)
+    ap.add_argument("--max-blocks", type=int, default=200)
+    ap.add_argument("--backend", choices=("auto", "nccl", "gloo"), default="auto")
+    ap.add_argument("--sync-bn", action="store_true", help="minkunet, N > 1: MinkowskiSyncBatchNorm (reference recipe)")
+    ap.add_argument("--graph", action="store_true", help="minkunet: replay the step from a captured hipGraph")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+
+    t_start = time.perf_counter()
     import minkowskiengine_amd as ME
+    from minkowskiengine_amd import _lib
     from minkowskiengine_amd import backend as MEB
     from minkowskiengine_amd import distributed as dist_utils
 
-    rank, world, local_rank = dist_utils.init_from_env()
-    assert world == args.gpus or world == 1 and args.gpus == 1, \
-        f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
-    dev = torch.device("cuda", local_rank)
+    rank, world, local_rank = dist_utils.init_from_env(None if args.backend == "auto" else args.backend)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = dist_utils.local_device(local_rank)
     torch.cuda.set_device(dev)
+    # one-time start-up costs, separated from the workload's cold path: library load, device context, first launch
+    t_a = time.perf_counter()
+    lib = _lib.load()
+    t_b = time.perf_counter()
+    torch.zeros(1, device=dev)
+    torch.cuda.synchronize()
+    t_c = time.perf_counter()
+    probe = torch.zeros((4, 4), dtype=torch.int32, device=dev)
+    keys = torch.empty(4, dtype=torch.int64, device=dev)
+    import ctypes
+    _lib.check(lib.me_coords_spatial_keys(probe.data_ptr(), 4, 4, (ctypes.c_int32 * 3)(1, 1, 1), keys.data_ptr(),
+                                          torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    t_d = time.perf_counter()
+    startup = {"import_ms": round((t_a - t_start) * 1e3, 1), "dlopen_libme_amd_ms": round((t_b - t_a) * 1e3, 1),
+               "device_context_ms": round((t_c - t_b) * 1e3, 1), "first_kernel_ms": round((t_d - t_c) * 1e3, 1)}
 
     fn = bench_minkunet if args.workload == "minkunet" else bench_conv
-    line = fn(args, ME, MEB, dist_utils, rank, world, dev)
+    line = fn(args, ME, MEB, dist_utils, rank, world, dev, startup)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

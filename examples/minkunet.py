@@ -31,30 +31,37 @@ class MinkUNetBase(nn.Module):
         conv = lambda i, o, k, s=1: ME.MinkowskiConvolution(i, o, kernel_size=k, stride=s, dimension=D)
         up = lambda i, o: ME.MinkowskiConvolutionTranspose(i, o, kernel_size=2, stride=2, dimension=D)
 
+        # Module names are the reference's (examples/minkunet.py:50-123: conv{i}p{stride}s2 / bn{i} / block{i},
+        # convtr{i}p{stride}s2 / bntr{i}), so a reference state_dict loads unchanged; `p` = tensor stride of the
+        # layer's input.
         self.inplanes = self.INIT_DIM
         self.conv0p1s1, self.bn0 = conv(in_channels, self.inplanes, 5), ME.MinkowskiBatchNorm(self.inplanes)
+        fused = [self.bn0]
         # encoder: tensor stride 1 -> 2 -> 4 -> 8 -> 16
-        self.down = nn.ModuleList()
-        self.down_bn = nn.ModuleList()
-        self.enc = nn.ModuleList()
+        self._down, self._up = [], []
         for level in range(4):
-            self.down.append(conv(self.inplanes, self.inplanes, 2, 2))
-            self.down_bn.append(ME.MinkowskiBatchNorm(self.inplanes))
-            self.enc.append(self._make_layer(P[level], L[level]))
+            i, ts = level + 1, 2 ** level
+            names = (f"conv{i}p{ts}s2", f"bn{i}", f"block{i}")
+            setattr(self, names[0], conv(self.inplanes, self.inplanes, 2, 2))
+            setattr(self, names[1], ME.MinkowskiBatchNorm(self.inplanes))
+            setattr(self, names[2], self._make_layer(P[level], L[level]))
+            self._down.append(names)
+            fused.append(getattr(self, names[1]))
         # decoder: transposed conv back up, concatenate the encoder feature of that stride, residual stage
         skip_planes = [P[2] * E, P[1] * E, P[0] * E, self.INIT_DIM]
-        self.up = nn.ModuleList()
-        self.up_bn = nn.ModuleList()
-        self.dec = nn.ModuleList()
         for level in range(4):
-            self.up.append(up(self.inplanes, P[4 + level]))
-            self.up_bn.append(ME.MinkowskiBatchNorm(P[4 + level]))
+            i, ts = level + 4, 2 ** (4 - level)
+            names = (f"convtr{i}p{ts}s2", f"bntr{i}", f"block{i + 1}")
+            setattr(self, names[0], up(self.inplanes, P[4 + level]))
+            setattr(self, names[1], ME.MinkowskiBatchNorm(P[4 + level]))
             self.inplanes = P[4 + level] + skip_planes[level]
-            self.dec.append(self._make_layer(P[4 + level], L[4 + level]))
+            setattr(self, names[2], self._make_layer(P[4 + level], L[4 + level]))
+            self._up.append(names)
+            fused.append(getattr(self, names[1]))
         self.final = ME.MinkowskiConvolution(P[7] * E, out_channels, kernel_size=1, bias=True, dimension=D)
         self.relu = ME.MinkowskiReLU(inplace=True)
         # every one of these batch norms feeds self.relu directly in forward(): let the batch-norm kernels rectify
-        for bn in [self.bn0, *self.down_bn, *self.up_bn]:
+        for bn in fused:
             bn.fuse_relu = True
         self._init_weights()
 
@@ -81,14 +88,14 @@ class MinkUNetBase(nn.Module):
     def forward(self, x):
         out = self.relu(self.bn0(self.conv0p1s1(x)))
         skips = [out]                                   # tensor stride 1
-        for level in range(4):
-            out = self.relu(self.down_bn[level](self.down[level](out)))
-            out = self.enc[level](out)
+        for conv, bn, block in self._down:
+            out = self.relu(getattr(self, bn)(getattr(self, conv)(out)))
+            out = getattr(self, block)(out)
             skips.append(out)                           # strides 2, 4, 8, 16
-        for level in range(4):
-            out = self.relu(self.up_bn[level](self.up[level](out)))
+        for level, (conv, bn, block) in enumerate(self._up):
+            out = self.relu(getattr(self, bn)(getattr(self, conv)(out)))
             out = ME.cat(out, skips[3 - level])
-            out = self.dec[level](out)
+            out = getattr(self, block)(out)
         return self.final(out)
 
 

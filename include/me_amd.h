@@ -289,6 +289,23 @@ int me_global_pool_f32(const float *src_dev, const float *src2_dev, int32_t c, c
 int me_broadcast_f32(const float *in_dev, const float *glob_dev, const int32_t *batch_row_dev, int64_t n,
                      int32_t c, int32_t multiply, float *out_dev, void *stream);
 
+/* bf16 feature rows (uint16_t = raw bfloat16 bits) on the same kernels: values are widened to fp32, summed /
+ * compared in fp32 in the same order and rounded once at the store.  Counts and argmax masks keep their types;
+ * global pooling returns fp32 [n_batch, c] (a handful of rows; the caller rounds).  The reference has no
+ * reduced-precision pooling (pybind/extern.hpp:187-392 dispatches float / double only). */
+int me_pool_sum_bf16(const uint16_t *src_dev, int32_t c, const int32_t *tbl_dev, int64_t n_tgt, int64_t volume,
+                     const float *src_count_dev, int32_t average, uint16_t *dst_dev, float *dst_count_dev,
+                     void *stream);
+int me_pool_max_bf16(const uint16_t *src_dev, int32_t c, const int32_t *tbl_dev, int64_t n_tgt, int64_t volume,
+                     uint16_t *dst_dev, int32_t *mask_dev, void *stream);
+int me_pool_max_backward_bf16(const uint16_t *grad_out_dev, int32_t c, const int32_t *tbl_in_dev, int64_t n_in,
+                              int64_t volume, const int32_t *mask_dev, uint16_t *grad_in_dev, void *stream);
+int me_global_pool_bf16(const uint16_t *src_dev, const uint16_t *src2_dev, int32_t c, const int32_t *batch_row_dev,
+                        int64_t n, int32_t n_batch, int32_t mode, float *dst_dev, int32_t *dst_arg_dev,
+                        float *dst_count_dev, void *workspace_dev, int64_t workspace_bytes, void *stream);
+int me_broadcast_bf16(const uint16_t *in_dev, const uint16_t *glob_dev, const int32_t *batch_row_dev, int64_t n,
+                      int32_t c, int32_t multiply, uint16_t *out_dev, void *stream);
+
 /* Generative / expanding convolutions (CoordinateMapCPU::stride_region, src/coordinate_map_cpu.hpp:446-487;
  * manager: src/coordinate_map_manager.cpp:436-466): candidate output coordinates = every kernel offset of the
  * region around every input coordinate, candidate (row, k) at out[row * volume + k]; a following

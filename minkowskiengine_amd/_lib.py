@@ -92,6 +92,12 @@ SIGNATURES = {
     "me_global_pool_f32": (ctypes.c_int, [c_vp, c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp,
                                           c_i64, c_vp]),
     "me_broadcast_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
+    "me_pool_sum_bf16": (ctypes.c_int, [c_vp, c_i32, c_vp, c_i64, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp]),
+    "me_pool_max_bf16": (ctypes.c_int, [c_vp, c_i32, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp]),
+    "me_pool_max_backward_bf16": (ctypes.c_int, [c_vp, c_i32, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp]),
+    "me_global_pool_bf16": (ctypes.c_int, [c_vp, c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp,
+                                           c_i64, c_vp]),
+    "me_broadcast_bf16": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
     "me_conv_forward_naive_f32": (ctypes.c_int, [c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_i64,
                                                  c_vp, c_vp]),
     "me_conv_backward_naive_f32": (ctypes.c_int, [c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_i64,

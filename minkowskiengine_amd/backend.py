@@ -399,6 +399,7 @@ class CoordinateMapManagerGPU_c10:
         self._kernel_maps = {}   # kernel_map_key (src/types.hpp:183-192) -> KernelMapGPU
         self._origin_maps = {}
         self._prune_rows = {}
+        self._stride_maps = {}
 
     # ---- keys -----------------------------------------------------------------------------------
     @staticmethod
@@ -471,6 +472,40 @@ class CoordinateMapManagerGPU_c10:
             cmap, _, inverse = _insert(strided[:in_map.n], out_ts)
             self._maps[ok] = cmap
         return CoordinateMapKey(list(ok[0]), ok[1])
+
+    def stride_map(self, in_key, strided_key):
+        """stride_map_th (src/coordinate_map_manager.cpp:977-1034; pybind/extern.hpp:803) -> (in_rows, out_rows), two
+        int64 [n_in] tensors: every row of `in_key` and the row of `strided_key` that holds its floored coordinate
+        (CoordinateMapCPU::stride_map, src/coordinate_map_cpu.hpp:672-720).  Pairs come in input-row order (the
+        reference's order is its hash-table iteration order); an input voxel whose strided coordinate is absent
+        from `strided_key` is left out, as in the reference."""
+        ik, sk = self._k(in_key), self._k(strided_key)
+        _check(ik in self._maps, "coordinate map not found", ik)
+        _check(sk in self._maps, "coordinate map not found", sk)
+        _check(all(b % a == 0 for a, b in zip(ik[0], sk[0])),
+               "The tensor stride of the strided map must be divisible by the tensor stride of the input map.",
+               "strided_map_stride:", list(sk[0]), "in_map_stride:", list(ik[0]))
+        cached = self._stride_maps.get((ik, sk))
+        if cached is not None:
+            return cached
+        in_map, out_map = self._maps[ik], self._maps[sk]
+        lib = _lib.load()
+        dev = in_map.coords.device
+        ncol = len(sk[0]) + 1
+        strided = torch.empty((max(in_map.n, 1), ncol), dtype=torch.int32, device=dev)
+        rows = torch.empty(max(in_map.n, 1), dtype=torch.int32, device=dev)
+        ts_arr = (ctypes.c_int32 * len(sk[0]))(*sk[0])
+        with _on(dev):
+            _lib.check(lib.me_coords_stride(_ptr(in_map.coords), in_map.n, ncol, ts_arr, _ptr(strided), _stream(dev)))
+            _lib.check(lib.me_coords_find(_ptr(out_map.table), out_map.capacity, _ptr(out_map.coords), ncol,
+                                          _ptr(strided), in_map.n, _ptr(rows), _stream(dev)))
+        rows = rows[:in_map.n].long()
+        in_rows = torch.arange(in_map.n, dtype=torch.int64, device=dev)
+        found = rows >= 0
+        if not bool(found.all()):
+            in_rows, rows = in_rows[found], rows[found]
+        self._stride_maps[(ik, sk)] = (in_rows, rows)
+        return in_rows, rows
 
     def _register(self, ts, cmap, string_id=""):
         """insert under (ts, string_id), with a random suffix if that key is taken -> key tuple"""
@@ -580,9 +615,10 @@ class CoordinateMapManagerGPU_c10:
 
     # ---- origin map (one row per batch index) --------------------------------------------------
     def origin(self):
-        """CoordinateMapKey of the origin map: tensor stride all zeros, one row per batch index in
-        first-occurrence order of the finest map (src/coordinate_map_manager.cpp:470-508; the reference CPU
-        orders the rows by hash-table iteration, so rows are compared by their batch index)."""
+        """CoordinateMapKey of the origin map: tensor stride all zeros, one row per batch index, rows in ASCENDING
+        batch index — row b of a global pooling belongs to the b-th smallest batch index, whatever order the
+        points arrive in (the reference's GPU map sorts the unique batch indices, src/coordinate_map_gpu.cu:765-772;
+        its CPU map orders them by hash-table iteration, src/coordinate_map_manager.cpp:470-508)."""
         _check(len(self._maps) > 0, "origin() needs at least one coordinate map")
         any_key = next(iter(self._maps))
         D = len(any_key[0])
@@ -592,11 +628,11 @@ class CoordinateMapManagerGPU_c10:
             cands = [k for k in self._maps if all(t > 0 for t in k[0])]
             base_key = min(cands, key=lambda k: (sum(k[0]), k[1]))
             base = self._maps[base_key]
-            oc = torch.zeros_like(base.coords)
-            oc[:, 0] = base.coords[:, 0]
-            cmap, _, inverse = _insert(oc.contiguous(), okey[0])
+            batches = torch.unique(base.coords[:, 0])          # sorted
+            oc = torch.zeros((batches.numel(), base.coords.shape[1]), dtype=torch.int32, device=base.coords.device)
+            oc[:, 0] = batches
+            cmap, _, _ = _insert(oc.contiguous(), okey[0])      # unique rows: insertion order = sorted order
             self._maps[okey] = cmap
-            self._origin_maps[base_key] = inverse.to(torch.int32)
         return CoordinateMapKey(list(okey[0]), okey[1])
 
     def origin_map_size(self):
@@ -619,6 +655,10 @@ class CoordinateMapManagerGPU_c10:
                 _lib.check(lib.me_coords_find(_ptr(omap.table), omap.capacity, _ptr(omap.coords), q.shape[1],
                                               _ptr(q), in_map.n, _ptr(rows), _stream(dev)))
             rows = rows[:in_map.n]
+            # a map may hold batch indices the origin map (built from the finest map at its first use) does not
+            # know: the pooling / broadcast kernels would index row -1.  Checked once per map (one read-back).
+            _check(in_map.n == 0 or bool((rows >= 0).all()),
+                   "the origin map does not contain every batch index of this coordinate map")
             self._origin_maps[ik] = rows
         return rows
 
@@ -954,14 +994,24 @@ def ConvolutionTransposeBackwardGPU(in_feat, grad_out_feat, kernel, kernel_size,
 # pooling / broadcast operators (src/local_pooling_cpu.cpp, src/local_pooling_transpose_cpu.cpp,
 # src/global_pooling_cpu.cpp, src/broadcast_cpu.cpp; signatures pybind/extern.hpp:187-392)
 # ------------------------------------------------------------------------------------------------
+def _same_dtype(name, t, like):
+    """feature-shaped operands of one pooling / broadcast call share the dtype of the input features"""
+    _check(t.dtype == like.dtype, name, "must have the dtype of the input features:", t.dtype, "vs", like.dtype)
+
+
 def _pool_sum(src, tbl, n_tgt, volume, src_count=None, average=False, want_count=False):
+    """dtype dispatch: float32 rows run me_pool_sum_f32, bfloat16 rows me_pool_sum_bf16 (fp32 sums, one rounding
+    at the store); the output has the dtype of `src`, counts are float32."""
     lib = _lib.load()
     dev = src.device
     c = int(src.shape[1])
-    out = torch.empty((n_tgt, c), dtype=torch.float32, device=dev)
+    out = torch.empty((n_tgt, c), dtype=src.dtype, device=dev)
     cnt = torch.empty(max(n_tgt, 1), dtype=torch.float32, device=dev)[:n_tgt] if want_count else None
+    if src_count is not None:
+        _check(src_count.dtype == torch.float32, "num_nonzero must be float32")
+    fn = lib.me_pool_sum_bf16 if src.dtype == torch.bfloat16 else lib.me_pool_sum_f32
     with _on(dev):
-        _timed("pool_sum", dev, lambda: _lib.check(lib.me_pool_sum_f32(
+        _timed("pool_sum", dev, lambda: _lib.check(fn(
             _ptr(src), c, _ptr(tbl), n_tgt, volume, _ptr(src_count), 1 if average else 0, _ptr(out), _ptr(cnt),
             _stream(dev))))
     return out, cnt
@@ -996,10 +1046,11 @@ def LocalPoolingForwardGPU(in_feat, kernel_size, kernel_stride, kernel_dilation,
         lib = _lib.load()
         dev = in_feat.device
         c = int(in_feat.shape[1])
-        out = torch.empty((km.n_out, c), dtype=torch.float32, device=dev)
+        out = torch.empty((km.n_out, c), dtype=in_feat.dtype, device=dev)
         mask = torch.empty((km.n_out, c), dtype=torch.int32, device=dev)
+        fn = lib.me_pool_max_bf16 if in_feat.dtype == torch.bfloat16 else lib.me_pool_max_f32
         with _on(dev):
-            _timed("pool_max", dev, lambda: _lib.check(lib.me_pool_max_f32(
+            _timed("pool_max", dev, lambda: _lib.check(fn(
                 _ptr(in_feat), c, _ptr(km.table("out")), km.n_out, km.volume, _ptr(out), _ptr(mask), _stream(dev))))
         return out, mask
     _check(mode in (PoolingMode.LOCAL_SUM_POOLING, PoolingMode.LOCAL_AVG_POOLING), "Invalid pooling mode")
@@ -1017,6 +1068,8 @@ def LocalPoolingBackwardGPU(in_feat, grad_out_feat, num_nonzero, kernel_size, ke
     if not grad_out_feat.is_contiguous():
         grad_out_feat = grad_out_feat.contiguous()
     _check_feat("grad_out_feat", grad_out_feat)
+    if grad_out_feat.dtype != in_feat.dtype:
+        grad_out_feat = grad_out_feat.to(in_feat.dtype)
     km = manager._kernel_map(in_key, out_key, kernel_size, kernel_stride, kernel_dilation, region_type, offset,
                              False, True)
     _check(grad_out_feat.shape[0] == km.n_out, "Invalid grad_out size")
@@ -1025,10 +1078,12 @@ def LocalPoolingBackwardGPU(in_feat, grad_out_feat, num_nonzero, kernel_size, ke
         lib = _lib.load()
         dev = in_feat.device
         c = int(in_feat.shape[1])
-        grad_in = torch.empty((km.n_in, c), dtype=torch.float32, device=dev)
+        _check(num_nonzero.dtype == torch.int32, "the max-pooling mask must be int32")
+        grad_in = torch.empty((km.n_in, c), dtype=in_feat.dtype, device=dev)
+        fn = lib.me_pool_max_backward_bf16 if in_feat.dtype == torch.bfloat16 else lib.me_pool_max_backward_f32
         with _on(dev):
-            _lib.check(lib.me_pool_max_backward_f32(_ptr(grad_out_feat), c, _ptr(km.table("in")), km.n_in, km.volume,
-                                                    _ptr(num_nonzero), _ptr(grad_in), _stream(dev)))
+            _lib.check(fn(_ptr(grad_out_feat), c, _ptr(km.table("in")), km.n_in, km.volume,
+                          _ptr(num_nonzero), _ptr(grad_in), _stream(dev)))
         return grad_in
     avg = mode == PoolingMode.LOCAL_AVG_POOLING
     grad_in, _ = _pool_sum(grad_out_feat, km.table("in"), km.n_in, km.volume,
@@ -1053,6 +1108,8 @@ def LocalPoolingTransposeBackwardGPU(in_feat, grad_out_feat, num_nonzero, kernel
     if not grad_out_feat.is_contiguous():
         grad_out_feat = grad_out_feat.contiguous()
     _check_feat("grad_out_feat", grad_out_feat)
+    if grad_out_feat.dtype != in_feat.dtype:
+        grad_out_feat = grad_out_feat.to(in_feat.dtype)
     km = manager._kernel_map(in_key, out_key, kernel_size, kernel_stride, kernel_dilation, region_type, offset,
                              True, True)
     grad_in, _ = _pool_sum(grad_out_feat, km.table("in"), km.n_in, km.volume)
@@ -1072,13 +1129,19 @@ def _global_pool(src, src2, rows, n_batch, mode):
     lib = _lib.load()
     dev = src.device
     n, c = int(src.shape[0]), int(src.shape[1])
+    if src2 is not None:
+        _same_dtype("the second factor", src2, src)
+    # the kernels reduce in fp32 and write fp32 [n_batch, c]; bf16 inputs get their (tiny) result rounded here
     out = torch.empty((n_batch, c), dtype=torch.float32, device=dev)
     arg = torch.empty((n_batch, c), dtype=torch.int32, device=dev) if mode == 2 else None
     cnt = torch.empty(n_batch, dtype=torch.float32, device=dev) if mode != 2 else None
     ws = _workspace(lib.me_global_pool_workspace_bytes(n, n_batch, c), dev)
+    fn = lib.me_global_pool_bf16 if src.dtype == torch.bfloat16 else lib.me_global_pool_f32
     with _on(dev):
-        _lib.check(lib.me_global_pool_f32(_ptr(src), _ptr(src2), c, _ptr(rows), n, n_batch, mode, _ptr(out), _ptr(arg),
-                                          _ptr(cnt), _ptr(ws), ws.numel(), _stream(dev)))
+        _lib.check(fn(_ptr(src), _ptr(src2), c, _ptr(rows), n, n_batch, mode, _ptr(out), _ptr(arg),
+                      _ptr(cnt), _ptr(ws), ws.numel(), _stream(dev)))
+    if src.dtype != torch.float32:
+        out = out.to(src.dtype)
     return out, arg, cnt
 
 
@@ -1101,67 +1164,74 @@ def GlobalPoolingForwardGPU(in_feat, pooling_mode, in_key, out_key, manager):
     return out, (arg if m == 2 else cnt)
 
 
+def _broadcast(in_feat, glob, rows, n, c, multiply):
+    """out[i] = in[i] (+ | *) glob[rows[i]]  (in_feat None: out[i] = glob[rows[i]]); dtype of `glob`."""
+    lib = _lib.load()
+    dev = glob.device
+    if in_feat is not None:
+        _same_dtype("in_feat", in_feat, glob)
+    out = torch.empty((n, c), dtype=glob.dtype, device=dev)
+    fn = lib.me_broadcast_bf16 if glob.dtype == torch.bfloat16 else lib.me_broadcast_f32
+    with _on(dev):
+        _lib.check(fn(_ptr(in_feat), _ptr(glob), _ptr(rows), n, c, 1 if multiply else 0, _ptr(out), _stream(dev)))
+    return out
+
+
 def GlobalPoolingBackwardGPU(in_feat, grad_out_feat, num_nonzero, pooling_mode, in_key, out_key, manager):
-    """src/global_pooling_cpu.cpp:240-326 -> grad_in_feat."""
+    """src/global_pooling_cpu.cpp:240-326 -> grad_in_feat (dtype of in_feat)."""
+    _check_feat("in_feat", in_feat)
     if not grad_out_feat.is_contiguous():
         grad_out_feat = grad_out_feat.contiguous()
     _check_feat("grad_out_feat", grad_out_feat)
+    if grad_out_feat.dtype != in_feat.dtype:
+        grad_out_feat = grad_out_feat.to(in_feat.dtype)
     mode = PoolingMode(int(pooling_mode))
     n, c = int(in_feat.shape[0]), int(in_feat.shape[1])
     dev = in_feat.device
     if mode in _GLOBAL_MAX:
-        grad_in = torch.zeros((n, c), dtype=torch.float32, device=dev)
+        grad_in = torch.zeros((n, c), dtype=in_feat.dtype, device=dev)
         valid = num_nonzero.reshape(-1) >= 0
         grad_in.view(-1)[num_nonzero.reshape(-1)[valid].long()] = grad_out_feat.reshape(-1)[valid]
         return grad_in
     g = grad_out_feat
     if mode in _GLOBAL_AVG:
-        g = (g / num_nonzero.clamp_min(1.0)[:, None]).contiguous()
+        g = (g.float() / num_nonzero.clamp_min(1.0)[:, None]).to(in_feat.dtype).contiguous()
     rows = manager._origin_rows(in_key)
-    lib = _lib.load()
-    grad_in = torch.empty((n, c), dtype=torch.float32, device=dev)
-    with _on(dev):
-        _lib.check(lib.me_broadcast_f32(None, _ptr(g), _ptr(rows), n, c, 0, _ptr(grad_in), _stream(dev)))
-    return grad_in
+    return _broadcast(None, g, rows, n, c, False)
 
 
 def BroadcastForwardGPU(in_feat, in_feat_glob, broadcast_mode, in_key, glob_key, manager):
     """src/broadcast_cpu.cpp:38-97: out[i] = in[i] (+ | *) glob[batch of i]."""
     _check_feat("in_feat", in_feat)
     _check_feat("in_feat_glob", in_feat_glob)
+    _same_dtype("in_feat_glob", in_feat_glob, in_feat)
     _check(in_feat.shape[1] == in_feat_glob.shape[1], "feature sizes must match")
     _check(in_feat.shape[0] == manager.size(in_key), "Invalid in_feat size")
     _check(in_feat_glob.shape[0] == manager.size(glob_key), "Invalid in_feat_glob size")
     op = BroadcastMode(int(broadcast_mode))
     rows = manager._origin_rows(in_key)
-    lib = _lib.load()
-    dev = in_feat.device
-    out = torch.empty_like(in_feat)
-    with _on(dev):
-        _lib.check(lib.me_broadcast_f32(_ptr(in_feat), _ptr(in_feat_glob), _ptr(rows), in_feat.shape[0],
-                                        in_feat.shape[1], 1 if op == BroadcastMode.ELEMENTWISE_MULTIPLICATION else 0,
-                                        _ptr(out), _stream(dev)))
-    return out
+    return _broadcast(in_feat, in_feat_glob, rows, int(in_feat.shape[0]), int(in_feat.shape[1]),
+                      op == BroadcastMode.ELEMENTWISE_MULTIPLICATION)
 
 
 def BroadcastBackwardGPU(in_feat, in_feat_glob, grad_out_feat, broadcast_mode, in_key, glob_key, manager):
     """src/broadcast_cpu.cpp:99-160 -> (grad_in_feat, grad_in_feat_glob)."""
+    _check_feat("in_feat", in_feat)
+    _check_feat("in_feat_glob", in_feat_glob)
+    _same_dtype("in_feat_glob", in_feat_glob, in_feat)
     if not grad_out_feat.is_contiguous():
         grad_out_feat = grad_out_feat.contiguous()
     _check_feat("grad_out_feat", grad_out_feat)
+    if grad_out_feat.dtype != in_feat.dtype:
+        grad_out_feat = grad_out_feat.to(in_feat.dtype)
     op = BroadcastMode(int(broadcast_mode))
     rows = manager._origin_rows(in_key)
     n_batch = int(in_feat_glob.shape[0])
-    lib = _lib.load()
-    dev = in_feat.device
     if op == BroadcastMode.ELEMENTWISE_ADDITON:
         grad_in = grad_out_feat.clone()
         grad_glob, _, _ = _global_pool(grad_out_feat, None, rows, n_batch, 0)
     else:
-        grad_in = torch.empty_like(in_feat)
-        with _on(dev):
-            _lib.check(lib.me_broadcast_f32(_ptr(grad_out_feat), _ptr(in_feat_glob), _ptr(rows), in_feat.shape[0],
-                                            in_feat.shape[1], 1, _ptr(grad_in), _stream(dev)))
+        grad_in = _broadcast(grad_out_feat, in_feat_glob, rows, int(in_feat.shape[0]), int(in_feat.shape[1]), True)
         grad_glob, _, _ = _global_pool(grad_out_feat, in_feat, rows, n_batch, 0)
     return grad_in, grad_glob
 

@@ -85,6 +85,10 @@ class CoordinateManager:
     def origin_map_size(self):
         return self._manager.origin_map_size()
 
+    def stride_map(self, in_key, stride_key):
+        """(in rows, rows of the strided map) as two int64 tensors (MinkowskiCoordinateManager.py:429-430)"""
+        return self._manager.stride_map(in_key, stride_key)
+
     def union_map(self, in_keys, out_key):
         """one int64 [2, n_i] tensor per input key: (its rows, rows of the union map created under out_key)"""
         return self._manager.union_map(in_keys, out_key)
@@ -108,11 +112,11 @@ class CoordinateManager:
                                         convert_to_int_list(stride, D), convert_to_int_list(dilation, D),
                                         region_type, region_offset, is_transpose, is_pool)
 
+    get_kernel_map = kernel_map   # MinkowskiCoordinateManager.py:349-375 (older name, same arguments)
+
     def number_of_unique_batch_indices(self):
-        keys = list(self._manager._maps.values())
-        if not keys:
-            return 0
-        return int(torch.unique(keys[0].coords[:, 0]).numel())
+        """MinkowskiCoordinateManager.py:334-335"""
+        return self._manager.origin_map_size()
 
     def __repr__(self):
         return f"{self.__class__.__name__}(\n{self._manager!r}\n)"

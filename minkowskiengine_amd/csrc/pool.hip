@@ -14,31 +14,43 @@
 #include "common.hpp"
 
 #include <float.h>
+#include <initializer_list>
 
 namespace me {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// V consecutive channels (V = 4: one 16-byte access; V = 1 when C is not a multiple of 4)
+// V consecutive channels of one row, held in fp32 whatever the storage type T (float or __bf16: bf16 features are
+// summed / compared in fp32 and rounded once at the store, like the convolution kernels).  One access of
+// V * sizeof(T) bytes: 16 bytes for (float, 4) and (__bf16, 8), 8 bytes for (__bf16, 4), one element for V = 1.
 template <int V>
 struct Piece {
   float v[V];
 };
-template <int V>
-__device__ __forceinline__ Piece<V> load_piece(const float *p) {
+template <typename T, int V>
+__device__ __forceinline__ Piece<V> load_piece(const T *p) {
   Piece<V> r;
-  if constexpr (V == 4) {
-    const f32x4 t = *reinterpret_cast<const f32x4 *>(p);
-    r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+  if constexpr (V == 1) {
+    r.v[0] = (float)*p;
   } else {
-    r.v[0] = *p;
+    typedef T tvec __attribute__((ext_vector_type(V)));
+    const tvec t = *reinterpret_cast<const tvec *>(p);
+#pragma unroll
+    for (int j = 0; j < V; ++j) r.v[j] = (float)t[j];
   }
   return r;
 }
-template <int V>
-__device__ __forceinline__ void store_piece(float *p, const Piece<V> &r) {
-  if constexpr (V == 4) *reinterpret_cast<f32x4 *>(p) = f32x4{r.v[0], r.v[1], r.v[2], r.v[3]};
-  else *p = r.v[0];
+template <typename T, int V>
+__device__ __forceinline__ void store_piece(T *p, const Piece<V> &r) {
+  if constexpr (V == 1) {
+    *p = (T)r.v[0];
+  } else {
+    typedef T tvec __attribute__((ext_vector_type(V)));
+    tvec t;
+#pragma unroll
+    for (int j = 0; j < V; ++j) t[j] = (T)r.v[j];
+    *reinterpret_cast<tvec *>(p) = t;
+  }
 }
 
 // dst[t] = sum over k of src[tbl[k][t]]            (src_count == nullptr)
@@ -46,11 +58,11 @@ __device__ __forceinline__ void store_piece(float *p, const Piece<V> &r) {
 //                                                    src/pooling_avg_kernel.hpp:118-127)
 // then divided by the number of summed rows when `average` (forward, :96-108); that number is written to
 // dst_count when given.
-template <int V>
-__global__ __launch_bounds__(256) void k_pool_sum(const float *__restrict__ src, int c,
+template <typename T, int V>
+__global__ __launch_bounds__(256) void k_pool_sum(const T *__restrict__ src, int c,
                                                  const int32_t *__restrict__ tbl, int64_t n_tgt, int volume,
                                                  const float *__restrict__ src_count, int average,
-                                                 float *__restrict__ dst, float *__restrict__ dst_count) {
+                                                 T *__restrict__ dst, float *__restrict__ dst_count) {
   const int pieces = c / V;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n_tgt * pieces) return;
@@ -63,7 +75,7 @@ __global__ __launch_bounds__(256) void k_pool_sum(const float *__restrict__ src,
   for (int k = 0; k < volume; ++k) {
     const int32_t s = tbl[(int64_t)k * n_tgt + t];
     if (s < 0) continue;
-    const Piece<V> x = load_piece<V>(src + (int64_t)s * c + ch);
+    const Piece<V> x = load_piece<T, V>(src + (int64_t)s * c + ch);
     if (src_count) {
       const float d = src_count[s];
       if (d > 0.f) {
@@ -80,16 +92,16 @@ __global__ __launch_bounds__(256) void k_pool_sum(const float *__restrict__ src,
 #pragma unroll
     for (int j = 0; j < V; ++j) acc.v[j] /= cnt;
   }
-  store_piece<V>(dst + t * c + ch, acc);
+  store_piece<T, V>(dst + t * c + ch, acc);
   if (dst_count && ch == 0) dst_count[t] = cnt;
 }
 
 // dst[t][c] = max over k of src[tbl[k][t]][c], mask[t][c] = flat index (source row * C + c) of the
 // first maximum in k order, -FLT_MAX / -1 for rows without neighbours (src/pooling_max_kernel.hpp:36-96)
-template <int V>
-__global__ __launch_bounds__(256) void k_pool_max(const float *__restrict__ src, int c,
+template <typename T, int V>
+__global__ __launch_bounds__(256) void k_pool_max(const T *__restrict__ src, int c,
                                                  const int32_t *__restrict__ tbl, int64_t n_tgt, int volume,
-                                                 float *__restrict__ dst, int32_t *__restrict__ mask) {
+                                                 T *__restrict__ dst, int32_t *__restrict__ mask) {
   const int pieces = c / V;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n_tgt * pieces) return;
@@ -105,7 +117,7 @@ __global__ __launch_bounds__(256) void k_pool_max(const float *__restrict__ src,
   for (int k = 0; k < volume; ++k) {
     const int32_t s = tbl[(int64_t)k * n_tgt + t];
     if (s < 0) continue;
-    const Piece<V> x = load_piece<V>(src + (int64_t)s * c + ch);
+    const Piece<V> x = load_piece<T, V>(src + (int64_t)s * c + ch);
 #pragma unroll
     for (int j = 0; j < V; ++j) {
       if (best.v[j] < x.v[j]) {
@@ -114,18 +126,18 @@ __global__ __launch_bounds__(256) void k_pool_max(const float *__restrict__ src,
       }
     }
   }
-  store_piece<V>(dst + t * c + ch, best);
+  store_piece<T, V>(dst + t * c + ch, best);
 #pragma unroll
   for (int j = 0; j < V; ++j) mask[t * c + ch + j] = arg[j];
 }
 
 // grad_in[i][c] = sum over k of grad_out[o][c] for the output rows o = tblT[k][i] whose maximum came
 // from (i, c)  (src/pooling_max_kernel.hpp:98-117, without its scatter)
-template <int V>
-__global__ __launch_bounds__(256) void k_pool_max_backward(const float *__restrict__ grad_out, int c,
+template <typename T, int V>
+__global__ __launch_bounds__(256) void k_pool_max_backward(const T *__restrict__ grad_out, int c,
                                                           const int32_t *__restrict__ tbl_in, int64_t n_in,
                                                           int volume, const int32_t *__restrict__ mask,
-                                                          float *__restrict__ grad_in) {
+                                                          T *__restrict__ grad_in) {
   const int pieces = c / V;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n_in * pieces) return;
@@ -139,10 +151,10 @@ __global__ __launch_bounds__(256) void k_pool_max_backward(const float *__restri
     if (o < 0) continue;
 #pragma unroll
     for (int j = 0; j < V; ++j) {
-      if (mask[(int64_t)o * c + ch + j] == (int32_t)(i * c + ch + j)) acc.v[j] += grad_out[(int64_t)o * c + ch + j];
+      if (mask[(int64_t)o * c + ch + j] == (int32_t)(i * c + ch + j)) acc.v[j] += (float)grad_out[(int64_t)o * c + ch + j];
     }
   }
-  store_piece<V>(grad_in + i * c + ch, acc);
+  store_piece<T, V>(grad_in + i * c + ch, acc);
 }
 
 // ---- global pooling: reduce the rows of each batch index (origin map row) -------------------------
@@ -158,9 +170,9 @@ static inline int64_t global_chunk_rows(int64_t n) {
   return l < 256 ? 256 : l;
 }
 
-template <bool MAX, int V>
-__global__ __launch_bounds__(256) void k_global_partial(const float *__restrict__ src,
-                                                       const float *__restrict__ src2, int c,
+template <typename T, bool MAX, int V>
+__global__ __launch_bounds__(256) void k_global_partial(const T *__restrict__ src,
+                                                       const T *__restrict__ src2, int c,
                                                        const int32_t *__restrict__ batch_row, int64_t n,
                                                        int64_t chunk_rows, int n_batch,
                                                        float *__restrict__ partial,
@@ -190,9 +202,9 @@ __global__ __launch_bounds__(256) void k_global_partial(const float *__restrict_
     if (active) {
 #pragma unroll 4
       for (int64_t r = r0 + rl; r < r1; r += R) {
-        Piece<V> x = load_piece<V>(src + r * c + p * V);
+        Piece<V> x = load_piece<T, V>(src + r * c + p * V);
         if (src2) {
-          const Piece<V> y = load_piece<V>(src2 + r * c + p * V);
+          const Piece<V> y = load_piece<T, V>(src2 + r * c + p * V);
 #pragma unroll
           for (int j = 0; j < V; ++j) x.v[j] *= y.v[j];
         }
@@ -266,8 +278,8 @@ __global__ __launch_bounds__(256) void k_global_partial(const float *__restrict_
         arg = -1;
         cnt = 0.f;
       }
-      float x = src[r * c + ch];
-      if (src2) x *= src2[r * c + ch];
+      float x = (float)src[r * c + ch];
+      if (src2) x *= (float)src2[r * c + ch];
       if (MAX) {
         if (acc < x) {
           acc = x;
@@ -331,23 +343,23 @@ __global__ __launch_bounds__(256) void k_global_final(const float *__restrict__ 
 }
 
 // out[i][c] = in[i][c] (+ | *) glob[batch_row[i]][c]; with in == nullptr: out[i][c] = glob[...][c]
-template <int V>
-__global__ __launch_bounds__(256) void k_broadcast(const float *__restrict__ in, const float *__restrict__ glob,
+template <typename T, int V>
+__global__ __launch_bounds__(256) void k_broadcast(const T *__restrict__ in, const T *__restrict__ glob,
                                                   const int32_t *__restrict__ batch_row, int64_t n, int c,
-                                                  int multiply, float *__restrict__ out) {
+                                                  int multiply, T *__restrict__ out) {
   const int pieces = c / V;
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= n * pieces) return;
   const int64_t i = idx / pieces;
   const int ch = (int)(idx % pieces) * V;
-  const Piece<V> g = load_piece<V>(glob + (int64_t)batch_row[i] * c + ch);
+  const Piece<V> g = load_piece<T, V>(glob + (int64_t)batch_row[i] * c + ch);
   Piece<V> r = g;
   if (in) {
-    const Piece<V> x = load_piece<V>(in + i * c + ch);
+    const Piece<V> x = load_piece<T, V>(in + i * c + ch);
 #pragma unroll
     for (int j = 0; j < V; ++j) r.v[j] = multiply ? x.v[j] * g.v[j] : x.v[j] + g.v[j];
   }
-  store_piece<V>(out + i * c + ch, r);
+  store_piece<T, V>(out + i * c + ch, r);
 }
 
 // Segmented sum / mean of feature rows (voxelisation of duplicate coordinates, the reference's
@@ -370,7 +382,7 @@ __global__ __launch_bounds__(256) void k_segment_sum(const float *__restrict__ s
 #pragma unroll
   for (int j = 0; j < V; ++j) acc.v[j] = 0.f;
   for (int64_t i = b; i < e; ++i) {
-    const Piece<V> x = load_piece<V>(src + perm[i] * c + ch);
+    const Piece<V> x = load_piece<float, V>(src + perm[i] * c + ch);
 #pragma unroll
     for (int j = 0; j < V; ++j) acc.v[j] += x.v[j];
   }
@@ -379,75 +391,98 @@ __global__ __launch_bounds__(256) void k_segment_sum(const float *__restrict__ s
 #pragma unroll
     for (int j = 0; j < V; ++j) acc.v[j] /= inv;
   }
-  store_piece<V>(dst + s * c + ch, acc);
+  store_piece<float, V>(dst + s * c + ch, acc);
 }
 
 }  // namespace me
 
 using namespace me;
 
-extern "C" {
+namespace {
 
-int me_pool_sum_f32(const float *src, int32_t c, const int32_t *tbl, int64_t n_tgt, int64_t volume,
-                    const float *src_count, int32_t average, float *dst, float *dst_count, void *stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+// widest piece (elements) for rows of c channels of T at the given addresses: 16 bytes when everything is
+// 16-byte aligned, 8 bytes for bf16 rows of a multiple of 4 channels, else one element
+template <typename T>
+int piece_width(int c, std::initializer_list<const void *> ptrs) {
+  constexpr int W = 16 / (int)sizeof(T);
+  bool a16 = true, a8 = true;
+  for (const void *p : ptrs) {
+    if (p == nullptr) continue;
+    a16 = a16 && ((uintptr_t)p % 16 == 0);
+    a8 = a8 && ((uintptr_t)p % 8 == 0);
+  }
+  if (c % W == 0 && a16) return W;
+  if (sizeof(T) == 2 && c % 4 == 0 && a8) return 4;
+  return 1;
+}
+
+#define ME_POOL_DISPATCH_V(T, v, ...)                                                            \
+  do {                                                                                           \
+    if ((v) == 8) { constexpr int V = (sizeof(T) == 2 ? 8 : 4); __VA_ARGS__; }                   \
+    else if ((v) == 4) { constexpr int V = 4; __VA_ARGS__; }                                     \
+    else { constexpr int V = 1; __VA_ARGS__; }                                                   \
+  } while (0)
+
+template <typename T>
+int pool_sum(const T *src, int32_t c, const int32_t *tbl, int64_t n_tgt, int64_t volume, const float *src_count,
+             int32_t average, T *dst, float *dst_count, hipStream_t stream) {
   ME_CHECK(c > 0 && volume >= 1 && volume <= 65535, "invalid channel count or kernel volume");
   if (n_tgt == 0) return 0;
-  const bool vec = (c % 4) == 0 && (uintptr_t)src % 16 == 0 && (uintptr_t)dst % 16 == 0;
-  const int64_t total = n_tgt * (vec ? c / 4 : c);
+  const int v = piece_width<T>(c, {src, dst});
+  const int64_t total = n_tgt * (c / v);
   const dim3 grid((unsigned)ceil_div(total, 256)), block(256);
-  if (vec)
-    hipLaunchKernelGGL(k_pool_sum<4>, grid, block, 0, stream, src, c, tbl, n_tgt, (int)volume, src_count, average,
-                       dst, dst_count);
-  else
-    hipLaunchKernelGGL(k_pool_sum<1>, grid, block, 0, stream, src, c, tbl, n_tgt, (int)volume, src_count, average,
-                       dst, dst_count);
+  ME_POOL_DISPATCH_V(T, v, hipLaunchKernelGGL((k_pool_sum<T, V>), grid, block, 0, stream, src, c, tbl, n_tgt,
+                                              (int)volume, src_count, average, dst, dst_count));
   ME_LAUNCH_CHECK();
   return 0;
 }
 
-int me_pool_max_f32(const float *src, int32_t c, const int32_t *tbl, int64_t n_tgt, int64_t volume, float *dst,
-                    int32_t *mask, void *stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+template <typename T>
+int pool_max(const T *src, int32_t c, const int32_t *tbl, int64_t n_tgt, int64_t volume, T *dst, int32_t *mask,
+             hipStream_t stream) {
   ME_CHECK(c > 0 && volume >= 1 && volume <= 65535, "invalid channel count or kernel volume");
   if (n_tgt == 0) return 0;
-  const bool vec = (c % 4) == 0 && (uintptr_t)src % 16 == 0 && (uintptr_t)dst % 16 == 0;
-  const int64_t total = n_tgt * (vec ? c / 4 : c);
+  const int v = piece_width<T>(c, {src, dst});
+  const int64_t total = n_tgt * (c / v);
   const dim3 grid((unsigned)ceil_div(total, 256)), block(256);
-  if (vec) hipLaunchKernelGGL(k_pool_max<4>, grid, block, 0, stream, src, c, tbl, n_tgt, (int)volume, dst, mask);
-  else hipLaunchKernelGGL(k_pool_max<1>, grid, block, 0, stream, src, c, tbl, n_tgt, (int)volume, dst, mask);
+  ME_POOL_DISPATCH_V(T, v, hipLaunchKernelGGL((k_pool_max<T, V>), grid, block, 0, stream, src, c, tbl, n_tgt,
+                                              (int)volume, dst, mask));
   ME_LAUNCH_CHECK();
   return 0;
 }
 
-int me_pool_max_backward_f32(const float *grad_out, int32_t c, const int32_t *tbl_in, int64_t n_in,
-                             int64_t volume, const int32_t *mask, float *grad_in, void *stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+template <typename T>
+int pool_max_backward(const T *grad_out, int32_t c, const int32_t *tbl_in, int64_t n_in, int64_t volume,
+                      const int32_t *mask, T *grad_in, hipStream_t stream) {
   ME_CHECK(c > 0 && volume >= 1 && volume <= 65535, "invalid channel count or kernel volume");
   if (n_in == 0) return 0;
-  const bool vec = (c % 4) == 0 && (uintptr_t)grad_in % 16 == 0;
-  const int64_t total = n_in * (vec ? c / 4 : c);
+  const int v = piece_width<T>(c, {grad_in});
+  const int64_t total = n_in * (c / v);
   const dim3 grid((unsigned)ceil_div(total, 256)), block(256);
-  if (vec)
-    hipLaunchKernelGGL(k_pool_max_backward<4>, grid, block, 0, stream, grad_out, c, tbl_in, n_in, (int)volume, mask,
-                       grad_in);
-  else
-    hipLaunchKernelGGL(k_pool_max_backward<1>, grid, block, 0, stream, grad_out, c, tbl_in, n_in, (int)volume, mask,
-                       grad_in);
+  ME_POOL_DISPATCH_V(T, v, hipLaunchKernelGGL((k_pool_max_backward<T, V>), grid, block, 0, stream, grad_out, c,
+                                              tbl_in, n_in, (int)volume, mask, grad_in));
   ME_LAUNCH_CHECK();
   return 0;
 }
 
-int64_t me_global_pool_workspace_bytes(int64_t n, int32_t n_batch, int32_t c) {
-  const int64_t chunks = ceil_div(n < 1 ? 1 : n, global_chunk_rows(n));
-  // partial values | partial argmax | partial counts
-  return align_up(chunks * n_batch * c * 4, 256) * 2 + align_up(chunks * n_batch * 4, 256);
+template <typename T>
+int broadcast(const T *in, const T *glob, const int32_t *batch_row, int64_t n, int32_t c, int32_t multiply, T *out,
+              hipStream_t stream) {
+  ME_CHECK(c > 0, "invalid channel count");
+  if (n == 0) return 0;
+  const int v = piece_width<T>(c, {glob, out, in});
+  const int64_t total = n * (c / v);
+  const dim3 grid((unsigned)ceil_div(total, 256)), block(256);
+  ME_POOL_DISPATCH_V(T, v, hipLaunchKernelGGL((k_broadcast<T, V>), grid, block, 0, stream, in, glob, batch_row, n, c,
+                                              multiply, out));
+  ME_LAUNCH_CHECK();
+  return 0;
 }
 
-int me_global_pool_f32(const float *src, const float *src2, int32_t c, const int32_t *batch_row, int64_t n,
-                       int32_t n_batch, int32_t mode, float *dst, int32_t *dst_arg, float *dst_count,
-                       void *workspace, int64_t workspace_bytes, void *stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+template <typename T>
+int global_pool(const T *src, const T *src2, int32_t c, const int32_t *batch_row, int64_t n, int32_t n_batch,
+                int32_t mode, float *dst, int32_t *dst_arg, float *dst_count, void *workspace,
+                int64_t workspace_bytes, hipStream_t stream) {
   ME_CHECK(c > 0 && n_batch > 0, "invalid channel count or batch size");
   ME_CHECK(mode >= 0 && mode <= 2, "mode must be 0 (sum), 1 (average) or 2 (max)");
   ME_CHECK(mode != 2 || dst_arg != nullptr, "max pooling needs the argmax output");
@@ -459,6 +494,7 @@ int me_global_pool_f32(const float *src, const float *src2, int32_t c, const int
   int32_t *partial_arg = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(workspace) + vsz);
   float *partial_cnt = reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + 2 * vsz);
   const int64_t total = (int64_t)n_batch * c;
+  // a thread owns 4 channels (one 16-byte piece of a float row, 8 bytes of a bf16 row) or one channel
   const bool vec = (c % 4) == 0 && c / 4 <= 256 && (uintptr_t)src % 16 == 0 &&
                    (src2 == nullptr || (uintptr_t)src2 % 16 == 0);
   const int P = vec ? c / 4 : (c < 256 ? c : 256);
@@ -472,10 +508,10 @@ int me_global_pool_f32(const float *src, const float *src2, int32_t c, const int
     ME_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(partial), (int)0xff7fffff, (size_t)chunks * total, stream));
     if (n > 0) {
       if (vec)
-        hipLaunchKernelGGL((k_global_partial<true, 4>), dim3((unsigned)chunks), dim3(256), lds, stream, src, src2, c,
+        hipLaunchKernelGGL((k_global_partial<T, true, 4>), dim3((unsigned)chunks), dim3(256), lds, stream, src, src2, c,
                            batch_row, n, chunk_rows, n_batch, partial, partial_arg, partial_cnt);
       else
-        hipLaunchKernelGGL((k_global_partial<true, 1>), dim3((unsigned)chunks), dim3(256), lds, stream, src, src2, c,
+        hipLaunchKernelGGL((k_global_partial<T, true, 1>), dim3((unsigned)chunks), dim3(256), lds, stream, src, src2, c,
                            batch_row, n, chunk_rows, n_batch, partial, partial_arg, partial_cnt);
       ME_LAUNCH_CHECK();
     }
@@ -486,10 +522,10 @@ int me_global_pool_f32(const float *src, const float *src2, int32_t c, const int
     ME_HIP(hipMemsetAsync(partial_cnt, 0, (size_t)chunks * n_batch * 4, stream));
     if (n > 0) {
       if (vec)
-        hipLaunchKernelGGL((k_global_partial<false, 4>), dim3((unsigned)chunks), dim3(256), lds, stream, src, src2, c,
+        hipLaunchKernelGGL((k_global_partial<T, false, 4>), dim3((unsigned)chunks), dim3(256), lds, stream, src, src2, c,
                            batch_row, n, chunk_rows, n_batch, partial, partial_arg, partial_cnt);
       else
-        hipLaunchKernelGGL((k_global_partial<false, 1>), dim3((unsigned)chunks), dim3(256), lds, stream, src, src2, c,
+        hipLaunchKernelGGL((k_global_partial<T, false, 1>), dim3((unsigned)chunks), dim3(256), lds, stream, src, src2, c,
                            batch_row, n, chunk_rows, n_batch, partial, partial_arg, partial_cnt);
       ME_LAUNCH_CHECK();
     }
@@ -500,19 +536,66 @@ int me_global_pool_f32(const float *src, const float *src2, int32_t c, const int
   return 0;
 }
 
+}  // namespace
+
+extern "C" {
+
+int64_t me_global_pool_workspace_bytes(int64_t n, int32_t n_batch, int32_t c) {
+  const int64_t chunks = ceil_div(n < 1 ? 1 : n, global_chunk_rows(n));
+  // partial values | partial argmax | partial counts
+  return align_up(chunks * n_batch * c * 4, 256) * 2 + align_up(chunks * n_batch * 4, 256);
+}
+
+int me_pool_sum_f32(const float *src, int32_t c, const int32_t *tbl, int64_t n_tgt, int64_t volume,
+                    const float *src_count, int32_t average, float *dst, float *dst_count, void *stream) {
+  return pool_sum<float>(src, c, tbl, n_tgt, volume, src_count, average, dst, dst_count, (hipStream_t)stream);
+}
+int me_pool_sum_bf16(const uint16_t *src, int32_t c, const int32_t *tbl, int64_t n_tgt, int64_t volume,
+                     const float *src_count, int32_t average, uint16_t *dst, float *dst_count, void *stream) {
+  return pool_sum<__bf16>((const __bf16 *)src, c, tbl, n_tgt, volume, src_count, average, (__bf16 *)dst, dst_count,
+                          (hipStream_t)stream);
+}
+
+int me_pool_max_f32(const float *src, int32_t c, const int32_t *tbl, int64_t n_tgt, int64_t volume, float *dst,
+                    int32_t *mask, void *stream) {
+  return pool_max<float>(src, c, tbl, n_tgt, volume, dst, mask, (hipStream_t)stream);
+}
+int me_pool_max_bf16(const uint16_t *src, int32_t c, const int32_t *tbl, int64_t n_tgt, int64_t volume, uint16_t *dst,
+                     int32_t *mask, void *stream) {
+  return pool_max<__bf16>((const __bf16 *)src, c, tbl, n_tgt, volume, (__bf16 *)dst, mask, (hipStream_t)stream);
+}
+
+int me_pool_max_backward_f32(const float *grad_out, int32_t c, const int32_t *tbl_in, int64_t n_in,
+                             int64_t volume, const int32_t *mask, float *grad_in, void *stream) {
+  return pool_max_backward<float>(grad_out, c, tbl_in, n_in, volume, mask, grad_in, (hipStream_t)stream);
+}
+int me_pool_max_backward_bf16(const uint16_t *grad_out, int32_t c, const int32_t *tbl_in, int64_t n_in,
+                              int64_t volume, const int32_t *mask, uint16_t *grad_in, void *stream) {
+  return pool_max_backward<__bf16>((const __bf16 *)grad_out, c, tbl_in, n_in, volume, mask, (__bf16 *)grad_in,
+                                   (hipStream_t)stream);
+}
+
+int me_global_pool_f32(const float *src, const float *src2, int32_t c, const int32_t *batch_row, int64_t n,
+                       int32_t n_batch, int32_t mode, float *dst, int32_t *dst_arg, float *dst_count,
+                       void *workspace, int64_t workspace_bytes, void *stream) {
+  return global_pool<float>(src, src2, c, batch_row, n, n_batch, mode, dst, dst_arg, dst_count, workspace,
+                            workspace_bytes, (hipStream_t)stream);
+}
+int me_global_pool_bf16(const uint16_t *src, const uint16_t *src2, int32_t c, const int32_t *batch_row, int64_t n,
+                        int32_t n_batch, int32_t mode, float *dst, int32_t *dst_arg, float *dst_count,
+                        void *workspace, int64_t workspace_bytes, void *stream) {
+  return global_pool<__bf16>((const __bf16 *)src, (const __bf16 *)src2, c, batch_row, n, n_batch, mode, dst, dst_arg,
+                             dst_count, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
 int me_broadcast_f32(const float *in, const float *glob, const int32_t *batch_row, int64_t n, int32_t c,
-                     int32_t multiply, float *out, void *stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
-  ME_CHECK(c > 0, "invalid channel count");
-  if (n == 0) return 0;
-  const bool vec = (c % 4) == 0 && (uintptr_t)glob % 16 == 0 && (uintptr_t)out % 16 == 0 &&
-                   (in == nullptr || (uintptr_t)in % 16 == 0);
-  const int64_t total = n * (vec ? c / 4 : c);
-  const dim3 grid((unsigned)ceil_div(total, 256)), block(256);
-  if (vec) hipLaunchKernelGGL(k_broadcast<4>, grid, block, 0, stream, in, glob, batch_row, n, c, multiply, out);
-  else hipLaunchKernelGGL(k_broadcast<1>, grid, block, 0, stream, in, glob, batch_row, n, c, multiply, out);
-  ME_LAUNCH_CHECK();
-  return 0;
+                     int32_t multiply, float *out, void *stream) {
+  return broadcast<float>(in, glob, batch_row, n, c, multiply, out, (hipStream_t)stream);
+}
+int me_broadcast_bf16(const uint16_t *in, const uint16_t *glob, const int32_t *batch_row, int64_t n, int32_t c,
+                      int32_t multiply, uint16_t *out, void *stream) {
+  return broadcast<__bf16>((const __bf16 *)in, (const __bf16 *)glob, batch_row, n, c, multiply, (__bf16 *)out,
+                           (hipStream_t)stream);
 }
 
 int me_segment_sum_f32(const float *src, int32_t c, const int64_t *perm, const int64_t *seg_offsets, int64_t n_seg,

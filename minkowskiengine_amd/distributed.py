@@ -1,12 +1,27 @@
 """Sample-sharded data parallelism: one process per GPU, every rank owns whole scenes and its own
 coordinate manager / hash tables / kernel maps (no cross-GPU coordinate maps); the only exchange is
-the gradient all-reduce once per step — RCCL over xGMI through torch.distributed backend "nccl"
-(reference: examples/multigpu_ddp.py:72-131, PyTorch DDP over NCCL; no native collectives exist in
-the reference).  Device-agnostic so the logic is testable with backend "gloo" on CPU."""
+the gradient all-reduce — RCCL over xGMI through torch.distributed backend "nccl" — done by
+torch's DistributedDataParallel: gradient buckets are reduced while the rest of the backward pass
+still runs (reference: examples/multigpu_ddp.py:81-95: init_process_group -> DDP ->
+MinkowskiSyncBatchNorm.convert_sync_batchnorm; the reference has no native collectives).
+
+Device-agnostic so the logic is testable with backend "gloo": on CPU tensors (tests/test_distributed_cpu.py)
+and with several ranks sharing ONE GPU (tests/test_gpu_distributed.py, bench.py --gpus N on a 1-GPU box) —
+RCCL refuses two ranks on one device, gloo stages CUDA tensors through the host."""
 import os
 
 import torch
 import torch.distributed as dist
+
+
+def visible_gpus():
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+def pick_backend(world, n_gpus=None):
+    """"nccl" (= RCCL on ROCm) when every rank gets its own GPU, else "gloo" (CPU, or ranks sharing a GPU)."""
+    n_gpus = visible_gpus() if n_gpus is None else n_gpus
+    return "nccl" if n_gpus >= world and n_gpus > 0 else "gloo"
 
 
 def init_from_env(backend=None):
@@ -19,15 +34,24 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+            backend = pick_backend(world)
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank % visible_gpus())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
 
 
+def local_device(local_rank):
+    """cuda device of a rank; ranks wrap around when there are fewer GPUs than ranks (gloo test mode)"""
+    return torch.device("cuda", local_rank % visible_gpus())
+
+
 def world_size():
     return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def backend_name():
+    return dist.get_backend() if dist.is_initialized() else None
 
 
 def shard_scenes(n_scenes, rank, world):
@@ -44,52 +68,78 @@ def broadcast_parameters(module, src=0):
         dist.broadcast(b.data, src=src)
 
 
+def data_parallel(module, device=None, bucket_cap_mb=25, sync_batchnorm=False):
+    """Wrap `module` for sample-sharded training: torch DistributedDataParallel (parameters broadcast from rank 0,
+    gradients averaged in `bucket_cap_mb` buckets overlapped with the backward pass; few, large collectives suit
+    the per-link-bound xGMI rings).  `sync_batchnorm` converts MinkowskiBatchNorm layers first, as the reference's
+    example does (examples/multigpu_ddp.py:95).  With one rank the module is returned unchanged."""
+    if world_size() == 1:
+        return module
+    if sync_batchnorm:
+        from .layers import MinkowskiSyncBatchNorm
+        module = MinkowskiSyncBatchNorm.convert_sync_batchnorm(module)
+    from torch.nn.parallel import DistributedDataParallel
+    if device is not None and device.type == "cuda":
+        return DistributedDataParallel(module, device_ids=[device.index], output_device=device.index,
+                                       bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True)
+    return DistributedDataParallel(module, bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True)
+
+
 def allreduce_gradients(module, average=True, bucket_bytes=25 * 1024 * 1024):
-    """Sum (or average) all parameter gradients over the ranks in flat buckets (few, large
-    collectives: xGMI rings are per-link bound)."""
+    """Explicit post-backward all-reduce of all parameter gradients in flat buckets, for loops that do not use
+    `data_parallel` (no overlap with the backward pass — DDP is the training path).  Every rank issues the same
+    collectives whatever its local state: ALL parameters that require a gradient take part in registration order
+    (a missing gradient counts as zeros and is materialised), buckets never mix dtypes, and the reduced values are
+    always copied back into `.grad` (also for a single-tensor bucket and for non-contiguous gradients)."""
     w = world_size()
     if w == 1:
         return
-    grads = [p.grad for p in module.parameters() if p.grad is not None]
+    params = [p for p in module.parameters() if p.requires_grad]
+    for p in params:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
     bucket, size = [], 0
 
     def flush():
         if not bucket:
             return
-        flat = torch.cat([g.reshape(-1) for g in bucket]) if len(bucket) > 1 else bucket[0].reshape(-1)
+        flat = torch.cat([g.reshape(-1) for g in bucket])      # always an explicit buffer (one dtype)
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         if average:
             flat.div_(w)
-        if len(bucket) > 1:
-            off = 0
-            for g in bucket:
-                g.copy_(flat[off:off + g.numel()].view_as(g))
-                off += g.numel()
+        off = 0
+        for g in bucket:
+            g.copy_(flat[off:off + g.numel()].view(g.shape))
+            off += g.numel()
 
-    for g in grads:
-        if size + g.numel() * g.element_size() > bucket_bytes and bucket:
+    for p in params:
+        g = p.grad
+        nbytes = g.numel() * g.element_size()
+        if bucket and (size + nbytes > bucket_bytes or g.dtype != bucket[0].dtype or g.device != bucket[0].device):
             flush()
             bucket, size = [], 0
         bucket.append(g)
-        size += g.numel() * g.element_size()
+        size += nbytes
     flush()
+
+
+def _reduce_scalar(value, op, device):
+    if world_size() == 1:
+        return float(value)
+    if device is None and backend_name() == "nccl":
+        device = torch.device("cuda", torch.cuda.current_device())
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=op)
+    return float(t.item())
 
 
 def max_over_ranks(value, device=None):
     """Max of a python float over all ranks (used for the step time)."""
-    if world_size() == 1:
-        return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t.item())
+    return _reduce_scalar(value, dist.ReduceOp.MAX, device)
 
 
 def sum_over_ranks(value, device=None):
-    if world_size() == 1:
-        return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return float(t.item())
+    return _reduce_scalar(value, dist.ReduceOp.SUM, device)
 
 
 def barrier():

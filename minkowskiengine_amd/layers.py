@@ -98,6 +98,7 @@ class MinkowskiSyncBatchNorm(MinkowskiBatchNorm):
     def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True,
                  process_group=None):
         nn.Module.__init__(self)
+        self.fuse_relu = False   # torch's SyncBatchNorm does the arithmetic: the following MinkowskiReLU rectifies
         self.bn = nn.SyncBatchNorm(num_features, eps=eps, momentum=momentum, affine=affine,
                                    track_running_stats=track_running_stats, process_group=process_group)
 

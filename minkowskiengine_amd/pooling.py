@@ -143,8 +143,10 @@ class MinkowskiPoolingTranspose(MinkowskiPoolingBase):
     def forward(self, input, coordinates=None):
         assert isinstance(input, SparseTensor)
         assert input.D == self.dimension
-        out_coordinate_map_key = _get_coordinate_map_key(input, coordinates,
-                                                         self.kernel_generator.expand_coordinates)
+        # (by keyword: positionally the flag would land in the tensor_stride slot of
+        # MinkowskiSparseTensor.py:754-759 and insert a map with tensor stride [0, ...], the origin map's key)
+        out_coordinate_map_key = _get_coordinate_map_key(
+            input, coordinates, expand_coordinates=self.kernel_generator.expand_coordinates)
         outfeat = self.pooling.apply(input.F, self.pooling_mode, self.kernel_generator, input.coordinate_map_key,
                                      out_coordinate_map_key, input._manager)
         return SparseTensor(outfeat, coordinate_map_key=out_coordinate_map_key,

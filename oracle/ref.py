@@ -124,3 +124,98 @@ class RefPool(RefConv):
         C = self.C
         op = C.BroadcastMode.ELEMENTWISE_MULTIPLICATION if multiply else C.BroadcastMode.ELEMENTWISE_ADDITON
         return C.BroadcastBackwardCPU(feats, glob, grad_out, op, self.in_key, self.glob_key, self.manager)
+
+
+def reference_root():
+    return os.environ.get("ME_REFERENCE_ROOT", "/root/reference")
+
+
+def package_available():
+    """the reference's Python package can only be imported where /root/reference exists (the authoring container)"""
+    return available() and os.path.isdir(os.path.join(reference_root(), "MinkowskiEngine"))
+
+
+def import_reference_package(backend=None):
+    """Import the REFERENCE's own Python package (/root/reference/MinkowskiEngine, v0.5.4) on top of `backend`
+    as its `MinkowskiEngineBackend._C` — by default the reference's own CPU operators (oracle/_ref/_C.so); the
+    drop-in tests pass minkowskiengine_amd.backend instead.  Returns the imported `MinkowskiEngine` module.
+    Side effects (this is why callers run it in a subprocess): sys.modules gets MinkowskiEngineBackend, a stub
+    `open3d` (examples/resnet.py imports it at module scope), sys.path gets the reference root, and the working
+    directory moves to a scratch directory holding an empty 1.ply (examples/resnet.py would download it)."""
+    import sys
+    import tempfile
+    import types
+    C = load() if backend is None else backend
+    pkg = types.ModuleType("MinkowskiEngineBackend")
+    pkg._C = C
+    pkg.__path__ = []
+    sys.modules["MinkowskiEngineBackend"] = pkg
+    sys.modules["MinkowskiEngineBackend._C"] = C
+    sys.modules.setdefault("open3d", types.ModuleType("open3d"))
+    if reference_root() not in sys.path:
+        sys.path.insert(0, reference_root())
+    work = tempfile.mkdtemp()
+    os.chdir(work)
+    open("1.ply", "w").close()
+    import MinkowskiEngine as RME
+    return RME
+
+
+class RefConvStack:
+    """TEST / BENCH INFRASTRUCTURE: the convolution layers of a network (a list of layer specs recorded from the
+    MI355X run) replayed on the reference's own CPU operators on the same coordinates — the `cpu_baseline` of
+    bench.py's MinkUNet workload where the reference's Python package (and so its network class) is absent.
+    A spec is (is_transpose, kernel_size, stride, c_in, c_out, in_tensor_stride); k = 1, s = 1 layers are the
+    reference's `use_mm` matmuls (MinkowskiConvolution.py:264-270, 304-308).  Batch norm / ReLU / concatenation are
+    NOT replayed (they are torch ops in the reference): the figure is a lower bound of the reference's step time."""
+
+    def __init__(self, coords, layers, num_threads=None, seed=0):
+        C = load()
+        self.C = C
+        coords = coords.contiguous().int().cpu()
+        D = coords.shape[1] - 1
+        self.D = D
+        nthreads = num_threads if num_threads is not None else min(os.cpu_count() or 1, 20)
+        self.manager = C.CoordinateMapManagerCPU(C.MinkowskiAlgorithm.DEFAULT, nthreads)
+        key, _ = self.manager.insert_and_map(coords, [1] * D, "")
+        self.keys = {tuple([1] * D): key}
+        self.empty_offset = torch.IntTensor()
+        g = torch.Generator().manual_seed(seed)
+        self.layers, self._feat, self._ones = [], {}, {}
+        for (tr, ks, st, cin, cout, ts) in layers:
+            ks, st, ts = [int(v) for v in ks], [int(v) for v in st], tuple(int(v) for v in ts)
+            in_key = self.keys[ts]
+            out_ts = tuple(t // s for t, s in zip(ts, st)) if tr else tuple(t * s for t, s in zip(ts, st))
+            if out_ts not in self.keys:
+                assert not tr, "a transposed convolution needs the finer map to exist"
+                self.keys[out_ts] = self.manager.stride(in_key, st, "")
+            out_key = self.keys[out_ts]
+            n_in, n_out = self.manager.size(in_key), self.manager.size(out_key)
+            volume = 1
+            for k in ks:
+                volume *= k
+            mm = volume == 1 and all(s == 1 for s in st)
+            w = (torch.rand((cin, cout) if mm else (volume, cin, cout), generator=g) - 0.5) * 0.1
+            if (n_in, cin) not in self._feat:
+                self._feat[(n_in, cin)] = torch.rand(n_in, cin, generator=g)
+            if (n_out, cout) not in self._ones:
+                self._ones[(n_out, cout)] = torch.ones(n_out, cout)
+            self.layers.append((tr, mm, ks, st, in_key, out_key, w, (n_in, cin), (n_out, cout)))
+
+    def run(self):
+        """one forward + backward of every layer"""
+        C = self.C
+        dl = [1] * self.D
+        for tr, mm, ks, st, in_key, out_key, w, fk, ok in self.layers:
+            x, gy = self._feat[fk], self._ones[ok]
+            if mm:
+                x.mm(w)
+                gy.mm(w.t())
+                x.t().mm(gy)
+                continue
+            fwd = C.ConvolutionTransposeForwardCPU if tr else C.ConvolutionForwardCPU
+            bwd = C.ConvolutionTransposeBackwardCPU if tr else C.ConvolutionBackwardCPU
+            fwd(x, w, ks, st, dl, C.RegionType.HYPER_CUBE, self.empty_offset, False, C.ConvolutionMode.DEFAULT, in_key,
+                out_key, self.manager)
+            bwd(x, gy, w, ks, st, dl, C.RegionType.HYPER_CUBE, self.empty_offset, C.ConvolutionMode.DEFAULT, in_key,
+                out_key, self.manager)

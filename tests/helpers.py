@@ -40,9 +40,36 @@ def golden_kmap(z):
 
 
 def rel_err(a, b):
+    """max |a - b| normalised by the largest reference magnitude (a coarse, GLOBAL figure: used only for
+    oracle-vs-reference sanity checks; the GPU parity tests use assert_close, which is per element)."""
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     return float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
+
+
+def close_excess(a, b, atol=1e-4, rtol=1e-4):
+    """max over elements of |a - b| / (atol + rtol * |b|): <= 1 means every element is within tolerance."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, f"shape mismatch {a.shape} vs {b.shape}"
+    if a.size == 0:
+        return 0.0
+    return float((np.abs(a - b) / (atol + rtol * np.abs(b))).max())
+
+
+def assert_close(a, b, atol=1e-4, rtol=1e-4, what=""):
+    """PER-ELEMENT parity check |a - b| <= atol + rtol * |b| — the fp32 bar of BASELINE.json's north_star
+    (1e-4 absolute + relative), not a max-normalised figure."""
+    if hasattr(a, "detach"):
+        a = a.detach().float().cpu().numpy()
+    if hasattr(b, "detach"):
+        b = b.detach().float().cpu().numpy()
+    ex = close_excess(a, b, atol, rtol)
+    if not ex <= 1.0:
+        a64, b64 = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        i = np.unravel_index(np.argmax(np.abs(a64 - b64) / (atol + rtol * np.abs(b64))), a64.shape)
+        raise AssertionError(f"{what} element {i}: got {a64[i]!r} want {b64[i]!r} "
+                             f"(|diff| {abs(a64[i] - b64[i]):.3e} = {ex:.2f} x tolerance {atol}+{rtol}|b|)")
 
 
 def row_mapping(coords_a, coords_b):

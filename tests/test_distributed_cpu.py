@@ -1,6 +1,7 @@
-"""The N>1 path on CPU: world_size-2 gloo processes exercise scene sharding, parameter broadcast,
-bucketed gradient all-reduce and max-over-ranks timing (the compute stand-in is a torch module; the
-HIP path needs a GPU)."""
+"""The N>1 path on CPU: world_size-2 gloo processes exercise scene sharding, parameter broadcast, the explicit
+bucketed gradient all-reduce (missing gradients, mixed dtypes, non-contiguous gradients, single-tensor buckets),
+the DistributedDataParallel wrapper of `distributed.data_parallel` and max-over-ranks timing.  The compute
+stand-in is a torch module; the HIP kernels under two ranks are covered by tests/test_gpu_distributed.py."""
 import os
 import socket
 
@@ -17,13 +18,24 @@ def _free_port():
     return p
 
 
+class _Mixed(torch.nn.Module):
+    """parameters of two dtypes, one that never receives a gradient on rank 1, one with a transposed gradient"""
+
+    def __init__(self):
+        super().__init__()
+        self.a = torch.nn.Parameter(torch.zeros(5, 3))
+        self.b = torch.nn.Parameter(torch.zeros(7, dtype=torch.float64))
+        self.c = torch.nn.Parameter(torch.zeros(4, 6))
+        self.d = torch.nn.Parameter(torch.zeros(2))
+
+
 def _worker(rank, world, port, out):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     from minkowskiengine_amd import distributed as D
     import minkowskiengine_amd as ME
     r, w, _ = D.init_from_env(backend="gloo")
-    assert (r, w) == (rank, world) and D.world_size() == world
+    assert (r, w) == (rank, world) and D.world_size() == world and D.backend_name() == "gloo"
     torch.manual_seed(100 + rank)                      # different init per rank ...
     conv = ME.MinkowskiConvolution(4, 6, kernel_size=3, dimension=3, bias=True)
     D.broadcast_parameters(conv)                       # ... identical after the broadcast
@@ -31,15 +43,34 @@ def _worker(rank, world, port, out):
     conv.kernel.grad = torch.full_like(conv.kernel, float(rank + 1))
     conv.bias.grad = torch.full_like(conv.bias, float(10 * (rank + 1)))
     D.allreduce_gradients(conv, average=True, bucket_bytes=1024)   # small buckets: multi-bucket path
+    # the defects of the round-1 version: a gradient missing on one rank, dtypes mixed in one bucket, a
+    # non-contiguous gradient alone in its bucket
+    m = _Mixed()
+    m.a.grad = torch.full((5, 3), float(rank + 1))
+    m.b.grad = torch.full((7,), float(rank + 1), dtype=torch.float64)
+    m.c.grad = torch.full((6, 4), float(rank + 1)).t()            # non-contiguous view
+    assert not m.c.grad.is_contiguous()
+    if rank == 0:
+        m.d.grad = torch.full((2,), 4.0)                          # rank 1 has no gradient for d
+    D.allreduce_gradients(m, average=True, bucket_bytes=64)       # one tensor per bucket
+    mixed = (m.a.grad.mean().item(), m.b.grad.mean().item(), m.b.grad.dtype == torch.float64,
+             m.c.grad.mean().item(), m.d.grad.mean().item())
+    # DistributedDataParallel wrapper: averaged gradients, parameters broadcast from rank 0
+    torch.manual_seed(7 + rank)
+    lin = torch.nn.Linear(3, 2)
+    ddp = D.data_parallel(lin)
+    x = torch.full((4, 3), float(rank + 1))
+    ddp(x).sum().backward()
+    ddp_out = (lin.weight.detach().sum().item(), lin.weight.grad.mean().item())
     t = D.max_over_ranks(0.5 + rank)
     s = D.sum_over_ranks(len(scenes))
     D.barrier()
     out[rank] = (conv.kernel.detach().sum().item(), conv.kernel.grad.mean().item(), conv.bias.grad.mean().item(),
-                 t, s, scenes)
+                 t, s, scenes, mixed, ddp_out)
     torch.distributed.destroy_process_group()
 
 
-@pytest.mark.timeout(120)
+@pytest.mark.timeout(180)
 def test_two_rank_gloo():
     world = 2
     mgr = mp.Manager()
@@ -50,3 +81,13 @@ def test_two_rank_gloo():
     assert a[1] == b[1] == 1.5 and a[2] == b[2] == 15.0, "gradient average wrong"
     assert a[3] == b[3] == 1.5, "max over ranks wrong"
     assert a[4] == b[4] == 5.0 and a[5] == [0, 2, 4] and b[5] == [1, 3]
+    assert a[6] == b[6] == (1.5, 1.5, True, 1.5, 2.0), (a[6], b[6])
+    assert a[7][0] == b[7][0], "DDP did not broadcast the parameters"
+    assert a[7][1] == b[7][1] == pytest.approx(4 * 1.5), (a[7], b[7])   # d(sum)/dW = sum of inputs, averaged
+
+
+def test_backend_choice():
+    from minkowskiengine_amd import distributed as D
+    assert D.pick_backend(8, n_gpus=8) == "nccl" and D.pick_backend(2, n_gpus=8) == "nccl"
+    assert D.pick_backend(2, n_gpus=1) == "gloo"      # ranks sharing a GPU: RCCL refuses, gloo stages through host
+    assert D.pick_backend(2, n_gpus=0) == "gloo"

@@ -1,15 +1,15 @@
 """GPU parity of the convolution feature kernels (forward, dgrad, wgrad; strided and transposed maps)
-against the oracle and against the fixtures produced by the reference itself.  Tolerance: 1e-4
-(abs + rel, as BASELINE.json's north_star states for fp32); typical error is ~1e-6."""
+against the oracle and against the fixtures produced by the reference itself.  Tolerance: PER ELEMENT
+|got - want| <= 1e-4 + 1e-4 |want| (BASELINE.json's north_star bar for fp32; helpers.assert_close); typical
+error is ~3e-7."""
 import numpy as np
 import pytest
 import torch
 
 from oracle import me_oracle as O
-from helpers import golden_cases, golden_kmap, make_cloud, rel_err, row_mapping
+from helpers import assert_close, golden_cases, golden_kmap, make_cloud, row_mapping
 
 pytestmark = pytest.mark.gpu
-TOL = 1e-4
 
 
 def _run_layer(device, coords, cin, cout, ks, stride=1, dil=1, seed=0, bias=False):
@@ -60,10 +60,10 @@ def test_conv_forward_backward_vs_oracle(device, n, extent, D, cin, cout, ks, st
     _, km = O.kernel_map(in_c, out_c, O.make_region(D, ks, dil, 1))
     w = conv.kernel.detach().cpu().numpy()
     ref = O.conv_forward(feats.numpy(), w, km, len(out_c))
-    assert rel_err(y.F.detach().cpu().numpy(), ref) < TOL
+    assert_close(y.F.detach().cpu().numpy(), ref)
     gi, gw = O.conv_backward(feats.numpy(), gy.numpy(), w, km)
-    assert rel_err(x.F.grad.cpu().numpy(), gi) < TOL
-    assert rel_err(conv.kernel.grad.cpu().numpy(), gw) < TOL
+    assert_close(x.F.grad.cpu().numpy(), gi)
+    assert_close(conv.kernel.grad.cpu().numpy(), gw)
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
@@ -110,10 +110,11 @@ def test_mfma_and_naive_kernels_agree(device):
     w = (torch.rand(27, 24, 40, generator=g) - 0.5).to(device)
     gy = torch.rand(3000, 40, generator=g).to(device)
     y1, y0 = MEB._conv_forward(x, w, km, "mfma"), MEB._conv_forward(x, w, km, "naive")
-    assert rel_err(y1.cpu().numpy(), y0.cpu().numpy()) < 1e-5
+    assert_close(y1, y0, 1e-5, 1e-5)
     a1, b1 = MEB._conv_backward(x, gy, w, km, "mfma")
     a0, b0 = MEB._conv_backward(x, gy, w, km, "naive")
-    assert rel_err(a1.cpu().numpy(), a0.cpu().numpy()) < 1e-5 and rel_err(b1.cpu().numpy(), b0.cpu().numpy()) < 1e-5
+    assert_close(a1, a0, 1e-5, 1e-5)
+    assert_close(b1, b0, 2e-5, 2e-5)
 
 
 def test_bitwise_reproducible(device):
@@ -122,6 +123,31 @@ def test_bitwise_reproducible(device):
     r2 = _run_layer(device, coords, 32, 64, 3)
     assert torch.equal(r1[2].F, r2[2].F) and torch.equal(r1[1].F.grad, r2[1].F.grad)
     assert torch.equal(r1[0].kernel.grad, r2[0].kernel.grad)
+
+
+def test_non_default_stream(device):
+    """Every launch goes to torch's CURRENT stream (DistributedDataParallel overlaps its collectives with the
+    backward pass on side streams; users wrap steps in torch.cuda.stream): coordinate insertion, kernel map, tile
+    plans, forward, dgrad, wgrad and pooling issued on a side stream — with the default stream kept busy by an
+    unrelated long kernel queue — give bit-identical results to the default-stream run."""
+    import minkowskiengine_amd as ME
+    coords = make_cloud(20000, 30, 3, seed=21)
+    ref = _run_layer(device, coords, 32, 64, 3)
+    side = torch.cuda.Stream(device)
+    busy = torch.rand(4096, 4096, device=device)
+    torch.cuda.synchronize()
+    for _ in range(20):                       # ~tens of ms of work queued on the DEFAULT stream
+        busy = (busy @ busy) * 2.4e-4      # stays O(1)
+    with torch.cuda.stream(side):
+        got = _run_layer(device, coords, 32, 64, 3)
+        pool = ME.MinkowskiMaxPooling(kernel_size=2, stride=2, dimension=3)(got[1])
+        pooled = pool.F.clone()
+    side.synchronize()                        # NOT a device-wide sync: only the side stream's work is awaited
+    assert torch.equal(got[2].F, ref[2].F) and torch.equal(got[1].F.grad, ref[1].F.grad)
+    assert torch.equal(got[0].kernel.grad, ref[0].kernel.grad)
+    torch.cuda.synchronize()
+    pool_ref = ME.MinkowskiMaxPooling(kernel_size=2, stride=2, dimension=3)(ref[1])
+    assert torch.equal(pooled, pool_ref.F)
 
 
 def test_bias_and_use_mm(device):
@@ -159,10 +185,10 @@ def test_against_reference_fixtures(device, path):
     d = mgr.kernel_map(key, y.coordinate_map_key, stride=st, kernel_size=ks, dilation=dl)
     O.assert_same_kernel_map({k: np.stack((v[0].cpu().numpy().astype(np.int64), m[v[1].cpu().numpy()]))
                               for k, v in d.items()}, golden_kmap(z))
-    assert rel_err(y.F.detach().cpu().numpy(), z["out"][m]) < TOL
+    assert_close(y.F.detach().cpu().numpy(), z["out"][m])
     y.F.backward(torch.from_numpy(z["grad_out"][m]).to(device))
-    assert rel_err(x.F.grad.cpu().numpy(), z["grad_in"]) < TOL
-    assert rel_err(conv.kernel.grad.cpu().numpy(), z["grad_kernel"]) < TOL
+    assert_close(x.F.grad.cpu().numpy(), z["grad_in"])
+    assert_close(conv.kernel.grad.cpu().numpy(), z["grad_kernel"])
     if "up" in z.files:
         convt = ME.MinkowskiConvolutionTranspose(cout, cin, kernel_size=ks, stride=st, dilation=dl, dimension=D)
         with torch.no_grad():
@@ -172,10 +198,10 @@ def test_against_reference_fixtures(device, path):
                               coordinate_manager=mgr, requires_grad=True)
         up = convt(xin)
         assert up.coordinate_map_key == key
-        assert rel_err(up.F.detach().cpu().numpy(), z["up"]) < TOL
+        assert_close(up.F.detach().cpu().numpy(), z["up"])
         up.F.backward(torch.from_numpy(z["up_grad_out"]).to(device))
-        assert rel_err(xin.F.grad.cpu().numpy(), z["up_grad_in"][m]) < TOL
-        assert rel_err(convt.kernel.grad.cpu().numpy(), z["up_grad_kernel"]) < TOL
+        assert_close(xin.F.grad.cpu().numpy(), z["up_grad_in"][m])
+        assert_close(convt.kernel.grad.cpu().numpy(), z["up_grad_kernel"])
 
 
 def test_config2_full_size(device):
@@ -186,10 +212,10 @@ def test_config2_full_size(device):
     _, km = O.kernel_map(coords.numpy(), coords.numpy(), O.make_region(3, 3))
     w = conv.kernel.detach().cpu().numpy()
     ref = O.conv_forward(feats.numpy(), w, km, 100000, dtype=np.float32)
-    assert rel_err(y.F.detach().cpu().numpy(), ref) < TOL
+    assert_close(y.F.detach().cpu().numpy(), ref)
     gi, gw = O.conv_backward(feats.numpy(), gy.numpy(), w, km, dtype=np.float32)
-    assert rel_err(x.F.grad.cpu().numpy(), gi) < TOL
-    assert rel_err(conv.kernel.grad.cpu().numpy(), gw) < TOL
+    assert_close(x.F.grad.cpu().numpy(), gi)
+    assert_close(conv.kernel.grad.cpu().numpy(), gw)
     # linearity: conv(2a - 3b) == 2 conv(a) - 3 conv(b)
     import minkowskiengine_amd as ME
     a, b = torch.rand_like(x.F.detach()), torch.rand_like(x.F.detach())
@@ -221,7 +247,7 @@ def test_config5_full_size(device):
     assert all(sizes.get(k, 0) == sizes.get(80 - k, 0) for k in range(81)) and sizes[40] == n
     w = conv.kernel.detach().cpu().numpy()
     ref = O.conv_forward(feats.numpy(), w, km, n, dtype=np.float32)
-    assert rel_err(y.F.detach().cpu().numpy(), ref) < TOL
+    assert_close(y.F.detach().cpu().numpy(), ref)
     gi, gw = O.conv_backward(feats.numpy(), gy.numpy(), w, km, dtype=np.float32)
-    assert rel_err(x.F.grad.cpu().numpy(), gi) < TOL
-    assert rel_err(conv.kernel.grad.cpu().numpy(), gw) < TOL
+    assert_close(x.F.grad.cpu().numpy(), gi)
+    assert_close(conv.kernel.grad.cpu().numpy(), gw)

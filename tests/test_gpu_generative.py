@@ -8,10 +8,9 @@ import pytest
 import torch
 
 from oracle import me_oracle as O
-from helpers import GOLDEN_DIR, make_cloud, rel_err, row_mapping
+from helpers import GOLDEN_DIR, assert_close, make_cloud, row_mapping
 
 pytestmark = pytest.mark.gpu
-TOL = 1e-4
 
 
 def _z():
@@ -33,10 +32,10 @@ def test_generative_transposed_convolution(device, name, ks, st):
     assert y.tensor_stride == z[f"{name}/out_tensor_stride"].tolist()
     assert y.coordinate_map_key != x.coordinate_map_key
     m = row_mapping(y.C.cpu().numpy(), z[f"{name}/out_coords"])
-    assert rel_err(y.F.detach().cpu().numpy(), z[f"{name}/out"][m]) < TOL
+    assert_close(y.F.detach().cpu().numpy(), z[f"{name}/out"][m])
     y.F.backward(torch.from_numpy(z[f"{name}/grad_out"][m]).to(device))
-    assert rel_err(feats.grad.cpu().numpy(), z[f"{name}/grad_in"]) < TOL
-    assert rel_err(conv.kernel.grad.cpu().numpy(), z[f"{name}/grad_kernel"]) < TOL
+    assert_close(feats.grad.cpu().numpy(), z[f"{name}/grad_in"])
+    assert_close(conv.kernel.grad.cpu().numpy(), z[f"{name}/grad_kernel"])
     # a second generative layer on the same input creates another map (random string id), never reuses
     y2 = conv(x)
     assert y2.coordinate_map_key != y.coordinate_map_key and y2.F.shape == y.F.shape
@@ -54,7 +53,7 @@ def test_transposed_convolution_creates_missing_map(device):
         up.kernel.copy_(torch.from_numpy(z["gen_k2s2/kernel"]).to(device))
     y = up(x)                                   # no stride-1 map yet: generated, same result as the generative layer
     m = row_mapping(y.C.cpu().numpy(), z["gen_k2s2/out_coords"])
-    assert rel_err(y.F.detach().cpu().numpy(), z["gen_k2s2/out"][m]) < TOL
+    assert_close(y.F.detach().cpu().numpy(), z["gen_k2s2/out"][m])
     y2 = up(x)                                  # now the stride-1 map exists: reused
     assert y2.coordinate_map_key == y.coordinate_map_key
 
@@ -69,7 +68,7 @@ def test_expanding_convolution(device):
     y = conv.to(device)(x)
     assert y.tensor_stride == [2, 2, 2]
     m = row_mapping(y.C.cpu().numpy(), z["expand/out_coords"])
-    assert rel_err(y.F.detach().cpu().numpy(), z["expand/out"][m]) < TOL
+    assert_close(y.F.detach().cpu().numpy(), z["expand/out"][m])
 
 
 def test_pruning(device):
@@ -91,7 +90,7 @@ def test_pruning(device):
     out = conv(y)
     _, km = O.kernel_map(y.C.cpu().numpy(), y.C.cpu().numpy(), O.make_region(3, 3))
     ref = O.conv_forward(y.F.detach().cpu().numpy(), conv.kernel.detach().cpu().numpy(), km, y.F.shape[0])
-    assert rel_err(out.F.detach().cpu().numpy(), ref) < TOL
+    assert_close(out.F.detach().cpu().numpy(), ref)
     # everything pruned: an empty tensor, not an error
     none = ME.MinkowskiPruning()(x, torch.zeros(x.F.shape[0], dtype=torch.bool, device=device))
     assert none.F.shape == (0, 5)
@@ -106,7 +105,7 @@ def test_union(device):
     b = ME.SparseTensor(fb, torch.from_numpy(z["union/b"]).to(device), coordinate_manager=a.coordinate_manager)
     u = ME.MinkowskiUnion()(a, b)
     m = row_mapping(u.C.cpu().numpy(), z["union/out_coords"])
-    assert rel_err(u.F.detach().cpu().numpy(), z["union/out"][m]) < 1e-6
+    assert_close(u.F.detach().cpu().numpy(), z["union/out"][m], 1e-6, 1e-6)
     g = torch.rand(u.F.shape, generator=torch.Generator().manual_seed(0)).to(device)
     u.F.backward(g)
     # every input row receives the gradient of its union row
