@@ -104,19 +104,25 @@ class MinkowskiSyncBatchNorm(MinkowskiBatchNorm):
 
     @classmethod
     def convert_sync_batchnorm(cls, module, process_group=None):
-        """MinkowskiNormalization.py:117-140"""
+        """MinkowskiNormalization.py:138-191.  Conscious divergence: the reference recurses into the children of a
+        MinkowskiBatchNorm it has just converted and its `add_module("bn", <the old nn.BatchNorm1d>)` puts the
+        UNSYNCHRONISED torch module back (MinkowskiNormalization.py:186-189), so its "sync" batch norm normalises with
+        per-rank statistics; here a converted module keeps its nn.SyncBatchNorm
+        (tests/test_gpu_distributed.py compares against one process on the batched scenes)."""
         out = module
-        if isinstance(module, MinkowskiBatchNorm) and not isinstance(module, MinkowskiSyncBatchNorm):
+        if isinstance(module, MinkowskiSyncBatchNorm):
+            return module
+        if isinstance(module, MinkowskiBatchNorm):
             out = cls(module.bn.num_features, module.bn.eps, module.bn.momentum, module.bn.affine,
                       module.bn.track_running_stats, process_group)
-            if module.bn.affine:
-                with torch.no_grad():
-                    out.bn.weight.copy_(module.bn.weight)
-                    out.bn.bias.copy_(module.bn.bias)
+            if module.bn.affine:          # the same Parameter objects, as the reference (:176-179)
+                out.bn.weight = module.bn.weight
+                out.bn.bias = module.bn.bias
             if module.bn.track_running_stats:
                 out.bn.running_mean = module.bn.running_mean
                 out.bn.running_var = module.bn.running_var
                 out.bn.num_batches_tracked = module.bn.num_batches_tracked
+            return out
         for name, child in module.named_children():
             out.add_module(name, cls.convert_sync_batchnorm(child, process_group))
         return out

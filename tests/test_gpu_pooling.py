@@ -162,9 +162,9 @@ def test_bf16_pooling_and_broadcast(device, c, ks, stride):
     b = coords[:, 0].numpy()
     want = np.stack([f32[b == i].astype(np.float64).mean(0) for i in range(2)])
     order = pooled.C[:, 0].cpu().numpy()
-    assert np.all(np.abs(pooled.F.float().cpu().numpy() - want[order]) <= 2.0 ** -7 * np.abs(want[order]) + 1e-4)
+    assert np.all(np.abs(pooled.F.detach().float().cpu().numpy() - want[order]) <= 2.0 ** -7 * np.abs(want[order]) + 1e-4)
     gmax = ME.MinkowskiGlobalMaxPooling()(x)
-    assert np.array_equal(gmax.F.float().cpu().numpy(), np.stack([f32[b == i].max(0) for i in order]))
+    assert np.array_equal(gmax.F.detach().float().cpu().numpy(), np.stack([f32[b == i].max(0) for i in order]))
     for mul, cls in ((False, ME.MinkowskiBroadcastAddition), (True, ME.MinkowskiBroadcastMultiplication)):
         glob = ME.SparseTensor(pooled.F.detach().clone().requires_grad_(True),
                                coordinate_map_key=pooled.coordinate_map_key, coordinate_manager=x.coordinate_manager)
