@@ -447,6 +447,259 @@ __global__ __launch_bounds__(NC * 4, ((NC >= 96 || KC == 96) ? 2 : 3)) void k_co
 }
 
 
+// =================================================================================================
+// target-stationary convolution, LDS-DMA variant (round 2): k_conv_tile_dma_f32
+// =================================================================================================
+// The same tile plan and the same arithmetic as k_conv_tile_f32 (single-offset batches of <= 4 groups of 16
+// (source row, target row) entries, W_k slice in registers, fp32 accumulator tile in LDS, wave-private columns,
+// fixed summation order), with the staging redesigned around what round 1 measured (an fp32 MFMA
+// owns its SIMD — every VALU / VMEM instruction of ANY resident wave is paid for in matrix time — and the
+// per-batch barrier pair + register staging + LDS round trips left the matrix pipe 50 % busy):
+//   * gathered rows go global -> LDS directly (global_load_lds_dwordx4, 1 KiB = 4 rows per wave instruction; the
+//     XOR swizzle of the stage image is applied to the per-lane SOURCE address, the LDS image of an instruction is
+//     lane-linear): no staging registers, no ds_write pass, no second barrier;
+//   * two stage buffers: the DMA of batch b+1 is issued right after the ONE barrier of batch b and lands while
+//     batch b is multiplied; the barrier's s_waitcnt vmcnt(0) is the only wait on vector memory in the loop;
+//   * the MFMA accumulators are INITIALISED from the LDS accumulator tile (old value as the C operand of the
+//     first MFMA) and written back after the last k-step: no zero-fill, no v_add_f32 — the sum of a target row is
+//     ((old + x_0 w_0) + x_1 w_1) + ... in plan order, still a fixed order (bitwise reproducible);
+//   * all operand reads of up to four groups are in flight before the first MFMA and the four accumulator chains
+//     are interleaved k-step-major (dependent MFMAs 128 cycles apart): one LDS latency per batch instead of two;
+//   * plan indices reach the lanes through ds_bpermute_b32 from ONE coalesced load per wave (no LDS index
+//     array), weights alternate between two register sets (no copy);
+//   * NC = 128: eight waves own ALL output columns of a 64 -> 128 layer, so every gathered row is fetched once
+//     instead of once per 64-column slab (half the gather instructions and half the L2-side traffic per MFMA).
+// Requirements (host-checked, else k_conv_tile_f32 runs): c_src a multiple of 64, c_dst a multiple of NC, source
+// matrix below 2^24 rows and 4 GiB.
+template <int R>
+__device__ __forceinline__ void mma_groups_dma(const float *__restrict__ a0p, const int (&pofs)[4],
+                                               const float (&w)[16], const int *d, float *__restrict__ accp) {
+  // Read order = use order (the LDS returns in order): accumulators and the operands of quad-steps 0 and 1 first
+  // (3 R reads before the first MFMA instead of 5 R), the operands of quad-steps 2 and 3 are requested from INSIDE
+  // the MFMA stream (LDS instructions co-issue with the matrix pipe).
+  f32x4 acc[R];
+  f32x4 a[4][R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) acc[r] = *reinterpret_cast<const f32x4 *>(accp + d[r]);
+#pragma unroll
+  for (int r = 0; r < R; ++r) a[0][r] = *reinterpret_cast<const f32x4 *>(a0p + r * 16 * 64 + pofs[0]);
+#pragma unroll
+  for (int r = 0; r < R; ++r) a[1][r] = *reinterpret_cast<const f32x4 *>(a0p + r * 16 * 64 + pofs[1]);
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4 acc2 = f32x4{0.f, 0.f, 0.f, 0.f};   // R == 1 only: second chain (odd k-steps)
+  auto block = [&](int s4) {
+    if constexpr (R == 1) {
+      // one group: two interleaved chains instead of sixteen back-to-back dependent MFMAs (40-cycle latency)
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s4 * 4 + 0], a[s4][0][0], acc[0], 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s4 * 4 + 1], a[s4][0][1], acc2, 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s4 * 4 + 2], a[s4][0][2], acc[0], 0, 0, 0);
+      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s4 * 4 + 3], a[s4][0][3], acc2, 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s4 * 4 + j], a[s4][r][j], acc[r], 0, 0, 0);
+      }
+    }
+  };
+  block(0);
+  // (hipcc waits lgkmcnt(0) behind a sched_barrier: the reads of quad-steps 2 AND 3 are issued here, a whole block
+  // of MFMAs before their first use, so that wait never stalls)
+#pragma unroll
+  for (int r = 0; r < R; ++r) a[2][r] = *reinterpret_cast<const f32x4 *>(a0p + r * 16 * 64 + pofs[2]);
+#pragma unroll
+  for (int r = 0; r < R; ++r) a[3][r] = *reinterpret_cast<const f32x4 *>(a0p + r * 16 * 64 + pofs[3]);
+  __builtin_amdgcn_sched_barrier(0);
+  block(1);
+  __builtin_amdgcn_sched_barrier(0);
+  block(2);
+  block(3);
+  if constexpr (R == 1) acc[0] += acc2;
+#pragma unroll
+  for (int r = 0; r < R; ++r) *reinterpret_cast<f32x4 *>(accp + d[r]) = acc[r];
+}
+
+__host__ __device__ constexpr int conv_dma_lds_bytes(int nc, int tile_rows, int batch_groups) {
+  return (tile_rows + 1) * (nc + kAccPad) * 4 + 2 * batch_groups * 16 * 64 * 4;
+}
+
+template <int NC, int VAR>
+__global__ __launch_bounds__(NC * 4, 2) void k_conv_tile_dma_f32(
+    const float *__restrict__ src, int c_src, const f32x4 *__restrict__ wp, int c_dst,
+    const int32_t *__restrict__ plan_src, const int32_t *__restrict__ plan_dst,
+    const int32_t *__restrict__ batch_desc, const int32_t *__restrict__ tile_bptr,
+    const int32_t *__restrict__ order, float *__restrict__ dst, int64_t n_tgt, int tile_rows, int batch_groups) {
+  typedef int i32x2 __attribute__((ext_vector_type(2)));
+  constexpr int WAVES = NC / 16;
+  constexpr int NT = WAVES * 64;
+  constexpr int ACC_LD = NC + kAccPad;
+  constexpr int GSTEP = WAVES / 4;        // groups covered by one "DMA slot" of the workgroup (1 or 2)
+  constexpr int JMAX = 4 / GSTEP;         // DMA instructions per wave and batch (4 or 2)
+  static_assert(NC == 64 || NC == 128, "column slabs of 64 or 128");
+  static_assert(ME_MAX_BATCH_GROUPS == 4, "batches hold at most 4 groups");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *s_acc = reinterpret_cast<float *>(smem);              // [(tile_rows + 1) x ACC_LD]
+  float *s_st = s_acc + (tile_rows + 1) * ACC_LD;              // [2][batch_groups * 16 x 64], swizzled rows
+  const int st_floats = batch_groups * 16 * 64;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, q = lane >> 4;
+  const int tile = blockIdx.x;
+  const int nchunks = c_src >> 6;
+  const int ncb = c_dst >> 4;
+  const int cb = blockIdx.y * WAVES + wave;                    // this wave's 16-column block (c_dst % NC == 0)
+  int pofs[4];
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) pofs[s4] = ((4 * s4 + q) ^ i16) * 4;
+
+  for (int x = tid; x < (tile_rows + 1) * ACC_LD / 4; x += NT)
+    reinterpret_cast<f32x4 *>(s_acc)[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int b0 = tile_bptr[tile];
+  const int nb = tile_bptr[tile + 1] - b0;
+  const int n_it = nb * nchunks;  // iterations: chunk-major, then the batches of the tile
+  auto locate = [&](int it, int &chunk, int &g0, int &ng, int &k) {
+    int r = min(it, n_it - 1);
+    chunk = 0;
+    while (r >= nb) {
+      r -= nb;
+      ++chunk;
+    }
+    const i32x2 dsc = *reinterpret_cast<const i32x2 *>(batch_desc + 2 * (int64_t)(b0 + r));
+    g0 = dsc.x;
+    ng = dsc.y & 255;
+    k = (int)((uint32_t)dsc.y >> 8);
+  };
+
+  // DMA geometry of this wave: slot j covers the 4 rows (wave & 3) * 4 .. + 3 of group j * GSTEP + (wave >> 2);
+  // lane l moves piece (l & 15) ^ swz(row) of row (l >> 4) — the LDS image is lane-linear, the swizzle is on the
+  // source address (row & 15 = (wave & 3) * 4 + (l >> 4) in every group)
+  const int rb = (wave & 3) * 4;
+  const int gsel = wave >> 2;
+  const unsigned piece_off = (unsigned)((lane & 15) ^ (rb + (lane >> 4))) * 16u;
+  const char *srcb = reinterpret_cast<const char *>(src);
+  const unsigned row_bytes = (unsigned)c_src * 4u;
+  const int sel_src = (rb + (lane >> 4)) * 4;   // ds_bpermute byte selector of this lane's row inside a group
+  // plan indices of this lane's rows in the JMAX DMA slots (ds_bpermute from the wave's 64-entry window)
+  auto dma_rows = [&](int sv, int (&idx)[JMAX]) {
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) idx[j] = __builtin_amdgcn_ds_bpermute(sel_src + (j * GSTEP + gsel) * 64, sv);
+  };
+  auto dma = [&](const int (&idx)[JMAX], int chunk, int ng, float *st) {
+    const unsigned cofs = piece_off + (unsigned)chunk * 256u;
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) {
+      const int g = j * GSTEP + gsel;
+      if (g < ng) {                                             // wave-uniform
+        const unsigned off = __umul24((unsigned)max(idx[j], 0), row_bytes) + cofs;
+        if (!(VAR & 16))
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcb + off),
+                                           (__attribute__((address_space(3))) void *)(st + (g * 16 + rb) * 64), 16, 0,
+                                           0);
+      }
+    }
+  };
+  auto load_w = [&](float (&w)[16], int chunk, int k) {
+    const f32x4 *p = wp + ((((int64_t)k * nchunks + chunk) * ncb + cb) * 4) * 64 + lane;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const f32x4 t = p[v * 64];
+      w[v * 4 + 0] = t.x;
+      w[v * 4 + 1] = t.y;
+      w[v * 4 + 2] = t.z;
+      w[v * 4 + 3] = t.w;
+    }
+  };
+  // (the 64-entry index window of a batch is read to its end unconditionally: the plan is followed by 64 valid
+  // entries, k_plan_fill)
+  auto load_idx = [&](const int32_t *plan, int g0) {
+    return *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(plan + (int64_t)g0 * 16) +
+                                              (unsigned)(lane * 4));
+  };
+
+  float wA[16], wB[16];
+  if (n_it > 0) {
+    int chA, gA, nA, kA, chB, gB, nB, kB, chC, gC, nC, kC;
+    locate(0, chA, gA, nA, kA);
+    locate(1, chB, gB, nB, kB);
+    locate(2, chC, gC, nC, kC);
+    int svB, dvA, dvB;
+    {
+      const int svA = load_idx(plan_src, gA);
+      dvA = load_idx(plan_dst, gA);
+      svB = load_idx(plan_src, gB);
+      dvB = load_idx(plan_dst, gB);
+      int idxA[JMAX];
+      dma_rows(svA, idxA);
+      __syncthreads();                       // accumulator tile cleared (the DMA does not touch it; ordering only)
+      dma(idxA, chA, nA, s_st);
+      load_w(wA, chA, kA);
+    }
+    float *accp = &s_acc[wave * 16 + q * 4];
+
+    auto iteration = [&](int it, float (&wc)[16], float (&wn)[16]) {
+      // plan indices of the NEXT batch's rows and the accumulator rows of THIS batch's entries reach the lanes by
+      // ds_bpermute before the barrier (their loads were issued an iteration ago; the crossbar latency overlaps the
+      // wait for the other waves); padding slots -> the dummy accumulator row `tile_rows`
+      int idxB[JMAX];
+      dma_rows(svB, idxB);
+      int d[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        d[r] = (int)__umul24((unsigned)__builtin_amdgcn_ds_bpermute((r * 16 + i16) * 4, dvA), (unsigned)ACC_LD);
+      // batch `it` has landed in stage[it & 1] (this wave's DMA: vmcnt(0); everybody's: the barrier), and every
+      // wave is done reading stage[(it + 1) & 1] (batch it - 1)
+      __syncthreads();
+      float *st_cur = s_st + (it & 1) * st_floats;
+      float *st_nxt = s_st + ((it + 1) & 1) * st_floats;
+      int svC = svB, dvC = dvB;
+      if (it + 1 < n_it) {                   // wave-uniform
+        dma(idxB, chB, nB, st_nxt);
+        load_w(wn, chB, kB);
+        svC = load_idx(plan_src, gC);
+        dvC = load_idx(plan_dst, gC);
+      }
+      const float *a0p = st_cur + i16 * 64;
+      if (nA == 4) mma_groups_dma<4>(a0p, pofs, wc, d, accp);
+      else if (nA == 3) mma_groups_dma<3>(a0p, pofs, wc, d, accp);
+      else if (nA == 2) mma_groups_dma<2>(a0p, pofs, wc, d, accp);
+      else mma_groups_dma<1>(a0p, pofs, wc, d, accp);
+      chA = chB; gA = gB; nA = nB; kA = kB;
+      chB = chC; gB = gC; nB = nC; kB = kC;
+      dvA = dvB;
+      svB = svC;
+      dvB = dvC;
+      locate(it + 3, chC, gC, nC, kC);
+    };
+    int it = 0;
+    for (; it + 1 < n_it; it += 2) {
+      iteration(it, wA, wB);
+      iteration(it + 1, wB, wA);
+    }
+    if (it < n_it) iteration(it, wA, wB);
+  }
+  __syncthreads();
+
+  // every target row of the tile is written exactly once; local row r is target row order[row0 + r]
+  const int64_t row0 = (int64_t)tile * tile_rows;
+  const int rows_here = (int)min((int64_t)tile_rows, n_tgt - row0);
+  const int col_base = blockIdx.y * NC;
+  for (int x = tid; x < tile_rows * NC / 4; x += NT) {
+    const int row = x / (NC / 4);
+    const int c4 = x % (NC / 4);
+    if (row < rows_here) {
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(&s_acc[row * ACC_LD + c4 * 4]);
+      const int64_t grow = order ? (int64_t)order[row0 + row] : row0 + row;
+      *reinterpret_cast<f32x4 *>(dst + grow * c_dst + col_base + c4 * 4) = v;
+    }
+  }
+}
+
+
 __global__ __launch_bounds__(256) void k_transpose_kernel(const float *__restrict__ w, int64_t volume,
                                                          int c_in, int c_out,
                                                          float *__restrict__ wt) {
@@ -1319,7 +1572,7 @@ static int launch_conv_tile(const float *src, int c_src, const float *wp, int c_
                             int tile_rows, int batch_groups, hipStream_t stream, bool small = false) {
   // variants 2048 + n (experiment): n KiB of unused LDS, to cap the resident workgroups per CU
   const int lds = conv_lds_bytes(NC, KC, tile_rows, batch_groups) +
-                  (g_conv_variant >= 2048 ? (g_conv_variant - 2048) * 1024 : 0);
+                  (g_conv_variant >= 2048 && g_conv_variant < 3000 ? (g_conv_variant - 2048) * 1024 : 0);
   ME_CHECK(lds <= kLdsBudget, "tile_rows / batch_groups too large for the LDS of one workgroup");
   const bool exact = (c_src % KC) == 0;
   // the timing ablations (VAR != 0) exist with 64-bit addresses only
@@ -1343,6 +1596,38 @@ static int launch_conv_tile(const float *src, int c_src, const float *wp, int c_
                      plan_src, plan_dst, batch_desc, tile_bptr, order, dst, n_tgt, tile_rows, batch_groups);
   ME_LAUNCH_CHECK();
   return 0;
+}
+
+template <int NC>
+static int launch_conv_tile_dma(const float *src, int c_src, const float *wp, int c_dst, const int32_t *plan_src,
+                                const int32_t *plan_dst, const int32_t *batch_desc, const int32_t *tile_bptr,
+                                const int32_t *order, float *dst, int64_t n_tgt, int tile_rows, int batch_groups,
+                                hipStream_t stream) {
+  const int lds = conv_dma_lds_bytes(NC, tile_rows, batch_groups);
+  ME_CHECK(lds <= kLdsBudget, "tile_rows / batch_groups too large for the LDS of one workgroup (LDS-DMA kernel)");
+  typedef void (*kernel_t)(const float *, int, const f32x4 *, int, const int32_t *, const int32_t *, const int32_t *,
+                           const int32_t *, const int32_t *, float *, int64_t, int, int);
+  const kernel_t fn = g_conv_variant == 3016 ? &k_conv_tile_dma_f32<NC, 16> : &k_conv_tile_dma_f32<NC, 0>;
+  static bool attr_set[2] = {false, false};
+  const int which = g_conv_variant == 3016 ? 1 : 0;
+  if (!attr_set[which]) {
+    ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               kLdsBudget));
+    attr_set[which] = true;
+  }
+  const dim3 grid((unsigned)ceil_div(n_tgt, tile_rows), (unsigned)(c_dst / NC));
+  hipLaunchKernelGGL(fn, grid, dim3(NC * 4), (size_t)lds, stream, src, c_src, reinterpret_cast<const f32x4 *>(wp), c_dst,
+                     plan_src, plan_dst, batch_desc, tile_bptr, order, dst, n_tgt, tile_rows, batch_groups);
+  ME_LAUNCH_CHECK();
+  return 0;
+}
+
+// which LDS-DMA instantiation (columns per workgroup) takes a (c_src, c_dst) problem; 0 = none
+static int conv_dma_columns(int c_src, int c_dst) {
+  if (g_conv_variant < 3000 || g_conv_variant >= 3100) return 0;     // (experiment switch; see me_conv_target_f32)
+  if (c_src % 64 != 0 || c_dst % 64 != 0) return 0;
+  if (g_conv_variant == 3064) return 64;
+  return c_dst % 128 == 0 ? 128 : 64;
 }
 
 int g_wgrad_depth = 0;         // me_debug_set_wgrad_config: 0 = default
@@ -1559,7 +1844,17 @@ int me_conv_target_f32(const float *src, int64_t n_src, int32_t c_src, const flo
       batch_groups, stream
   // 32-bit byte offsets with a 24-bit row multiply need a source matrix below 4 GiB (variant 6: 64-bit addresses)
   const bool small = n_src > 0 && n_src < (1ll << 24) && n_src * c_src * 4 < (1ll << 32) && g_conv_variant != 6;
-  if (g_conv_variant >= 2048 && v.nc == 64 && v.kc == 64) return launch_conv_tile<64, 64, 0>(ME_CONV_ARGS, small);
+  if (small) {
+    const int dma_nc = conv_dma_columns(c_src, c_dst);
+    if (dma_nc == 128)
+      return launch_conv_tile_dma<128>(src, c_src, wp, c_dst, plan_src, plan_dst, batch_desc, tile_bptr, order, dst, n_tgt,
+                                       tile_rows, batch_groups, stream);
+    if (dma_nc == 64)
+      return launch_conv_tile_dma<64>(src, c_src, wp, c_dst, plan_src, plan_dst, batch_desc, tile_bptr, order, dst, n_tgt,
+                                      tile_rows, batch_groups, stream);
+  }
+  if (g_conv_variant >= 2048 && g_conv_variant < 3000 && v.nc == 64 && v.kc == 64)
+    return launch_conv_tile<64, 64, 0>(ME_CONV_ARGS, small);
   if (g_conv_variant == 1000 && v.kc == 64 && c_dst >= 128 && c_dst % 128 == 0)  // experiment: 128-column workgroups
     return launch_conv_tile<128, 64, 0>(src, c_src, wp, c_dst, c_dst / 128, plan_src, plan_dst, batch_desc, tile_bptr,
                                         order, dst, n_tgt, tile_rows, batch_groups, stream);
