@@ -123,6 +123,70 @@ int me_kernel_map_transpose(const int32_t *in_pairs_dev, const int32_t *out_pair
                             const int64_t *k_offsets_dev, int64_t volume, int64_t n_pairs,
                             int64_t n_in, int32_t *nbrT_dev, void *stream);
 
+/* ---- spatial index + LDS-bucketed kernel map (round 2) ---------------------------------------------------------
+ * The north_star's "LDS-bucketed open-address hashing with coalesced HBM reads": the bucket of a kernel-map probe
+ * is SPATIAL.  A map's rows are ordered by the supercell that contains them (<= 4096 cells: 16^3 for D = 3); a
+ * workgroup owns one supercell of the query map, stages the rows of the 3^D neighbouring supercells of the lookup
+ * map (contiguous ranges of its sorted coordinate array: coalesced reads, the only HBM reads of the build) into a
+ * dense halo grid in LDS and answers all rows x volume probes from LDS; the neighbour table is written in POSITION
+ * space (position = rank in supercell order; `order` maps positions back to rows), where a supercell is one
+ * contiguous, coalesced range.  Replaces CoordinateMapGPU::kernel_map (src/coordinate_map_gpu.cu:1546-1745), whose
+ * probes each walk the global table (src/3rdparty/concurrent_unordered_map.cuh:304-360). */
+typedef struct me_spatial_grid {
+  int32_t ncol;                        /* D + 1 */
+  int32_t shift[ME_MAX_DIM];           /* log2 of the supercell side (cells of one tensor stride) per axis */
+  int32_t sc_min[ME_MAX_DIM + 1];      /* [0] smallest batch index, [1 + d] smallest supercell coordinate of axis d */
+  int32_t sc_dim[ME_MAX_DIM + 1];      /* extents of the dense supercell directory: batch indices, supercells per axis */
+  int32_t tensor_stride[ME_MAX_DIM];   /* cell size */
+} me_spatial_grid;
+
+/* me_coords_insert_and_map that also returns the bounding box of the coordinates (host int32 [2 * ncol]: the minima
+ * of the ncol columns, then the maxima) on the SAME read-back: it sizes the supercell directory without a
+ * synchronisation of its own. */
+int me_coords_insert_and_map_bbox(const int32_t *coords_dev, int64_t n, int32_t ncol, uint64_t *table_dev,
+                                  int64_t capacity, int32_t *coords_unique_dev, int64_t *unique_map_dev,
+                                  int64_t *inverse_map_dev, int64_t *n_unique, int32_t *bbox /* host, may be NULL */,
+                                  void *workspace_dev, int64_t workspace_bytes, void *stream);
+
+/* number of supercells m of the directory (product of sc_dim), -1 if invalid / too large */
+int64_t me_spatial_cells(const me_spatial_grid *grid);
+int64_t me_spatial_index_workspace_bytes(int64_t n, int64_t m);
+/* order [n] (position -> row), pos_of_row [n], coords_sorted [n, ncol] (rows in position order), dir_start uint32
+ * [m + 1] (first position of every supercell).  One key pass, ceil(log2 m / 8) stable radix passes: no host sync. */
+int me_spatial_index_build(const int32_t *coords_dev, int64_t n, const me_spatial_grid *grid, int32_t *order_dev,
+                           int32_t *pos_of_row_dev, int32_t *coords_sorted_dev, uint32_t *dir_start_dev,
+                           void *workspace_dev, int64_t workspace_bytes, void *stream);
+
+/* LDS bytes of the probe for this region and map pair, or -1 when it is not eligible (maps of different tensor
+ * stride or supercell side, offsets reaching beyond one supercell, halo grid larger than the LDS): the caller then
+ * uses me_kernel_map_probe. */
+int64_t me_kernel_map_probe_lds_bytes(const me_region *region, const me_spatial_grid *query_grid,
+                                      const me_spatial_grid *lookup_grid);
+/* nbr_pos int32 [volume, n_q] (out): ROW of the lookup map paired with (offset k, query POSITION p), or -1.
+ * k_offsets_dev int64 [volume + 1] (out, device; may be NULL): exclusive prefix of the per-offset pair counts — the
+ * counts are taken inside the probe (wave ballots) and scanned into the workspace (me_kernel_map_workspace_bytes),
+ * which then feeds me_kernel_map_compact_ordered.  NO host synchronisation: copy k_offsets_dev asynchronously and
+ * read it when a host value is first needed. */
+int me_kernel_map_probe_lds(const me_spatial_grid *query_grid, const int32_t *q_coords_sorted_dev,
+                            const uint32_t *q_dir_start_dev, int64_t n_q, const me_spatial_grid *lookup_grid,
+                            const int32_t *l_coords_sorted_dev, const int32_t *l_order_dev,
+                            const uint32_t *l_dir_start_dev, const me_region *region, int32_t *nbr_pos_dev,
+                            int64_t *k_offsets_dev, void *workspace_dev, int64_t workspace_bytes, void *stream);
+/* Per-offset pair counts of an existing neighbour table (+ their prefix in the workspace for the compaction):
+ * k_offsets_dev int64 [volume + 1] on the device; k_offsets (host, may be NULL: then NO synchronisation — copy
+ * k_offsets_dev asynchronously and read it when first needed). */
+int me_kernel_map_count(const int32_t *nbr_dev, int64_t n_out, int64_t volume, int64_t *k_offsets /* host or NULL */,
+                        int64_t *k_offsets_dev, void *workspace_dev, int64_t workspace_bytes, void *stream);
+/* me_kernel_map_compact for a position-space table: the target row of position p is order[p] (NULL: p itself). */
+int me_kernel_map_compact_ordered(const int32_t *nbr_dev, const int32_t *order_dev, int64_t n_out, int64_t volume,
+                                  int32_t *in_pairs_dev, int32_t *out_pairs_dev, void *workspace_dev,
+                                  int64_t workspace_bytes, void *stream);
+/* me_kernel_map_transpose into the POSITION space of the in map: nbrT[k, pos_in[in row]] = out row (pos_in NULL: the
+ * row itself).  n_pairs_bound: any upper bound of the pair count (launch geometry only). */
+int me_kernel_map_transpose_ordered(const int32_t *in_pairs_dev, const int32_t *out_pairs_dev,
+                                    const int64_t *k_offsets_dev, int64_t volume, int64_t n_pairs_bound, int64_t n_in,
+                                    const int32_t *pos_in_dev, int32_t *nbrT_dev, void *stream);
+
 /* ---- tile plan for the target-stationary convolution ----------------------------------------- */
 /* A plan cuts the target rows into tiles of `tile_rows` consecutive rows (any value in
  * [ME_GROUP_ROWS, ME_MAX_TILE_ROWS]; me_conv_plan_config picks it so that tiles x column slabs
@@ -150,7 +214,9 @@ int64_t me_plan_workspace_bytes(int64_t n_tgt, int64_t volume, int32_t tile_rows
  *                                                the dummy row `tile_rows`; the global target row of
  *                                                (tile t, local row d) is order[t * tile_rows + d]
  *   batch_desc_dev int32 [2 * max_groups]  (out) per batch {first group, (k << 8) | number of groups}
- *   tile_bptr_dev  int32 [num_tiles + 1]   (out) batch range of each tile
+ *   tile_bptr_dev  int32 [2 * num_tiles + 1] (out) [0, num_tiles]: batch range of each tile; behind it the DISPATCH
+ *                  ORDER of the tiles (a permutation, heaviest tile first): workgroup b of the convolution kernels
+ *                  takes tile tile_bptr[num_tiles + 1 + b]
  *   item_gptr_dev  int32 [num_tiles * volume + 1] (out) first group of each (tile, k) item
  */
 int me_plan_build(const int32_t *tbl_dev, const int32_t *order_dev, int64_t n_tgt, int64_t volume,

@@ -30,6 +30,18 @@ class MeRegion(ctypes.Structure):
     ]
 
 
+class MeSpatialGrid(ctypes.Structure):
+    """struct me_spatial_grid (include/me_amd.h)."""
+    _fields_ = [
+        ("ncol", c_i32),
+        ("shift", c_i32 * ME_MAX_DIM),
+        ("sc_min", c_i32 * (ME_MAX_DIM + 1)),
+        ("sc_dim", c_i32 * (ME_MAX_DIM + 1)),
+        ("tensor_stride", c_i32 * ME_MAX_DIM),
+    ]
+
+
+_P_GRID = ctypes.POINTER(MeSpatialGrid)
 _P_REGION = ctypes.POINTER(MeRegion)
 _P_I64 = ctypes.POINTER(c_i64)
 _P_I32 = ctypes.POINTER(c_i32)
@@ -43,6 +55,17 @@ SIGNATURES = {
     "me_insert_workspace_bytes": (c_i64, [c_i64]),
     "me_coords_insert_and_map": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp, c_vp, _P_I64,
                                                 c_vp, c_i64, c_vp]),
+    "me_coords_insert_and_map_bbox": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i64, c_vp, c_vp, c_vp, _P_I64, _P_I32,
+                                                     c_vp, c_i64, c_vp]),
+    "me_spatial_cells": (c_i64, [_P_GRID]),
+    "me_spatial_index_workspace_bytes": (c_i64, [c_i64, c_i64]),
+    "me_spatial_index_build": (ctypes.c_int, [c_vp, c_i64, _P_GRID, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "me_kernel_map_probe_lds_bytes": (c_i64, [_P_REGION, _P_GRID, _P_GRID]),
+    "me_kernel_map_probe_lds": (ctypes.c_int, [_P_GRID, c_vp, c_vp, c_i64, _P_GRID, c_vp, c_vp, c_vp, _P_REGION, c_vp,
+                                               c_vp, c_vp, c_i64, c_vp]),
+    "me_kernel_map_count": (ctypes.c_int, [c_vp, c_i64, c_i64, _P_I64, c_vp, c_vp, c_i64, c_vp]),
+    "me_kernel_map_compact_ordered": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "me_kernel_map_transpose_ordered": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp]),
     "me_coords_stride": (ctypes.c_int, [c_vp, c_i64, c_i32, _P_I32, c_vp, c_vp]),
     "me_coords_spatial_keys": (ctypes.c_int, [c_vp, c_i64, c_i32, _P_I32, c_vp, c_vp]),
     "me_coords_find": (ctypes.c_int, [c_vp, c_i64, c_vp, c_i32, c_vp, c_i64, c_vp, c_vp]),
@@ -122,6 +145,8 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported
         fn.restype = restype
         fn.argtypes = argtypes
+    if os.environ.get("ME_AMD_CONV_VARIANT"):      # kernel-selection experiments (scripts/)
+        lib.me_debug_set_conv_variant(int(os.environ["ME_AMD_CONV_VARIANT"]))
     _lib = lib
     return lib
 

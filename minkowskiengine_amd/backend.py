@@ -206,16 +206,79 @@ def _workspace(nbytes, device):
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
+_SUPERCELL_SHIFT = {1: 12, 2: 6, 3: 4, 4: 3, 5: 2, 6: 2, 7: 1}   # log2 side: <= 4096 cells per supercell
+_MIN_SUPERCELL_SHIFT = {1: 6, 2: 4, 3: 3, 4: 2, 5: 1, 6: 1, 7: 1}
+_MIN_SUPERCELLS = 1024      # aim for at least this many supercells (workgroups of the probe kernel)
+_MAX_SUPERCELLS = 1 << 22   # beyond this the dense supercell directory is not built (flat-table probes instead)
+
+
+class _SpatialIndex:
+    """Rows of a coordinate map in supercell order (csrc/coords.hip, me_spatial_index_build): `order` int32 [n]
+    position -> row, `pos_of_row` its inverse, `coords_sorted` the coordinates in position order, `dir_start` uint32
+    [m + 1] the first position of every supercell of the dense directory described by `grid`."""
+    __slots__ = ("grid", "m", "order", "pos_of_row", "coords_sorted", "dir_start")
+
+
 class _CoordinateMapGPU:
     """One coordinate map resident in HBM: unique int32 coordinates [n, D+1] in row order and the
     open-addressing table {hash tag | row} (replaces CoordinateMapGPU,
-    src/coordinate_map_gpu.cuh:47-223)."""
+    src/coordinate_map_gpu.cuh:47-223); `bbox` (host ints: column minima, then maxima) came back with the
+    insert's own read-back and sizes the spatial index, which is built on first use."""
 
-    __slots__ = ("coords", "table", "capacity", "tensor_stride", "n")
+    __slots__ = ("coords", "table", "capacity", "tensor_stride", "n", "bbox", "_spatial")
 
-    def __init__(self, coords, table, capacity, tensor_stride, n):
+    def __init__(self, coords, table, capacity, tensor_stride, n, bbox=None):
         self.coords, self.table, self.capacity = coords, table, capacity
         self.tensor_stride, self.n = tuple(tensor_stride), int(n)
+        self.bbox = bbox
+        self._spatial = False    # False: not tried yet; None: not available
+
+    def spatial(self):
+        """-> _SpatialIndex or None (empty map, no bounding box, or a bounding box of too many supercells)."""
+        if self._spatial is not False:
+            return self._spatial
+        self._spatial = None
+        ncol = int(self.coords.shape[1])
+        D = ncol - 1
+        if self.n == 0 or self.bbox is None or D not in _SUPERCELL_SHIFT or any(t <= 0 for t in self.tensor_stride):
+            return None
+        lib = _lib.load()
+        g = _lib.MeSpatialGrid()
+        g.ncol = ncol
+        g.sc_min[0] = int(self.bbox[0])
+        g.sc_dim[0] = int(self.bbox[ncol]) - int(self.bbox[0]) + 1
+        # supercell side: the largest (<= 4096 cells) that still gives the probe kernel a few workgroups per CU — a
+        # 70^3 scene in 16^3 supercells is only 125 workgroups for 256 CUs
+        sh = _SUPERCELL_SHIFT[D]
+        while True:
+            m = g.sc_dim[0]
+            for d in range(D):
+                ts = int(self.tensor_stride[d])
+                lo = (int(self.bbox[1 + d]) // ts) >> sh          # python floor division / arithmetic shift
+                hi = (int(self.bbox[ncol + 1 + d]) // ts) >> sh
+                g.shift[d], g.tensor_stride[d] = sh, ts
+                g.sc_min[1 + d], g.sc_dim[1 + d] = lo, hi - lo + 1
+                m *= hi - lo + 1
+            if m >= _MIN_SUPERCELLS or sh <= _MIN_SUPERCELL_SHIFT.get(D, 1):
+                break
+            sh -= 1
+        m = int(lib.me_spatial_cells(ctypes.byref(g)))
+        if m < 1 or m > _MAX_SUPERCELLS:
+            return None
+        dev = self.coords.device
+        sp = _SpatialIndex()
+        sp.grid, sp.m = g, m
+        sp.order = torch.empty(self.n, dtype=torch.int32, device=dev)
+        sp.pos_of_row = torch.empty(self.n, dtype=torch.int32, device=dev)
+        sp.coords_sorted = torch.empty((self.n, ncol), dtype=torch.int32, device=dev)
+        sp.dir_start = torch.empty(m + 1, dtype=torch.int32, device=dev)
+        ws = _workspace(lib.me_spatial_index_workspace_bytes(self.n, m), dev)
+        with _on(dev):
+            _lib.check(lib.me_spatial_index_build(_ptr(self.coords), self.n, ctypes.byref(g), _ptr(sp.order),
+                                                  _ptr(sp.pos_of_row), _ptr(sp.coords_sorted), _ptr(sp.dir_start),
+                                                  _ptr(ws), ws.numel(), _stream(dev)))
+        self._spatial = sp
+        return sp
 
 
 def _insert(coords, tensor_stride):
@@ -231,13 +294,35 @@ def _insert(coords, tensor_stride):
     wsb = int(lib.me_insert_workspace_bytes(n))
     ws = _workspace(wsb, dev)
     n_unique = ctypes.c_int64(0)
+    bbox = (ctypes.c_int32 * (2 * ncol))()
     with _on(dev):
-        _lib.check(lib.me_coords_insert_and_map(_ptr(coords), n, ncol, _ptr(table), cap, _ptr(coords_unique),
-                                                _ptr(unique_map), _ptr(inverse_map), ctypes.byref(n_unique),
-                                                _ptr(ws), ws.numel(), _stream(dev)))
+        _lib.check(lib.me_coords_insert_and_map_bbox(_ptr(coords), n, ncol, _ptr(table), cap, _ptr(coords_unique),
+                                                     _ptr(unique_map), _ptr(inverse_map), ctypes.byref(n_unique),
+                                                     bbox, _ptr(ws), ws.numel(), _stream(dev)))
     nu = int(n_unique.value)
-    cmap = _CoordinateMapGPU(coords_unique[:nu], table, cap, tensor_stride, nu)
+    cmap = _CoordinateMapGPU(coords_unique[:nu], table, cap, tensor_stride, nu, bbox=list(bbox) if n > 0 else None)
     return cmap, unique_map[:nu], inverse_map[:n]
+
+
+class _LazyOffsets:
+    """The per-offset pair prefix of a kernel map, read back from the device WITHOUT stalling the build: the copy into
+    pinned host memory is enqueued right behind the counting kernels, the host waits for it only when a host value
+    is first needed (launch geometry of the weight gradient, plan sizes, the dict view)."""
+    __slots__ = ("pinned", "event", "values")
+
+    def __init__(self, k_offsets_dev):
+        self.pinned = torch.empty(k_offsets_dev.numel(), dtype=torch.int64, pin_memory=True)
+        self.pinned.copy_(k_offsets_dev, non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record(torch.cuda.current_stream(k_offsets_dev.device))
+        self.values = None
+
+    def get(self):
+        if self.values is None:
+            self.event.synchronize()
+            self.values = self.pinned.tolist()
+            self.pinned = self.event = None
+        return self.values
 
 
 class KernelMapGPU:
@@ -245,8 +330,11 @@ class KernelMapGPU:
 
     * ``in_pairs`` / ``out_pairs`` + ``k_offsets``: the reference's per-offset (in row, out row)
       lists, concatenated; offset k owns [k_offsets[k], k_offsets[k+1]).
-    * ``table('out')`` = nbr[k, out row] -> in row or -1, ``table('in')`` its transpose; the tile
-      plans of the target-stationary convolution are built from them on first use and cached.
+    * neighbour tables nbr[k, target] -> source ROW or -1 for both sides.  Maps built by the LDS-bucketed probe hold
+      them in POSITION space (target = rank of the target row in its map's supercell order, ``order`` maps positions
+      back to rows): ``table_pos(target)`` -> (table, order | None) is what the kernels consume (tiles of
+      consecutive positions are spatially compact); ``table(target)`` is the row-space view (tests, pooling).
+    * the tile plans of the target-stationary convolution are built on first use and cached.
     A transposed view (``swapped()``) shares all device buffers with in/out roles exchanged
     (src/coordinate_map_manager.cpp:763-774).
     """
@@ -255,16 +343,30 @@ class KernelMapGPU:
                  flip=False, in_map=None, out_map=None):
         self.volume, self.n_in, self.n_out = int(volume), int(n_in), int(n_out)
         self.in_map, self.out_map = in_map, out_map   # _CoordinateMapGPU of either side (spatial tile order)
-        self.k_offsets = k_offsets            # host list of volume+1 ints
+        self._k_offsets = k_offsets           # host list of volume+1 ints, or _LazyOffsets
         self.k_offsets_dev = k_offsets_dev    # int64 [volume+1] on the device
-        self.in_pairs, self.out_pairs = in_pairs, out_pairs
+        self.in_pairs_buf, self.out_pairs_buf = in_pairs, out_pairs   # may be longer than n_pairs (upper bound)
         self._store = store if store is not None else {}
         self._flip = flip
         self._launch_cache = {}               # per view: launch geometry and device addresses of the plans
 
     @property
+    def k_offsets(self):
+        if isinstance(self._k_offsets, _LazyOffsets):
+            self._k_offsets = self._k_offsets.get()
+        return self._k_offsets
+
+    @property
     def n_pairs(self):
         return int(self.k_offsets[-1])
+
+    @property
+    def in_pairs(self):
+        return self.in_pairs_buf[:self.n_pairs]
+
+    @property
+    def out_pairs(self):
+        return self.out_pairs_buf[:self.n_pairs]
 
     @property
     def device(self):
@@ -276,34 +378,65 @@ class KernelMapGPU:
         return kind + "_" + target
 
     def swapped(self):
-        return KernelMapGPU(self.volume, self.n_out, self.n_in, self.k_offsets, self.k_offsets_dev,
-                            self.out_pairs, self.in_pairs, store=self._store, flip=not self._flip,
+        return KernelMapGPU(self.volume, self.n_out, self.n_in, self._k_offsets, self.k_offsets_dev,
+                            self.out_pairs_buf, self.in_pairs_buf, store=self._store, flip=not self._flip,
                             in_map=self.out_map, out_map=self.in_map)
 
-    def table(self, target):
-        """target 'out': [volume, n_out] -> in row; target 'in': [volume, n_in] -> out row."""
+    def table_pos(self, target):
+        """(table, order): table [volume, n_tgt] of source ROWS indexed by target POSITION, order int32 [n_tgt]
+        position -> target row, or None when positions are rows (flat-table maps)."""
         name = self._name("nbr", target)
+        order = self._store.get(self._name("order", target))
         if name not in self._store:
             lib = _lib.load()
             dev = self.device
             # the missing table is the transpose of the existing one: scatter the pair lists
             n_tgt = self.n_out if target == "out" else self.n_in
-            src_pairs = self.in_pairs if target == "out" else self.out_pairs   # values stored
-            tgt_pairs = self.out_pairs if target == "out" else self.in_pairs   # rows indexed
+            src_pairs = self.in_pairs_buf if target == "out" else self.out_pairs_buf   # values stored
+            tgt_pairs = self.out_pairs_buf if target == "out" else self.in_pairs_buf   # rows indexed
+            pos = self._store.get(self._name("pos", target))
             tbl = torch.empty((self.volume, max(n_tgt, 1)), dtype=torch.int32, device=dev)
+            bound = (self.n_out if target == "in" else self.n_in) * self.volume
             with _on(dev):
-                _lib.check(lib.me_kernel_map_transpose(_ptr(tgt_pairs), _ptr(src_pairs), _ptr(self.k_offsets_dev),
-                                                       self.volume, self.n_pairs, n_tgt, _ptr(tbl), _stream(dev)))
+                _lib.check(lib.me_kernel_map_transpose_ordered(_ptr(tgt_pairs), _ptr(src_pairs),
+                                                               _ptr(self.k_offsets_dev), self.volume, bound, n_tgt,
+                                                               _ptr(pos), _ptr(tbl), _stream(dev)))
             self._store[name] = tbl
+        return self._store[name], order
+
+    def table(self, target):
+        """target 'out': [volume, n_out] -> in row; target 'in': [volume, n_in] -> out row (ROW space)."""
+        tbl, order = self.table_pos(target)
+        if order is None:
+            return tbl
+        name = self._name("nbrrow", target)
+        if name not in self._store:
+            row = torch.empty_like(tbl)
+            row[:, order.long()] = tbl[:, :order.numel()]
+            self._store[name] = row
         return self._store[name]
 
     def order(self, target):
-        """Target rows in tile order: the argsort of the Z-order keys of the target map's coordinates
-        (int32 [n_tgt]); None when disabled (ME_AMD_SPATIAL_TILES=0).  Tiles of spatially close rows
-        gather (almost) the same source rows for all kernel offsets -> L2 hits instead of HBM."""
+        """Target rows in tile order (int32 [n_tgt]: tile position -> row) for the convolution kernels' stores, or
+        None when tiles are runs of consecutive rows.  Position-space maps: the supercell order of the target map
+        (tiles are spatially compact: their gathers hit the L2) unless ME_AMD_TILE_ORDER=rows (the plan then reads
+        the position-space table through pos_of_row: tiles of consecutive rows again); flat-table maps: the argsort
+        of the Z-order keys when ME_AMD_SPATIAL_TILES=1 (round-1 experiment), else None."""
+        native = self._store.get(self._name("order", target))
+        if native is not None:
+            return native if self._tile_order(target) == "spatial" else None
+        return self._legacy_order(target)
+
+    def _tile_order(self, target):
+        if _TILE_ORDER != "auto":
+            return _TILE_ORDER
+        n_tgt = self.n_out if target == "out" else self.n_in
+        return "rows" if self.volume * n_tgt * 4 <= _TILE_ORDER_ROWS_MAX_BYTES else "spatial"
+
+    def _legacy_order(self, target):
         if not _SPATIAL_TILES:
             return None
-        name = self._name("order", target)
+        name = self._name("zorder", target)
         if name not in self._store:
             cmap = self.out_map if target == "out" else self.in_map
             if cmap is None or cmap.n == 0:
@@ -323,25 +456,30 @@ class KernelMapGPU:
         """Tile plan with `target` rows stationary, tiles of `tile_rows` rows and batches of at most
         `batch_groups` groups: (plan_src, plan_dst, batch_desc, tile_bptr, item_gptr); built once per
         (target, tile_rows, batch_groups)."""
-        name = self._name("plan", target) + f"_{int(tile_rows)}_{int(batch_groups)}"
+        name = self._name("plan", target) + f"_{int(tile_rows)}_{int(batch_groups)}_{self._tile_order(target)}"
         if name not in self._store:
             lib = _lib.load()
             dev = self.device
             n_tgt = self.n_out if target == "out" else self.n_in
-            tbl = self.table(target)
+            tbl, native = self.table_pos(target)
             max_groups = int(lib.me_plan_max_groups(n_tgt, self.volume, self.n_pairs, tile_rows))
             n_tiles = int(lib.me_plan_num_tiles(n_tgt, tile_rows))
             plan_src = torch.empty(max_groups * _lib.ME_GROUP_ROWS, dtype=torch.int32, device=dev)
             plan_dst = torch.empty(max_groups * _lib.ME_GROUP_ROWS, dtype=torch.int32, device=dev)
             batch_desc = torch.empty(2 * max_groups, dtype=torch.int32, device=dev)
-            tile_bptr = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
+            tile_bptr = torch.empty(2 * n_tiles + 1, dtype=torch.int32, device=dev)   # + the dispatch order
             item_gptr = torch.empty(n_tiles * self.volume + 1, dtype=torch.int32, device=dev)
             ws = _workspace(lib.me_plan_workspace_bytes(n_tgt, self.volume, tile_rows), dev)
-            order = self.order(target)
+            # a position-space table is read in its own order (tiles = runs of positions); a row-space table goes
+            # through the optional Z-order permutation
+            if native is not None:
+                gather_order = None if self._tile_order(target) == "spatial" else self._store[self._name("pos", target)]
+            else:
+                gather_order = self._legacy_order(target)
             with _on(dev):
-                _lib.check(lib.me_plan_build(_ptr(tbl), _ptr(order), n_tgt, self.volume, tile_rows, batch_groups,
-                                             _ptr(plan_src), _ptr(plan_dst), _ptr(batch_desc), _ptr(tile_bptr),
-                                             _ptr(item_gptr), _ptr(ws), ws.numel(), _stream(dev)))
+                _lib.check(lib.me_plan_build(_ptr(tbl), _ptr(gather_order), n_tgt, self.volume, tile_rows,
+                                             batch_groups, _ptr(plan_src), _ptr(plan_dst), _ptr(batch_desc),
+                                             _ptr(tile_bptr), _ptr(item_gptr), _ptr(ws), ws.numel(), _stream(dev)))
             self._store[name] = (plan_src, plan_dst, batch_desc, tile_bptr, item_gptr)
         return self._store[name]
 
@@ -352,8 +490,60 @@ class KernelMapGPU:
         for k in range(self.volume):
             b, e = self.k_offsets[k], self.k_offsets[k + 1]
             if e > b:
-                out[k] = torch.stack((self.in_pairs[b:e], self.out_pairs[b:e]))
+                out[k] = torch.stack((self.in_pairs_buf[b:e], self.out_pairs_buf[b:e]))
         return out
+
+
+# Kernel-map build: "auto" = the LDS-bucketed build (spatial index + k_kmap_probe_lds, position-space tables) where it
+# pays — measured (profiles/r02_kmap_build.log): 2.1x faster than the flat-table probe on config 5 (K = 81, 32 M
+# probes), on par on config 2 (K = 27, 2.7 M probes), where the one-off spatial index of the map (~110 us) makes the
+# cold path slower; True / False (ME_AMD_SPATIAL_MAPS=1 / 0) force one path.
+_SPATIAL_MAPS = {"1": True, "0": False}.get(os.environ.get("ME_AMD_SPATIAL_MAPS", "auto"), "auto")
+_SPATIAL_MIN_VOLUME = 64            # auto: kernels of at least this many offsets ...
+_SPATIAL_MIN_PROBES = 1 << 24       # ... or maps of at least this many (row, offset) probes
+# Tiles of position-space maps: "rows" = runs of consecutive rows (the plan reads the table through pos_of_row),
+# "spatial" = runs of positions (spatially compact tiles: 2 - 2.6x less HBM-side traffic in the convolution, but
+# 3 - 7 % slower on uniform random scenes, profiles/r02_tile_order.log)
+# "auto": row tiles while the table is small enough for the plan builder's scattered reads (<= 32 MiB: L2 / Infinity
+# Cache resident), spatial tiles beyond (config 5: 130 MB table — the row-order plan took 2.0 ms instead of 0.37)
+_TILE_ORDER = os.environ.get("ME_AMD_TILE_ORDER", "auto")
+_TILE_ORDER_ROWS_MAX_BYTES = 32 << 20
+
+
+def _build_kernel_map_lds(in_map, out_map, region, volume):
+    """LDS-bucketed build (csrc/coords.hip k_kmap_probe_lds): the neighbour table comes out in the position space of
+    the out map; no host synchronisation.  None when the pair of maps / the region is not eligible."""
+    if _SPATIAL_MAPS is False or in_map.tensor_stride != out_map.tensor_stride or in_map.n == 0 or out_map.n == 0:
+        return None
+    if _SPATIAL_MAPS == "auto" and volume < _SPATIAL_MIN_VOLUME and out_map.n * volume < _SPATIAL_MIN_PROBES:
+        return None
+    lib = _lib.load()
+    sq, sl = out_map.spatial(), in_map.spatial()
+    if sq is None or sl is None:
+        return None
+    if int(lib.me_kernel_map_probe_lds_bytes(ctypes.byref(region), ctypes.byref(sq.grid), ctypes.byref(sl.grid))) < 0:
+        return None
+    dev = in_map.coords.device
+    n_out, n_in = out_map.n, in_map.n
+    nbr = torch.empty((volume, n_out), dtype=torch.int32, device=dev)
+    ws = _workspace(lib.me_kernel_map_workspace_bytes(n_out, volume), dev)
+    k_offsets_dev = torch.empty(volume + 1, dtype=torch.int64, device=dev)
+    # pair lists at their upper bound (the pair count stays on the device until somebody needs it on the host)
+    in_pairs = torch.empty(n_out * volume, dtype=torch.int32, device=dev)
+    out_pairs = torch.empty(n_out * volume, dtype=torch.int32, device=dev)
+    with _on(dev):
+        st = _stream(dev)
+        _lib.check(lib.me_kernel_map_probe_lds(ctypes.byref(sq.grid), _ptr(sq.coords_sorted), _ptr(sq.dir_start), n_out,
+                                               ctypes.byref(sl.grid), _ptr(sl.coords_sorted), _ptr(sl.order),
+                                               _ptr(sl.dir_start), ctypes.byref(region), _ptr(nbr),
+                                               _ptr(k_offsets_dev), _ptr(ws), ws.numel(), st))
+        lazy = _LazyOffsets(k_offsets_dev)
+        _lib.check(lib.me_kernel_map_compact_ordered(_ptr(nbr), _ptr(sq.order), n_out, volume, _ptr(in_pairs),
+                                                     _ptr(out_pairs), _ptr(ws), ws.numel(), st))
+    store = {"nbr_out": nbr, "order_out": sq.order, "pos_out": sq.pos_of_row, "order_in": sl.order,
+             "pos_in": sl.pos_of_row}
+    return KernelMapGPU(volume, n_in, n_out, lazy, k_offsets_dev, in_pairs, out_pairs, store=store, in_map=in_map,
+                        out_map=out_map)
 
 
 def _build_kernel_map(in_map, out_map, region):
@@ -362,6 +552,9 @@ def _build_kernel_map(in_map, out_map, region):
     dev = in_map.coords.device
     volume = int(lib.me_region_volume(ctypes.byref(region)))
     _check(volume > 0, "invalid kernel region")
+    km = _build_kernel_map_lds(in_map, out_map, region, volume)
+    if km is not None:
+        return km
     n_out, n_in = out_map.n, in_map.n
     nbr = torch.empty((volume, max(n_out, 1)), dtype=torch.int32, device=dev)
     ws = _workspace(lib.me_kernel_map_workspace_bytes(n_out, volume), dev)
@@ -887,7 +1080,7 @@ def _conv_backward(in_feat, grad_out, kernel, km, algo=None):
         koffs = (ctypes.c_int64 * (volume + 1))(*km.k_offsets)
         wsb = int((lib.me_conv_wgrad_workspace_bytes_bf16 if bf16 else lib.me_conv_wgrad_workspace_bytes)(
             koffs, volume, c_in, c_out))
-        cfg = (koffs, wsb, _ptr(km.in_pairs), _ptr(km.out_pairs), _ptr(km.k_offsets_dev))
+        cfg = (koffs, wsb, _ptr(km.in_pairs_buf), _ptr(km.out_pairs_buf), _ptr(km.k_offsets_dev))
         km._launch_cache[ck] = cfg
     koffs, wsb, p_in, p_out, p_koffs = cfg
     if _WGRAD_TUNING:   # the debug switches change the workspace need

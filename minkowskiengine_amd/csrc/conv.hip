@@ -70,9 +70,14 @@ __device__ __forceinline__ void mma_groups(const float *__restrict__ a0p, const 
   int d[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) d[r] = (int)__umul24((unsigned)dstp[r * 16], (unsigned)ACC_LD);
+  // The accumulators START from the LDS tile (the old sum is the C operand of the first MFMA) and are written back
+  // after the last k-step: no zero-fill, no v_add_f32 — on gfx950 every VALU instruction costs matrix time
+  // (DESIGN.md 3.1a).  The sum of a target row is ((old + x_0 w_0) + x_1 w_1) + ... in plan order: still a fixed
+  // order.  (VAR & 64: timing ablation without the LDS accumulator traffic.)
   f32x4 acc[R];
 #pragma unroll
-  for (int r = 0; r < R; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int r = 0; r < R; ++r)
+    acc[r] = (VAR & 64) ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4 *>(accp + d[r]);
   // ALL operand reads of the R groups are issued before the first MFMA (LDS returns in order, so the MFMAs of
   // quad-step 0 start as soon as its reads land while the rest stream in).  hipcc's own schedule read two
   // pieces, waited, multiplied, read the next two, waited ...: the LDS latency was exposed KQ/4 times per
@@ -95,18 +100,15 @@ __device__ __forceinline__ void mma_groups(const float *__restrict__ a0p, const 
         acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[s4 * 4 + j], a[s4][r][j], acc[r], 0, 0, 0);
     }
   }
-  if (VAR & 64) {  // ablation: no read-add-write of the LDS accumulator (results kept alive through one write)
+  if (VAR & 64) {  // ablation: no write of the LDS accumulator (results kept alive through one never-taken write)
     f32x4 s = acc[0];
 #pragma unroll
     for (int r = 1; r < R; ++r) s += acc[r];
     if (s.x == 12345.678f) *reinterpret_cast<f32x4 *>(accp + d[0]) = s;
     return;
   }
-  f32x4 old[R];
 #pragma unroll
-  for (int r = 0; r < R; ++r) old[r] = *reinterpret_cast<const f32x4 *>(accp + d[r]);
-#pragma unroll
-  for (int r = 0; r < R; ++r) *reinterpret_cast<f32x4 *>(accp + d[r]) = old[r] + acc[r];
+  for (int r = 0; r < R; ++r) *reinterpret_cast<f32x4 *>(accp + d[r]) = acc[r];
 }
 
 // Packed weights: the exact register image of the kernel.  For offset k, source-channel chunk c,
@@ -212,7 +214,9 @@ __global__ __launch_bounds__(NC * 4, ((NC >= 96 || KC == 96) ? 2 : 3)) void k_co
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i16 = lane & 15;  // gathered row (MFMA B column) / weight column (MFMA A row) of this lane
   const int q = lane >> 4;    // MFMA k index of this lane; after the MFMA: output columns q*4 .. q*4+3
-  const int tile = blockIdx.x;
+  // workgroups take the tiles in the plan's dispatch order (heaviest first: me_plan_build), stored behind the
+  // n_tiles + 1 batch pointers; gridDim.x == n_tiles
+  const int tile = tile_bptr[gridDim.x + 1 + blockIdx.x];
   const int col_base = blockIdx.y * NC;
   const bool vec_ok = (c_src % 4) == 0;
   const int nchunks = (c_src + KC - 1) / KC;
@@ -237,6 +241,17 @@ __global__ __launch_bounds__(NC * 4, ((NC >= 96 || KC == 96) ? 2 : 3)) void k_co
   };
   for (int x = tid; x < (tile_rows + 1) * ACC_LD / 4; x += NT)
     reinterpret_cast<f32x4 *>(s_acc)[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // the rows this tile's positions stand for (tiles of a position-space map): requested now, parked in the free
+  // stage buffer after the main loop — a load of order[] inside the store loop put one memory latency in front of
+  // every store (spatial tiles measured 5 - 13 % slower than row tiles because of it)
+  constexpr int ORD = (ME_MAX_TILE_ROWS + NT - 1) / NT;
+  int32_t my_ord[ORD];
+#pragma unroll
+  for (int j = 0; j < ORD; ++j) {
+    const int r = j * NT + tid;
+    my_ord[j] = (order != nullptr && r < tile_rows && (int64_t)tile * tile_rows + r < n_tgt)
+                    ? order[(int64_t)tile * tile_rows + r] : 0;
+  }
 
   const int b0 = tile_bptr[tile];
   const int nb = tile_bptr[tile + 1] - b0;
@@ -417,6 +432,13 @@ __global__ __launch_bounds__(NC * 4, ((NC >= 96 || KC == 96) ? 2 : 3)) void k_co
   // (row0 + r without an order)
   const int64_t row0 = (int64_t)tile * tile_rows;
   const int rows_here = (int)min((int64_t)tile_rows, n_tgt - row0);
+  int32_t *s_ord = reinterpret_cast<int32_t *>(s_a);   // (the stage buffer is free now; cap_rows * A_LD >= 256 ints)
+  if (order != nullptr) {
+#pragma unroll
+    for (int j = 0; j < ORD; ++j)
+      if (j * NT + tid < tile_rows) s_ord[j * NT + tid] = my_ord[j];
+    __syncthreads();
+  }
   const bool vec_out = (c_dst % 4) == 0;
   for (int x = tid; x < tile_rows * NC / 4; x += NT) {
     const int row = x / (NC / 4);
@@ -424,7 +446,7 @@ __global__ __launch_bounds__(NC * 4, ((NC >= 96 || KC == 96) ? 2 : 3)) void k_co
     const int cc = col_base + c4 * 4;
     if (row < rows_here && cc < c_dst) {
       const f32x4 v = *reinterpret_cast<const f32x4 *>(&s_acc[row * ACC_LD + c4 * 4]);
-      const int64_t grow = order ? (int64_t)order[row0 + row] : row0 + row;
+      const int64_t grow = order ? (int64_t)s_ord[row] : row0 + row;
       float *o = dst + grow * c_dst + cc;
       if (vec_out) {
         *reinterpret_cast<f32x4 *>(o) = v;
@@ -471,103 +493,153 @@ __global__ __launch_bounds__(NC * 4, ((NC >= 96 || KC == 96) ? 2 : 3)) void k_co
 //     instead of once per 64-column slab (half the gather instructions and half the L2-side traffic per MFMA).
 // Requirements (host-checked, else k_conv_tile_f32 runs): c_src a multiple of 64, c_dst a multiple of NC, source
 // matrix below 2^24 rows and 4 GiB.
-template <int R>
-__device__ __forceinline__ void mma_groups_dma(const float *__restrict__ a0p, const int (&pofs)[4],
-                                               const float (&w)[16], const int *d, float *__restrict__ accp) {
-  // Read order = use order (the LDS returns in order): accumulators and the operands of quad-steps 0 and 1 first
-  // (3 R reads before the first MFMA instead of 5 R), the operands of quad-steps 2 and 3 are requested from INSIDE
-  // the MFMA stream (LDS instructions co-issue with the matrix pipe).
-  f32x4 acc[R];
-  f32x4 a[4][R];
+// R groups x CBW 16-column blocks x (KCH * 16) k-steps.  `w[c][s]`: weight register of column block c, k-step s;
+// stage image: chunk h of the batch at a0p + h * st_chunk (floats), group r at + r * 16 * 64.
+template <int R, int CBW, int KCH, int VAR = 0, typename Mid>
+__device__ __forceinline__ void mma_groups_dma(const float *__restrict__ a0p, int st_chunk, const int (&pofs)[4],
+                                               const float (&w)[CBW][16 * KCH], const int *d,
+                                               float *__restrict__ accp, Mid &&mid) {
+  // Read order = use order (the LDS returns in order): accumulators and the operands of quad-steps 0 and 1 first;
+  // the operands of quad-steps 2p + 2 and 2p + 3 are requested from INSIDE the MFMA stream at the end of block 2p
+  // (LDS instructions co-issue with the matrix pipe) and first used a whole block later, so the s_waitcnt
+  // lgkmcnt(0) hipcc puts behind a sched_barrier never finds a young read outstanding.
+  constexpr int S = 4 * KCH;  // quad-steps (4 MFMA k-steps each)
+  f32x4 acc[R][CBW];
+  f32x4 a[S][R];
 #pragma unroll
-  for (int r = 0; r < R; ++r) acc[r] = *reinterpret_cast<const f32x4 *>(accp + d[r]);
+  for (int r = 0; r < R; ++r) {
 #pragma unroll
-  for (int r = 0; r < R; ++r) a[0][r] = *reinterpret_cast<const f32x4 *>(a0p + r * 16 * 64 + pofs[0]);
+    for (int c = 0; c < CBW; ++c) {
+      if (VAR & 64) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};   // timing ablation: no accumulator read
+      else acc[r][c] = *reinterpret_cast<const f32x4 *>(accp + d[r] + c * 16);
+    }
+  }
+  auto read_step = [&](int s) {
+    const float *p = a0p + (s >> 2) * st_chunk + pofs[s & 3];
 #pragma unroll
-  for (int r = 0; r < R; ++r) a[1][r] = *reinterpret_cast<const f32x4 *>(a0p + r * 16 * 64 + pofs[1]);
+    for (int r = 0; r < R; ++r) {
+      if (VAR & 32) {   // timing ablation: no operand reads (opaque register values, so the MFMAs are not folded)
+        f32x4 t = f32x4{1.f + r, 2.f + s, 3.f, 4.f};
+        asm volatile("" : "+v"(t));
+        a[s][r] = t;
+      } else {
+        a[s][r] = *reinterpret_cast<const f32x4 *>(p + r * 16 * 64);
+      }
+    }
+  };
+  read_step(0);
+  read_step(1);
   __builtin_amdgcn_sched_barrier(0);
-  f32x4 acc2 = f32x4{0.f, 0.f, 0.f, 0.f};   // R == 1 only: second chain (odd k-steps)
-  auto block = [&](int s4) {
-    if constexpr (R == 1) {
-      // one group: two interleaved chains instead of sixteen back-to-back dependent MFMAs (40-cycle latency)
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s4 * 4 + 0], a[s4][0][0], acc[0], 0, 0, 0);
-      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s4 * 4 + 1], a[s4][0][1], acc2, 0, 0, 0);
-      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s4 * 4 + 2], a[s4][0][2], acc[0], 0, 0, 0);
-      acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s4 * 4 + 3], a[s4][0][3], acc2, 0, 0, 0);
+  f32x4 acc2[CBW];   // R == 1 only: second chain (odd k-steps)
+#pragma unroll
+  for (int c = 0; c < CBW; ++c) acc2[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  auto block = [&](int s) {
+    if constexpr (R == 1 && CBW == 1) {
+      // one group, one column block: two interleaved chains instead of back-to-back dependent MFMAs (40-cycle
+      // latency against a 32-cycle issue interval)
+      acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[0][s * 4 + 0], a[s][0][0], acc[0][0], 0, 0, 0);
+      acc2[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[0][s * 4 + 1], a[s][0][1], acc2[0], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[0][s * 4 + 2], a[s][0][2], acc[0][0], 0, 0, 0);
+      acc2[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[0][s * 4 + 3], a[s][0][3], acc2[0], 0, 0, 0);
     } else {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
 #pragma unroll
-        for (int r = 0; r < R; ++r)
-          acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s4 * 4 + j], a[s4][r][j], acc[r], 0, 0, 0);
+        for (int r = 0; r < R; ++r) {
+#pragma unroll
+          for (int c = 0; c < CBW; ++c)
+            acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c][s * 4 + j], a[s][r][j], acc[r][c], 0, 0, 0);
+        }
       }
     }
   };
-  block(0);
-  // (hipcc waits lgkmcnt(0) behind a sched_barrier: the reads of quad-steps 2 AND 3 are issued here, a whole block
-  // of MFMAs before their first use, so that wait never stalls)
 #pragma unroll
-  for (int r = 0; r < R; ++r) a[2][r] = *reinterpret_cast<const f32x4 *>(a0p + r * 16 * 64 + pofs[2]);
+  for (int s = 0; s < S; s += 2) {
+    block(s);
+    if (s + 2 < S) {
+      read_step(s + 2);
+      read_step(s + 3);
+    }
+    if (s == 0) mid();   // scalar / LDS-crossbar work of the NEXT iterations, issued inside the MFMA stream
+    __builtin_amdgcn_sched_barrier(0);
+    block(s + 1);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if constexpr (R == 1 && CBW == 1) acc[0][0] += acc2[0];
 #pragma unroll
-  for (int r = 0; r < R; ++r) a[3][r] = *reinterpret_cast<const f32x4 *>(a0p + r * 16 * 64 + pofs[3]);
-  __builtin_amdgcn_sched_barrier(0);
-  block(1);
-  __builtin_amdgcn_sched_barrier(0);
-  block(2);
-  block(3);
-  if constexpr (R == 1) acc[0] += acc2;
+  for (int r = 0; r < R; ++r) {
 #pragma unroll
-  for (int r = 0; r < R; ++r) *reinterpret_cast<f32x4 *>(accp + d[r]) = acc[r];
+    for (int c = 0; c < CBW; ++c) {
+      if (VAR & 64) {   // timing ablation: no accumulator write (kept alive through a never-taken store)
+        if (acc[r][c].x == 12345.678f) *reinterpret_cast<f32x4 *>(accp + d[r] + c * 16) = acc[r][c];
+      } else {
+        *reinterpret_cast<f32x4 *>(accp + d[r] + c * 16) = acc[r][c];
+      }
+    }
+  }
 }
 
-__host__ __device__ constexpr int conv_dma_lds_bytes(int nc, int tile_rows, int batch_groups) {
-  return (tile_rows + 1) * (nc + kAccPad) * 4 + 2 * batch_groups * 16 * 64 * 4;
+__host__ __device__ constexpr int conv_dma_lds_bytes(int nc, int kch, int tile_rows, int batch_groups) {
+  return (tile_rows + 1) * (nc + kAccPad) * 4 + 2 * kch * batch_groups * 16 * 64 * 4;
 }
 
-template <int NC, int VAR>
-__global__ __launch_bounds__(NC * 4, 2) void k_conv_tile_dma_f32(
+// NC output columns per workgroup; CBW 16-column blocks per wave (waves = NC / (16 * CBW)); KCH 64-channel source
+// chunks staged and multiplied per batch.  Measured on config 2 (profiles/r02_tune_conv_dma.log): waves of one SIMD
+// do NOT overlap each other's non-matrix work (the VALU / VMEM instructions of a wave starve while its neighbour's
+// fp32 MFMAs run), so what counts is MFMAs per barrier interval — <128, 2, 1> (forward 64 -> 128)
+// and <64, 1, 2> (dgrad 128 -> 64) run ONE four-wave workgroup per CU with 128 MFMAs per wave and batch.
+template <int NC, int CBW, int KCH, int VAR>
+__global__ __launch_bounds__(NC / CBW * 4, (CBW * KCH >= 2 ? 1 : 2)) void k_conv_tile_dma_f32(
     const float *__restrict__ src, int c_src, const f32x4 *__restrict__ wp, int c_dst,
     const int32_t *__restrict__ plan_src, const int32_t *__restrict__ plan_dst,
     const int32_t *__restrict__ batch_desc, const int32_t *__restrict__ tile_bptr,
     const int32_t *__restrict__ order, float *__restrict__ dst, int64_t n_tgt, int tile_rows, int batch_groups) {
   typedef int i32x2 __attribute__((ext_vector_type(2)));
-  constexpr int WAVES = NC / 16;
+  constexpr int WAVES = NC / (16 * CBW);
   constexpr int NT = WAVES * 64;
   constexpr int ACC_LD = NC + kAccPad;
   constexpr int GSTEP = WAVES / 4;        // groups covered by one "DMA slot" of the workgroup (1 or 2)
-  constexpr int JMAX = 4 / GSTEP;         // DMA instructions per wave and batch (4 or 2)
-  static_assert(NC == 64 || NC == 128, "column slabs of 64 or 128");
+  constexpr int JMAX = 4 / GSTEP;         // DMA slots per wave and batch (4 or 2)
+  static_assert(WAVES == 4 || WAVES == 8, "four or eight waves");
   static_assert(ME_MAX_BATCH_GROUPS == 4, "batches hold at most 4 groups");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float *s_acc = reinterpret_cast<float *>(smem);              // [(tile_rows + 1) x ACC_LD]
-  float *s_st = s_acc + (tile_rows + 1) * ACC_LD;              // [2][batch_groups * 16 x 64], swizzled rows
-  const int st_floats = batch_groups * 16 * 64;
+  float *s_st = s_acc + (tile_rows + 1) * ACC_LD;              // [2][KCH][batch_groups * 16 x 64], swizzled rows
+  const int st_chunk = batch_groups * 16 * 64;                 // floats of one chunk of one stage buffer
+  const int st_floats = st_chunk * KCH;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i16 = lane & 15, q = lane >> 4;
-  const int tile = blockIdx.x;
-  const int nchunks = c_src >> 6;
+  // workgroups take the tiles in the plan's dispatch order (heaviest first: me_plan_build), stored behind the
+  // n_tiles + 1 batch pointers; gridDim.x == n_tiles
+  const int tile = tile_bptr[gridDim.x + 1 + blockIdx.x];
+  const int nchunks = c_src >> 6;          // 64-channel chunks of the source rows (a multiple of KCH)
+  const int nsuper = nchunks / KCH;        // chunk groups = passes over the tile's batches
   const int ncb = c_dst >> 4;
-  const int cb = blockIdx.y * WAVES + wave;                    // this wave's 16-column block (c_dst % NC == 0)
+  const int cb0 = (blockIdx.y * WAVES + wave) * CBW;           // this wave's first 16-column block
   int pofs[4];
 #pragma unroll
   for (int s4 = 0; s4 < 4; ++s4) pofs[s4] = ((4 * s4 + q) ^ i16) * 4;
 
   for (int x = tid; x < (tile_rows + 1) * ACC_LD / 4; x += NT)
     reinterpret_cast<f32x4 *>(s_acc)[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // the rows this tile's positions stand for: requested now, parked in the free stage buffer after the main loop
+  int32_t my_ord = 0;
+  if (order != nullptr && tid < tile_rows && (int64_t)tile * tile_rows + tid < n_tgt)
+    my_ord = order[(int64_t)tile * tile_rows + tid];     // (tile_rows <= 256 = NT)
 
   const int b0 = tile_bptr[tile];
   const int nb = tile_bptr[tile + 1] - b0;
-  const int n_it = nb * nchunks;  // iterations: chunk-major, then the batches of the tile
-  auto locate = [&](int it, int &chunk, int &g0, int &ng, int &k) {
+  const int n_it = (VAR & 512) ? 0 : nb * nsuper;  // iterations: chunk-group-major, then the batches of the tile
+  auto locate = [&](int it, int &chunk, int &g0, int &ng, int &k) {                // (VAR & 512: prologue + epilogue only)
     int r = min(it, n_it - 1);
     chunk = 0;
     while (r >= nb) {
       r -= nb;
-      ++chunk;
+      chunk += KCH;
     }
     const i32x2 dsc = *reinterpret_cast<const i32x2 *>(batch_desc + 2 * (int64_t)(b0 + r));
     g0 = dsc.x;
@@ -596,32 +668,40 @@ __global__ __launch_bounds__(NC * 4, 2) void k_conv_tile_dma_f32(
       const int g = j * GSTEP + gsel;
       if (g < ng) {                                             // wave-uniform
         const unsigned off = __umul24((unsigned)max(idx[j], 0), row_bytes) + cofs;
-        if (!(VAR & 16))
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(srcb + off),
-                                           (__attribute__((address_space(3))) void *)(st + (g * 16 + rb) * 64), 16, 0,
-                                           0);
+#pragma unroll
+        for (int h = 0; h < KCH; ++h) {
+          if (!(VAR & 16))
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void *)(srcb + off + h * 256),
+                (__attribute__((address_space(3))) void *)(st + h * st_chunk + (g * 16 + rb) * 64), 16, 0, 0);
+        }
       }
     }
   };
-  auto load_w = [&](float (&w)[16], int chunk, int k) {
-    const f32x4 *p = wp + ((((int64_t)k * nchunks + chunk) * ncb + cb) * 4) * 64 + lane;
+  auto load_w = [&](float (&w)[CBW][16 * KCH], int chunk, int k) {
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
-      const f32x4 t = p[v * 64];
-      w[v * 4 + 0] = t.x;
-      w[v * 4 + 1] = t.y;
-      w[v * 4 + 2] = t.z;
-      w[v * 4 + 3] = t.w;
+    for (int h = 0; h < KCH; ++h) {
+#pragma unroll
+      for (int c = 0; c < CBW; ++c) {
+        // (32-bit element offset: the packed image of a layer is far below 2^31 pieces)
+        const unsigned e = (unsigned)(((k * nchunks + chunk + h) * ncb + cb0 + c) * 256 + lane);
+        const f32x4 *p = wp + e;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const f32x4 t = p[v * 64];
+          w[c][h * 16 + v * 4 + 0] = t.x;
+          w[c][h * 16 + v * 4 + 1] = t.y;
+          w[c][h * 16 + v * 4 + 2] = t.z;
+          w[c][h * 16 + v * 4 + 3] = t.w;
+        }
+      }
     }
   };
   // (the 64-entry index window of a batch is read to its end unconditionally: the plan is followed by 64 valid
   // entries, k_plan_fill)
-  auto load_idx = [&](const int32_t *plan, int g0) {
-    return *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(plan + (int64_t)g0 * 16) +
-                                              (unsigned)(lane * 4));
-  };
+  auto load_idx = [&](const int32_t *plan, int g0) { return plan[(unsigned)(g0 * 16 + lane)]; };
 
-  float wA[16], wB[16];
+  float wA[CBW][16 * KCH], wB[CBW][16 * KCH];
   if (n_it > 0) {
     int chA, gA, nA, kA, chB, gB, nB, kB, chC, gC, nC, kC;
     locate(0, chA, gA, nA, kA);
@@ -639,41 +719,56 @@ __global__ __launch_bounds__(NC * 4, 2) void k_conv_tile_dma_f32(
       dma(idxA, chA, nA, s_st);
       load_w(wA, chA, kA);
     }
-    float *accp = &s_acc[wave * 16 + q * 4];
+    float *accp = &s_acc[wave * CBW * 16 + q * 4];
 
-    auto iteration = [&](int it, float (&wc)[16], float (&wn)[16]) {
-      // plan indices of the NEXT batch's rows and the accumulator rows of THIS batch's entries reach the lanes by
-      // ds_bpermute before the barrier (their loads were issued an iteration ago; the crossbar latency overlaps the
-      // wait for the other waves); padding slots -> the dummy accumulator row `tile_rows`
-      int idxB[JMAX];
-      dma_rows(svB, idxB);
-      int d[4];
+    // accumulator rows of this lane's entries of a batch (float offsets; padding slots -> the dummy row `tile_rows`)
+    auto dst_rows = [&](int dv, int (&d)[4]) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        d[r] = (int)__umul24((unsigned)__builtin_amdgcn_ds_bpermute((r * 16 + i16) * 4, dvA), (unsigned)ACC_LD);
+        d[r] = (int)__umul24((unsigned)__builtin_amdgcn_ds_bpermute((r * 16 + i16) * 4, dv), (unsigned)ACC_LD);
+    };
+    int dA[4];
+    dst_rows(dvA, dA);
+
+    auto iteration = [&](int it, float (&wc)[CBW][16 * KCH], float (&wn)[CBW][16 * KCH]) {
+      // plan indices of the NEXT batch's rows reach the lanes by ds_bpermute before the barrier (their load was
+      // issued an iteration ago; the crossbar latency overlaps the wait for the other waves)
+      int idxB[JMAX];
+      dma_rows(svB, idxB);
       // batch `it` has landed in stage[it & 1] (this wave's DMA: vmcnt(0); everybody's: the barrier), and every
       // wave is done reading stage[(it + 1) & 1] (batch it - 1)
-      __syncthreads();
+      if (VAR & 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // timing ablation: no barrier
+      else __syncthreads();
       float *st_cur = s_st + (it & 1) * st_floats;
       float *st_nxt = s_st + ((it + 1) & 1) * st_floats;
       int svC = svB, dvC = dvB;
       if (it + 1 < n_it) {                   // wave-uniform
         dma(idxB, chB, nB, st_nxt);
-        load_w(wn, chB, kB);
+        if (!(VAR & 2)) load_w(wn, chB, kB);   // (VAR & 2: timing ablation, the first batch's weights are reused)
         svC = load_idx(plan_src, gC);
         dvC = load_idx(plan_dst, gC);
       }
       const float *a0p = st_cur + i16 * 64;
-      if (nA == 4) mma_groups_dma<4>(a0p, pofs, wc, d, accp);
-      else if (nA == 3) mma_groups_dma<3>(a0p, pofs, wc, d, accp);
-      else if (nA == 2) mma_groups_dma<2>(a0p, pofs, wc, d, accp);
-      else mma_groups_dma<1>(a0p, pofs, wc, d, accp);
+      // inside the MFMA stream (LDS crossbar and scalar instructions co-issue with the matrix pipe): the
+      // accumulator rows of the NEXT batch (its index load was issued an iteration ago) and the descriptor of the
+      // batch three iterations ahead (scalar load: its latency used to be exposed at the loop's end)
+      int dN[4];
+      int chD, gD, nD, kD;
+      auto mid = [&]() {
+        dst_rows(dvB, dN);
+        locate(it + 3, chD, gD, nD, kD);
+      };
+      if (nA == 4) mma_groups_dma<4, CBW, KCH, VAR>(a0p, st_chunk, pofs, (VAR & 2) ? wA : wc, dA, accp, mid);
+      else if (nA == 3) mma_groups_dma<3, CBW, KCH, VAR>(a0p, st_chunk, pofs, (VAR & 2) ? wA : wc, dA, accp, mid);
+      else if (nA == 2) mma_groups_dma<2, CBW, KCH, VAR>(a0p, st_chunk, pofs, (VAR & 2) ? wA : wc, dA, accp, mid);
+      else mma_groups_dma<1, CBW, KCH, VAR>(a0p, st_chunk, pofs, (VAR & 2) ? wA : wc, dA, accp, mid);
       chA = chB; gA = gB; nA = nB; kA = kB;
       chB = chC; gB = gC; nB = nC; kB = kC;
-      dvA = dvB;
+      chC = chD; gC = gD; nC = nD; kC = kD;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dA[r] = dN[r];
       svB = svC;
       dvB = dvC;
-      locate(it + 3, chC, gC, nC, kC);
     };
     int it = 0;
     for (; it + 1 < n_it; it += 2) {
@@ -688,12 +783,17 @@ __global__ __launch_bounds__(NC * 4, 2) void k_conv_tile_dma_f32(
   const int64_t row0 = (int64_t)tile * tile_rows;
   const int rows_here = (int)min((int64_t)tile_rows, n_tgt - row0);
   const int col_base = blockIdx.y * NC;
+  int32_t *s_ord = reinterpret_cast<int32_t *>(s_st);   // (free now; >= 1024 ints)
+  if (order != nullptr) {
+    if (tid < tile_rows) s_ord[tid] = my_ord;
+    __syncthreads();
+  }
   for (int x = tid; x < tile_rows * NC / 4; x += NT) {
     const int row = x / (NC / 4);
     const int c4 = x % (NC / 4);
     if (row < rows_here) {
       const f32x4 v = *reinterpret_cast<const f32x4 *>(&s_acc[row * ACC_LD + c4 * 4]);
-      const int64_t grow = order ? (int64_t)order[row0 + row] : row0 + row;
+      const int64_t grow = order ? (int64_t)s_ord[row] : row0 + row;
       *reinterpret_cast<f32x4 *>(dst + grow * c_dst + col_base + c4 * 4) = v;
     }
   }
@@ -1598,36 +1698,56 @@ static int launch_conv_tile(const float *src, int c_src, const float *wp, int c_
   return 0;
 }
 
-template <int NC>
+template <int NC, int CBW, int KCH>
 static int launch_conv_tile_dma(const float *src, int c_src, const float *wp, int c_dst, const int32_t *plan_src,
                                 const int32_t *plan_dst, const int32_t *batch_desc, const int32_t *tile_bptr,
                                 const int32_t *order, float *dst, int64_t n_tgt, int tile_rows, int batch_groups,
                                 hipStream_t stream) {
-  const int lds = conv_dma_lds_bytes(NC, tile_rows, batch_groups);
+  const int lds = conv_dma_lds_bytes(NC, KCH, tile_rows, batch_groups);
   ME_CHECK(lds <= kLdsBudget, "tile_rows / batch_groups too large for the LDS of one workgroup (LDS-DMA kernel)");
   typedef void (*kernel_t)(const float *, int, const f32x4 *, int, const int32_t *, const int32_t *, const int32_t *,
                            const int32_t *, const int32_t *, float *, int64_t, int, int);
-  const kernel_t fn = g_conv_variant == 3016 ? &k_conv_tile_dma_f32<NC, 16> : &k_conv_tile_dma_f32<NC, 0>;
-  static bool attr_set[2] = {false, false};
-  const int which = g_conv_variant == 3016 ? 1 : 0;
-  if (!attr_set[which]) {
-    ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               kLdsBudget));
-    attr_set[which] = true;
+  // timing ablations (variant = family * 100 + code; instantiated for the <128, 2, 1> shape only): 16 no gather,
+  // 2 weights of the first batch reused, 4 no barrier, 32 no operand reads, 64 no accumulator read / write,
+  // 99 all of them, 98 prologue + epilogue only
+  kernel_t fn = &k_conv_tile_dma_f32<NC, CBW, KCH, 0>;
+  const int code = g_conv_variant % 100;
+  if (code == 16) fn = &k_conv_tile_dma_f32<NC, CBW, KCH, 16>;
+  if constexpr (NC == 128 && CBW == 2) {
+    if (code == 2) fn = &k_conv_tile_dma_f32<NC, CBW, KCH, 2>;
+    if (code == 4) fn = &k_conv_tile_dma_f32<NC, CBW, KCH, 4>;
+    if (code == 32) fn = &k_conv_tile_dma_f32<NC, CBW, KCH, 32>;
+    if (code == 64) fn = &k_conv_tile_dma_f32<NC, CBW, KCH, 64>;
+    if (code == 99) fn = &k_conv_tile_dma_f32<NC, CBW, KCH, 16 + 2 + 4 + 32 + 64>;
+    if (code == 98) fn = &k_conv_tile_dma_f32<NC, CBW, KCH, 512>;
   }
+  ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             kLdsBudget));
   const dim3 grid((unsigned)ceil_div(n_tgt, tile_rows), (unsigned)(c_dst / NC));
-  hipLaunchKernelGGL(fn, grid, dim3(NC * 4), (size_t)lds, stream, src, c_src, reinterpret_cast<const f32x4 *>(wp), c_dst,
-                     plan_src, plan_dst, batch_desc, tile_bptr, order, dst, n_tgt, tile_rows, batch_groups);
+  hipLaunchKernelGGL(fn, grid, dim3(NC / CBW * 4), (size_t)lds, stream, src, c_src,
+                     reinterpret_cast<const f32x4 *>(wp), c_dst, plan_src, plan_dst, batch_desc, tile_bptr, order, dst,
+                     n_tgt, tile_rows, batch_groups);
   ME_LAUNCH_CHECK();
   return 0;
 }
 
-// which LDS-DMA instantiation (columns per workgroup) takes a (c_src, c_dst) problem; 0 = none
-static int conv_dma_columns(int c_src, int c_dst) {
-  if (g_conv_variant < 3000 || g_conv_variant >= 3100) return 0;     // (experiment switch; see me_conv_target_f32)
-  if (c_src % 64 != 0 || c_dst % 64 != 0) return 0;
-  if (g_conv_variant == 3064) return 64;
-  return c_dst % 128 == 0 ? 128 : 64;
+// LDS-DMA instantiation for a (c_src, c_dst) problem: columns per workgroup, column blocks per wave, chunks per batch
+struct ConvDmaShape {
+  int nc, cbw, kch;   // nc == 0: not eligible
+};
+static ConvDmaShape conv_dma_shape(int c_src, int c_dst) {
+  ConvDmaShape z{0, 0, 0};
+  if (g_conv_variant < 3000 || g_conv_variant >= 3400) return z;     // (experiment switch; see me_conv_target_f32)
+  if (c_src % 64 != 0 || c_dst % 64 != 0) return z;
+  const int family = g_conv_variant / 100;   // 30: eight-wave / two-per-CU shapes of the first experiment; 31: long batches
+  if (family == 30) {
+    if (g_conv_variant == 3064) return ConvDmaShape{64, 1, 1};
+    return c_dst % 128 == 0 ? ConvDmaShape{128, 1, 1} : ConvDmaShape{64, 1, 1};
+  }
+  // families 31+: one four-wave workgroup per CU, as many MFMAs per batch as the shape allows
+  if (c_dst % 128 == 0) return ConvDmaShape{128, 2, 1};
+  if (c_src % 128 == 0) return ConvDmaShape{64, 1, 2};
+  return ConvDmaShape{64, 1, 1};
 }
 
 int g_wgrad_depth = 0;         // me_debug_set_wgrad_config: 0 = default
@@ -1845,13 +1965,14 @@ int me_conv_target_f32(const float *src, int64_t n_src, int32_t c_src, const flo
   // 32-bit byte offsets with a 24-bit row multiply need a source matrix below 4 GiB (variant 6: 64-bit addresses)
   const bool small = n_src > 0 && n_src < (1ll << 24) && n_src * c_src * 4 < (1ll << 32) && g_conv_variant != 6;
   if (small) {
-    const int dma_nc = conv_dma_columns(c_src, c_dst);
-    if (dma_nc == 128)
-      return launch_conv_tile_dma<128>(src, c_src, wp, c_dst, plan_src, plan_dst, batch_desc, tile_bptr, order, dst, n_tgt,
-                                       tile_rows, batch_groups, stream);
-    if (dma_nc == 64)
-      return launch_conv_tile_dma<64>(src, c_src, wp, c_dst, plan_src, plan_dst, batch_desc, tile_bptr, order, dst, n_tgt,
-                                      tile_rows, batch_groups, stream);
+    const ConvDmaShape ds = conv_dma_shape(c_src, c_dst);
+#define ME_DMA_ARGS src, c_src, wp, c_dst, plan_src, plan_dst, batch_desc, tile_bptr, order, dst, n_tgt, tile_rows, \
+                    batch_groups, stream
+    if (ds.nc == 128 && ds.cbw == 1) return launch_conv_tile_dma<128, 1, 1>(ME_DMA_ARGS);
+    if (ds.nc == 128 && ds.cbw == 2) return launch_conv_tile_dma<128, 2, 1>(ME_DMA_ARGS);
+    if (ds.nc == 64 && ds.kch == 2) return launch_conv_tile_dma<64, 1, 2>(ME_DMA_ARGS);
+    if (ds.nc == 64) return launch_conv_tile_dma<64, 1, 1>(ME_DMA_ARGS);
+#undef ME_DMA_ARGS
   }
   if (g_conv_variant >= 2048 && g_conv_variant < 3000 && v.nc == 64 && v.kc == 64)
     return launch_conv_tile<64, 64, 0>(ME_CONV_ARGS, small);

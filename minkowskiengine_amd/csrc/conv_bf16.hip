@@ -120,7 +120,9 @@ __global__ __launch_bounds__(NC * 4, 3) void k_conv_tile_bf16(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i16 = lane & 15;
   const int q = lane >> 4;
-  const int tile = blockIdx.x;
+  // workgroups take the tiles in the plan's dispatch order (heaviest first: me_plan_build), stored behind the
+  // n_tiles + 1 batch pointers; gridDim.x == n_tiles
+  const int tile = tile_bptr[gridDim.x + 1 + blockIdx.x];
   const int col_base = blockIdx.y * NC;
   const bool vec_ok = (c_src % 8) == 0;
   const int nchunks = (c_src + KC - 1) / KC;
@@ -129,6 +131,16 @@ __global__ __launch_bounds__(NC * 4, 3) void k_conv_tile_bf16(
 
   for (int x = tid; x < (tile_rows + 1) * ACC_LD / 4; x += NT)
     reinterpret_cast<f32x4 *>(s_acc)[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // the rows this tile's positions stand for (tiles of a position-space map): requested now, parked in the free
+  // stage buffer after the main loop (as in k_conv_tile_f32)
+  constexpr int ORD = (ME_MAX_TILE_ROWS + NT - 1) / NT;
+  int32_t my_ord[ORD];
+#pragma unroll
+  for (int j = 0; j < ORD; ++j) {
+    const int r = j * NT + tid;
+    my_ord[j] = (order != nullptr && r < tile_rows && (int64_t)tile * tile_rows + r < n_tgt)
+                    ? order[(int64_t)tile * tile_rows + r] : 0;
+  }
 
   const int b0 = tile_bptr[tile];
   const int nb = tile_bptr[tile + 1] - b0;
@@ -259,13 +271,20 @@ __global__ __launch_bounds__(NC * 4, 3) void k_conv_tile_bf16(
   const int64_t row0 = (int64_t)tile * tile_rows;
   const int rows_here = (int)min((int64_t)tile_rows, n_tgt - row0);
   const bool vec_out = (c_dst % 4) == 0;
+  int32_t *s_ord = reinterpret_cast<int32_t *>(s_a);   // (the stage buffer is free now: >= 16 rows x 32 channels x 2 B)
+  if (order != nullptr) {
+#pragma unroll
+    for (int j = 0; j < ORD; ++j)
+      if (j * NT + tid < tile_rows) s_ord[j * NT + tid] = my_ord[j];
+    __syncthreads();
+  }
   for (int x = tid; x < tile_rows * NC / 4; x += NT) {
     const int row = x / (NC / 4);
     const int c4 = x % (NC / 4);
     const int cc = col_base + c4 * 4;
     if (row < rows_here && cc < c_dst) {
       const f32x4 v = *reinterpret_cast<const f32x4 *>(&s_acc[row * ACC_LD + c4 * 4]);
-      const int64_t grow = order ? (int64_t)order[row0 + row] : row0 + row;
+      const int64_t grow = order ? (int64_t)s_ord[row] : row0 + row;
       __bf16 *o = dst + grow * c_dst + cc;
       if (vec_out) {
         *reinterpret_cast<bf16x4 *>(o) = bf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};

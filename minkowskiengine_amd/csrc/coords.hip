@@ -569,6 +569,49 @@ __global__ __launch_bounds__(256) void k_plan_fill(const int32_t *__restrict__ t
   }
 }
 
+// Dispatch order of the tiles: heaviest first (longest-processing-time-first list scheduling).  The hardware hands
+// workgroups to CUs in blockIdx order as slots free up; a plan has about two rounds of tiles per slot and their work
+// (16-row groups) varies by +-10 % — +-20 % for spatially compact tiles, whose density follows the scene — so in
+// tile order the last round ends ragged (simulated makespan 1.04x / 1.11x the ideal on config 2; 1.01x sorted).
+// One workgroup: min / max of the work, a 256-bin counting sort by descending work (the order inside a bin is
+// arbitrary: it only permutes the dispatch, never a result).  perm = tile_bptr + n_tiles + 1.
+__global__ __launch_bounds__(1024) void k_plan_tile_order(const int32_t *__restrict__ item_gptr, int64_t volume,
+                                                         int64_t n_tiles, int32_t *__restrict__ perm) {
+  __shared__ int32_t s_min, s_max;
+  __shared__ uint32_t s_bin[256];
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    s_min = INT32_MAX;
+    s_max = 0;
+  }
+  if (tid < 256) s_bin[tid] = 0;
+  __syncthreads();
+  auto work = [&](int64_t t) { return item_gptr[(t + 1) * volume] - item_gptr[t * volume]; };
+  int32_t lo = INT32_MAX, hi = 0;
+  for (int64_t t = tid; t < n_tiles; t += blockDim.x) {
+    const int32_t w = work(t);
+    lo = min(lo, w);
+    hi = max(hi, w);
+  }
+  atomicMin(&s_min, lo);
+  atomicMax(&s_max, hi);
+  __syncthreads();
+  const int32_t wmin = s_min, span = max(s_max - s_min, 1);
+  auto bin = [&](int32_t w) { return 255 - (int)(((int64_t)(w - wmin) * 255) / span); };   // heavy tiles: low bins
+  for (int64_t t = tid; t < n_tiles; t += blockDim.x) atomicAdd(&s_bin[bin(work(t))], 1u);
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t run = 0;
+    for (int b = 0; b < 256; ++b) {
+      const uint32_t c = s_bin[b];
+      s_bin[b] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+  for (int64_t t = tid; t < n_tiles; t += blockDim.x) perm[atomicAdd(&s_bin[bin(work(t))], 1u)] = (int32_t)t;
+}
+
 // Voxel labels (the reference's quantize_label, src/quantization.cpp:140-196): a voxel keeps the label of
 // its first point unless another point of the voxel disagrees -> ignore_label.  Every writer of a voxel
 // writes the same value and the comparison reads the INPUT labels, so the result does not depend on the
@@ -588,6 +631,383 @@ __global__ __launch_bounds__(256) void k_quantize_labels_mark(const int64_t *__r
   if (row >= n) return;
   const int64_t u = inverse_map[row];
   if (labels[row] != labels[unique_map[u]]) colabels[u] = ignore_label;
+}
+
+
+// =================================================================================================
+// spatial index + LDS-bucketed kernel map (round 2)
+// =================================================================================================
+// BASELINE's north_star asks for "LDS-bucketed open-address hashing with coalesced HBM reads".  The flat table
+// above answers point queries; a KERNEL MAP asks, for every row, for its K spatial neighbours — N * K probes whose
+// answers sit within a few cells of the query.  The bucket that serves them is therefore SPATIAL: the rows of a
+// map are ordered by the supercell (16^3 cells for D = 3, 8^4 for D = 4, <= 4096 cells) that contains them
+// (me_spatial_index_build: one key pass, a stable LSD radix sort, a dense supercell directory), and
+// k_kmap_probe_lds gives every supercell of the query map to one workgroup, which
+//   * reads the rows of the 3^D neighbouring supercells of the LOOKUP map as contiguous ranges of its sorted
+//     coordinate array (coalesced 16-byte rows — the only HBM reads of the build) into a dense halo grid in LDS
+//     (cell -> row id; (16 + 2 h)^3 int32 = 23 KiB for k = 3),
+//   * answers all rows x K probes of the supercell with ONE ds_read each (own cell + a per-offset constant), and
+//   * writes the neighbour table in POSITION space (position = rank in supercell order), where its supercell is a
+//     contiguous range: coalesced stores.  Row-space consumers go through `order` (position -> row).
+// No atomics, no hashing in the probe; the flat table remains the dedup structure of insert_and_map and the
+// fallback for kernels whose halo does not fit the LDS or whose maps differ in tensor stride (strided maps: K = 8).
+
+struct SpatialGrid {           // device copy of me_spatial_grid
+  int32_t shift[ME_MAX_DIM];   // log2 of the supercell side per spatial axis (cells)
+  int32_t sc_min[ME_MAX_DIM + 1];  // [0]: smallest batch index; [1 + d]: smallest supercell coordinate of axis d
+  int32_t sc_dim[ME_MAX_DIM + 1];  // extents of the dense supercell directory (batch indices, supercells per axis)
+  int32_t ts[ME_MAX_DIM];      // tensor stride = cell size
+};
+
+__device__ __forceinline__ int32_t floor_div(int32_t c, int32_t ts) {
+  int32_t q = c / ts;
+  if ((c % ts != 0) && ((c < 0) != (ts < 0))) --q;
+  return q;
+}
+
+// linear supercell index of a coordinate row, or -1 outside the directory
+template <int NCOL>
+__device__ __forceinline__ int64_t supercell_of(const SpatialGrid &g, const int32_t (&c)[NCOL]) {
+  int64_t lin = (int64_t)c[0] - g.sc_min[0];
+  if (lin < 0 || lin >= g.sc_dim[0]) return -1;
+#pragma unroll
+  for (int d = 0; d < NCOL - 1; ++d) {
+    const int32_t sc = (floor_div(c[d + 1], g.ts[d]) >> g.shift[d]) - g.sc_min[d + 1];
+    if (sc < 0 || sc >= g.sc_dim[d + 1]) return -1;
+    lin = lin * g.sc_dim[d + 1] + sc;
+  }
+  return lin;
+}
+
+template <int NCOL>
+__global__ __launch_bounds__(256) void k_sp_keys(const int32_t *__restrict__ coords, int64_t n, SpatialGrid g,
+                                                uint32_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int32_t c[NCOL];
+  load_coords<NCOL>(coords, i, c);
+  const int64_t sc = supercell_of<NCOL>(g, c);   // inside by construction (the grid is the map's bounding box)
+  keys[i] = sc < 0 ? 0u : (uint32_t)sc;
+  vals[i] = (uint32_t)i;
+}
+
+// directory of the sorted keys: dir_start[sc] = first position whose key is >= sc (lower bound), dir_start[m] = n.
+// (a histogram with one atomicAdd per row took 100 us on 100k rows in 125 supercells: contention; this is m
+// independent binary searches over an L2-resident array)
+__global__ __launch_bounds__(256) void k_sp_directory(const uint32_t *__restrict__ sorted_keys, int64_t n, int64_t m,
+                                                     uint32_t *__restrict__ dir_start) {
+  const int64_t sc = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (sc > m) return;
+  int64_t lo = 0, hi = n;                         // first position with key >= sc
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if ((int64_t)sorted_keys[mid] < sc) lo = mid + 1; else hi = mid;
+  }
+  dir_start[sc] = (uint32_t)lo;
+}
+
+// ---- stable LSD radix sort of (key, value) pairs, 8-bit digits ------------------------------------------------
+constexpr int kRsTile = 1024;   // elements per block in both passes
+__global__ __launch_bounds__(256) void k_rs_hist(const uint32_t *__restrict__ keys, int64_t n, int shift,
+                                                int64_t nblocks, uint32_t *__restrict__ hist) {
+  __shared__ uint32_t s_h[256];
+  s_h[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * kRsTile;
+#pragma unroll
+  for (int j = 0; j < kRsTile / 256; ++j) {
+    const int64_t e = base + j * 256 + threadIdx.x;
+    if (e < n) atomicAdd(&s_h[(keys[e] >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  hist[(int64_t)threadIdx.x * nblocks + blockIdx.x] = s_h[threadIdx.x];   // digit-major: one scan gives all offsets
+}
+
+// one wave per block walks its tile 64 elements at a time; inside a step the rank of an element among the
+// equal digits of lower lanes comes from eight ballots (match-any), across steps from a running count per digit
+__global__ __launch_bounds__(64) void k_rs_scatter(const uint32_t *__restrict__ keys_in,
+                                                  const uint32_t *__restrict__ vals_in, int64_t n, int shift,
+                                                  int64_t nblocks, const uint32_t *__restrict__ offs,
+                                                  uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out) {
+  __shared__ uint32_t s_cnt[256];
+  const int lane = threadIdx.x;
+  for (int d = lane; d < 256; d += 64) s_cnt[d] = offs[(int64_t)d * nblocks + blockIdx.x];
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * kRsTile;
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (int r = 0; r < kRsTile / 64; ++r) {
+    const int64_t e = base + r * 64 + lane;
+    const bool valid = e < n;
+    const uint32_t key = valid ? keys_in[e] : 0u;
+    const uint32_t val = valid ? vals_in[e] : 0u;
+    const uint32_t d = (key >> shift) & 255u;
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const bool bit = (d >> b) & 1u;
+      const unsigned long long m = __ballot(bit);
+      peers &= bit ? m : ~m;
+    }
+    const uint32_t rank = (uint32_t)__popcll(peers & lt);
+    const uint32_t cnt = (uint32_t)__popcll(peers);
+    uint32_t pos = 0;
+    if (valid) pos = s_cnt[d] + rank;
+    __syncthreads();                             // (one wave: orders the reads above before the updates below)
+    if (valid && rank == 0) s_cnt[d] += cnt;
+    __syncthreads();
+    if (valid) {
+      keys_out[pos] = key;
+      vals_out[pos] = val;
+    }
+  }
+}
+
+template <int NCOL>
+__global__ __launch_bounds__(256) void k_sp_finish(const int32_t *__restrict__ coords, int64_t n,
+                                                  const uint32_t *__restrict__ sorted_rows,
+                                                  int32_t *__restrict__ order, int32_t *__restrict__ pos_of_row,
+                                                  int32_t *__restrict__ coords_sorted) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const uint32_t row = sorted_rows[p];
+  order[p] = (int32_t)row;
+  pos_of_row[row] = (int32_t)p;
+  int32_t c[NCOL];
+  load_coords<NCOL>(coords, row, c);
+  store_coords<NCOL>(coords_sorted, p, c);
+}
+
+struct ProbeLds {
+  int32_t halo[ME_MAX_DIM];    // cells of halo on either side of a supercell
+  int32_t gdim[ME_MAX_DIM];    // halo grid extents (supercell side + 2 * halo)
+  int32_t grid_cells;          // product of gdim
+  int32_t sc_cells;            // cells of a supercell (upper bound of its rows)
+};
+
+// One workgroup per supercell of the query map (grid-stride).  LDS: halo grid [grid_cells] | own cells
+// [sc_cells] | offset deltas [volume] | neighbour ranges [2 * 3^D].
+// wcount (may be NULL): per (offset, 64-position chunk) pair counts for the compaction, fused here (a wave re-reads
+// its chunk's probes from LDS and ballots; chunks shared with a neighbouring supercell are added atomically —
+// integer sums, order-independent); it must be zeroed before the launch.
+template <int NCOL>
+__global__ __launch_bounds__(256) void k_kmap_probe_lds(SpatialGrid gq, const int32_t *__restrict__ q_coords,
+                                                       const uint32_t *__restrict__ q_dir, int64_t n_q,
+                                                       int64_t m_q, SpatialGrid gl,
+                                                       const int32_t *__restrict__ l_coords,
+                                                       const int32_t *__restrict__ l_order,
+                                                       const uint32_t *__restrict__ l_dir, me_region rg,
+                                                       ProbeLds pl, int32_t volume, int32_t *__restrict__ nbr,
+                                                       uint32_t *__restrict__ wcount, int64_t nw) {
+  constexpr int D = NCOL - 1;
+  extern __shared__ __attribute__((aligned(16))) int32_t s_mem[];
+  int32_t *s_grid = s_mem;
+  int32_t *s_qlin = s_grid + pl.grid_cells;
+  int32_t *s_delta = s_qlin + pl.sc_cells;
+  uint32_t *s_rng = reinterpret_cast<uint32_t *>(s_delta + volume);
+  const int tid = threadIdx.x;
+  // linear halo-grid step of every kernel offset (offsets of the region in cells of the lookup map)
+  for (int k = tid; k < volume; k += blockDim.x) {
+    int32_t zero[NCOL], off[NCOL];
+#pragma unroll
+    for (int d = 0; d < NCOL; ++d) zero[d] = 0;
+    region_coordinate_at<NCOL>(rg, k, zero, off);
+    int32_t lin = 0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) lin = lin * pl.gdim[d] + off[d + 1] / gl.ts[d];
+    s_delta[k] = lin;
+  }
+  int n_nb = 1;
+#pragma unroll
+  for (int d = 0; d < D; ++d) n_nb *= 3;
+  for (int64_t sc = blockIdx.x; sc < m_q; sc += gridDim.x) {
+    const uint32_t start = q_dir[sc], end = q_dir[sc + 1];
+    const int rows = (int)(end - start);
+    if (rows == 0) continue;                                   // workgroup-uniform
+    // absolute supercell coordinates of this supercell and the origin cell of its halo grid
+    int32_t A[D], org[D];
+    int64_t rem = sc;
+#pragma unroll
+    for (int d = D - 1; d >= 0; --d) {
+      A[d] = (int32_t)(rem % gq.sc_dim[d + 1]) + gq.sc_min[d + 1];
+      rem /= gq.sc_dim[d + 1];
+      org[d] = (A[d] << gq.shift[d]) - pl.halo[d];
+    }
+    const int32_t batch = (int32_t)rem + gq.sc_min[0];
+    for (int x = tid; x < pl.grid_cells; x += blockDim.x) s_grid[x] = -1;
+    // position ranges of the 3^D neighbouring supercells of the lookup map: fetched by 3^D threads at once (one
+    // directory round trip per supercell instead of 3^D dependent ones)
+    const int32_t bl = batch - gl.sc_min[0];
+    for (int nb = tid; nb < n_nb; nb += blockDim.x) {
+      int64_t lin_sc = bl;
+      bool inside = bl >= 0 && bl < gl.sc_dim[0];
+      int32_t dl[D];
+      int t = nb;
+#pragma unroll
+      for (int d = D - 1; d >= 0; --d) {
+        dl[d] = t % 3 - 1;
+        t /= 3;
+      }
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const int32_t idx = A[d] + dl[d] - gl.sc_min[d + 1];
+        inside = inside && idx >= 0 && idx < gl.sc_dim[d + 1];
+        lin_sc = lin_sc * gl.sc_dim[d + 1] + idx;
+      }
+      s_rng[2 * nb] = inside ? l_dir[lin_sc] : 0u;
+      s_rng[2 * nb + 1] = inside ? l_dir[lin_sc + 1] : 0u;
+    }
+    __syncthreads();
+    // stage the lookup map's rows of those supercells (contiguous ranges of its sorted coordinate array).  The
+    // ranges are walked as ONE concatenated list (exclusive prefix of their lengths in s_rng[2 nb + 1]): a loop over
+    // the 3^D neighbours with a handful of rows each paid one memory latency per neighbour (81 in 4-D)
+    if (tid == 0) {
+      uint32_t run = 0;
+      for (int nb = 0; nb < n_nb; ++nb) {
+        const uint32_t len = s_rng[2 * nb + 1] - s_rng[2 * nb];
+        s_rng[2 * nb + 1] = run;            // exclusive prefix
+        run += len;
+      }
+      s_rng[2 * n_nb] = run;                // total rows to stage
+    }
+    __syncthreads();
+    const uint32_t n_stage = s_rng[2 * n_nb];
+    for (uint32_t j = tid; j < n_stage; j += blockDim.x) {
+      int lo = 0, hi = n_nb - 1;            // last neighbour whose prefix is <= j (empty ranges share a prefix: the
+      while (lo < hi) {                     // LAST of them is the non-empty one that owns j)
+        const int mid = (lo + hi + 1) >> 1;
+        if (s_rng[2 * mid + 1] <= j) lo = mid; else hi = mid - 1;
+      }
+      const uint32_t p = s_rng[2 * lo] + (j - s_rng[2 * lo + 1]);
+      int32_t c[NCOL];
+      load_coords<NCOL>(l_coords, p, c);
+      int32_t lin = 0;
+      bool ok = true;
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const int32_t loc = floor_div(c[d + 1], gl.ts[d]) - org[d];
+        ok = ok && loc >= 0 && loc < pl.gdim[d];
+        lin = lin * pl.gdim[d] + loc;
+      }
+      if (ok) s_grid[lin] = l_order[p];
+    }
+    // the halo-grid cell of every row of this supercell
+    for (int i = tid; i < rows; i += blockDim.x) {
+      int32_t c[NCOL];
+      load_coords<NCOL>(q_coords, start + i, c);
+      int32_t lin = 0;
+#pragma unroll
+      for (int d = 0; d < D; ++d) lin = lin * pl.gdim[d] + (floor_div(c[d + 1], gq.ts[d]) - org[d]);
+      s_qlin[i] = lin;
+    }
+    __syncthreads();
+    // (offset, 64-position chunk) items, one per wave and step: consecutive lanes = consecutive positions ->
+    // coalesced stores; the ballot of the hits is the chunk's pair count
+    const uint32_t c0 = start >> 6, c1 = (end - 1) >> 6;      // global 64-position chunks this supercell touches
+    const int n_chunks = (int)(c1 - c0 + 1);
+    const int lane = tid & 63, wave = tid >> 6;
+    const int items = n_chunks * volume;
+    for (int item = wave; item < items; item += (int)(blockDim.x >> 6)) {
+      const int k = item / n_chunks;
+      const uint32_t chunk = c0 + (uint32_t)(item - k * n_chunks);
+      const uint32_t p = (chunk << 6) + (uint32_t)lane;
+      int32_t r = -1;
+      if (p >= start && p < end) {
+        r = s_grid[s_qlin[p - start] + s_delta[k]];
+        nbr[(int64_t)k * n_q + p] = r;
+      }
+      if (wcount != nullptr) {
+        const uint32_t cnt = (uint32_t)__popcll(__ballot(r >= 0));
+        if (lane == 0 && cnt != 0) {
+          uint32_t *w = &wcount[(int64_t)k * nw + chunk];
+          if ((chunk << 6) >= start && (chunk << 6) + 64 <= end) *w = cnt;   // chunk owned by this supercell alone
+          else atomicAdd(w, cnt);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// per-offset pair counts of an existing neighbour table (the counting half of k_kmap_probe)
+__global__ __launch_bounds__(256) void k_kmap_count(const int32_t *__restrict__ nbr, int64_t n_out,
+                                                   uint32_t *__restrict__ wcount, int64_t nw) {
+  const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int32_t k = blockIdx.y;
+  const int32_t r = (u < n_out) ? nbr[(int64_t)k * n_out + u] : -1;
+  const unsigned long long m = __ballot(r >= 0);
+  const int64_t wave_global = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (lane_id() == 0 && wave_global < nw) wcount[(int64_t)k * nw + wave_global] = (uint32_t)__popcll(m);
+}
+
+// compaction of a POSITION-space table: the pair of (offset k, position p) names the target row order[p]
+__global__ __launch_bounds__(256) void k_kmap_compact_ordered(const int32_t *__restrict__ nbr,
+                                                             const int32_t *__restrict__ order, int64_t n_out,
+                                                             const uint32_t *__restrict__ woffs, int64_t nw,
+                                                             int32_t *__restrict__ in_pairs,
+                                                             int32_t *__restrict__ out_pairs) {
+  const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int32_t k = blockIdx.y;
+  const int32_t r = (u < n_out) ? nbr[(int64_t)k * n_out + u] : -1;
+  const unsigned long long m = __ballot(r >= 0);
+  const int64_t wave_global = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (r >= 0) {
+    const uint32_t dst = woffs[(int64_t)k * nw + wave_global] + mask_prefix(m);
+    in_pairs[dst] = r;
+    out_pairs[dst] = order[u];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_kmap_transpose_ordered(const int32_t *__restrict__ in_pairs,
+                                                               const int32_t *__restrict__ out_pairs,
+                                                               const int64_t *__restrict__ koffs,
+                                                               const int32_t *__restrict__ pos_in, int64_t n_in,
+                                                               int32_t *__restrict__ nbrT) {
+  const int32_t k = blockIdx.y;
+  const int64_t e0 = koffs[k], e1 = koffs[k + 1];
+  for (int64_t e = e0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < e1;
+       e += (int64_t)gridDim.x * blockDim.x)
+    nbrT[(int64_t)k * n_in + pos_in[in_pairs[e]]] = out_pairs[e];
+}
+
+template <int NCOL>
+__global__ __launch_bounds__(256) void k_bbox(const int32_t *__restrict__ coords, int64_t n,
+                                             int32_t *__restrict__ bbox /* [2 * NCOL]: mins, then maxs */) {
+  __shared__ int32_t s_lo[4][NCOL], s_hi[4][NCOL];
+  int32_t lo[NCOL], hi[NCOL];
+#pragma unroll
+  for (int d = 0; d < NCOL; ++d) {
+    lo[d] = INT32_MAX;
+    hi[d] = INT32_MIN;
+  }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int32_t c[NCOL];
+    load_coords<NCOL>(coords, i, c);
+#pragma unroll
+    for (int d = 0; d < NCOL; ++d) {
+      lo[d] = min(lo[d], c[d]);
+      hi[d] = max(hi[d], c[d]);
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < NCOL; ++d) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      lo[d] = min(lo[d], __shfl_xor(lo[d], off, 64));
+      hi[d] = max(hi[d], __shfl_xor(hi[d], off, 64));
+    }
+    if (lane_id() == 0) {
+      s_lo[threadIdx.x >> 6][d] = lo[d];
+      s_hi[threadIdx.x >> 6][d] = hi[d];
+    }
+  }
+  __syncthreads();
+  // one atomic per column and block (a few dozen blocks: the atomics of every wave serialised on 2 * NCOL
+  // addresses and took 22 us for 100k rows)
+  if (threadIdx.x < NCOL) {
+    const int d = threadIdx.x;
+    atomicMin(&bbox[d], min(min(s_lo[0][d], s_lo[1][d]), min(s_lo[2][d], s_lo[3][d])));
+    atomicMax(&bbox[NCOL + d], max(max(s_hi[0][d], s_hi[1][d]), max(s_hi[2][d], s_hi[3][d])));
+  }
 }
 
 }  // namespace me
@@ -628,10 +1048,10 @@ int64_t me_insert_workspace_bytes(int64_t n) {
   return 3 * insert_ws_arrays(n) + 256 + scan_workspace_bytes(n);
 }
 
-int me_coords_insert_and_map(const int32_t *coords, int64_t n, int32_t ncol, uint64_t *table,
-                             int64_t capacity, int32_t *coords_unique, int64_t *unique_map,
-                             int64_t *inverse_map, int64_t *n_unique, void *workspace,
-                             int64_t workspace_bytes, void *stream_) {
+int me_coords_insert_and_map_bbox(const int32_t *coords, int64_t n, int32_t ncol, uint64_t *table,
+                                  int64_t capacity, int32_t *coords_unique, int64_t *unique_map,
+                                  int64_t *inverse_map, int64_t *n_unique, int32_t *bbox, void *workspace,
+                                  int64_t workspace_bytes, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   ME_CHECK(n >= 0 && n < (1ll << 31), "number of coordinates must fit in int32");
   ME_CHECK(capacity >= 2 * n && capacity >= 64 && (capacity & (capacity - 1)) == 0 &&
@@ -646,6 +1066,8 @@ int me_coords_insert_and_map(const int32_t *coords, int64_t n, int32_t ncol, uin
   ME_HIP(hipMemsetAsync(table, 0xff, (size_t)capacity * 8, stream));
   if (n == 0) {
     *n_unique = 0;
+    if (bbox)
+      for (int d = 0; d < 2 * ncol; ++d) bbox[d] = 0;
     return 0;
   }
   char *ws = reinterpret_cast<char *>(workspace);
@@ -667,12 +1089,39 @@ int me_coords_insert_and_map(const int32_t *coords, int64_t n, int32_t ncol, uin
                                             table, slot_of_row, wrow, flag, coords_unique,
                                             unique_map, inverse_map));
   ME_LAUNCH_CHECK();
-  uint32_t host_total = 0;
-  ME_HIP(hipMemcpyAsync(&host_total, total, 4, hipMemcpyDeviceToHost, stream));
+  // the bounding box of the coordinates rides on the one read-back this function needs anyway: it sizes the dense
+  // supercell directory of the map's spatial index (me_spatial_index_build) without a synchronisation of its own
+  uint32_t host_buf[1 + 2 * (ME_MAX_DIM + 1)];
+  int32_t *bbox_dev = reinterpret_cast<int32_t *>(total + 1);   // (inside the 256-byte `total` slot)
+  if (bbox) {
+    int32_t init[2 * (ME_MAX_DIM + 1)];
+    for (int d = 0; d < ncol; ++d) {
+      init[d] = INT32_MAX;
+      init[ncol + d] = INT32_MIN;
+    }
+    ME_HIP(hipMemcpyAsync(bbox_dev, init, (size_t)2 * ncol * 4, hipMemcpyHostToDevice, stream));
+    int64_t gb = ceil_div(n, 256 * 16);
+    if (gb > 48) gb = 48;
+    ME_DISPATCH_NCOL(ncol, hipLaunchKernelGGL(k_bbox<NCOL>, dim3((unsigned)gb), dim3(256), 0, stream, coords, n,
+                                              bbox_dev));
+    ME_LAUNCH_CHECK();
+  }
+  ME_HIP(hipMemcpyAsync(host_buf, total, (size_t)(1 + (bbox ? 2 * ncol : 0)) * 4, hipMemcpyDeviceToHost, stream));
   ME_HIP(hipStreamSynchronize(stream));
-  *n_unique = (int64_t)host_total;
+  *n_unique = (int64_t)host_buf[0];
+  if (bbox)
+    for (int d = 0; d < 2 * ncol; ++d) bbox[d] = (int32_t)host_buf[1 + d];
   return 0;
 }
+
+int me_coords_insert_and_map(const int32_t *coords, int64_t n, int32_t ncol, uint64_t *table,
+                             int64_t capacity, int32_t *coords_unique, int64_t *unique_map,
+                             int64_t *inverse_map, int64_t *n_unique, void *workspace,
+                             int64_t workspace_bytes, void *stream_) {
+  return me_coords_insert_and_map_bbox(coords, n, ncol, table, capacity, coords_unique, unique_map, inverse_map,
+                                       n_unique, nullptr, workspace, workspace_bytes, stream_);
+}
+
 
 int me_coords_stride(const int32_t *coords, int64_t n, int32_t ncol, const int32_t *out_ts,
                      int32_t *out_coords, void *stream_) {
@@ -904,6 +1353,277 @@ int me_plan_build(const int32_t *tbl, const int32_t *order, int64_t n_tgt, int64
   hipLaunchKernelGGL(k_plan_fill, grid, block, 0, stream, tbl, order, n_tgt, volume, items, (int)tile_rows,
                      (int)batch_groups, offs_gb, total_gb, plan_src, plan_dst, batch_desc, tile_bptr, item_gptr,
                      n_tiles);
+  ME_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_plan_tile_order, dim3(1), dim3(1024), 0, stream, item_gptr, volume, n_tiles,
+                     tile_bptr + n_tiles + 1);
+  ME_LAUNCH_CHECK();
+  return 0;
+}
+
+
+// ---- spatial index + LDS-bucketed kernel map -----------------------------------------------------------------
+static SpatialGrid to_device_grid(const me_spatial_grid *g) {
+  SpatialGrid d;
+  for (int i = 0; i < ME_MAX_DIM; ++i) {
+    d.shift[i] = g->shift[i];
+    d.ts[i] = g->tensor_stride[i] > 0 ? g->tensor_stride[i] : 1;
+  }
+  for (int i = 0; i <= ME_MAX_DIM; ++i) {
+    d.sc_min[i] = g->sc_min[i];
+    d.sc_dim[i] = g->sc_dim[i] > 0 ? g->sc_dim[i] : 1;
+  }
+  return d;
+}
+
+int64_t me_spatial_cells(const me_spatial_grid *g) {
+  if (!g || g->ncol < 2 || g->ncol > ME_MAX_DIM + 1) return -1;
+  int64_t m = 1;
+  for (int d = 0; d < g->ncol; ++d) {
+    if (g->sc_dim[d] <= 0) return -1;
+    m *= g->sc_dim[d];
+    if (m > (1ll << 31)) return -1;
+  }
+  return m;
+}
+
+static int64_t rs_blocks(int64_t n) { return ceil_div(n < 1 ? 1 : n, kRsTile); }
+
+int64_t me_spatial_index_workspace_bytes(int64_t n, int64_t m) {
+  if (n < 1) n = 1;
+  if (m < 1) m = 1;
+  const int64_t scan_items = 256 * rs_blocks(n) > m ? 256 * rs_blocks(n) : m;
+  return 4 * align_up(n * 4, 256) + align_up(256 * rs_blocks(n) * 4, 256) + 256 + scan_workspace_bytes(scan_items);
+}
+
+int me_spatial_index_build(const int32_t *coords, int64_t n, const me_spatial_grid *grid, int32_t *order,
+                           int32_t *pos_of_row, int32_t *coords_sorted, uint32_t *dir_start, void *workspace,
+                           int64_t workspace_bytes, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int64_t m = me_spatial_cells(grid);
+  ME_CHECK(m >= 1 && m <= (1ll << 30), "supercell directory out of range");
+  ME_CHECK(n >= 0 && n < (1ll << 31), "number of rows must fit in int32");
+  ME_CHECK(workspace_bytes >= me_spatial_index_workspace_bytes(n, m), "workspace too small");
+  const int ncol = grid->ncol;
+  ME_CHECK(ncol != 4 || ((uintptr_t)coords % 16 == 0 && (uintptr_t)coords_sorted % 16 == 0),
+           "coordinates with 4 columns must be 16-byte aligned");
+  if (n == 0) {
+    ME_HIP(hipMemsetAsync(dir_start, 0, (size_t)(m + 1) * 4, stream));
+    return 0;
+  }
+  char *ws = reinterpret_cast<char *>(workspace);
+  const int64_t asz = align_up(n * 4, 256);
+  uint32_t *keys[2] = {reinterpret_cast<uint32_t *>(ws), reinterpret_cast<uint32_t *>(ws + asz)};
+  uint32_t *vals[2] = {reinterpret_cast<uint32_t *>(ws + 2 * asz), reinterpret_cast<uint32_t *>(ws + 3 * asz)};
+  const int64_t nblocks = rs_blocks(n);
+  uint32_t *hist = reinterpret_cast<uint32_t *>(ws + 4 * asz);
+  uint32_t *hist_total = reinterpret_cast<uint32_t *>(ws + 4 * asz + align_up(256 * nblocks * 4, 256));
+  void *scan_ws = ws + 4 * asz + align_up(256 * nblocks * 4, 256) + 256;
+  const int64_t scan_items = 256 * nblocks > m ? 256 * nblocks : m;
+  const SpatialGrid g = to_device_grid(grid);
+  const dim3 grid_n((unsigned)ceil_div(n, 256)), block(256);
+  ME_DISPATCH_NCOL(ncol, hipLaunchKernelGGL(k_sp_keys<NCOL>, grid_n, block, 0, stream, coords, n, g, keys[0], vals[0]));
+  ME_LAUNCH_CHECK();
+  // stable LSD radix sort of (supercell, row) by supercell: ceil(log2 m / 8) passes
+  int bits = 0;
+  while ((1ll << bits) < m) ++bits;
+  int cur = 0;
+  for (int shift = 0; shift < bits; shift += 8) {
+    hipLaunchKernelGGL(k_rs_hist, dim3((unsigned)nblocks), dim3(256), 0, stream, keys[cur], n, shift, nblocks, hist);
+    ME_LAUNCH_CHECK();
+    if (int rc = exclusive_scan_u32(hist, hist, 256 * nblocks, hist_total, scan_ws, scan_workspace_bytes(scan_items),
+                                    stream))
+      return rc;
+    hipLaunchKernelGGL(k_rs_scatter, dim3((unsigned)nblocks), dim3(64), 0, stream, keys[cur], vals[cur], n, shift,
+                       nblocks, hist, keys[cur ^ 1], vals[cur ^ 1]);
+    ME_LAUNCH_CHECK();
+    cur ^= 1;
+  }
+  // directory: first position of every supercell in the sorted keys; dir_start[m] = n
+  hipLaunchKernelGGL(k_sp_directory, dim3((unsigned)ceil_div(m + 1, 256)), dim3(256), 0, stream, keys[cur], n, m,
+                     dir_start);
+  ME_LAUNCH_CHECK();
+  ME_DISPATCH_NCOL(ncol, hipLaunchKernelGGL(k_sp_finish<NCOL>, grid_n, block, 0, stream, coords, n, vals[cur], order,
+                                            pos_of_row, coords_sorted));
+  ME_LAUNCH_CHECK();
+  return 0;
+}
+
+// halo (cells on either side) of a region on the lookup map's grid, per axis; -1 when it is not a whole number of cells
+static bool region_halo(const me_region *rg, const me_spatial_grid *l, int32_t *halo) {
+  const int D = rg->ncol - 1;
+  for (int d = 0; d < D; ++d) {
+    if (rg->tensor_stride[d] != l->tensor_stride[d]) return false;   // offsets step by the lookup map's cell
+    const int ks = rg->kernel_size[d], dil = rg->dilation[d];
+    const int reach = (ks % 2 == 0) ? (ks - 1) : (ks / 2);
+    halo[d] = reach * dil;
+  }
+  return true;
+}
+
+static bool probe_lds_geometry(const me_region *rg, const me_spatial_grid *q, const me_spatial_grid *l, ProbeLds *pl,
+                               int64_t *lds_bytes) {
+  if (!rg || !q || !l || q->ncol != l->ncol || rg->ncol != q->ncol) return false;
+  const int D = q->ncol - 1;
+  if (rg->region_type != ME_REGION_HYPER_CUBE && rg->region_type != ME_REGION_HYPER_CROSS) return false;
+  int32_t halo[ME_MAX_DIM];
+  if (!region_halo(rg, l, halo)) return false;
+  int64_t cells = 1, sc_cells = 1;
+  for (int d = 0; d < D; ++d) {
+    // both maps on the same cell size and the same supercell side; offsets reach at most one supercell away
+    if (q->tensor_stride[d] != l->tensor_stride[d] || q->shift[d] != l->shift[d]) return false;
+    const int side = 1 << q->shift[d];
+    if (halo[d] > side) return false;
+    pl->halo[d] = halo[d];
+    pl->gdim[d] = side + 2 * halo[d];
+    cells *= pl->gdim[d];
+    sc_cells *= side;
+    if (cells > (1 << 20)) return false;
+  }
+  for (int d = D; d < ME_MAX_DIM; ++d) pl->halo[d] = 0, pl->gdim[d] = 1;
+  const int64_t volume = me_region_volume(rg);
+  if (volume < 1) return false;
+  pl->grid_cells = (int32_t)cells;
+  pl->sc_cells = (int32_t)sc_cells;
+  int64_t n_nb = 1;
+  for (int d = 0; d < D; ++d) n_nb *= 3;
+  *lds_bytes = (cells + sc_cells + volume + 2 * n_nb + 2) * 4;
+  return *lds_bytes <= 160 * 1024 - 256;
+}
+
+int64_t me_kernel_map_probe_lds_bytes(const me_region *region, const me_spatial_grid *q_grid,
+                                      const me_spatial_grid *l_grid) {
+  ProbeLds pl;
+  int64_t bytes = 0;
+  return probe_lds_geometry(region, q_grid, l_grid, &pl, &bytes) ? bytes : -1;
+}
+
+int me_kernel_map_probe_lds(const me_spatial_grid *q_grid, const int32_t *q_coords_sorted, const uint32_t *q_dir,
+                            int64_t n_q, const me_spatial_grid *l_grid, const int32_t *l_coords_sorted,
+                            const int32_t *l_order, const uint32_t *l_dir, const me_region *region, int32_t *nbr_pos,
+                            int64_t *k_offsets_dev, void *workspace, int64_t workspace_bytes, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ProbeLds pl;
+  int64_t lds = 0;
+  ME_CHECK(probe_lds_geometry(region, q_grid, l_grid, &pl, &lds),
+           "this kernel region / map pair is not eligible for the LDS-bucketed probe (me_kernel_map_probe_lds_bytes)");
+  const int64_t volume = me_region_volume(region);
+  ME_CHECK(n_q >= 0 && n_q * volume < (1ll << 32), "n_q * volume must fit in 32 bits");
+  ME_CHECK(k_offsets_dev == nullptr || workspace_bytes >= me_kernel_map_workspace_bytes(n_q, volume),
+           "workspace too small");
+  if (n_q == 0) {
+    if (k_offsets_dev) ME_HIP(hipMemsetAsync(k_offsets_dev, 0, (size_t)(volume + 1) * 8, stream));
+    return 0;
+  }
+  const int64_t m_q = me_spatial_cells(q_grid);
+  ME_CHECK(m_q >= 1, "invalid query grid");
+  // with k_offsets_dev: the per-(offset, 64-position chunk) pair counts are taken inside the probe, then scanned
+  // (the workspace afterwards feeds me_kernel_map_compact_ordered, exactly as after me_kernel_map_probe)
+  char *ws = reinterpret_cast<char *>(workspace);
+  const int64_t nw = kmap_nw(n_q);
+  uint32_t *wcount = k_offsets_dev ? reinterpret_cast<uint32_t *>(ws) : nullptr;
+  if (wcount) ME_HIP(hipMemsetAsync(wcount, 0, (size_t)volume * nw * 4, stream));
+  const int ncol = q_grid->ncol;
+  ME_CHECK(ncol != 4 || ((uintptr_t)q_coords_sorted % 16 == 0 && (uintptr_t)l_coords_sorted % 16 == 0),
+           "coordinates with 4 columns must be 16-byte aligned");
+  const SpatialGrid gq = to_device_grid(q_grid), gl = to_device_grid(l_grid);
+  const me_region rg = *region;
+  int64_t blocks = m_q;
+  const int64_t cap = (int64_t)4 * 256 * (lds > 40 * 1024 ? 1 : 2);   // a few supercells per CU in flight
+  if (blocks > cap) blocks = cap;
+#define ME_PROBE_LDS(NC)                                                                                        \
+  do {                                                                                                          \
+    static bool attr_set = false;                                                                               \
+    if (lds > 48 * 1024 && !attr_set) {                                                                         \
+      ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_kmap_probe_lds<NC>),                         \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                      \
+      attr_set = true;                                                                                          \
+    }                                                                                                           \
+    hipLaunchKernelGGL(k_kmap_probe_lds<NC>, dim3((unsigned)blocks), dim3(256), (size_t)lds, stream, gq,        \
+                       q_coords_sorted, q_dir, n_q, m_q, gl, l_coords_sorted, l_order, l_dir, rg, pl,           \
+                       (int32_t)volume, nbr_pos, wcount, nw);                                                   \
+  } while (0)
+  ME_DISPATCH_NCOL(ncol, ME_PROBE_LDS(NCOL));
+#undef ME_PROBE_LDS
+  ME_LAUNCH_CHECK();
+  if (wcount) {
+    uint32_t *total = reinterpret_cast<uint32_t *>(ws + kmap_counts_bytes(n_q, volume));
+    void *scan_ws = ws + kmap_counts_bytes(n_q, volume) + 256 + align_up((volume + 1) * 8, 256);
+    if (int rc = exclusive_scan_u32(wcount, wcount, volume * nw, total, scan_ws, scan_workspace_bytes(volume * nw),
+                                    stream))
+      return rc;
+    hipLaunchKernelGGL(k_kmap_koffsets, dim3((unsigned)ceil_div(volume + 1, 256)), dim3(256), 0, stream, wcount,
+                       total, nw, volume, k_offsets_dev);
+    ME_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+int me_kernel_map_count(const int32_t *nbr, int64_t n_out, int64_t volume, int64_t *k_offsets,
+                        int64_t *k_offsets_dev, void *workspace, int64_t workspace_bytes, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ME_CHECK(volume >= 1 && volume <= 65535, "kernel volume out of range");
+  ME_CHECK(k_offsets_dev != nullptr, "k_offsets_dev must not be null");
+  ME_CHECK(workspace_bytes >= me_kernel_map_workspace_bytes(n_out, volume), "workspace too small");
+  if (n_out == 0) {
+    if (k_offsets)
+      for (int64_t k = 0; k <= volume; ++k) k_offsets[k] = 0;
+    ME_HIP(hipMemsetAsync(k_offsets_dev, 0, (size_t)(volume + 1) * 8, stream));
+    return 0;
+  }
+  char *ws = reinterpret_cast<char *>(workspace);
+  const int64_t nw = kmap_nw(n_out);
+  uint32_t *wcount = reinterpret_cast<uint32_t *>(ws);
+  uint32_t *total = reinterpret_cast<uint32_t *>(ws + kmap_counts_bytes(n_out, volume));
+  void *scan_ws = ws + kmap_counts_bytes(n_out, volume) + 256 + align_up((volume + 1) * 8, 256);
+  const dim3 grid((unsigned)ceil_div(n_out, 256), (unsigned)volume), block(256);
+  hipLaunchKernelGGL(k_kmap_count, grid, block, 0, stream, nbr, n_out, wcount, nw);
+  ME_LAUNCH_CHECK();
+  if (int rc = exclusive_scan_u32(wcount, wcount, volume * nw, total, scan_ws, scan_workspace_bytes(volume * nw),
+                                  stream))
+    return rc;
+  hipLaunchKernelGGL(k_kmap_koffsets, dim3((unsigned)ceil_div(volume + 1, 256)), dim3(256), 0, stream, wcount, total,
+                     nw, volume, k_offsets_dev);
+  ME_LAUNCH_CHECK();
+  if (k_offsets) {   // optional: the caller may instead copy k_offsets_dev asynchronously and read it when needed
+    ME_HIP(hipMemcpyAsync(k_offsets, k_offsets_dev, (size_t)(volume + 1) * 8, hipMemcpyDeviceToHost, stream));
+    ME_HIP(hipStreamSynchronize(stream));
+  }
+  return 0;
+}
+
+int me_kernel_map_compact_ordered(const int32_t *nbr, const int32_t *order, int64_t n_out, int64_t volume,
+                                  int32_t *in_pairs, int32_t *out_pairs, void *workspace, int64_t workspace_bytes,
+                                  void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (order == nullptr)
+    return me_kernel_map_compact(nbr, n_out, volume, in_pairs, out_pairs, workspace, workspace_bytes, stream_);
+  ME_CHECK(volume >= 1 && volume <= 65535, "kernel volume out of range");
+  ME_CHECK(workspace_bytes >= me_kernel_map_workspace_bytes(n_out, volume), "workspace too small");
+  if (n_out == 0) return 0;
+  const int64_t nw = kmap_nw(n_out);
+  const uint32_t *woffs = reinterpret_cast<const uint32_t *>(workspace);
+  const dim3 grid((unsigned)ceil_div(n_out, 256), (unsigned)volume), block(256);
+  hipLaunchKernelGGL(k_kmap_compact_ordered, grid, block, 0, stream, nbr, order, n_out, woffs, nw, in_pairs,
+                     out_pairs);
+  ME_LAUNCH_CHECK();
+  return 0;
+}
+
+int me_kernel_map_transpose_ordered(const int32_t *in_pairs, const int32_t *out_pairs, const int64_t *k_offsets_dev,
+                                    int64_t volume, int64_t n_pairs_bound, int64_t n_in, const int32_t *pos_in,
+                                    int32_t *nbrT, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (pos_in == nullptr)
+    return me_kernel_map_transpose(in_pairs, out_pairs, k_offsets_dev, volume, n_pairs_bound, n_in, nbrT, stream_);
+  ME_CHECK(volume >= 1 && volume <= 65535, "kernel volume out of range");
+  if (n_in == 0) return 0;
+  ME_HIP(hipMemsetAsync(nbrT, 0xff, (size_t)volume * n_in * 4, stream));
+  if (n_pairs_bound == 0) return 0;
+  int64_t bx = ceil_div(ceil_div(n_pairs_bound, volume), 256);
+  if (bx < 1) bx = 1;
+  if (bx > 4096) bx = 4096;
+  hipLaunchKernelGGL(k_kmap_transpose_ordered, dim3((unsigned)bx, (unsigned)volume), dim3(256), 0, stream, in_pairs,
+                     out_pairs, k_offsets_dev, pos_in, n_in, nbrT);
   ME_LAUNCH_CHECK();
   return 0;
 }

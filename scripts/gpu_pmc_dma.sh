@@ -1,0 +1,36 @@
+#!/bin/bash
+# SQ PMC passes of the LDS-DMA tile kernel (one wave per SIMD: the wave-cycle breakdown reads directly).
+set +e
+TAG=${1:-r02_pmc_dma}
+OUT=$PWD/gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+REPO=$PWD
+cd /tmp
+run() { n=$1; shift
+  timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$n -o $n -- python $REPO/scripts/prof_conv.py > $OUT/$n.log 2>&1
+  echo "$n rc=$?"; }
+export TILE=196 CAP=4 BWD=0 ITERS=10
+VARIANT=3100 run a1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32
+VARIANT=3100 run a2 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU
+VARIANT=3100 run a3 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_FLAT SQ_INSTS_MFMA
+VARIANT=3199 run b1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32
+VARIANT=0 TILE=0 CAP=0 run c1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32
+cd $REPO
+python - <<PY
+import csv, glob, collections, os
+out = "$OUT"
+for d in sorted(glob.glob(out + "/*/")):
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for row in csv.DictReader(open(f)):
+            k = row.get("Kernel_Name", "")[:70]
+            agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        print("==", os.path.basename(d.rstrip("/")))
+        for k, cs in agg.items():
+            if "conv_tile" not in k: continue
+            print("  ", k, {c: round(sum(v) / len(v), 1) for c, v in cs.items()}, "n=", len(next(iter(cs.values()))))
+PY
+ls $OUT/a1 | head
+find $OUT -name "*.csv" -size +3M -delete
+echo done

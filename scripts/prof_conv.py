@@ -22,6 +22,7 @@ x = torch.rand(100000, 64, device=dev).to(tdt)
 w = torch.rand(27, 64, 128, device=dev) - 0.5
 gy = torch.rand(100000, 128, device=dev).to(tdt)
 MEB._TILE_ROWS = T
+MEB._BATCH_GROUPS = int(os.environ.get("CAP", "0"))
 lib.me_debug_set_conv_variant(var)
 for _ in range(iters):
     y = MEB._conv_forward(x, w, km, "mfma")

@@ -150,6 +150,38 @@ def test_non_default_stream(device):
     assert torch.equal(pooled, pool_ref.F)
 
 
+@pytest.mark.parametrize("cin,cout", [(64, 128), (128, 64), (64, 64), (128, 128)])
+@pytest.mark.parametrize("variant,T,cap", [(3000, 96, 4), (3064, 80, 3), (3100, 96, 4), (3100, 64, 2)])
+@pytest.mark.parametrize("spatial,tile_order", [(False, "rows"), (True, "rows"), (True, "spatial")])
+def test_lds_dma_tile_kernel_matches_the_oracle(device, monkeypatch, cin, cout, variant, T, cap, spatial, tile_order):
+    """k_conv_tile_dma_f32 (LDS-DMA gather, accumulators initialised from the LDS tile; debug variants 3000 / 3064 /
+    3100 select its instantiations: eight waves x 16 columns, four waves x 16 columns, four waves with 32 columns or
+    two source chunks per batch) on flat-table maps, LDS-bucketed maps with row tiles and with spatial tiles:
+    forward and dgrad against the oracle, per element."""
+    from minkowskiengine_amd import _lib
+    from minkowskiengine_amd import backend as MEB
+    lib = _lib.load()
+    monkeypatch.setattr(MEB, "_SPATIAL_MAPS", spatial)
+    monkeypatch.setattr(MEB, "_TILE_ORDER", tile_order)
+    monkeypatch.setattr(MEB, "_TILE_ROWS", T)
+    monkeypatch.setattr(MEB, "_BATCH_GROUPS", cap)
+    coords = make_cloud(5000, 18, 3, seed=cin + cout, batch=2, negative=True)
+    lib.me_debug_set_conv_variant(variant)
+    try:
+        conv, x, y, feats, gy = _run_layer(device, coords, cin, cout, 3)
+    finally:
+        lib.me_debug_set_conv_variant(0)
+    km_gpu = x.coordinate_manager._manager._kernel_map(x.coordinate_map_key, y.coordinate_map_key, [3] * 3, [1] * 3,
+                                                       [1] * 3, MEB.RegionType.HYPER_CUBE, None, False, False)
+    assert (km_gpu._store.get("order_out") is not None) == spatial
+    _, km = O.kernel_map(coords.numpy(), coords.numpy(), O.make_region(3, 3))
+    w = conv.kernel.detach().cpu().numpy()
+    assert_close(y.F, O.conv_forward(feats.numpy(), w, km, len(coords)))
+    gi, gw = O.conv_backward(feats.numpy(), gy.numpy(), w, km)
+    assert_close(x.F.grad, gi)
+    assert_close(conv.kernel.grad, gw)
+
+
 def test_bias_and_use_mm(device):
     import minkowskiengine_amd as ME
     coords = make_cloud(500, 10, 3, seed=2).to(device)
@@ -223,7 +255,7 @@ def test_config2_full_size(device):
     with torch.no_grad():
         lhs = conv(mk(2 * a - 3 * b)).F
         rhs = 2 * conv(mk(a)).F - 3 * conv(mk(b)).F
-    assert float((lhs - rhs).abs().max()) < 1e-4
+    assert_close(lhs, rhs, 1e-4, 1e-4, "linearity")
 
 
 def test_config5_full_size(device):

@@ -124,9 +124,16 @@ def test_kernel_map_pair_sets_identical(device, n, extent, D, ks, stride, dil, r
     for k, v in d.items():
         assert v.dtype == torch.int32 and v.shape[0] == 2
     O.assert_same_kernel_map(d, km_o)
-    # our order is deterministic (sorted by output row), so here even the lists are identical
-    for k in km_o:
-        assert np.array_equal(d[k].cpu().numpy(), km_o[k])
+    # flat-table maps list the pairs of an offset sorted by output row like the oracle: the lists are identical;
+    # LDS-bucketed maps list them in supercell order of the output rows (still deterministic, same sets)
+    if km._store.get("order_out") is None:
+        for k in km_o:
+            assert np.array_equal(d[k].cpu().numpy(), km_o[k])
+    else:
+        pos = km._store["pos_out"].cpu().numpy()
+        for k in km_o:
+            out_rows = d[k][1].cpu().numpy()
+            assert np.all(np.diff(pos[out_rows]) > 0), "pairs of an offset are ordered by output position"
     assert km.n_pairs == sum(v.shape[1] for v in km_o.values())
     # dense neighbour tables
     assert np.array_equal(km.table("out").cpu().numpy()[:, :len(out_c)], nbr_o)
@@ -139,15 +146,21 @@ def test_kernel_map_pair_sets_identical(device, n, extent, D, ks, stride, dil, r
     assert mgr._kernel_map(key, okey, ksl, [stride] * D, [dil] * D, MEB.RegionType(region), None, False, False) is km
 
 
+@pytest.mark.parametrize("tile_order", ["rows", "spatial"])
+@pytest.mark.parametrize("stride", [2, 1])      # 2: flat-table map (row-space tables); 1: LDS-bucketed map (positions)
 @pytest.mark.parametrize("target,T,CAP", [("out", 128, 4), ("in", 128, 4), ("out", 131, 3), ("in", 37, 1),
                                           ("out", 16, 2), ("out", 256, 4)])
-def test_tile_plan_covers_every_pair_once(device, target, T, CAP):
+def test_tile_plan_covers_every_pair_once(device, target, T, CAP, stride, tile_order, monkeypatch):
     from minkowskiengine_amd import _lib
+    from minkowskiengine_amd import backend as MEB0
+    monkeypatch.setattr(MEB0, "_SPATIAL_MAPS", True)      # (the automatic choice takes the flat table at this size)
+    monkeypatch.setattr(MEB0, "_TILE_ORDER", tile_order)
     coords = make_cloud(5000, 16, 3, seed=21, batch=2, negative=True)
     MEB, mgr = _mgr()
     key, _ = mgr.insert_and_map(coords.to(device), [1, 1, 1], "")
-    okey = mgr.stride(key, [2, 2, 2])
-    km = mgr._kernel_map(key, okey, [3, 3, 3], [2, 2, 2], [1, 1, 1], MEB.RegionType.HYPER_CUBE, None, False, False)
+    okey = mgr.stride(key, [stride] * 3)
+    km = mgr._kernel_map(key, okey, [3, 3, 3], [stride] * 3, [1, 1, 1], MEB.RegionType.HYPER_CUBE, None, False, False)
+    assert (km._store.get("order_out") is not None) == (stride == 1)
     plan_src, plan_dst, batch_desc, tile_bptr, item_gptr = [t.cpu().numpy() for t in km.plan(target, T, CAP)]
     tbl = km.table(target).cpu().numpy()
     n_tgt = km.n_out if target == "out" else km.n_in
@@ -158,6 +171,12 @@ def test_tile_plan_covers_every_pair_once(device, target, T, CAP):
     K = km.volume
     n_tiles = (n_tgt + T - 1) // T
     assert tile_bptr[0] == 0 and np.all(np.diff(tile_bptr[:n_tiles + 1]) >= 0)
+    # behind the batch pointers: the dispatch order, a permutation of the tiles with (binned) non-increasing work
+    perm = tile_bptr[n_tiles + 1:2 * n_tiles + 1]
+    assert sorted(perm.tolist()) == list(range(n_tiles))
+    work = np.array([item_gptr[(t + 1) * km.volume] - item_gptr[t * km.volume] for t in range(n_tiles)])
+    span = max(int(work.max() - work.min()), 1)
+    assert np.all(np.diff(work[perm]) <= span / 255 + 1), "heaviest tiles first, up to one bin of the counting sort"
     assert item_gptr[0] == 0 and np.all(np.diff(item_gptr[:n_tiles * K + 1]) >= 0)
     seen = set()
     next_group = 0
@@ -217,7 +236,7 @@ def test_kernel_map_100k_properties(device):
     O.assert_same_kernel_map(d, km_o)
     # centre offset is the identity; offset k and 26-k are mirror images (stride-1 symmetry)
     c = d[13].cpu().numpy()
-    assert np.array_equal(c[0], np.arange(100000)) and np.array_equal(c[1], c[0])
+    assert np.array_equal(np.sort(c[0]), np.arange(100000)) and np.array_equal(c[1], c[0])
     for k in range(13):
         a, b = d[k].cpu().numpy(), d[26 - k].cpu().numpy()
         pa = a.T[np.lexsort((a[1], a[0]))]
@@ -229,3 +248,92 @@ def test_kernel_map_100k_properties(device):
     d2 = mgr2.kernel_map(key2, key2, [3] * 3, [1] * 3, [1] * 3, MEB.RegionType.HYPER_CUBE, None, False, False)
     for k in d:
         assert torch.equal(d[k], d2[k])
+
+
+@pytest.mark.parametrize("n,extent,D,batch,ts", [(6000, 20, 3, 2, 1), (5000, 300, 3, 3, 1), (3000, 9, 4, 2, 1),
+                                                 (4000, 50, 2, 1, 1), (2000, 40, 3, 2, 4), (700, 5000, 1, 2, 1),
+                                                 (1, 3, 3, 1, 1)])
+def test_spatial_index(device, n, extent, D, batch, ts):
+    """me_spatial_index_build: `order` is a stable sort of the rows by supercell (batch-major, then the axes), the
+    directory holds the first position of every supercell, coords_sorted / pos_of_row are consistent."""
+    from minkowskiengine_amd import backend as MEB
+    coords = make_cloud(n, extent, D, seed=7 * n + D, batch=batch, negative=True) * torch.tensor([1] + [ts] * D).int()
+    cmap, _, _ = MEB._insert(coords.contiguous().to(device), [ts] * D)
+    sp = cmap.spatial()
+    assert sp is not None
+    c = coords.numpy().astype(np.int64)
+    order = sp.order.cpu().numpy()
+    assert sorted(order.tolist()) == list(range(len(c)))
+    assert np.array_equal(sp.pos_of_row.cpu().numpy()[order], np.arange(len(c)))
+    assert np.array_equal(sp.coords_sorted.cpu().numpy(), coords.numpy()[order])
+    g = sp.grid
+    key = c[:, 0] - g.sc_min[0]
+    for d in range(D):
+        sc = ((c[:, 1 + d] // ts) >> g.shift[d]) - g.sc_min[1 + d]
+        assert sc.min() >= 0 and sc.max() < g.sc_dim[1 + d]
+        key = key * g.sc_dim[1 + d] + sc
+    assert np.array_equal(order, np.argsort(key, kind="stable")), "stable sort by supercell key"
+    ds = sp.dir_start.cpu().numpy().astype(np.int64)
+    assert ds[0] == 0 and ds[-1] == len(c) and len(ds) == sp.m + 1
+    assert np.array_equal(np.diff(ds), np.bincount(key, minlength=sp.m))
+
+
+LDS_CASES = [
+    # n, extent, D, kernel_size, dilation, region, batch, tensor stride
+    (6000, 20, 3, 3, 1, 0, 2, 1),
+    (6000, 90, 3, 3, 1, 0, 3, 1),           # sparse, several supercells per axis
+    (4000, 14, 3, 5, 1, 0, 2, 1),           # K = 125, halo 2
+    (4000, 30, 3, 3, 3, 0, 1, 1),           # dilation 3: halo 3
+    (3000, 9, 4, 3, 1, 0, 2, 1),            # 4-D, K = 81
+    (3000, 40, 2, [3, 2], 1, 0, 2, 1),      # mixed odd / even kernel
+    (3000, 14, 3, 3, 1, 1, 2, 1),           # HYPER_CROSS
+    (3000, 40, 3, 3, 1, 0, 2, 2),           # maps of tensor stride 2 (a layer below a strided conv)
+    (2000, 3000, 1, 3, 1, 0, 2, 1),         # 1-D
+    (1, 2, 3, 3, 1, 0, 1, 1),
+]
+
+
+@pytest.mark.parametrize("n,extent,D,ks,dil,region,batch,ts", LDS_CASES)
+def test_lds_bucketed_kernel_map_equals_the_flat_table_build(device, n, extent, D, ks, dil, region, batch, ts):
+    """The LDS-bucketed build (spatial index + k_kmap_probe_lds, position-space tables, no host sync) and the
+    flat-table build (k_kmap_probe) produce the same row-space neighbour tables and the same pair sets, and both
+    match the oracle."""
+    from minkowskiengine_amd import backend as MEB
+    coords = make_cloud(n, extent, D, seed=3 * n + D, batch=batch, negative=True) * torch.tensor([1] + [ts] * D).int()
+    coords = coords.contiguous()
+    ksl = [ks] * D if isinstance(ks, int) else ks
+    kms = []
+    for spatial in (True, False):
+        old = MEB._SPATIAL_MAPS
+        MEB._SPATIAL_MAPS = spatial
+        try:
+            mgr = MEB.CoordinateMapManagerGPU_c10()
+            key, _ = mgr.insert_and_map(coords.to(device), [ts] * D, "")
+            km = mgr._kernel_map(key, key, ksl, [1] * D, [dil] * D, MEB.RegionType(region), None, False, False)
+            kms.append((km, km.table("out").cpu().numpy(), km.table("in").cpu().numpy(), km.to_dict(), km.n_pairs))
+        finally:
+            MEB._SPATIAL_MAPS = old
+    (a, a_out, a_in, a_d, a_n), (b, b_out, b_in, b_d, b_n) = kms
+    assert a._store.get("order_out") is not None, "the LDS-bucketed path must have been taken"
+    assert b._store.get("order_out") is None
+    assert a_n == b_n and np.array_equal(a_out, b_out) and np.array_equal(a_in, b_in)
+    O.assert_same_kernel_map(a_d, b_d)
+    nbr_o, km_o = O.kernel_map(coords.numpy(), coords.numpy(), O.make_region(D, ksl, dil, ts, region))
+    assert np.array_equal(a_out, nbr_o)
+    O.assert_same_kernel_map(a_d, km_o)
+
+
+def test_lds_bucketed_build_falls_back(device):
+    """A kernel whose reach exceeds one supercell (dilation 20 > 16 cells) and maps of different tensor stride take
+    the flat-table build."""
+    from minkowskiengine_amd import backend as MEB
+    coords = make_cloud(3000, 60, 3, seed=5, batch=2)
+    mgr = MEB.CoordinateMapManagerGPU_c10()
+    key, _ = mgr.insert_and_map(coords.to(device), [1, 1, 1], "")
+    km = mgr._kernel_map(key, key, [3] * 3, [1] * 3, [20] * 3, MEB.RegionType.HYPER_CUBE, None, False, False)
+    assert km._store.get("order_out") is None
+    _, km_o = O.kernel_map(coords.numpy(), coords.numpy(), O.make_region(3, 3, 20, 1))
+    O.assert_same_kernel_map(km.to_dict(), km_o)
+    okey = mgr.stride(key, [2, 2, 2])
+    km2 = mgr._kernel_map(key, okey, [2] * 3, [2] * 3, [1] * 3, MEB.RegionType.HYPER_CUBE, None, False, False)
+    assert km2._store.get("order_out") is None

@@ -148,8 +148,16 @@ def test_ddp_with_sync_batchnorm_matches_one_process_on_the_batched_scenes(devic
     scale = float(y.F.abs().max())
     assert_close(out["y0"], y.F[:n0].detach().cpu(), 2e-4 * scale, 1e-4, "rank 0 output")
     assert_close(out["y1"], y.F[n0:].detach().cpu(), 2e-4 * scale, 1e-4, "rank 1 output")
+    # gradients: both ranks hold the same averaged tensors; against the one-process run they are compared in norm.
+    # The two runs differ in arithmetic (torch's SyncBatchNorm kernels vs csrc/norm.hip), and the gradients of this
+    # random-sign loss through 40 training-mode batch norms are ill-conditioned: the reference's OWN fp32 run
+    # deviates from its float64 run by ~5 % of an element's size on this network (tests/golden/minkunet14_3k.npz,
+    # noise/*), so a per-element bound would test the noise.  Relative L2 error <= 3 %, cosine >= 0.999.
     params = dict(net.named_parameters())
     for key, g0 in out[0].items():
-        want = (params[key].grad / world).cpu()
+        want = (params[key].grad / world).cpu().double()
         assert torch.equal(g0, out[1][key]), key
-        assert_close(g0, want, 5e-4 * float(want.abs().max()), 1e-4, key)
+        got = g0.double()
+        rel = float((got - want).norm() / want.norm())
+        cos = float((got * want).sum() / (got.norm() * want.norm()))
+        assert rel <= 0.03 and cos >= 0.999, (key, rel, cos)
