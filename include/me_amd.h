@@ -316,6 +316,21 @@ int me_conv_wgrad_bf16(const uint16_t *x_dev, int64_t n_in, int32_t c_in, const 
                        int64_t volume, float *grad_w_dev, void *workspace_dev,
                        int64_t workspace_bytes, void *stream);
 
+/* Output-stationary bf16 convolution (k_conv_gather_bf16): the target rows' fp32 accumulators stay in registers for
+ * all kernel offsets, absent neighbours multiply as zero rows (bf16 MFMAs cost 1/16 of fp32 ones: the waste is cheaper
+ * than the plan kernel's LDS accumulator traffic).  Works on a neighbour table directly — tbl int32 [volume, n_tgt]:
+ * source ROW of (offset k, target position p) or -1; order (may be NULL): position -> target row — for forward (table
+ * of the out side) and dgrad (table of the in side, weights packed transposed).  No tile plan.  Same semantics as
+ * me_conv_target_bf16 (fp32 sums in offset order, one rounding at the store).  Channel counts: multiples of 32
+ * (me_conv_gather_supported_bf16), else use me_conv_target_bf16. */
+int32_t me_conv_gather_supported_bf16(int32_t c_src, int32_t c_dst);
+int64_t me_conv_gather_weight_elems_bf16(int64_t volume, int32_t c_src, int32_t c_dst);
+int me_conv_gather_pack_weights_bf16(const void *w_dev, int32_t w_is_f32, int64_t volume, int32_t c_src, int32_t c_dst,
+                                     int32_t transposed, uint16_t *packed_dev, void *stream);
+int me_conv_gather_bf16(const uint16_t *src_feat_dev, int64_t n_src, int32_t c_src, const uint16_t *packed_dev,
+                        int64_t volume, int32_t c_dst, const int32_t *tbl_dev, const int32_t *order_dev,
+                        uint16_t *dst_feat_dev, int64_t n_tgt, void *stream);
+
 /* ---- pooling / broadcast (replace src/pooling_avg_kernel.cu, src/pooling_max_kernel.cu,
  *      src/broadcast_kernel.cu; CPU twins src/pooling_avg_kernel.hpp:41-150,
  *      src/pooling_max_kernel.hpp:36-117, src/broadcast_kernel.hpp:35-160) ------------------------

@@ -105,6 +105,10 @@ SIGNATURES = {
     "me_conv_pack_weights_bf16": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "me_conv_target_bf16": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp,
                                            c_vp, c_i64, c_i32, c_i32, c_vp]),
+    "me_conv_gather_supported_bf16": (c_i32, [c_i32, c_i32]),
+    "me_conv_gather_weight_elems_bf16": (c_i64, [c_i64, c_i32, c_i32]),
+    "me_conv_gather_pack_weights_bf16": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "me_conv_gather_bf16": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "me_conv_wgrad_workspace_bytes_bf16": (c_i64, [_P_I64, c_i64, c_i32, c_i32]),
     "me_conv_wgrad_bf16": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, _P_I64, c_vp, c_i64, c_vp,
                                           c_vp, c_i64, c_vp]),

@@ -925,6 +925,7 @@ CoordinateMapManagerGPU_default = CoordinateMapManagerGPU_c10
 # ------------------------------------------------------------------------------------------------
 # convolution operators (src/convolution_gpu.cu:45-244, src/convolution_transpose_gpu.cu)
 # ------------------------------------------------------------------------------------------------
+_BF16_GATHER = os.environ.get("ME_AMD_BF16_GATHER", "0") != "0"   # bf16: output-stationary kernel (opt-in: measured slower than the tile-plan kernel)
 _ALGO = os.environ.get("ME_AMD_CONV_ALGO", "mfma")  # "naive" = VALU/atomics cross-check kernels
 _WGRAD_TUNING = False  # set by the tuning scripts, which flip the wgrad debug switches between calls: the
                        # workspace size is then re-queried on every call instead of cached per kernel map
@@ -999,6 +1000,26 @@ def _conv_target(src_feat, kernel, km, target, n_tgt, name="conv_target", transp
     bf16 = src_feat.dtype == torch.bfloat16
     out = torch.empty((n_tgt, c_dst), dtype=src_feat.dtype, device=dev)
     if n_tgt == 0:
+        return out
+    if bf16 and _BF16_GATHER and lib.me_conv_gather_supported_bf16(c_src, c_dst):
+        # output-stationary kernel on the neighbour table itself (no tile plan): csrc/conv_bf16.hip k_conv_gather_bf16
+        _check(kernel.dtype in (torch.float32, torch.bfloat16), "kernel must be float32 or bfloat16")
+        ck = ("gather", target, c_src, c_dst)
+        cfg = km._launch_cache.get(ck)
+        if cfg is None:
+            tbl, order = km.table_pos(target)
+            cfg = (tbl, order, int(lib.me_conv_gather_weight_elems_bf16(volume, c_src, c_dst)), _ptr(tbl), _ptr(order))
+            km._launch_cache[ck] = cfg
+        _, _, elems, p_tbl, p_order = cfg
+        stream = _stream(dev)
+        with _on(dev):
+            packed = torch.empty(elems, dtype=torch.bfloat16, device=dev)
+            _lib.check(lib.me_conv_gather_pack_weights_bf16(kernel.data_ptr(), 1 if kernel.dtype == torch.float32 else 0,
+                                                            volume, c_src, c_dst, 1 if transposed else 0,
+                                                            packed.data_ptr(), stream))
+            _timed(name, dev, lambda: _lib.check(lib.me_conv_gather_bf16(
+                src_feat.data_ptr(), src_feat.shape[0], c_src, packed.data_ptr(), km.volume, c_dst, p_tbl, p_order,
+                out.data_ptr(), n_tgt, stream)), flops=2.0 * km.n_pairs * c_src * c_dst if KERNEL_TIMER else 0.0)
         return out
     # launch geometry of this (map side, channel shape, dtype): computed once per kernel map
     ck = (target, c_src, c_dst, bf16, _TILE_ROWS, _BATCH_GROUPS, _SPATIAL_TILES)

@@ -298,6 +298,181 @@ __global__ __launch_bounds__(NC * 4, 3) void k_conv_tile_bf16(
   }
 }
 
+// =================================================================================================
+// output-stationary ("gather") convolution on bf16 features: k_conv_gather_bf16 (round 2)
+// =================================================================================================
+// In bf16 one MFMA (16 rows x 16 columns x 32 channels) costs ~17 cycles against 32 x 16 for the same block in
+// fp32: the plan kernel above is bound by everything EXCEPT the matrix pipe (LDS accumulator read-add-write,
+// staging, two barriers per batch: 8 % of the bf16 peak on config 2).  With the matrix pipe this cheap the
+// classical trade flips: keep the TARGET rows' accumulators in registers for the whole tile and multiply EVERY
+// kernel offset against them, absent neighbours as zero rows —
+//   * no tile plan, no LDS accumulator, no scatter: a wave owns 32 target rows (two MFMA row blocks) x up to 128
+//     columns (64 fp32 accumulator registers), walks the K offsets in order and stores its rows once (rounded to
+//     bf16 once): the sum of a target row is the sum over k = 0 .. K-1 in fp32, a fixed order;
+//   * the B operand (gathered rows) needs no LDS either: lane (row i16, channel group q) loads its 8 consecutive
+//     channels of row nbr[k][target i16] straight into the MFMA register (16-byte loads, exec-masked where the
+//     neighbour is absent); a row block whose 16 neighbours are all absent skips its MFMAs (wave-uniform);
+//   * the A operand (weights) is the same for every workgroup: the packed register image of (offset, 64-channel
+//     chunk, column slab) — 16 KiB for 64 x 128 — streams global -> LDS by LDS-DMA into two buffers, one barrier per
+//     stage, and every MFMA reads its A operand with one conflict-free ds_read_b128;
+//   * wasted matrix work on absent neighbours: K N / P (3.2x at the dense headline density, ~17x at config 5,
+//     minus the skipped all-absent blocks) — affordable at 1/16 of the fp32 price; the gather traffic is the
+//     plan kernel's (absent rows are not loaded).
+// Works on the neighbour table directly (row space or position space + order), forward and dgrad alike.
+// Requirements (else the plan kernel runs): c_src a multiple of 32, c_dst a multiple of 32 (slabs of CB = 2, 4, 6
+// or 8 column blocks), rows 16-byte aligned.
+// a row of zeros for absent neighbours / channel blocks beyond the row: their loads stay unconditional (the load
+// count per stage is fixed, so hipcc can wait for "all but the newest stage" with a counted s_waitcnt)
+constexpr int kZeroRowElems = 8192;
+__device__ __attribute__((aligned(16))) __bf16 d_zero_row[kZeroRowElems];
+
+// Pipeline (round-2 measurement: with the rows of only the NEXT stage in flight a stage lasted one memory latency,
+// 2.4 us for 540 cycles of MFMAs): at stage s the rows of stage s + 2, the neighbour indices of stage s + 3 and the
+// weights of stage s + 2 (into registers; written to the LDS buffer one stage later) are requested; every load is
+// unconditional and plain (no LDS-DMA: hipcc drains everything at the next use once a DMA is in flight), so its
+// counted waits leave two stages of gathers in flight across the one barrier per stage.
+template <int CB>
+__global__ __launch_bounds__(256, 2) void k_conv_gather_bf16(
+    const __bf16 *__restrict__ src, int c_src, const bf16x8 *__restrict__ wp, int c_dst,
+    const int32_t *__restrict__ tbl, const int32_t *__restrict__ order, __bf16 *__restrict__ dst, int64_t n_tgt,
+    int volume) {
+  constexpr int R = 2;                      // 16-row blocks per wave
+  constexpr int ROWS = 4 * R * 16;          // target rows per workgroup
+  constexpr int STAGE = CB * 2 * 64;        // bf16x8 elements of one weight stage (64 channels x CB * 16 columns)
+  constexpr int WPT = CB / 2;               // weight elements (16 bytes) per thread and stage
+  constexpr int DEPTH = 3;                  // row ring: stage s multiplies slot s % 3, stage s + 2 is in flight
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16x8 *s_w = reinterpret_cast<bf16x8 *>(smem);   // [2][CB][2][64]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, q = lane >> 4;
+  const int nchunks = (c_src + 63) >> 6;    // 64-channel chunks (the last one may hold 32 channels)
+  const int ncb = c_dst >> 4;
+  const int slab = blockIdx.y;
+  const int64_t p0 = (int64_t)blockIdx.x * ROWS + wave * (R * 16);
+  const int n_stage = volume * nchunks;
+
+  // target position of this lane in its two row blocks (clamped: loads stay unconditional)
+  int64_t pos[R];
+  bool live[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    pos[r] = p0 + r * 16 + i16;
+    live[r] = pos[r] < n_tgt;
+    if (!live[r]) pos[r] = n_tgt - 1;
+  }
+  auto load_idx = [&](int st, int32_t (&idx)[R]) {
+    const int k = min(st / nchunks, volume - 1);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int32_t v = tbl[(int64_t)k * n_tgt + pos[r]];
+      idx[r] = live[r] ? v : -1;
+    }
+  };
+  auto load_w = [&](int st, bf16x8 (&w)[WPT]) {
+    st = min(st, n_stage - 1);
+    const int k = st / nchunks, c = st % nchunks;
+    const bf16x8 *g = wp + ((int64_t)(k * nchunks + c) * ncb + slab * CB) * 2 * 64 + tid;
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) w[j] = g[j * 256];
+  };
+  auto store_w = [&](const bf16x8 (&w)[WPT], int buf) {
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) s_w[buf * STAGE + j * 256 + tid] = w[j];
+  };
+  // B operands of a stage: 8 channels of the neighbour row per (row block, 32-channel block); absent neighbours and
+  // channel blocks beyond c_src read the zero row
+  auto load_b = [&](const int32_t (&idx)[R], int st, bf16x8 (&b)[R][2]) {
+    const int c = min(st, n_stage - 1) % nchunks;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const int ch = c * 64 + kb * 32 + q * 8;
+        const bool real = idx[r] >= 0 && ch < c_src;
+        const __bf16 *p = real ? src + (int64_t)idx[r] * c_src + ch : d_zero_row + ch;
+        b[r][kb] = *reinterpret_cast<const bf16x8 *>(p);
+      }
+    }
+  };
+
+  f32x4 acc[R][CB];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) acc[r][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  int32_t idx[DEPTH][R];
+  bf16x8 b[DEPTH][R][2];
+  bf16x8 wst[WPT];
+  // prologue: indices of stages 0 .. 2, rows of stages 0 and 1, weights of stage 0 in LDS, of stage 1 in registers
+  load_idx(0, idx[0]);
+  load_idx(1, idx[1]);
+  load_idx(2, idx[2]);
+  load_w(0, wst);
+  load_b(idx[0], 0, b[0]);
+  store_w(wst, 0);
+  load_w(1, wst);
+  load_b(idx[1], 1, b[1]);
+
+  auto stage = [&](int s, int32_t (&idx_c)[R], bf16x8 (&b_c)[R][2], int32_t (&idx_2)[R], bf16x8 (&b_2)[R][2]) {
+    // idx_c / b_c: this stage's ring slot; idx_2: indices of stage s + 2 (loaded two stages ago), b_2: its ring slot
+    __syncthreads();                 // weights of stage s are visible; buffer (s + 1) & 1 is free
+    store_w(wst, (s + 1) & 1);       // weights of stage s + 1 (requested a stage ago)
+    load_w(s + 2, wst);
+    load_b(idx_2, s + 2, b_2);
+    int32_t idx_t[R];                // indices of stage s + 3 take this stage's slot after its last use
+    load_idx(s + 3, idx_t);
+    const bf16x8 *w = s_w + (s & 1) * STAGE + lane;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (__ballot(idx_c[r] >= 0) == 0ull) continue;     // all 16 neighbours of this row block absent
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+          acc[r][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[(cb * 2 + kb) * 64], b_c[r][kb], acc[r][cb], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) idx_c[r] = idx_t[r];
+  };
+  int s = 0;
+  for (; s + 2 < n_stage; s += 3) {
+    stage(s, idx[0], b[0], idx[2], b[2]);
+    stage(s + 1, idx[1], b[1], idx[0], b[0]);
+    stage(s + 2, idx[2], b[2], idx[1], b[1]);
+  }
+  if (s < n_stage) stage(s, idx[0], b[0], idx[2], b[2]);
+  if (s + 1 < n_stage) stage(s + 1, idx[1], b[1], idx[0], b[0]);
+
+  // every target row is written once, rounded to bf16 (RNE); the lane holds columns cb * 16 + q * 4 .. + 3 of row i16
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (!live[r]) continue;
+    const int64_t grow = order ? (int64_t)order[pos[r]] : pos[r];
+    __bf16 *o = dst + grow * c_dst + slab * CB * 16 + q * 4;
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+      const f32x4 v = acc[r][cb];
+      *reinterpret_cast<bf16x4 *>(o + cb * 16) = bf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+    }
+  }
+}
+
+// column blocks per slab of the gather kernel for c_dst columns: the largest of 8, 6, 4, 2 that divides c_dst / 16;
+// 0: not eligible
+static int conv_gather_cb(int c_src, int c_dst) {
+  if (c_src < 32 || c_src % 32 != 0 || c_src + 64 > kZeroRowElems || c_dst < 32 || c_dst % 32 != 0) return 0;
+  const int ncb = c_dst / 16;
+  for (int cb = 8; cb >= 2; cb -= 2)
+    if (ncb % cb == 0) return cb;
+  return 0;
+}
+
 struct ConvVariantBf16 {
   int nc, slabs, kc;
 };
@@ -436,6 +611,64 @@ int me_conv_target_bf16(const uint16_t *src_, int64_t n_src, int32_t c_src, cons
     ME_CONV_CASE(64, 32);
   }
 #undef ME_CONV_CASE
+}
+
+}  // extern "C"
+
+
+extern "C" {
+
+int32_t me_conv_gather_supported_bf16(int32_t c_src, int32_t c_dst) { return conv_gather_cb(c_src, c_dst) > 0 ? 1 : 0; }
+
+int64_t me_conv_gather_weight_elems_bf16(int64_t volume, int32_t c_src, int32_t c_dst) {
+  if (volume <= 0 || c_src <= 0 || c_dst <= 0) return 0;
+  return volume * align_up(c_src, 64) * align_up(c_dst, 16);
+}
+
+int me_conv_gather_pack_weights_bf16(const void *w, int32_t w_is_f32, int64_t volume, int32_t c_src, int32_t c_dst,
+                                     int32_t transposed, uint16_t *wp, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ME_CHECK(volume >= 1 && c_src > 0 && c_dst > 0, "invalid weight shape");
+  ME_CHECK((uintptr_t)wp % 16 == 0, "packed weights must be 16-byte aligned");
+  const int nchunks = (int)ceil_div(c_src, 64), ncb = (int)ceil_div(c_dst, 16);
+  const int64_t total = volume * nchunks * ncb * 2 * 64;  // 16-byte elements
+  bf16x8 *wp8 = reinterpret_cast<bf16x8 *>(wp);
+  const dim3 grid((unsigned)ceil_div(total, 256)), block(256);
+  if (w_is_f32)
+    hipLaunchKernelGGL((k_pack_weights_bf16<64, true>), grid, block, 0, stream, w, c_src, c_dst, transposed, nchunks,
+                       ncb, wp8, total);
+  else
+    hipLaunchKernelGGL((k_pack_weights_bf16<64, false>), grid, block, 0, stream, w, c_src, c_dst, transposed, nchunks,
+                       ncb, wp8, total);
+  ME_LAUNCH_CHECK();
+  return 0;
+}
+
+int me_conv_gather_bf16(const uint16_t *src_, int64_t n_src, int32_t c_src, const uint16_t *wp_, int64_t volume,
+                        int32_t c_dst, const int32_t *tbl, const int32_t *order, uint16_t *dst_, int64_t n_tgt,
+                        void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  (void)n_src;
+  const int cb = conv_gather_cb(c_src, c_dst);
+  ME_CHECK(cb > 0, "channel counts not eligible for the gather kernel (me_conv_gather_supported_bf16)");
+  ME_CHECK(volume >= 1 && volume <= 65535, "kernel volume out of range");
+  ME_CHECK((uintptr_t)src_ % 16 == 0 && (uintptr_t)dst_ % 8 == 0 && (uintptr_t)wp_ % 16 == 0,
+           "feature and weight pointers must be 16-byte aligned");
+  if (n_tgt == 0) return 0;
+  const __bf16 *src = reinterpret_cast<const __bf16 *>(src_);
+  const bf16x8 *wp = reinterpret_cast<const bf16x8 *>(wp_);
+  __bf16 *dst = reinterpret_cast<__bf16 *>(dst_);
+  const dim3 grid((unsigned)ceil_div(n_tgt, 128), (unsigned)(c_dst / (cb * 16)));
+#define ME_GATHER(CBV)                                                                                        \
+  hipLaunchKernelGGL(k_conv_gather_bf16<CBV>, grid, dim3(256), (size_t)(2 * CBV * 2 * 64 * 16), stream, src, c_src, \
+                     wp, c_dst, tbl, order, dst, n_tgt, (int)volume)
+  if (cb == 8) ME_GATHER(8);
+  else if (cb == 6) ME_GATHER(6);
+  else if (cb == 4) ME_GATHER(4);
+  else ME_GATHER(2);
+#undef ME_GATHER
+  ME_LAUNCH_CHECK();
+  return 0;
 }
 
 }  // extern "C"

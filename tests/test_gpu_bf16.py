@@ -65,8 +65,13 @@ BF16_CASES = [
 ]
 
 
+@pytest.mark.parametrize("gather", [True, False], ids=["gather", "plan"])
 @pytest.mark.parametrize("n,extent,D,cin,cout,ks,stride,dil", BF16_CASES)
-def test_bf16_conv_forward_backward_vs_oracle(device, n, extent, D, cin, cout, ks, stride, dil):
+def test_bf16_conv_forward_backward_vs_oracle(device, monkeypatch, n, extent, D, cin, cout, ks, stride, dil, gather):
+    """gather: the output-stationary kernel (k_conv_gather_bf16) where the channel counts are multiples of 32, the
+    plan kernel elsewhere; plan: the target-stationary plan kernel (k_conv_tile_bf16) for every shape."""
+    from minkowskiengine_amd import backend as MEB
+    monkeypatch.setattr(MEB, "_BF16_GATHER", gather)
     coords = make_cloud(n, extent, D, seed=n + cin, batch=2 if n > 100 else 1, negative=True)
     conv, x, y, feats, gy = _run_layer(device, coords, cin, cout, ks, stride, dil)
     in_c = coords.numpy()
