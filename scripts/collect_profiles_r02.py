@@ -1,0 +1,104 @@
+"""Copy the round-2 measurements worth judging from gpurun_out/ (scratch) into profiles/ (tracked), as compact
+summaries: per-kernel counter averages instead of raw counter CSVs, kernel-stats CSVs as they are, bench lines and
+tuning logs as they are.  Idempotent; missing sources are skipped with a note."""
+import collections
+import csv
+import glob
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out")
+DST = os.path.join(ROOT, "profiles")
+
+
+def copy(src, dst):
+    s = os.path.join(SRC, src)
+    if not os.path.exists(s):
+        print("skip (absent):", src)
+        return
+    shutil.copyfile(s, os.path.join(DST, dst))
+    print("copied", src, "->", dst)
+
+
+def counters(src_dir, dst, keep=("conv_tile", "wgrad", "kmap", "k_sp_", "k_rs_", "conv_gather"), header=""):
+    """Average every counter per kernel over the launches of each pass directory under src_dir."""
+    d = os.path.join(SRC, src_dir)
+    if not os.path.isdir(d):
+        print("skip (absent):", src_dir)
+        return
+    lines = [header] if header else []
+    for sub in sorted(os.listdir(d)):
+        files = glob.glob(os.path.join(d, sub, "**", "*counter_collection.csv"), recursive=True)
+        for f in files:
+            agg = collections.defaultdict(lambda: collections.defaultdict(list))
+            dur = collections.defaultdict(list)
+            for row in csv.DictReader(open(f)):
+                k = row.get("Kernel_Name", "")
+                agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+                dur[k].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+            lines.append(f"== pass {sub}")
+            for k, cs in agg.items():
+                if not any(t in k for t in keep):
+                    continue
+                n = len(next(iter(cs.values())))
+                avg = {c: round(sum(v) / len(v), 1) for c, v in cs.items()}
+                lines.append(f"  {k[:110]}\n      launches={n} avg_ns={sum(dur[k]) / len(dur[k]):.0f} {avg}")
+    with open(os.path.join(DST, dst), "w") as fh:
+        fh.write("\n".join(lines) + "\n")
+    print("summarised", src_dir, "->", dst)
+
+
+def stats(src_glob, dst):
+    files = glob.glob(os.path.join(SRC, src_glob), recursive=True)
+    if not files:
+        print("skip (absent):", src_glob)
+        return
+    shutil.copyfile(files[0], os.path.join(DST, dst))
+    print("copied", os.path.relpath(files[0], SRC), "->", dst)
+
+
+def main():
+    os.makedirs(DST, exist_ok=True)
+    # fp32 tile kernels: tuning of the LDS-DMA family against the round-1 kernel, its PMC breakdown, HBM traffic
+    for i, tag in enumerate(["r02b", "r02c", "r02c2", "r02c3"]):
+        copy(f"{tag}/tune_dma.log", f"r02_tune_conv_dma_{i + 1}.log")
+    counters("r02_pmc_dma", "r02_pmc_conv_dma.log",
+             header="# rocprofv3 --pmc passes over scripts/prof_conv.py (config-2 conv 64->128, 834914 pairs); "
+                    "SQ_* cycle counters are in quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES = 32 x N_mfma")
+    counters("r02g_traffic", "r02_pmc_traffic_tile_order.log",
+             header="# FETCH_SIZE / WRITE_SIZE (KB, as reported: the gfx950 fetch correction x2 is applied in "
+                    "DESIGN.md), TCC hit/miss; v8 = round-1 kernel, dma = LDS-DMA kernel <128,2,1>; rows / spatial = "
+                    "tile order")
+    # kernel-map build
+    for wl in ("conv3d", "conv4d"):
+        for lds in (0, 1):
+            stats(f"r02f_kmap/{wl}_{lds}/**/*kernel_stats.csv", f"r02_rocprof_kernel_stats_kmap_{wl}_{'lds' if lds else 'flat'}.csv")
+    # bench lines
+    copy("r02a/bench_n2.json", "r02_bench_conv_n2_selfspawn_1gpu.json")
+    copy("r02a/bench_unet_n2.json", "r02_bench_minkunet34c_n2_1gpu_ddp.json")
+    copy("r02a/ddp_example.log", "r02_ddp_example_2ranks_1gpu.log")
+    copy("r02i/bench.json", "r02_bench_conv_lpt.json")
+    copy("r02i/bench4d.json", "r02_bench_conv4d_lpt.json")
+    copy("r02i/bench_sparse.json", "r02_bench_conv_sparse_lpt.json")
+    copy("r02g2/bench_v8_rows.json", "r02_bench_conv_v8_row_tiles.json")
+    copy("r02g2/bench_v8_spatial.json", "r02_bench_conv_v8_spatial_tiles.json")
+    copy("r02g2/bench_dma_rows.json", "r02_bench_conv_dma_row_tiles.json")
+    copy("r02g2/bench_dma_spatial.json", "r02_bench_conv_dma_spatial_tiles.json")
+    copy("r02j/unet_bf16_0.json", "r02_bench_minkunet34c_bf16_plan.json")
+    copy("r02j/unet_bf16_1.json", "r02_bench_minkunet34c_bf16_gather_v1.json")
+    copy("r02j/unet_bf16_graph.json", "r02_bench_minkunet34c_bf16_gather_v1_graph.json")
+    copy("r02j/bench_bf16_0.json", "r02_bench_conv_bf16_plan.json")
+    copy("r02j/bench_bf16_1.json", "r02_bench_conv_bf16_gather_v1.json")
+    copy("r02k/bench_bf16_1.json", "r02_bench_conv_bf16_gather_v2_ring.json")
+    copy("r02j/bench4d_bf16_0.json", "r02_bench_conv4d_bf16_plan.json")
+    copy("r02j/bench4d_bf16_1.json", "r02_bench_conv4d_bf16_gather_v1.json")
+    copy("config3_parity.log", "r02_config3_parity.log")
+    for extra in sys.argv[1:]:          # "src:dst" pairs for later sessions
+        s, d = extra.split(":")
+        copy(s, d)
+
+
+if __name__ == "__main__":
+    main()
