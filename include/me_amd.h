@@ -331,6 +331,30 @@ int me_conv_gather_bf16(const uint16_t *src_feat_dev, int64_t n_src, int32_t c_s
                         int64_t volume, int32_t c_dst, const int32_t *tbl_dev, const int32_t *order_dev,
                         uint16_t *dst_feat_dev, int64_t n_tgt, void *stream);
 
+/* ---- fp32 convolution on the bf16 matrix pipe ("bf16x6" split, csrc/conv_f32x3.hip) ---------------------
+ * Same contract as me_conv_target_f32 (fp32 features / weights in, fp32 out, the reference's
+ * ConvolutionForwardKernelGPU / BackwardKernelGPU input gradient, src/convolution_kernel.cu:320-757, in fp32 as
+ * AT_DISPATCH_FLOATING_TYPES computes it), different arithmetic unit: every operand is split exactly into three
+ * bf16 terms (a = a1 + a2 + a3) and the product is rebuilt from six v_mfma_f32_16x16x32_bf16 with fp32
+ * accumulation; the dropped terms are < 2^-23 |a b| per product, i.e. below one fp32 rounding.  Fixed summation
+ * order (bitwise reproducible).  An infinite input yields NaN (fp32 arithmetic would keep the infinity).
+ * Needs c_src % 8 == 0 (me_conv_f32x3_supported); plans come from me_plan_build with the geometry of
+ * me_conv_plan_config_f32x3; weights packed by me_conv_pack_weights_f32x3 (three bf16 planes). */
+int32_t me_conv_f32x3_supported(int32_t c_src, int32_t c_dst);
+/* phase counters of the instrumented build (me_debug_set_conv_variant(256)); layout as me_debug_conv_timing */
+int me_debug_conv_timing_f32x3(uint64_t *out8, int32_t reset);
+int me_conv_plan_config_f32x3(int64_t n_tgt, int64_t volume, int64_t n_pairs, int32_t c_src, int32_t c_dst,
+                              int32_t *tile_rows, int32_t *batch_groups);
+int64_t me_conv_packed_weight_elems_f32x3(int64_t volume, int32_t c_src, int32_t c_dst); /* bf16 elements */
+int me_conv_pack_weights_f32x3(const float *w_dev, int64_t volume, int32_t c_src, int32_t c_dst,
+                               int32_t transposed, uint16_t *packed_dev, void *stream);
+int me_conv_target_f32x3(const float *src_feat_dev, int64_t n_src, int32_t c_src,
+                         const uint16_t *packed_w_dev, int64_t volume, int32_t c_dst,
+                         const int32_t *plan_src_dev, const int32_t *plan_dst_dev,
+                         const int32_t *batch_desc_dev, const int32_t *tile_bptr_dev,
+                         const int32_t *order_dev, float *dst_feat_dev,
+                         int64_t n_tgt, int32_t tile_rows, int32_t batch_groups, void *stream);
+
 /* ---- pooling / broadcast (replace src/pooling_avg_kernel.cu, src/pooling_max_kernel.cu,
  *      src/broadcast_kernel.cu; CPU twins src/pooling_avg_kernel.hpp:41-150,
  *      src/pooling_max_kernel.hpp:36-117, src/broadcast_kernel.hpp:35-160) ------------------------

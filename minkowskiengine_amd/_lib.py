@@ -100,6 +100,13 @@ SIGNATURES = {
     "me_coords_expand_region": (ctypes.c_int, [c_vp, c_i64, c_i32, _P_REGION, _P_I32, c_vp, c_vp, c_vp]),
     "me_coords_quantize_labels": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp]),
     "me_segment_sum_f32": (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp]),
+    "me_conv_f32x3_supported": (c_i32, [c_i32, c_i32]),
+    "me_debug_conv_timing_f32x3": (ctypes.c_int, [c_vp, c_i32]),
+    "me_conv_plan_config_f32x3": (ctypes.c_int, [c_i64, c_i64, c_i64, c_i32, c_i32, _P_I32, _P_I32]),
+    "me_conv_packed_weight_elems_f32x3": (c_i64, [c_i64, c_i32, c_i32]),
+    "me_conv_pack_weights_f32x3": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "me_conv_target_f32x3": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                            c_vp, c_i64, c_i32, c_i32, c_vp]),
     "me_conv_plan_config_bf16": (ctypes.c_int, [c_i64, c_i64, c_i64, c_i32, c_i32, _P_I32, _P_I32]),
     "me_conv_packed_weight_elems_bf16": (c_i64, [c_i64, c_i32, c_i32]),
     "me_conv_pack_weights_bf16": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),

@@ -926,6 +926,9 @@ CoordinateMapManagerGPU_default = CoordinateMapManagerGPU_c10
 # convolution operators (src/convolution_gpu.cu:45-244, src/convolution_transpose_gpu.cu)
 # ------------------------------------------------------------------------------------------------
 _BF16_GATHER = os.environ.get("ME_AMD_BF16_GATHER", "0") != "0"   # bf16: output-stationary kernel (opt-in: measured slower than the tile-plan kernel)
+# fp32 features: forward / dgrad on the bf16 matrix pipe with exactly split operands (csrc/conv_f32x3.hip; fp32-grade
+# results); "0" = the fp32-MFMA kernels k_conv_tile_f32
+_F32_SPLIT = os.environ.get("ME_AMD_F32_SPLIT", "1") != "0"
 _ALGO = os.environ.get("ME_AMD_CONV_ALGO", "mfma")  # "naive" = VALU/atomics cross-check kernels
 _WGRAD_TUNING = False  # set by the tuning scripts, which flip the wgrad debug switches between calls: the
                        # workspace size is then re-queried on every call instead of cached per kernel map
@@ -980,11 +983,11 @@ def _timed(name, device, launch, flops=0.0):
     return r
 
 
-def plan_config(n_tgt, volume, n_pairs, c_src, c_dst, bf16=False):
+def plan_config(n_tgt, volume, n_pairs, c_src, c_dst, bf16=False, split=False):
     """(tile_rows, batch_groups) of the tile plan for a (target rows, channels) problem."""
     lib = _lib.load()
     t, g = ctypes.c_int32(0), ctypes.c_int32(0)
-    fn = lib.me_conv_plan_config_bf16 if bf16 else lib.me_conv_plan_config
+    fn = lib.me_conv_plan_config_bf16 if bf16 else (lib.me_conv_plan_config_f32x3 if split else lib.me_conv_plan_config)
     _lib.check(fn(n_tgt, volume, n_pairs, c_src, c_dst, ctypes.byref(t), ctypes.byref(g)))
     return _TILE_ROWS or int(t.value), _BATCH_GROUPS or int(g.value)
 
@@ -1022,12 +1025,14 @@ def _conv_target(src_feat, kernel, km, target, n_tgt, name="conv_target", transp
                 out.data_ptr(), n_tgt, stream)), flops=2.0 * km.n_pairs * c_src * c_dst if KERNEL_TIMER else 0.0)
         return out
     # launch geometry of this (map side, channel shape, dtype): computed once per kernel map
-    ck = (target, c_src, c_dst, bf16, _TILE_ROWS, _BATCH_GROUPS, _SPATIAL_TILES)
+    split = (not bf16) and _F32_SPLIT and bool(lib.me_conv_f32x3_supported(c_src, c_dst))
+    ck = (target, c_src, c_dst, bf16, split, _TILE_ROWS, _BATCH_GROUPS, _SPATIAL_TILES)
     cfg = km._launch_cache.get(ck)
     if cfg is None:
-        tile_rows, batch_groups = plan_config(n_tgt, km.volume, km.n_pairs, c_src, c_dst, bf16)
+        tile_rows, batch_groups = plan_config(n_tgt, km.volume, km.n_pairs, c_src, c_dst, bf16, split)
         plan_src, plan_dst, batch_desc, tile_bptr, _ = km.plan(target, tile_rows, batch_groups)
-        elems = int((lib.me_conv_packed_weight_elems_bf16 if bf16 else lib.me_conv_packed_weight_elems)(
+        elems = int((lib.me_conv_packed_weight_elems_bf16 if bf16 else
+                     (lib.me_conv_packed_weight_elems_f32x3 if split else lib.me_conv_packed_weight_elems))(
             volume, c_src, c_dst))
         order = km.order(target)
         cfg = (tile_rows, batch_groups, plan_src, plan_dst, batch_desc, tile_bptr, order, elems,
@@ -1049,6 +1054,14 @@ def _conv_target(src_feat, kernel, km, target, n_tgt, name="conv_target", transp
                 p_desc, p_bptr, p_order, out.data_ptr(), n_tgt, tile_rows, batch_groups, stream)), flops=flops)
             return out
         _check(kernel.dtype == torch.float32, "float32 features need a float32 kernel, got", kernel.dtype)
+        if split:
+            packed = torch.empty(elems, dtype=torch.bfloat16, device=dev)
+            _lib.check(lib.me_conv_pack_weights_f32x3(kernel.data_ptr(), volume, c_src, c_dst, 1 if transposed else 0,
+                                                      packed.data_ptr(), stream))
+            _timed(name, dev, lambda: _lib.check(lib.me_conv_target_f32x3(
+                src_feat.data_ptr(), src_feat.shape[0], c_src, packed.data_ptr(), km.volume, c_dst, p_src, p_dst,
+                p_desc, p_bptr, p_order, out.data_ptr(), n_tgt, tile_rows, batch_groups, stream)), flops=flops)
+            return out
         packed = torch.empty(elems, dtype=torch.float32, device=dev)
         _lib.check(lib.me_conv_pack_weights_f32(kernel.data_ptr(), volume, c_src, c_dst, 1 if transposed else 0,
                                                 packed.data_ptr(), stream))

@@ -1628,7 +1628,10 @@ int plan_tile_rows(const PlanShape &s, int64_t n_tgt, int64_t volume, int64_t n_
   double best_cost = 1e300;
   int best_t = 128;
   // resident workgroups per CU: 3 waves per SIMD by registers (__launch_bounds__(NC * 4, 3)), then the LDS
-  for (int occ = 12 / waves; occ >= 1; --occ) {
+  int occ_max = 12 / waves;
+  if (s.max_occ > 0 && s.max_occ < occ_max) occ_max = s.max_occ;
+  if (occ_max < 1) occ_max = 1;
+  for (int occ = occ_max; occ >= 1; --occ) {
     const int64_t slots = (int64_t)cus * occ;
     for (int rounds = 1; rounds <= 64; ++rounds) {
       int64_t t = ceil_div(n_tgt * s.slabs, slots * rounds);

@@ -19,9 +19,11 @@
 
 namespace me {
 
-// stage row stride in elements: KC + 8 (16 bytes of padding: 16 rows x one 16-byte piece hit 64 distinct banks)
+// stage row stride in elements: KC + 16 (32 bytes of padding: the 16 (row, piece) accesses of every lane group in
+// which the LDS serves a ds_read_b128 — {0-3,12-15,20-27}, ... — then fall on 16 distinct 16-byte bank slots; with 16
+// bytes of padding, the round-1 layout, they were 2-way conflicting)
 __host__ __device__ constexpr int conv_bf16_lds_bytes(int nc, int kc, int tile_rows, int batch_groups) {
-  return (tile_rows + 1) * (nc + kAccPad) * 4 + batch_groups * 16 * ((kc + 8) * 2 + 4);
+  return (tile_rows + 1) * (nc + kAccPad) * 4 + batch_groups * 16 * ((kc + 16) * 2 + 4);
 }
 
 // R groups of one offset: per 32-channel step one ds_read_b128 per group and one MFMA, issued
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(NC * 4, 3) void k_conv_tile_bf16(
   typedef int i32x2 __attribute__((ext_vector_type(2)));
   constexpr int WAVES = NC / 16;
   constexpr int NT = WAVES * 64;
-  constexpr int A_LD = KC + 8;         // bf16 elements
+  constexpr int A_LD = KC + 16;        // bf16 elements
   constexpr int ACC_LD = NC + kAccPad;
   constexpr int KS = KC / 32;          // MFMA steps per chunk (= 16-byte weight registers per lane)
   constexpr int F8 = KC / 8;           // 16-byte pieces per gathered row
@@ -539,7 +541,7 @@ int me_conv_plan_config_bf16(int64_t n_tgt, int64_t volume, int64_t n_pairs, int
   s.slabs = v.slabs;
   s.chunks = (int)ceil_div(c_src, v.kc);
   s.group_cycles = 64.0 + (v.kc / 32) * 24.0;  // LDS-bound: accumulator read-add-write + operand reads
-  s.stage_row_bytes = (v.kc + 8) * 2 + 4;
+  s.stage_row_bytes = (v.kc + 16) * 2 + 4;
   *tile_rows = plan_tile_rows(s, n_tgt, volume, n_pairs);
   return 0;
 }

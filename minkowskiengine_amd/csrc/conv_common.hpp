@@ -30,6 +30,7 @@ struct PlanShape {
   int nc, slabs, chunks;   // columns per workgroup, column slabs, source-channel chunks
   double group_cycles;     // matrix-pipe (or LDS) cycles of one 16-row group and chunk in one wave
   int stage_row_bytes;     // LDS bytes per staged row (+ its target index)
+  int max_occ = 0;         // resident workgroups per CU the kernel's registers allow (0: three waves per SIMD)
 };
 int plan_tile_rows(const PlanShape &s, int64_t n_tgt, int64_t volume, int64_t n_pairs);
 

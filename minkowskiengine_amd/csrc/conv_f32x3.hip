@@ -1,0 +1,552 @@
+// fp32 sparse convolution (forward / dgrad) on the bf16 matrix pipe of gfx950: every fp32 operand is split
+// EXACTLY into three bf16 terms and the product is rebuilt from six v_mfma_f32_16x16x32_bf16 ("bf16x6", the
+// 3xTF32 idea with three terms), accumulated in fp32.
+//
+// Why: an fp32 MFMA (v_mfma_f32_16x16x4_f32, 157 TFLOP/s) blocks its SIMD for every other wave and
+// k_conv_tile_f32 sits at 0.5 of that peak; the bf16 pipe is 16x faster per product and co-issues with vector
+// instructions.  Six bf16 MFMAs per 32 channels cost 96 cycles against 256 for eight fp32 MFMAs.
+//
+// Arithmetic.  a = a1 + a2 + a3 exactly, where a1 = the upper 16 bits of a's fp32 encoding (a bf16 by truncation),
+// a2 = the upper 16 bits of (a - a1), a3 = a - a1 - a2 (at most 8 significant bits are left, so it IS a bf16);
+// all subtractions are exact in fp32.  Then  a * b = a1 b1 + (a1 b2 + a2 b1) + (a1 b3 + a2 b2 + a3 b1) + rest,
+// |rest| = |a2 b3 + a3 b2 + a3 b3| < 2^-23 |a b|: the dropped terms are below one fp32 rounding of the product.
+// bf16 x bf16 products are exact in fp32 and the MFMA accumulates in fp32, so the result differs from an fp32 FMA
+// chain by rounding noise of the same order (tests: <= 2e-6 of sum |a b| against float64; the reference operators
+// themselves are at 1e-6).  Sums run in the plan's fixed order: bitwise reproducible.  Non-finite inputs: an
+// infinity turns into NaN (inf - inf in the split) where fp32 arithmetic would keep the infinity.
+//
+// Structure: the tile-plan kernel of conv_bf16.hip (target-stationary, fp32 accumulator tile in LDS, single-offset
+// batches, heaviest-first tile order) with fp32 rows gathered into registers, split while they are written to the
+// three LDS stage planes, and fp32 output.  The reference computes this path in fp32
+// (src/convolution_gpu.cu:137-155, AT_DISPATCH_FLOATING_TYPES).
+#include "conv_common.hpp"
+
+namespace me {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Stage rows are padded by 32 bytes: with row strides of KC * 2 + 32 bytes the 16 (row, 8-channel piece) accesses
+// of every lane group in which the LDS serves a ds_read_b128 ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...) fall on 16
+// distinct 16-byte bank slots; 16 bytes of padding (the first layout) left them 2-way conflicting, and the operand
+// reads are the largest LDS stream of the kernel.
+constexpr int kStagePadX3 = 16;   // bf16 elements
+
+// waves of a workgroup: NC / 16 column blocks x GS group shares (wave = share * (NC / 16) + column block); a share
+// takes every GS-th group of a batch, so that narrow column slabs still put two waves on every SIMD
+__host__ __device__ constexpr int x3_group_shares(int nc) { return nc >= 96 ? 1 : (nc == 64 ? 2 : 4); }
+
+__host__ __device__ constexpr int conv_f32x3_lds_bytes(int nc, int kc, int tile_rows, int batch_groups) {
+  return (tile_rows + 1) * (nc + kAccPad) * 4 + batch_groups * 16 * (3 * (kc + kStagePadX3) * 2 + 4);
+}
+
+// eight fp32 values -> the three bf16 planes of the exact split (see the header)
+__device__ __forceinline__ void split3(const f32x4 &lo, const f32x4 &hi, u32x4 &p1, u32x4 &p2, u32x4 &p3) {
+  float a[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+  uint32_t b1[8], b2[8], b3[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    b1[e] = __float_as_uint(a[e]);
+    const float r = a[e] - __uint_as_float(b1[e] & 0xffff0000u);
+    b2[e] = __float_as_uint(r);
+    b3[e] = __float_as_uint(r - __uint_as_float(b2[e] & 0xffff0000u));
+  }
+  // upper halves of two encodings -> one dword (element 2j in the lower half)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    p1[j] = __builtin_amdgcn_perm(b1[2 * j + 1], b1[2 * j], 0x07060302u);
+    p2[j] = __builtin_amdgcn_perm(b2[2 * j + 1], b2[2 * j], 0x07060302u);
+    p3[j] = __builtin_amdgcn_perm(b3[2 * j + 1], b3[2 * j], 0x07060302u);
+  }
+}
+
+// Packed weights: for offset k, source-channel chunk c, 16-column block cb, split plane p (0..2) and 32-channel
+// step v, lane (q = lane >> 4, i16 = lane & 15) finds the plane-p terms of
+//   W[k][c*KC + v*32 + q*8 + j][cb*16 + i16],  j = 0..7
+// as ONE 16-byte element at (((((k*nchunks + c)*ncb + cb)*3 + p)*(KC/32) + v)*64 + lane); zero beyond the real
+// channel counts.
+template <int KC>
+__global__ __launch_bounds__(256) void k_pack_weights_f32x3(const float *__restrict__ w, int c_src, int c_dst,
+                                                           int transposed, int nchunks, int ncb,
+                                                           u32x4 *__restrict__ wp, int64_t total) {
+  constexpr int KS = KC / 32;
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one (k, c, cb, v, lane): writes 3 planes
+  if (e >= total) return;
+  const int lane = (int)(e % 64);
+  int64_t r = e / 64;
+  const int v = (int)(r % KS);
+  r /= KS;
+  const int cb = (int)(r % ncb);
+  r /= ncb;
+  const int c = (int)(r % nchunks);
+  const int64_t k = r / nchunks;
+  const int q = lane >> 4, i16 = lane & 15;
+  const int col = cb * 16 + i16;
+  float val[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int ch = c * KC + v * 32 + q * 8 + j;
+    val[j] = 0.f;
+    if (ch < c_src && col < c_dst) {
+      // plain: w is [K, c_src, c_dst]; transposed (dgrad): w is the forward kernel [K, c_dst, c_src]
+      const int64_t idx = transposed ? (k * c_dst + col) * c_src + ch : (k * c_src + ch) * c_dst + col;
+      val[j] = w[idx];
+    }
+  }
+  u32x4 p1, p2, p3;
+  split3(f32x4{val[0], val[1], val[2], val[3]}, f32x4{val[4], val[5], val[6], val[7]}, p1, p2, p3);
+  const int64_t base = ((((k * nchunks + c) * ncb + cb) * 3) * KS + v) * 64 + lane;
+  wp[base] = p1;
+  wp[base + (int64_t)KS * 64] = p2;
+  wp[base + (int64_t)2 * KS * 64] = p3;
+}
+
+// R groups of one offset.  Per 32-channel step and group: the three planes of the rows (3 ds_read_b128) and six
+// MFMAs, smallest terms first; A = weights, B = rows, so a lane ends with 4 consecutive output columns of one
+// target row.  The accumulators start from the LDS tile (rows of a single-offset batch are distinct and the
+// columns are wave-private), so the accumulate is a plain store.
+template <int R, int GS, int KS, int A_LD, int PLANE, int ACC_LD>
+__device__ __forceinline__ void mma_groups_f32x3(const __bf16 *__restrict__ a0p, const bf16x8 (&w)[3][KS],
+                                                 const int32_t *__restrict__ dstp, float *__restrict__ accp) {
+  int d[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) d[r] = (int)__umul24((unsigned)dstp[r * GS * 16], (unsigned)ACC_LD);
+  f32x4 acc[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) acc[r] = *reinterpret_cast<const f32x4 *>(accp + d[r]);
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    bf16x8 a[R][3];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        a[r][p] = *reinterpret_cast<const bf16x8 *>(a0p + p * PLANE + r * GS * 16 * A_LD + s * 32);
+    }
+    // (weight plane, row plane) by ascending magnitude: 2^-16 terms, 2^-8 terms, leading term
+    constexpr int WP[6] = {2, 0, 1, 1, 0, 0};
+    constexpr int AP[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[WP[t]][s], a[r][AP[t]], acc[r], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) *reinterpret_cast<f32x4 *>(accp + d[r]) = acc[r];
+}
+
+// See k_conv_tile_bf16 (conv_bf16.hip) / k_conv_tile_f32 (conv.hip) for the pipeline.
+// EXACT: c_src is a multiple of KC.  SMALL: 32-bit gather offsets (host-checked: < 2^24 rows, source < 4 GiB).
+// c_src % 8 == 0 is required (a 32-byte piece is wholly inside the row or wholly beyond it).
+// phase cycle counters of the TIMED instrumentation build (debug variant 256; s_memtime ticks summed over wave 0 of
+// every workgroup): barrier A, split + stage write (incl. the wait for the rows), barrier B, load issue, multiply,
+// prologue, epilogue; [7] = batches
+__device__ unsigned long long d_x3_timing[8];
+
+template <int NC, int KC, bool EXACT, bool SMALL, bool TIMED = false>
+__global__ __launch_bounds__(NC * 4 * x3_group_shares(NC), 1) void k_conv_tile_f32x3(
+    const float *__restrict__ src, int c_src, const bf16x8 *__restrict__ wp, int c_dst,
+    const int32_t *__restrict__ plan_src, const int32_t *__restrict__ plan_dst,
+    const int32_t *__restrict__ batch_desc, const int32_t *__restrict__ tile_bptr,
+    const int32_t *__restrict__ order, float *__restrict__ dst, int64_t n_tgt, int tile_rows, int batch_groups) {
+  typedef int i32x2 __attribute__((ext_vector_type(2)));
+  constexpr int GS = x3_group_shares(NC);
+  constexpr int CBW = NC / 16;         // column blocks (waves per group share)
+  constexpr int WAVES = CBW * GS;
+  constexpr int NT = WAVES * 64;
+  constexpr int A_LD = KC + kStagePadX3;   // bf16 elements per staged row and plane
+  constexpr int ACC_LD = NC + kAccPad;
+  constexpr int KS = KC / 32;
+  constexpr int F8 = KC / 8;           // 8-channel pieces per gathered row (32 bytes of fp32)
+  constexpr int ITER = (ME_MAX_BATCH_GROUPS * 16 * F8 + NT - 1) / NT;
+  constexpr int PLANE = ME_MAX_BATCH_GROUPS * 16 * A_LD;   // elements between the planes of the stage buffer
+  static_assert(KC % 32 == 0, "KC must be a multiple of 32");
+  static_assert(ME_MAX_BATCH_GROUPS == 4, "mma_groups runs cover at most 4 groups");
+
+  const int cap_rows = batch_groups * 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *s_acc = reinterpret_cast<float *>(smem);                              // [(tile_rows + 1) x ACC_LD]
+  __bf16 *s_a = reinterpret_cast<__bf16 *>(s_acc + (tile_rows + 1) * ACC_LD);  // [3][64 x A_LD]
+  int32_t *s_dst = reinterpret_cast<int32_t *>(s_a + 3 * PLANE);               // [64]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15;
+  const int q = lane >> 4;
+  const int tile = tile_bptr[gridDim.x + 1 + blockIdx.x];   // heaviest-first dispatch order (me_plan_build)
+  const int col_base = blockIdx.y * NC;
+  const int nchunks = (c_src + KC - 1) / KC;
+  const int ncb = (c_dst + 15) / 16;
+  const int wcb = wave % CBW;          // column block of this wave inside the slab
+  const int share = wave / CBW;        // its groups of a batch: share, share + GS, ...
+  const int cb = min(col_base / 16 + wcb, ncb - 1);
+
+  unsigned long long tm[7] = {0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_prev = TIMED ? __builtin_amdgcn_s_memtime() : 0ull;
+  auto tick = [&](int slot) {
+    if (TIMED) {
+      const unsigned long long now = __builtin_amdgcn_s_memtime();
+      tm[slot] += now - t_prev;
+      t_prev = now;
+    }
+  };
+  for (int x = tid; x < (tile_rows + 1) * ACC_LD / 4; x += NT)
+    reinterpret_cast<f32x4 *>(s_acc)[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int ORD = (ME_MAX_TILE_ROWS + NT - 1) / NT;
+  int32_t my_ord[ORD];
+#pragma unroll
+  for (int j = 0; j < ORD; ++j) {
+    const int r = j * NT + tid;
+    my_ord[j] = (order != nullptr && r < tile_rows && (int64_t)tile * tile_rows + r < n_tgt)
+                    ? order[(int64_t)tile * tile_rows + r] : 0;
+  }
+
+  const int b0 = tile_bptr[tile];
+  const int nb = tile_bptr[tile + 1] - b0;
+  const int n_it = nb * nchunks;
+
+  auto locate = [&](int it, int &chunk, int &g0, int &ng, int &k) {
+    int r = min(it, n_it - 1);
+    chunk = 0;
+    while (r >= nb) {
+      r -= nb;
+      ++chunk;
+    }
+    const i32x2 d = *reinterpret_cast<const i32x2 *>(batch_desc + 2 * (int64_t)(b0 + r));
+    g0 = d.x;
+    ng = d.y & 255;
+    k = (int)((uint32_t)d.y >> 8);
+  };
+
+  // Two batches of gathered rows are in flight (round-2 measurement: with one, a batch lasted a whole gather
+  // latency, ~2500 cycles, however little work it held): batch x uses register slot x & 1 for its rows, target
+  // indices and source indices.  Issue order inside an iteration — indices (b + 3), weights (b + 1), rows (b + 2) —
+  // is what lets the counted s_waitcnt of each consumer leave the younger loads outstanding.
+  f32x4 stage[2][ITER][2];
+  int32_t dstv[2] = {tile_rows, tile_rows};
+  int32_t sidx[2][ITER];
+  bf16x8 wreg[3][KS], wnxt[3][KS];
+
+  // the 64-entry index window of a batch is read to its end unconditionally (the plan is followed by 64 valid
+  // entries; threads beyond the window — wide workgroups on narrow chunks — re-read its last entry); padding slots
+  // (index -1) gather row 0 and their products land in the dummy accumulator row
+  auto load_sidx = [&](int g0, int32_t (&sx)[ITER]) {
+    const char *pb = reinterpret_cast<const char *>(plan_src + (int64_t)g0 * 16);
+#pragma unroll
+    for (int j = 0; j < ITER; ++j)
+      sx[j] = *reinterpret_cast<const int32_t *>(pb + (unsigned)(min((j * NT + tid) / F8, ME_MAX_BATCH_GROUPS * 16 - 1) * 4));
+  };
+  const char *srcb = reinterpret_cast<const char *>(src);
+  const unsigned row_bytes = (unsigned)c_src * 4u;
+  auto gather = [&](int chunk, int g0, const int32_t (&sx)[ITER], f32x4 (&st)[ITER][2], int32_t &dv) {
+    const int c0 = chunk * KC;
+    dv = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(plan_dst + (int64_t)g0 * 16) +
+                                           (unsigned)(min(tid, ME_MAX_BATCH_GROUPS * 16 - 1) * 4));
+#pragma unroll
+    for (int j = 0; j < ITER; ++j) {
+      const int ch = c0 + ((j * NT + tid) % F8) * 8;
+      const int chl = EXACT ? ch : min(ch, c_src - 8);
+      const int sr = max(sx[j], 0);
+      const f32x4 *p;
+      if (SMALL) p = reinterpret_cast<const f32x4 *>(srcb + (__umul24((unsigned)sr, row_bytes) + (unsigned)chl * 4u));
+      else p = reinterpret_cast<const f32x4 *>(src + (int64_t)sr * c_src + chl);
+      st[j][0] = p[0];
+      st[j][1] = p[1];
+    }
+  };
+  auto write_stage = [&](int chunk, const f32x4 (&st)[ITER][2], int32_t dv) {
+    const int c0 = chunk * KC;
+#pragma unroll
+    for (int j = 0; j < ITER; ++j) {
+      const int idx = j * NT + tid;
+      const int r = idx / F8;
+      const int ch = c0 + (idx % F8) * 8;
+      u32x4 p1, p2, p3;
+      split3(st[j][0], st[j][1], p1, p2, p3);
+      if (!EXACT && ch >= c_src) p1 = p2 = p3 = u32x4{0u, 0u, 0u, 0u};
+      if (r < cap_rows) {
+        __bf16 *o = &s_a[r * A_LD + (idx % F8) * 8];
+        *reinterpret_cast<u32x4 *>(o) = p1;
+        *reinterpret_cast<u32x4 *>(o + PLANE) = p2;
+        *reinterpret_cast<u32x4 *>(o + 2 * PLANE) = p3;
+      }
+    }
+    if (tid < cap_rows) s_dst[tid] = dv;
+  };
+  auto load_w = [&](int chunk, int k) {
+    const bf16x8 *p = wp + (((((int64_t)k * nchunks + chunk) * ncb + cb) * 3) * KS) * 64 + lane;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+      for (int v = 0; v < KS; ++v) wnxt[pl][v] = p[(pl * KS + v) * 64];
+    }
+  };
+
+  if (n_it > 0) {
+    int chA, gA, nA, kA, chB, gB, nB, kB, chC, gC, nC, kC, chD, gD, nD, kD;
+    locate(0, chA, gA, nA, kA);
+    locate(1, chB, gB, nB, kB);
+    locate(2, chC, gC, nC, kC);
+    locate(3, chD, gD, nD, kD);
+    load_sidx(gA, sidx[0]);
+    load_sidx(gB, sidx[1]);
+    load_w(chA, kA);
+    gather(chA, gA, sidx[0], stage[0], dstv[0]);
+    gather(chB, gB, sidx[1], stage[1], dstv[1]);
+    load_sidx(gC, sidx[0]);
+    tick(5);
+
+    // one batch; SLOT = its parity
+    auto iteration = [&](int it, f32x4 (&st)[ITER][2], int32_t &dv, int32_t (&sx_cur)[ITER], int32_t (&sx_far)[ITER]) {
+      __syncthreads();
+      tick(0);
+      write_stage(chA, st, dv);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+        for (int sx = 0; sx < KS; ++sx) wreg[pl][sx] = wnxt[pl][sx];
+      }
+      if (TIMED) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      tick(1);
+      __syncthreads();
+      tick(2);
+      load_sidx(gD, sx_far);              // batch it + 3 (its slot held the indices of batch it + 1: consumed)
+      load_w(chB, kB);                    // batch it + 1
+      gather(chC, gC, sx_cur, st, dv);    // batch it + 2 into the slot just written to LDS
+      tick(3);
+      {
+        const __bf16 *a0p = &s_a[(share * 16 + i16) * A_LD + q * 8];
+        const int32_t *dstp = &s_dst[share * 16 + i16];
+        float *accp = &s_acc[wcb * 16 + q * 4];
+        const int mine = (nA - share + GS - 1) / GS;     // groups share, share + GS, ... below nA
+        if constexpr (GS == 1) {
+          if (mine >= 4) mma_groups_f32x3<4, GS, KS, A_LD, PLANE, ACC_LD>(a0p, wreg, dstp, accp);
+          else if (mine == 3) mma_groups_f32x3<3, GS, KS, A_LD, PLANE, ACC_LD>(a0p, wreg, dstp, accp);
+        }
+        if constexpr (GS <= 2) {
+          if (mine == 2) mma_groups_f32x3<2, GS, KS, A_LD, PLANE, ACC_LD>(a0p, wreg, dstp, accp);
+        }
+        if (mine == 1) mma_groups_f32x3<1, GS, KS, A_LD, PLANE, ACC_LD>(a0p, wreg, dstp, accp);
+      }
+      if (TIMED) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      tick(4);
+      chA = chB; gA = gB; nA = nB; kA = kB;
+      chB = chC; gB = gC; nB = nC; kB = kC;
+      chC = chD; gC = gD; nC = nD; kC = kD;
+      locate(it + 4, chD, gD, nD, kD);
+    };
+    int it = 0;
+    for (; it + 1 < n_it; it += 2) {
+      iteration(it, stage[0], dstv[0], sidx[0], sidx[1]);
+      iteration(it + 1, stage[1], dstv[1], sidx[1], sidx[0]);
+    }
+    if (it < n_it) iteration(it, stage[0], dstv[0], sidx[0], sidx[1]);
+  }
+  __syncthreads();
+
+  // every target row of the tile is written exactly once (rows without neighbours get zeros)
+  const int64_t row0 = (int64_t)tile * tile_rows;
+  const int rows_here = (int)min((int64_t)tile_rows, n_tgt - row0);
+  const bool vec_out = (c_dst % 4) == 0;
+  int32_t *s_ord = reinterpret_cast<int32_t *>(s_a);   // the stage buffer is free now
+  if (order != nullptr) {
+#pragma unroll
+    for (int j = 0; j < ORD; ++j)
+      if (j * NT + tid < tile_rows) s_ord[j * NT + tid] = my_ord[j];
+    __syncthreads();
+  }
+  for (int x = tid; x < tile_rows * NC / 4; x += NT) {
+    const int row = x / (NC / 4);
+    const int c4 = x % (NC / 4);
+    const int cc = col_base + c4 * 4;
+    if (row < rows_here && cc < c_dst) {
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(&s_acc[row * ACC_LD + c4 * 4]);
+      const int64_t grow = order ? (int64_t)s_ord[row] : row0 + row;
+      float *o = dst + grow * c_dst + cc;
+      if (vec_out) {
+        *reinterpret_cast<f32x4 *>(o) = v;
+      } else {
+        o[0] = v.x;
+        if (cc + 1 < c_dst) o[1] = v.y;
+        if (cc + 2 < c_dst) o[2] = v.z;
+        if (cc + 3 < c_dst) o[3] = v.w;
+      }
+    }
+  }
+  if (TIMED) {
+    tick(6);
+    if (tid == 0) {
+#pragma unroll
+      for (int t = 0; t < 7; ++t) atomicAdd(&d_x3_timing[t], tm[t]);
+      atomicAdd(&d_x3_timing[7], (unsigned long long)n_it);
+    }
+  }
+}
+
+extern int g_conv_variant;  // conv.hip: variant 6 = 64-bit gather addresses, 256 = phase counters
+
+struct ConvVariantX3 {
+  int nc, slabs, kc;
+};
+
+static ConvVariantX3 conv_variant_f32x3(int c_src, int c_dst) {
+  ConvVariantX3 v;
+  // as many columns per workgroup as there are (up to 128, eight waves): the gather, the split and the stage writes
+  // of a batch are paid once per workgroup, and with the cheap bf16 MFMAs they, not the matrix pipe, are the cost
+  if (c_dst % 128 == 0) v.nc = 128;
+  else if (c_dst % 96 == 0) v.nc = 96;
+  else v.nc = c_dst <= 32 ? 32 : 64;
+  v.slabs = (int)ceil_div(c_dst, v.nc);
+  // widest chunk that tiles the source channels (one pass over the plan per chunk); 128 only next to <= 64 columns
+  // (accumulator tile + three stage planes must fit the LDS)
+  if (c_src % 128 == 0 && v.nc <= 64) v.kc = 128;
+  else if (c_src % 64 == 0) v.kc = 64;
+  else if (c_src % 96 == 0) v.kc = 96;
+  else v.kc = c_src <= 32 ? 32 : 64;
+  return v;
+}
+
+template <int NC, int KC>
+static int launch_conv_tile_f32x3(const float *src, int c_src, const bf16x8 *wp, int c_dst, int slabs,
+                                  const int32_t *plan_src, const int32_t *plan_dst, const int32_t *batch_desc,
+                                  const int32_t *tile_bptr, const int32_t *order, float *dst, int64_t n_tgt,
+                                  int tile_rows, int batch_groups, hipStream_t stream, bool small) {
+  const int lds = conv_f32x3_lds_bytes(NC, KC, tile_rows, ME_MAX_BATCH_GROUPS);
+  ME_CHECK(lds <= kLdsBudget, "tile_rows too large for the LDS of one workgroup");
+  const bool exact = (c_src % KC) == 0;
+  typedef void (*kernel_t)(const float *, int, const bf16x8 *, int, const int32_t *, const int32_t *, const int32_t *,
+                           const int32_t *, const int32_t *, float *, int64_t, int, int);
+  kernel_t fn = small ? (exact ? &k_conv_tile_f32x3<NC, KC, true, true> : &k_conv_tile_f32x3<NC, KC, false, true>)
+                      : (exact ? &k_conv_tile_f32x3<NC, KC, true, false> : &k_conv_tile_f32x3<NC, KC, false, false>);
+  constexpr bool kHasTimed = KC >= 64 && NC >= 64;   // instrumented build: the headline shapes only
+  bool timed = false;
+  if constexpr (kHasTimed) {
+    if (g_conv_variant == 256 && small && exact) {
+      fn = &k_conv_tile_f32x3<NC, KC, true, true, true>;
+      timed = true;
+    }
+  }
+  static bool attr_set[5] = {false, false, false, false, false};  // per instantiation
+  const int which = timed ? 4 : (small ? 2 : 0) + (exact ? 1 : 0);
+  if (lds > 48 * 1024 && !attr_set[which]) {
+    ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               kLdsBudget));
+    attr_set[which] = true;
+  }
+  const dim3 grid((unsigned)ceil_div(n_tgt, tile_rows), (unsigned)slabs);
+  hipLaunchKernelGGL(fn, grid, dim3(NC * 4 * x3_group_shares(NC)), (size_t)lds, stream, src, c_src, wp, c_dst, plan_src, plan_dst, batch_desc,
+                     tile_bptr, order, dst, n_tgt, tile_rows, batch_groups);
+  ME_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // namespace me
+
+using namespace me;
+
+extern "C" {
+
+int me_debug_conv_timing_f32x3(uint64_t *out8, int32_t reset) {
+  unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (out8 != nullptr) {
+    ME_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(d_x3_timing), sizeof(h)));
+    for (int i = 0; i < 8; ++i) out8[i] = h[i];
+  }
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    ME_HIP(hipMemcpyToSymbol(HIP_SYMBOL(d_x3_timing), z, sizeof(z)));
+  }
+  return 0;
+}
+
+int32_t me_conv_f32x3_supported(int32_t c_src, int32_t c_dst) { return (c_src >= 8 && c_src % 8 == 0 && c_dst > 0) ? 1 : 0; }
+
+int me_conv_plan_config_f32x3(int64_t n_tgt, int64_t volume, int64_t n_pairs, int32_t c_src, int32_t c_dst,
+                              int32_t *tile_rows, int32_t *batch_groups) {
+  ME_CHECK(tile_rows != nullptr && batch_groups != nullptr, "output pointers must not be null");
+  *tile_rows = 128;
+  *batch_groups = ME_MAX_BATCH_GROUPS;
+  if (n_tgt <= 0 || volume <= 0 || c_src <= 0 || c_dst <= 0) return 0;
+  const ConvVariantX3 v = conv_variant_f32x3(c_src, c_dst);
+  PlanShape s;
+  s.nc = v.nc;
+  s.slabs = v.slabs;
+  s.chunks = (int)ceil_div(c_src, v.kc);
+  s.group_cycles = 64.0 + (v.kc / 32) * 96.0;   // six MFMAs per 32 channels + the accumulator round trip
+  s.stage_row_bytes = 3 * (v.kc + kStagePadX3) * 2 + 4;
+  s.max_occ = 1;   // eight waves per workgroup (six for 96 columns)
+  *tile_rows = plan_tile_rows(s, n_tgt, volume, n_pairs);
+  return 0;
+}
+
+int64_t me_conv_packed_weight_elems_f32x3(int64_t volume, int32_t c_src, int32_t c_dst) {   /* bf16 elements */
+  if (volume <= 0 || c_src <= 0 || c_dst <= 0) return 0;
+  const ConvVariantX3 v = conv_variant_f32x3(c_src, c_dst);
+  return 3 * volume * align_up(c_src, v.kc) * align_up(c_dst, 16);
+}
+
+int me_conv_pack_weights_f32x3(const float *w, int64_t volume, int32_t c_src, int32_t c_dst, int32_t transposed,
+                               uint16_t *wp, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ME_CHECK(volume >= 1 && c_src > 0 && c_dst > 0, "invalid weight shape");
+  ME_CHECK((uintptr_t)wp % 16 == 0, "packed weights must be 16-byte aligned");
+  const ConvVariantX3 v = conv_variant_f32x3(c_src, c_dst);
+  const int nchunks = (int)ceil_div(c_src, v.kc), ncb = (int)ceil_div(c_dst, 16);
+  const int64_t total = volume * nchunks * ncb * (v.kc / 32) * 64;  // threads: one 16-byte element per plane each
+  u32x4 *wp4 = reinterpret_cast<u32x4 *>(wp);
+  const dim3 grid((unsigned)ceil_div(total, 256)), block(256);
+  if (v.kc == 128)
+    hipLaunchKernelGGL((k_pack_weights_f32x3<128>), grid, block, 0, stream, w, c_src, c_dst, transposed, nchunks, ncb, wp4, total);
+  else if (v.kc == 96)
+    hipLaunchKernelGGL((k_pack_weights_f32x3<96>), grid, block, 0, stream, w, c_src, c_dst, transposed, nchunks, ncb, wp4, total);
+  else if (v.kc == 64)
+    hipLaunchKernelGGL((k_pack_weights_f32x3<64>), grid, block, 0, stream, w, c_src, c_dst, transposed, nchunks, ncb, wp4, total);
+  else
+    hipLaunchKernelGGL((k_pack_weights_f32x3<32>), grid, block, 0, stream, w, c_src, c_dst, transposed, nchunks, ncb, wp4, total);
+  ME_LAUNCH_CHECK();
+  return 0;
+}
+
+int me_conv_target_f32x3(const float *src, int64_t n_src, int32_t c_src, const uint16_t *wp_, int64_t volume,
+                         int32_t c_dst, const int32_t *plan_src, const int32_t *plan_dst, const int32_t *batch_desc,
+                         const int32_t *tile_bptr, const int32_t *order, float *dst, int64_t n_tgt, int32_t tile_rows,
+                         int32_t batch_groups, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  (void)volume;
+  ME_CHECK(me_conv_f32x3_supported(c_src, c_dst), "source channels must be a positive multiple of 8 (me_conv_f32x3_supported)");
+  const bool small = n_src > 0 && n_src < (1ll << 24) && n_src * c_src * 4 < (1ll << 32) && g_conv_variant != 6;
+  ME_CHECK(tile_rows >= ME_GROUP_ROWS && tile_rows <= ME_MAX_TILE_ROWS, "tile_rows out of range");
+  ME_CHECK(batch_groups >= 1 && batch_groups <= ME_MAX_BATCH_GROUPS, "batch_groups out of range");
+  ME_CHECK((uintptr_t)src % 16 == 0 && (uintptr_t)dst % 16 == 0 && (uintptr_t)wp_ % 16 == 0,
+           "feature and weight pointers must be 16-byte aligned");
+  if (n_tgt == 0) return 0;
+  const bf16x8 *wp = reinterpret_cast<const bf16x8 *>(wp_);
+  const ConvVariantX3 v = conv_variant_f32x3(c_src, c_dst);
+#define ME_CONV_CASE(NCV, KCV)                                                                                    \
+  return launch_conv_tile_f32x3<NCV, KCV>(src, c_src, wp, c_dst, v.slabs, plan_src, plan_dst, batch_desc, tile_bptr, \
+                                          order, dst, n_tgt, tile_rows, batch_groups, stream, small)
+  if (v.nc == 32) {
+    if (v.kc == 128) ME_CONV_CASE(32, 128);
+    if (v.kc == 96) ME_CONV_CASE(32, 96);
+    if (v.kc == 64) ME_CONV_CASE(32, 64);
+    ME_CONV_CASE(32, 32);
+  } else if (v.nc == 64) {
+    if (v.kc == 128) ME_CONV_CASE(64, 128);
+    if (v.kc == 96) ME_CONV_CASE(64, 96);
+    if (v.kc == 64) ME_CONV_CASE(64, 64);
+    ME_CONV_CASE(64, 32);
+  } else if (v.nc == 96) {
+    if (v.kc == 96) ME_CONV_CASE(96, 96);
+    if (v.kc == 64) ME_CONV_CASE(96, 64);
+    ME_CONV_CASE(96, 32);
+  } else {
+    if (v.kc == 96) ME_CONV_CASE(128, 96);
+    if (v.kc == 64) ME_CONV_CASE(128, 64);
+    ME_CONV_CASE(128, 32);
+  }
+#undef ME_CONV_CASE
+}
+
+}  // extern "C"

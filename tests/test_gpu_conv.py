@@ -47,8 +47,13 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize("pipe", ["bf16x6", "fp32_mfma"])
 @pytest.mark.parametrize("n,extent,D,cin,cout,ks,stride,dil", CONV_CASES)
-def test_conv_forward_backward_vs_oracle(device, n, extent, D, cin, cout, ks, stride, dil):
+def test_conv_forward_backward_vs_oracle(device, monkeypatch, pipe, n, extent, D, cin, cout, ks, stride, dil):
+    """Both fp32 forward / dgrad kernels: the exactly-split operands on the bf16 matrix pipe (default where
+    c_src % 8 == 0) and the fp32-MFMA kernel (ME_AMD_F32_SPLIT=0, and the fall-back for other channel counts)."""
+    from minkowskiengine_amd import backend as MEB
+    monkeypatch.setattr(MEB, "_F32_SPLIT", pipe == "bf16x6")
     coords = make_cloud(n, extent, D, seed=n + cin, batch=2 if n > 100 else 1, negative=True)
     conv, x, y, feats, gy = _run_layer(device, coords, cin, cout, ks, stride, dil)
     in_c = coords.numpy()
@@ -161,6 +166,7 @@ def test_lds_dma_tile_kernel_matches_the_oracle(device, monkeypatch, cin, cout, 
     from minkowskiengine_amd import _lib
     from minkowskiengine_amd import backend as MEB
     lib = _lib.load()
+    monkeypatch.setattr(MEB, "_F32_SPLIT", False)
     monkeypatch.setattr(MEB, "_SPATIAL_MAPS", spatial)
     monkeypatch.setattr(MEB, "_TILE_ORDER", tile_order)
     monkeypatch.setattr(MEB, "_TILE_ROWS", T)
@@ -180,6 +186,38 @@ def test_lds_dma_tile_kernel_matches_the_oracle(device, monkeypatch, cin, cout, 
     gi, gw = O.conv_backward(feats.numpy(), gy.numpy(), w, km)
     assert_close(x.F.grad, gi)
     assert_close(conv.kernel.grad, gw)
+
+
+@pytest.mark.parametrize("cin,cout,scale", [(64, 128, 1.0), (32, 32, 1e-3), (96, 96, 300.0), (256, 64, 1.0)])
+def test_split_bf16_pipe_is_fp32_grade(device, monkeypatch, cin, cout, scale):
+    """k_conv_tile_f32x3 rebuilds every fp32 product from six bf16 MFMAs (a = a1 + a2 + a3 exactly; the dropped terms
+    are < 2^-23 |a b|).  Against float64 ground truth its error must be of fp32 order: per element
+    <= 2e-6 * sum_k |x| |w| (the fp32-MFMA kernel measures ~2e-7 of that sum; bf16 arithmetic would be ~4e-3), for
+    operands across magnitudes, signs and with values whose low mantissa bits are all set; and it must not be worse
+    than 4x the fp32-MFMA kernel's own error."""
+    from minkowskiengine_amd import backend as MEB
+    coords = make_cloud(4000, 12, 3, seed=cin, negative=True)
+    mgr = MEB.CoordinateMapManagerGPU_c10()
+    key, _ = mgr.insert_and_map(coords.to(device), [1, 1, 1], "")
+    km = mgr._kernel_map(key, key, [3] * 3, [1] * 3, [1] * 3, MEB.RegionType.HYPER_CUBE, None, False, False)
+    g = torch.Generator().manual_seed(cin + cout)
+    x = ((torch.rand(4000, cin, generator=g) - 0.5) * scale)
+    x[::7] = torch.nextafter(x[::7], torch.full_like(x[::7], 1e30))        # odd low bits
+    x[5] = 0.0
+    x[6, :] = torch.tensor(1.0 + 2.0 ** -23) * scale                           # 1 + ulp: a2 = 0, a3 carries the bit
+    w = (torch.rand(27, cin, cout, generator=g) - 0.5) / scale
+    _, okm = O.kernel_map(coords.numpy(), coords.numpy(), O.make_region(3, 3))
+    x64, w64 = x.double().numpy(), w.double().numpy()
+    truth = O.conv_forward(x64, w64, okm, len(coords))
+    bound = O.conv_forward(np.abs(x64), np.abs(w64), okm, len(coords))        # sum |x| |w| per output element
+    errs = {}
+    for split in (True, False):
+        monkeypatch.setattr(MEB, "_F32_SPLIT", split)
+        y = MEB._conv_forward(x.to(device), w.to(device), km, "mfma").double().cpu().numpy()
+        errs[split] = float(np.max(np.abs(y - truth) / np.maximum(bound, 1e-300)))
+    print(f"relative to sum|x||w|: bf16x6 {errs[True]:.2e}, fp32 MFMA {errs[False]:.2e}")
+    assert errs[True] <= 2e-6, errs
+    assert errs[True] <= 4 * errs[False] + 1e-7, errs
 
 
 def test_bias_and_use_mm(device):
