@@ -248,8 +248,11 @@ def run_timed(step, args, dist_utils, MEB, dev):
     return min(blocks), blocks, timer, args.steps * len(blocks)
 
 
-def roofline_entry(kernel, flops, compulsory_bytes, avg_ms, bf16, traffic, traffic_src):
-    """the roof is chosen by the launch's arithmetic intensity on its COMPULSORY bytes"""
+def roofline_entry(kernel, flops, compulsory_bytes, avg_ms, bf16, traffic, traffic_src, split=False):
+    """the roof is chosen by the launch's arithmetic intensity on its COMPULSORY bytes.
+    split: an fp32 workload computed by k_conv_tile_f32x3 — `peak` stays the fp32 MFMA peak (the matrix peak of the
+    precision the workload is quoted in, and the line the earlier rounds are compared on); the ceiling of the pipe that
+    kernel actually issues to (six bf16 MFMAs per fp32 product block) is reported next to it."""
     peak_t = PEAK_BF16_MATRIX_TFLOPS if bf16 else PEAK_F32_MATRIX_TFLOPS
     ridge = RIDGE_BF16 if bf16 else RIDGE_F32
     intensity = flops / compulsory_bytes
@@ -265,6 +268,12 @@ def roofline_entry(kernel, flops, compulsory_bytes, avg_ms, bf16, traffic, traff
     else:
         r.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                   "frac": round(gbs / PEAK_HBM_GBS, 4)})
+    if split:
+        pipe_peak = PEAK_BF16_MATRIX_TFLOPS / 6.0
+        r["pipe"] = ("bf16 matrix pipe: fp32 operands split exactly into three bf16 terms, six v_mfma_f32_16x16x32_bf16 "
+                     "per product block, fp32 accumulation (fp32-grade results, tests/test_gpu_conv.py)")
+        r["peak_of_pipe"] = round(pipe_peak, 1)
+        r["frac_of_pipe"] = round(tflops / pipe_peak, 4)
     r["traffic"] = traffic
     r["traffic_note"] = ("HBM-side bytes per launch (FETCH_SIZE x2 + WRITE_SIZE) — a CITED constant from the committed "
                          f"rocprofv3 --pmc passes ({traffic_src}; average of the forward and dgrad launches of the "
@@ -327,9 +336,17 @@ def bench_conv(args, ME, MEB, dist_utils, rank, world, dev, startup):
     if bf16:
         # conv_variant_bf16() of csrc/conv_bf16.hip
         kc = 128 if cin % 128 == 0 else 96 if cin % 96 == 0 else 32 if cin <= 32 else 64 if cin <= 64 else 128
+    from minkowskiengine_amd import _lib
+    split = (not bf16) and MEB._use_split(_lib.load(), cin, cout)
+    if split:
+        # conv_variant_f32x3() of csrc/conv_f32x3.hip: fp32 operands split exactly into three bf16 terms, six bf16 MFMAs
+        nc = 128 if cout % 128 == 0 else 96 if cout % 96 == 0 else 32 if cout <= 32 else 64
+        kc = 128 if cin % 128 == 0 and nc <= 64 else 64 if cin % 64 == 0 else 96 if cin % 96 == 0 else \
+            32 if cin <= 32 else 64
+    kname = "k_conv_tile_bf16" if bf16 else "k_conv_tile_f32x3" if split else "k_conv_tile_f32"
     esz = 2 if bf16 else 4
     compulsory = esz * (n * cin + n * cout + K * cin * cout) + 8 * n_pairs   # SURVEY 8d, forward
-    traffic, traffic_src = pmc_traffic("k_conv_tile_bf16_forward" if bf16 else "k_conv_tile_f32", n, extent, cin,
+    traffic, traffic_src = pmc_traffic("k_conv_tile_bf16_forward" if bf16 else kname, n, extent, cin,
                                        cout) if D == 3 else (None, None)
     ms_step = best / args.steps * 1e3
     line = {
@@ -352,8 +369,8 @@ def bench_conv(args, ME, MEB, dist_utils, rank, world, dev, startup):
                    "blocks_ms_per_step": [round(b / args.steps * 1e3, 4) for b in blocks],
                    "timed_region_s": round(sum(blocks), 4),
                    "reported": "fastest block (max over ranks inside each block)"},
-        "roofline": roofline_entry(f"k_conv_tile_{'bf16' if bf16 else 'f32'}<{nc},{kc}> (forward)", flops_per_launch,
-                                   compulsory, kernels["conv_forward"]["avg_ms"], bf16, traffic, traffic_src),
+        "roofline": roofline_entry(f"{kname}<{nc},{kc}> (forward)", flops_per_launch,
+                                   compulsory, kernels["conv_forward"]["avg_ms"], bf16, traffic, traffic_src, split),
         "kernels": kernels,
         "cold_ms": round(cold_ms, 2),
         "cold_breakdown_ms": {"process_startup_to_first_launch": startup,

@@ -927,8 +927,19 @@ CoordinateMapManagerGPU_default = CoordinateMapManagerGPU_c10
 # ------------------------------------------------------------------------------------------------
 _BF16_GATHER = os.environ.get("ME_AMD_BF16_GATHER", "0") != "0"   # bf16: output-stationary kernel (opt-in: measured slower than the tile-plan kernel)
 # fp32 features: forward / dgrad on the bf16 matrix pipe with exactly split operands (csrc/conv_f32x3.hip; fp32-grade
-# results); "0" = the fp32-MFMA kernels k_conv_tile_f32
-_F32_SPLIT = os.environ.get("ME_AMD_F32_SPLIT", "1") != "0"
+# results).  "auto": where it measured faster than the fp32-MFMA kernel k_conv_tile_f32 — layers with
+# c_src * c_dst >= 8192 (64 -> 128 and wider: 1.1 - 1.6x on every map density tried; below that the per-batch costs of
+# three operand planes outweigh the cheaper MFMAs, profiles/r02_tune_split_policy.log); "1": wherever supported
+# (c_src % 8 == 0); "0": never.
+_F32_SPLIT = {"0": False, "1": True}.get(os.environ.get("ME_AMD_F32_SPLIT", "auto"), "auto")
+
+
+def _use_split(lib, c_src, c_dst):
+    if _F32_SPLIT is False or not lib.me_conv_f32x3_supported(c_src, c_dst):
+        return False
+    return True if _F32_SPLIT is True else c_src * c_dst >= 8192
+
+
 _ALGO = os.environ.get("ME_AMD_CONV_ALGO", "mfma")  # "naive" = VALU/atomics cross-check kernels
 _WGRAD_TUNING = False  # set by the tuning scripts, which flip the wgrad debug switches between calls: the
                        # workspace size is then re-queried on every call instead of cached per kernel map
@@ -1025,7 +1036,7 @@ def _conv_target(src_feat, kernel, km, target, n_tgt, name="conv_target", transp
                 out.data_ptr(), n_tgt, stream)), flops=2.0 * km.n_pairs * c_src * c_dst if KERNEL_TIMER else 0.0)
         return out
     # launch geometry of this (map side, channel shape, dtype): computed once per kernel map
-    split = (not bf16) and _F32_SPLIT and bool(lib.me_conv_f32x3_supported(c_src, c_dst))
+    split = (not bf16) and _use_split(lib, c_src, c_dst)
     ck = (target, c_src, c_dst, bf16, split, _TILE_ROWS, _BATCH_GROUPS, _SPATIAL_TILES)
     cfg = km._launch_cache.get(ck)
     if cfg is None:

@@ -19,24 +19,37 @@
 // batches, heaviest-first tile order) with fp32 rows gathered into registers, split while they are written to the
 // three LDS stage planes, and fp32 output.  The reference computes this path in fp32
 // (src/convolution_gpu.cu:137-155, AT_DISPATCH_FLOATING_TYPES).
+#include <type_traits>
 #include "conv_common.hpp"
 
 namespace me {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-// Stage rows are padded by 32 bytes: with row strides of KC * 2 + 32 bytes the 16 (row, 8-channel piece) accesses
-// of every lane group in which the LDS serves a ds_read_b128 ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...) fall on 16
-// distinct 16-byte bank slots; 16 bytes of padding (the first layout) left them 2-way conflicting, and the operand
-// reads are the largest LDS stream of the kernel.
-constexpr int kStagePadX3 = 16;   // bf16 elements
+// LDS stage layout of one plane: 64 rows x KC bf16.  The LDS serves a ds_read_b128 in four fixed lane groups
+// ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...), i.e. 16 (row, 8-channel piece) accesses per cycle that must fall on 16
+// distinct 16-byte bank slots.  For KC = 32 / 64 / 128 an XOR swizzle of the piece index by a function of the row does
+// that without padding (checked exhaustively, scripts/check_stage_layout.py); KC = 96 uses rows padded by 32 bytes.
+// (16 bytes of padding — the round-1 bf16 layout — left every group 2-way conflicting.)
+template <int KC>
+struct StageLayout {
+  static constexpr bool kSwizzled = KC == 32 || KC == 64 || KC == 128;
+  static constexpr int kLd = kSwizzled ? KC : KC + 16;   // bf16 elements per row
+  __host__ __device__ static constexpr int swz(int row) {
+    return KC == 128 ? (row & 15) : KC == 64 ? ((row >> 1) & 7) : KC == 32 ? ((row >> 1) & 3) : 0;
+  }
+  // element offset of the 8-channel piece u of stage row r
+  __host__ __device__ static constexpr int off(int r, int u) { return r * kLd + ((u ^ swz(r)) * 8); }
+};
+__host__ __device__ constexpr int x3_stage_ld(int kc) { return (kc == 32 || kc == 64 || kc == 128) ? kc : kc + 16; }
 
 // waves of a workgroup: NC / 16 column blocks x GS group shares (wave = share * (NC / 16) + column block); a share
 // takes every GS-th group of a batch, so that narrow column slabs still put two waves on every SIMD
 __host__ __device__ constexpr int x3_group_shares(int nc) { return nc >= 96 ? 1 : (nc == 64 ? 2 : 4); }
 
-__host__ __device__ constexpr int conv_f32x3_lds_bytes(int nc, int kc, int tile_rows, int batch_groups) {
-  return (tile_rows + 1) * (nc + kAccPad) * 4 + batch_groups * 16 * (3 * (kc + kStagePadX3) * 2 + 4);
+// accumulator tile + TWO stage buffers (three planes + the target indices of 64 rows each)
+__host__ __device__ constexpr int conv_f32x3_lds_bytes(int nc, int kc, int tile_rows) {
+  return (tile_rows + 1) * (nc + kAccPad) * 4 + 2 * ME_MAX_BATCH_GROUPS * 16 * (3 * x3_stage_ld(kc) * 2 + 4);
 }
 
 // eight fp32 values -> the three bf16 planes of the exact split (see the header)
@@ -100,50 +113,104 @@ __global__ __launch_bounds__(256) void k_pack_weights_f32x3(const float *__restr
   wp[base + (int64_t)2 * KS * 64] = p3;
 }
 
-// R groups of one offset.  Per 32-channel step and group: the three planes of the rows (3 ds_read_b128) and six
+// R groups of one offset in one wave: groups share, share + GS, ... of the staged batch, 16 output columns.
+// Per 32-channel step and group: the three planes of the rows (3 ds_read_b128, requested one step ahead) and six
 // MFMAs, smallest terms first; A = weights, B = rows, so a lane ends with 4 consecutive output columns of one
-// target row.  The accumulators start from the LDS tile (rows of a single-offset batch are distinct and the
-// columns are wave-private), so the accumulate is a plain store.
-template <int R, int GS, int KS, int A_LD, int PLANE, int ACC_LD>
-__device__ __forceinline__ void mma_groups_f32x3(const __bf16 *__restrict__ a0p, const bf16x8 (&w)[3][KS],
-                                                 const int32_t *__restrict__ dstp, float *__restrict__ accp) {
-  int d[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) d[r] = (int)__umul24((unsigned)dstp[r * GS * 16], (unsigned)ACC_LD);
-  f32x4 acc[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) acc[r] = *reinterpret_cast<const f32x4 *>(accp + d[r]);
-#pragma unroll
-  for (int s = 0; s < KS; ++s) {
-    bf16x8 a[R][3];
+// target row.  The old accumulator values are requested before the first MFMA and added at the end (rows of a
+// single-offset batch are distinct and the columns are wave-private: plain read - add - write, no atomics).
+// The operand reads are inline asm with hand-placed waits: left to itself hipcc sinks every ds_read next to the MFMA
+// that uses it (ds_read, s_waitcnt lgkmcnt(0), v_mfma, ds_read, ...), which puts one LDS latency in front of almost
+// every MFMA — measured 2400 cycles per batch for 768 cycles of MFMAs.  Here all reads of a step are issued back to
+// back, one step ahead of the MFMAs that consume them.
+template <int R, int GS, int KC>
+__device__ __forceinline__ void mma_groups_f32x3(const __bf16 *__restrict__ rowp, const int (&pofs)[KC / 32],
+                                                 const bf16x8 (&w)[3][KC / 32], const int32_t *__restrict__ dstp,
+                                                 float *__restrict__ accp, int acc_ld) {
+  typedef __attribute__((address_space(3))) const char lds_char;
+  constexpr int KS = KC / 32;
+  constexpr int LD = StageLayout<KC>::kLd;
+  constexpr int PLANE = ME_MAX_BATCH_GROUPS * 16 * LD;
+  const unsigned row_addr = (unsigned)(uintptr_t)(lds_char *)rowp;   // LDS byte address of this lane's row
+  bf16x8 a[2][R][3];
+  auto read_step = [&](int s, bf16x8 (&dst)[R][3]) {
+    const unsigned addr = row_addr + (unsigned)pofs[s] * 2u;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
 #pragma unroll
       for (int p = 0; p < 3; ++p)
-        a[r][p] = *reinterpret_cast<const bf16x8 *>(a0p + p * PLANE + r * GS * 16 * A_LD + s * 32);
+        asm volatile("ds_read_b128 %0, %1 offset:%2"
+                     : "=v"(dst[r][p])
+                     : "v"(addr), "n"((p * PLANE + r * GS * 16 * LD) * 2));
     }
-    // (weight plane, row plane) by ascending magnitude: 2^-16 terms, 2^-8 terms, leading term
-    constexpr int WP[6] = {2, 0, 1, 1, 0, 0};
-    constexpr int AP[6] = {0, 2, 1, 0, 1, 0};
+  };
+  // all LDS operations older than the last `younger` ones have completed; ties the registers so that the MFMAs
+  // reading them stay below
+  // (the accumulators are tied in as well: the wait of step s + 1 must stay below the MFMAs of step s)
+  f32x4 old[R], acc[R];
+  auto wait_step = [](bf16x8 (&dst)[R][3], f32x4 (&acc)[R], auto younger) {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      asm volatile("s_waitcnt lgkmcnt(%4)"
+                   : "+v"(dst[r][0]), "+v"(dst[r][1]), "+v"(dst[r][2]), "+v"(acc[r])
+                   : "n"(decltype(younger)::value));
+  };
+  int d[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) d[r] = dstp[r * GS * 16];
+  read_step(0, a[0]);
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    d[r] = (int)__umul24((unsigned)d[r], (unsigned)acc_ld);
+    old[r] = *reinterpret_cast<const f32x4 *>(accp + d[r]);
+    acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  // (weight plane, row plane) by ascending magnitude: 2^-16 terms, 2^-8 terms, leading term
+  constexpr int WP[6] = {2, 0, 1, 1, 0, 0};
+  constexpr int AP[6] = {0, 2, 1, 0, 1, 0};
+  auto step = [&](auto s_) {
+    constexpr int S = decltype(s_)::value;
+    if constexpr (S + 1 < KS) {
+      read_step(S + 1, a[(S + 1) & 1]);
+      // younger than the reads of step S: the reads of step S + 1 and, for S = 0, the R accumulator reads (the
+      // counter has four bits: 15 over-waits by one read when R = 4)
+      constexpr int kYounger = 3 * R + (S == 0 ? R : 0);
+      wait_step(a[S & 1], acc, std::integral_constant<int, (kYounger > 15 ? 15 : kYounger)>{});
+    } else {
+      wait_step(a[S & 1], acc, std::integral_constant<int, (S == 0 ? R : 0)>{});
+    }
 #pragma unroll
     for (int t = 0; t < 6; ++t) {
 #pragma unroll
       for (int r = 0; r < R; ++r)
-        acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[WP[t]][s], a[r][AP[t]], acc[r], 0, 0, 0);
+        acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[WP[t]][S], a[S & 1][r][AP[t]], acc[r], 0, 0, 0);
     }
-  }
+  };
+  step(std::integral_constant<int, 0>{});
+  if constexpr (KS > 1) step(std::integral_constant<int, 1>{});
+  if constexpr (KS > 2) step(std::integral_constant<int, 2>{});
+  if constexpr (KS > 3) step(std::integral_constant<int, 3>{});
+  static_assert(KS <= 4, "KC <= 128");
 #pragma unroll
-  for (int r = 0; r < R; ++r) *reinterpret_cast<f32x4 *>(accp + d[r]) = acc[r];
+  for (int r = 0; r < R; ++r) *reinterpret_cast<f32x4 *>(accp + d[r]) = old[r] + acc[r];
 }
 
-// See k_conv_tile_bf16 (conv_bf16.hip) / k_conv_tile_f32 (conv.hip) for the pipeline.
-// EXACT: c_src is a multiple of KC.  SMALL: 32-bit gather offsets (host-checked: < 2^24 rows, source < 4 GiB).
-// c_src % 8 == 0 is required (a 32-byte piece is wholly inside the row or wholly beyond it).
 // phase cycle counters of the TIMED instrumentation build (debug variant 256; s_memtime ticks summed over wave 0 of
-// every workgroup): barrier A, split + stage write (incl. the wait for the rows), barrier B, load issue, multiply,
-// prologue, epilogue; [7] = batches
+// every workgroup — a multiply-first wave): [0] barrier wait, [1] produce (split + stage write, incl. the wait for the
+// gathered rows, + load issue), [4] multiply, [5] prologue, [6] epilogue; [7] = batches
 __device__ unsigned long long d_x3_timing[8];
 
+// Target-stationary tile kernel (plan, batches and epilogue as k_conv_tile_bf16 / k_conv_tile_f32).  Pipeline:
+//   * two LDS stage buffers; batch b is multiplied from buffer b & 1 while batch b + 1 is split and written into the
+//     other one: ONE barrier per batch;
+//   * the waves of a workgroup are skewed ("ping-pong"): waves 0-3 multiply first and produce second, waves 4-7
+//     produce first and multiply second.  Waves w and w + 4 sit on the same SIMD, so on every SIMD one wave feeds the
+//     matrix pipe while the other issues the vector / LDS-store / load instructions of the next batch (the bf16 MFMA
+//     co-issues with them);
+//   * gathered rows are two batches ahead in registers (slot = batch parity), their indices three; a wave's weights
+//     (its 16 columns, three planes) one batch ahead.  All loads are plain and unconditional so that hipcc's counted
+//     s_waitcnt leaves the younger ones in flight.
+// EXACT: c_src is a multiple of KC.  SMALL: 32-bit gather offsets (host-checked: < 2^24 rows, source < 4 GiB).
+// c_src % 8 == 0 is required (a 32-byte piece is wholly inside the row or wholly beyond it).
 template <int NC, int KC, bool EXACT, bool SMALL, bool TIMED = false>
 __global__ __launch_bounds__(NC * 4 * x3_group_shares(NC), 1) void k_conv_tile_f32x3(
     const float *__restrict__ src, int c_src, const bf16x8 *__restrict__ wp, int c_dst,
@@ -151,24 +218,26 @@ __global__ __launch_bounds__(NC * 4 * x3_group_shares(NC), 1) void k_conv_tile_f
     const int32_t *__restrict__ batch_desc, const int32_t *__restrict__ tile_bptr,
     const int32_t *__restrict__ order, float *__restrict__ dst, int64_t n_tgt, int tile_rows, int batch_groups) {
   typedef int i32x2 __attribute__((ext_vector_type(2)));
+  typedef StageLayout<KC> SL;
   constexpr int GS = x3_group_shares(NC);
   constexpr int CBW = NC / 16;         // column blocks (waves per group share)
   constexpr int WAVES = CBW * GS;
   constexpr int NT = WAVES * 64;
-  constexpr int A_LD = KC + kStagePadX3;   // bf16 elements per staged row and plane
+  constexpr int LD = SL::kLd;          // bf16 elements per staged row and plane
   constexpr int ACC_LD = NC + kAccPad;
   constexpr int KS = KC / 32;
   constexpr int F8 = KC / 8;           // 8-channel pieces per gathered row (32 bytes of fp32)
-  constexpr int ITER = (ME_MAX_BATCH_GROUPS * 16 * F8 + NT - 1) / NT;
-  constexpr int PLANE = ME_MAX_BATCH_GROUPS * 16 * A_LD;   // elements between the planes of the stage buffer
+  constexpr int CAP = ME_MAX_BATCH_GROUPS * 16;
+  constexpr int ITER = (CAP * F8 + NT - 1) / NT;
+  constexpr int PLANE = CAP * LD;      // elements between the planes of a stage buffer
   static_assert(KC % 32 == 0, "KC must be a multiple of 32");
   static_assert(ME_MAX_BATCH_GROUPS == 4, "mma_groups runs cover at most 4 groups");
+  (void)batch_groups;
 
-  const int cap_rows = batch_groups * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float *s_acc = reinterpret_cast<float *>(smem);                              // [(tile_rows + 1) x ACC_LD]
-  __bf16 *s_a = reinterpret_cast<__bf16 *>(s_acc + (tile_rows + 1) * ACC_LD);  // [3][64 x A_LD]
-  int32_t *s_dst = reinterpret_cast<int32_t *>(s_a + 3 * PLANE);               // [64]
+  __bf16 *s_a = reinterpret_cast<__bf16 *>(s_acc + (tile_rows + 1) * ACC_LD);  // [2][3][64 x LD]
+  int32_t *s_dst = reinterpret_cast<int32_t *>(s_a + 2 * 3 * PLANE);           // [2][64]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -182,6 +251,7 @@ __global__ __launch_bounds__(NC * 4 * x3_group_shares(NC), 1) void k_conv_tile_f
   const int wcb = wave % CBW;          // column block of this wave inside the slab
   const int share = wave / CBW;        // its groups of a batch: share, share + GS, ...
   const int cb = min(col_base / 16 + wcb, ncb - 1);
+  const bool produce_first = wave >= 4;   // waves w and w + 4 share a SIMD: opposite phase order
 
   unsigned long long tm[7] = {0, 0, 0, 0, 0, 0, 0};
   unsigned long long t_prev = TIMED ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -207,43 +277,45 @@ __global__ __launch_bounds__(NC * 4 * x3_group_shares(NC), 1) void k_conv_tile_f
   const int nb = tile_bptr[tile + 1] - b0;
   const int n_it = nb * nchunks;
 
-  auto locate = [&](int it, int &chunk, int &g0, int &ng, int &k) {
+  struct Desc {
+    int chunk, g0, ng, k;
+  };
+  auto locate = [&](int it) {
     int r = min(it, n_it - 1);
-    chunk = 0;
+    Desc d;
+    d.chunk = 0;
     while (r >= nb) {
       r -= nb;
-      ++chunk;
+      ++d.chunk;
     }
-    const i32x2 d = *reinterpret_cast<const i32x2 *>(batch_desc + 2 * (int64_t)(b0 + r));
-    g0 = d.x;
-    ng = d.y & 255;
-    k = (int)((uint32_t)d.y >> 8);
+    const i32x2 v = *reinterpret_cast<const i32x2 *>(batch_desc + 2 * (int64_t)(b0 + r));
+    d.g0 = v.x;
+    d.ng = v.y & 255;
+    d.k = (int)((uint32_t)v.y >> 8);
+    return d;
   };
 
-  // Two batches of gathered rows are in flight (round-2 measurement: with one, a batch lasted a whole gather
-  // latency, ~2500 cycles, however little work it held): batch x uses register slot x & 1 for its rows, target
-  // indices and source indices.  Issue order inside an iteration — indices (b + 3), weights (b + 1), rows (b + 2) —
-  // is what lets the counted s_waitcnt of each consumer leave the younger loads outstanding.
+  // registers of the batches in flight: slot = batch parity
   f32x4 stage[2][ITER][2];
   int32_t dstv[2] = {tile_rows, tile_rows};
   int32_t sidx[2][ITER];
-  bf16x8 wreg[3][KS], wnxt[3][KS];
+  bf16x8 wreg[2][3][KS];
 
   // the 64-entry index window of a batch is read to its end unconditionally (the plan is followed by 64 valid
   // entries; threads beyond the window — wide workgroups on narrow chunks — re-read its last entry); padding slots
   // (index -1) gather row 0 and their products land in the dummy accumulator row
-  auto load_sidx = [&](int g0, int32_t (&sx)[ITER]) {
-    const char *pb = reinterpret_cast<const char *>(plan_src + (int64_t)g0 * 16);
+  auto load_sidx = [&](const Desc &d, int32_t (&sx)[ITER]) {
+    const char *pb = reinterpret_cast<const char *>(plan_src + (int64_t)d.g0 * 16);
 #pragma unroll
     for (int j = 0; j < ITER; ++j)
-      sx[j] = *reinterpret_cast<const int32_t *>(pb + (unsigned)(min((j * NT + tid) / F8, ME_MAX_BATCH_GROUPS * 16 - 1) * 4));
+      sx[j] = *reinterpret_cast<const int32_t *>(pb + (unsigned)(min((j * NT + tid) / F8, CAP - 1) * 4));
   };
   const char *srcb = reinterpret_cast<const char *>(src);
   const unsigned row_bytes = (unsigned)c_src * 4u;
-  auto gather = [&](int chunk, int g0, const int32_t (&sx)[ITER], f32x4 (&st)[ITER][2], int32_t &dv) {
-    const int c0 = chunk * KC;
-    dv = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(plan_dst + (int64_t)g0 * 16) +
-                                           (unsigned)(min(tid, ME_MAX_BATCH_GROUPS * 16 - 1) * 4));
+  auto gather = [&](const Desc &d, const int32_t (&sx)[ITER], f32x4 (&st)[ITER][2], int32_t &dv) {
+    const int c0 = d.chunk * KC;
+    dv = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(plan_dst + (int64_t)d.g0 * 16) +
+                                           (unsigned)(min(tid, CAP - 1) * 4));
 #pragma unroll
     for (int j = 0; j < ITER; ++j) {
       const int ch = c0 + ((j * NT + tid) % F8) * 8;
@@ -256,8 +328,9 @@ __global__ __launch_bounds__(NC * 4 * x3_group_shares(NC), 1) void k_conv_tile_f
       st[j][1] = p[1];
     }
   };
-  auto write_stage = [&](int chunk, const f32x4 (&st)[ITER][2], int32_t dv) {
-    const int c0 = chunk * KC;
+  auto write_stage = [&](const Desc &d, const f32x4 (&st)[ITER][2], int32_t dv, int buf) {
+    const int c0 = d.chunk * KC;
+    __bf16 *base = s_a + buf * 3 * PLANE;
 #pragma unroll
     for (int j = 0; j < ITER; ++j) {
       const int idx = j * NT + tid;
@@ -266,91 +339,108 @@ __global__ __launch_bounds__(NC * 4 * x3_group_shares(NC), 1) void k_conv_tile_f
       u32x4 p1, p2, p3;
       split3(st[j][0], st[j][1], p1, p2, p3);
       if (!EXACT && ch >= c_src) p1 = p2 = p3 = u32x4{0u, 0u, 0u, 0u};
-      if (r < cap_rows) {
-        __bf16 *o = &s_a[r * A_LD + (idx % F8) * 8];
+      if (ITER * NT == CAP * F8 || r < CAP) {
+        __bf16 *o = base + SL::off(r, idx % F8);
         *reinterpret_cast<u32x4 *>(o) = p1;
         *reinterpret_cast<u32x4 *>(o + PLANE) = p2;
         *reinterpret_cast<u32x4 *>(o + 2 * PLANE) = p3;
       }
     }
-    if (tid < cap_rows) s_dst[tid] = dv;
+    if (tid < CAP) s_dst[buf * CAP + tid] = dv;
   };
-  auto load_w = [&](int chunk, int k) {
-    const bf16x8 *p = wp + (((((int64_t)k * nchunks + chunk) * ncb + cb) * 3) * KS) * 64 + lane;
+  auto load_w = [&](const Desc &d, bf16x8 (&w)[3][KS]) {
+    const bf16x8 *p = wp + (((((int64_t)d.k * nchunks + d.chunk) * ncb + cb) * 3) * KS) * 64 + lane;
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
-      for (int v = 0; v < KS; ++v) wnxt[pl][v] = p[(pl * KS + v) * 64];
+      for (int v = 0; v < KS; ++v) w[pl][v] = p[(pl * KS + v) * 64];
     }
+  };
+  // lane constants of the operand reads: row (share * 16 + i16) of the buffer, swizzled piece offsets per step
+  int pofs[KS];
+#pragma unroll
+  for (int sx = 0; sx < KS; ++sx) pofs[sx] = ((sx * 4 + q) ^ SL::swz(i16)) * 8;
+  auto multiply = [&](const Desc &d, const bf16x8 (&w)[3][KS], int buf) {
+    const __bf16 *rowp = s_a + buf * 3 * PLANE + (share * 16 + i16) * LD;
+    const int32_t *dstp = s_dst + buf * CAP + share * 16 + i16;
+    float *accp = &s_acc[wcb * 16 + q * 4];
+    const int mine = (d.ng - share + GS - 1) / GS;     // groups share, share + GS, ... below ng
+    if constexpr (GS == 1 && KC < 96) {
+      if (mine >= 4) mma_groups_f32x3<4, GS, KC>(rowp, pofs, w, dstp, accp, ACC_LD);
+      else if (mine == 3) mma_groups_f32x3<3, GS, KC>(rowp, pofs, w, dstp, accp, ACC_LD);
+    }
+    if constexpr (GS == 1 && KC >= 96) {
+      // three or four groups of a wide chunk in two runs: the operand registers of four groups x three steps,
+      // two deep, do not fit next to the batches in flight
+      if (mine >= 3) {
+        mma_groups_f32x3<2, GS, KC>(rowp, pofs, w, dstp, accp, ACC_LD);
+        if (mine >= 4) mma_groups_f32x3<2, GS, KC>(rowp + 32 * LD, pofs, w, dstp + 32, accp, ACC_LD);
+        else mma_groups_f32x3<1, GS, KC>(rowp + 32 * LD, pofs, w, dstp + 32, accp, ACC_LD);
+      }
+    }
+    if constexpr (GS <= 2) {
+      if (mine == 2) mma_groups_f32x3<2, GS, KC>(rowp, pofs, w, dstp, accp, ACC_LD);
+    }
+    if (mine == 1) mma_groups_f32x3<1, GS, KC>(rowp, pofs, w, dstp, accp, ACC_LD);
   };
 
   if (n_it > 0) {
-    int chA, gA, nA, kA, chB, gB, nB, kB, chC, gC, nC, kC, chD, gD, nD, kD;
-    locate(0, chA, gA, nA, kA);
-    locate(1, chB, gB, nB, kB);
-    locate(2, chC, gC, nC, kC);
-    locate(3, chD, gD, nD, kD);
-    load_sidx(gA, sidx[0]);
-    load_sidx(gB, sidx[1]);
-    load_w(chA, kA);
-    gather(chA, gA, sidx[0], stage[0], dstv[0]);
-    gather(chB, gB, sidx[1], stage[1], dstv[1]);
-    load_sidx(gC, sidx[0]);
+    // descriptors of batches it .. it + 4
+    Desc dA = locate(0), dB = locate(1), dC = locate(2), dD = locate(3), dE = locate(4);
+    // produce(x), x = the batch after the one being multiplied (slots NX = x & 1, CU = the other parity): split and
+    // store its rows into buffer NX, request the indices of batch x + 3 and the rows of batch x + 2
+    auto produce = [&](const Desc &dx, const Desc &dx2, const Desc &dx3, int buf, f32x4 (&st)[ITER][2], int32_t &dv,
+                       int32_t (&sx_nx)[ITER], int32_t (&sx_cu)[ITER]) {
+      write_stage(dx, st, dv, buf);
+      load_sidx(dx3, sx_cu);          // batch x + 3: the slot held the indices of batch x + 1, already used
+      gather(dx2, sx_nx, st, dv);     // batch x + 2 into the registers just stored
+    };
+    load_sidx(dA, sidx[0]);
+    load_sidx(dB, sidx[1]);
+    load_w(dA, wreg[0]);
+    gather(dA, sidx[0], stage[0], dstv[0]);
+    gather(dB, sidx[1], stage[1], dstv[1]);
+    load_sidx(dC, sidx[0]);
+    produce(dA, dC, dD, 0, stage[0], dstv[0], sidx[0], sidx[1]);   // batch 0 -> buffer 0
     tick(5);
+    __syncthreads();
 
-    // one batch; SLOT = its parity
-    auto iteration = [&](int it, f32x4 (&st)[ITER][2], int32_t &dv, int32_t (&sx_cur)[ITER], int32_t (&sx_far)[ITER]) {
+    // iteration `it` with parity P = it & 1: multiply batch it (buffer P, weights w_cu) and produce batch it + 1
+    auto iteration = [&](int it, int P, bf16x8 (&w_cu)[3][KS], bf16x8 (&w_nx)[3][KS], f32x4 (&st_nx)[ITER][2],
+                         int32_t &dv_nx, int32_t (&sx_nx)[ITER], int32_t (&sx_cu)[ITER]) {
+      if (!produce_first) {
+        load_w(dB, w_nx);
+        multiply(dA, w_cu, P);
+        if (TIMED) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        tick(4);
+        produce(dB, dD, dE, P ^ 1, st_nx, dv_nx, sx_nx, sx_cu);
+        if (TIMED) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        tick(1);
+      } else {
+        produce(dB, dD, dE, P ^ 1, st_nx, dv_nx, sx_nx, sx_cu);
+        load_w(dB, w_nx);
+        multiply(dA, w_cu, P);
+      }
       __syncthreads();
       tick(0);
-      write_stage(chA, st, dv);
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) {
-#pragma unroll
-        for (int sx = 0; sx < KS; ++sx) wreg[pl][sx] = wnxt[pl][sx];
-      }
-      if (TIMED) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      tick(1);
-      __syncthreads();
-      tick(2);
-      load_sidx(gD, sx_far);              // batch it + 3 (its slot held the indices of batch it + 1: consumed)
-      load_w(chB, kB);                    // batch it + 1
-      gather(chC, gC, sx_cur, st, dv);    // batch it + 2 into the slot just written to LDS
-      tick(3);
-      {
-        const __bf16 *a0p = &s_a[(share * 16 + i16) * A_LD + q * 8];
-        const int32_t *dstp = &s_dst[share * 16 + i16];
-        float *accp = &s_acc[wcb * 16 + q * 4];
-        const int mine = (nA - share + GS - 1) / GS;     // groups share, share + GS, ... below nA
-        if constexpr (GS == 1) {
-          if (mine >= 4) mma_groups_f32x3<4, GS, KS, A_LD, PLANE, ACC_LD>(a0p, wreg, dstp, accp);
-          else if (mine == 3) mma_groups_f32x3<3, GS, KS, A_LD, PLANE, ACC_LD>(a0p, wreg, dstp, accp);
-        }
-        if constexpr (GS <= 2) {
-          if (mine == 2) mma_groups_f32x3<2, GS, KS, A_LD, PLANE, ACC_LD>(a0p, wreg, dstp, accp);
-        }
-        if (mine == 1) mma_groups_f32x3<1, GS, KS, A_LD, PLANE, ACC_LD>(a0p, wreg, dstp, accp);
-      }
-      if (TIMED) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      tick(4);
-      chA = chB; gA = gB; nA = nB; kA = kB;
-      chB = chC; gB = gC; nB = nC; kB = kC;
-      chC = chD; gC = gD; nC = nD; kC = kD;
-      locate(it + 4, chD, gD, nD, kD);
+      dA = dB; dB = dC; dC = dD; dD = dE;
+      dE = locate(it + 5);
     };
     int it = 0;
     for (; it + 1 < n_it; it += 2) {
-      iteration(it, stage[0], dstv[0], sidx[0], sidx[1]);
-      iteration(it + 1, stage[1], dstv[1], sidx[1], sidx[0]);
+      iteration(it, 0, wreg[0], wreg[1], stage[1], dstv[1], sidx[1], sidx[0]);
+      iteration(it + 1, 1, wreg[1], wreg[0], stage[0], dstv[0], sidx[0], sidx[1]);
     }
-    if (it < n_it) iteration(it, stage[0], dstv[0], sidx[0], sidx[1]);
+    if (it < n_it) iteration(it, 0, wreg[0], wreg[1], stage[1], dstv[1], sidx[1], sidx[0]);
+  } else {
+    __syncthreads();
   }
-  __syncthreads();
 
   // every target row of the tile is written exactly once (rows without neighbours get zeros)
   const int64_t row0 = (int64_t)tile * tile_rows;
   const int rows_here = (int)min((int64_t)tile_rows, n_tgt - row0);
   const bool vec_out = (c_dst % 4) == 0;
-  int32_t *s_ord = reinterpret_cast<int32_t *>(s_a);   // the stage buffer is free now
+  int32_t *s_ord = reinterpret_cast<int32_t *>(s_a);   // the stage buffers are free now
   if (order != nullptr) {
 #pragma unroll
     for (int j = 0; j < ORD; ++j)
@@ -413,7 +503,7 @@ static int launch_conv_tile_f32x3(const float *src, int c_src, const bf16x8 *wp,
                                   const int32_t *plan_src, const int32_t *plan_dst, const int32_t *batch_desc,
                                   const int32_t *tile_bptr, const int32_t *order, float *dst, int64_t n_tgt,
                                   int tile_rows, int batch_groups, hipStream_t stream, bool small) {
-  const int lds = conv_f32x3_lds_bytes(NC, KC, tile_rows, ME_MAX_BATCH_GROUPS);
+  const int lds = conv_f32x3_lds_bytes(NC, KC, tile_rows);
   ME_CHECK(lds <= kLdsBudget, "tile_rows too large for the LDS of one workgroup");
   const bool exact = (c_src % KC) == 0;
   typedef void (*kernel_t)(const float *, int, const bf16x8 *, int, const int32_t *, const int32_t *, const int32_t *,
@@ -474,8 +564,8 @@ int me_conv_plan_config_f32x3(int64_t n_tgt, int64_t volume, int64_t n_pairs, in
   s.nc = v.nc;
   s.slabs = v.slabs;
   s.chunks = (int)ceil_div(c_src, v.kc);
-  s.group_cycles = 64.0 + (v.kc / 32) * 96.0;   // six MFMAs per 32 channels + the accumulator round trip
-  s.stage_row_bytes = 3 * (v.kc + kStagePadX3) * 2 + 4;
+  s.group_cycles = 32.0 + (v.kc / 32) * 96.0;   // six MFMAs per 32 channels + the accumulator round trip
+  s.stage_row_bytes = 2 * (3 * x3_stage_ld(v.kc) * 2 + 4);   // two stage buffers
   s.max_occ = 1;   // eight waves per workgroup (six for 96 columns)
   *tile_rows = plan_tile_rows(s, n_tgt, volume, n_pairs);
   return 0;
