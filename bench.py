@@ -85,7 +85,7 @@ def pmc_traffic(kernel, n, extent, cin, cout):
         if (w["points"], w["extent"], w["cin"], w["cout"]) != (n, extent, cin, cout):
             return None, None
         k = t["kernels"][kernel]
-        return int(k["fetch_bytes"] + k["write_bytes"]), t.get("source", "profiles/pmc_traffic.json")
+        return int(k["fetch_bytes"] + k["write_bytes"]), k.get("source", t.get("source", "profiles/pmc_traffic.json"))
     except Exception:  # noqa: BLE001
         return None, None
 
@@ -276,8 +276,7 @@ def roofline_entry(kernel, flops, compulsory_bytes, avg_ms, bf16, traffic, traff
         r["frac_of_pipe"] = round(tflops / pipe_peak, 4)
     r["traffic"] = traffic
     r["traffic_note"] = ("HBM-side bytes per launch (FETCH_SIZE x2 + WRITE_SIZE) — a CITED constant from the committed "
-                         f"rocprofv3 --pmc passes ({traffic_src}; average of the forward and dgrad launches of the "
-                         "kernel), not measured in this run" if traffic is not None else
+                         f"rocprofv3 --pmc passes ({traffic_src}), not measured in this run" if traffic is not None else
                          "no committed PMC pass for this workload")
     return r
 

@@ -95,6 +95,20 @@ def main():
     copy("r02j/bench4d_bf16_0.json", "r02_bench_conv4d_bf16_plan.json")
     copy("r02j/bench4d_bf16_1.json", "r02_bench_conv4d_bf16_gather_v1.json")
     copy("config3_parity.log", "r02_config3_parity.log")
+    # fp32 on the bf16 matrix pipe (k_conv_tile_f32x3)
+    copy("tune_split1.log", "r02_tune_split_policy.log")
+    copy("r02o/phase.log", "r02_phase_timing_f32x3_two_barriers.log")
+    copy("r02p/phase.log", "r02_phase_timing_f32x3_pingpong.log")
+    counters("r02r", "r02_pmc_traffic_f32x3.log", keep=("conv_tile", "wgrad"),
+             header="# FETCH_SIZE / WRITE_SIZE (KB as reported; fetch x2 per the gfx950 correction), TCC hit / miss of the "
+                    "config-2 launches with the round-2 default kernels (scripts/gpu_r02r.sh)")
+    copy("r02l/bench_1.json", "r02_bench_conv_f32x3_first.json")
+    copy("r02l/bench_0.json", "r02_bench_conv_f32_mfma_same_session.json")
+    copy("r02r/bench.json", "r02_bench_conv_f32x3_pingpong.json")
+    copy("r02r/bench4d.json", "r02_bench_conv4d_auto_policy.json")
+    copy("r02r/unet_f32.json", "r02_bench_minkunet34c_f32_auto_policy.json")
+    copy("r02r/unet_bf16.json", "r02_bench_minkunet34c_bf16_stage_pad.json")
+    copy("r02r/pytest_gpu.log", "r02_pytest_gpu_full.log")
     for extra in sys.argv[1:]:          # "src:dst" pairs for later sessions
         s, d = extra.split(":")
         copy(s, d)
