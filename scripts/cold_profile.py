@@ -25,6 +25,17 @@ def step(x):
 x = ME.SparseTensor(feats, coords)
 for _ in range(3):
     step(x if mode == "warm" else ME.SparseTensor(feats, coords))
+if os.environ.get("PROFILE", "0") != "0":      # host-side picture of the cold path (cProfile inflates everything ~2x)
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(steps):
+        step(x if mode == "warm" else ME.SparseTensor(feats, coords))
+    torch.cuda.synchronize()
+    pr.disable()
+    st = pstats.Stats(pr)
+    st.sort_stats("cumulative").print_stats(45)
+    st.sort_stats("tottime").print_stats(30)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(steps):
     step(x if mode == "warm" else ME.SparseTensor(feats, coords))
