@@ -405,7 +405,7 @@ def bench_minkunet(args, ME, MEB, dist_utils, rank, world, dev, startup):
     net = dist_utils.data_parallel(model, dev, sync_batchnorm=args.sync_bn)
     opt = torch.optim.SGD(net.parameters(), lr=1e-3, momentum=0.9)
     labels = torch.randint(0, 20, (n,), generator=g).to(dev)
-    crit = torch.nn.CrossEntropyLoss()
+    crit = torch.nn.CrossEntropyLoss() if args.torch_loss else MU.cross_entropy   # same value and gradient
     bf16 = args.dtype == "bf16"
     tdt = torch.bfloat16 if bf16 else torch.float32
     x = ME.SparseTensor(feats.to(dev).to(tdt), coords.to(dev))   # coordinate + kernel maps cached in x's manager
@@ -422,7 +422,7 @@ def bench_minkunet(args, ME, MEB, dist_utils, rank, world, dev, startup):
 
     def step():
         opt.zero_grad(set_to_none=True)
-        loss = crit(net(x).F.float(), labels)
+        loss = crit(net(x).F.float(), labels)   # mean cross-entropy over the voxels
         loss.backward()
         opt.step()
 
@@ -524,6 +524,8 @@ def main():
     ap.add_argument("--min-blocks", type=int, default=3)
     ap.add_argument("--max-blocks", type=int, default=200)
     ap.add_argument("--backend", choices=("auto", "nccl", "gloo"), default="auto")
+    ap.add_argument("--torch-loss", action="store_true",
+                    help="minkunet: torch.nn.CrossEntropyLoss instead of examples/minkunet.py::cross_entropy (same math)")
     ap.add_argument("--sync-bn", action="store_true", help="minkunet, N > 1: MinkowskiSyncBatchNorm (reference recipe)")
     ap.add_argument("--graph", action="store_true", help="minkunet: replay the step from a captured hipGraph")
     args = ap.parse_args()

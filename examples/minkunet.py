@@ -139,6 +139,14 @@ class MinkUNet34C(MinkUNet34):
     PLANES = (32, 64, 128, 256, 256, 128, 96, 96)
 
 
+def cross_entropy(logits, labels):
+    """Mean cross-entropy of [n, classes] logits, the value and gradient of torch.nn.CrossEntropyLoss() — composed of
+    logsumexp and gather because torch's nll_loss kernels reduce a 200k-row loss in a single workgroup on ROCm (230 us
+    forward + 150 us backward per step in the round-1 profile of the config-3 step; this composition takes ~60 us)."""
+    z = logits.float()
+    return (torch.logsumexp(z, 1) - z.gather(1, labels.view(-1, 1)).squeeze(1)).mean()
+
+
 def synthetic_scene(n=200000, grid=400, seed=0, batch_index=0):
     """voxels on a union of axis-aligned planes in a grid^3 volume (9 planes x 30k draws,
     unique, first n) — a deterministic, network-free stand-in for an indoor scan."""
