@@ -453,6 +453,7 @@ int me_segment_sum_f32(const float *src_dev, int32_t c, const int64_t *perm_dev,
 int64_t me_bn_workspace_bytes(int64_t n, int32_t c);
 int me_bn_stats(const void *x_dev, int32_t is_bf16, int64_t n, int32_t c, float eps, float momentum,
                 float *mean_dev, float *rstd_dev, float *running_mean_dev, float *running_var_dev,
+                int64_t *num_batches_tracked_dev /* may be NULL; += 1 (torch's BatchNorm buffer) */,
                 void *workspace_dev, int64_t workspace_bytes, void *stream);
 int me_bn_apply(const void *x_dev, int32_t is_bf16, int64_t n, int32_t c, const float *mean_dev,
                 const float *rstd_dev, const float *gamma_dev, const float *beta_dev, int32_t relu, void *y_dev,

@@ -1484,8 +1484,9 @@ def _bn_check(x):
     _check(x.shape[0] > 0, "batch norm needs at least one row")
 
 
-def bn_stats(x, eps, momentum, running_mean=None, running_var=None):
-    """-> (mean, rstd) float32 [c] of the batch; running statistics updated in place when given."""
+def bn_stats(x, eps, momentum, running_mean=None, running_var=None, num_batches_tracked=None):
+    """-> (mean, rstd) float32 [c] of the batch; running statistics updated in place when given (and the int64
+    num_batches_tracked buffer incremented by the same kernel)."""
     _bn_check(x)
     lib = _lib.load()
     dev = x.device
@@ -1496,7 +1497,7 @@ def bn_stats(x, eps, momentum, running_mean=None, running_var=None):
     with _on(dev):
         _lib.check(lib.me_bn_stats(_ptr(x), 1 if x.dtype == torch.bfloat16 else 0, n, c, float(eps),
                                    float(momentum), _ptr(mean), _ptr(rstd), _ptr(running_mean), _ptr(running_var),
-                                   _ptr(ws), ws.numel(), _stream(dev)))
+                                   _ptr(num_batches_tracked), _ptr(ws), ws.numel(), _stream(dev)))
     return mean, rstd
 
 

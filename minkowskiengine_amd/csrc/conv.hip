@@ -1468,15 +1468,19 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_lds_f32(const float *__restric
 // order is fixed (bitwise reproducible).
 // TR: the images come from k_wgrad_bf16 (MFMA row i of block m <-> input channel 16*m + i, column j of block
 // n <-> output channel 16*n + j) instead of k_wgrad_f32's interleave.
+constexpr int kWgReducePhases = 4;   // waves per block of k_wgrad_reduce (16 measured slower: most offsets own ~10
+                                     // slots, and 4x the waves cost more than the long chain of the centre offset saves)
+
 template <int NB, bool TR>
-__global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ partial,
+__global__ __launch_bounds__(64 * kWgReducePhases) void k_wgrad_reduce(const float *__restrict__ partial,
                                                      const int64_t *__restrict__ koffs, int volume,
                                                      int64_t n_pairs, int n_ranges, int n_cib, int n_cob,
                                                      int c_in, int c_out, float *__restrict__ grad_w) {
   constexpr int MB = kWgMB;
   constexpr int kImage = MB * NB * 4 * 64;
+  constexpr int PH = kWgReducePhases;
   __shared__ int64_t s_r[2];
-  __shared__ float s_part[4][64];
+  __shared__ float s_part[PH][64];
   const int k = blockIdx.y;
   const int64_t b = koffs[k], e = koffs[k + 1];
   if (threadIdx.x == 0) {
@@ -1488,6 +1492,8 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ 
     }
   }
   __syncthreads();
+  // the waves take the slots first + phase, + PH, ...; eight independent loads in flight per thread (the centre
+  // offset of a sparse map owns half of all slots: its block sets the kernel's duration, and the loop is latency-bound)
   const int j = threadIdx.x & 63, phase = threadIdx.x >> 6;
   const int64_t idx = (int64_t)blockIdx.x * 64 + j;
   const int64_t per_slot = (int64_t)n_cib * n_cob * kImage;
@@ -1496,17 +1502,21 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ 
     const int64_t first = s_r[0], last = s_r[1];
     const float *p = partial + idx;
     int64_t slot = first + phase;
-    for (; slot + 12 <= last; slot += 16) {
-      const float v0 = p[slot * per_slot], v1 = p[(slot + 4) * per_slot];
-      const float v2 = p[(slot + 8) * per_slot], v3 = p[(slot + 12) * per_slot];
-      s = ((s + v0) + v1) + v2 + v3;
+    for (; slot + 7 * PH <= last; slot += 8 * PH) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(slot + u * PH) * per_slot];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
     }
-    for (; slot <= last; slot += 4) s += p[slot * per_slot];
+    for (; slot <= last; slot += PH) s += p[slot * per_slot];
   }
   s_part[phase][j] = s;
   __syncthreads();
   if (phase != 0 || idx >= per_slot) return;
-  s = ((s_part[0][j] + s_part[1][j]) + s_part[2][j]) + s_part[3][j];
+  s = s_part[0][j];
+#pragma unroll
+  for (int ph = 1; ph < PH; ++ph) s += s_part[ph][j];   // fixed order: bitwise reproducible
   const int lane = (int)(idx % 64);
   const int reg = (int)((idx / 64) % (MB * NB * 4));
   const int cob = (int)((idx / kImage) % n_cob);
@@ -1892,7 +1902,7 @@ static int wgrad_launch(const T *x, int64_t n_in, int32_t c_in, const T *dy, int
   }
   const dim3 rgrid((unsigned)ceil_div(g.slot_floats, 64), (unsigned)volume);
 #define ME_WGRAD_REDUCE(NBV)                                                                               \
-  hipLaunchKernelGGL((k_wgrad_reduce<NBV, false>), rgrid, dim3(256), 0, stream, partial, k_offsets_dev, (int)volume, \
+  hipLaunchKernelGGL((k_wgrad_reduce<NBV, false>), rgrid, dim3(64 * kWgReducePhases), 0, stream, partial, k_offsets_dev, (int)volume, \
                      n_pairs > 0 ? n_pairs : 1, (int)g.ranges, g.n_cib, g.n_cob, c_in, c_out, grad_w)
   if (g.nb == 1) ME_WGRAD_REDUCE(1);
   else if (g.nb == 2) ME_WGRAD_REDUCE(2);
@@ -2088,10 +2098,10 @@ int me_conv_wgrad_f32(const float *x, int64_t n_in, int32_t c_in, const float *d
   }
   const dim3 rgrid((unsigned)ceil_div(g.slot_floats, 64), (unsigned)volume);
   if (g.nb == 1)
-    hipLaunchKernelGGL((k_wgrad_reduce<1, true>), rgrid, dim3(256), 0, stream, partial, k_offsets_dev, (int)volume,
+    hipLaunchKernelGGL((k_wgrad_reduce<1, true>), rgrid, dim3(64 * kWgReducePhases), 0, stream, partial, k_offsets_dev, (int)volume,
                        n_pairs > 0 ? n_pairs : 1, (int)g.ranges, g.n_cib, g.n_cob, c_in, c_out, grad_w);
   else
-    hipLaunchKernelGGL((k_wgrad_reduce<2, true>), rgrid, dim3(256), 0, stream, partial, k_offsets_dev, (int)volume,
+    hipLaunchKernelGGL((k_wgrad_reduce<2, true>), rgrid, dim3(64 * kWgReducePhases), 0, stream, partial, k_offsets_dev, (int)volume,
                        n_pairs > 0 ? n_pairs : 1, (int)g.ranges, g.n_cib, g.n_cob, c_in, c_out, grad_w);
   ME_LAUNCH_CHECK();
   return 0;
@@ -2141,7 +2151,7 @@ int me_conv_wgrad_bf16(const uint16_t *x_, int64_t n_in, int32_t c_in, const uin
   }
   const dim3 rgrid((unsigned)ceil_div(g.slot_floats, 64), (unsigned)volume);
 #define ME_WGRAD_REDUCE_TR(NBV)                                                                               \
-  hipLaunchKernelGGL((k_wgrad_reduce<NBV, true>), rgrid, dim3(256), 0, stream, partial, k_offsets_dev, (int)volume, \
+  hipLaunchKernelGGL((k_wgrad_reduce<NBV, true>), rgrid, dim3(64 * kWgReducePhases), 0, stream, partial, k_offsets_dev, (int)volume, \
                      n_pairs > 0 ? n_pairs : 1, (int)g.ranges, g.n_cib, g.n_cob, c_in, c_out, grad_w)
   if (g.nb == 1) ME_WGRAD_REDUCE_TR(1);
   else ME_WGRAD_REDUCE_TR(2);

@@ -586,27 +586,49 @@ __global__ __launch_bounds__(1024) void k_plan_tile_order(const int32_t *__restr
   }
   if (tid < 256) s_bin[tid] = 0;
   __syncthreads();
-  auto work = [&](int64_t t) { return item_gptr[(t + 1) * volume] - item_gptr[t * volume]; };
+  auto work_of = [&](int64_t t) { return item_gptr[(t + 1) * volume] - item_gptr[t * volume]; };
+  // the first tile of every thread stays in a register (plans rarely have more tiles than the block has threads)
+  const int32_t w_first = tid < n_tiles ? work_of(tid) : 0;
+  auto work = [&](int64_t t) { return t == tid ? w_first : work_of(t); };
   int32_t lo = INT32_MAX, hi = 0;
   for (int64_t t = tid; t < n_tiles; t += blockDim.x) {
     const int32_t w = work(t);
     lo = min(lo, w);
     hi = max(hi, w);
   }
-  atomicMin(&s_min, lo);
-  atomicMax(&s_max, hi);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {   // one LDS atomic per wave
+    lo = min(lo, __shfl_xor(lo, off, 64));
+    hi = max(hi, __shfl_xor(hi, off, 64));
+  }
+  if ((tid & 63) == 0) {
+    atomicMin(&s_min, lo);
+    atomicMax(&s_max, hi);
+  }
   __syncthreads();
   const int32_t wmin = s_min, span = max(s_max - s_min, 1);
   auto bin = [&](int32_t w) { return 255 - (int)(((int64_t)(w - wmin) * 255) / span); };   // heavy tiles: low bins
   for (int64_t t = tid; t < n_tiles; t += blockDim.x) atomicAdd(&s_bin[bin(work(t))], 1u);
   __syncthreads();
-  if (tid == 0) {
-    uint32_t run = 0;
-    for (int b = 0; b < 256; ++b) {
-      const uint32_t c = s_bin[b];
-      s_bin[b] = run;
-      run += c;
+  // exclusive scan of the 256 bins: shuffle scan inside the four waves that hold them + the wave totals (a serial
+  // scan by one thread — 256 dependent LDS round trips — was most of this kernel's 10 us)
+  __shared__ uint32_t s_wsum[4];
+  uint32_t v = 0, incl = 0;
+  if (tid < 256) {
+    v = s_bin[tid];
+    incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t up = __shfl_up(incl, off, 64);
+      if ((tid & 63) >= off) incl += up;
     }
+    if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
+  }
+  __syncthreads();
+  if (tid < 256) {
+    uint32_t base = 0;
+    for (int w = 0; w < (tid >> 6); ++w) base += s_wsum[w];
+    s_bin[tid] = base + incl - v;
   }
   __syncthreads();
   for (int64_t t = tid; t < n_tiles; t += blockDim.x) perm[atomicAdd(&s_bin[bin(work(t))], 1u)] = (int32_t)t;

@@ -129,9 +129,11 @@ __global__ __launch_bounds__(256) void k_bn_final(const float *__restrict__ part
                                                  const float *__restrict__ part_m2, int64_t n, int c, int chunks,
                                                  float eps, float momentum, float *__restrict__ mean_out,
                                                  float *__restrict__ rstd_out, float *__restrict__ running_mean,
-                                                 float *__restrict__ running_var) {
+                                                 float *__restrict__ running_var,
+                                                 int64_t *__restrict__ num_batches_tracked) {
   const int lane = threadIdx.x & 63;
   const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (num_batches_tracked != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
   if (ch >= c) return;  // whole wave
   float cn = 0.f, cm = 0.f, cq = 0.f;
   for (int g = lane; g < chunks; g += 64) {
@@ -344,7 +346,8 @@ static int bn_chunks(int64_t n) {
 
 template <typename T>
 static int bn_stats(const T *x, int64_t n, int c, float eps, float momentum, float *mean, float *rstd,
-                    float *running_mean, float *running_var, float *ws, hipStream_t stream) {
+                    float *running_mean, float *running_var, int64_t *num_batches_tracked, float *ws,
+                    hipStream_t stream) {
   const int chunks = bn_chunks(n);
   float *pm = ws, *pq = ws + (int64_t)chunks * c;
   constexpr int W = 16 / (int)sizeof(T);  // channels per 16-byte access
@@ -358,7 +361,7 @@ static int bn_stats(const T *x, int64_t n, int c, float eps, float momentum, flo
   else if (v == 4) hipLaunchKernelGGL((k_bn_partial<T, 4>), dim3(chunks), dim3(256), lds, stream, x, n, c, chunks, pm, pq);
   else hipLaunchKernelGGL((k_bn_partial<T, 1>), dim3(chunks), dim3(256), lds, stream, x, n, c, chunks, pm, pq);
   hipLaunchKernelGGL(k_bn_final, dim3((unsigned)ceil_div(c, 4)), dim3(256), 0, stream, pm, pq, n, c, chunks, eps,
-                     momentum, mean, rstd, running_mean, running_var);
+                     momentum, mean, rstd, running_mean, running_var, num_batches_tracked);
   ME_LAUNCH_CHECK();
   return 0;
 }
@@ -428,17 +431,17 @@ int64_t me_bn_workspace_bytes(int64_t n, int32_t c) {
 }
 
 int me_bn_stats(const void *x, int32_t is_bf16, int64_t n, int32_t c, float eps, float momentum, float *mean,
-                float *rstd, float *running_mean, float *running_var, void *workspace, int64_t workspace_bytes,
-                void *stream_) {
+                float *rstd, float *running_mean, float *running_var, int64_t *num_batches_tracked, void *workspace,
+                int64_t workspace_bytes, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   ME_CHECK(n > 0 && c > 0, "batch norm needs at least one row and one channel");
   ME_CHECK(workspace_bytes >= me_bn_workspace_bytes(n, c), "workspace too small");
   float *ws = reinterpret_cast<float *>(workspace);
   if (is_bf16)
     return bn_stats<__bf16>(reinterpret_cast<const __bf16 *>(x), n, c, eps, momentum, mean, rstd, running_mean,
-                            running_var, ws, stream);
+                            running_var, num_batches_tracked, ws, stream);
   return bn_stats<float>(reinterpret_cast<const float *>(x), n, c, eps, momentum, mean, rstd, running_mean,
-                         running_var, ws, stream);
+                         running_var, num_batches_tracked, ws, stream);
 }
 
 int me_bn_apply(const void *x, int32_t is_bf16, int64_t n, int32_t c, const float *mean, const float *rstd,

@@ -22,11 +22,11 @@ class _BatchNormTrainFunction(Function):
     fixed summation order).  weight / bias may be None."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu=False):
+    def forward(ctx, x, weight, bias, running_mean, running_var, momentum, eps, relu=False, num_batches_tracked=None):
         x = x.contiguous()
         w32 = weight.float() if weight is not None else None
         b32 = bias.float() if bias is not None else None
-        mean, rstd = MEB.bn_stats(x, eps, momentum, running_mean, running_var)
+        mean, rstd = MEB.bn_stats(x, eps, momentum, running_mean, running_var, num_batches_tracked)
         y = MEB.bn_apply(x, mean, rstd, w32, b32, relu)
         ctx.save_for_backward(x, mean, rstd, w32, b32)
         ctx.param_dtype = weight.dtype if weight is not None else None
@@ -40,7 +40,7 @@ class _BatchNormTrainFunction(Function):
         dx, gg, gb = MEB.bn_backward(x, dy, mean, rstd, w32, b32, ctx.relu)
         gw = gg.to(ctx.param_dtype) if ctx.param_dtype is not None else None
         gbias = gb.to(ctx.param_dtype) if ctx.has_bias else None
-        return dx, gw, gbias, None, None, None, None, None
+        return dx, gw, gbias, None, None, None, None, None, None
 
 
 class MinkowskiBatchNorm(nn.Module):
@@ -72,9 +72,13 @@ class MinkowskiBatchNorm(nn.Module):
         if use_batch_stats:
             rm = bn.running_mean if (bn.training and bn.track_running_stats) else None
             rv = bn.running_var if (bn.training and bn.track_running_stats) else None
-            if rm is not None:
-                bn.num_batches_tracked.add_(1)
-            y = _BatchNormTrainFunction.apply(f, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps, self.fuse_relu)
+            # (num_batches_tracked is incremented by the statistics kernel: 62 one-element torch kernels per
+            # MinkUNet34C pass otherwise)
+            nbt = bn.num_batches_tracked if rm is not None else None
+            if nbt is not None and (nbt.dtype != torch.int64 or not nbt.is_cuda):
+                nbt.add_(1)
+                nbt = None
+            y = _BatchNormTrainFunction.apply(f, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps, self.fuse_relu, nbt)
             out = _rewrap(input, y)
             out._rectified = self.fuse_relu
             return out
