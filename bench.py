@@ -420,10 +420,36 @@ def bench_minkunet(args, ME, MEB, dist_utils, rank, world, dev, startup):
         hooks = [m.register_forward_hook(record) for m in model.modules()
                  if isinstance(m, (ME.MinkowskiConvolution, ME.MinkowskiConvolutionTranspose))]
 
+    feats_dev, coords_dev = x.F.detach(), coords.to(dev)
+    pending = [None]
+    if args.scenes == "pipelined":
+        # a new scene every step, its maps built on a side stream during the previous step's backward pass
+        # (set_map_prefetch: the previous scene's build requests are replayed right after the coordinate insert)
+        ME.set_map_prefetch(True)
+        main_stream, side_stream = torch.cuda.current_stream(), torch.cuda.Stream()
+
+        def next_scene():
+            with torch.cuda.stream(side_stream):
+                t = ME.SparseTensor(feats_dev, coords_dev)
+            t.coordinate_manager.record_stream(main_stream)
+            ev = torch.cuda.Event()
+            ev.record(side_stream)
+            return t, ev
+        pending[0] = next_scene()
+
     def step():
         opt.zero_grad(set_to_none=True)
-        loss = crit(net(x).F.float(), labels)   # mean cross-entropy over the voxels
+        if args.scenes == "cached":
+            xin = x
+        elif args.scenes == "fresh":
+            xin = ME.SparseTensor(feats_dev, coords_dev)      # coordinate maps, kernel maps, plans rebuilt lazily
+        else:
+            xin, ev = pending[0]
+            main_stream.wait_event(ev)
+        loss = crit(net(xin).F.float(), labels)   # mean cross-entropy over the voxels
         loss.backward()
+        if args.scenes == "pipelined":
+            pending[0] = next_scene()
         opt.step()
 
     torch.cuda.synchronize()
@@ -434,6 +460,8 @@ def bench_minkunet(args, ME, MEB, dist_utils, rank, world, dev, startup):
     for h in hooks:
         h.remove()
     graphed = False
+    if args.graph and args.scenes != "cached":
+        raise SystemExit("--graph needs --scenes cached (a captured step replays fixed shapes and addresses)")
     if args.graph:
         step, graphed = capture_step(step), True
     best, blocks, timer, timed_steps = run_timed(step, args, dist_utils, MEB, dev)
@@ -458,7 +486,11 @@ def bench_minkunet(args, ME, MEB, dist_utils, rank, world, dev, startup):
         "config": {"workload": f"MinkUNet34C (3 -> 20 classes, {n_params} parameters) "
                                f"forward + cross-entropy + backward + SGD step, {n} voxels/GPU on a union of 9 planes "
                                f"in 400^3 (SURVEY 8d), {'bf16 activations / fp32 master weights and accumulation' if bf16 else 'fp32'}, "
-                               "maps cached (BASELINE configs[2]; configs[3] with N = 8)",
+                               + {"cached": "maps cached", "fresh": "a NEW scene every step (all maps and plans rebuilt)",
+                                  "pipelined": "a NEW scene every step, its maps prefetched on a side stream during the "
+                                               "previous backward pass"}[args.scenes]
+                               + " (BASELINE configs[2]; configs[3] with N = 8)",
+                   "scenes": args.scenes,
                    "points_per_gpu": n,
                    "parallelism": f"scene-sharded dp{world}" + (
                        f", torch DDP over {dist_utils.backend_name()} (25 MB gradient buckets overlapped with backward)"
@@ -524,6 +556,8 @@ def main():
     ap.add_argument("--min-blocks", type=int, default=3)
     ap.add_argument("--max-blocks", type=int, default=200)
     ap.add_argument("--backend", choices=("auto", "nccl", "gloo"), default="auto")
+    ap.add_argument("--scenes", choices=("cached", "fresh", "pipelined"), default="cached",
+                    help="minkunet: reuse one scene's maps (default, BASELINE configs[2]), or rebuild them every step")
     ap.add_argument("--torch-loss", action="store_true",
                     help="minkunet: torch.nn.CrossEntropyLoss instead of examples/minkunet.py::cross_entropy (same math)")
     ap.add_argument("--sync-bn", action="store_true", help="minkunet, N > 1: MinkowskiSyncBatchNorm (reference recipe)")

@@ -20,7 +20,7 @@ from .convolution import (  # noqa: F401
 from .pruning import MinkowskiPruning, MinkowskiPruningFunction  # noqa: F401
 from .union import MinkowskiUnion, MinkowskiUnionFunction  # noqa: F401
 from .coordinate_manager import (  # noqa: F401
-    CoordinateManager, set_gpu_allocator, set_memory_manager_backend)
+    CoordinateManager, set_gpu_allocator, set_memory_manager_backend, set_map_prefetch, map_prefetch_enabled)
 from .kernel_generator import KernelGenerator, get_kernel_volume  # noqa: F401
 from .layers import (  # noqa: F401
     MinkowskiBatchNorm, MinkowskiDropout, MinkowskiELU, MinkowskiLeakyReLU, MinkowskiLinear, MinkowskiReLU,

@@ -349,6 +349,7 @@ class KernelMapGPU:
         self._store = store if store is not None else {}
         self._flip = flip
         self._launch_cache = {}               # per view: launch geometry and device addresses of the plans
+        self._recipe, self._recipe_key = None, None   # the owning manager's request log (CoordinateMapManager.prefetch)
 
     @property
     def k_offsets(self):
@@ -593,6 +594,12 @@ class CoordinateMapManagerGPU_c10:
         self._origin_maps = {}
         self._prune_rows = {}
         self._stride_maps = {}
+        # Not in the reference: the map-building requests this manager served on a cache miss, in order — strided
+        # maps, kernel maps, tile-plan / weight-gradient configurations.  `prefetch(recipe)` replays such a list on a
+        # NEW scene right after its coordinates are inserted, so that every host read-back of the build (output sizes,
+        # pair counts) happens in one burst before the forward pass instead of draining the launch queue in the
+        # middle of it.
+        self._recipe = []
 
     # ---- keys -----------------------------------------------------------------------------------
     @staticmethod
@@ -664,6 +671,7 @@ class CoordinateMapManagerGPU_c10:
                                                 _stream(dev)))
             cmap, _, inverse = _insert(strided[:in_map.n], out_ts)
             self._maps[ok] = cmap
+            self._recipe.append(("stride", ik, tuple(stride), str(string_id)))
         return CoordinateMapKey(list(ok[0]), ok[1])
 
     def stride_map(self, in_key, strided_key):
@@ -902,7 +910,86 @@ class CoordinateMapManagerGPU_c10:
                 fwd = _build_kernel_map(out_map, in_map, region)
             km = fwd.swapped()
         self._kernel_maps[key] = km
+        km._recipe, km._recipe_key = self._recipe, key
+        self._recipe.append(("kernel_map", key))
         return km
+
+    def device_tensors(self):
+        """Every device tensor this manager holds (coordinate maps, hash tables, spatial indices, kernel maps, tile
+        plans, cached launch configurations)."""
+        seen, out = set(), []
+
+        def walk(o, depth=0):
+            if isinstance(o, torch.Tensor):
+                if o.is_cuda and id(o) not in seen:
+                    seen.add(id(o))
+                    out.append(o)
+                return
+            if id(o) in seen or depth > 6:
+                return
+            if isinstance(o, (list, tuple, set)):
+                seen.add(id(o))
+                for v in o:
+                    walk(v, depth + 1)
+            elif isinstance(o, dict):
+                seen.add(id(o))
+                for v in o.values():
+                    walk(v, depth + 1)
+            elif isinstance(o, (_CoordinateMapGPU, KernelMapGPU, _SpatialIndex, _LazyOffsets)):
+                seen.add(id(o))
+                names = getattr(type(o), "__slots__", None) or list(vars(o))
+                for name in names:
+                    if name not in ("_recipe", "in_map", "out_map"):
+                        walk(getattr(o, name, None), depth + 1)
+        for store in (self._maps, self._kernel_maps, self._origin_maps, self._prune_rows, self._stride_maps):
+            walk(store)
+        return out
+
+    def record_stream(self, stream):
+        """Tell the caching allocator that `stream` uses this manager's buffers (torch.Tensor.record_stream on each):
+        needed when the maps were built on a side stream — e.g. the next scene's maps during the current step's
+        backward pass, DESIGN 9.8 — and are consumed on another one."""
+        for t in self.device_tensors():
+            t.record_stream(stream)
+
+    def recipe(self):
+        """The build requests served so far (a list of plain tuples; see __init__)."""
+        return list(self._recipe)
+
+    def prefetch(self, recipe):
+        """Replay the build requests of another scene's manager on this one: strided coordinate maps, kernel maps,
+        tile plans and weight-gradient launch configurations are built now (results are cached under the same keys
+        the layers will ask for).  Requests that do not apply to this manager are skipped.  Returns the number of
+        requests replayed."""
+        done = 0
+        for op in recipe:
+            try:
+                if op[0] == "stride":
+                    _, ik, stride, sid = op
+                    if ik in self._maps:
+                        self.stride(CoordinateMapKey(list(ik[0]), ik[1]), list(stride), sid)
+                        done += 1
+                elif op[0] == "kernel_map":
+                    ik, ok, ks, st, dl, rt, tr, pool = op[1]
+                    if ik in self._maps and ok in self._maps:
+                        self._kernel_map(CoordinateMapKey(list(ik[0]), ik[1]), CoordinateMapKey(list(ok[0]), ok[1]), ks,
+                                         st, dl, RegionType(rt), None, tr, pool)
+                        done += 1
+                elif op[0] == "conv_cfg":
+                    _, key, target, c_src, c_dst, bf16 = op
+                    km = self._kernel_maps.get(key)
+                    if km is not None:
+                        _conv_launch_cfg(km, target, km.n_out if target == "out" else km.n_in, c_src, c_dst, bf16)
+                        done += 1
+                elif op[0] == "wgrad_cfg":
+                    _, key, c_in, c_out, bf16 = op
+                    km = self._kernel_maps.get(key)
+                    if km is not None:
+                        _wgrad_launch_cfg(km, c_in, c_out, bf16)
+                        done += 1
+            except RuntimeError:
+                continue
+        return done
 
     def kernel_map(self, in_key, out_key, kernel_size, kernel_stride, kernel_dilation, region_type, offset,
                    is_transpose, is_pool):
@@ -1003,6 +1090,45 @@ def plan_config(n_tgt, volume, n_pairs, c_src, c_dst, bf16=False, split=False):
     return _TILE_ROWS or int(t.value), _BATCH_GROUPS or int(g.value)
 
 
+def _conv_launch_cfg(km, target, n_tgt, c_src, c_dst, bf16):
+    """Launch geometry of a (kernel map side, channel shape, dtype): tile plan + device addresses, computed once per
+    kernel map -> (split, cfg)."""
+    lib = _lib.load()
+    volume = km.volume
+    split = (not bf16) and _use_split(lib, c_src, c_dst)
+    ck = (target, c_src, c_dst, bf16, split, _TILE_ROWS, _BATCH_GROUPS, _SPATIAL_TILES)
+    cfg = km._launch_cache.get(ck)
+    if cfg is None:
+        tile_rows, batch_groups = plan_config(n_tgt, km.volume, km.n_pairs, c_src, c_dst, bf16, split)
+        plan_src, plan_dst, batch_desc, tile_bptr, _ = km.plan(target, tile_rows, batch_groups)
+        elems = int((lib.me_conv_packed_weight_elems_bf16 if bf16 else
+                     (lib.me_conv_packed_weight_elems_f32x3 if split else lib.me_conv_packed_weight_elems))(
+            volume, c_src, c_dst))
+        order = km.order(target)
+        cfg = (tile_rows, batch_groups, plan_src, plan_dst, batch_desc, tile_bptr, order, elems,
+               _ptr(plan_src), _ptr(plan_dst), _ptr(batch_desc), _ptr(tile_bptr), _ptr(order))
+        km._launch_cache[ck] = cfg
+        if km._recipe is not None:
+            km._recipe.append(("conv_cfg", km._recipe_key, target, c_src, c_dst, bool(bf16)))
+    return split, cfg
+
+
+def _wgrad_launch_cfg(km, c_in, c_out, bf16):
+    lib = _lib.load()
+    ck = ("wgrad", c_in, c_out, bf16)
+    cfg = km._launch_cache.get(ck)
+    if cfg is None:
+        volume = km.volume
+        koffs = (ctypes.c_int64 * (volume + 1))(*km.k_offsets)
+        wsb = int((lib.me_conv_wgrad_workspace_bytes_bf16 if bf16 else lib.me_conv_wgrad_workspace_bytes)(
+            koffs, volume, c_in, c_out))
+        cfg = (koffs, wsb, _ptr(km.in_pairs_buf), _ptr(km.out_pairs_buf), _ptr(km.k_offsets_dev))
+        km._launch_cache[ck] = cfg
+        if km._recipe is not None:
+            km._recipe.append(("wgrad_cfg", km._recipe_key, c_in, c_out, bool(bf16)))
+    return cfg
+
+
 def _conv_target(src_feat, kernel, km, target, n_tgt, name="conv_target", transposed=False):
     """dst[t] = sum over plan entries of src[s] @ W[k].
     transposed=False: W[k] = kernel[k] ([c_src, c_dst]);  transposed=True (dgrad): W[k] = kernel[k]^T."""
@@ -1035,20 +1161,7 @@ def _conv_target(src_feat, kernel, km, target, n_tgt, name="conv_target", transp
                 src_feat.data_ptr(), src_feat.shape[0], c_src, packed.data_ptr(), km.volume, c_dst, p_tbl, p_order,
                 out.data_ptr(), n_tgt, stream)), flops=2.0 * km.n_pairs * c_src * c_dst if KERNEL_TIMER else 0.0)
         return out
-    # launch geometry of this (map side, channel shape, dtype): computed once per kernel map
-    split = (not bf16) and _use_split(lib, c_src, c_dst)
-    ck = (target, c_src, c_dst, bf16, split, _TILE_ROWS, _BATCH_GROUPS, _SPATIAL_TILES)
-    cfg = km._launch_cache.get(ck)
-    if cfg is None:
-        tile_rows, batch_groups = plan_config(n_tgt, km.volume, km.n_pairs, c_src, c_dst, bf16, split)
-        plan_src, plan_dst, batch_desc, tile_bptr, _ = km.plan(target, tile_rows, batch_groups)
-        elems = int((lib.me_conv_packed_weight_elems_bf16 if bf16 else
-                     (lib.me_conv_packed_weight_elems_f32x3 if split else lib.me_conv_packed_weight_elems))(
-            volume, c_src, c_dst))
-        order = km.order(target)
-        cfg = (tile_rows, batch_groups, plan_src, plan_dst, batch_desc, tile_bptr, order, elems,
-               _ptr(plan_src), _ptr(plan_dst), _ptr(batch_desc), _ptr(tile_bptr), _ptr(order))
-        km._launch_cache[ck] = cfg
+    split, cfg = _conv_launch_cfg(km, target, n_tgt, c_src, c_dst, bf16)
     tile_rows, batch_groups, _, _, _, _, _, elems, p_src, p_dst, p_desc, p_bptr, p_order = cfg
     flops = 2.0 * km.n_pairs * c_src * c_dst
     stream = _stream(dev)
@@ -1119,14 +1232,7 @@ def _conv_backward(in_feat, grad_out, kernel, km, algo=None):
     grad_in = _conv_target(grad_out, kernel, km, "in", km.n_in, name="conv_dgrad", transposed=True)
     # wgrad: always accumulated and reduced in fp32; handed back in the kernel's dtype
     grad_w = torch.empty(kernel.shape, dtype=torch.float32, device=dev)
-    ck = ("wgrad", c_in, c_out, bf16)
-    cfg = km._launch_cache.get(ck)
-    if cfg is None:
-        koffs = (ctypes.c_int64 * (volume + 1))(*km.k_offsets)
-        wsb = int((lib.me_conv_wgrad_workspace_bytes_bf16 if bf16 else lib.me_conv_wgrad_workspace_bytes)(
-            koffs, volume, c_in, c_out))
-        cfg = (koffs, wsb, _ptr(km.in_pairs_buf), _ptr(km.out_pairs_buf), _ptr(km.k_offsets_dev))
-        km._launch_cache[ck] = cfg
+    cfg = _wgrad_launch_cfg(km, c_in, c_out, bf16)
     koffs, wsb, p_in, p_out, p_koffs = cfg
     if _WGRAD_TUNING:   # the debug switches change the workspace need
         wsb = int((lib.me_conv_wgrad_workspace_bytes_bf16 if bf16 else lib.me_conv_wgrad_workspace_bytes)(

@@ -14,6 +14,33 @@ _coordinate_map_type = CoordinateMapType.CUDA
 _minkowski_algorithm = MinkowskiAlgorithm.DEFAULT
 
 
+# Map prefetch (not in the reference): when on, a SparseTensor that creates its own CoordinateManager replays, right after
+# its coordinates are inserted, the map-building requests that the PREVIOUS scene's manager served (strided maps, kernel
+# maps, tile plans) — a training loop builds the same maps for every scene, and building them in one burst keeps the
+# host read-backs of the build out of the forward pass (backend.CoordinateMapManagerGPU_c10.prefetch).
+_map_prefetch = os.environ.get("ME_AMD_MAP_PREFETCH", "0") != "0"
+_last_manager = None   # weak reference to the most recent CoordinateManager made by a SparseTensor
+
+
+def set_map_prefetch(enabled=True):
+    global _map_prefetch
+    _map_prefetch = bool(enabled)
+
+
+def map_prefetch_enabled():
+    return _map_prefetch
+
+
+def _prefetch_from_previous(manager):
+    """Called by SparseTensor for a freshly created manager whose coordinates have just been inserted."""
+    global _last_manager
+    prev = _last_manager() if _last_manager is not None else None
+    if _map_prefetch and prev is not None and prev is not manager and prev.D == manager.D:
+        manager.prefetch(prev.recipe())
+    import weakref
+    _last_manager = weakref.ref(manager)
+
+
 def set_coordinate_map_type(coordinate_map_type):
     global _coordinate_map_type
     _coordinate_map_type = coordinate_map_type
@@ -52,6 +79,17 @@ class CoordinateManager:
         self._manager = self._CoordinateManagerClass(minkowski_algorithm, num_threads)
         self.D = D
         self.minkowski_algorithm = minkowski_algorithm
+
+    # ---- build-request log (not in the reference; see set_map_prefetch) ---------------------------------------------
+    def recipe(self):
+        return self._manager.recipe()
+
+    def prefetch(self, recipe):
+        return self._manager.prefetch(recipe)
+
+    def record_stream(self, stream):
+        """See backend.CoordinateMapManagerGPU_c10.record_stream (maps built on a side stream)."""
+        self._manager.record_stream(stream)
 
     # ---- maps -----------------------------------------------------------------------------------
     def insert_and_map(self, coordinates, tensor_stride=1, string_id=""):

@@ -78,6 +78,7 @@ class SparseTensor:
                 coordinates = coordinates.to(device)
 
         self._D = coordinates.size(1) - 1 if coordinates is not None else coordinate_manager.D
+        own_manager = False
 
         if coordinate_manager is None:
             if _sparse_tensor_operation_mode == SparseTensorOperationMode.SHARE_COORDINATE_MANAGER:
@@ -89,6 +90,7 @@ class SparseTensor:
             else:
                 coordinate_manager = CoordinateManager(D=self._D, allocator_type=allocator_type,
                                                        minkowski_algorithm=minkowski_algorithm)
+                own_manager = True
         self._manager = coordinate_manager
 
         if coordinates is not None:
@@ -98,6 +100,9 @@ class SparseTensor:
             coordinate_map_key = CoordinateMapKey(convert_to_int_list(tensor_stride, self._D), "")
             coordinates, features, coordinate_map_key = self.initialize_coordinates(
                 coordinates, features, coordinate_map_key)
+            if own_manager:
+                from .coordinate_manager import _prefetch_from_previous
+                _prefetch_from_previous(coordinate_manager)
         else:
             assert coordinate_map_key.is_key_set(), "The coordinate key must be valid."
 
