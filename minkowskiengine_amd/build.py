@@ -33,5 +33,24 @@ def build(force=False, verbose=False):
     return OUT
 
 
+CPP_EXAMPLE_SRC = os.path.join(HERE, "..", "examples", "cpp", "conv_layer.cpp")
+CPP_EXAMPLE = os.path.join(HERE, "..", "examples", "cpp", "conv_layer")
+
+
+def build_cpp_example(force=False):
+    """examples/cpp/conv_layer: a convolution layer driven from plain C++ through the C ABI (include/me_amd.h), linked
+    against the in-tree libme_amd.so with an $ORIGIN-relative rpath so that it runs wherever the tree is copied."""
+    build()
+    src, out = os.path.normpath(CPP_EXAMPLE_SRC), os.path.normpath(CPP_EXAMPLE)
+    if not os.path.exists(src):
+        return None
+    deps = [src, OUT, os.path.join(HERE, "..", "include", "me_amd.h")]
+    if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+        return out
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", "-I", os.path.join(HERE, "..", "include"),
+                           src, "-L", HERE, "-lme_amd", "-Wl,-rpath,$ORIGIN/../../minkowskiengine_amd", "-o", out])
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
