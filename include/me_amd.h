@@ -284,6 +284,8 @@ int me_conv_wgrad_f32(const float *x_dev, int64_t n_in /* rows of x */, int32_t 
  * pairs); depth -1 = bf16 rows through the fp32-MFMA kernel instead of k_wgrad_bf16; depth -2 = fp32 rows through
  * the LDS-staged kernel; wgs_per_cu = resident workgroups per CU the ranges are sized for; 0 = shipped defaults. */
 void me_debug_set_wgrad_config(int depth, int wgs_per_cu);
+/* 0 (default): ranges of the same list fraction go to the same XCD (WgRangeOrder, conv.hip); -1: launch order */
+void me_debug_set_wgrad_order(int mode);
 
 /* ---- bf16 features (fp32 accumulation) --------------------------------------------------------------
  * The reference computes in float / double only (AT_DISPATCH_FLOATING_TYPES, src/convolution_gpu.cu:137-155);

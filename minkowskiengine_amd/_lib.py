@@ -91,6 +91,7 @@ SIGNATURES = {
     "me_conv_wgrad_f32": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, _P_I64, c_vp, c_i64, c_vp,
                                          c_vp, c_i64, c_vp]),
     "me_debug_set_wgrad_config": (None, [ctypes.c_int, ctypes.c_int]),
+    "me_debug_set_wgrad_order": (None, [ctypes.c_int]),
     "me_bn_workspace_bytes": (c_i64, [c_i64, c_i32]),
     "me_bn_stats": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i32, ctypes.c_float, ctypes.c_float, c_vp, c_vp, c_vp, c_vp,
                                    c_vp, c_vp, c_i64, c_vp]),

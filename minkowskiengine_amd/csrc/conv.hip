@@ -23,7 +23,9 @@
 // of the transposed neighbour table.  wgrad reduces over the per-offset pair lists in chunks.
 #include "conv_common.hpp"
 
+#include <algorithm>
 #include <type_traits>
+#include <vector>
 
 namespace me {
 
@@ -841,6 +843,18 @@ __global__ __launch_bounds__(256) void k_transpose_kernel(const float *__restric
 // in range order (fixed summation order -> bitwise reproducible) and undoes the channel interleave.
 constexpr int kWgMB = 4;  // 16-row MFMA blocks of input channels per wave (64 channels, one dwordx4 per lane)
 
+// Which range a workgroup takes (round 2).  All ranges are resident at once and every range walks its pairs in
+// ascending output row, so the ranges that started at the same FRACTION of their offset's list read the same dy rows
+// at the same time — one range per offset, ~27 of them.  Workgroups go to the eight XCDs round-robin by index, so in
+// launch order those 27 land on eight different L2s and every dy row is fetched from the Infinity Cache / HBM once
+// per pair (TCC hit rate 19 %).  The table sends ranges of the same fraction to the same XCD; it travels as a kernel
+// argument (no device buffer, no copy).  n = 0: identity.
+constexpr int kWgMaxOrder = 1024;
+struct WgRangeOrder {
+  int n;
+  uint16_t v[kWgMaxOrder];
+};
+
 // largest k in [0, volume) with koffs[k] <= e
 __device__ __forceinline__ int wgrad_locate_offset(const int64_t *__restrict__ koffs, int volume, int64_t e) {
   int lo = 0, hi = volume;
@@ -913,13 +927,13 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 3)) void k_wgrad_f32(const T *_
                                                   const int32_t *__restrict__ out_pairs,
                                                   const int64_t *__restrict__ koffs, int volume,
                                                   int64_t n_pairs, int n_ranges, int n_cob,
-                                                  float *__restrict__ partial) {
+                                                  float *__restrict__ partial, const WgRangeOrder order) {
   constexpr int MB = kWgMB;
   static_assert(DEPTH <= 8 && 16 % DEPTH == 0, "ring depth must divide the 16 steps of a 64-pair block");
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int i16 = lane & 15, q = lane >> 4;
-  const int range = blockIdx.x;
+  const int range = order.n > 0 ? (int)order.v[blockIdx.x] : (int)blockIdx.x;
   const int ci0 = blockIdx.y * (16 * MB);
   const int cob = blockIdx.z * (blockDim.x >> 6) + wave;  // block of 16*NB output channels
   if (cob >= n_cob) return;  // whole wave idle (there are no barriers in this kernel)
@@ -1244,6 +1258,238 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_bf16(const __bf16 *__restrict_
     multiply(buf);
     pending = (cB == 0 || kB != kA) ? kA : -1;  // last step of offset kA inside this range
     buf ^= 1;
+    kA = kB; eA = eB; cA = cB;
+    kB = kC; eB = eC; cB = cC;
+    advance(kC, eC, cC);
+    cC = step_count(kC, eC);
+  }
+  if (pending >= 0) flush(pending);
+}
+
+// =================================================================================================
+// wgrad of fp32 rows on the bf16 matrix pipe (round 2): k_wgrad_f32x3
+// =================================================================================================
+// k_wgrad_f32 runs at 0.68 of the fp32 MFMA peak (107 TF at config 2) — with 5 TB/s of gathers it LOOKED bandwidth
+// bound, but sending ranges that read the same dy rows to the same XCD (WgRangeOrder) cut its HBM-side traffic by
+// 20 % and its duration by nothing: the fp32 MFMA, which blocks the SIMD for the loop's address arithmetic and
+// loads, is the limit.  Here the fp32 rows are split exactly into three bf16 terms (conv_f32x3.hip) while they are
+// written to LDS and the products are rebuilt from six v_mfma_f32_16x16x32_bf16: structure of k_wgrad_bf16 (rows
+// staged once per workgroup, operands read back transposed with ds_read_b64_tr_b16, equal pair ranges, register
+// image partials, ordered reduction), one LDS buffer of three planes per operand and two barriers per 32-pair step
+// so that three workgroups fit a CU and cover each other's split / store phases.
+template <int NB>
+__global__ __launch_bounds__(256, 3) void k_wgrad_f32x3(const float *__restrict__ x, int c_in,
+                                                       const float *__restrict__ dy, int c_out,
+                                                       const int32_t *__restrict__ in_pairs,
+                                                       const int32_t *__restrict__ out_pairs,
+                                                       const int64_t *__restrict__ koffs, int volume,
+                                                       int64_t n_pairs, int n_ranges, int n_cob,
+                                                       float *__restrict__ partial, const WgRangeOrder order) {
+  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+  constexpr int MB = 4;
+  constexpr int SP = 32;                 // pairs per step = the K of one MFMA
+  constexpr int COB = 64 * NB;           // output channels per workgroup
+  constexpr int XLD = 64 + kWgStepLd;    // elements
+  constexpr int DLD = COB + kWgStepLd;
+  constexpr int XPL = SP * XLD, DPL = SP * DLD;   // elements of one plane
+  constexpr int XP = SP * 8 / 256;       // 8-channel x pieces (32 bytes of fp32) per thread and step
+  constexpr int DP = SP * (COB / 8) / 256;
+  static_assert(XP == 1 && DP >= 1, "step size");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __bf16 *s_x = reinterpret_cast<__bf16 *>(smem);            // [3][SP][XLD]
+  __bf16 *s_d = s_x + 3 * XPL;                                // [3][SP][DLD]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15, q = lane >> 4;
+  const int range = order.n > 0 ? (int)order.v[blockIdx.x] : (int)blockIdx.x;
+  const int ci0 = blockIdx.y * 64;
+  const int cog = blockIdx.z * COB;                           // first output channel of the workgroup
+  const int cob = blockIdx.z * 4 + wave;                      // this wave's block of 16*NB output channels
+  const int64_t e_lo = n_pairs * range / n_ranges;
+  const int64_t e_hi = n_pairs * (range + 1) / n_ranges;
+  if (e_lo >= e_hi) return;                                   // whole workgroup
+
+  constexpr int kImage = MB * NB * 4 * 64;
+  const int64_t image_stride = (int64_t)gridDim.y * n_cob * kImage;
+  float *const image0 = partial + ((int64_t)blockIdx.y * n_cob + min(cob, n_cob - 1)) * kImage + lane;
+
+  auto first_offset = [&](int64_t e) {
+    int lo = 0, hi = volume;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (koffs[mid] <= e) lo = mid; else hi = mid;
+    }
+    return lo;
+  };
+  auto step_count = [&](int k, int64_t e) -> int {
+    if (e >= e_hi) return 0;
+    const int64_t kend = min(koffs[k + 1], e_hi);
+    return (int)min((int64_t)SP, kend - e);
+  };
+  auto advance = [&](int &k, int64_t &e, int cnt) {
+    e += cnt;
+    if (e < e_hi) {
+      while (koffs[k + 1] <= e) ++k;
+    }
+  };
+
+  int32_t pin = 0, pout = 0;            // pair indices of the step whose rows are loaded next (lane l: pair e + l)
+  f32x4 rx[XP][2], rd[DP][2];
+  auto load_idx = [&](int64_t e) {
+    const int64_t ec = min(e + lane, n_pairs - 1);            // unconditional load from a valid address
+    const int32_t *pi = in_pairs + ec, *po = out_pairs + ec;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(pin) : "v"(pi) : "memory");
+    asm volatile("global_load_dword %0, %1, off" : "=v"(pout) : "v"(po) : "memory");
+  };
+  // (inline asm as in k_wgrad_bf16: hipcc sinks ordinary loads whose first use is in the next iteration below the
+  // MFMAs; the matching s_waitcnt is wait_rows)
+  auto load_rows = [&]() {
+#pragma unroll
+    for (int j = 0; j < XP; ++j) {
+      const int idx = j * 256 + tid;
+      const int row = idx >> 3;
+      const int ch = ci0 + (idx & 7) * 8;
+      const int32_t r = __shfl(pin, row, 64);
+      const float *p = x + (int64_t)r * c_in + (ch < c_in ? ch : 0);
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rx[j][0]) : "v"(p) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(rx[j][1]) : "v"(p) : "memory");
+    }
+#pragma unroll
+    for (int j = 0; j < DP; ++j) {
+      const int idx = j * 256 + tid;
+      const int row = idx / (COB / 8);
+      const int ch = cog + (idx % (COB / 8)) * 8;
+      const int32_t r = __shfl(pout, row, 64);
+      const float *p = dy + (int64_t)r * c_out + (ch < c_out ? ch : 0);
+      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rd[j][0]) : "v"(p) : "memory");
+      asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(rd[j][1]) : "v"(p) : "memory");
+    }
+  };
+  auto wait_rows = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pin), "+v"(pout));
+#pragma unroll
+    for (int j = 0; j < XP; ++j) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rx[j][0]), "+v"(rx[j][1]));
+#pragma unroll
+    for (int j = 0; j < DP; ++j) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rd[j][0]), "+v"(rd[j][1]));
+  };
+  auto write_lds = [&](int cnt) {
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < XP; ++j) {
+      const int idx = j * 256 + tid;
+      const int row = idx >> 3;
+      const int ch = ci0 + (idx & 7) * 8;
+      const bool ok = row < cnt && ch < c_in;                // pairs beyond the step / channels beyond c_in: zeros
+      u32x4 p1, p2, p3;
+      split3(rx[j][0], rx[j][1], p1, p2, p3);
+      __bf16 *o = s_x + row * XLD + (idx & 7) * 8;
+      *reinterpret_cast<u32x4 *>(o) = ok ? p1 : zero;
+      *reinterpret_cast<u32x4 *>(o + XPL) = ok ? p2 : zero;
+      *reinterpret_cast<u32x4 *>(o + 2 * XPL) = ok ? p3 : zero;
+    }
+#pragma unroll
+    for (int j = 0; j < DP; ++j) {
+      const int idx = j * 256 + tid;
+      const int row = idx / (COB / 8);
+      const int pc = idx % (COB / 8);
+      const bool ok = row < cnt && cog + pc * 8 < c_out;
+      u32x4 p1, p2, p3;
+      split3(rd[j][0], rd[j][1], p1, p2, p3);
+      __bf16 *o = s_d + row * DLD + pc * 8;
+      *reinterpret_cast<u32x4 *>(o) = ok ? p1 : zero;
+      *reinterpret_cast<u32x4 *>(o + DPL) = ok ? p2 : zero;
+      *reinterpret_cast<u32x4 *>(o + 2 * DPL) = ok ? p3 : zero;
+    }
+  };
+
+  f32x4 acc[MB][NB];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int n = 0; n < NB; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto flush = [&](int k) {
+    if (cob < n_cob) {
+      float *img = image0 + (int64_t)(range + k) * image_stride;
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) img[((m * NB + n) * 4 + r) * 64] = acc[m][n][r];
+    }
+  };
+  // operand fragments as in k_wgrad_bf16: lane (i16, q) addresses row 4*q + (i16 >> 2) of each 16-row half and the
+  // 4-channel chunk (i16 & 3); it receives channel i16 of rows 4*q .. 4*q + 3
+  const int frag_row = 4 * q + (i16 >> 2);
+  const int frag_col = 4 * (i16 & 3);
+  auto multiply = [&]() {
+    const __bf16 *bx = s_x + frag_row * XLD + frag_col;
+    const __bf16 *bd = s_d + frag_row * DLD + wave * 16 * NB + frag_col;
+    bf16x8 a[3][MB], b[3][NB];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+      for (int m = 0; m < MB; ++m) {
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(bx + pl * XPL + 16 * m));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(bx + pl * XPL + 16 * XLD + 16 * m));
+        a[pl][m] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+#pragma unroll
+      for (int n = 0; n < NB; ++n) {
+        const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(bd + pl * DPL + 16 * n));
+        const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(bd + pl * DPL + 16 * DLD + 16 * n));
+        b[pl][n] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+    }
+    // (x plane, dy plane) by ascending magnitude: 2^-16 terms, 2^-8 terms, leading term
+    constexpr int XPI[6] = {2, 0, 1, 1, 0, 0};
+    constexpr int DPI[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[XPI[t]][m], b[DPI[t]][n], acc[m][n], 0, 0, 0);
+  };
+
+  // cursors: A = step being multiplied, B = step whose rows are in flight, C = step whose indices are in flight
+  int kA = first_offset(e_lo);
+  int64_t eA = e_lo;
+  int cA = step_count(kA, eA);
+  int kB = kA;
+  int64_t eB = eA;
+  advance(kB, eB, cA);
+  int cB = step_count(kB, eB);
+  int kC = kB;
+  int64_t eC = eB;
+  advance(kC, eC, cB);
+  int cC = step_count(kC, eC);
+
+  load_idx(eA);
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(pin), "+v"(pout));
+  load_rows();          // rows of step A
+  load_idx(eB);         // indices of step B
+  zero_acc();
+  int pending = -1;     // offset whose accumulators must be flushed before the next step is multiplied
+  while (cA > 0) {
+    if (pending >= 0) {
+      flush(pending);
+      zero_acc();
+    }
+    wait_rows();
+    __syncthreads();      // everybody is done reading the previous step
+    write_lds(cA);        // rows of step A (requested one step ago), split into the three planes
+    load_rows();          // rows of step B (its indices arrived with A's rows)
+    load_idx(eC);         // indices of step C
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();      // step A visible
+    multiply();
+    pending = (cB == 0 || kB != kA) ? kA : -1;  // last step of offset kA inside this range
     kA = kB; eA = eB; cA = cB;
     kB = kC; eB = eC; cB = cC;
     advance(kC, eC, cC);
@@ -1765,6 +2011,7 @@ static ConvDmaShape conv_dma_shape(int c_src, int c_dst) {
 
 int g_wgrad_depth = 0;         // me_debug_set_wgrad_config: 0 = default
 int g_wgrad_wgs_per_cu = 0;
+int g_wgrad_order = 0;         // me_debug_set_wgrad_order: 0 = XCD-aware range order, -1 = launch order
 
 // launch geometry of the wgrad kernels for a (pairs, channels) problem
 struct WgradGeom {
@@ -1797,7 +2044,7 @@ static WgradGeom wgrad_geom(int64_t n_pairs, int64_t volume, int c_in, int c_out
 
 // geometry of the LDS-staged kernels (k_wgrad_bf16, k_wgrad_lds_f32): always four waves side by side along the
 // output channels
-static WgradGeom wgrad_geom_staged(int64_t n_pairs, int c_in, int c_out) {
+static WgradGeom wgrad_geom_staged(int64_t n_pairs, int c_in, int c_out, int wpc_default = 2) {
   WgradGeom g;
   // 64 or 128 output channels per workgroup; wider layers take several workgroup columns (grid.z) that
   // re-gather the x rows (the <4, 1> instantiation — 256 channels, 32-pair steps — faulted on the GPU and is
@@ -1807,7 +2054,7 @@ static WgradGeom wgrad_geom_staged(int64_t n_pairs, int c_in, int c_out) {
   g.n_cob = (int)ceil_div(c_out, 16 * g.nb);
   g.waves = 4;
   g.gz = (int)ceil_div(g.n_cob, 4);
-  const int wpc = g_wgrad_wgs_per_cu > 0 ? g_wgrad_wgs_per_cu : 2;
+  const int wpc = g_wgrad_wgs_per_cu > 0 ? g_wgrad_wgs_per_cu : wpc_default;
   int64_t r = ceil_div((int64_t)device_cu_count() * wpc, (int64_t)g.n_cib * g.gz);
   if (r > n_pairs / 64) r = n_pairs / 64;
   if (r < 1) r = 1;
@@ -1854,9 +2101,70 @@ static int launch_wgrad_lds_f32(const WgradGeom &g, const float *x, int c_in, co
   return 0;
 }
 
+template <int NB>
+static int launch_wgrad_f32x3(const WgradGeom &g, const float *x, int c_in, const float *dy, int c_out,
+                              const int32_t *in_pairs, const int32_t *out_pairs, const int64_t *k_offsets_dev,
+                              int volume, int64_t n_pairs, float *partial, const WgRangeOrder &order,
+                              hipStream_t stream) {
+  const int lds = 3 * 32 * ((64 + kWgStepLd) + (64 * NB + kWgStepLd)) * 2;
+  const dim3 grid((unsigned)g.ranges, (unsigned)g.n_cib, (unsigned)g.gz);
+  hipLaunchKernelGGL((k_wgrad_f32x3<NB>), grid, dim3(256), (size_t)lds, stream, x, c_in, dy, c_out, in_pairs,
+                     out_pairs, k_offsets_dev, volume, n_pairs, (int)g.ranges, g.n_cob, partial, order);
+  ME_LAUNCH_CHECK();
+  return 0;
+}
+
+// fp32 rows on the bf16 matrix pipe: whole 32-byte pieces and enough matrix work (the dispatch rule of the forward /
+// dgrad kernels, backend.py); me_debug_set_wgrad_config(-3, 0) = never, (-4, 0) = wherever the rows allow
+static bool wgrad_use_split(int c_in, int c_out) {
+  if (g_wgrad_depth == -3 || (c_in % 8) != 0 || (c_out % 8) != 0) return false;
+  if (g_wgrad_depth == -4) return true;
+  return g_wgrad_depth == 0 && (int64_t)c_in * c_out >= 8192;
+}
+
 }  // namespace me
 
 using namespace me;
+
+// see WgRangeOrder.  Ranges sorted by the fraction of their offset's pair list at which they start, cut into groups
+// of 32 (one range of every offset + the extra ranges of the centre offset), group g -> XCD g % 8; XCD x owns the
+// workgroups x, x + 8, ...  Only for grids with one workgroup per range (the table indexes blockIdx.x).
+static WgRangeOrder wgrad_range_order(const int64_t *k_offsets, int64_t volume, int64_t n_pairs, int64_t ranges,
+                                      int64_t wgs_per_range) {
+  WgRangeOrder o;
+  o.n = 0;
+  if (g_wgrad_order < 0 || ranges < 64 || ranges > kWgMaxOrder || wgs_per_range != 1 || volume < 2) return o;
+  struct Item {
+    double f;
+    int r;
+  };
+  std::vector<Item> items((size_t)ranges);
+  int k = 0;
+  for (int64_t r = 0; r < ranges; ++r) {
+    const int64_t e = wgrad_range_begin(r, n_pairs, ranges);
+    while (k + 1 < volume && k_offsets[k + 1] <= e) ++k;
+    const int64_t len = k_offsets[k + 1] - k_offsets[k];
+    items[(size_t)r] = {len > 0 ? (double)(e - k_offsets[k]) / (double)len : 0.0, (int)r};
+  }
+  std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return a.f < b.f; });
+  constexpr int kXcds = 8, kGroup = 32;
+  std::vector<std::vector<int>> per_xcd(kXcds);
+  for (int64_t i = 0; i < ranges; ++i) per_xcd[(size_t)((i / kGroup) % kXcds)].push_back(items[(size_t)i].r);
+  std::vector<int> assigned((size_t)ranges, -1), spill;
+  for (int x = 0; x < kXcds; ++x) {
+    for (size_t i = 0; i < per_xcd[(size_t)x].size(); ++i) {
+      const int64_t b = (int64_t)i * kXcds + x;
+      if (b < ranges) assigned[(size_t)b] = per_xcd[(size_t)x][i];
+      else spill.push_back(per_xcd[(size_t)x][i]);
+    }
+  }
+  size_t sp = 0;
+  for (int64_t b = 0; b < ranges; ++b)
+    if (assigned[(size_t)b] < 0) assigned[(size_t)b] = spill[sp++];
+  o.n = (int)ranges;
+  for (int64_t b = 0; b < ranges; ++b) o.v[b] = (uint16_t)assigned[(size_t)b];
+  return o;
+}
 
 template <typename T>
 static int wgrad_launch(const T *x, int64_t n_in, int32_t c_in, const T *dy, int64_t n_out, int32_t c_out,
@@ -1881,18 +2189,19 @@ static int wgrad_launch(const T *x, int64_t n_in, int32_t c_in, const T *dy, int
     const bool small = n_in > 0 && n_out > 0 && n_in < (1 << 24) && n_out < (1 << 24) &&
                        n_in * c_in * (int64_t)sizeof(T) < lim && n_out * c_out * (int64_t)sizeof(T) < lim &&
                        g_conv_variant != 6;  // (variant 6: the 64-bit address path, tests/test_gpu_conv.py)
+    const WgRangeOrder order = wgrad_range_order(k_offsets, volume, n_pairs, g.ranges, (int64_t)g.n_cib * g.gz);
 #define ME_WGRAD_LAUNCH(NBV, DV)                                                                                 \
   do {                                                                                                           \
     if (vec && small)                                                                                            \
       hipLaunchKernelGGL((k_wgrad_f32<T, NBV, DV, true, true>), grid, block, 0, stream, x, c_in, dy, c_out,      \
                          in_pairs, out_pairs, k_offsets_dev, (int)volume, n_pairs, (int)g.ranges, g.n_cob,       \
-                         partial);                                                                               \
+                         partial, order);                                                                        \
     else if (vec)                                                                                                \
       hipLaunchKernelGGL((k_wgrad_f32<T, NBV, DV, true>), grid, block, 0, stream, x, c_in, dy, c_out, in_pairs,  \
-                         out_pairs, k_offsets_dev, (int)volume, n_pairs, (int)g.ranges, g.n_cob, partial);       \
+                         out_pairs, k_offsets_dev, (int)volume, n_pairs, (int)g.ranges, g.n_cob, partial, order); \
     else                                                                                                         \
       hipLaunchKernelGGL((k_wgrad_f32<T, NBV, 8, false>), grid, block, 0, stream, x, c_in, dy, c_out, in_pairs,  \
-                         out_pairs, k_offsets_dev, (int)volume, n_pairs, (int)g.ranges, g.n_cob, partial);       \
+                         out_pairs, k_offsets_dev, (int)volume, n_pairs, (int)g.ranges, g.n_cob, partial, order); \
   } while (0)
     if (g.nb == 1) { if (depth == 4) ME_WGRAD_LAUNCH(1, 4); else ME_WGRAD_LAUNCH(1, 8); }
     else if (g.nb == 2) { if (depth == 4) ME_WGRAD_LAUNCH(2, 4); else ME_WGRAD_LAUNCH(2, 8); }
@@ -2056,10 +2365,12 @@ int64_t me_conv_wgrad_workspace_bytes(const int64_t *k_offsets, int64_t volume, 
   if (volume < 1 || c_in <= 0 || c_out <= 0) return 256;
   // the larger need of the two kernels (k_wgrad_lds_f32 / k_wgrad_f32)
   const WgradGeom g = wgrad_geom(k_offsets[volume], volume, c_in, c_out);
-  const WgradGeom h = wgrad_geom_staged(k_offsets[volume], c_in, c_out);
+  const WgradGeom h = wgrad_geom_staged(k_offsets[volume], c_in, c_out, 3);   // (k_wgrad_f32x3: three per CU)
   const int64_t a = (g.ranges + volume) * g.slot_floats, b = (h.ranges + volume) * h.slot_floats;
   return align_up((a > b ? a : b) * 4, 256);
 }
+
+void me_debug_set_wgrad_order(int mode) { g_wgrad_order = mode; }
 
 void me_debug_set_wgrad_config(int depth, int wgs_per_cu) {
   g_wgrad_depth = depth;
@@ -2076,6 +2387,31 @@ int me_conv_wgrad_f32(const float *x, int64_t n_in, int32_t c_in, const float *d
   // the same 82 TF on config 2 (profiles/r01_tune_wgrad_f32_staged.log): in fp32 the weight gradient is bound by
   // the ~4 TB/s at which 640 MB of random rows arrive from beyond the L2s, not by how the matrix pipe is fed
   // (it is 13 % faster on sparse maps and 40 % slower on 32 -> 32, so it is not the default).
+  if (wgrad_use_split(c_in, c_out)) {
+    ME_CHECK(volume >= 1 && volume <= 65535, "kernel volume out of range");
+    ME_CHECK((uintptr_t)x % 16 == 0 && (uintptr_t)dy % 16 == 0, "feature pointers must be 16-byte aligned");
+    ME_CHECK(workspace_bytes >= me_conv_wgrad_workspace_bytes(k_offsets, volume, c_in, c_out), "workspace too small");
+    const int64_t n_pairs = k_offsets[volume];
+    const WgradGeom g = wgrad_geom_staged(n_pairs, c_in, c_out, 3);
+    float *partial = reinterpret_cast<float *>(workspace);
+    if (n_pairs > 0) {
+      const WgRangeOrder order = wgrad_range_order(k_offsets, volume, n_pairs, g.ranges, (int64_t)g.n_cib * g.gz);
+      const int rc = g.nb == 1 ? launch_wgrad_f32x3<1>(g, x, c_in, dy, c_out, in_pairs, out_pairs, k_offsets_dev,
+                                                        (int)volume, n_pairs, partial, order, stream)
+                               : launch_wgrad_f32x3<2>(g, x, c_in, dy, c_out, in_pairs, out_pairs, k_offsets_dev,
+                                                        (int)volume, n_pairs, partial, order, stream);
+      if (rc != 0) return rc;
+    }
+    const dim3 rgrid((unsigned)ceil_div(g.slot_floats, 64), (unsigned)volume);
+    if (g.nb == 1)
+      hipLaunchKernelGGL((k_wgrad_reduce<1, true>), rgrid, dim3(64 * kWgReducePhases), 0, stream, partial, k_offsets_dev,
+                         (int)volume, n_pairs > 0 ? n_pairs : 1, (int)g.ranges, g.n_cib, g.n_cob, c_in, c_out, grad_w);
+    else
+      hipLaunchKernelGGL((k_wgrad_reduce<2, true>), rgrid, dim3(64 * kWgReducePhases), 0, stream, partial, k_offsets_dev,
+                         (int)volume, n_pairs > 0 ? n_pairs : 1, (int)g.ranges, g.n_cib, g.n_cob, c_in, c_out, grad_w);
+    ME_LAUNCH_CHECK();
+    return 0;
+  }
   if ((c_in % 4) != 0 || (c_out % 4) != 0 || g_wgrad_depth != -2)
     return wgrad_launch<float>(x, n_in, c_in, dy, n_out, c_out, in_pairs, out_pairs, k_offsets, k_offsets_dev, volume, grad_w,
                                workspace, workspace_bytes, stream);

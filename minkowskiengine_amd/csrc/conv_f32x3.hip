@@ -24,8 +24,6 @@
 
 namespace me {
 
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
 // LDS stage layout of one plane: 64 rows x KC bf16.  The LDS serves a ds_read_b128 in four fixed lane groups
 // ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...), i.e. 16 (row, 8-channel piece) accesses per cycle that must fall on 16
 // distinct 16-byte bank slots.  For KC = 32 / 64 / 128 an XOR swizzle of the piece index by a function of the row does
@@ -50,26 +48,6 @@ __host__ __device__ constexpr int x3_group_shares(int nc) { return nc >= 96 ? 1 
 // accumulator tile + TWO stage buffers (three planes + the target indices of 64 rows each)
 __host__ __device__ constexpr int conv_f32x3_lds_bytes(int nc, int kc, int tile_rows) {
   return (tile_rows + 1) * (nc + kAccPad) * 4 + 2 * ME_MAX_BATCH_GROUPS * 16 * (3 * x3_stage_ld(kc) * 2 + 4);
-}
-
-// eight fp32 values -> the three bf16 planes of the exact split (see the header)
-__device__ __forceinline__ void split3(const f32x4 &lo, const f32x4 &hi, u32x4 &p1, u32x4 &p2, u32x4 &p3) {
-  float a[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-  uint32_t b1[8], b2[8], b3[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    b1[e] = __float_as_uint(a[e]);
-    const float r = a[e] - __uint_as_float(b1[e] & 0xffff0000u);
-    b2[e] = __float_as_uint(r);
-    b3[e] = __float_as_uint(r - __uint_as_float(b2[e] & 0xffff0000u));
-  }
-  // upper halves of two encodings -> one dword (element 2j in the lower half)
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    p1[j] = __builtin_amdgcn_perm(b1[2 * j + 1], b1[2 * j], 0x07060302u);
-    p2[j] = __builtin_amdgcn_perm(b2[2 * j + 1], b2[2 * j], 0x07060302u);
-    p3[j] = __builtin_amdgcn_perm(b3[2 * j + 1], b3[2 * j], 0x07060302u);
-  }
 }
 
 // Packed weights: for offset k, source-channel chunk c, 16-column block cb, split plane p (0..2) and 32-channel

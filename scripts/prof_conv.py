@@ -24,6 +24,7 @@ gy = torch.rand(100000, 128, device=dev).to(tdt)
 MEB._TILE_ROWS = T
 MEB._BATCH_GROUPS = int(os.environ.get("CAP", "0"))
 lib.me_debug_set_conv_variant(var)
+lib.me_debug_set_wgrad_order(int(os.environ.get("WGRAD_ORDER", "0")))
 for _ in range(iters):
     y = MEB._conv_forward(x, w, km, "mfma")
     if os.environ.get("BWD", "1") == "1":

@@ -52,8 +52,18 @@ CONV_CASES = [
 def test_conv_forward_backward_vs_oracle(device, monkeypatch, pipe, n, extent, D, cin, cout, ks, stride, dil):
     """Both fp32 forward / dgrad kernels: the exactly-split operands on the bf16 matrix pipe (default where
     c_src % 8 == 0) and the fp32-MFMA kernel (ME_AMD_F32_SPLIT=0, and the fall-back for other channel counts)."""
-    from minkowskiengine_amd import backend as MEB
+    from minkowskiengine_amd import backend as MEB, _lib
     monkeypatch.setattr(MEB, "_F32_SPLIT", pipe == "bf16x6")
+    # the weight gradient follows: k_wgrad_f32x3 wherever the rows allow (-4) / never (-3)
+    lib = _lib.load()
+    lib.me_debug_set_wgrad_config(-4 if pipe == "bf16x6" else -3, 0)
+    try:
+        _conv_case(device, n, extent, D, cin, cout, ks, stride, dil)
+    finally:
+        lib.me_debug_set_wgrad_config(0, 0)
+
+
+def _conv_case(device, n, extent, D, cin, cout, ks, stride, dil):
     coords = make_cloud(n, extent, D, seed=n + cin, batch=2 if n > 100 else 1, negative=True)
     conv, x, y, feats, gy = _run_layer(device, coords, cin, cout, ks, stride, dil)
     in_c = coords.numpy()
@@ -218,6 +228,43 @@ def test_split_bf16_pipe_is_fp32_grade(device, monkeypatch, cin, cout, scale):
     print(f"relative to sum|x||w|: bf16x6 {errs[True]:.2e}, fp32 MFMA {errs[False]:.2e}")
     assert errs[True] <= 2e-6, errs
     assert errs[True] <= 4 * errs[False] + 1e-7, errs
+
+
+@pytest.mark.parametrize("cin,cout", [(64, 128), (128, 128), (32, 64)])
+def test_wgrad_range_order_and_split_kernel(device, cin, cout):
+    """(a) The XCD-aware range order of the weight-gradient kernels only changes which workgroup takes which range:
+    results are bit-identical to launch order.  (b) k_wgrad_f32x3 (fp32 rows split into three bf16 terms, six bf16
+    MFMAs) against float64 ground truth: error of fp32 order, not worse than 4x the fp32-MFMA kernel's."""
+    from minkowskiengine_amd import backend as MEB, _lib
+    lib = _lib.load()
+    coords = make_cloud(30000, 30, 3, seed=cin, negative=True)
+    n = coords.shape[0]
+    mgr = MEB.CoordinateMapManagerGPU_c10()
+    key, _ = mgr.insert_and_map(coords.to(device), [1, 1, 1], "")
+    km = mgr._kernel_map(key, key, [3] * 3, [1] * 3, [1] * 3, MEB.RegionType.HYPER_CUBE, None, False, False)
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(n, cin, generator=g) - 0.5
+    gy = torch.rand(n, cout, generator=g) - 0.5
+    w = torch.rand(27, cin, cout, generator=g).to(device)
+    _, okm = O.kernel_map(coords.numpy(), coords.numpy(), O.make_region(3, 3))
+    _, truth = O.conv_backward(x.double().numpy(), gy.double().numpy(), w.double().cpu().numpy(), okm)
+    _, bound = O.conv_backward(x.abs().double().numpy(), gy.abs().double().numpy(), w.double().cpu().numpy(), okm)
+    got = {}
+    try:
+        for name, depth, order in (("split", -4, 0), ("split_launch_order", -4, -1), ("mfma", -3, 0),
+                                   ("mfma_launch_order", -3, -1)):
+            lib.me_debug_set_wgrad_config(depth, 0)
+            lib.me_debug_set_wgrad_order(order)
+            got[name] = MEB._conv_backward(x.to(device), gy.to(device), w, km, "mfma")[1].clone()
+    finally:
+        lib.me_debug_set_wgrad_config(0, 0)
+        lib.me_debug_set_wgrad_order(0)
+    assert torch.equal(got["split"], got["split_launch_order"])
+    assert torch.equal(got["mfma"], got["mfma_launch_order"])
+    err = {k: float(np.max(np.abs(v.double().cpu().numpy() - truth) / np.maximum(bound, 1e-300)))
+           for k, v in got.items()}
+    print(f"wgrad {cin}->{cout}: error relative to sum |x||dy|: bf16x6 {err['split']:.2e}, fp32 MFMA {err['mfma']:.2e}")
+    assert err["split"] <= 2e-6 and err["split"] <= 4 * err["mfma"] + 1e-7, err
 
 
 def test_bias_and_use_mm(device):
