@@ -2114,12 +2114,14 @@ static int launch_wgrad_f32x3(const WgradGeom &g, const float *x, int c_in, cons
   return 0;
 }
 
-// fp32 rows on the bf16 matrix pipe: whole 32-byte pieces and enough matrix work (the dispatch rule of the forward /
-// dgrad kernels, backend.py); me_debug_set_wgrad_config(-3, 0) = never, (-4, 0) = wherever the rows allow
+// fp32 rows on the bf16 matrix pipe: whole 32-byte pieces and at least 32 x 32 channels (measured on dense and sparse
+// maps, profiles/r02_tune_wgrad_f32x3.log: 32->32 on par, 32->64 1.4x, 64->128 1.3x, 96->96 1.4x, 256->256 1.1 - 1.5x;
+// narrower layers would multiply mostly padding: the x tile is 64 channels wide);
+// me_debug_set_wgrad_config(-3, 0) = never, (-4, 0) = wherever the rows allow
 static bool wgrad_use_split(int c_in, int c_out) {
   if (g_wgrad_depth == -3 || (c_in % 8) != 0 || (c_out % 8) != 0) return false;
   if (g_wgrad_depth == -4) return true;
-  return g_wgrad_depth == 0 && (int64_t)c_in * c_out >= 8192;
+  return g_wgrad_depth == 0 && c_in >= 32 && c_out >= 32;
 }
 
 }  // namespace me

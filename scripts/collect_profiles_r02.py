@@ -109,6 +109,10 @@ def main():
     copy("r02r/unet_f32.json", "r02_bench_minkunet34c_f32_auto_policy.json")
     copy("r02r/unet_bf16.json", "r02_bench_minkunet34c_bf16_stage_pad.json")
     copy("r02r/pytest_gpu.log", "r02_pytest_gpu_full.log")
+    copy("tune_wgrad_x3.log", "r02_tune_wgrad_f32x3.log")
+    copy("pmc_wgrad_order.log", "r02_pmc_wgrad_range_order.log")
+    copy("r02v/bench.json", "r02_bench_conv_f32x3_wgrad_split.json")
+    copy("r02v/unet_f32.json", "r02_bench_minkunet34c_f32_wgrad_split.json")
     for extra in sys.argv[1:]:          # "src:dst" pairs for later sessions
         s, d = extra.split(":")
         copy(s, d)
