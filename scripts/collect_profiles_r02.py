@@ -113,6 +113,19 @@ def main():
     copy("pmc_wgrad_order.log", "r02_pmc_wgrad_range_order.log")
     copy("r02v/bench.json", "r02_bench_conv_f32x3_wgrad_split.json")
     copy("r02v/unet_f32.json", "r02_bench_minkunet34c_f32_wgrad_split.json")
+    # closing session of the round (scripts/gpu_final_r02.sh)
+    for src, dst in (("bench.json", "r02_bench_final.json"), ("bench_bf16.json", "r02_bench_final_bf16.json"),
+                     ("bench_sparse.json", "r02_bench_final_sparse.json"), ("bench_conv4d.json", "r02_bench_final_conv4d.json"),
+                     ("bench_conv4d_bf16.json", "r02_bench_final_conv4d_bf16.json"),
+                     ("bench_n2.json", "r02_bench_final_n2_selfspawn_1gpu.json"),
+                     ("unet_bf16.json", "r02_bench_final_minkunet34c_bf16.json"),
+                     ("unet_f32.json", "r02_bench_final_minkunet34c_f32.json"),
+                     ("unet_bf16_graph.json", "r02_bench_final_minkunet34c_bf16_graph.json"),
+                     ("kernel_stats_bench.csv", "r02_rocprof_kernel_stats_final.csv"),
+                     ("pytest_gpu.log", "r02_pytest_gpu_final.log"), ("smoke.log", "r02_smoke_final.log")):
+        copy("r02_final/" + src, dst)
+    copy("r02_final2/unet_bf16_fresh.json", "r02_bench_final_minkunet34c_bf16_fresh_scenes.json")
+    copy("r02_final2/unet_bf16_pipelined.json", "r02_bench_final_minkunet34c_bf16_pipelined_scenes.json")
     for extra in sys.argv[1:]:          # "src:dst" pairs for later sessions
         s, d = extra.split(":")
         copy(s, d)

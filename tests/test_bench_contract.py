@@ -12,7 +12,8 @@ REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
 def _lines():
     out = []
     for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r01_bench_v7*.json")) +
-                    glob.glob(os.path.join(ROOT, "profiles", "r01_bench_minkunet34c_*.json"))):
+                    glob.glob(os.path.join(ROOT, "profiles", "r01_bench_minkunet34c_*.json")) +
+                    glob.glob(os.path.join(ROOT, "profiles", "r02_bench_final*.json"))):
         with open(p) as f:
             out.append((os.path.basename(p), json.loads(f.read().strip().splitlines()[-1])))
     return out
@@ -31,13 +32,33 @@ def test_committed_bench_lines_follow_the_contract():
         for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
             assert k in r, (name, k)
         assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-        assert d["dtype"] in ("f32", "bf16") and r["peak"] == (2500.0 if d["dtype"] == "bf16" else 157.3)
+        # the roof follows the launch's arithmetic intensity (round 2): matrix peak of the dtype, or the 8 TB/s of HBM
+        assert d["dtype"] in ("f32", "bf16")
+        assert r["peak"] == ((2500.0 if d["dtype"] == "bf16" else 157.3) if r["bound"] == "mfma" else 8000.0)
+        assert r["unit"] == ("TFLOP/s" if r["bound"] == "mfma" else "GB/s")
         # value = voxels of all ranks / step time
         pts = d["config"]["points_per_gpu"] * d["n_gpus"]
         assert abs(d["value"] - pts / (d["ms_per_step"] * 1e-3) / 1e6) < 0.01 * d["value"]
         if d["cpu_baseline"] is not None:
             c = d["cpu_baseline"]
             assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+
+
+def test_round_2_headline_line():
+    """The closing line of round 2: config 2 in fp32 on one GPU, the reference's own CPU operators timed beside it,
+    the forward kernel priced against the fp32 MFMA peak (and, since it issues to the bf16 pipe, against that pipe's
+    ceiling for six MFMAs per product), HBM traffic from the committed PMC pass of that kernel."""
+    d = dict(_lines())["r02_bench_final.json"]
+    assert d["dtype"] == "f32" and d["n_gpus"] == 1
+    assert "100000 voxels" in d["config"]["workload"] and "64->128" in d["config"]["workload"]
+    assert d["cpu_baseline"]["kind"] == "reference" and d["cpu_baseline"]["cores"] >= 1
+    r = d["roofline"]
+    assert r["kernel"].startswith("k_conv_tile_f32x3") and r["bound"] == "mfma" and r["peak"] == 157.3
+    assert abs(r["peak_of_pipe"] - 2500.0 / 6) < 0.1 and abs(r["frac_of_pipe"] - r["achieved"] / r["peak_of_pipe"]) < 1e-3
+    assert r["traffic"] > r["compulsory_bytes_per_launch"]
+    assert len(d["timing"]["blocks_ms_per_step"]) >= 3 and min(d["timing"]["blocks_ms_per_step"]) == d["ms_per_step"]
+    two = dict(_lines())["r02_bench_final_n2_selfspawn_1gpu.json"]
+    assert two["n_gpus"] == 2 and two["config"]["oversubscribed"] is True      # two ranks on the one GPU of the box
 
 
 def test_headline_line_is_config_2_in_fp32():
