@@ -337,3 +337,30 @@ def test_lds_bucketed_build_falls_back(device):
     okey = mgr.stride(key, [2, 2, 2])
     km2 = mgr._kernel_map(key, okey, [2] * 3, [2] * 3, [1] * 3, MEB.RegionType.HYPER_CUBE, None, False, False)
     assert km2._store.get("order_out") is None
+
+
+@pytest.mark.parametrize("host_readback", [True, False])
+def test_kernel_map_count_recounts_an_existing_table(device, host_readback):
+    """me_kernel_map_count: the per-offset pair prefix of a neighbour table that already exists (e.g. one produced by
+    the LDS-bucketed probe of another library instance, or edited by pruning) — with the host read-back and without it
+    (NULL host pointer: no synchronisation, the prefix stays on the device)."""
+    import ctypes
+    from minkowskiengine_amd import backend as MEB, _lib
+    lib = _lib.load()
+    coords = make_cloud(5000, 16, 3, seed=11, batch=2, negative=True)
+    mgr = MEB.CoordinateMapManagerGPU_c10()
+    key, _ = mgr.insert_and_map(coords.to(device), [1, 1, 1], "")
+    km = mgr._kernel_map(key, key, [3] * 3, [1] * 3, [1] * 3, MEB.RegionType.HYPER_CUBE, None, False, False)
+    nbr = km.table("out").contiguous()
+    volume, n = nbr.shape
+    ws = torch.empty(int(lib.me_kernel_map_workspace_bytes(n, volume)), dtype=torch.uint8, device=device)
+    koffs_dev = torch.full((volume + 1,), -1, dtype=torch.int64, device=device)
+    host = (ctypes.c_int64 * (volume + 1))() if host_readback else None
+    _lib.check(lib.me_kernel_map_count(nbr.data_ptr(), n, volume, host, koffs_dev.data_ptr(), ws.data_ptr(), ws.numel(),
+                                       torch.cuda.current_stream().cuda_stream))
+    want = [0]
+    for k in range(volume):
+        want.append(want[-1] + int((nbr[k] >= 0).sum()))
+    assert koffs_dev.cpu().tolist() == want == list(km.k_offsets)
+    if host_readback:
+        assert [int(v) for v in host] == want
