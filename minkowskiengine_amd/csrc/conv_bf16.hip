@@ -94,12 +94,13 @@ __global__ __launch_bounds__(256) void k_pack_weights_bf16(const void *__restric
 // See k_conv_tile_f32 (conv.hip) for the pipeline; differences are the element type and the MFMA shape.
 // EXACT: c_src is a multiple of KC (rows need no channel guards).
 // SMALL: 32-bit gather offsets with a 24-bit row multiply (host-checked: < 2^24 rows, source matrix < 4 GiB).
-template <int NC, int KC, bool EXACT, bool SMALL>
+template <int NC, int KC, bool EXACT, bool SMALL, bool FUSE = false>
 __global__ __launch_bounds__(NC * 4, 3) void k_conv_tile_bf16(
     const __bf16 *__restrict__ src, int c_src, const bf16x8 *__restrict__ wp, int c_dst,
     const int32_t *__restrict__ plan_src, const int32_t *__restrict__ plan_dst,
     const int32_t *__restrict__ batch_desc, const int32_t *__restrict__ tile_bptr,
-    const int32_t *__restrict__ order, __bf16 *__restrict__ dst, int64_t n_tgt, int tile_rows, int batch_groups) {
+    const int32_t *__restrict__ order, __bf16 *__restrict__ dst, int64_t n_tgt, int tile_rows, int batch_groups,
+    int fuse) {
   typedef int i32x2 __attribute__((ext_vector_type(2)));
   constexpr int WAVES = NC / 16;
   constexpr int NT = WAVES * 64;
@@ -148,29 +149,66 @@ __global__ __launch_bounds__(NC * 4, 3) void k_conv_tile_bf16(
   const int nb = tile_bptr[tile + 1] - b0;
   const int n_it = nb * nchunks;
 
-  auto locate = [&](int it, int &chunk, int &g0, int &ng, int &k) {
-    int r = min(it, n_it - 1);
-    chunk = 0;
-    while (r >= nb) {
-      r -= nb;
-      ++chunk;
+  // Batch fusion (round 2).  On sparse maps most (tile, offset) items hold one 16-row group — MinkUNet's stride-1 / 2
+  // levels: 7 - 23 pairs per item — and a batch of one group pays the two barriers, the stage write and the pipeline
+  // latency of four.  Consecutive batches of a tile are contiguous in the plan, so up to MAXSUB of them are staged
+  // together while they fit the 64-row window ("super-batch"); every sub-batch keeps its own offset's weights and
+  // the sub-batches are multiplied and accumulated one after the other, i.e. in exactly the order of the unfused
+  // loop: results are bit-identical.  MAXSUB is 4 while the weights of four offsets fit the register budget
+  // (KC <= 64), 2 beyond.  FUSE is a template parameter: the descriptor look-ahead, the extra weight registers and
+  // the sub-batch loop cost a dense layer (whose batches are full) 20 - 40 %, so the host picks the instantiation by
+  // the map's density (me_conv_target_bf16 / me_conv_target_bf16_fused); fuse = 0 at run time: tests.
+  constexpr int MAXSUB = !FUSE ? 1 : (KS <= 2 ? 4 : 2);
+  struct Super {
+    int chunk, g0, ng, nsub;     // source-channel chunk, first group, groups in total, sub-batches (0: none)
+    int k[MAXSUB], sg[MAXSUB];   // offset and groups of each sub-batch
+  };
+  int cur_chunk = 0, cur_r = 0;  // the next batch to hand out
+  auto next_super = [&]() {
+    Super sb;
+    const bool valid = cur_chunk < nchunks && nb > 0;
+    const int r = valid ? cur_r : max(nb - 1, 0);
+    sb.chunk = valid ? cur_chunk : max(nchunks - 1, 0);
+    const int avail = valid ? nb - cur_r : 1;
+    i32x2 d[MAXSUB];
+#pragma unroll
+    for (int j = 0; j < MAXSUB; ++j)   // (descriptors behind the tile's last batch are readable: me_plan_max_groups)
+      d[j] = *reinterpret_cast<const i32x2 *>(batch_desc + 2 * (int64_t)(b0 + r + j));
+    sb.g0 = d[0].x;
+    sb.ng = 0;
+    sb.nsub = 0;
+#pragma unroll
+    for (int j = 0; j < MAXSUB; ++j) {
+      const int g = d[j].y & 255;
+      const bool take = j == 0 || (fuse && sb.nsub == j && j < avail && sb.ng + g <= ME_MAX_BATCH_GROUPS);
+      sb.k[j] = take ? (int)((uint32_t)d[j].y >> 8) : sb.k[j > 0 ? j - 1 : 0];
+      sb.sg[j] = take ? g : 0;
+      if (take) {
+        sb.ng += g;
+        sb.nsub = j + 1;
+      }
     }
-    const i32x2 d = *reinterpret_cast<const i32x2 *>(batch_desc + 2 * (int64_t)(b0 + r));
-    g0 = d.x;
-    ng = d.y & 255;
-    k = (int)((uint32_t)d.y >> 8);
+    if (valid) {
+      cur_r += sb.nsub;
+      if (cur_r >= nb) {
+        cur_r = 0;
+        ++cur_chunk;
+      }
+    } else {
+      sb.nsub = 0;
+    }
+    return sb;
   };
 
   bf16x8 stage[ITER];
   int32_t dstv = tile_rows;
   int32_t sidx[ITER];
-  bf16x8 wreg[KS], wnxt[KS];
+  bf16x8 wreg[MAXSUB][KS], wnxt[MAXSUB][KS];
 
   // As in k_conv_tile_f32: the 64-entry index window of a batch is read to its end unconditionally (the plan is
   // followed by 64 valid entries), and padding slots (index -1) gather row 0 without being zeroed — their
   // products land in the dummy accumulator row.
-  auto load_sidx = [&](int g0, int ng) {
-    (void)ng;
+  auto load_sidx = [&](int g0) {
     const char *pb = reinterpret_cast<const char *>(plan_src + (int64_t)g0 * 16);
 #pragma unroll
     for (int j = 0; j < ITER; ++j)
@@ -178,9 +216,8 @@ __global__ __launch_bounds__(NC * 4, 3) void k_conv_tile_bf16(
   };
   const char *srcb = reinterpret_cast<const char *>(src);
   const unsigned row_bytes = (unsigned)c_src * 2u;
-  auto gather = [&](int chunk, int g0, int ng) {
+  auto gather = [&](int chunk, int g0) {
     const int c0 = chunk * KC;
-    (void)ng;
     dstv = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(plan_dst + (int64_t)g0 * 16) +
                                              (unsigned)(min(tid, ME_MAX_BATCH_GROUPS * 16 - 1) * 4));
 #pragma unroll
@@ -223,48 +260,64 @@ __global__ __launch_bounds__(NC * 4, 3) void k_conv_tile_bf16(
     }
     if (tid < cap_rows) s_dst[tid] = dstv;
   };
-  auto load_w = [&](int chunk, int k) {
-    const bf16x8 *p = wp + ((((int64_t)k * nchunks + chunk) * ncb + cb) * KS) * 64 + lane;
+  // weights of every sub-batch of a super-batch (wave-uniform branches: a dense batch loads one slice)
+  auto load_w = [&](const Super &sb) {
 #pragma unroll
-    for (int v = 0; v < KS; ++v) wnxt[v] = p[v * 64];
+    for (int j = 0; j < MAXSUB; ++j) {
+      if (j == 0 || j < sb.nsub) {
+        const bf16x8 *p = wp + ((((int64_t)sb.k[j] * nchunks + sb.chunk) * ncb + cb) * KS) * 64 + lane;
+#pragma unroll
+        for (int v = 0; v < KS; ++v) wnxt[j][v] = p[v * 64];
+      }
+    }
   };
 
-  if (n_it > 0) {
-    int chA, gA, nA, kA, chB, gB, nB, kB, chC, gC, nC, kC;
-    locate(0, chA, gA, nA, kA);
-    locate(1, chB, gB, nB, kB);
-    locate(2, chC, gC, nC, kC);
-    load_w(chA, kA);
-    load_sidx(gA, nA);
-    gather(chA, gA, nA);
-    load_sidx(gB, nB);
+  Super sA = next_super();
+  if (sA.nsub > 0) {
+    Super sB = next_super();
+    Super sC = next_super();
+    load_w(sA);
+    load_sidx(sA.g0);
+    gather(sA.chunk, sA.g0);
+    load_sidx(sB.g0);
 
-    for (int it = 0; it < n_it; ++it) {
+    while (sA.nsub > 0) {
       __syncthreads();
-      write_stage(chA);
+      write_stage(sA.chunk);
 #pragma unroll
-      for (int sx = 0; sx < KS; ++sx) wreg[sx] = wnxt[sx];
+      for (int j = 0; j < MAXSUB; ++j) {
+#pragma unroll
+        for (int sx = 0; sx < KS; ++sx) wreg[j][sx] = wnxt[j][sx];
+      }
       __syncthreads();
-      load_w(chB, kB);
-      gather(chB, gB, nB);
-      load_sidx(gC, nC);
+      load_w(sB);
+      gather(sB.chunk, sB.g0);
+      load_sidx(sC.g0);
       {
-        const __bf16 *a0p = &s_a[i16 * A_LD + q * 8];
-        const int32_t *dstp = &s_dst[i16];
-        float *accp = &s_acc[wave * 16 + q * 4];
-        if (nA == 4) {
-          mma_groups_bf16<4, KS, A_LD, ACC_LD>(a0p, wreg, dstp, accp);
-        } else if (nA == 3) {
-          mma_groups_bf16<3, KS, A_LD, ACC_LD>(a0p, wreg, dstp, accp);
-        } else if (nA == 2) {
-          mma_groups_bf16<2, KS, A_LD, ACC_LD>(a0p, wreg, dstp, accp);
-        } else {
-          mma_groups_bf16<1, KS, A_LD, ACC_LD>(a0p, wreg, dstp, accp);
+        int row = 0;
+#pragma unroll
+        for (int j = 0; j < MAXSUB; ++j) {
+          if (j < sA.nsub) {   // wave-uniform
+            const __bf16 *a0p = &s_a[(row + i16) * A_LD + q * 8];
+            const int32_t *dstp = &s_dst[row + i16];
+            float *accp = &s_acc[wave * 16 + q * 4];
+            const int g = sA.sg[j];
+            if (g == 4) {
+              mma_groups_bf16<4, KS, A_LD, ACC_LD>(a0p, wreg[j], dstp, accp);
+            } else if (g == 3) {
+              mma_groups_bf16<3, KS, A_LD, ACC_LD>(a0p, wreg[j], dstp, accp);
+            } else if (g == 2) {
+              mma_groups_bf16<2, KS, A_LD, ACC_LD>(a0p, wreg[j], dstp, accp);
+            } else {
+              mma_groups_bf16<1, KS, A_LD, ACC_LD>(a0p, wreg[j], dstp, accp);
+            }
+            row += g * 16;
+          }
         }
       }
-      chA = chB; gA = gB; nA = nB; kA = kB;
-      chB = chC; gB = gC; nB = nC; kB = kC;
-      locate(it + 3, chC, gC, nC, kC);
+      sA = sB;
+      sB = sC;
+      sC = next_super();
     }
   }
   __syncthreads();
@@ -475,6 +528,8 @@ static int conv_gather_cb(int c_src, int c_dst) {
   return 0;
 }
 
+extern int g_conv_variant;  // conv.hip: variant 6 = 64-bit gather addresses, 7 = no batch fusion
+
 struct ConvVariantBf16 {
   int nc, slabs, kc;
 };
@@ -497,16 +552,19 @@ template <int NC, int KC>
 static int launch_conv_tile_bf16(const __bf16 *src, int c_src, const bf16x8 *wp, int c_dst, int slabs,
                                  const int32_t *plan_src, const int32_t *plan_dst, const int32_t *batch_desc,
                                  const int32_t *tile_bptr, const int32_t *order, __bf16 *dst, int64_t n_tgt,
-                                 int tile_rows, int batch_groups, hipStream_t stream, bool small) {
+                                 int tile_rows, int batch_groups, hipStream_t stream, bool small, bool fuse = false) {
   const int lds = conv_bf16_lds_bytes(NC, KC, tile_rows, batch_groups);
   ME_CHECK(lds <= kLdsBudget, "tile_rows / batch_groups too large for the LDS of one workgroup");
   const bool exact = (c_src % KC) == 0;
   typedef void (*kernel_t)(const __bf16 *, int, const bf16x8 *, int, const int32_t *, const int32_t *, const int32_t *,
-                           const int32_t *, const int32_t *, __bf16 *, int64_t, int, int);
-  const kernel_t fn = small ? (exact ? &k_conv_tile_bf16<NC, KC, true, true> : &k_conv_tile_bf16<NC, KC, false, true>)
-                            : (exact ? &k_conv_tile_bf16<NC, KC, true, false> : &k_conv_tile_bf16<NC, KC, false, false>);
-  static bool attr_set[4] = {false, false, false, false};  // per instantiation
-  const int which = (small ? 2 : 0) + (exact ? 1 : 0);
+                           const int32_t *, const int32_t *, __bf16 *, int64_t, int, int, int);
+  const kernel_t fn =
+      fuse ? (small ? (exact ? &k_conv_tile_bf16<NC, KC, true, true, true> : &k_conv_tile_bf16<NC, KC, false, true, true>)
+                    : (exact ? &k_conv_tile_bf16<NC, KC, true, false, true> : &k_conv_tile_bf16<NC, KC, false, false, true>))
+           : (small ? (exact ? &k_conv_tile_bf16<NC, KC, true, true> : &k_conv_tile_bf16<NC, KC, false, true>)
+                    : (exact ? &k_conv_tile_bf16<NC, KC, true, false> : &k_conv_tile_bf16<NC, KC, false, false>));
+  static bool attr_set[8] = {false, false, false, false, false, false, false, false};  // per instantiation
+  const int which = (fuse ? 4 : 0) + (small ? 2 : 0) + (exact ? 1 : 0);
   if (lds > 48 * 1024 && !attr_set[which]) {
     ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                kLdsBudget));
@@ -514,16 +572,12 @@ static int launch_conv_tile_bf16(const __bf16 *src, int c_src, const bf16x8 *wp,
   }
   const dim3 grid((unsigned)ceil_div(n_tgt, tile_rows), (unsigned)slabs);
   hipLaunchKernelGGL(fn, grid, dim3(NC * 4), (size_t)lds, stream, src, c_src, wp, c_dst, plan_src, plan_dst, batch_desc,
-                     tile_bptr, order, dst, n_tgt, tile_rows, batch_groups);
+                     tile_bptr, order, dst, n_tgt, tile_rows, batch_groups, g_conv_variant == 7 ? 0 : 1);
   ME_LAUNCH_CHECK();
   return 0;
 }
 
 }  // namespace me
-
-namespace me {
-extern int g_conv_variant;  // conv.hip: variant 6 = 64-bit gather addresses
-}
 
 using namespace me;
 
@@ -580,10 +634,10 @@ int me_conv_pack_weights_bf16(const void *w, int32_t w_is_f32, int64_t volume, i
   return 0;
 }
 
-int me_conv_target_bf16(const uint16_t *src_, int64_t n_src, int32_t c_src, const uint16_t *wp_, int64_t volume,
-                        int32_t c_dst, const int32_t *plan_src, const int32_t *plan_dst,
-                        const int32_t *batch_desc, const int32_t *tile_bptr, const int32_t *order, uint16_t *dst_,
-                        int64_t n_tgt, int32_t tile_rows, int32_t batch_groups, void *stream_) {
+static int conv_target_bf16(const uint16_t *src_, int64_t n_src, int32_t c_src, const uint16_t *wp_, int64_t volume,
+                            int32_t c_dst, const int32_t *plan_src, const int32_t *plan_dst,
+                            const int32_t *batch_desc, const int32_t *tile_bptr, const int32_t *order, uint16_t *dst_,
+                            int64_t n_tgt, int32_t tile_rows, int32_t batch_groups, void *stream_, bool fuse) {
   hipStream_t stream = (hipStream_t)stream_;
   (void)volume;
   // 32-bit byte offsets with a 24-bit row multiply need a source matrix below 4 GiB
@@ -600,7 +654,7 @@ int me_conv_target_bf16(const uint16_t *src_, int64_t n_src, int32_t c_src, cons
   const ConvVariantBf16 v = conv_variant_bf16(c_src, c_dst);
 #define ME_CONV_CASE(NCV, KCV)                                                                                   \
   return launch_conv_tile_bf16<NCV, KCV>(src, c_src, wp, c_dst, v.slabs, plan_src, plan_dst, batch_desc, tile_bptr, \
-                                         order, dst, n_tgt, tile_rows, batch_groups, stream, small)
+                                         order, dst, n_tgt, tile_rows, batch_groups, stream, small, fuse)
   if (v.nc == 32) {
     if (v.kc == 128) ME_CONV_CASE(32, 128);
     if (v.kc == 96) ME_CONV_CASE(32, 96);
@@ -613,6 +667,22 @@ int me_conv_target_bf16(const uint16_t *src_, int64_t n_src, int32_t c_src, cons
     ME_CONV_CASE(64, 32);
   }
 #undef ME_CONV_CASE
+}
+
+int me_conv_target_bf16(const uint16_t *src, int64_t n_src, int32_t c_src, const uint16_t *wp, int64_t volume,
+                        int32_t c_dst, const int32_t *plan_src, const int32_t *plan_dst, const int32_t *batch_desc,
+                        const int32_t *tile_bptr, const int32_t *order, uint16_t *dst, int64_t n_tgt, int32_t tile_rows,
+                        int32_t batch_groups, void *stream) {
+  return conv_target_bf16(src, n_src, c_src, wp, volume, c_dst, plan_src, plan_dst, batch_desc, tile_bptr, order, dst,
+                          n_tgt, tile_rows, batch_groups, stream, false);
+}
+
+int me_conv_target_bf16_fused(const uint16_t *src, int64_t n_src, int32_t c_src, const uint16_t *wp, int64_t volume,
+                              int32_t c_dst, const int32_t *plan_src, const int32_t *plan_dst,
+                              const int32_t *batch_desc, const int32_t *tile_bptr, const int32_t *order, uint16_t *dst,
+                              int64_t n_tgt, int32_t tile_rows, int32_t batch_groups, void *stream) {
+  return conv_target_bf16(src, n_src, c_src, wp, volume, c_dst, plan_src, plan_dst, batch_desc, tile_bptr, order, dst,
+                          n_tgt, tile_rows, batch_groups, stream, true);
 }
 
 }  // extern "C"

@@ -126,6 +126,7 @@ def main():
         copy("r02_final/" + src, dst)
     copy("r02_final2/unet_bf16_fresh.json", "r02_bench_final_minkunet34c_bf16_fresh_scenes.json")
     copy("r02_final2/unet_bf16_pipelined.json", "r02_bench_final_minkunet34c_bf16_pipelined_scenes.json")
+    copy("bf16_batch_fusion.log", "r02_bench_bf16_batch_fusion.log")
     for extra in sys.argv[1:]:          # "src:dst" pairs for later sessions
         s, d = extra.split(":")
         copy(s, d)

@@ -160,3 +160,30 @@ def test_bf16_config2_full_size(device):
         lhs, ra, rb = conv1(mk(a + b)).F, conv1(mk(a)).F, conv1(mk(b)).F
     assert float(lhs.float().abs().max()) < 256
     assert torch.equal(lhs, ra + rb)
+
+
+@pytest.mark.parametrize("n,extent,cin,cout,ks,D", [(6000, 40, 96, 96, 3, 3), (6000, 40, 32, 64, 3, 3), (4000, 14, 64, 128, 3, 3),
+                                                     (3000, 10, 32, 64, 3, 4), (5000, 40, 128, 96, 3, 3)])
+def test_batch_fusion_is_bit_identical(device, monkeypatch, n, extent, cin, cout, ks, D):
+    """k_conv_tile_bf16 stages consecutive small batches of a tile together (up to four offsets per barrier pair on
+    sparse maps); the sub-batches are multiplied and accumulated in the order of the unfused loop, so forward and
+    input-gradient results must be BIT-identical with fusion (me_conv_target_bf16_fused) and without (me_conv_target_bf16)."""
+    from minkowskiengine_amd import backend as MEB, _lib
+    lib = _lib.load()
+    coords = make_cloud(n, extent, D, seed=cin + cout, batch=2, negative=True)
+    mgr = MEB.CoordinateMapManagerGPU_c10()
+    key, _ = mgr.insert_and_map(coords.to(device), [1] * D, "")
+    km = mgr._kernel_map(key, key, [ks] * D, [1] * D, [1] * D, MEB.RegionType.HYPER_CUBE, None, False, False)
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand(coords.shape[0], cin, generator=g) - 0.5).to(device).bfloat16()
+    gy = (torch.rand(coords.shape[0], cout, generator=g) - 0.5).to(device).bfloat16()
+    w = (torch.rand(ks ** D, cin, cout, generator=g) - 0.5).to(device)
+    res = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setattr(MEB, "_BF16_FUSE", fuse)
+        km._launch_cache.clear()
+        y = MEB._conv_forward(x, w, km, "mfma")
+        gi = MEB._conv_target(gy, w, km, "in", km.n_in, name="d", transposed=True)
+        res[0 if fuse == "1" else 7] = (y.clone(), gi.clone())
+    assert torch.equal(res[0][0], res[7][0]) and torch.equal(res[0][1], res[7][1])
+    assert float(res[0][0].float().abs().max()) > 0
