@@ -1013,9 +1013,9 @@ CoordinateMapManagerGPU_default = CoordinateMapManagerGPU_c10
 # convolution operators (src/convolution_gpu.cu:45-244, src/convolution_transpose_gpu.cu)
 # ------------------------------------------------------------------------------------------------
 # bf16 tile kernel with batch fusion (me_conv_target_bf16_fused): "auto" = maps with fewer than 24 pairs per (tile,
-# offset) item, whose batches mostly hold ONE 16-row group (config 5: +11 %, 994 -> 1105 Mpoints/s in bf16; sparse
-# config 2: +5 %; no gain on MinkUNet34C, where the per-group accumulate chain, not the barrier count, sets the time;
-# dense layers lose 20 - 40 % on it: profiles/r02_bench_bf16_batch_fusion.log); "1" / "0" force
+# offset) item, whose batches mostly hold ONE 16-row group (config 5 in bf16: forward 170 -> 144 us, dgrad 137 -> 98,
+# 973 -> 1156 Mpoints/s; sparse config 2: +8 %; dense layers lose 20 - 35 % on it and MinkUNet34C as a whole 3 %:
+# profiles/r02_bench_bf16_batch_fusion.log); "1" / "0" force
 _BF16_FUSE = os.environ.get("ME_AMD_BF16_FUSE", "auto")
 _BF16_FUSE_MAX_PAIRS_PER_ITEM = 24.0
 _BF16_GATHER = os.environ.get("ME_AMD_BF16_GATHER", "0") != "0"   # bf16: output-stationary kernel (opt-in: measured slower than the tile-plan kernel)

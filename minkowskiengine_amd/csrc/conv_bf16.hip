@@ -53,6 +53,39 @@ __device__ __forceinline__ void mma_groups_bf16(const __bf16 *__restrict__ a0p, 
   for (int r = 0; r < R; ++r) *reinterpret_cast<f32x4 *>(accp + d[r]) = old[r] + acc[r];
 }
 
+// n single-group batches of DIFFERENT offsets staged together (batch fusion): group r multiplies with its own
+// offset's weights w[r].  All index / operand reads first, then the MFMAs (independent accumulators), then the
+// accumulator updates in batch order — a later group may hit a row of an earlier one, and LDS operations of a wave
+// execute in order, so issuing read r + 1 behind write r is enough.  Same sums in the same order as n calls of
+// mma_groups_bf16<1>: bit-identical, without n dependent LDS round-trip chains.
+template <int M, int KS, int A_LD, int ACC_LD>
+__device__ __forceinline__ void mma_singles_bf16(const __bf16 *__restrict__ a0p, const bf16x8 (&w)[M][KS], int n,
+                                                 const int32_t *__restrict__ dstp, float *__restrict__ accp) {
+  int d[M];
+  bf16x8 a[M][KS];
+  f32x4 acc[M];
+#pragma unroll
+  for (int r = 0; r < M; ++r) {
+    d[r] = (int)__umul24((unsigned)dstp[r * 16], (unsigned)ACC_LD);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) a[r][s] = *reinterpret_cast<const bf16x8 *>(a0p + r * 16 * A_LD + s * 32);
+    acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+#pragma unroll
+    for (int r = 0; r < M; ++r)
+      if (r < n) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[r][s], a[r][s], acc[r], 0, 0, 0);   // wave-uniform
+  }
+#pragma unroll
+  for (int r = 0; r < M; ++r) {
+    if (r < n) {
+      const f32x4 old = *reinterpret_cast<const f32x4 *>(accp + d[r]);
+      *reinterpret_cast<f32x4 *>(accp + d[r]) = old + acc[r];
+    }
+  }
+}
+
 // Packed weights: the register image of the MFMA A operand.  For offset k, source-channel chunk c,
 // 16-column block cb and 32-channel step v, lane (q = lane >> 4, i16 = lane & 15) finds its eight weights
 //   W[k][c*KC + v*32 + q*8 + j][cb*16 + i16],  j = 0..7
@@ -149,12 +182,12 @@ __global__ __launch_bounds__(NC * 4, 3) void k_conv_tile_bf16(
   const int nb = tile_bptr[tile + 1] - b0;
   const int n_it = nb * nchunks;
 
-  // Batch fusion (round 2).  On sparse maps most (tile, offset) items hold one 16-row group — MinkUNet's stride-1 / 2
-  // levels: 7 - 23 pairs per item — and a batch of one group pays the two barriers, the stage write and the pipeline
-  // latency of four.  Consecutive batches of a tile are contiguous in the plan, so up to MAXSUB of them are staged
-  // together while they fit the 64-row window ("super-batch"); every sub-batch keeps its own offset's weights and
-  // the sub-batches are multiplied and accumulated one after the other, i.e. in exactly the order of the unfused
-  // loop: results are bit-identical.  MAXSUB is 4 while the weights of four offsets fit the register budget
+  // Batch fusion (round 2).  On sparse maps most (tile, offset) items hold ONE 16-row group — MinkUNet's stride-1
+  // level: 7 - 11 pairs per item; config 5: 11 — and a batch of one group pays the two barriers, the stage write,
+  // the gather latency and a chain of dependent LDS round trips for 16 rows.  Consecutive batches of a tile are
+  // contiguous in the plan, so up to MAXSUB single-group batches are staged together ("super-batch"), each group
+  // multiplied with its own offset's weights, and the accumulator tile updated in batch order (mma_singles_bf16):
+  // results are bit-identical.  MAXSUB is 4 while the weights of four offsets fit the register budget
   // (KC <= 64), 2 beyond.  FUSE is a template parameter: the descriptor look-ahead, the extra weight registers and
   // the sub-batch loop cost a dense layer (whose batches are full) 20 - 40 %, so the host picks the instantiation by
   // the map's density (me_conv_target_bf16 / me_conv_target_bf16_fused); fuse = 0 at run time: tests.
@@ -180,7 +213,8 @@ __global__ __launch_bounds__(NC * 4, 3) void k_conv_tile_bf16(
 #pragma unroll
     for (int j = 0; j < MAXSUB; ++j) {
       const int g = d[j].y & 255;
-      const bool take = j == 0 || (fuse && sb.nsub == j && j < avail && sb.ng + g <= ME_MAX_BATCH_GROUPS);
+      // (only single-group batches are fused: group r <-> sub-batch r, see mma_singles_bf16)
+      const bool take = j == 0 || (fuse && sb.nsub == j && j < avail && sb.ng == j && g == 1);
       sb.k[j] = take ? (int)((uint32_t)d[j].y >> 8) : sb.k[j > 0 ? j - 1 : 0];
       sb.sg[j] = take ? g : 0;
       if (take) {
@@ -294,24 +328,21 @@ __global__ __launch_bounds__(NC * 4, 3) void k_conv_tile_bf16(
       gather(sB.chunk, sB.g0);
       load_sidx(sC.g0);
       {
-        int row = 0;
-#pragma unroll
-        for (int j = 0; j < MAXSUB; ++j) {
-          if (j < sA.nsub) {   // wave-uniform
-            const __bf16 *a0p = &s_a[(row + i16) * A_LD + q * 8];
-            const int32_t *dstp = &s_dst[row + i16];
-            float *accp = &s_acc[wave * 16 + q * 4];
-            const int g = sA.sg[j];
-            if (g == 4) {
-              mma_groups_bf16<4, KS, A_LD, ACC_LD>(a0p, wreg[j], dstp, accp);
-            } else if (g == 3) {
-              mma_groups_bf16<3, KS, A_LD, ACC_LD>(a0p, wreg[j], dstp, accp);
-            } else if (g == 2) {
-              mma_groups_bf16<2, KS, A_LD, ACC_LD>(a0p, wreg[j], dstp, accp);
-            } else {
-              mma_groups_bf16<1, KS, A_LD, ACC_LD>(a0p, wreg[j], dstp, accp);
-            }
-            row += g * 16;
+        const __bf16 *a0p = &s_a[i16 * A_LD + q * 8];
+        const int32_t *dstp = &s_dst[i16];
+        float *accp = &s_acc[wave * 16 + q * 4];
+        if (MAXSUB > 1 && sA.nsub > 1) {   // wave-uniform
+          mma_singles_bf16<MAXSUB, KS, A_LD, ACC_LD>(a0p, wreg, sA.nsub, dstp, accp);
+        } else {
+          const int g = sA.sg[0];
+          if (g == 4) {
+            mma_groups_bf16<4, KS, A_LD, ACC_LD>(a0p, wreg[0], dstp, accp);
+          } else if (g == 3) {
+            mma_groups_bf16<3, KS, A_LD, ACC_LD>(a0p, wreg[0], dstp, accp);
+          } else if (g == 2) {
+            mma_groups_bf16<2, KS, A_LD, ACC_LD>(a0p, wreg[0], dstp, accp);
+          } else {
+            mma_groups_bf16<1, KS, A_LD, ACC_LD>(a0p, wreg[0], dstp, accp);
           }
         }
       }

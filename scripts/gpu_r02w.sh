@@ -6,7 +6,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_gpu_bf16.py -m gpu -q --timeout 600 -k "fusion or vs_oracle" > $OUT/pytest.log 2>&1; echo "pytest rc=$?"
 grep -E "^(FAILED|ERROR)|passed|failed" $OUT/pytest.log | head -20
-for v in auto 0 1; do
+for v in 1 0; do
   ME_AMD_BF16_FUSE=$v timeout 600 python bench.py --workload minkunet --dtype bf16 --steps 10 --warmup 3 --cpu-budget 0 > $OUT/unet_bf16_v$v.json 2>/dev/null
   python - <<PY
 import json
