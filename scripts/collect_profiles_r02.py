@@ -127,6 +127,8 @@ def main():
     copy("r02_final2/unet_bf16_fresh.json", "r02_bench_final_minkunet34c_bf16_fresh_scenes.json")
     copy("r02_final2/unet_bf16_pipelined.json", "r02_bench_final_minkunet34c_bf16_pipelined_scenes.json")
     copy("bf16_batch_fusion.log", "r02_bench_bf16_batch_fusion.log")
+    copy("r02_final3/pytest_gpu.log", "r02_pytest_gpu_final.log")          # after the last kernel change of the round
+    copy("r02_final3/bench.json", "r02_bench_final_rerun.json")
     for extra in sys.argv[1:]:          # "src:dst" pairs for later sessions
         s, d = extra.split(":")
         copy(s, d)
