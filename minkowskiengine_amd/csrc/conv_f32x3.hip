@@ -118,7 +118,9 @@ __device__ __forceinline__ void mma_groups_f32x3(const __bf16 *__restrict__ rowp
       for (int p = 0; p < 3; ++p)
         asm volatile("ds_read_b128 %0, %1 offset:%2"
                      : "=v"(dst[r][p])
-                     : "v"(addr), "n"((p * PLANE + r * GS * 16 * LD) * 2));
+                     : "v"(addr), "n"((p * PLANE + r * GS * 16 * LD) * 2)
+                     : "memory");   // (keeps the compiler's own LDS loads / stores on their side of the read: the
+                                    // counted waits below assume program order)
     }
   };
   // all LDS operations older than the last `younger` ones have completed; ties the registers so that the MFMAs
@@ -130,7 +132,8 @@ __device__ __forceinline__ void mma_groups_f32x3(const __bf16 *__restrict__ rowp
     for (int r = 0; r < R; ++r)
       asm volatile("s_waitcnt lgkmcnt(%4)"
                    : "+v"(dst[r][0]), "+v"(dst[r][1]), "+v"(dst[r][2]), "+v"(acc[r])
-                   : "n"(decltype(younger)::value));
+                   : "n"(decltype(younger)::value)
+                   : "memory");
   };
   int d[R];
 #pragma unroll
@@ -453,6 +456,464 @@ __global__ __launch_bounds__(NC * 4 * x3_group_shares(NC), 1) void k_conv_tile_f
   }
 }
 
+// =================================================================================================
+// wave-specialised variant (round 2, debug variant 31 until it is the default): k_conv_tile_f32x3_ws
+// =================================================================================================
+// Same plan, arithmetic, stage layout and epilogue as k_conv_tile_f32x3; what changes is who does what.  The
+// ping-pong kernel gives every wave both jobs and 16 columns; its LDS budget per batch (operand reads 768 cycles —
+// eight waves each read all 64 rows —, accumulator 740, stage writes 310) is above the 1536 MFMA cycles per SIMD it
+// could run at.  Here waves 0-3 ONLY multiply, each NC / 4 columns (32 for a 128-column slab: every operand read
+// feeds two column blocks, so the operand reads halve), and waves 4-7 ONLY produce (gather, split, stage); wave w
+// and w + 4 share a SIMD, so every SIMD runs one matrix stream and one vector / memory stream, separated by the one
+// barrier per batch.  A multiplier takes its groups in two passes of two (operand registers), operand reads one
+// step ahead of the MFMAs (inline asm, see mma_groups_f32x3).
+// One batch in a multiplier wave: groups 0 .. RP0 - 1 (pass 0) and 2 .. 2 + RP1 - 1 (pass 1).  EVERY LDS operation of
+// the batch is inline asm in a fixed order with counted waits: left to the compiler, the plain loads of the target
+// indices and of the old accumulator values float between the MFMAs and bring `s_waitcnt lgkmcnt(0)` with them —
+// 200 - 500 idle matrix cycles each time.  Order (the in-order lgkm counter is what the waits count against):
+//   pass 0: indices, operands of step 0 | old accumulators | per step: next operands (last step: pass 1's indices and
+//   first operands), wait, MFMAs | pass 1: old accumulators, stores of pass 0 | per step as before | stores.
+template <int RP0, int RP1, int CB, int KC, int ABL = 0>
+__device__ __forceinline__ void consume_batch_f32x3(const __bf16 *__restrict__ rowp, const int (&pofs)[KC / 32],
+                                                    const bf16x8 (&w)[CB][3][KC / 32],
+                                                    const int32_t *__restrict__ dstp, float *__restrict__ accp,
+                                                    int acc_ld) {
+  typedef __attribute__((address_space(3))) const char lds_char;
+  constexpr int KS = KC / 32;
+  constexpr int LD = StageLayout<KC>::kLd;
+  constexpr int PLANE = ME_MAX_BATCH_GROUPS * 16 * LD;
+  constexpr int RPM = RP0 > RP1 ? RP0 : RP1;
+  constexpr int R1 = RP1 > 0 ? RP1 : 1;
+  const unsigned row_addr = (unsigned)(uintptr_t)(lds_char *)rowp;
+  const unsigned dst_addr = (unsigned)(uintptr_t)(lds_char *)dstp;
+  const unsigned acc_addr = (unsigned)(uintptr_t)(lds_char *)accp;
+  bf16x8 a[2][RPM][3];          // operands: steps alternate between the two halves
+  bf16x8 a1[R1][3];             // first operands of pass 1
+  f32x4 acc[RPM][CB];
+  unsigned op_addr[2][KS];      // byte address of this lane's operand piece: [pass][step]
+#pragma unroll
+  for (int sx = 0; sx < KS; ++sx) {
+    op_addr[0][sx] = row_addr + (unsigned)pofs[sx] * 2u;
+    op_addr[1][sx] = op_addr[0][sx] + (unsigned)(2 * 16 * LD * 2);
+  }
+  // ABL (timing ablations, results invalid): 1 = no MFMAs, 2 = no operand reads, 3 = no accumulator reads / stores
+  auto read_ops = [](unsigned addr, auto n_, bf16x8 (*dst)[3]) {
+    constexpr int N = decltype(n_)::value;
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        if constexpr (ABL == 2) asm volatile("" : "=v"(dst[r][p]) : "v"(addr));
+        else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst[r][p]) : "v"(addr), "n"((p * PLANE + r * 16 * LD) * 2) : "memory");
+      }
+    }
+  };
+  auto read_idx = [](unsigned addr, auto n_, int32_t *d) {
+    constexpr int N = decltype(n_)::value;
+#pragma unroll
+    for (int r = 0; r < N; ++r)
+      asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(d[r]) : "v"(addr), "n"(r * 64) : "memory");
+  };
+  // wait until at most `younger` LDS operations are outstanding; the listed registers are tied to the wait
+  auto wait_idx = [](auto n_, int32_t *d, auto younger) {
+    constexpr int N = decltype(n_)::value;
+#pragma unroll
+    for (int r = 0; r < N; ++r) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(d[r]) : "n"(decltype(younger)::value) : "memory");
+  };
+  auto wait_ops = [](auto n_, bf16x8 (*dst)[3], f32x4 (*ac)[CB], auto younger) {
+    constexpr int N = decltype(n_)::value;
+#pragma unroll
+    for (int r = 0; r < N; ++r)
+      asm volatile("s_waitcnt lgkmcnt(%4)"
+                   : "+v"(dst[r][0]), "+v"(dst[r][1]), "+v"(dst[r][2]), "+v"(ac[r][0])
+                   : "n"(decltype(younger)::value)
+                   : "memory");
+  };
+  auto read_old = [](auto n_, const unsigned *addr, f32x4 (*old)[CB]) {
+    constexpr int N = decltype(n_)::value;
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+#pragma unroll
+      for (int c = 0; c < CB; ++c) {
+        if constexpr (ABL == 3) asm volatile("" : "=v"(old[r][c]) : "v"(addr[r]));
+        else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(old[r][c]) : "v"(addr[r]), "n"(c * 64) : "memory");
+      }
+    }
+  };
+  auto store_acc = [](auto n_, const unsigned *addr, f32x4 (*old)[CB], f32x4 (*ac)[CB]) {
+    constexpr int N = decltype(n_)::value;
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+#pragma unroll
+      for (int c = 0; c < CB; ++c) {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(old[r][c]) : : "memory");   // (long since arrived; ties the value)
+        const f32x4 v = old[r][c] + ac[r][c];
+        if constexpr (ABL == 3) asm volatile("" : : "v"(addr[r]), "v"(v));
+        else asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(addr[r]), "v"(v), "n"(c * 64) : "memory");
+      }
+    }
+  };
+  auto mfmas = [&w](auto n_, auto s_, bf16x8 (*ops)[3], f32x4 (*ac)[CB]) {
+    constexpr int N = decltype(n_)::value;
+    constexpr int S = decltype(s_)::value;
+    constexpr int WP[6] = {2, 0, 1, 1, 0, 0};   // (weight plane, row plane) by ascending magnitude
+    constexpr int AP[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+#pragma unroll
+      for (int c = 0; c < CB; ++c) {
+#pragma unroll
+        for (int r = 0; r < N; ++r) {
+          if constexpr (ABL == 1) asm volatile("" : "+v"(ac[r][c]) : "v"(w[c][WP[t]][S]), "v"(ops[r][AP[t]]));
+          else ac[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[c][WP[t]][S], ops[r][AP[t]], ac[r][c], 0, 0, 0);
+        }
+      }
+    }
+  };
+  using IC0 = std::integral_constant<int, RP0>;
+  using IC1 = std::integral_constant<int, RP1>;
+  auto cap = [](int v) constexpr { return v > 15 ? 15 : v; };
+  // ---- pass 0 ----
+  int32_t d0[RP0], d1[R1];
+  unsigned addr0[RP0], addr1[R1];
+  f32x4 old0[RP0][CB], old1[R1][CB];
+  read_idx(dst_addr, IC0{}, d0);
+  read_ops(op_addr[0][0], IC0{}, a[0]);
+  wait_idx(IC0{}, d0, std::integral_constant<int, 3 * RP0>{});
+#pragma unroll
+  for (int r = 0; r < RP0; ++r) addr0[r] = acc_addr + __umul24((unsigned)d0[r], (unsigned)acc_ld) * 4u;
+  read_old(IC0{}, addr0, old0);
+#pragma unroll
+  for (int r = 0; r < RP0; ++r) {
+#pragma unroll
+    for (int c = 0; c < CB; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  auto step0 = [&](auto s_) {
+    constexpr int S = decltype(s_)::value;
+    constexpr int kOld = S == 0 ? RP0 * CB : 0;
+    if constexpr (S + 1 < KS) {
+      read_ops(op_addr[0][S + 1 < KS ? S + 1 : 0], IC0{}, a[(S + 1) & 1]);
+      wait_ops(IC0{}, a[S & 1], acc, std::integral_constant<int, cap(kOld + 3 * RP0)>{});
+    } else if constexpr (RP1 > 0) {
+      read_idx(dst_addr + 2 * 64, IC1{}, d1);   // last step of pass 0: pass 1's indices and first operands go out now
+      read_ops(op_addr[1][0], IC1{}, a1);
+      wait_ops(IC0{}, a[S & 1], acc, std::integral_constant<int, cap(kOld + 4 * RP1)>{});
+    } else {
+      wait_ops(IC0{}, a[S & 1], acc, std::integral_constant<int, kOld>{});
+    }
+    mfmas(IC0{}, s_, a[S & 1], acc);
+  };
+  step0(std::integral_constant<int, 0>{});
+  if constexpr (KS > 1) step0(std::integral_constant<int, 1>{});
+  if constexpr (KS > 2) step0(std::integral_constant<int, 2>{});
+  if constexpr (KS > 3) step0(std::integral_constant<int, 3>{});
+  if constexpr (RP1 == 0) {
+    store_acc(IC0{}, addr0, old0, acc);
+  } else {
+    // ---- pass 1 (groups 2 ..: other rows than pass 0 — the groups of a batch share their offset) ----
+    wait_idx(IC1{}, d1, std::integral_constant<int, 3 * RP1>{});
+#pragma unroll
+    for (int r = 0; r < RP1; ++r) addr1[r] = acc_addr + __umul24((unsigned)d1[r], (unsigned)acc_ld) * 4u;
+    read_old(IC1{}, addr1, old1);
+    {
+      // stores of pass 0 (its old values arrived before pass 1's indices); no wait inside: counted below
+#pragma unroll
+      for (int r = 0; r < RP0; ++r) {
+#pragma unroll
+        for (int c = 0; c < CB; ++c) {
+          asm volatile("" : "+v"(old0[r][c]));
+          const f32x4 v = old0[r][c] + acc[r][c];
+          if constexpr (ABL == 3) asm volatile("" : : "v"(addr0[r]), "v"(v));
+          else asm volatile("ds_write_b128 %0, %1 offset:%2" : : "v"(addr0[r]), "v"(v), "n"(c * 64) : "memory");
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RP1; ++r) {
+#pragma unroll
+      for (int c = 0; c < CB; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    auto step1 = [&](auto s_) {
+      constexpr int S = decltype(s_)::value;
+      bf16x8(*cur)[3] = S == 0 ? a1 : a[S & 1];
+      constexpr int kFirst = S == 0 ? (RP1 + RP0) * CB : 0;   // pass 1's old reads + pass 0's stores, issued behind a1
+      if constexpr (S + 1 < KS) {
+        read_ops(op_addr[1][S + 1 < KS ? S + 1 : 0], IC1{}, a[(S + 1) & 1]);
+        wait_ops(IC1{}, cur, acc, std::integral_constant<int, cap(kFirst + 3 * RP1)>{});
+      } else {
+        wait_ops(IC1{}, cur, acc, std::integral_constant<int, cap(kFirst)>{});
+      }
+      mfmas(IC1{}, s_, cur, acc);
+    };
+    step1(std::integral_constant<int, 0>{});
+    if constexpr (KS > 1) step1(std::integral_constant<int, 1>{});
+    if constexpr (KS > 2) step1(std::integral_constant<int, 2>{});
+    if constexpr (KS > 3) step1(std::integral_constant<int, 3>{});
+    store_acc(IC1{}, addr1, old1, acc);
+  }
+}
+
+template <int NC, int KC, bool EXACT, bool SMALL, bool TIMED = false, int PRIO = 2, int ABL = 0>
+__global__ __launch_bounds__(512, 1) void k_conv_tile_f32x3_ws(
+    const float *__restrict__ src, int c_src, const bf16x8 *__restrict__ wp, int c_dst,
+    const int32_t *__restrict__ plan_src, const int32_t *__restrict__ plan_dst,
+    const int32_t *__restrict__ batch_desc, const int32_t *__restrict__ tile_bptr,
+    const int32_t *__restrict__ order, float *__restrict__ dst, int64_t n_tgt, int tile_rows, int batch_groups) {
+  typedef int i32x2 __attribute__((ext_vector_type(2)));
+  typedef StageLayout<KC> SL;
+  static_assert(NC == 64 || NC == 128, "four multiplier waves of 16 or 32 columns");
+  constexpr int CB = NC / 64;          // 16-column blocks per multiplier wave
+  constexpr int NT = 512, NTP = 256;   // threads, producer threads
+  constexpr int LD = SL::kLd;
+  constexpr int ACC_LD = NC + kAccPad;
+  constexpr int KS = KC / 32;
+  constexpr int F8 = KC / 8;
+  constexpr int CAP = ME_MAX_BATCH_GROUPS * 16;
+  constexpr int ITER = (CAP * F8 + NTP - 1) / NTP;
+  constexpr int PLANE = CAP * LD;
+  (void)batch_groups;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *s_acc = reinterpret_cast<float *>(smem);                              // [(tile_rows + 1) x ACC_LD]
+  __bf16 *s_a = reinterpret_cast<__bf16 *>(s_acc + (tile_rows + 1) * ACC_LD);  // [2][3][64 x LD]
+  int32_t *s_dst = reinterpret_cast<int32_t *>(s_a + 2 * 3 * PLANE);           // [2][64]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15;
+  const int q = lane >> 4;
+  const int tile = tile_bptr[gridDim.x + 1 + blockIdx.x];   // heaviest-first dispatch order (me_plan_build)
+  const int col_base = blockIdx.y * NC;
+  const int nchunks = (c_src + KC - 1) / KC;
+  const int ncb = (c_dst + 15) / 16;
+
+  for (int x = tid; x < (tile_rows + 1) * ACC_LD / 4; x += NT)
+    reinterpret_cast<f32x4 *>(s_acc)[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int ORD = (ME_MAX_TILE_ROWS + NT - 1) / NT;
+  int32_t my_ord[ORD];
+#pragma unroll
+  for (int j = 0; j < ORD; ++j) {
+    const int r = j * NT + tid;
+    my_ord[j] = (order != nullptr && r < tile_rows && (int64_t)tile * tile_rows + r < n_tgt)
+                    ? order[(int64_t)tile * tile_rows + r] : 0;
+  }
+
+  const int b0 = tile_bptr[tile];
+  const int nb = tile_bptr[tile + 1] - b0;
+  const int n_it = nb * nchunks;
+  struct Desc {
+    int chunk, g0, ng, k;
+  };
+  auto locate = [&](int it) {
+    int r = min(it, n_it - 1);
+    Desc d;
+    d.chunk = 0;
+    while (r >= nb) {
+      r -= nb;
+      ++d.chunk;
+    }
+    const i32x2 v = *reinterpret_cast<const i32x2 *>(batch_desc + 2 * (int64_t)(b0 + r));
+    d.g0 = v.x;
+    d.ng = v.y & 255;
+    d.k = (int)((uint32_t)v.y >> 8);
+    return d;
+  };
+
+  if (n_it > 0 && wave >= 4) {
+    // ------------------------------------------------ producer waves ------------------------------------------------
+    const int ptid = tid - NTP;
+    f32x4 stage[2][ITER][2];
+    int32_t dstv[2] = {tile_rows, tile_rows};
+    int32_t sidx[2][ITER];
+    auto load_sidx = [&](const Desc &d, int32_t (&sx)[ITER]) {
+      const char *pb = reinterpret_cast<const char *>(plan_src + (int64_t)d.g0 * 16);
+#pragma unroll
+      for (int j = 0; j < ITER; ++j)
+        sx[j] = *reinterpret_cast<const int32_t *>(pb + (unsigned)(min((j * NTP + ptid) / F8, CAP - 1) * 4));
+    };
+    const char *srcb = reinterpret_cast<const char *>(src);
+    const unsigned row_bytes = (unsigned)c_src * 4u;
+    auto gather = [&](const Desc &d, const int32_t (&sx)[ITER], f32x4 (&st)[ITER][2], int32_t &dv) {
+      const int c0 = d.chunk * KC;
+      dv = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(plan_dst + (int64_t)d.g0 * 16) +
+                                             (unsigned)(min(ptid, CAP - 1) * 4));
+#pragma unroll
+      for (int j = 0; j < ITER; ++j) {
+        const int ch = c0 + ((j * NTP + ptid) % F8) * 8;
+        const int chl = EXACT ? ch : min(ch, c_src - 8);
+        const int sr = max(sx[j], 0);
+        const f32x4 *p;
+        if (SMALL) p = reinterpret_cast<const f32x4 *>(srcb + (__umul24((unsigned)sr, row_bytes) + (unsigned)chl * 4u));
+        else p = reinterpret_cast<const f32x4 *>(src + (int64_t)sr * c_src + chl);
+        st[j][0] = p[0];
+        st[j][1] = p[1];
+      }
+    };
+    auto write_stage = [&](const Desc &d, const f32x4 (&st)[ITER][2], int32_t dv, int buf) {
+      const int c0 = d.chunk * KC;
+      __bf16 *base = s_a + buf * 3 * PLANE;
+#pragma unroll
+      for (int j = 0; j < ITER; ++j) {
+        const int idx = j * NTP + ptid;
+        const int r = idx / F8;
+        const int ch = c0 + (idx % F8) * 8;
+        u32x4 p1, p2, p3;
+        split3(st[j][0], st[j][1], p1, p2, p3);
+        if (!EXACT && ch >= c_src) p1 = p2 = p3 = u32x4{0u, 0u, 0u, 0u};
+        if (ITER * NTP == CAP * F8 || r < CAP) {
+          __bf16 *o = base + SL::off(r, idx % F8);
+          *reinterpret_cast<u32x4 *>(o) = p1;
+          *reinterpret_cast<u32x4 *>(o + PLANE) = p2;
+          *reinterpret_cast<u32x4 *>(o + 2 * PLANE) = p3;
+        }
+      }
+      if (ptid < CAP) s_dst[buf * CAP + ptid] = dv;
+    };
+    // produce(x): store batch x into buffer x & 1, request the indices of batch x + 3 and the rows of batch x + 2
+    bool started = false;
+    auto produce = [&](const Desc &dx, const Desc &dx2, const Desc &dx3, int buf, f32x4 (&st)[ITER][2], int32_t &dv,
+                       int32_t (&sx_nx)[ITER], int32_t (&sx_cu)[ITER]) {
+      if (ABL != 6) write_stage(dx, st, dv, buf);      // (ABL 6: no split / stage stores; 5: no gathers after the first)
+      load_sidx(dx3, sx_cu);
+      if (ABL != 5 || !started) gather(dx2, sx_nx, st, dv);
+    };
+    Desc dA = locate(0), dB = locate(1), dC = locate(2), dD = locate(3), dE = locate(4);
+    load_sidx(dA, sidx[0]);
+    load_sidx(dB, sidx[1]);
+    gather(dA, sidx[0], stage[0], dstv[0]);
+    gather(dB, sidx[1], stage[1], dstv[1]);
+    load_sidx(dC, sidx[0]);
+    produce(dA, dC, dD, 0, stage[0], dstv[0], sidx[0], sidx[1]);   // batch 0 -> buffer 0
+    started = true;
+    __syncthreads();
+    unsigned long long tm_a = 0, tm_b = 0, t_prev = TIMED ? __builtin_amdgcn_s_memtime() : 0ull;
+    auto iteration = [&](int it, int P, f32x4 (&st_nx)[ITER][2], int32_t &dv_nx, int32_t (&sx_nx)[ITER],
+                         int32_t (&sx_cu)[ITER]) {
+      produce(dB, dD, dE, P ^ 1, st_nx, dv_nx, sx_nx, sx_cu);   // batch it + 1 while batch it is multiplied
+      if (TIMED) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        tm_a += now - t_prev;
+        t_prev = now;
+      }
+      __syncthreads();
+      if (TIMED) {
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        tm_b += now - t_prev;
+        t_prev = now;
+      }
+      dA = dB; dB = dC; dC = dD; dD = dE;
+      dE = locate(it + 5);
+    };
+    int it = 0;
+    for (; it + 1 < n_it; it += 2) {
+      iteration(it, 0, stage[1], dstv[1], sidx[1], sidx[0]);
+      iteration(it + 1, 1, stage[0], dstv[0], sidx[0], sidx[1]);
+    }
+    if (it < n_it) iteration(it, 0, stage[1], dstv[1], sidx[1], sidx[0]);
+    if (TIMED && tid == NTP) {
+      atomicAdd(&d_x3_timing[1], tm_a);   // producer: split + stage write + load issue
+      atomicAdd(&d_x3_timing[2], tm_b);   // producer: barrier wait
+    }
+  } else if (n_it > 0) {
+    // ----------------------------------------------- multiplier waves -----------------------------------------------
+    // (the matrix stream wins the issue arbitration against the producer wave of its SIMD)
+    __builtin_amdgcn_s_setprio(PRIO);
+    const int cbi0 = col_base / 16 + wave * CB;
+    bf16x8 w[2][CB][3][KS];
+    auto load_w = [&](const Desc &d, bf16x8 (&wd)[CB][3][KS]) {
+#pragma unroll
+      for (int c = 0; c < CB; ++c) {
+        const bf16x8 *p = wp + (((((int64_t)d.k * nchunks + d.chunk) * ncb + min(cbi0 + c, ncb - 1)) * 3) * KS) * 64 + lane;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+          for (int v = 0; v < KS; ++v) wd[c][pl][v] = p[(pl * KS + v) * 64];
+        }
+      }
+    };
+    int pofs[KS];
+#pragma unroll
+    for (int sx = 0; sx < KS; ++sx) pofs[sx] = ((sx * 4 + q) ^ SL::swz(i16)) * 8;
+    auto multiply = [&](const Desc &d, const bf16x8 (&wc)[CB][3][KS], int buf) {
+      const __bf16 *rowp = s_a + buf * 3 * PLANE + i16 * LD;
+      const int32_t *dstp = s_dst + buf * CAP + i16;
+      float *accp = &s_acc[wave * CB * 16 + q * 4];
+      // groups 0, 1 then 2, 3 (two passes keep the operand registers of a pass at 2 x 3 planes, two steps deep)
+      if (d.ng >= 4) consume_batch_f32x3<2, 2, CB, KC, ABL>(rowp, pofs, wc, dstp, accp, ACC_LD);
+      else if (d.ng == 3) consume_batch_f32x3<2, 1, CB, KC, ABL>(rowp, pofs, wc, dstp, accp, ACC_LD);
+      else if (d.ng == 2) consume_batch_f32x3<2, 0, CB, KC, ABL>(rowp, pofs, wc, dstp, accp, ACC_LD);
+      else consume_batch_f32x3<1, 0, CB, KC, ABL>(rowp, pofs, wc, dstp, accp, ACC_LD);
+    };
+    Desc dA = locate(0), dB = locate(1);
+    load_w(dA, w[0]);
+    __syncthreads();                      // batch 0 is staged
+    unsigned long long tm_a = 0, tm_b = 0, t_prev = TIMED ? __builtin_amdgcn_s_memtime() : 0ull;
+    auto iteration = [&](int it, int P, bf16x8 (&w_cu)[CB][3][KS], bf16x8 (&w_nx)[CB][3][KS]) {
+      if (ABL != 4 || it == 0) load_w(dB, w_nx);      // (ABL 4: the weights are loaded once — timing ablation)
+      multiply(dA, w_cu, P);
+      if (TIMED) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        tm_a += now - t_prev;
+        t_prev = now;
+      }
+      __syncthreads();
+      if (TIMED) {
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        tm_b += now - t_prev;
+        t_prev = now;
+      }
+      dA = dB;
+      dB = locate(it + 2);
+    };
+    int it = 0;
+    for (; it + 1 < n_it; it += 2) {
+      iteration(it, 0, w[0], w[1]);
+      iteration(it + 1, 1, w[1], w[0]);
+    }
+    if (it < n_it) iteration(it, 0, w[0], w[1]);
+    if (TIMED && tid == 0) {
+      atomicAdd(&d_x3_timing[4], tm_a);   // multiplier: weights issue + multiply
+      atomicAdd(&d_x3_timing[0], tm_b);   // multiplier: barrier wait
+      atomicAdd(&d_x3_timing[7], (unsigned long long)n_it);
+    }
+  } else {
+    __syncthreads();
+  }
+
+  // every target row of the tile is written exactly once (rows without neighbours get zeros)
+  const int64_t row0 = (int64_t)tile * tile_rows;
+  const int rows_here = (int)min((int64_t)tile_rows, n_tgt - row0);
+  const bool vec_out = (c_dst % 4) == 0;
+  int32_t *s_ord = reinterpret_cast<int32_t *>(s_a);   // the stage buffers are free now
+  if (order != nullptr) {
+#pragma unroll
+    for (int j = 0; j < ORD; ++j)
+      if (j * NT + tid < tile_rows) s_ord[j * NT + tid] = my_ord[j];
+    __syncthreads();
+  }
+  for (int x = tid; x < tile_rows * NC / 4; x += NT) {
+    const int row = x / (NC / 4);
+    const int c4 = x % (NC / 4);
+    const int cc = col_base + c4 * 4;
+    if (row < rows_here && cc < c_dst) {
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(&s_acc[row * ACC_LD + c4 * 4]);
+      const int64_t grow = order ? (int64_t)s_ord[row] : row0 + row;
+      float *o = dst + grow * c_dst + cc;
+      if (vec_out) {
+        *reinterpret_cast<f32x4 *>(o) = v;
+      } else {
+        o[0] = v.x;
+        if (cc + 1 < c_dst) o[1] = v.y;
+        if (cc + 2 < c_dst) o[2] = v.z;
+        if (cc + 3 < c_dst) o[3] = v.w;
+      }
+    }
+  }
+}
+
 extern int g_conv_variant;  // conv.hip: variant 6 = 64-bit gather addresses, 256 = phase counters
 
 struct ConvVariantX3 {
@@ -488,6 +949,45 @@ static int launch_conv_tile_f32x3(const float *src, int c_src, const bf16x8 *wp,
                            const int32_t *, const int32_t *, float *, int64_t, int, int);
   kernel_t fn = small ? (exact ? &k_conv_tile_f32x3<NC, KC, true, true> : &k_conv_tile_f32x3<NC, KC, false, true>)
                       : (exact ? &k_conv_tile_f32x3<NC, KC, true, false> : &k_conv_tile_f32x3<NC, KC, false, false>);
+  if constexpr (NC == 64 || NC == 128) {
+    // default: the wave-specialised kernel; debug variant 30 = the ping-pong kernel, 256 = its phase counters,
+    // 257 = the wave-specialised kernel's phase counters
+    if (g_conv_variant != 30 && g_conv_variant != 256) {
+      kernel_t ws = small ? (exact ? &k_conv_tile_f32x3_ws<NC, KC, true, true> : &k_conv_tile_f32x3_ws<NC, KC, false, true>)
+                          : (exact ? &k_conv_tile_f32x3_ws<NC, KC, true, false> : &k_conv_tile_f32x3_ws<NC, KC, false, false>);
+      static bool ws_attr[12] = {false, false, false, false, false, false, false, false, false, false, false, false};
+      int wi = (small ? 2 : 0) + (exact ? 1 : 0);
+      if constexpr (KC >= 64) {
+        if (g_conv_variant == 257 && small && exact) {
+          ws = &k_conv_tile_f32x3_ws<NC, KC, true, true, true>;
+          wi = 4;
+        }
+        if (g_conv_variant == 32 && small && exact) {   // A/B: no priority for the multiplier waves
+          ws = &k_conv_tile_f32x3_ws<NC, KC, true, true, false, 0>;
+          wi = 5;
+        }
+        if (g_conv_variant >= 33 && g_conv_variant <= 38 && small && exact) {   // timing ablations (results invalid)
+          ws = g_conv_variant == 33   ? &k_conv_tile_f32x3_ws<NC, KC, true, true, false, 2, 1>
+               : g_conv_variant == 34 ? &k_conv_tile_f32x3_ws<NC, KC, true, true, false, 2, 2>
+               : g_conv_variant == 35 ? &k_conv_tile_f32x3_ws<NC, KC, true, true, false, 2, 3>
+               : g_conv_variant == 36 ? &k_conv_tile_f32x3_ws<NC, KC, true, true, false, 2, 4>
+               : g_conv_variant == 37 ? &k_conv_tile_f32x3_ws<NC, KC, true, true, false, 2, 5>
+                                      : &k_conv_tile_f32x3_ws<NC, KC, true, true, false, 2, 6>;
+          wi = 3 + (g_conv_variant - 30);
+        }
+      }
+      if (lds > 48 * 1024 && !ws_attr[wi]) {
+        ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ws), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   kLdsBudget));
+        ws_attr[wi] = true;
+      }
+      const dim3 wgrid((unsigned)ceil_div(n_tgt, tile_rows), (unsigned)slabs);
+      hipLaunchKernelGGL(ws, wgrid, dim3(512), (size_t)lds, stream, src, c_src, wp, c_dst, plan_src, plan_dst, batch_desc,
+                         tile_bptr, order, dst, n_tgt, tile_rows, batch_groups);
+      ME_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   constexpr bool kHasTimed = KC >= 64 && NC >= 64;   // instrumented build: the headline shapes only
   bool timed = false;
   if constexpr (kHasTimed) {

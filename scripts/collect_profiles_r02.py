@@ -129,6 +129,9 @@ def main():
     copy("bf16_batch_fusion.log", "r02_bench_bf16_batch_fusion.log")
     copy("r02_final3/pytest_gpu.log", "r02_pytest_gpu_final.log")          # after the last kernel change of the round
     copy("r02_final3/bench.json", "r02_bench_final_rerun.json")
+    copy("ablation_f32x3_ws.log", "r02_ablation_conv_f32x3_ws.log")
+    copy("r02ws3/bench_v0.json", "r02_bench_conv_f32x3_ws.json")
+    copy("r02ws3/unet_f32_v0.json", "r02_bench_minkunet34c_f32_ws.json")
     for extra in sys.argv[1:]:          # "src:dst" pairs for later sessions
         s, d = extra.split(":")
         copy(s, d)

@@ -7,7 +7,9 @@ from minkowskiengine_amd import backend as MEB, _lib
 from bench import make_scene
 dev = torch.device("cuda:0")
 lib = _lib.load()
-NAMES = ["barrier A", "split+stage write", "barrier B", "load issue", "multiply", "prologue", "epilogue", "batches"]
+VAR = int(os.environ.get("VARIANT", "257"))   # 257: wave-specialised kernel, 256: ping-pong kernel
+NAMES = (["multiplier barrier wait", "producer work", "producer barrier wait", "-", "multiplier work", "-", "-", "batches"]
+         if VAR == 257 else ["barrier A", "split+stage write", "barrier B", "load issue", "multiply", "prologue", "epilogue", "batches"])
 MEB._TILE_ROWS = int(os.environ.get("TILE", "0"))
 coords = make_scene(100000, int(os.environ.get("EXTENT", "70")), 0).to(dev)
 mgr = MEB.CoordinateMapManagerGPU_c10()
@@ -18,7 +20,7 @@ gy = torch.rand(100000, 128, device=dev)
 w = torch.rand(27, 64, 128, device=dev) - 0.5
 for name, fn in (("forward 64->128", lambda: MEB._conv_forward(x, w, km, "mfma")),
                  ("dgrad 128->64", lambda: MEB._conv_target(gy, w, km, "in", km.n_in, name="conv_dgrad", transposed=True))):
-    for var in (0, 256):
+    for var in (0 if VAR == 257 else 30, VAR):
         lib.me_debug_set_conv_variant(var)
         fn()
         torch.cuda.synchronize()
@@ -28,7 +30,7 @@ for name, fn in (("forward 64->128", lambda: MEB._conv_forward(x, w, km, "mfma")
         fn()
         e.record()
         torch.cuda.synchronize()
-        if var == 0:
+        if var in (0, 30):
             print(f"{name}: plain kernel {s.elapsed_time(e)*1e3:.0f} us")
             continue
         out = (ctypes.c_uint64 * 8)()

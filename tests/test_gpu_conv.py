@@ -267,6 +267,38 @@ def test_wgrad_range_order_and_split_kernel(device, cin, cout):
     assert err["split"] <= 2e-6 and err["split"] <= 4 * err["mfma"] + 1e-7, err
 
 
+@pytest.mark.parametrize("n,extent,cin,cout", [(6000, 18, 64, 128), (6000, 18, 128, 64), (5000, 40, 64, 64),
+                                               (4000, 16, 96, 128), (4000, 16, 128, 128), (3000, 14, 72, 120)])
+def test_wave_specialised_split_kernel_is_bit_identical(device, monkeypatch, n, extent, cin, cout):
+    """k_conv_tile_f32x3_ws (four multiplier waves + four producer waves; the default for 64- and 128-column slabs)
+    runs the same plan and the same MFMA sequence per output element as the ping-pong kernel k_conv_tile_f32x3
+    (debug variant 30): forward and input gradient must be bit-identical, and both match the oracle."""
+    from minkowskiengine_amd import backend as MEB, _lib
+    lib = _lib.load()
+    monkeypatch.setattr(MEB, "_F32_SPLIT", True)
+    coords = make_cloud(n, extent, 3, seed=cin + cout, batch=2, negative=True)
+    mgr = MEB.CoordinateMapManagerGPU_c10()
+    key, _ = mgr.insert_and_map(coords.to(device), [1, 1, 1], "")
+    km = mgr._kernel_map(key, key, [3] * 3, [1] * 3, [1] * 3, MEB.RegionType.HYPER_CUBE, None, False, False)
+    g = torch.Generator().manual_seed(2)
+    x = (torch.rand(coords.shape[0], cin, generator=g) - 0.5)
+    gy = (torch.rand(coords.shape[0], cout, generator=g) - 0.5)
+    w = (torch.rand(27, cin, cout, generator=g) - 0.5)
+    res = {}
+    try:
+        for variant in (0, 30):
+            lib.me_debug_set_conv_variant(variant)
+            y = MEB._conv_forward(x.to(device), w.to(device), km, "mfma")
+            gi = MEB._conv_target(gy.to(device), w.to(device), km, "in", km.n_in, name="d", transposed=True)
+            res[variant] = (y.clone(), gi.clone())
+    finally:
+        lib.me_debug_set_conv_variant(0)
+    assert torch.equal(res[0][0], res[30][0]) and torch.equal(res[0][1], res[30][1])
+    _, okm = O.kernel_map(coords.numpy(), coords.numpy(), O.make_region(3, 3))
+    assert_close(res[0][0], O.conv_forward(x.numpy(), w.numpy(), okm, coords.shape[0]))
+    assert_close(res[0][1], O.conv_backward(x.numpy(), gy.numpy(), w.numpy(), okm)[0])
+
+
 def test_bias_and_use_mm(device):
     import minkowskiengine_amd as ME
     coords = make_cloud(500, 10, 3, seed=2).to(device)
