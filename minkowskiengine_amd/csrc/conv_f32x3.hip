@@ -473,11 +473,11 @@ __global__ __launch_bounds__(NC * 4 * x3_group_shares(NC), 1) void k_conv_tile_f
 // 200 - 500 idle matrix cycles each time.  Order (the in-order lgkm counter is what the waits count against):
 //   pass 0: indices, operands of step 0 | old accumulators | per step: next operands (last step: pass 1's indices and
 //   first operands), wait, MFMAs | pass 1: old accumulators, stores of pass 0 | per step as before | stores.
-template <int RP0, int RP1, int CB, int KC, int ABL = 0>
+template <int RP0, int RP1, int CB, int KC, int ABL = 0, typename NextWeights>
 __device__ __forceinline__ void consume_batch_f32x3(const __bf16 *__restrict__ rowp, const int (&pofs)[KC / 32],
                                                     const bf16x8 (&w)[CB][3][KC / 32],
                                                     const int32_t *__restrict__ dstp, float *__restrict__ accp,
-                                                    int acc_ld) {
+                                                    int acc_ld, NextWeights &&load_next_weights) {
   typedef __attribute__((address_space(3))) const char lds_char;
   constexpr int KS = KC / 32;
   constexpr int LD = StageLayout<KC>::kLd;
@@ -579,6 +579,9 @@ __device__ __forceinline__ void consume_batch_f32x3(const __bf16 *__restrict__ r
   f32x4 old0[RP0][CB], old1[R1][CB];
   read_idx(dst_addr, IC0{}, d0);
   read_ops(op_addr[0][0], IC0{}, a[0]);
+  // the next batch's weight loads (12 vector-memory issues) go out here: their issue time hides behind the LDS
+  // round trip that the first MFMA has to wait for anyway, instead of standing in front of it
+  load_next_weights();
   wait_idx(IC0{}, d0, std::integral_constant<int, 3 * RP0>{});
 #pragma unroll
   for (int r = 0; r < RP0; ++r) addr0[r] = acc_addr + __umul24((unsigned)d0[r], (unsigned)acc_ld) * 4u;
@@ -836,23 +839,24 @@ __global__ __launch_bounds__(512, 1) void k_conv_tile_f32x3_ws(
     int pofs[KS];
 #pragma unroll
     for (int sx = 0; sx < KS; ++sx) pofs[sx] = ((sx * 4 + q) ^ SL::swz(i16)) * 8;
-    auto multiply = [&](const Desc &d, const bf16x8 (&wc)[CB][3][KS], int buf) {
+    auto multiply = [&](const Desc &d, const bf16x8 (&wc)[CB][3][KS], int buf, auto &&next_w) {
       const __bf16 *rowp = s_a + buf * 3 * PLANE + i16 * LD;
       const int32_t *dstp = s_dst + buf * CAP + i16;
       float *accp = &s_acc[wave * CB * 16 + q * 4];
       // groups 0, 1 then 2, 3 (two passes keep the operand registers of a pass at 2 x 3 planes, two steps deep)
-      if (d.ng >= 4) consume_batch_f32x3<2, 2, CB, KC, ABL>(rowp, pofs, wc, dstp, accp, ACC_LD);
-      else if (d.ng == 3) consume_batch_f32x3<2, 1, CB, KC, ABL>(rowp, pofs, wc, dstp, accp, ACC_LD);
-      else if (d.ng == 2) consume_batch_f32x3<2, 0, CB, KC, ABL>(rowp, pofs, wc, dstp, accp, ACC_LD);
-      else consume_batch_f32x3<1, 0, CB, KC, ABL>(rowp, pofs, wc, dstp, accp, ACC_LD);
+      if (d.ng >= 4) consume_batch_f32x3<2, 2, CB, KC, ABL>(rowp, pofs, wc, dstp, accp, ACC_LD, next_w);
+      else if (d.ng == 3) consume_batch_f32x3<2, 1, CB, KC, ABL>(rowp, pofs, wc, dstp, accp, ACC_LD, next_w);
+      else if (d.ng == 2) consume_batch_f32x3<2, 0, CB, KC, ABL>(rowp, pofs, wc, dstp, accp, ACC_LD, next_w);
+      else consume_batch_f32x3<1, 0, CB, KC, ABL>(rowp, pofs, wc, dstp, accp, ACC_LD, next_w);
     };
     Desc dA = locate(0), dB = locate(1);
     load_w(dA, w[0]);
     __syncthreads();                      // batch 0 is staged
     unsigned long long tm_a = 0, tm_b = 0, t_prev = TIMED ? __builtin_amdgcn_s_memtime() : 0ull;
     auto iteration = [&](int it, int P, bf16x8 (&w_cu)[CB][3][KS], bf16x8 (&w_nx)[CB][3][KS]) {
-      if (ABL != 4 || it == 0) load_w(dB, w_nx);      // (ABL 4: the weights are loaded once — timing ablation)
-      multiply(dA, w_cu, P);
+      multiply(dA, w_cu, P, [&]() {
+        if (ABL != 4 || it == 0) load_w(dB, w_nx);    // (ABL 4: the weights are loaded once — timing ablation)
+      });
       if (TIMED) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const unsigned long long now = __builtin_amdgcn_s_memtime();
