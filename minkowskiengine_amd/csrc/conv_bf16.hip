@@ -180,7 +180,6 @@ __global__ __launch_bounds__(NC * 4, 3) void k_conv_tile_bf16(
 
   const int b0 = tile_bptr[tile];
   const int nb = tile_bptr[tile + 1] - b0;
-  const int n_it = nb * nchunks;
 
   // Batch fusion (round 2).  On sparse maps most (tile, offset) items hold ONE 16-row group — MinkUNet's stride-1
   // level: 7 - 11 pairs per item; config 5: 11 — and a batch of one group pays the two barriers, the stage write,
