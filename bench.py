@@ -352,7 +352,9 @@ def bench_conv(args, ME, MEB, dist_utils, rank, world, dev, startup):
         nc = 128 if cout % 128 == 0 else 96 if cout % 96 == 0 else 32 if cout <= 32 else 64
         kc = 128 if cin % 128 == 0 and nc <= 64 else 64 if cin % 64 == 0 else 96 if cin % 96 == 0 else \
             32 if cin <= 32 else 64
-    kname = "k_conv_tile_bf16" if bf16 else "k_conv_tile_f32x3" if split else "k_conv_tile_f32"
+    # (64- and 128-column slabs of the split kernel run its wave-specialised instantiation)
+    kname = "k_conv_tile_bf16" if bf16 else ("k_conv_tile_f32x3_ws" if nc in (64, 128) else "k_conv_tile_f32x3") \
+        if split else "k_conv_tile_f32"
     esz = 2 if bf16 else 4
     compulsory = esz * (n * cin + n * cout + K * cin * cout) + 8 * n_pairs   # SURVEY 8d, forward
     traffic, traffic_src = pmc_traffic("k_conv_tile_bf16_forward" if bf16 else kname, n, extent, cin,
