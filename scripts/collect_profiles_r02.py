@@ -129,7 +129,7 @@ def main():
     copy("bf16_batch_fusion.log", "r02_bench_bf16_batch_fusion.log")
     copy("r02_final3/bench.json", "r02_bench_before_wave_specialisation.json")
     copy("r02_final5/pytest_gpu.log", "r02_pytest_gpu_final.log")      # the state the round ends in
-    copy("r02_final5/bench.json", "r02_bench_final.json")
+    copy("r02_final6/bench.json", "r02_bench_final.json")
     copy("ablation_f32x3_ws.log", "r02_ablation_conv_f32x3_ws.log")
     copy("r02ws3/bench_v0.json", "r02_bench_conv_f32x3_ws.json")
     copy("r02ws3/unet_f32_v0.json", "r02_bench_minkunet34c_f32_ws.json")
