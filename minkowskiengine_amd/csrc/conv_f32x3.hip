@@ -656,17 +656,23 @@ __device__ __forceinline__ void consume_batch_f32x3(const __bf16 *__restrict__ r
   }
 }
 
-template <int NC, int KC, bool EXACT, bool SMALL, bool TIMED = false, int PRIO = 2, int ABL = 0>
-__global__ __launch_bounds__(512, 1) void k_conv_tile_f32x3_ws(
+// NCW: multiplier waves.  4: NC / 4 columns each.  8 (128-column slabs, the default there): 16 columns each, two
+// multipliers per SIMD next to the producer — the operand reads double again, but one multiplier's MFMAs cover the
+// other's waits: forward 64 -> 128 11 - 17 % faster (scripts/check_variant.py).  (Eight multipliers on a 64-column slab,
+// each taking one pass of a batch, were tried: KC = 128 no longer fits 168 registers, 64 -> 64 gains 3 %.)
+template <int NC, int KC, bool EXACT, bool SMALL, bool TIMED = false, int PRIO = 2, int ABL = 0, int NCW = 4>
+__global__ __launch_bounds__((NCW + 4) * 64, 1) void k_conv_tile_f32x3_ws(
     const float *__restrict__ src, int c_src, const bf16x8 *__restrict__ wp, int c_dst,
     const int32_t *__restrict__ plan_src, const int32_t *__restrict__ plan_dst,
     const int32_t *__restrict__ batch_desc, const int32_t *__restrict__ tile_bptr,
     const int32_t *__restrict__ order, float *__restrict__ dst, int64_t n_tgt, int tile_rows, int batch_groups) {
   typedef int i32x2 __attribute__((ext_vector_type(2)));
   typedef StageLayout<KC> SL;
-  static_assert(NC == 64 || NC == 128, "four multiplier waves of 16 or 32 columns");
-  constexpr int CB = NC / 64;          // 16-column blocks per multiplier wave
-  constexpr int NT = 512, NTP = 256;   // threads, producer threads
+  static_assert(NC == 64 || NC == 128, "multiplier waves of 16 or 32 columns");
+  static_assert(NCW == 4 || (NCW == 8 && NC == 128), "four multiplier waves, or eight on a 128-column slab");
+  constexpr int CB = NC / (16 * NCW);  // 16-column blocks per multiplier wave
+  constexpr int NTP = 256;             // producer threads (four waves)
+  constexpr int NT = NCW * 64 + NTP;   // threads
   constexpr int LD = SL::kLd;
   constexpr int ACC_LD = NC + kAccPad;
   constexpr int KS = KC / 32;
@@ -723,9 +729,9 @@ __global__ __launch_bounds__(512, 1) void k_conv_tile_f32x3_ws(
     return d;
   };
 
-  if (n_it > 0 && wave >= 4) {
+  if (n_it > 0 && wave >= NCW) {
     // ------------------------------------------------ producer waves ------------------------------------------------
-    const int ptid = tid - NTP;
+    const int ptid = tid - NCW * 64;
     f32x4 stage[2][ITER][2];
     int32_t dstv[2] = {tile_rows, tile_rows};
     int32_t sidx[2][ITER];
@@ -815,7 +821,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_tile_f32x3_ws(
       iteration(it + 1, 1, stage[0], dstv[0], sidx[0], sidx[1]);
     }
     if (it < n_it) iteration(it, 0, stage[1], dstv[1], sidx[1], sidx[0]);
-    if (TIMED && tid == NTP) {
+    if (TIMED && tid == NCW * 64) {
       atomicAdd(&d_x3_timing[1], tm_a);   // producer: split + stage write + load issue
       atomicAdd(&d_x3_timing[2], tm_b);   // producer: barrier wait
     }
@@ -957,18 +963,36 @@ static int launch_conv_tile_f32x3(const float *src, int c_src, const bf16x8 *wp,
     // default: the wave-specialised kernel; debug variant 30 = the ping-pong kernel, 256 = its phase counters,
     // 257 = the wave-specialised kernel's phase counters
     if (g_conv_variant != 30 && g_conv_variant != 256) {
-      kernel_t ws = small ? (exact ? &k_conv_tile_f32x3_ws<NC, KC, true, true> : &k_conv_tile_f32x3_ws<NC, KC, false, true>)
-                          : (exact ? &k_conv_tile_f32x3_ws<NC, KC, true, false> : &k_conv_tile_f32x3_ws<NC, KC, false, false>);
-      static bool ws_attr[12] = {false, false, false, false, false, false, false, false, false, false, false, false};
+      kernel_t ws;
       int wi = (small ? 2 : 0) + (exact ? 1 : 0);
+      int wthreads = 512;
+      static bool ws_attr[20] = {};
+      if constexpr (NC == 128) {
+        if (g_conv_variant != 31) {   // default: eight multiplier waves (variant 31: four)
+          ws = small ? (exact ? &k_conv_tile_f32x3_ws<NC, KC, true, true, false, 2, 0, 8>
+                              : &k_conv_tile_f32x3_ws<NC, KC, false, true, false, 2, 0, 8>)
+                     : (exact ? &k_conv_tile_f32x3_ws<NC, KC, true, false, false, 2, 0, 8>
+                              : &k_conv_tile_f32x3_ws<NC, KC, false, false, false, 2, 0, 8>);
+          wi += 13;
+          wthreads = 768;
+        } else {
+          ws = small ? (exact ? &k_conv_tile_f32x3_ws<NC, KC, true, true> : &k_conv_tile_f32x3_ws<NC, KC, false, true>)
+                     : (exact ? &k_conv_tile_f32x3_ws<NC, KC, true, false> : &k_conv_tile_f32x3_ws<NC, KC, false, false>);
+        }
+      } else {
+        ws = small ? (exact ? &k_conv_tile_f32x3_ws<NC, KC, true, true> : &k_conv_tile_f32x3_ws<NC, KC, false, true>)
+                   : (exact ? &k_conv_tile_f32x3_ws<NC, KC, true, false> : &k_conv_tile_f32x3_ws<NC, KC, false, false>);
+      }
       if constexpr (KC >= 64) {
         if (g_conv_variant == 257 && small && exact) {
           ws = &k_conv_tile_f32x3_ws<NC, KC, true, true, true>;
           wi = 4;
+          wthreads = 512;
         }
-        if (g_conv_variant == 32 && small && exact) {   // A/B: no priority for the multiplier waves
+        if (g_conv_variant == 32 && small && exact) {   // A/B: no priority for the multiplier waves (four of them)
           ws = &k_conv_tile_f32x3_ws<NC, KC, true, true, false, 0>;
           wi = 5;
+          wthreads = 512;
         }
         if (g_conv_variant >= 33 && g_conv_variant <= 38 && small && exact) {   // timing ablations (results invalid)
           ws = g_conv_variant == 33   ? &k_conv_tile_f32x3_ws<NC, KC, true, true, false, 2, 1>
@@ -978,6 +1002,7 @@ static int launch_conv_tile_f32x3(const float *src, int c_src, const bf16x8 *wp,
                : g_conv_variant == 37 ? &k_conv_tile_f32x3_ws<NC, KC, true, true, false, 2, 5>
                                       : &k_conv_tile_f32x3_ws<NC, KC, true, true, false, 2, 6>;
           wi = 3 + (g_conv_variant - 30);
+          wthreads = 512;
         }
       }
       if (lds > 48 * 1024 && !ws_attr[wi]) {
@@ -986,7 +1011,7 @@ static int launch_conv_tile_f32x3(const float *src, int c_src, const bf16x8 *wp,
         ws_attr[wi] = true;
       }
       const dim3 wgrid((unsigned)ceil_div(n_tgt, tile_rows), (unsigned)slabs);
-      hipLaunchKernelGGL(ws, wgrid, dim3(512), (size_t)lds, stream, src, c_src, wp, c_dst, plan_src, plan_dst, batch_desc,
+      hipLaunchKernelGGL(ws, wgrid, dim3(wthreads), (size_t)lds, stream, src, c_src, wp, c_dst, plan_src, plan_dst, batch_desc,
                          tile_bptr, order, dst, n_tgt, tile_rows, batch_groups);
       ME_LAUNCH_CHECK();
       return 0;

@@ -136,6 +136,9 @@ def main():
     counters("r02_pmc_final", "r02_pmc_traffic_final.log", keep=("conv_tile", "wgrad"),
              header="# FETCH_SIZE / WRITE_SIZE (KB as reported; fetch x2 per the gfx950 correction), TCC hit / miss of the "
                     "config-2 launches of the kernels the round ends on (scripts/gpu_pmc_final.sh)")
+    copy("r02ws5/bench_v0.json", "r02_bench_conv_f32x3_ws_eight_multipliers.json")
+    copy("r02ws5/bench_v31.json", "r02_bench_conv_f32x3_ws_four_multipliers.json")
+    copy("r02ws5/unet_f32_v0.json", "r02_bench_minkunet34c_f32_ws_eight_multipliers.json")
     for extra in sys.argv[1:]:          # "src:dst" pairs for later sessions
         s, d = extra.split(":")
         copy(s, d)

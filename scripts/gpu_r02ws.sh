@@ -4,9 +4,9 @@ TAG=${1:-r02ws}
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_gpu_conv.py -m gpu -q --timeout 600 -k "wave_specialised" > $OUT/pytest.log 2>&1; echo "pytest rc=$?"
+timeout 600 python -m pytest tests/test_gpu_conv.py -m gpu -q --timeout 600 -k "wave_specialised or vs_oracle or fixtures or full_size" > $OUT/pytest.log 2>&1; echo "pytest rc=$?"
 grep -E "^(FAILED|ERROR)|passed|failed" $OUT/pytest.log | head
-for v in 0 30; do
+for v in 0 31; do
   ME_AMD_CONV_VARIANT=$v timeout 300 python bench.py --steps 20 --warmup 5 --cpu-budget 0 > $OUT/bench_v$v.json 2>/dev/null
   python - <<PY
 import json
