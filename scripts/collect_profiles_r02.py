@@ -123,13 +123,12 @@ def main():
                      ("unet_bf16_graph.json", "r02_bench_final_minkunet34c_bf16_graph.json"),
                      ("kernel_stats_bench.csv", "r02_rocprof_kernel_stats_final.csv"),
                      ("pytest_gpu.log", "r02_pytest_gpu_final.log"), ("smoke.log", "r02_smoke_final.log")):
-        copy("r02_final4/" + src, dst)
-    copy("r02_final4/unet_bf16_fresh.json", "r02_bench_final_minkunet34c_bf16_fresh_scenes.json")
-    copy("r02_final4/unet_bf16_pipelined.json", "r02_bench_final_minkunet34c_bf16_pipelined_scenes.json")
+        copy("r02_final7/" + src, dst)
+    copy("r02_final7/unet_bf16_fresh.json", "r02_bench_final_minkunet34c_bf16_fresh_scenes.json")
+    copy("r02_final7/unet_bf16_pipelined.json", "r02_bench_final_minkunet34c_bf16_pipelined_scenes.json")
     copy("bf16_batch_fusion.log", "r02_bench_bf16_batch_fusion.log")
     copy("r02_final3/bench.json", "r02_bench_before_wave_specialisation.json")
-    copy("r02_final5/pytest_gpu.log", "r02_pytest_gpu_final.log")      # the state the round ends in
-    copy("r02_final6/bench.json", "r02_bench_final.json")
+    copy("r02_final6/bench.json", "r02_bench_four_multipliers_best_box.json")
     copy("ablation_f32x3_ws.log", "r02_ablation_conv_f32x3_ws.log")
     copy("r02ws3/bench_v0.json", "r02_bench_conv_f32x3_ws.json")
     copy("r02ws3/unet_f32_v0.json", "r02_bench_minkunet34c_f32_ws.json")
