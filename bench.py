@@ -100,7 +100,7 @@ def hip_timed(fn):
     return r, s.elapsed_time(e)
 
 
-def cold_path(ME, MEB, feats, coords, dev, n, D=3, K=27, cin=64, cout=128):
+def cold_path(ME, MEB, feats, coords, dev, n, D=3, K=27, cin=64, cout=128, bf16=False):
     """Coordinate insertion + kernel-map build + tile plans of one scene, each timed with HIP events (best of
     three: the first repetition pays the allocator), with the achieved rate on SURVEY 8(d)'s algorithmic bytes
     (probes N*K x key bytes + 8 B per pair written; insert N x key bytes + table + maps)."""
@@ -113,8 +113,9 @@ def cold_path(ME, MEB, feats, coords, dev, n, D=3, K=27, cin=64, cout=128):
                                                      None, False, False))
 
         def plans():
+            # the launch configurations of forward and dgrad: tile plan (+ the spatial index behind its tile order)
             for tgt, (cs, cd) in (("out", (cin, cout)), ("in", (cout, cin))):
-                km.plan(tgt, *MEB.plan_config(n, K, km.n_pairs, cs, cd))
+                MEB._conv_launch_cfg(km, tgt, n, cs, cd, bf16)
         _, t_plan = hip_timed(plans)
         for name, t in (("insert_ms", t_ins), ("kernel_map_ms", t_km), ("plans_ms", t_plan)):
             best[name] = min(best.get(name, 1e9), t)
@@ -334,7 +335,7 @@ def bench_conv(args, ME, MEB, dist_utils, rank, world, dev, startup):
     best, blocks, timer, timed_steps = run_timed(step, args, dist_utils, MEB, dev)
     total_points = dist_utils.sum_over_ranks(n, dev)
     pairs_all = dist_utils.sum_over_ranks(n_pairs, dev)
-    cold = cold_path(ME, MEB, feats, coords.to(dev), dev, n, D, K, cin, cout) if rank == 0 else None
+    cold = cold_path(ME, MEB, feats, coords.to(dev), dev, n, D, K, cin, cout, args.dtype == "bf16") if rank == 0 else None
     if rank != 0:
         return None
     kernels = kernel_table(timer, timed_steps)

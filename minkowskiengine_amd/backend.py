@@ -417,29 +417,44 @@ class KernelMapGPU:
             self._store[name] = row
         return self._store[name]
 
-    def order(self, target):
+    def order(self, target, tile_order=None):
         """Target rows in tile order (int32 [n_tgt]: tile position -> row) for the convolution kernels' stores, or
-        None when tiles are runs of consecutive rows.  Position-space maps: the supercell order of the target map
-        (tiles are spatially compact: their gathers hit the L2) unless ME_AMD_TILE_ORDER=rows (the plan then reads
-        the position-space table through pos_of_row: tiles of consecutive rows again); flat-table maps: the argsort
-        of the Z-order keys when ME_AMD_SPATIAL_TILES=1 (round-1 experiment), else None."""
+        None when tiles are runs of consecutive rows.  `tile_order` "spatial": the supercell order of the target's
+        coordinate map (tiles are spatially compact: their gathers hit the L2) — the map's own position space when
+        it was built by the LDS-bucketed probe, else the spatial index of the target map, built on first use;
+        "rows": runs of consecutive rows (a position-space table is then read through pos_of_row)."""
+        tile_order = tile_order or self._tile_order(target)
         native = self._store.get(self._name("order", target))
         if native is not None:
-            return native if self._tile_order(target) == "spatial" else None
-        return self._legacy_order(target)
+            return native if tile_order == "spatial" else None
+        return self._flat_order(target, tile_order)
 
-    def _tile_order(self, target):
+    def _tile_order(self, target, matrix_bound=False):
+        """"rows" | "spatial" for a launch family.  `matrix_bound`: the fp32 kernels on the bf16 matrix pipe
+        (csrc/conv_f32x3.hip) — their tile time does not depend on how even the tiles are, so they always take the
+        spatially compact tiles (config 2: 1.5 - 1.6x the compulsory HBM traffic instead of 3.2x at the same
+        speed, profiles/r02_pmc_traffic_tile_order_final.log); the latency-bound kernels keep row tiles while the
+        neighbour table is small enough for the plan builder's scattered reads."""
         if _TILE_ORDER != "auto":
             return _TILE_ORDER
+        if matrix_bound:
+            return "spatial"
         n_tgt = self.n_out if target == "out" else self.n_in
         return "rows" if self.volume * n_tgt * 4 <= _TILE_ORDER_ROWS_MAX_BYTES else "spatial"
 
-    def _legacy_order(self, target):
+    def _flat_order(self, target, tile_order):
+        """Tile permutation of a row-space (flat-table) map: the supercell order of the target's coordinate map for
+        "spatial" tiles (None when that map has no spatial index: the tiles are then row tiles), the argsort of the
+        Z-order keys with ME_AMD_SPATIAL_TILES=1 (round-1 experiment), else None."""
+        cmap = self.out_map if target == "out" else self.in_map
+        if tile_order == "spatial" and cmap is not None and cmap.n > 0:
+            sp = cmap.spatial()
+            if sp is not None:
+                return sp.order
         if not _SPATIAL_TILES:
             return None
         name = self._name("zorder", target)
         if name not in self._store:
-            cmap = self.out_map if target == "out" else self.in_map
             if cmap is None or cmap.n == 0:
                 self._store[name] = None
             else:
@@ -453,11 +468,12 @@ class KernelMapGPU:
                 self._store[name] = torch.argsort(keys, stable=True).to(torch.int32)
         return self._store[name]
 
-    def plan(self, target, tile_rows, batch_groups):
+    def plan(self, target, tile_rows, batch_groups, tile_order=None):
         """Tile plan with `target` rows stationary, tiles of `tile_rows` rows and batches of at most
         `batch_groups` groups: (plan_src, plan_dst, batch_desc, tile_bptr, item_gptr); built once per
-        (target, tile_rows, batch_groups)."""
-        name = self._name("plan", target) + f"_{int(tile_rows)}_{int(batch_groups)}_{self._tile_order(target)}"
+        (target, tile_rows, batch_groups, tile order)."""
+        tile_order = tile_order or self._tile_order(target)
+        name = self._name("plan", target) + f"_{int(tile_rows)}_{int(batch_groups)}_{tile_order}"
         if name not in self._store:
             lib = _lib.load()
             dev = self.device
@@ -474,9 +490,9 @@ class KernelMapGPU:
             # a position-space table is read in its own order (tiles = runs of positions); a row-space table goes
             # through the optional Z-order permutation
             if native is not None:
-                gather_order = None if self._tile_order(target) == "spatial" else self._store[self._name("pos", target)]
+                gather_order = None if tile_order == "spatial" else self._store[self._name("pos", target)]
             else:
-                gather_order = self._legacy_order(target)
+                gather_order = self._flat_order(target, tile_order)
             with _on(dev):
                 _lib.check(lib.me_plan_build(_ptr(tbl), _ptr(gather_order), n_tgt, self.volume, tile_rows,
                                              batch_groups, _ptr(plan_src), _ptr(plan_dst), _ptr(batch_desc),
@@ -1106,11 +1122,12 @@ def _conv_launch_cfg(km, target, n_tgt, c_src, c_dst, bf16):
     cfg = km._launch_cache.get(ck)
     if cfg is None:
         tile_rows, batch_groups = plan_config(n_tgt, km.volume, km.n_pairs, c_src, c_dst, bf16, split)
-        plan_src, plan_dst, batch_desc, tile_bptr, _ = km.plan(target, tile_rows, batch_groups)
+        tile_order = km._tile_order(target, matrix_bound=split)
+        plan_src, plan_dst, batch_desc, tile_bptr, _ = km.plan(target, tile_rows, batch_groups, tile_order)
         elems = int((lib.me_conv_packed_weight_elems_bf16 if bf16 else
                      (lib.me_conv_packed_weight_elems_f32x3 if split else lib.me_conv_packed_weight_elems))(
             volume, c_src, c_dst))
-        order = km.order(target)
+        order = km.order(target, tile_order)
         # batch fusion (bf16 tile kernel): on maps whose (tile, offset) items mostly hold one or two 16-row groups
         n_tiles = -(-n_tgt // tile_rows)
         per_item = (km.n_pairs - min(km.n_in, km.n_out)) / max(1, (volume - 1) * n_tiles) if volume > 1 else 1e9

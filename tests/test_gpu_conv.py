@@ -300,6 +300,40 @@ def test_wave_specialised_split_kernel_is_bit_identical(device, monkeypatch, n, 
     assert_close(res[0][1], O.conv_backward(x.numpy(), gy.numpy(), w.numpy(), okm)[0])
 
 
+@pytest.mark.parametrize("spatial_maps", [False, True])
+@pytest.mark.parametrize("n,extent,cin,cout", [(6000, 18, 64, 128), (5000, 40, 128, 64), (3000, 14, 72, 120)])
+def test_matrix_bound_kernels_take_spatial_tiles(device, monkeypatch, n, extent, cin, cout, spatial_maps):
+    """The fp32 kernels on the bf16 matrix pipe take spatially compact tiles by default (supercell order of the
+    target map: the map's own position space, or — flat-table maps — the spatial index of the coordinate map,
+    KernelMapGPU._flat_order).  The tile order only regroups target rows: the sum of a row runs over the offsets in
+    the same order, so forward and input gradient are bit-identical to row tiles, and both match the oracle."""
+    from minkowskiengine_amd import backend as MEB
+    monkeypatch.setattr(MEB, "_F32_SPLIT", True)
+    monkeypatch.setattr(MEB, "_SPATIAL_MAPS", spatial_maps)
+    coords = make_cloud(n, extent, 3, seed=cin + cout, batch=2, negative=True)
+    g = torch.Generator().manual_seed(2)
+    x = (torch.rand(coords.shape[0], cin, generator=g) - 0.5)
+    gy = (torch.rand(coords.shape[0], cout, generator=g) - 0.5)
+    w = (torch.rand(27, cin, cout, generator=g) - 0.5)
+    res = {}
+    for order in ("auto", "rows"):
+        monkeypatch.setattr(MEB, "_TILE_ORDER", order)
+        mgr = MEB.CoordinateMapManagerGPU_c10()
+        key, _ = mgr.insert_and_map(coords.to(device), [1, 1, 1], "")
+        km = mgr._kernel_map(key, key, [3] * 3, [1] * 3, [1] * 3, MEB.RegionType.HYPER_CUBE, None, False, False)
+        y = MEB._conv_forward(x.to(device), w.to(device), km, "mfma")
+        gi = MEB._conv_target(gy.to(device), w.to(device), km, "in", km.n_in, name="d", transposed=True)
+        _, cfg = MEB._conv_launch_cfg(km, "out", km.n_out, cin, cout, False)
+        res[order] = (y.clone(), gi.clone(), cfg[6])
+    assert res["auto"][2] is not None and res["rows"][2] is None      # a tile permutation / none
+    perm = res["auto"][2].long().cpu()
+    assert torch.equal(torch.sort(perm).values, torch.arange(coords.shape[0]))
+    assert torch.equal(res["auto"][0], res["rows"][0]) and torch.equal(res["auto"][1], res["rows"][1])
+    _, okm = O.kernel_map(coords.numpy(), coords.numpy(), O.make_region(3, 3))
+    assert_close(res["auto"][0], O.conv_forward(x.numpy(), w.numpy(), okm, coords.shape[0]))
+    assert_close(res["auto"][1], O.conv_backward(x.numpy(), gy.numpy(), w.numpy(), okm)[0])
+
+
 def test_bias_and_use_mm(device):
     import minkowskiengine_amd as ME
     coords = make_cloud(500, 10, 3, seed=2).to(device)
