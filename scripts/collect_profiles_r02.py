@@ -138,6 +138,28 @@ def main():
     copy("r02ws5/bench_v0.json", "r02_bench_conv_f32x3_ws_eight_multipliers.json")
     copy("r02ws5/bench_v31.json", "r02_bench_conv_f32x3_ws_four_multipliers.json")
     copy("r02ws5/unet_f32_v0.json", "r02_bench_minkunet34c_f32_ws_eight_multipliers.json")
+    # tile order of the matrix-bound fp32 kernels (end of the round): row tiles vs supercell order (position-space
+    # maps, or the spatial index on flat-table maps = the default) vs Z-order argsort
+    hdr = ("# FETCH_SIZE / WRITE_SIZE (KB as reported; fetch x2 per the gfx950 correction), TCC hit / miss of the "
+           "config-2 launches (scripts/gpu_pmc_final.sh); ")
+    counters("r02_pmc_tile_order_final", "r02_pmc_traffic_tile_order_final.log", keep=("conv_tile", "wgrad"),
+             header=hdr + "DEFAULT: flat-table map, tiles in the supercell order of the target map")
+    counters("r02_pmc_spatial", "r02_pmc_traffic_tile_order_position_space_maps.log", keep=("conv_tile", "wgrad"),
+             header=hdr + "ME_AMD_SPATIAL_MAPS=1 ME_AMD_TILE_ORDER=spatial (position-space map, pair lists in position order)")
+    counters("r02_pmc_zorder", "r02_pmc_traffic_tile_order_zorder.log", keep=("conv_tile", "wgrad"),
+             header=hdr + "ME_AMD_SPATIAL_TILES=1 (argsort of the Z-order keys)")
+    for src, dst in (("r02_exp8/c2_rows.json", "r02_bench_tile_order_rows.json"),
+                     ("r02_exp9/c2_f32_spatial.json", "r02_bench_tile_order_position_space_maps.json"),
+                     ("r02_exp11/c2_f32.json", "r02_bench_tile_order_zorder.json"),
+                     ("r02_exp13/c2_f32.json", "r02_bench_tile_order_default.json"),
+                     ("r02_exp13/unet_f32.json", "r02_bench_minkunet34c_f32_tile_order_default.json"),
+                     ("r02_exp13/unet_f32_fresh.json", "r02_bench_minkunet34c_f32_fresh_tile_order_default.json"),
+                     ("r02_exp13/unet_f32_fresh_rows.json", "r02_bench_minkunet34c_f32_fresh_row_tiles.json"),
+                     ("r02_exp8/c5_split.json", "r02_bench_conv4d_split_forced.json"),
+                     ("r02_exp8/c5_auto.json", "r02_bench_conv4d_split_auto.json"),
+                     ("r02_exp12/rows.log", "r02_host_time_layer_step_bf16.log"),
+                     ("r02_exp12/sparse_rows.log", "r02_host_time_layer_step_sparse_f32.log")):
+        copy(src, dst)
     for extra in sys.argv[1:]:          # "src:dst" pairs for later sessions
         s, d = extra.split(":")
         copy(s, d)
