@@ -518,11 +518,14 @@ class KernelMapGPU:
 _SPATIAL_MAPS = {"1": True, "0": False}.get(os.environ.get("ME_AMD_SPATIAL_MAPS", "auto"), "auto")
 _SPATIAL_MIN_VOLUME = 64            # auto: kernels of at least this many offsets ...
 _SPATIAL_MIN_PROBES = 1 << 24       # ... or maps of at least this many (row, offset) probes
-# Tiles of position-space maps: "rows" = runs of consecutive rows (the plan reads the table through pos_of_row),
-# "spatial" = runs of positions (spatially compact tiles: 2 - 2.6x less HBM-side traffic in the convolution, but
-# 3 - 7 % slower on uniform random scenes, profiles/r02_tile_order.log)
-# "auto": row tiles while the table is small enough for the plan builder's scattered reads (<= 32 MiB: L2 / Infinity
-# Cache resident), spatial tiles beyond (config 5: 130 MB table — the row-order plan took 2.0 ms instead of 0.37)
+# Tile order of the convolution plans: "rows" = runs of consecutive rows (a position-space table is read through
+# pos_of_row), "spatial" = runs of positions in the supercell order of the target map (spatially compact tiles: 2 -
+# 2.6x less HBM-side traffic in the convolution; flat-table maps take the order from the target coordinate map's
+# spatial index).  "auto" decides per launch family (KernelMapGPU._tile_order): the fp32 kernels on the bf16 matrix
+# pipe always take spatial tiles (same speed); the others — 3 - 12 % slower on spatial tiles of uniform
+# random scenes — keep row tiles while the table is small enough for the plan builder's scattered reads (<= 32 MiB:
+# L2 / Infinity Cache resident) and take spatial tiles beyond (config 5: 130 MB table — the row-order plan took
+# 2.0 ms instead of 0.37)
 _TILE_ORDER = os.environ.get("ME_AMD_TILE_ORDER", "auto")
 _TILE_ORDER_ROWS_MAX_BYTES = 32 << 20
 
