@@ -123,9 +123,9 @@ def main():
                      ("unet_bf16_graph.json", "r02_bench_final_minkunet34c_bf16_graph.json"),
                      ("kernel_stats_bench.csv", "r02_rocprof_kernel_stats_final.csv"),
                      ("pytest_gpu.log", "r02_pytest_gpu_final.log"), ("smoke.log", "r02_smoke_final.log")):
-        copy("r02_final7/" + src, dst)
-    copy("r02_final7/unet_bf16_fresh.json", "r02_bench_final_minkunet34c_bf16_fresh_scenes.json")
-    copy("r02_final7/unet_bf16_pipelined.json", "r02_bench_final_minkunet34c_bf16_pipelined_scenes.json")
+        copy("r02_final8/" + src, dst)
+    copy("r02_final8/unet_bf16_fresh.json", "r02_bench_final_minkunet34c_bf16_fresh_scenes.json")
+    copy("r02_final8/unet_bf16_pipelined.json", "r02_bench_final_minkunet34c_bf16_pipelined_scenes.json")
     copy("bf16_batch_fusion.log", "r02_bench_bf16_batch_fusion.log")
     copy("r02_final3/bench.json", "r02_bench_before_wave_specialisation.json")
     copy("r02_final6/bench.json", "r02_bench_four_multipliers_best_box.json")
