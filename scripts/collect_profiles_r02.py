@@ -160,6 +160,7 @@ def main():
                      ("r02_exp12/rows.log", "r02_host_time_layer_step_bf16.log"),
                      ("r02_exp12/sparse_rows.log", "r02_host_time_layer_step_sparse_f32.log")):
         copy(src, dst)
+    copy("r02_unet_prof_final/kernel_stats_bf16.csv", "r02_rocprof_kernel_stats_minkunet34c_bf16_final.csv")
     for extra in sys.argv[1:]:          # "src:dst" pairs for later sessions
         s, d = extra.split(":")
         copy(s, d)
