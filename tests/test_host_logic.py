@@ -79,3 +79,22 @@ def test_enums_match_reference_names():  # pybind/extern.hpp:669-741
     assert hasattr(ME.ConvolutionMode, "DIRECT_GEMM") and hasattr(ME.MinkowskiAlgorithm, "SPEED_OPTIMIZED")
     assert hasattr(MEB, "ConvolutionForwardGPU") and hasattr(MEB, "ConvolutionTransposeBackwardGPU")
     assert MEB.is_cuda_available()
+
+
+def test_tile_order_policy(monkeypatch):
+    """KernelMapGPU._tile_order: the matrix-bound launch family (fp32 on the bf16 matrix pipe) takes spatially compact
+    tiles, the others row tiles while the neighbour table is at most 32 MiB; ME_AMD_TILE_ORDER overrides both; a map
+    without coordinate maps (nothing to take a spatial order from) falls back to row tiles (order None)."""
+    offs = torch.zeros(28, dtype=torch.int64)
+    pairs = torch.zeros(0, dtype=torch.int32)
+    small = MEB.KernelMapGPU(27, 100000, 100000, [0] * 28, offs, pairs, pairs)
+    big = MEB.KernelMapGPU(81, 400000, 400000, [0] * 82, torch.zeros(82, dtype=torch.int64), pairs, pairs)
+    monkeypatch.setattr(MEB, "_TILE_ORDER", "auto")
+    assert small._tile_order("out") == "rows" and small._tile_order("in") == "rows"
+    assert small._tile_order("out", matrix_bound=True) == "spatial"
+    assert big._tile_order("out") == "spatial"                      # 81 x 400k x 4 B = 130 MB table
+    monkeypatch.setattr(MEB, "_TILE_ORDER", "rows")
+    assert small._tile_order("out", matrix_bound=True) == "rows" and big._tile_order("out") == "rows"
+    monkeypatch.setattr(MEB, "_TILE_ORDER", "auto")
+    monkeypatch.setattr(MEB, "_SPATIAL_TILES", False)
+    assert small.order("out", "spatial") is None and small.order("out") is None
