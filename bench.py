@@ -19,8 +19,9 @@ check of the N > 1 path, not a scaling number.
 
 Timing: W warm-up steps, then blocks of EXACTLY K steps, each bracketed by barrier + synchronize on both
 sides and reduced with max over ranks; blocks are repeated until at least --min-time seconds have been
-timed (a 20-step block of the headline workload is 10 ms) and the FASTEST block is reported (`ms_per_step`,
-`value`); every block is listed under `blocks_ms_per_step`.
+timed (a 20-step block of the headline workload is 7 ms) and the MEDIAN block is reported (`ms_per_step`, `value`;
+round 2 reported the fastest block, which is still listed as `fastest_block_ms_per_step`); every block is under
+`blocks_ms_per_step`.
 
 Other workloads (never the default; parity-test configurations timed for DESIGN.md):
     --workload conv4d     BASELINE configs[4]: 4-D k = 3 (K = 81), 400k voxels in 100^3 x 8 frames, 32 -> 64
@@ -130,6 +131,13 @@ def cold_path(ME, MEB, feats, coords, dev, n, D=3, K=27, cin=64, cout=128, bf16=
     return out
 
 
+def rank_points(n, rank, world, imbalance):
+    """voxels of this rank's scene: n, or with --imbalance a ramp from 0.75 n (rank 0) to 1.25 n (last rank)"""
+    if not imbalance or world < 2:
+        return n
+    return int(n * (0.75 + 0.5 * rank / (world - 1)))
+
+
 def make_scene(n, extent, seed, D=3):
     """unique, unsorted voxels drawn uniformly from [0, extent)^D (extent: int or one
     value per axis), batch index 0."""
@@ -141,6 +149,38 @@ def make_scene(n, extent, seed, D=3):
     pts = pts[torch.randperm(pts.shape[0], generator=g)][:n]
     assert pts.shape[0] == n, "extent too small for n unique voxels"
     return torch.cat([torch.zeros(n, 1, dtype=torch.long), pts], 1).int().contiguous()
+
+
+REFERENCE_THREAD_CAP = 16   # the reference caps its own OpenMP threads (MinkowskiEngine/__init__.py:34-46)
+
+
+class _threads:
+    """with _threads(n): torch / MKL / OpenMP thread count for the CPU baseline (n = 0: leave as is)"""
+    def __init__(self, n):
+        self.n, self.old = n, None
+
+    def __enter__(self):
+        if self.n:
+            self.old = torch.get_num_threads()
+            torch.set_num_threads(self.n)
+
+    def __exit__(self, *exc):
+        if self.old:
+            torch.set_num_threads(self.old)
+        return False
+
+
+def cpu_baseline_both(fn, budget_s):
+    """`fn(budget)` timed at the box's full thread count (the reported baseline: the most favourable for the reference)
+    and, beside it, under the reference's own 16-thread cap when the box has more cores."""
+    full = fn(budget_s)
+    if full is not None and full.get("kind") == "reference" and torch.get_num_threads() > REFERENCE_THREAD_CAP:
+        with _threads(REFERENCE_THREAD_CAP):
+            capped = fn(max(1.0, budget_s / 3))
+        if capped is not None:
+            full["capped"] = {k: capped[k] for k in ("value", "unit", "cores", "ms_per_step") if k in capped}
+            full["capped"]["note"] = "same sample under the reference's own thread cap (MinkowskiEngine/__init__.py:34-46)"
+    return full
 
 
 def cpu_baseline(coords, feats, kernel, budget_s):
@@ -223,7 +263,7 @@ def kernel_table(timer, steps):
 
 
 def run_timed(step, args, dist_utils, MEB, dev, timers_in_blocks=True):
-    """-> (seconds of the fastest K-step block [max over ranks], every block's seconds, KernelTimer of ALL timed
+    """-> (seconds of the MEDIAN K-step block [max over ranks], every block's seconds, KernelTimer of ALL timed
     blocks, number of timed steps).  Each block: barrier + synchronize | K steps | synchronize + barrier.
     timers_in_blocks=False (host-bound loops: a new scene every step): the per-launch HIP events — two event records
     per convolution launch, ~1 ms of host time per MinkUNet step — stay out of the timed blocks and the kernel table
@@ -256,14 +296,16 @@ def run_timed(step, args, dist_utils, MEB, dev, timers_in_blocks=True):
         total += elapsed
         if (total >= args.min_time and len(blocks) >= args.min_blocks) or len(blocks) >= args.max_blocks:
             break
-    return min(blocks), blocks, timer, args.steps * (len(blocks) if timers_in_blocks else 1)
+    srt = sorted(blocks)
+    median = srt[(len(srt) - 1) // 2]      # lower median: a measured block, never an interpolation
+    return median, blocks, timer, args.steps * (len(blocks) if timers_in_blocks else 1)
 
 
 def roofline_entry(kernel, flops, compulsory_bytes, avg_ms, bf16, traffic, traffic_src, split=False):
     """the roof is chosen by the launch's arithmetic intensity on its COMPULSORY bytes.
-    split: an fp32 workload computed by k_conv_tile_f32x3 — `peak` stays the fp32 MFMA peak (the matrix peak of the
-    precision the workload is quoted in, and the line the earlier rounds are compared on); the ceiling of the pipe that
-    kernel actually issues to (six bf16 MFMAs per fp32 product block) is reported next to it."""
+    split: an fp32 workload computed by k_conv_tile_f32x3 — `peak` / `frac` are those of the pipe the kernel issues to
+    (six bf16 MFMAs per fp32 product block: 2500 / 6 TFLOP/s); the fraction of the fp32 MFMA peak (the denominator of
+    rounds 1 and 2) is reported next to it."""
     peak_t = PEAK_BF16_MATRIX_TFLOPS if bf16 else PEAK_F32_MATRIX_TFLOPS
     ridge = RIDGE_BF16 if bf16 else RIDGE_F32
     intensity = flops / compulsory_bytes
@@ -280,11 +322,17 @@ def roofline_entry(kernel, flops, compulsory_bytes, avg_ms, bf16, traffic, traff
         r.update({"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                   "frac": round(gbs / PEAK_HBM_GBS, 4)})
     if split:
+        # the kernel issues to the bf16 matrix pipe, six MFMAs per fp32 product block: THAT pipe's ceiling for this
+        # arithmetic (2500 / 6 TFLOP/s of fp32-grade products) is the roof `frac` is quoted against; the fraction of
+        # the fp32-MFMA peak (the round-1 / round-2 denominator, which this kernel can exceed) stays beside it
         pipe_peak = PEAK_BF16_MATRIX_TFLOPS / 6.0
         r["pipe"] = ("bf16 matrix pipe: fp32 operands split exactly into three bf16 terms, six v_mfma_f32_16x16x32_bf16 "
                      "per product block, fp32 accumulation (fp32-grade results, tests/test_gpu_conv.py)")
         r["peak_of_pipe"] = round(pipe_peak, 1)
         r["frac_of_pipe"] = round(tflops / pipe_peak, 4)
+        r["frac_of_fp32_mfma_peak"] = round(tflops / PEAK_F32_MATRIX_TFLOPS, 4)
+        if r["bound"] == "mfma":
+            r.update({"peak": round(pipe_peak, 1), "frac": r["frac_of_pipe"]})
     r["traffic"] = traffic
     r["traffic_note"] = ("HBM-side bytes per launch (FETCH_SIZE x2 + WRITE_SIZE) — a CITED constant from the committed "
                          f"rocprofv3 --pmc passes ({traffic_src}), not measured in this run" if traffic is not None else
@@ -300,6 +348,7 @@ def bench_conv(args, ME, MEB, dist_utils, rank, world, dev, startup):
         D, n, extent, cin, cout = 3, args.points or 100000, args.extent, args.cin or 64, args.cout or 128
         cfg, ext_s = "BASELINE configs[1]", f"[0,{args.extent})^3"
     K = 3 ** D
+    n = rank_points(n, rank, world, args.imbalance)
     coords = make_scene(n, extent, seed=rank, D=D)            # one independent scene per rank
     g = torch.Generator().manual_seed(1000 + rank)
     feats = torch.rand(n, cin, generator=g)
@@ -376,11 +425,13 @@ def bench_conv(args, ME, MEB, dist_utils, rank, world, dev, startup):
                    "parallelism": f"scene-sharded dp{world}" + (
                        f", torch DDP over {dist_utils.backend_name()} (gradient buckets overlapped with backward)"
                        if world > 1 else ""),
+                   "imbalance": bool(args.imbalance and world > 1),
                    "oversubscribed": world > max(1, dist_utils.visible_gpus())},
         "timing": {"blocks": len(blocks), "steps_per_block": args.steps,
                    "blocks_ms_per_step": [round(b / args.steps * 1e3, 4) for b in blocks],
                    "timed_region_s": round(sum(blocks), 4),
-                   "reported": "fastest block (max over ranks inside each block)"},
+                   "fastest_block_ms_per_step": round(min(blocks) / args.steps * 1e3, 4),
+                   "reported": "median block (max over ranks inside each block)"},
         "roofline": roofline_entry(f"{kname}<{nc},{kc}> (forward)", flops_per_launch,
                                    compulsory, kernels["conv_forward"]["avg_ms"], bf16, traffic, traffic_src, split),
         "kernels": kernels,
@@ -397,7 +448,8 @@ def bench_conv(args, ME, MEB, dist_utils, rank, world, dev, startup):
         "cold": cold,
     }
     if world == 1 and args.cpu_budget > 0:      # the reference CPU path is fp32 whatever our feature dtype
-        line["cpu_baseline"] = cpu_baseline(coords, feats, conv.kernel.detach().float().cpu(), args.cpu_budget)
+        w_cpu = conv.kernel.detach().float().cpu()
+        line["cpu_baseline"] = cpu_baseline_both(lambda b: cpu_baseline(coords, feats, w_cpu, b), args.cpu_budget)
         line["speedup_vs_cpu_baseline"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
     else:
         line["cpu_baseline"] = None
@@ -407,7 +459,7 @@ def bench_conv(args, ME, MEB, dist_utils, rank, world, dev, startup):
 def bench_minkunet(args, ME, MEB, dist_utils, rank, world, dev, startup):
     sys.path.insert(0, os.path.join(ROOT, "examples"))
     import minkunet as MU
-    n = args.points or 200000
+    n = rank_points(args.points or 200000, rank, world, args.imbalance)
     coords = MU.synthetic_scene(n, seed=rank)
     n = coords.shape[0]
     g = torch.Generator().manual_seed(1000 + rank)
@@ -510,11 +562,13 @@ def bench_minkunet(args, ME, MEB, dist_utils, rank, world, dev, startup):
                        f", torch DDP over {dist_utils.backend_name()} (25 MB gradient buckets overlapped with backward)"
                        + (", MinkowskiSyncBatchNorm" if args.sync_bn else ", per-rank batch norm") if world > 1 else ""),
                    "hip_graph": graphed,
+                   "imbalance": bool(args.imbalance and world > 1),
                    "oversubscribed": world > max(1, dist_utils.visible_gpus())},
         "timing": {"blocks": len(blocks), "steps_per_block": args.steps,
                    "blocks_ms_per_step": [round(b / args.steps * 1e3, 3) for b in blocks],
                    "timed_region_s": round(sum(blocks), 4),
-                   "reported": "fastest block (max over ranks inside each block)" + ("" if args.scenes == "cached" else
+                   "fastest_block_ms_per_step": round(min(blocks) / args.steps * 1e3, 3),
+                   "reported": "median block (max over ranks inside each block)" + ("" if args.scenes == "cached" else
                                 "; per-kernel HIP events recorded in one extra block outside the timed region")},
         "roofline": {"bound": "mfma", "kernel": "all convolution launches of a step (k_conv_tile_* forward + dgrad, "
                                                 "k_wgrad_*); HIP-event timed" + (" in a separate eager pass: the timed "
@@ -529,12 +583,54 @@ def bench_minkunet(args, ME, MEB, dist_utils, rank, world, dev, startup):
         "cold_ms": round(cold_ms, 2),
     }
     if world == 1 and args.cpu_budget > 0 and specs:
-        line["cpu_baseline"] = cpu_baseline_minkunet(coords, specs, args.cpu_budget)
+        line["cpu_baseline"] = cpu_baseline_both(lambda b: cpu_baseline_minkunet(coords, specs, b), args.cpu_budget) \
+            if args.cpu_capped else cpu_baseline_minkunet(coords, specs, args.cpu_budget)
         if line["cpu_baseline"]:
             line["speedup_vs_cpu_baseline"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
     else:
         line["cpu_baseline"] = None
     return line
+
+
+def extra_workloads(args, ME, MEB, dist_utils, rank, world, dev, startup):
+    """The other single-GPU BASELINE configurations, measured in the same process right after the headline workload
+    and reported as compact entries (their full lines: `python bench.py --workload ...`): configs[2] MinkUNet34C bf16 on
+    the 200k-voxel scene, configs[4] the 4-D convolution.  Each entry carries its own roofline and its own
+    reference-CPU baseline; short blocks (the driver's run has to stay within a few minutes)."""
+    out = {}
+    plan = (("minkunet34c_bf16_200k", dict(workload="minkunet", dtype="bf16", steps=5, warmup=2, min_time=0.15,
+                                            cpu_budget=min(args.cpu_budget, 1.0))),
+            ("conv4d_f32_400k", dict(workload="conv4d", dtype="f32", steps=10, warmup=3, min_time=0.1,
+                                     cpu_budget=min(args.cpu_budget, 4.0))))
+    for name, over in plan:
+        a = argparse.Namespace(**vars(args))
+        for k, v in over.items():
+            setattr(a, k, v)
+        a.points = a.cin = a.cout = 0
+        a.scenes, a.graph, a.sync_bn, a.imbalance = "cached", False, False, False
+        t0 = time.perf_counter()
+        try:
+            full = (bench_minkunet if a.workload == "minkunet" else bench_conv)(a, ME, MEB, dist_utils, rank, world, dev,
+                                                                               startup)
+        except Exception as e:  # noqa: BLE001  (the headline line must survive a failure here)
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+            continue
+        finally:
+            torch.cuda.empty_cache()
+        if full is None:
+            continue
+        keep = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "roofline", "cpu_baseline",
+                "speedup_vs_cpu_baseline", "cold_ms")
+        ent = {k: full[k] for k in keep if k in full}
+        ent["config"] = {"workload": full["config"]["workload"]}
+        ent["kernels"] = {k: {"avg_ms": v["avg_ms"], "tflops": v["tflops"]} for k, v in full.get("kernels", {}).items()}
+        if "cold" in full and full["cold"]:
+            ent["cold"] = {k: full["cold"][k] for k in ("insert_ms", "kernel_map_ms", "plans_ms", "kernel_map_GBs")
+                           if k in full["cold"]}
+        ent["blocks_ms_per_step"] = full["timing"]["blocks_ms_per_step"]
+        ent["wall_s"] = round(time.perf_counter() - t0, 1)
+        out[name] = ent
+    return out
 
 
 def capture_step(step):
@@ -577,6 +673,16 @@ def main():
                     help="minkunet: torch.nn.CrossEntropyLoss instead of examples/minkunet.py::cross_entropy (same math)")
     ap.add_argument("--sync-bn", action="store_true", help="minkunet, N > 1: MinkowskiSyncBatchNorm (reference recipe)")
     ap.add_argument("--graph", action="store_true", help="minkunet: replay the step from a captured hipGraph")
+    ap.add_argument("--extra-workloads", choices=("auto", "on", "off"), default="auto",
+                    help="append compact entries for BASELINE configs[2] (MinkUNet34C bf16 @200k) and configs[4] (4-D "
+                         "conv) under `workloads` (auto: with the default single-GPU headline run only)")
+    ap.add_argument("--cpu-capped", action="store_true",
+                    help="minkunet: also time the reference CPU layers under its own 16-thread cap (doubles the CPU time)")
+    ap.add_argument("--imbalance", action="store_true",
+                    help="N > 1: ranks get scenes of different sizes, 0.75x .. 1.25x the nominal voxel count (real scans "
+                         "differ in size: the scaling risk SURVEY 8(e) names); value still counts the voxels of all ranks")
+    ap.add_argument("--debug-conv-variant", type=int, default=0,
+                    help="kernel-selection switch of csrc/me_amd_debug.h (tuning scripts; 0 = shipped kernels)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -610,8 +716,14 @@ def main():
     startup = {"import_ms": round((t_a - t_start) * 1e3, 1), "dlopen_libme_amd_ms": round((t_b - t_a) * 1e3, 1),
                "device_context_ms": round((t_c - t_b) * 1e3, 1), "first_kernel_ms": round((t_d - t_c) * 1e3, 1)}
 
+    if args.debug_conv_variant:
+        _lib.check(lib.me_debug_set_conv_variant(args.debug_conv_variant))
     fn = bench_minkunet if args.workload == "minkunet" else bench_conv
     line = fn(args, ME, MEB, dist_utils, rank, world, dev, startup)
+    default_headline = (args.workload == "conv3d" and args.dtype == "f32" and world == 1 and not args.points and
+                        not args.cin and not args.cout and args.extent == 70)
+    if args.extra_workloads == "on" or (args.extra_workloads == "auto" and default_headline):
+        line["workloads"] = extra_workloads(args, ME, MEB, dist_utils, rank, world, dev, startup)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

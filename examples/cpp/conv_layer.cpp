@@ -73,7 +73,7 @@ static Plan build_plan(const int32_t *tbl, int64_t n_tgt, int64_t volume, int64_
   p.src = dev_alloc<int32_t>(16 * groups);
   p.dst = dev_alloc<int32_t>(16 * groups);
   p.desc = dev_alloc<int32_t>(2 * groups);
-  p.bptr = dev_alloc<int32_t>(2 * tiles + 1);
+  p.bptr = dev_alloc<int32_t>(me_plan_tile_bptr_elems(n_tgt, p.tile_rows));
   p.gptr = dev_alloc<int32_t>(tiles * volume + 1);
   const int64_t wsb = me_plan_workspace_bytes(n_tgt, volume, p.tile_rows);
   char *ws = dev_alloc<char>(wsb);

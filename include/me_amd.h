@@ -42,6 +42,12 @@ typedef struct me_region {
 } me_region;
 
 /* ---- library ------------------------------------------------------------------------------- */
+/* 100 * major + 10 * minor.  Changelog:
+ *   1.0 (100)  round 1: coordinate maps, kernel maps, tile plans, fp32 / bf16 convolution, pooling
+ *   1.1        round 2: tile_bptr_dev grew to 2 * num_tiles + 1 int32 (dispatch order behind the batch ranges) — an
+ *              ABI change without a size argument; LDS-bucketed kernel-map build; split fp32 kernels
+ *   1.2 (120)  round 3: me_plan_tile_bptr_elems sizes that buffer; me_debug_* hooks left this header
+ *              (csrc/me_amd_debug.h: tests / tuning only) */
 int me_version(void);
 const char *me_last_error(void);
 /* kernel volume of a region: src/kernel_region.hpp:250-270 (set_volume) */
@@ -198,6 +204,10 @@ int me_kernel_map_transpose_ordered(const int32_t *in_pairs_dev, const int32_t *
 #define ME_MAX_TILE_ROWS 256
 #define ME_MAX_BATCH_GROUPS 4
 int64_t me_plan_num_tiles(int64_t n_tgt, int32_t tile_rows);
+/* int32 elements of tile_bptr_dev: 2 * num_tiles + 1 since ABI 1.2 (the tiles' batch ranges, then their dispatch
+ * order).  Size the buffer with this call, not with num_tiles + 1 (the ABI 1.0 size): me_plan_build writes and every
+ * me_conv_target_* reads the dispatch order behind the ranges. */
+int64_t me_plan_tile_bptr_elems(int64_t n_tgt, int32_t tile_rows);
 /* upper bound on the number of groups (and of batches) for a table with n_pairs valid entries; includes the four
  * groups (64 slots) that me_plan_build fills BEHIND the last group of the plan with {source row 0, dummy target row}:
  * the convolution kernels read the 64-slot index window of a batch to its end without clamping.  plan_src_dev /
@@ -214,7 +224,7 @@ int64_t me_plan_workspace_bytes(int64_t n_tgt, int64_t volume, int32_t tile_rows
  *                                                the dummy row `tile_rows`; the global target row of
  *                                                (tile t, local row d) is order[t * tile_rows + d]
  *   batch_desc_dev int32 [2 * max_groups]  (out) per batch {first group, (k << 8) | number of groups}
- *   tile_bptr_dev  int32 [2 * num_tiles + 1] (out) [0, num_tiles]: batch range of each tile; behind it the DISPATCH
+ *   tile_bptr_dev  int32 [me_plan_tile_bptr_elems = 2 * num_tiles + 1] (out) [0, num_tiles]: batch range of each tile; behind it the DISPATCH
  *                  ORDER of the tiles (a permutation, heaviest tile first): workgroup b of the convolution kernels
  *                  takes tile tile_bptr[num_tiles + 1 + b]
  *   item_gptr_dev  int32 [num_tiles * volume + 1] (out) first group of each (tile, k) item
@@ -257,11 +267,6 @@ int me_conv_target_f32(const float *src_feat_dev, int64_t n_src, int32_t c_src,
 int me_conv_plan_config(int64_t n_tgt, int64_t volume, int64_t n_pairs, int32_t c_src, int32_t c_dst,
                         int32_t *tile_rows, int32_t *batch_groups);
 
-/* Tuning / ablation switch for me_conv_target_f32 (0 = shipped configuration; see conv.hip). */
-void me_debug_set_conv_variant(int variant);
-/* Phase cycle counters of the instrumented build (variant 256): barrier A, stage write + wait, barrier B, load
- * issue, multiply, prologue, epilogue (s_memtime cycles summed over wave 0 of every workgroup), batches. */
-int me_debug_conv_timing(uint64_t *out8, int32_t reset);
 /* wt[k, j, i] = w[k, i, j] */
 int me_transpose_kernel_f32(const float *w_dev, int64_t volume, int32_t c_in, int32_t c_out,
                             float *wt_dev, void *stream);
@@ -280,12 +285,6 @@ int me_conv_wgrad_f32(const float *x_dev, int64_t n_in /* rows of x */, int32_t 
                       const int64_t *k_offsets /* host */, const int64_t *k_offsets_dev,
                       int64_t volume, float *grad_w_dev, void *workspace_dev,
                       int64_t workspace_bytes, void *stream);
-/* Tuning switch for the weight-gradient kernels: depth 4 / 8 = prefetch ring depth of k_wgrad_f32 (steps of 4
- * pairs); depth -1 = bf16 rows through the fp32-MFMA kernel instead of k_wgrad_bf16; depth -2 = fp32 rows through
- * the LDS-staged kernel; wgs_per_cu = resident workgroups per CU the ranges are sized for; 0 = shipped defaults. */
-void me_debug_set_wgrad_config(int depth, int wgs_per_cu);
-/* 0 (default): ranges of the same list fraction go to the same XCD (WgRangeOrder, conv.hip); -1: launch order */
-void me_debug_set_wgrad_order(int mode);
 
 /* ---- bf16 features (fp32 accumulation) --------------------------------------------------------------
  * The reference computes in float / double only (AT_DISPATCH_FLOATING_TYPES, src/convolution_gpu.cu:137-155);
@@ -352,8 +351,6 @@ int me_conv_gather_bf16(const uint16_t *src_feat_dev, int64_t n_src, int32_t c_s
  * Needs c_src % 8 == 0 (me_conv_f32x3_supported); plans come from me_plan_build with the geometry of
  * me_conv_plan_config_f32x3; weights packed by me_conv_pack_weights_f32x3 (three bf16 planes). */
 int32_t me_conv_f32x3_supported(int32_t c_src, int32_t c_dst);
-/* phase counters of the instrumented build (me_debug_set_conv_variant(256)); layout as me_debug_conv_timing */
-int me_debug_conv_timing_f32x3(uint64_t *out8, int32_t reset);
 int me_conv_plan_config_f32x3(int64_t n_tgt, int64_t volume, int64_t n_pairs, int32_t c_src, int32_t c_dst,
                               int32_t *tile_rows, int32_t *batch_groups);
 int64_t me_conv_packed_weight_elems_f32x3(int64_t volume, int32_t c_src, int32_t c_dst); /* bf16 elements */

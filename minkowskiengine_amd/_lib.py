@@ -9,7 +9,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libme_amd.so")
+# (ME_AMD_LIB_TAG: an A/B build made by build.py under the same tag — tuning scripts only)
+_TAG = os.environ.get("ME_AMD_LIB_TAG", "")
+LIB_PATH = os.path.join(_HERE, f"libme_amd_{_TAG}.so" if _TAG else "libme_amd.so")
 
 ME_MAX_DIM = 7
 ME_MAX_TILE_ROWS = 256
@@ -75,6 +77,7 @@ SIGNATURES = {
     "me_kernel_map_compact": (ctypes.c_int, [c_vp, c_i64, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "me_kernel_map_transpose": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp]),
     "me_plan_num_tiles": (c_i64, [c_i64, c_i32]),
+    "me_plan_tile_bptr_elems": (c_i64, [c_i64, c_i32]),
     "me_plan_max_groups": (c_i64, [c_i64, c_i64, c_i64, c_i32]),
     "me_plan_workspace_bytes": (c_i64, [c_i64, c_i64, c_i32]),
     "me_plan_build": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
@@ -84,14 +87,10 @@ SIGNATURES = {
     "me_conv_target_f32": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp,
                                           c_vp, c_i64, c_i32, c_i32, c_vp]),
     "me_conv_plan_config": (ctypes.c_int, [c_i64, c_i64, c_i64, c_i32, c_i32, _P_I32, _P_I32]),
-    "me_debug_set_conv_variant": (None, [ctypes.c_int]),
-    "me_debug_conv_timing": (ctypes.c_int, [c_vp, c_i32]),
     "me_transpose_kernel_f32": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
     "me_conv_wgrad_workspace_bytes": (c_i64, [_P_I64, c_i64, c_i32, c_i32]),
     "me_conv_wgrad_f32": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, _P_I64, c_vp, c_i64, c_vp,
                                          c_vp, c_i64, c_vp]),
-    "me_debug_set_wgrad_config": (None, [ctypes.c_int, ctypes.c_int]),
-    "me_debug_set_wgrad_order": (None, [ctypes.c_int]),
     "me_bn_workspace_bytes": (c_i64, [c_i64, c_i32]),
     "me_bn_stats": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i32, ctypes.c_float, ctypes.c_float, c_vp, c_vp, c_vp, c_vp,
                                    c_vp, c_vp, c_i64, c_vp]),
@@ -102,7 +101,6 @@ SIGNATURES = {
     "me_coords_quantize_labels": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp]),
     "me_segment_sum_f32": (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp]),
     "me_conv_f32x3_supported": (c_i32, [c_i32, c_i32]),
-    "me_debug_conv_timing_f32x3": (ctypes.c_int, [c_vp, c_i32]),
     "me_conv_plan_config_f32x3": (ctypes.c_int, [c_i64, c_i64, c_i64, c_i32, c_i32, _P_I32, _P_I32]),
     "me_conv_packed_weight_elems_f32x3": (c_i64, [c_i64, c_i32, c_i32]),
     "me_conv_pack_weights_f32x3": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
@@ -141,6 +139,16 @@ SIGNATURES = {
                                                   c_i64, c_vp, c_vp, c_vp]),
 }
 
+# test / tuning hooks (csrc/me_amd_debug.h): exported by the library, not part of include/me_amd.h
+DEBUG_SIGNATURES = {
+    "me_debug_variants_compiled": (c_i32, []),
+    "me_debug_set_conv_variant": (ctypes.c_int, [ctypes.c_int]),
+    "me_debug_conv_timing": (ctypes.c_int, [c_vp, c_i32]),
+    "me_debug_conv_timing_f32x3": (ctypes.c_int, [c_vp, c_i32]),
+    "me_debug_set_wgrad_config": (None, [ctypes.c_int, ctypes.c_int]),
+    "me_debug_set_wgrad_order": (None, [ctypes.c_int]),
+}
+
 _lib = None
 
 
@@ -155,12 +163,11 @@ def load():
             "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
             "There is no CPU fallback for the MI355X path.")
     lib = ctypes.CDLL(LIB_PATH)
-    for name, (restype, argtypes) in SIGNATURES.items():
-        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
-        fn.restype = restype
-        fn.argtypes = argtypes
-    if os.environ.get("ME_AMD_CONV_VARIANT"):      # kernel-selection experiments (scripts/)
-        lib.me_debug_set_conv_variant(int(os.environ["ME_AMD_CONV_VARIANT"]))
+    for table in (SIGNATURES, DEBUG_SIGNATURES):
+        for name, (restype, argtypes) in table.items():
+            fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+            fn.restype = restype
+            fn.argtypes = argtypes
     _lib = lib
     return lib
 

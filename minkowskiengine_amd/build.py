@@ -7,30 +7,58 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OUT = os.path.join(HERE, "libme_amd.so")
+# ME_AMD_LIB_TAG=x: a second library libme_amd_x.so (own object cache) next to the default one — A/B builds with
+# ME_AMD_EXTRA_HIPCC_FLAGS for the tuning scripts; _lib.py loads the tagged library when the variable is set
+_TAG = os.environ.get("ME_AMD_LIB_TAG", "")
+OUT = os.path.join(HERE, f"libme_amd_{_TAG}.so" if _TAG else "libme_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function",
-         "-Wno-unused-lambda-capture"]
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+          "-Wno-unused-lambda-capture"]
 
 
 def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
-def _stale():
-    if not os.path.exists(OUT):
-        return True
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.hpp")) + [os.path.join(HERE, "..", "include", "me_amd.h")]
-    return any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps)
+OBJ_DIR = os.path.join(HERE, "csrc", "build_" + _TAG if _TAG else "build")   # per-file objects (git-ignored): only edited files are recompiled
 
 
-def build(force=False, verbose=False):
-    if not force and not _stale():
-        return OUT
-    cmd = [HIPCC] + FLAGS + sources() + ["-o", OUT]
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
+def _headers():
+    return glob.glob(os.path.join(CSRC, "*.hpp")) + [os.path.join(HERE, "..", "include", "me_amd.h")]
+
+
+def _compile_one(src, extra, verbose):
+    obj = os.path.join(OBJ_DIR, os.path.splitext(os.path.basename(src))[0] + ".o")
+    stamp = obj + ".flags"
+    flags = " ".join(CFLAGS + extra)
+    fresh = (os.path.exists(obj) and os.path.exists(stamp) and open(stamp).read() == flags and
+             all(os.path.getmtime(d) <= os.path.getmtime(obj) for d in [src] + _headers()))
+    if not fresh:
+        cmd = [HIPCC] + CFLAGS + extra + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+        with open(stamp, "w") as f:
+            f.write(flags)
+    return obj
+
+
+def build(force=False, verbose=False, extra_flags=()):
+    """Compile every csrc/*.hip to its own object (in parallel, cached per file) and link libme_amd.so.
+    `extra_flags`: e.g. ("-DME_DEBUG_VARIANTS",) for the tuning / ablation instantiations (scripts/ only)."""
+    extra = list(extra_flags) + os.environ.get("ME_AMD_EXTRA_HIPCC_FLAGS", "").split()
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    if force:
+        for f in glob.glob(os.path.join(OBJ_DIR, "*.o")):
+            os.remove(f)
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(lambda s: _compile_one(s, extra, verbose), sources()))
+    if force or not os.path.exists(OUT) or any(os.path.getmtime(o) > os.path.getmtime(OUT) for o in objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", OUT]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
     return OUT
 
 

@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include "../../include/me_amd.h"
+#include "me_amd_debug.h"
 
 namespace me {
 

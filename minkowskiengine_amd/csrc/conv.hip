@@ -1396,7 +1396,7 @@ __global__ __launch_bounds__(256, 3) void k_wgrad_f32x3(const float *__restrict_
       const int pc = idx % (COB / 8);
       const bool ok = row < cnt && cog + pc * 8 < c_out;
       u32x4 p1, p2, p3;
-      split3(rd[j][0], rd[j][1], p1, p2, p3);
+      split3<true>(rd[j][0], rd[j][1], p1, p2, p3);   // dy is the "weight side" of the non-finite rule (conv_common.hpp)
       __bf16 *o = s_d + row * DLD + pc * 8;
       *reinterpret_cast<u32x4 *>(o) = ok ? p1 : zero;
       *reinterpret_cast<u32x4 *>(o + DPL) = ok ? p2 : zero;
@@ -2288,6 +2288,7 @@ int me_conv_target_f32(const float *src, int64_t n_src, int32_t c_src, const flo
       batch_groups, stream
   // 32-bit byte offsets with a 24-bit row multiply need a source matrix below 4 GiB (variant 6: 64-bit addresses)
   const bool small = n_src > 0 && n_src < (1ll << 24) && n_src * c_src * 4 < (1ll << 32) && g_conv_variant != 6;
+#ifdef ME_DEBUG_VARIANTS   // experiments and timing ablations (some with invalid results): tuning builds only
   if (small) {
     const ConvDmaShape ds = conv_dma_shape(c_src, c_dst);
 #define ME_DMA_ARGS src, c_src, wp, c_dst, plan_src, plan_dst, batch_desc, tile_bptr, order, dst, n_tgt, tile_rows, \
@@ -2316,6 +2317,7 @@ int me_conv_target_f32(const float *src, int64_t n_src, int32_t c_src, const flo
       default: break;
     }
   }
+#endif
 #define ME_CONV_CASE(NCV, KCV) return launch_conv_tile<NCV, KCV, 0>(ME_CONV_ARGS, small)
   if (v.nc == 96) {
     if (v.kc == 96) ME_CONV_CASE(96, 96);
@@ -2337,7 +2339,26 @@ int me_conv_target_f32(const float *src, int64_t n_src, int32_t c_src, const flo
 #undef ME_CONV_ARGS
 }
 
-void me_debug_set_conv_variant(int variant) { g_conv_variant = variant; }
+int32_t me_debug_variants_compiled(void) {
+#ifdef ME_DEBUG_VARIANTS
+  return 1;
+#else
+  return 0;
+#endif
+}
+
+// The default build holds the shipped kernels and the alternates whose results are VALID (the bit-identity tests
+// compare them): 6 = 64-bit gather addresses, 7 = no batch fusion, 9 = 32-wide passes for 96 channels, 30 / 31 =
+// ping-pong / four-multiplier split kernels.  Everything else (phase counters, timing ablations with invalid
+// results, the LDS-DMA family) exists only in a -DME_DEBUG_VARIANTS build (scripts/) and is refused otherwise.
+int me_debug_set_conv_variant(int variant) {
+#ifndef ME_DEBUG_VARIANTS
+  const bool ok = variant == 0 || variant == 6 || variant == 7 || variant == 9 || variant == 30 || variant == 31;
+  ME_CHECK(ok, "this conv variant needs a -DME_DEBUG_VARIANTS build of libme_amd.so (tuning / ablation kernels)");
+#endif
+  g_conv_variant = variant;
+  return 0;
+}
 
 int me_debug_conv_timing(uint64_t *out8, int32_t reset) {
   unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};

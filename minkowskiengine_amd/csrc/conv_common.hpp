@@ -27,7 +27,20 @@ static inline int device_cu_count() {
 }
 
 // eight fp32 values -> the three bf16 planes of the exact split (conv_f32x3.hip: a = a1 + a2 + a3 with
-// a1 = the upper 16 bits of a's encoding, a2 = the upper 16 bits of a - a1, a3 = a - a1 - a2; all exact)
+// a1 = the upper 16 bits of a's encoding, a2 = the upper 16 bits of a - a1, a3 = a - a1 - a2; all exact).
+//
+// Non-finite inputs.  a = +-inf or NaN makes a - a1 a NaN, and the six products would turn every infinity into NaN
+// where fp32 arithmetic (the reference's sgemm, src/math_functions_cpu.cpp:29-46) keeps it.  The kept products are
+// (row plane, weight plane) = (1,1) (1,2) (2,1) (1,3) (2,2) (3,1): a value in plane 3 meets ONLY plane 1 of the other
+// operand, which is zero only for |x| < 2^-126.  So a non-finite ROW value (WEIGHT_SIDE = false: gathered features,
+// upstream gradients, the x rows of the weight gradient) is stored as planes (0, 0, a): its one product a * w1 is
+// +-inf with the sign of a * w (NaN for NaN, or for w = 0 — exactly fp32 semantics).  A non-finite value on the
+// WEIGHT side (packed weights, the dy rows of the weight gradient) becomes NaN in all three planes: every output it
+// reaches is NaN (fp32 would keep the sign of an infinite weight — the one divergence left; inf * inf must not fall
+// into the dropped (3,3) product and vanish).  Cost on the fast path: the second remainders are NaN exactly for
+// non-finite inputs, so the OR of their eight encodings is tested once per piece (an all-ones exponent; a false
+// positive from OR-ed exponents only takes the slow path, whose result is the same).
+template <bool WEIGHT_SIDE = false>
 __device__ __forceinline__ void split3(const f32x4 &lo, const f32x4 &hi, u32x4 &p1, u32x4 &p2, u32x4 &p3) {
   float a[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
   uint32_t b1[8], b2[8], b3[8];
@@ -38,6 +51,27 @@ __device__ __forceinline__ void split3(const f32x4 &lo, const f32x4 &hi, u32x4 &
     b2[e] = __float_as_uint(r);
     b3[e] = __float_as_uint(r - __uint_as_float(b2[e] & 0xffff0000u));
   }
+#ifndef ME_SPLIT_NO_NONFINITE
+  const uint32_t any = (b3[0] | b3[1] | b3[2]) | (b3[3] | b3[4] | b3[5]) | (b3[6] | b3[7]);
+  if (__builtin_expect(__any((any & 0x7f800000u) == 0x7f800000u), 0)) {   // wave-uniform, rare
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const uint32_t bits = __float_as_uint(a[e]);
+      const bool nonfinite = (bits & 0x7f800000u) == 0x7f800000u;
+      // the bf16 that stands for it: +-inf, or a quiet NaN (a payload in the low 16 bits must not truncate to inf)
+      const uint32_t t = (bits & 0xffff0000u) | ((bits & 0x007fffffu) ? 0x00400000u : 0u);
+      if (WEIGHT_SIDE) {
+        b1[e] = nonfinite ? 0x7fc00000u : b1[e];
+        b2[e] = nonfinite ? 0x7fc00000u : b2[e];
+        b3[e] = nonfinite ? 0x7fc00000u : b3[e];
+      } else {
+        b1[e] = nonfinite ? 0u : b1[e];
+        b2[e] = nonfinite ? 0u : b2[e];
+        b3[e] = nonfinite ? t : b3[e];
+      }
+    }
+  }
+#endif
   // upper halves of two encodings -> one dword (element 2j in the lower half)
 #pragma unroll
   for (int j = 0; j < 4; ++j) {

@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void k_pack_weights_f32x3(const float *__restr
     }
   }
   u32x4 p1, p2, p3;
-  split3(f32x4{val[0], val[1], val[2], val[3]}, f32x4{val[4], val[5], val[6], val[7]}, p1, p2, p3);
+  split3<true>(f32x4{val[0], val[1], val[2], val[3]}, f32x4{val[4], val[5], val[6], val[7]}, p1, p2, p3);
   const int64_t base = ((((k * nchunks + c) * ncb + cb) * 3) * KS + v) * 64 + lane;
   wp[base] = p1;
   wp[base + (int64_t)KS * 64] = p2;
@@ -983,6 +983,7 @@ static int launch_conv_tile_f32x3(const float *src, int c_src, const bf16x8 *wp,
         ws = small ? (exact ? &k_conv_tile_f32x3_ws<NC, KC, true, true> : &k_conv_tile_f32x3_ws<NC, KC, false, true>)
                    : (exact ? &k_conv_tile_f32x3_ws<NC, KC, true, false> : &k_conv_tile_f32x3_ws<NC, KC, false, false>);
       }
+#ifdef ME_DEBUG_VARIANTS   // phase counters, priority A/B and timing ablations (results invalid): tuning builds only
       if constexpr (KC >= 64) {
         if (g_conv_variant == 257 && small && exact) {
           ws = &k_conv_tile_f32x3_ws<NC, KC, true, true, true>;
@@ -1005,6 +1006,7 @@ static int launch_conv_tile_f32x3(const float *src, int c_src, const bf16x8 *wp,
           wthreads = 512;
         }
       }
+#endif
       if (lds > 48 * 1024 && !ws_attr[wi]) {
         ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ws), hipFuncAttributeMaxDynamicSharedMemorySize,
                                    kLdsBudget));
@@ -1017,14 +1019,16 @@ static int launch_conv_tile_f32x3(const float *src, int c_src, const bf16x8 *wp,
       return 0;
     }
   }
-  constexpr bool kHasTimed = KC >= 64 && NC >= 64;   // instrumented build: the headline shapes only
   bool timed = false;
+#ifdef ME_DEBUG_VARIANTS
+  constexpr bool kHasTimed = KC >= 64 && NC >= 64;   // instrumented build: the headline shapes only
   if constexpr (kHasTimed) {
     if (g_conv_variant == 256 && small && exact) {
       fn = &k_conv_tile_f32x3<NC, KC, true, true, true>;
       timed = true;
     }
   }
+#endif
   static bool attr_set[5] = {false, false, false, false, false};  // per instantiation
   const int which = timed ? 4 : (small ? 2 : 0) + (exact ? 1 : 0);
   if (lds > 48 * 1024 && !attr_set[which]) {

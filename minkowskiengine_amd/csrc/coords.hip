@@ -1041,7 +1041,7 @@ using namespace me;
 
 extern "C" {
 
-int me_version(void) { return 100; }
+int me_version(void) { return 120; }   // 100 * major + 10 * minor: see the changelog in include/me_amd.h
 const char *me_last_error(void) { return g_last_error; }
 
 int64_t me_region_volume(const me_region *rg) {
@@ -1115,8 +1115,8 @@ int me_coords_insert_and_map_bbox(const int32_t *coords, int64_t n, int32_t ncol
   // supercell directory of the map's spatial index (me_spatial_index_build) without a synchronisation of its own
   uint32_t host_buf[1 + 2 * (ME_MAX_DIM + 1)];
   int32_t *bbox_dev = reinterpret_cast<int32_t *>(total + 1);   // (inside the 256-byte `total` slot)
+  int32_t init[2 * (ME_MAX_DIM + 1)];   // source of an asynchronous copy: must live until the synchronisation below
   if (bbox) {
-    int32_t init[2 * (ME_MAX_DIM + 1)];
     for (int d = 0; d < ncol; ++d) {
       init[d] = INT32_MAX;
       init[ncol + d] = INT32_MIN;
@@ -1330,6 +1330,10 @@ int me_kernel_map_transpose(const int32_t *in_pairs, const int32_t *out_pairs, c
 
 int64_t me_plan_num_tiles(int64_t n_tgt, int32_t tile_rows) {
   return tile_rows > 0 ? ceil_div(n_tgt, tile_rows) : -1;
+}
+int64_t me_plan_tile_bptr_elems(int64_t n_tgt, int32_t tile_rows) {
+  const int64_t t = me_plan_num_tiles(n_tgt, tile_rows);
+  return t < 0 ? -1 : 2 * t + 1;   // batch ranges [num_tiles + 1] + dispatch order [num_tiles]
 }
 int64_t me_plan_max_groups(int64_t n_tgt, int64_t volume, int64_t n_pairs, int32_t tile_rows) {
   const int64_t items = me_plan_num_tiles(n_tgt, tile_rows) * volume;

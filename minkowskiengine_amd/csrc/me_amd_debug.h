@@ -1,0 +1,35 @@
+/* Test and tuning hooks of libme_amd.so.  NOT part of the drop-in boundary (include/me_amd.h): these switches are
+ * process-global, not thread-safe, and exist so that tests/ can compare alternate kernels that must agree bit for
+ * bit (64-bit addresses, ping-pong vs wave-specialised split kernels, weight-gradient pipes) and scripts/ can time
+ * ablations.  A host integrator never calls them. */
+#ifndef ME_AMD_DEBUG_H
+#define ME_AMD_DEBUG_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* 1 when the library was built with -DME_DEBUG_VARIANTS (phase counters, timing ablations whose RESULTS ARE INVALID,
+ * the LDS-DMA experiment family); the default build does not contain those kernels. */
+int32_t me_debug_variants_compiled(void);
+/* Kernel selection for me_conv_target_* (0 = shipped).  Default build: 6 (64-bit gather addresses), 7 (no batch
+ * fusion), 9 (32-wide passes for 96 channels), 30 / 31 (ping-pong / four-multiplier split kernels) — all with valid,
+ * bit-identical results; any other code returns an error unless me_debug_variants_compiled(). */
+int me_debug_set_conv_variant(int variant);
+/* Phase cycle counters of the instrumented builds (variants 256 / 257, ME_DEBUG_VARIANTS only): barrier A, stage
+ * write + wait, barrier B, load issue, multiply, prologue, epilogue (s_memtime cycles summed over wave 0 of every
+ * workgroup), batches. */
+int me_debug_conv_timing(uint64_t *out8, int32_t reset);
+int me_debug_conv_timing_f32x3(uint64_t *out8, int32_t reset);
+/* Weight-gradient kernels: depth 4 / 8 = prefetch ring depth of k_wgrad_f32 (steps of 4 pairs); depth -1 = bf16 rows
+ * through the fp32-MFMA kernel instead of k_wgrad_bf16; -2 = fp32 rows through the LDS-staged kernel; -3 / -4 = fp32
+ * rows through the fp32-MFMA / the split kernel; wgs_per_cu = resident workgroups per CU the ranges are sized for;
+ * 0 = shipped defaults. */
+void me_debug_set_wgrad_config(int depth, int wgs_per_cu);
+/* 0 (default): ranges of the same list fraction go to the same XCD (WgRangeOrder, conv.hip); -1: launch order */
+void me_debug_set_wgrad_order(int mode);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

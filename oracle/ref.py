@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE ONLY — loader for the reference's own CPU extension (oracle/_ref/_C.so,
 built unmodified from /root/reference by oracle/build_ref.py).  The shared object travels to the GPU
-box; /root/reference itself does not, so only the compiled operators are used here (never the
-reference's Python package)."""
+box; /root/reference itself does not: bench.py and smoke() use only the compiled operators, and the one test that
+needs the reference's Python package on a GPU box finds the copy staged by oracle/stage_ref_package.py."""
 import importlib.machinery
 import importlib.util
 import os
@@ -127,7 +127,16 @@ class RefPool(RefConv):
 
 
 def reference_root():
-    return os.environ.get("ME_REFERENCE_ROOT", "/root/reference")
+    """Where the reference's Python package is: $ME_REFERENCE_ROOT, /root/reference (the authoring container), or the
+    copy staged in oracle/_ref/reference_tree by oracle/stage_ref_package.py (the GPU box: git-ignored scratch that
+    travels with the snapshot, like the compiled reference next to it)."""
+    env = os.environ.get("ME_REFERENCE_ROOT")
+    if env:
+        return env
+    if os.path.isdir("/root/reference/MinkowskiEngine"):
+        return "/root/reference"
+    staged = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "reference_tree")
+    return staged if os.path.isdir(os.path.join(staged, "MinkowskiEngine")) else "/root/reference"
 
 
 def package_available():

@@ -9,8 +9,8 @@ from minkowskiengine_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "me_amd.h")).read()
+def declared_symbols(path=("include", "me_amd.h")):
+    text = open(os.path.join(ROOT, *path)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(me_[a-z0-9_]+)\s*\(", text)))
 
@@ -33,6 +33,18 @@ def test_ctypes_prototypes_match_header():
     assert sorted(_lib.SIGNATURES) == declared_symbols()
     lib = _lib.load()
     assert lib.me_version() >= 100
+
+
+def test_debug_hooks_are_not_part_of_the_public_header():
+    """me_debug_* (process-global kernel-selection switches for tests/ and scripts/) live in csrc/me_amd_debug.h; the
+    drop-in boundary does not declare them, and the default build refuses result-invalidating variants."""
+    assert not [s for s in declared_symbols() if s.startswith("me_debug")]
+    assert sorted(_lib.DEBUG_SIGNATURES) == declared_symbols(("minkowskiengine_amd", "csrc", "me_amd_debug.h"))
+    lib = _lib.load()
+    if not lib.me_debug_variants_compiled():
+        for v in (16, 33, 38, 256, 257, 3000):
+            assert lib.me_debug_set_conv_variant(v) != 0
+        assert lib.me_debug_set_conv_variant(0) == 0
 
 
 def test_host_only_entry_points():

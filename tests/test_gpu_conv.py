@@ -97,7 +97,7 @@ def test_wide_address_kernels_match_the_default(device, dtype, n, extent, D, cin
     kernel = torch.rand(ks ** D, cin, cout, generator=g) - 0.5
     results = []
     for variant in (0, 6):
-        lib.me_debug_set_conv_variant(variant)
+        _lib.check(lib.me_debug_set_conv_variant(variant))
         try:
             conv = ME.MinkowskiConvolution(cin, cout, kernel_size=ks, stride=stride, dilation=dil, dimension=D)
             with torch.no_grad():
@@ -181,8 +181,10 @@ def test_lds_dma_tile_kernel_matches_the_oracle(device, monkeypatch, cin, cout, 
     monkeypatch.setattr(MEB, "_TILE_ORDER", tile_order)
     monkeypatch.setattr(MEB, "_TILE_ROWS", T)
     monkeypatch.setattr(MEB, "_BATCH_GROUPS", cap)
+    if not lib.me_debug_variants_compiled():
+        pytest.skip("the LDS-DMA experiment family is only in a -DME_DEBUG_VARIANTS build (scripts/build_debug.sh)")
     coords = make_cloud(5000, 18, 3, seed=cin + cout, batch=2, negative=True)
-    lib.me_debug_set_conv_variant(variant)
+    _lib.check(lib.me_debug_set_conv_variant(variant))
     try:
         conv, x, y, feats, gy = _run_layer(device, coords, cin, cout, 3)
     finally:
@@ -287,7 +289,7 @@ def test_wave_specialised_split_kernel_is_bit_identical(device, monkeypatch, n, 
     res = {}
     try:
         for variant in (0, 31, 30):      # shipped (eight multipliers on 128-column slabs), four multipliers, ping-pong
-            lib.me_debug_set_conv_variant(variant)
+            _lib.check(lib.me_debug_set_conv_variant(variant))
             y = MEB._conv_forward(x.to(device), w.to(device), km, "mfma")
             gi = MEB._conv_target(gy.to(device), w.to(device), km, "in", km.n_in, name="d", transposed=True)
             res[variant] = (y.clone(), gi.clone())
@@ -435,3 +437,72 @@ def test_config5_full_size(device):
     gi, gw = O.conv_backward(feats.numpy(), gy.numpy(), w, km, dtype=np.float32)
     assert_close(x.F.grad.cpu().numpy(), gi)
     assert_close(conv.kernel.grad.cpu().numpy(), gw)
+
+
+def _same_nonfinite(got, want, what):
+    """Element-wise class agreement for non-finite results: NaN where the reference is NaN, the same infinity where
+    it is infinite; finite elements within the 1e-4 bar."""
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    assert np.array_equal(np.isnan(got), np.isnan(want)), f"{what}: NaN positions differ"
+    inf = np.isinf(want)
+    assert np.array_equal(np.isinf(got), inf), f"{what}: infinity positions differ"
+    assert np.array_equal(got[inf], want[inf]), f"{what}: signs of infinities differ"
+    fin = np.isfinite(want)
+    assert_close(np.where(fin, got, 0.0), np.where(fin, want, 0.0), what=what)
+
+
+@pytest.mark.parametrize("pipe", ["bf16x6", "fp32_mfma"])
+@pytest.mark.parametrize("cin,cout", [(64, 128), (32, 64)])
+def test_nonfinite_and_tiny_inputs_follow_fp32_semantics(device, monkeypatch, pipe, cin, cout):
+    """+-inf / NaN / 1e-38 in the features and in the upstream gradient: the reference multiplies in fp32 (sgemm,
+    src/math_functions_cpu.cpp:29-46), where inf * w is +-inf (NaN for w = 0) and sums of opposite infinities are NaN.
+    The split kernels keep that (conv_common.hpp split3: a non-finite row value travels in the third bf16 plane alone),
+    including weights that are exact in bf16 (second / third plane zero) and exact zeros; the one documented divergence
+    — a non-finite WEIGHT-side value (weights; dy in the weight gradient) gives NaN where fp32 keeps an infinity's
+    sign — is pinned as 'non-finite wherever the reference is non-finite'."""
+    from minkowskiengine_amd import backend as MEB, _lib
+    lib = _lib.load()
+    monkeypatch.setattr(MEB, "_F32_SPLIT", pipe == "bf16x6")
+    lib.me_debug_set_wgrad_config(-4 if pipe == "bf16x6" else -3, 0)
+    try:
+        coords = make_cloud(3000, 14, 3, seed=cin, negative=True)
+        n = coords.shape[0]
+        mgr = MEB.CoordinateMapManagerGPU_c10()
+        key, _ = mgr.insert_and_map(coords.to(device), [1, 1, 1], "")
+        km = mgr._kernel_map(key, key, [3] * 3, [1] * 3, [1] * 3, MEB.RegionType.HYPER_CUBE, None, False, False)
+        g = torch.Generator().manual_seed(7)
+        x = torch.rand(n, cin, generator=g) - 0.5
+        w = torch.rand(27, cin, cout, generator=g) - 0.5
+        w[:, 3, :] = 1.0                 # exact in bf16: planes 2 and 3 of the split are zero
+        w[:, 4, ::2] = 0.0               # inf * 0 = NaN
+        w[:, 5, :] = -0.5
+        gy = torch.rand(n, cout, generator=g) - 0.5
+        inf = float("inf")
+        x[10, 3], x[11, 3], x[12, 4], x[13, 5], x[14, 7] = inf, -inf, inf, inf, float("nan")
+        x[15, 3], x[15, 5] = inf, inf    # +inf * 1 and +inf * -0.5 in one sum: NaN
+        x[20, :] = 1e-38                 # below 2^-100: the third plane may lose bits (absolute error < 2^-133)
+        x[21, 0] = 1e-38
+        gy[30, 2], gy[31, 9], gy[32, 1] = inf, -inf, float("nan")
+        _, okm = O.kernel_map(coords.numpy(), coords.numpy(), O.make_region(3, 3))
+        with np.errstate(invalid="ignore", over="ignore"):
+            want_y = O.conv_forward(x.numpy(), w.numpy(), okm, n)
+            want_gi, want_gw = O.conv_backward(x.numpy(), gy.numpy(), w.numpy(), okm)
+        y = MEB._conv_forward(x.to(device), w.to(device), km, "mfma")
+        gi, gw = MEB._conv_backward(x.to(device), gy.to(device), w.to(device), km, "mfma")
+        assert np.isnan(want_y).any() and np.isinf(want_y).any() and np.isfinite(want_y).mean() > 0.9
+        _same_nonfinite(y.cpu().numpy(), want_y, "forward")
+        _same_nonfinite(gi.cpu().numpy(), want_gi, "grad_in")
+        # weight gradient: x (row side) and dy (weight side) both carry non-finite values here
+        gw, want_gw = gw.cpu().numpy().astype(np.float64), np.asarray(want_gw, np.float64)
+        bad = ~np.isfinite(want_gw)
+        assert bad.any() and np.array_equal(~np.isfinite(gw), bad), "grad_kernel: non-finite positions differ"
+        assert_close(np.where(bad, 0.0, gw), np.where(bad, 0.0, want_gw), what="grad_kernel")
+        # a non-finite weight: every output it reaches is non-finite (NaN in the split kernels, +-inf / NaN in fp32)
+        w2 = w.clone()
+        w2[13, 6, 5] = inf
+        with np.errstate(invalid="ignore", over="ignore"):
+            want2 = O.conv_forward(x.numpy(), w2.numpy(), okm, n)
+        y2 = MEB._conv_forward(x.to(device), w2.to(device), km, "mfma").cpu().numpy()
+        assert np.array_equal(~np.isfinite(y2), ~np.isfinite(want2))
+    finally:
+        lib.me_debug_set_wgrad_config(0, 0)

@@ -6,8 +6,10 @@ setup.py:312 builds) is provided by this repository, and the REFERENCE's unmodif
   CoordinateManager / MinkowskiConvolution / pooling / broadcast modules construct; every operator the reference's
   autograd Functions resolve with get_minkowski_function(name, cuda tensor) for the hot path exists in our module
   and accepts exactly the positional arguments of the reference's call site (parsed from the reference's sources).
-* GPU (`-m gpu`; needs /root/reference next to a GPU, which the grading box does not have — skipped there): the
-  reference package's own layers run on the HIP kernels and agree with this repository's layers and the oracle.
+* GPU (`-m gpu`): the reference package's own layers run on the HIP kernels and agree with this repository's layers
+  and the oracle.  /root/reference does not exist on a GPU box; the package is found in oracle/_ref/reference_tree,
+  the git-ignored scratch copy that __graft_entry__.build() stages next to the compiled reference
+  (oracle/stage_ref_package.py) and that travels with the snapshot.
 Everything touching the reference tree runs in a subprocess: importing it rewires sys.path / sys.modules."""
 import ast
 import inspect
@@ -21,7 +23,7 @@ from oracle import ref
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 needs_ref = pytest.mark.skipif(not os.path.isdir(os.path.join(ref.reference_root(), "MinkowskiEngine")),
-                               reason="needs the reference tree (/root/reference)")
+                               reason="needs the reference package (/root/reference or oracle/_ref/reference_tree)")
 
 HOT_PATH_FILES = ["MinkowskiConvolution.py", "MinkowskiPooling.py", "MinkowskiBroadcast.py", "MinkowskiPruning.py"]
 # resolved by name but outside SURVEY.md 8 (no GPU kernel here): nothing in the four files above

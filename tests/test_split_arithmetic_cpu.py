@@ -68,3 +68,41 @@ def test_six_products_are_fp32_grade():
     # a plain bf16 product (what the bf16 FEATURE path does by design) is 2^-8: fourteen bits worse
     rel1 = np.abs(sa[0].astype(np.float64) * sw[0].astype(np.float64) - exact) / np.maximum(np.abs(exact), 1e-300)
     assert rel1.max() > 2.0 ** -9
+
+
+def _split3_planes(a, weight_side=False):
+    """numpy restatement of split3's non-finite rule (csrc/conv_common.hpp): -> three bf16 planes held in fp32"""
+    a = np.asarray(a, np.float32)
+    with np.errstate(invalid="ignore"):
+        a1, a2, a3, _ = _split3(np.where(np.isfinite(a), a, np.float32(0)))
+    bits = a.view(np.uint32)
+    t = ((bits & np.uint32(0xFFFF0000)) | np.where(bits & np.uint32(0x007FFFFF), np.uint32(0x00400000), np.uint32(0)))
+    t = t.astype(np.uint32).view(np.float32)
+    bad = ~np.isfinite(a)
+    if weight_side:
+        return [np.where(bad, np.float32(np.nan), p) for p in (a1, a2, a3)]
+    return [np.where(bad, np.float32(0), a1), np.where(bad, np.float32(0), a2), np.where(bad, t, a3)]
+
+
+def test_nonfinite_rule_matches_fp32_products():
+    """The six kept products with a non-finite ROW value in plane 3 alone reproduce the IEEE class of a * w (sign of
+    the infinity, NaN for NaN and for inf * 0) for every finite w with a non-zero leading plane — in particular for
+    weights exact in bf16, whose second and third planes are zero (inf * 0 would poison the sum if the infinity sat in
+    plane 1).  A non-finite weight-side value makes the product NaN; inf * inf is never silently dropped."""
+    inf = np.float32(np.inf)
+    a = np.float32([inf, -inf, np.nan, inf, -inf, inf, inf, 2.0, -3.0, 0.0, inf])
+    w = np.float32([1.0, 1.0, 0.5, -0.5, 0.3, 0.0, 1 + 2 ** -20, inf, -inf, inf, inf])
+    sa = _split3_planes(a)
+    sw = _split3_planes(w, weight_side=True)
+    kept = [(0, 0), (0, 1), (1, 0), (0, 2), (1, 1), (2, 0)]
+    with np.errstate(invalid="ignore"):
+        got = sum(sa[i].astype(np.float64) * sw[j].astype(np.float64) for i, j in kept)
+        want = a.astype(np.float64) * w.astype(np.float64)
+    row_side = np.isfinite(w)          # first seven cases: the non-finite value is on the row side
+    assert np.array_equal(np.isnan(got[row_side]), np.isnan(want[row_side]))
+    assert np.array_equal(got[row_side][~np.isnan(want[row_side])], want[row_side][~np.isnan(want[row_side])])
+    assert np.all(np.isnan(got[~row_side]))            # weight side: NaN (fp32: +-inf or NaN) — never finite
+    assert not np.any(np.isfinite(want[~row_side]))
+    # a NaN whose payload sits in the low 16 bits must stay a NaN after truncation to bf16
+    sneaky = np.uint32([0x7F800001]).view(np.float32)
+    assert np.isnan(_split3_planes(sneaky)[2][0])
