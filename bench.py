@@ -681,6 +681,8 @@ def main():
     ap.add_argument("--imbalance", action="store_true",
                     help="N > 1: ranks get scenes of different sizes, 0.75x .. 1.25x the nominal voxel count (real scans "
                          "differ in size: the scaling risk SURVEY 8(e) names); value still counts the voxels of all ranks")
+    ap.add_argument("--debug-bf16-shape", default="",
+                    help="'nc,kc': slab width / chunk depth override of the bf16 tile kernel (csrc/me_amd_debug.h)")
     ap.add_argument("--debug-conv-variant", type=int, default=0,
                     help="kernel-selection switch of csrc/me_amd_debug.h (tuning scripts; 0 = shipped kernels)")
     args = ap.parse_args()
@@ -718,6 +720,8 @@ def main():
 
     if args.debug_conv_variant:
         _lib.check(lib.me_debug_set_conv_variant(args.debug_conv_variant))
+    if args.debug_bf16_shape:
+        lib.me_debug_set_bf16_shape(*[int(v) for v in args.debug_bf16_shape.split(",")])
     fn = bench_minkunet if args.workload == "minkunet" else bench_conv
     line = fn(args, ME, MEB, dist_utils, rank, world, dev, startup)
     default_headline = (args.workload == "conv3d" and args.dtype == "f32" and world == 1 and not args.points and

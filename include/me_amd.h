@@ -363,6 +363,32 @@ int me_conv_target_f32x3(const float *src_feat_dev, int64_t n_src, int32_t c_src
                          const int32_t *order_dev, float *dst_feat_dev,
                          int64_t n_tgt, int32_t tile_rows, int32_t batch_groups, void *stream);
 
+/* ---- weights of many layers packed by ONE launch (csrc/pack.hip) ------------------------------------------
+ * The packed images above only change when the weights do (the optimizer step), not per activation: a network packs
+ * all its (layer, direction) images at once instead of twice per layer and step (MinkUNet34C: 126 launches -> 1).
+ * Images are bit-identical to me_conv_pack_weights_bf16 / me_conv_pack_weights_f32x3.
+ *   host:   fill w / wp / volume / c_src / c_dst / transposed / w_is_f32 / mode of each job, call
+ *           me_conv_pack_job_init (sets kc, nchunks, ncb, threads), build the exclusive prefix of `threads`
+ *           (n_jobs + 1 int64), copy jobs and prefix to the device;
+ *   device: me_conv_pack_weights_multi(jobs_dev, n_jobs, prefix_dev, prefix[n_jobs], stream).
+ * c_src / c_dst are the channels of the LAUNCH the image is for (forward: Cin, Cout; input gradient: Cout, Cin with
+ * transposed = 1, `w` always the reference-layout kernel[K, Cin, Cout]). */
+#define ME_PACK_BF16 0    /* image of me_conv_pack_weights_bf16 (w_is_f32: fp32 master weights are rounded RNE) */
+#define ME_PACK_F32X3 1   /* image of me_conv_pack_weights_f32x3 (fp32 weights, three bf16 planes) */
+typedef struct me_pack_job {
+  const void *w;        /* device: kernel[K, Cin, Cout] */
+  void *wp;             /* device: packed image, me_conv_packed_weight_elems_{bf16,f32x3} bf16 elements, 16-byte aligned */
+  int64_t volume;
+  int64_t threads;      /* out: 16-byte elements (bf16) / element triples (f32x3) of the image */
+  int32_t c_src, c_dst, transposed, w_is_f32, mode;
+  int32_t kc, nchunks, ncb;   /* out: source-channel chunk of the tile kernel, chunks, 16-column blocks */
+} me_pack_job;
+int32_t me_conv_pack_chunk_bf16(int32_t c_src, int32_t c_dst);
+int32_t me_conv_pack_chunk_f32x3(int32_t c_src, int32_t c_dst);
+int me_conv_pack_job_init(me_pack_job *job);
+int me_conv_pack_weights_multi(const me_pack_job *jobs_dev, int32_t n_jobs, const int64_t *thread_prefix_dev,
+                               int64_t total_threads, void *stream);
+
 /* ---- pooling / broadcast (replace src/pooling_avg_kernel.cu, src/pooling_max_kernel.cu,
  *      src/broadcast_kernel.cu; CPU twins src/pooling_avg_kernel.hpp:41-150,
  *      src/pooling_max_kernel.hpp:36-117, src/broadcast_kernel.hpp:35-160) ------------------------

@@ -32,6 +32,17 @@ class MeRegion(ctypes.Structure):
     ]
 
 
+class MePackJob(ctypes.Structure):
+    """me_pack_job of include/me_amd.h"""
+    _fields_ = [("w", ctypes.c_void_p), ("wp", ctypes.c_void_p), ("volume", ctypes.c_int64),
+                ("threads", ctypes.c_int64), ("c_src", ctypes.c_int32), ("c_dst", ctypes.c_int32),
+                ("transposed", ctypes.c_int32), ("w_is_f32", ctypes.c_int32), ("mode", ctypes.c_int32),
+                ("kc", ctypes.c_int32), ("nchunks", ctypes.c_int32), ("ncb", ctypes.c_int32)]
+
+
+ME_PACK_BF16, ME_PACK_F32X3 = 0, 1
+
+
 class MeSpatialGrid(ctypes.Structure):
     """struct me_spatial_grid (include/me_amd.h)."""
     _fields_ = [
@@ -106,6 +117,10 @@ SIGNATURES = {
     "me_conv_pack_weights_f32x3": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "me_conv_target_f32x3": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp,
                                             c_vp, c_i64, c_i32, c_i32, c_vp]),
+    "me_conv_pack_chunk_bf16": (c_i32, [c_i32, c_i32]),
+    "me_conv_pack_chunk_f32x3": (c_i32, [c_i32, c_i32]),
+    "me_conv_pack_job_init": (ctypes.c_int, [ctypes.POINTER(MePackJob)]),
+    "me_conv_pack_weights_multi": (ctypes.c_int, [c_vp, c_i32, c_vp, c_i64, c_vp]),
     "me_conv_plan_config_bf16": (ctypes.c_int, [c_i64, c_i64, c_i64, c_i32, c_i32, _P_I32, _P_I32]),
     "me_conv_packed_weight_elems_bf16": (c_i64, [c_i64, c_i32, c_i32]),
     "me_conv_pack_weights_bf16": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
@@ -147,6 +162,7 @@ DEBUG_SIGNATURES = {
     "me_debug_conv_timing_f32x3": (ctypes.c_int, [c_vp, c_i32]),
     "me_debug_set_wgrad_config": (None, [ctypes.c_int, ctypes.c_int]),
     "me_debug_set_wgrad_order": (None, [ctypes.c_int]),
+    "me_debug_set_bf16_shape": (None, [ctypes.c_int, ctypes.c_int]),
 }
 
 _lib = None

@@ -1051,6 +1051,18 @@ def _use_split(lib, c_src, c_dst):
 
 
 _ALGO = os.environ.get("ME_AMD_CONV_ALGO", "mfma")  # "naive" = VALU/atomics cross-check kernels
+# weight gradient on a side stream, concurrent with the input gradient of the same layer (_conv_backward); "0": one stream
+_WGRAD_STREAM = os.environ.get("ME_AMD_WGRAD_STREAM", "1") != "0"
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev):
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    s = _SIDE_STREAMS.get(idx)
+    if s is None:
+        s = _SIDE_STREAMS[idx] = torch.cuda.Stream(device=idx)
+    return s
+
 _WGRAD_TUNING = False  # set by the tuning scripts, which flip the wgrad debug switches between calls: the
                        # workspace size is then re-queried on every call instead of cached per kernel map
 _TILE_ROWS = int(os.environ.get("ME_AMD_TILE_ROWS", "0"))        # 0 = me_conv_plan_config (tuning overrides)
@@ -1157,6 +1169,110 @@ def _wgrad_launch_cfg(km, c_in, c_out, bf16):
     return cfg
 
 
+# ------------------------------------------------------------------------------------------------
+# packed weights: cached per (weight tensor, direction), every stale image repacked by ONE launch
+# ------------------------------------------------------------------------------------------------
+_PACK_CACHE = os.environ.get("ME_AMD_PACK_CACHE", "1") != "0"   # "0": pack per launch (round-2 behaviour)
+
+
+class _PackEntry:
+    __slots__ = ("ref", "ptr", "shape", "dtype", "mode", "transposed", "version", "packed", "job")
+
+
+class _WeightPacker:
+    """Packed MFMA images of the convolution weights of one device (csrc/pack.hip).
+
+    The images depend on the weights alone, and the weights change at the optimizer step — not between the forward
+    and the backward launch of a layer, and not between layers.  An image is therefore kept next to its weight
+    tensor, keyed by (storage address, direction, kernel family) and validated by the tensor's VERSION COUNTER (every
+    in-place update — optimizer step, copy_, load_state_dict — bumps it; a new storage is a new key).  On a miss ALL
+    images whose weight has moved on are repacked together by me_conv_pack_weights_multi: in a training loop that is
+    the first convolution after the optimizer step — one launch per step instead of two per layer (MinkUNet34C: 126),
+    with the job table cached on the device while the set of stale images repeats.
+    Entries hold only a weak reference to the weight: a temporary weight tensor (tests, functional calls) is packed
+    per call as before.  Not for concurrent use of one layer from two streams (the image buffer is reused in place;
+    stream order protects the previous step's launches)."""
+
+    def __init__(self, dev):
+        self.dev = dev
+        self.entries = {}
+        self.table_key, self.table = None, None     # device copy of the last job table
+
+    @staticmethod
+    def _alive(ent):
+        t = ent.ref()
+        return t is not None and t.data_ptr() == ent.ptr
+
+    def get(self, kernel, mode, transposed, c_src, c_dst, elems):
+        key = (kernel.data_ptr(), mode, bool(transposed))
+        ent = self.entries.get(key)
+        if ent is not None and self._alive(ent) and ent.shape == tuple(kernel.shape) and ent.dtype == kernel.dtype:
+            if ent.version == kernel._version:
+                return ent.packed
+        else:
+            import weakref
+            if len(self.entries) > 4096:
+                self.entries = {k: e for k, e in self.entries.items() if self._alive(e)}
+            ent = _PackEntry()
+            # (a full view of a parameter — a 1x1 convolution passes kernel.unsqueeze(0) — is anchored at its base:
+            # the view object dies with the autograd node, the parameter lives on; they share the version counter)
+            base = kernel._base
+            anchor = base if (base is not None and base.data_ptr() == kernel.data_ptr() and
+                              base.numel() == kernel.numel()) else kernel
+            ent.ref, ent.ptr, ent.shape, ent.dtype = weakref.ref(anchor), kernel.data_ptr(), tuple(kernel.shape), kernel.dtype
+            ent.mode, ent.transposed, ent.version = mode, bool(transposed), None
+            ent.packed = torch.empty(elems, dtype=torch.bfloat16, device=self.dev)
+            job = _lib.MePackJob()
+            job.w, job.wp, job.volume = ent.ptr, ent.packed.data_ptr(), int(kernel.shape[0])
+            job.c_src, job.c_dst, job.transposed = int(c_src), int(c_dst), 1 if transposed else 0
+            job.w_is_f32, job.mode = 1 if kernel.dtype == torch.float32 else 0, mode
+            _lib.check(_lib.load().me_conv_pack_job_init(ctypes.byref(job)))
+            ent.job = job
+            self.entries[key] = ent
+        self._repack_stale(ent, kernel)
+        return ent.packed
+
+    def _repack_stale(self, wanted, kernel):
+        stale = []
+        for ent in self.entries.values():
+            if ent is wanted:
+                continue
+            t = ent.ref()
+            if t is not None and t.data_ptr() == ent.ptr and ent.version is not None and t._version != ent.version:
+                stale.append((ent, t._version))
+        stale.append((wanted, kernel._version))
+        if len(stale) > 1024:
+            stale = stale[-1024:]
+        lib = _lib.load()
+        key = tuple(id(e) for e, _ in stale)
+        if key != self.table_key:
+            jobs = (_lib.MePackJob * len(stale))(*[e.job for e, _ in stale])
+            prefix = [0]
+            for e, _ in stale:
+                prefix.append(prefix[-1] + int(e.job.threads))
+            jb = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(self.dev)
+            pf = torch.tensor(prefix, dtype=torch.int64).to(self.dev)
+            self.table_key, self.table = key, (jb, pf, prefix[-1], [e for e, _ in stale])   # (entries kept alive)
+        jb, pf, total, _ = self.table
+        with _on(self.dev):
+            _lib.check(lib.me_conv_pack_weights_multi(jb.data_ptr(), len(stale), pf.data_ptr(), total,
+                                                      _stream(self.dev)))
+        for e, v in stale:
+            e.version = v
+
+
+_PACKERS = {}
+
+
+def _packed_weights(kernel, mode, transposed, c_src, c_dst, elems):
+    """bf16 / split image of `kernel` for a launch with (c_src, c_dst) channels, from the device's _WeightPacker"""
+    dev = kernel.device
+    pk = _PACKERS.get(dev.index)
+    if pk is None:
+        pk = _PACKERS[dev.index] = _WeightPacker(dev)
+    return pk.get(kernel, mode, transposed, c_src, c_dst, elems)
+
+
 def _conv_target(src_feat, kernel, km, target, n_tgt, name="conv_target", transposed=False):
     """dst[t] = sum over plan entries of src[s] @ W[k].
     transposed=False: W[k] = kernel[k] ([c_src, c_dst]);  transposed=True (dgrad): W[k] = kernel[k]^T."""
@@ -1197,10 +1313,13 @@ def _conv_target(src_feat, kernel, km, target, n_tgt, name="conv_target", transp
         if bf16:
             # bf16 features: weights (fp32 master copy or bf16) are rounded to bf16 while being packed
             _check(kernel.dtype in (torch.float32, torch.bfloat16), "kernel must be float32 or bfloat16")
-            packed = torch.empty(elems, dtype=torch.bfloat16, device=dev)
-            _lib.check(lib.me_conv_pack_weights_bf16(kernel.data_ptr(), 1 if kernel.dtype == torch.float32 else 0,
-                                                     volume, c_src, c_dst, 1 if transposed else 0,
-                                                     packed.data_ptr(), stream))
+            if _PACK_CACHE:
+                packed = _packed_weights(kernel, _lib.ME_PACK_BF16, transposed, c_src, c_dst, elems)
+            else:
+                packed = torch.empty(elems, dtype=torch.bfloat16, device=dev)
+                _lib.check(lib.me_conv_pack_weights_bf16(kernel.data_ptr(), 1 if kernel.dtype == torch.float32 else 0,
+                                                         volume, c_src, c_dst, 1 if transposed else 0,
+                                                         packed.data_ptr(), stream))
             fn = lib.me_conv_target_bf16_fused if fuse else lib.me_conv_target_bf16
             _timed(name, dev, lambda: _lib.check(fn(
                 src_feat.data_ptr(), src_feat.shape[0], c_src, packed.data_ptr(), km.volume, c_dst, p_src, p_dst,
@@ -1208,9 +1327,12 @@ def _conv_target(src_feat, kernel, km, target, n_tgt, name="conv_target", transp
             return out
         _check(kernel.dtype == torch.float32, "float32 features need a float32 kernel, got", kernel.dtype)
         if split:
-            packed = torch.empty(elems, dtype=torch.bfloat16, device=dev)
-            _lib.check(lib.me_conv_pack_weights_f32x3(kernel.data_ptr(), volume, c_src, c_dst, 1 if transposed else 0,
-                                                      packed.data_ptr(), stream))
+            if _PACK_CACHE:
+                packed = _packed_weights(kernel, _lib.ME_PACK_F32X3, transposed, c_src, c_dst, elems)
+            else:
+                packed = torch.empty(elems, dtype=torch.bfloat16, device=dev)
+                _lib.check(lib.me_conv_pack_weights_f32x3(kernel.data_ptr(), volume, c_src, c_dst,
+                                                          1 if transposed else 0, packed.data_ptr(), stream))
             _timed(name, dev, lambda: _lib.check(lib.me_conv_target_f32x3(
                 src_feat.data_ptr(), src_feat.shape[0], c_src, packed.data_ptr(), km.volume, c_dst, p_src, p_dst,
                 p_desc, p_bptr, p_order, out.data_ptr(), n_tgt, tile_rows, batch_groups, stream)), flops=flops)
@@ -1239,7 +1361,7 @@ def _conv_forward(in_feat, kernel, km, algo=None):
     return _conv_target(in_feat, kernel, km, "out", km.n_out, name="conv_forward")
 
 
-def _conv_backward(in_feat, grad_out, kernel, km, algo=None):
+def _conv_backward(in_feat, grad_out, kernel, km, algo=None, need_grad_in=True):
     algo = algo or _ALGO
     lib = _lib.load()
     dev = in_feat.device
@@ -1257,23 +1379,43 @@ def _conv_backward(in_feat, grad_out, kernel, km, algo=None):
                                                       km.volume, km.n_pairs, _ptr(grad_in), _ptr(grad_w),
                                                       _stream(dev)))
         return grad_in, grad_w
-    # dgrad: the same target-stationary kernel; the weights are packed transposed per offset
-    grad_in = _conv_target(grad_out, kernel, km, "in", km.n_in, name="conv_dgrad", transposed=True)
-    # wgrad: always accumulated and reduced in fp32; handed back in the kernel's dtype
+    # wgrad: always accumulated and reduced in fp32; handed back in the kernel's dtype.  The two gradients of a layer
+    # are independent (both read grad_out; dgrad reads the weights, wgrad the layer's input), and on all but the
+    # largest maps neither launch fills the 256 CUs for its whole duration (a (tile, offset) chain in one, a few
+    # hundred pair ranges in the other): the weight gradient goes to a SIDE STREAM and runs next to the input
+    # gradient.  Fork / join inside this call (side waits for what the current stream has produced; the current stream
+    # waits for the side stream before anything downstream can touch grad_w), so callers — autograd's AccumulateGrad,
+    # DDP's bucket hooks, a hipGraph capture — see plain stream-ordered tensors.
     grad_w = torch.empty(kernel.shape, dtype=torch.float32, device=dev)
     cfg = _wgrad_launch_cfg(km, c_in, c_out, bf16)
     koffs, wsb, p_in, p_out, p_koffs = cfg
     if _WGRAD_TUNING:   # the debug switches change the workspace need
         wsb = int((lib.me_conv_wgrad_workspace_bytes_bf16 if bf16 else lib.me_conv_wgrad_workspace_bytes)(
             koffs, volume, c_in, c_out))
-    ws = _workspace(wsb, dev)
     fn = lib.me_conv_wgrad_bf16 if bf16 else lib.me_conv_wgrad_f32
-    stream = _stream(dev)
-    with _on(dev):
-        _timed("conv_wgrad", dev, lambda: _lib.check(fn(
-            in_feat.data_ptr(), in_feat.shape[0], c_in, grad_out.data_ptr(), grad_out.shape[0], c_out, p_in, p_out,
-            koffs, p_koffs, volume,
-            grad_w.data_ptr(), ws.data_ptr(), ws.numel(), stream)), flops=2.0 * km.n_pairs * c_in * c_out)
+
+    def wgrad():
+        ws = _workspace(wsb, dev)      # (allocated under the stream that uses it)
+        stream = _stream(dev)
+        with _on(dev):
+            _timed("conv_wgrad", dev, lambda: _lib.check(fn(
+                in_feat.data_ptr(), in_feat.shape[0], c_in, grad_out.data_ptr(), grad_out.shape[0], c_out, p_in, p_out,
+                koffs, p_koffs, volume,
+                grad_w.data_ptr(), ws.data_ptr(), ws.numel(), stream)), flops=2.0 * km.n_pairs * c_in * c_out)
+
+    side = _side_stream(dev) if (_WGRAD_STREAM and km.n_pairs > 0) else None
+    if side is not None:
+        main = torch.cuda.current_stream(dev)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            wgrad()
+    # dgrad: the same target-stationary kernel; the weights are packed transposed per offset
+    grad_in = _conv_target(grad_out, kernel, km, "in", km.n_in, name="conv_dgrad", transposed=True) \
+        if need_grad_in else None
+    if side is not None:
+        main.wait_stream(side)
+    else:
+        wgrad()
     return grad_in, grad_w if kernel.dtype == torch.float32 else grad_w.to(kernel.dtype)
 
 
@@ -1323,8 +1465,9 @@ def ConvolutionForwardGPU(in_feat, kernel, kernel_size, kernel_stride, kernel_di
 
 
 def ConvolutionBackwardGPU(in_feat, grad_out_feat, kernel, kernel_size, kernel_stride, kernel_dilation,
-                           region_type, offset, convolution_mode, in_key, out_key, manager):
-    """src/convolution_gpu.cu:161-244 -> (grad_in_feat, grad_kernel)."""
+                           region_type, offset, convolution_mode, in_key, out_key, manager, need_grad_in=True):
+    """src/convolution_gpu.cu:161-244 -> (grad_in_feat, grad_kernel).  need_grad_in (not in the reference, optional):
+    False skips the input gradient (returned as None)."""
     _check_feat("in_feat", in_feat)
     _check_feat("kernel", kernel)
     if not grad_out_feat.is_contiguous():
@@ -1335,7 +1478,7 @@ def ConvolutionBackwardGPU(in_feat, grad_out_feat, kernel, kernel_size, kernel_s
     km = manager._kernel_map(in_key, out_key, kernel_size, kernel_stride, kernel_dilation, region_type, offset,
                              False, False)
     _check(grad_out_feat.shape[0] == km.n_out, "Invalid grad_out size")
-    return _conv_backward(in_feat, grad_out_feat, kernel, km)
+    return _conv_backward(in_feat, grad_out_feat, kernel, km, need_grad_in=need_grad_in)
 
 
 def ConvolutionTransposeForwardGPU(in_feat, kernel, kernel_size, kernel_stride, kernel_dilation, region_type,
@@ -1350,7 +1493,7 @@ def ConvolutionTransposeForwardGPU(in_feat, kernel, kernel_size, kernel_stride, 
 
 def ConvolutionTransposeBackwardGPU(in_feat, grad_out_feat, kernel, kernel_size, kernel_stride,
                                     kernel_dilation, region_type, offset, convolution_mode, in_key, out_key,
-                                    manager):
+                                    manager, need_grad_in=True):
     """src/convolution_transpose_cpu.cpp:127-191 -> (grad_in_feat, grad_kernel)."""
     _check_feat("in_feat", in_feat)
     _check_feat("kernel", kernel)
@@ -1360,7 +1503,7 @@ def ConvolutionTransposeBackwardGPU(in_feat, grad_out_feat, kernel, kernel_size,
     km = manager._kernel_map(in_key, out_key, kernel_size, kernel_stride, kernel_dilation, region_type, offset,
                              True, False)
     _check(grad_out_feat.shape[0] == km.n_out, "Invalid grad_out size")
-    return _conv_backward(in_feat, grad_out_feat, kernel, km)
+    return _conv_backward(in_feat, grad_out_feat, kernel, km, need_grad_in=need_grad_in)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -16,6 +16,23 @@ from .sparse_tensor import SparseTensor, _get_coordinate_map_key
 
 
 _MM_AS_CONV = os.environ.get("ME_AMD_MM_AS_CONV", "1") != "0"   # 1x1 convolutions on the conv kernels
+# bf16 features: channel counts that are not multiples of 8 (a 3-channel stem, a 20-class head) are zero-padded to the
+# next multiple of 8 around the operator — 16-byte row pieces for the gathers and the bf16 weight-gradient kernel instead
+# of the scalar / fp32-MFMA fall-backs (MinkUNet34C stem 3 -> 32, K = 125: forward 121 us, weight gradient 138 us at
+# 1.3 TFLOP/s before, profiles/r03_layers_minkunet34c_bf16_before.log); results are those of the unpadded operator
+# (padded inputs and weights are zero, padded outputs are dropped), gradients flow through torch's pad / slice
+_PAD_CHANNELS = os.environ.get("ME_AMD_PAD_CHANNELS", "1") != "0"
+
+
+def _pad_channels(feats, kernel, cin, cout):
+    """-> (feats, kernel, cout_padded | None) with channel counts rounded up to multiples of 8 (bf16 features only)"""
+    if not (_PAD_CHANNELS and feats.is_cuda and feats.dtype == torch.bfloat16 and (cin % 8 or cout % 8)):
+        return feats, kernel, None
+    pi, po = (-cin) % 8, (-cout) % 8
+    if pi:
+        feats = torch.nn.functional.pad(feats, (0, pi))
+    kernel = torch.nn.functional.pad(kernel, (0, po, 0, pi))
+    return feats, kernel, (cout + po if po else None)
 
 
 class MinkowskiConvolutionFunction(Function):
@@ -40,11 +57,13 @@ class MinkowskiConvolutionFunction(Function):
         grad_out_feat = grad_out_feat.contiguous()
         kernel_generator, convolution_mode, in_key, out_key, coordinate_manager = ctx.misc
         bw_fn = get_minkowski_function("ConvolutionBackward", grad_out_feat)
+        # (not in the reference: the input gradient is skipped when autograd does not ask for it — the first layer
+        # of a network, whose input features are data)
         grad_in_feat, grad_kernel = bw_fn(ctx.input_features, grad_out_feat, ctx.kernel_weights,
                                           kernel_generator.kernel_size, kernel_generator.kernel_stride,
                                           kernel_generator.kernel_dilation, kernel_generator.region_type,
                                           kernel_generator.region_offsets, convolution_mode, in_key, out_key,
-                                          coordinate_manager._manager)
+                                          coordinate_manager._manager, need_grad_in=ctx.needs_input_grad[0])
         return grad_in_feat, grad_kernel, None, None, None, None, None
 
 
@@ -74,7 +93,7 @@ class MinkowskiConvolutionTransposeFunction(Function):
                                           kernel_generator.kernel_size, kernel_generator.kernel_stride,
                                           kernel_generator.kernel_dilation, kernel_generator.region_type,
                                           kernel_generator.region_offsets, convolution_mode, in_key, out_key,
-                                          coordinate_manager._manager)
+                                          coordinate_manager._manager, need_grad_in=ctx.needs_input_grad[0])
         return grad_in_feat, grad_kernel, None, None, None, None, None
 
 
@@ -118,9 +137,13 @@ class MinkowskiConvolutionBase(MinkowskiModuleBase):
             if _MM_AS_CONV and not self.is_transpose and input.F.is_cuda and input.F.shape[0] > 0:
                 # run it as a one-offset convolution on this package's kernels: rocBLAS / hipBLASLt pick slow
                 # kernels for the skinny products of a segmentation head (200k x 96 @ 96 x 20 took 325 us)
-                outfeat = self.conv.apply(input.F, self.kernel.unsqueeze(0), self.kernel_generator,
+                feats, kernel, cpad = _pad_channels(input.F, self.kernel.unsqueeze(0), self.in_channels,
+                                                    self.out_channels)
+                outfeat = self.conv.apply(feats, kernel, self.kernel_generator,
                                           self.convolution_mode, input.coordinate_map_key, out_coordinate_map_key,
                                           input._manager)
+                if cpad is not None:
+                    outfeat = outfeat[:, :self.out_channels].contiguous()
             else:
                 # bf16 features with fp32 master weights: the product runs in the feature dtype
                 outfeat = input.F.mm(self.kernel if self.kernel.dtype == input.F.dtype
@@ -130,8 +153,11 @@ class MinkowskiConvolutionBase(MinkowskiModuleBase):
             # MinkowskiConvolution.py:311-313; passed by keyword here)
             out_coordinate_map_key = _get_coordinate_map_key(
                 input, coordinates, expand_coordinates=self.kernel_generator.expand_coordinates)
-            outfeat = self.conv.apply(input.F, self.kernel, self.kernel_generator, self.convolution_mode,
+            feats, kernel, cpad = _pad_channels(input.F, self.kernel, self.in_channels, self.out_channels)
+            outfeat = self.conv.apply(feats, kernel, self.kernel_generator, self.convolution_mode,
                                       input.coordinate_map_key, out_coordinate_map_key, input._manager)
+            if cpad is not None:
+                outfeat = outfeat[:, :self.out_channels].contiguous()
         if self.bias is not None:
             outfeat = outfeat + (self.bias if self.bias.dtype == outfeat.dtype else self.bias.to(outfeat.dtype))
         return SparseTensor(outfeat, coordinate_map_key=out_coordinate_map_key, coordinate_manager=input._manager)

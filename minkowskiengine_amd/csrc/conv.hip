@@ -1376,32 +1376,44 @@ __global__ __launch_bounds__(256, 3) void k_wgrad_f32x3(const float *__restrict_
   };
   auto write_lds = [&](int cnt) {
     const u32x4 zero = {0u, 0u, 0u, 0u};
+    // non-finite rows (conv_common.hpp): x is the row side of the rule, dy the weight side; FIX = the exact, rare pass
+    auto store_step = [&](auto fix) {
+      constexpr bool FIX = decltype(fix)::value;
+      uint32_t flag = 0u;
 #pragma unroll
-    for (int j = 0; j < XP; ++j) {
-      const int idx = j * 256 + tid;
-      const int row = idx >> 3;
-      const int ch = ci0 + (idx & 7) * 8;
-      const bool ok = row < cnt && ch < c_in;                // pairs beyond the step / channels beyond c_in: zeros
-      u32x4 p1, p2, p3;
-      split3(rx[j][0], rx[j][1], p1, p2, p3);
-      __bf16 *o = s_x + row * XLD + (idx & 7) * 8;
-      *reinterpret_cast<u32x4 *>(o) = ok ? p1 : zero;
-      *reinterpret_cast<u32x4 *>(o + XPL) = ok ? p2 : zero;
-      *reinterpret_cast<u32x4 *>(o + 2 * XPL) = ok ? p3 : zero;
-    }
+      for (int j = 0; j < XP; ++j) {
+        const int idx = j * 256 + tid;
+        const int row = idx >> 3;
+        const int ch = ci0 + (idx & 7) * 8;
+        const bool ok = row < cnt && ch < c_in;                // pairs beyond the step / channels beyond c_in: zeros
+        u32x4 p1, p2, p3;
+        if (FIX) split3_fix<false>(rx[j][0], rx[j][1], p1, p2, p3);
+        else split3_raw(rx[j][0], rx[j][1], p1, p2, p3);
+        if (ok) flag = split3_flag(flag, p3);
+        __bf16 *o = s_x + row * XLD + (idx & 7) * 8;
+        *reinterpret_cast<u32x4 *>(o) = ok ? p1 : zero;
+        *reinterpret_cast<u32x4 *>(o + XPL) = ok ? p2 : zero;
+        *reinterpret_cast<u32x4 *>(o + 2 * XPL) = ok ? p3 : zero;
+      }
 #pragma unroll
-    for (int j = 0; j < DP; ++j) {
-      const int idx = j * 256 + tid;
-      const int row = idx / (COB / 8);
-      const int pc = idx % (COB / 8);
-      const bool ok = row < cnt && cog + pc * 8 < c_out;
-      u32x4 p1, p2, p3;
-      split3<true>(rd[j][0], rd[j][1], p1, p2, p3);   // dy is the "weight side" of the non-finite rule (conv_common.hpp)
-      __bf16 *o = s_d + row * DLD + pc * 8;
-      *reinterpret_cast<u32x4 *>(o) = ok ? p1 : zero;
-      *reinterpret_cast<u32x4 *>(o + DPL) = ok ? p2 : zero;
-      *reinterpret_cast<u32x4 *>(o + 2 * DPL) = ok ? p3 : zero;
-    }
+      for (int j = 0; j < DP; ++j) {
+        const int idx = j * 256 + tid;
+        const int row = idx / (COB / 8);
+        const int pc = idx % (COB / 8);
+        const bool ok = row < cnt && cog + pc * 8 < c_out;
+        u32x4 p1, p2, p3;
+        if (FIX) split3_fix<true>(rd[j][0], rd[j][1], p1, p2, p3);
+        else split3_raw(rd[j][0], rd[j][1], p1, p2, p3);
+        if (ok) flag = split3_flag(flag, p3);
+        __bf16 *o = s_d + row * DLD + pc * 8;
+        *reinterpret_cast<u32x4 *>(o) = ok ? p1 : zero;
+        *reinterpret_cast<u32x4 *>(o + DPL) = ok ? p2 : zero;
+        *reinterpret_cast<u32x4 *>(o + 2 * DPL) = ok ? p3 : zero;
+      }
+      return flag;
+    };
+    const uint32_t flag = store_step(std::false_type{});
+    if (__builtin_expect(__any(split3_suspect(flag)), 0)) store_step(std::true_type{});
   };
 
   f32x4 acc[MB][NB];
@@ -1884,7 +1896,7 @@ int plan_tile_rows(const PlanShape &s, int64_t n_tgt, int64_t volume, int64_t n_
   double best_cost = 1e300;
   int best_t = 128;
   // resident workgroups per CU: 3 waves per SIMD by registers (__launch_bounds__(NC * 4, 3)), then the LDS
-  int occ_max = 12 / waves;
+  int occ_max = (s.wave_slots > 0 ? s.wave_slots : 12) / waves;
   if (s.max_occ > 0 && s.max_occ < occ_max) occ_max = s.max_occ;
   if (occ_max < 1) occ_max = 1;
   for (int occ = occ_max; occ >= 1; --occ) {

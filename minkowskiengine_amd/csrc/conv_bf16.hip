@@ -127,8 +127,13 @@ __global__ __launch_bounds__(256) void k_pack_weights_bf16(const void *__restric
 // See k_conv_tile_f32 (conv.hip) for the pipeline; differences are the element type and the MFMA shape.
 // EXACT: c_src is a multiple of KC (rows need no channel guards).
 // SMALL: 32-bit gather offsets with a 24-bit row multiply (host-checked: < 2^24 rows, source matrix < 4 GiB).
+// waves per SIMD the register budget is sized for: 3 (168 registers) for four-wave workgroups; an eight-wave
+// workgroup (128 columns) is sized for 4 (128 registers: two of them per CU) unless its weight slices need more
+// (KC = 256: 64 registers of weights alone)
+__host__ __device__ constexpr int conv_bf16_waves_per_simd(int nc, int kc) { return (nc == 128 && kc <= 128) ? 4 : (nc == 128 ? 2 : 3); }
+
 template <int NC, int KC, bool EXACT, bool SMALL, bool FUSE = false>
-__global__ __launch_bounds__(NC * 4, 3) void k_conv_tile_bf16(
+__global__ __launch_bounds__(NC * 4, conv_bf16_waves_per_simd(NC, KC)) void k_conv_tile_bf16(
     const __bf16 *__restrict__ src, int c_src, const bf16x8 *__restrict__ wp, int c_dst,
     const int32_t *__restrict__ plan_src, const int32_t *__restrict__ plan_dst,
     const int32_t *__restrict__ batch_desc, const int32_t *__restrict__ tile_bptr,
@@ -564,17 +569,30 @@ struct ConvVariantBf16 {
   int nc, slabs, kc;
 };
 
+int g_bf16_nc = 0, g_bf16_kc = 0;   // me_debug_set_bf16_shape: tuning overrides of the slab width / chunk depth (0 = policy)
+
 static ConvVariantBf16 conv_variant_bf16(int c_src, int c_dst) {
   ConvVariantBf16 v;
   // 64 columns per workgroup whenever there are more than 32: the matrix pipe is nearly idle in bf16, so a
-  // half-empty last slab costs nothing, while every extra slab re-gathers all source rows
+  // half-empty last slab costs nothing, while every extra slab re-gathers all source rows.  128 columns (eight
+  // waves) where they tile the output exactly: the per-batch chain of a tile (index window -> gather -> stage ->
+  // barrier -> operands -> MFMA -> accumulate, ~1 us) is then paid once per 128 columns, and a 256-channel layer on
+  // a 5k - 20k voxel map (MinkUNet's deepest levels: one workgroup per CU, nothing to overlap with) walks half as
+  // many batches (round 3, profiles/r03_*layers*)
   v.nc = c_dst <= 32 ? 32 : 64;
+  if (c_dst % 128 == 0) v.nc = 128;
+  if (g_bf16_nc == 32 || g_bf16_nc == 64 || g_bf16_nc == 128) v.nc = (g_bf16_nc == 32 && c_dst > 32) ? 64 : g_bf16_nc;
+  if (v.nc == 128 && c_dst <= 64) v.nc = 64;
   v.slabs = (int)ceil_div(c_dst, v.nc);
   // widest chunk that tiles the source channels exactly (MinkUNet's 96 / 192-channel layers sit on its largest
-  // maps); otherwise the smallest chunk that covers them, or 128
-  if (c_src % 128 == 0) v.kc = 128;
+  // maps); otherwise the smallest chunk that covers them, or 128.  256 halves the batches of a 256-channel layer once
+  // more (64 KiB of weights per batch and slab stay in flight in registers: eight-wave workgroups only).
+  if (c_src % 256 == 0 && v.nc == 128) v.kc = 256;
+  else if (c_src % 128 == 0) v.kc = 128;
   else if (c_src % 96 == 0) v.kc = 96;
   else v.kc = c_src <= 32 ? 32 : (c_src <= 64 ? 64 : 128);
+  if (g_bf16_kc == 32 || g_bf16_kc == 64 || g_bf16_kc == 96 || g_bf16_kc == 128 || (g_bf16_kc == 256 && v.nc == 128))
+    v.kc = g_bf16_kc;
   return v;
 }
 
@@ -588,11 +606,15 @@ static int launch_conv_tile_bf16(const __bf16 *src, int c_src, const bf16x8 *wp,
   const bool exact = (c_src % KC) == 0;
   typedef void (*kernel_t)(const __bf16 *, int, const bf16x8 *, int, const int32_t *, const int32_t *, const int32_t *,
                            const int32_t *, const int32_t *, __bf16 *, int64_t, int, int, int);
-  const kernel_t fn =
-      fuse ? (small ? (exact ? &k_conv_tile_bf16<NC, KC, true, true, true> : &k_conv_tile_bf16<NC, KC, false, true, true>)
-                    : (exact ? &k_conv_tile_bf16<NC, KC, true, false, true> : &k_conv_tile_bf16<NC, KC, false, false, true>))
-           : (small ? (exact ? &k_conv_tile_bf16<NC, KC, true, true> : &k_conv_tile_bf16<NC, KC, false, true>)
-                    : (exact ? &k_conv_tile_bf16<NC, KC, true, false> : &k_conv_tile_bf16<NC, KC, false, false>));
+  kernel_t fn = small ? (exact ? &k_conv_tile_bf16<NC, KC, true, true> : &k_conv_tile_bf16<NC, KC, false, true>)
+                      : (exact ? &k_conv_tile_bf16<NC, KC, true, false> : &k_conv_tile_bf16<NC, KC, false, false>);
+  if constexpr (NC <= 64 && KC <= 128) {   // batch fusion: four-wave workgroups only (sparse maps of narrow layers)
+    if (fuse)
+      fn = small ? (exact ? &k_conv_tile_bf16<NC, KC, true, true, true> : &k_conv_tile_bf16<NC, KC, false, true, true>)
+                 : (exact ? &k_conv_tile_bf16<NC, KC, true, false, true> : &k_conv_tile_bf16<NC, KC, false, false, true>);
+  } else {
+    fuse = false;
+  }
   static bool attr_set[8] = {false, false, false, false, false, false, false, false};  // per instantiation
   const int which = (fuse ? 4 : 0) + (small ? 2 : 0) + (exact ? 1 : 0);
   if (lds > 48 * 1024 && !attr_set[which]) {
@@ -626,6 +648,7 @@ int me_conv_plan_config_bf16(int64_t n_tgt, int64_t volume, int64_t n_pairs, int
   s.chunks = (int)ceil_div(c_src, v.kc);
   s.group_cycles = 64.0 + (v.kc / 32) * 24.0;  // LDS-bound: accumulator read-add-write + operand reads
   s.stage_row_bytes = (v.kc + 16) * 2 + 4;
+  s.wave_slots = 4 * conv_bf16_waves_per_simd(v.nc, v.kc);
   *tile_rows = plan_tile_rows(s, n_tgt, volume, n_pairs);
   return 0;
 }
@@ -634,6 +657,15 @@ int64_t me_conv_packed_weight_elems_bf16(int64_t volume, int32_t c_src, int32_t 
   if (volume <= 0 || c_src <= 0 || c_dst <= 0) return 0;
   const ConvVariantBf16 v = conv_variant_bf16(c_src, c_dst);
   return volume * align_up(c_src, v.kc) * align_up(c_dst, 16);
+}
+
+void me_debug_set_bf16_shape(int nc, int kc) {
+  g_bf16_nc = nc;
+  g_bf16_kc = kc;
+}
+
+int32_t me_conv_pack_chunk_bf16(int32_t c_src, int32_t c_dst) {
+  return (c_src > 0 && c_dst > 0) ? conv_variant_bf16(c_src, c_dst).kc : 0;
 }
 
 int me_conv_pack_weights_bf16(const void *w, int32_t w_is_f32, int64_t volume, int32_t c_src, int32_t c_dst,
@@ -655,7 +687,8 @@ int me_conv_pack_weights_bf16(const void *w, int32_t w_is_f32, int64_t volume, i
       hipLaunchKernelGGL((k_pack_weights_bf16<KCV, false>), grid, block, 0, stream, w, c_src, c_dst, transposed, \
                          nchunks, ncb, wp8, total);                                                             \
   } while (0)
-  if (v.kc == 128) ME_PACK(128);
+  if (v.kc == 256) ME_PACK(256);
+  else if (v.kc == 128) ME_PACK(128);
   else if (v.kc == 96) ME_PACK(96);
   else if (v.kc == 64) ME_PACK(64);
   else ME_PACK(32);
@@ -690,6 +723,12 @@ static int conv_target_bf16(const uint16_t *src_, int64_t n_src, int32_t c_src, 
     if (v.kc == 96) ME_CONV_CASE(32, 96);
     if (v.kc == 64) ME_CONV_CASE(32, 64);
     ME_CONV_CASE(32, 32);
+  } else if (v.nc == 128) {
+    if (v.kc == 256) ME_CONV_CASE(128, 256);
+    if (v.kc == 128) ME_CONV_CASE(128, 128);
+    if (v.kc == 96) ME_CONV_CASE(128, 96);
+    if (v.kc == 64) ME_CONV_CASE(128, 64);
+    ME_CONV_CASE(128, 32);
   } else {
     if (v.kc == 128) ME_CONV_CASE(64, 128);
     if (v.kc == 96) ME_CONV_CASE(64, 96);

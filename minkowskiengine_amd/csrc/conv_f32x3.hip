@@ -312,19 +312,38 @@ __global__ __launch_bounds__(NC * 4 * x3_group_shares(NC), 1) void k_conv_tile_f
   auto write_stage = [&](const Desc &d, const f32x4 (&st)[ITER][2], int32_t dv, int buf) {
     const int c0 = d.chunk * KC;
     __bf16 *base = s_a + buf * 3 * PLANE;
+    uint32_t flag = 0u;      // non-finite rows: conv_common.hpp (split3_flag / split3_fix)
 #pragma unroll
     for (int j = 0; j < ITER; ++j) {
       const int idx = j * NT + tid;
       const int r = idx / F8;
       const int ch = c0 + (idx % F8) * 8;
       u32x4 p1, p2, p3;
-      split3(st[j][0], st[j][1], p1, p2, p3);
+      split3_raw(st[j][0], st[j][1], p1, p2, p3);
+      flag = split3_flag(flag, p3);
       if (!EXACT && ch >= c_src) p1 = p2 = p3 = u32x4{0u, 0u, 0u, 0u};
       if (ITER * NT == CAP * F8 || r < CAP) {
         __bf16 *o = base + SL::off(r, idx % F8);
         *reinterpret_cast<u32x4 *>(o) = p1;
         *reinterpret_cast<u32x4 *>(o + PLANE) = p2;
         *reinterpret_cast<u32x4 *>(o + 2 * PLANE) = p3;
+      }
+    }
+    if (__builtin_expect(__any(split3_suspect(flag)), 0)) {   // rare: split again, exactly, over the first attempt
+#pragma unroll
+      for (int j = 0; j < ITER; ++j) {
+        const int idx = j * NT + tid;
+        const int r = idx / F8;
+        const int ch = c0 + (idx % F8) * 8;
+        u32x4 p1, p2, p3;
+        split3_fix(st[j][0], st[j][1], p1, p2, p3);
+        if (!EXACT && ch >= c_src) p1 = p2 = p3 = u32x4{0u, 0u, 0u, 0u};
+        if (ITER * NT == CAP * F8 || r < CAP) {
+          __bf16 *o = base + SL::off(r, idx % F8);
+          *reinterpret_cast<u32x4 *>(o) = p1;
+          *reinterpret_cast<u32x4 *>(o + PLANE) = p2;
+          *reinterpret_cast<u32x4 *>(o + 2 * PLANE) = p3;
+        }
       }
     }
     if (tid < CAP) s_dst[buf * CAP + tid] = dv;
@@ -762,19 +781,38 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void k_conv_tile_f32x3_ws(
     auto write_stage = [&](const Desc &d, const f32x4 (&st)[ITER][2], int32_t dv, int buf) {
       const int c0 = d.chunk * KC;
       __bf16 *base = s_a + buf * 3 * PLANE;
+      uint32_t flag = 0u;      // non-finite rows: conv_common.hpp (split3_flag / split3_fix)
 #pragma unroll
       for (int j = 0; j < ITER; ++j) {
         const int idx = j * NTP + ptid;
         const int r = idx / F8;
         const int ch = c0 + (idx % F8) * 8;
         u32x4 p1, p2, p3;
-        split3(st[j][0], st[j][1], p1, p2, p3);
+        split3_raw(st[j][0], st[j][1], p1, p2, p3);
+        flag = split3_flag(flag, p3);
         if (!EXACT && ch >= c_src) p1 = p2 = p3 = u32x4{0u, 0u, 0u, 0u};
         if (ITER * NTP == CAP * F8 || r < CAP) {
           __bf16 *o = base + SL::off(r, idx % F8);
           *reinterpret_cast<u32x4 *>(o) = p1;
           *reinterpret_cast<u32x4 *>(o + PLANE) = p2;
           *reinterpret_cast<u32x4 *>(o + 2 * PLANE) = p3;
+        }
+      }
+      if (__builtin_expect(__any(split3_suspect(flag)), 0)) {   // rare: split again, exactly, over the first attempt
+#pragma unroll
+        for (int j = 0; j < ITER; ++j) {
+          const int idx = j * NTP + ptid;
+          const int r = idx / F8;
+          const int ch = c0 + (idx % F8) * 8;
+          u32x4 p1, p2, p3;
+          split3_fix(st[j][0], st[j][1], p1, p2, p3);
+          if (!EXACT && ch >= c_src) p1 = p2 = p3 = u32x4{0u, 0u, 0u, 0u};
+          if (ITER * NTP == CAP * F8 || r < CAP) {
+            __bf16 *o = base + SL::off(r, idx % F8);
+            *reinterpret_cast<u32x4 *>(o) = p1;
+            *reinterpret_cast<u32x4 *>(o + PLANE) = p2;
+            *reinterpret_cast<u32x4 *>(o + 2 * PLANE) = p3;
+          }
         }
       }
       if (ptid < CAP) s_dst[buf * CAP + ptid] = dv;
@@ -1086,6 +1124,10 @@ int64_t me_conv_packed_weight_elems_f32x3(int64_t volume, int32_t c_src, int32_t
   if (volume <= 0 || c_src <= 0 || c_dst <= 0) return 0;
   const ConvVariantX3 v = conv_variant_f32x3(c_src, c_dst);
   return 3 * volume * align_up(c_src, v.kc) * align_up(c_dst, 16);
+}
+
+int32_t me_conv_pack_chunk_f32x3(int32_t c_src, int32_t c_dst) {
+  return (c_src > 0 && c_dst > 0) ? conv_variant_f32x3(c_src, c_dst).kc : 0;
 }
 
 int me_conv_pack_weights_f32x3(const float *w, int64_t volume, int32_t c_src, int32_t c_dst, int32_t transposed,

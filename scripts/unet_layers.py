@@ -7,6 +7,9 @@ import torch
 import minkowskiengine_amd as ME
 from minkowskiengine_amd import backend as MEB
 import minkunet as MU
+if os.environ.get("BF16_SHAPE"):     # "nc,kc": tuning override of the bf16 tile kernel's slab width / chunk depth
+    from minkowskiengine_amd import _lib
+    _lib.load().me_debug_set_bf16_shape(*[int(v) for v in os.environ["BF16_SHAPE"].split(",")])
 dev = torch.device("cuda:0")
 dt = torch.bfloat16 if os.environ.get("DTYPE", "bf16") == "bf16" else torch.float32
 coords = MU.synthetic_scene(200000, seed=0).to(dev)

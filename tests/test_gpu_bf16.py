@@ -187,3 +187,62 @@ def test_batch_fusion_is_bit_identical(device, monkeypatch, n, extent, cin, cout
         res[0 if fuse == "1" else 7] = (y.clone(), gi.clone())
     assert torch.equal(res[0][0], res[7][0]) and torch.equal(res[0][1], res[7][1])
     assert float(res[0][0].float().abs().max()) > 0
+
+
+@pytest.mark.parametrize("n,extent,D,cin,cout,ks,stride,dil", [c for c in BF16_CASES if c[3] % 8 or c[4] % 8])
+def test_bf16_odd_channels_without_padding(device, monkeypatch, n, extent, D, cin, cout, ks, stride, dil):
+    """Channel counts that are not multiples of 8 are zero-padded around the operator by default (convolution.py
+    _pad_channels); with the padding off the kernels' own scalar gather / store paths serve them: same results."""
+    from minkowskiengine_amd import convolution as MC
+    coords = make_cloud(n, extent, D, seed=n + cin, batch=2, negative=True)
+    res = {}
+    for pad in (True, False):
+        monkeypatch.setattr(MC, "_PAD_CHANNELS", pad)
+        conv, x, y, feats, gy = _run_layer(device, coords, cin, cout, ks, stride, dil)
+        res[pad] = (y.F.float().cpu().numpy(), x.F.grad.float().cpu().numpy(), conv.kernel.grad.cpu().numpy())
+        assert y.F.shape[1] == cout and x.F.grad.shape[1] == cin and conv.kernel.grad.shape[1:] == (cin, cout)
+    in_c = coords.numpy()
+    out_c = y.C.cpu().numpy()
+    _, km = O.kernel_map(in_c, out_c, O.make_region(D, ks, dil, 1))
+    w = conv.kernel.detach().float().cpu().numpy()
+    ref = O.conv_forward(feats.numpy(), w, km, len(out_c))
+    gi, gw = O.conv_backward(feats.numpy(), gy.numpy(), w, km)
+    for pad in (True, False):
+        assert_bf16_close(res[pad][0], ref, f"forward pad={pad}")
+        assert_bf16_close(res[pad][1], gi, f"grad_in pad={pad}")
+        assert_close(res[pad][2], gw)
+
+
+@pytest.mark.parametrize("cin,cout", [(256, 256), (128, 256), (64, 128), (384, 256)])
+def test_bf16_slab_width_does_not_change_a_bit(device, cin, cout):
+    """128-column workgroups (eight waves; the default where the output channels are a multiple of 128) against
+    64-column ones at the same source-channel chunk: the columns of a target row are independent sums in the same
+    order, so forward and input gradient are bit-identical; a deeper chunk (256) regroups the fp32 partial sums and
+    stays within the bf16 bar of the oracle."""
+    from minkowskiengine_amd import _lib, backend as MEB
+    lib = _lib.load()
+    coords = make_cloud(2500, 12, 3, seed=cin + cout, batch=2, negative=True)
+    mgr = MEB.CoordinateMapManagerGPU_c10()
+    key, _ = mgr.insert_and_map(coords.to(device), [1, 1, 1], "")
+    g = torch.Generator().manual_seed(3)
+    x = bf16_round(torch.rand(coords.shape[0], cin, generator=g) - 0.3)
+    gy = bf16_round(torch.rand(coords.shape[0], cout, generator=g) - 0.5)
+    w = bf16_round(torch.rand(27, cin, cout, generator=g) - 0.5)
+    res = {}
+    try:
+        for nc, kc in ((64, 128), (128, 128), (128, 0)):
+            lib.me_debug_set_bf16_shape(nc, kc)
+            # (plans and packed images depend on the shape: a fresh kernel map and fresh weight tensors per setting)
+            km = MEB._build_kernel_map(mgr._get(key), mgr._get(key), _lib.make_region(4, 0, [3] * 3, [1] * 3, [1] * 3))
+            wd = w.clone().to(device)
+            y = MEB._conv_forward(x.to(device).to(torch.bfloat16), wd, km)
+            gi = MEB._conv_target(gy.to(device).to(torch.bfloat16), wd, km, "in", km.n_in, name="d", transposed=True)
+            res[(nc, kc)] = (y.clone(), gi.clone())
+    finally:
+        lib.me_debug_set_bf16_shape(0, 0)
+    assert torch.equal(res[(64, 128)][0], res[(128, 128)][0]) and torch.equal(res[(64, 128)][1], res[(128, 128)][1])
+    _, okm = O.kernel_map(coords.numpy(), coords.numpy(), O.make_region(3, 3))
+    assert_bf16_close(res[(128, 0)][0].float().cpu().numpy(), O.conv_forward(x.numpy(), w.numpy(), okm, len(coords)),
+                      "forward, policy shape")
+    assert_bf16_close(res[(128, 0)][1].float().cpu().numpy(),
+                      O.conv_backward(x.numpy(), gy.numpy(), w.numpy(), okm)[0], "grad_in, policy shape")
