@@ -496,6 +496,16 @@ int me_bn_backward(const void *x_dev, const void *dy_dev, int32_t is_bf16, int64
                    const float *mean_dev, const float *rstd_dev, const float *gamma_dev, const float *beta_dev,
                    int32_t relu, void *dx_dev, float *grad_gamma_dev, float *grad_beta_dev, void *workspace_dev,
                    int64_t workspace_bytes, void *stream);
+/* Residual form (a ResNet block's `relu(bn(conv(x)) + skip)`): y = [relu] (T(x * a + b) + skip) in one pass, bit-identical
+ * to me_bn_apply followed by an addition and a ReLU; the backward pass masks dy where the stored output `yout` is not
+ * positive (relu != 0), writes the masked gradient to dskip (the residual branch's gradient; may be NULL) and dx. */
+int me_bn_apply_residual(const void *x_dev, const void *skip_dev, int32_t is_bf16, int64_t n, int32_t c,
+                         const float *mean_dev, const float *rstd_dev, const float *gamma_dev, const float *beta_dev,
+                         int32_t relu, void *y_dev, void *stream);
+int me_bn_backward_residual(const void *x_dev, const void *dy_dev, const void *yout_dev, int32_t is_bf16, int64_t n,
+                            int32_t c, const float *mean_dev, const float *rstd_dev, const float *gamma_dev,
+                            const float *beta_dev, int32_t relu, void *dx_dev, void *dskip_dev, float *grad_gamma_dev,
+                            float *grad_beta_dev, void *workspace_dev, int64_t workspace_bytes, void *stream);
 
 /* Plain VALU + atomics versions on the pair lists (debug cross-check only; never the default).
  * out / grad_in / grad_w must be zero-filled by the caller. */

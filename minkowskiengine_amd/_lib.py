@@ -108,6 +108,9 @@ SIGNATURES = {
     "me_bn_apply": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "me_bn_backward": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp,
                                       c_vp, c_i64, c_vp]),
+    "me_bn_apply_residual": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
+    "me_bn_backward_residual": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp,
+                                               c_vp, c_vp, c_vp, c_vp, c_i64, c_vp]),
     "me_coords_expand_region": (ctypes.c_int, [c_vp, c_i64, c_i32, _P_REGION, _P_I32, c_vp, c_vp, c_vp]),
     "me_coords_quantize_labels": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp]),
     "me_segment_sum_f32": (ctypes.c_int, [c_vp, c_i32, c_vp, c_vp, c_i64, c_i32, c_vp, c_vp]),

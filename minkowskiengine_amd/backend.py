@@ -1051,8 +1051,13 @@ def _use_split(lib, c_src, c_dst):
 
 
 _ALGO = os.environ.get("ME_AMD_CONV_ALGO", "mfma")  # "naive" = VALU/atomics cross-check kernels
-# weight gradient on a side stream, concurrent with the input gradient of the same layer (_conv_backward); "0": one stream
-_WGRAD_STREAM = os.environ.get("ME_AMD_WGRAD_STREAM", "1") != "0"
+# Weight gradient on a side stream, concurrent with the input gradient of the same layer (_conv_backward).  OPT-IN
+# ("1"): measured in round 3 (profiles/r03_wgrad_side_stream.md) it does not pay — both gradient launches already
+# occupy every CU (one to three workgroups per CU by LDS), so they time-share instead of overlapping: MinkUNet34C bf16
+# as a hipGraph 14.74 ms without, 14.62 - 14.86 ms with (any row threshold); the headline layer loses 3.5 % (0.342 vs
+# 0.330 ms), MinkUNet34C fp32 1 ms; only config 5 gains 3 %.  ME_AMD_WGRAD_STREAM_MAX_ROWS bounds it to small maps.
+_WGRAD_STREAM = os.environ.get("ME_AMD_WGRAD_STREAM", "0") != "0"
+_WGRAD_STREAM_MAX_ROWS = int(os.environ.get("ME_AMD_WGRAD_STREAM_MAX_ROWS", "100000000"))
 _SIDE_STREAMS = {}
 
 
@@ -1232,18 +1237,41 @@ class _WeightPacker:
         self._repack_stale(ent, kernel)
         return ent.packed
 
+    def _pack_one(self, ent, version):
+        """one image through the single-layer pack entry points, which take the geometry as arguments: no job table
+        to upload (an upload is not capturable into a hipGraph either)"""
+        lib = _lib.load()
+        job = ent.job
+        with _on(self.dev):
+            if job.mode == _lib.ME_PACK_BF16:
+                _lib.check(lib.me_conv_pack_weights_bf16(job.w, job.w_is_f32, job.volume, job.c_src, job.c_dst,
+                                                         job.transposed, job.wp, _stream(self.dev)))
+            else:
+                _lib.check(lib.me_conv_pack_weights_f32x3(job.w, job.volume, job.c_src, job.c_dst, job.transposed,
+                                                          job.wp, _stream(self.dev)))
+        ent.version = version
+
     def _repack_stale(self, wanted, kernel):
+        # a NEW entry (first use of a weight tensor, or a temporary one — a padded / reshaped copy made per step) is
+        # packed on its own, so that the set of established images — and with it the cached job table — repeats from
+        # step to step
+        if wanted.version is None:
+            self._pack_one(wanted, kernel._version)
         stale = []
         for ent in self.entries.values():
-            if ent is wanted:
+            if ent.version is None:
                 continue
-            t = ent.ref()
-            if t is not None and t.data_ptr() == ent.ptr and ent.version is not None and t._version != ent.version:
+            t = kernel if ent is wanted else ent.ref()
+            if t is not None and t.data_ptr() == ent.ptr and t._version != ent.version:
                 stale.append((ent, t._version))
-        stale.append((wanted, kernel._version))
+        if not stale:
+            return
         if len(stale) > 1024:
             stale = stale[-1024:]
         lib = _lib.load()
+        if len(stale) == 1:
+            self._pack_one(stale[0][0], stale[0][1])
+            return
         key = tuple(id(e) for e, _ in stale)
         if key != self.table_key:
             jobs = (_lib.MePackJob * len(stale))(*[e.job for e, _ in stale])
@@ -1380,12 +1408,11 @@ def _conv_backward(in_feat, grad_out, kernel, km, algo=None, need_grad_in=True):
                                                       _stream(dev)))
         return grad_in, grad_w
     # wgrad: always accumulated and reduced in fp32; handed back in the kernel's dtype.  The two gradients of a layer
-    # are independent (both read grad_out; dgrad reads the weights, wgrad the layer's input), and on all but the
-    # largest maps neither launch fills the 256 CUs for its whole duration (a (tile, offset) chain in one, a few
-    # hundred pair ranges in the other): the weight gradient goes to a SIDE STREAM and runs next to the input
-    # gradient.  Fork / join inside this call (side waits for what the current stream has produced; the current stream
-    # waits for the side stream before anything downstream can touch grad_w), so callers — autograd's AccumulateGrad,
-    # DDP's bucket hooks, a hipGraph capture — see plain stream-ordered tensors.
+    # are independent (both read grad_out; dgrad reads the weights, wgrad the layer's input); with ME_AMD_WGRAD_STREAM=1
+    # the weight gradient goes to a SIDE STREAM next to the input gradient (opt-in: see _WGRAD_STREAM).  Fork / join
+    # inside this call (side waits for what the current stream has produced; the current stream waits for the side
+    # stream before anything downstream can touch grad_w), so callers — autograd's AccumulateGrad, DDP's bucket
+    # hooks, a hipGraph capture — see plain stream-ordered tensors.
     grad_w = torch.empty(kernel.shape, dtype=torch.float32, device=dev)
     cfg = _wgrad_launch_cfg(km, c_in, c_out, bf16)
     koffs, wsb, p_in, p_out, p_koffs = cfg
@@ -1394,28 +1421,34 @@ def _conv_backward(in_feat, grad_out, kernel, km, algo=None, need_grad_in=True):
             koffs, volume, c_in, c_out))
     fn = lib.me_conv_wgrad_bf16 if bf16 else lib.me_conv_wgrad_f32
 
-    def wgrad():
-        ws = _workspace(wsb, dev)      # (allocated under the stream that uses it)
-        stream = _stream(dev)
-        with _on(dev):
-            _timed("conv_wgrad", dev, lambda: _lib.check(fn(
-                in_feat.data_ptr(), in_feat.shape[0], c_in, grad_out.data_ptr(), grad_out.shape[0], c_out, p_in, p_out,
-                koffs, p_koffs, volume,
-                grad_w.data_ptr(), ws.data_ptr(), ws.numel(), stream)), flops=2.0 * km.n_pairs * c_in * c_out)
+    # (the workspace comes from the current stream's pool and is used on the side stream: safe, because the current
+    # stream joins the side stream below before anything else can be enqueued on it)
+    ws = _workspace(wsb, dev)
 
-    side = _side_stream(dev) if (_WGRAD_STREAM and km.n_pairs > 0) else None
+    def wgrad(stream):
+        with _on(dev):
+            launch = lambda: _lib.check(fn(
+                in_feat.data_ptr(), in_feat.shape[0], c_in, grad_out.data_ptr(), grad_out.shape[0], c_out, p_in, p_out,
+                koffs, p_koffs, volume, grad_w.data_ptr(), ws.data_ptr(), ws.numel(), stream))
+            if KERNEL_TIMER is None:
+                launch()
+            else:   # (per-launch HIP events belong on the stream of the launch)
+                with torch.cuda.stream(side) if side is not None else _on(dev):
+                    _timed("conv_wgrad", dev, launch, flops=2.0 * km.n_pairs * c_in * c_out)
+
+    side = _side_stream(dev) if (_WGRAD_STREAM and need_grad_in and km.n_pairs > 0 and
+                                 max(km.n_in, km.n_out) <= _WGRAD_STREAM_MAX_ROWS) else None
     if side is not None:
         main = torch.cuda.current_stream(dev)
         side.wait_stream(main)
-        with torch.cuda.stream(side):
-            wgrad()
+        wgrad(side.cuda_stream)
     # dgrad: the same target-stationary kernel; the weights are packed transposed per offset
     grad_in = _conv_target(grad_out, kernel, km, "in", km.n_in, name="conv_dgrad", transposed=True) \
         if need_grad_in else None
     if side is not None:
         main.wait_stream(side)
     else:
-        wgrad()
+        wgrad(_stream(dev))
     return grad_in, grad_w if kernel.dtype == torch.float32 else grad_w.to(kernel.dtype)
 
 
@@ -1789,6 +1822,44 @@ def bn_apply(x, mean, rstd, gamma, beta, relu=False):
                                    _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), 1 if relu else 0, _ptr(y),
                                    _stream(dev)))
     return y
+
+
+def bn_apply_residual(x, skip, mean, rstd, gamma, beta, relu=True):
+    """y = [relu] (bn(x) + skip): batch-norm apply, residual addition and ReLU of a ResNet block in one pass
+    (bit-identical to the three separate kernels)."""
+    _bn_check(x)
+    _check(skip.shape == x.shape and skip.dtype == x.dtype and skip.is_contiguous(), "residual branch must match x")
+    lib = _lib.load()
+    dev = x.device
+    y = torch.empty_like(x)
+    with _on(dev):
+        _lib.check(lib.me_bn_apply_residual(_ptr(x), _ptr(skip), 1 if x.dtype == torch.bfloat16 else 0,
+                                            int(x.shape[0]), int(x.shape[1]), _ptr(mean), _ptr(rstd), _ptr(gamma),
+                                            _ptr(beta), 1 if relu else 0, _ptr(y), _stream(dev)))
+    return y
+
+
+def bn_backward_residual(x, dy, yout, mean, rstd, gamma, beta=None, relu=True, need_dskip=True):
+    """-> (dx, dskip, grad_gamma, grad_beta) of y = [relu] (bn(x) + skip); dskip is the (ReLU-masked) incoming
+    gradient, dy itself without ReLU."""
+    _bn_check(x)
+    lib = _lib.load()
+    dev = x.device
+    n, c = int(x.shape[0]), int(x.shape[1])
+    if dy.dtype != x.dtype:
+        dy = dy.to(x.dtype)
+    dy = dy.contiguous()
+    dx = torch.empty_like(x)
+    dskip = torch.empty_like(x) if (need_dskip and relu) else None
+    gg = torch.empty(c, dtype=torch.float32, device=dev)
+    gb = torch.empty(c, dtype=torch.float32, device=dev)
+    ws = _workspace(int(lib.me_bn_workspace_bytes(n, c)), dev)
+    with _on(dev):
+        _lib.check(lib.me_bn_backward_residual(_ptr(x), _ptr(dy), _ptr(yout), 1 if x.dtype == torch.bfloat16 else 0, n,
+                                               c, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), 1 if relu else 0,
+                                               _ptr(dx), _ptr(dskip), _ptr(gg), _ptr(gb), _ptr(ws), ws.numel(),
+                                               _stream(dev)))
+    return dx, (dskip if relu else dy) if need_dskip else None, gg, gb
 
 
 def bn_backward(x, dy, mean, rstd, gamma, beta=None, relu=False):

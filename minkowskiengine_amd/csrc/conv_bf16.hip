@@ -250,7 +250,9 @@ __global__ __launch_bounds__(NC * 4, conv_bf16_waves_per_simd(NC, KC)) void k_co
     const char *pb = reinterpret_cast<const char *>(plan_src + (int64_t)g0 * 16);
 #pragma unroll
     for (int j = 0; j < ITER; ++j)
-      sidx[j] = *reinterpret_cast<const int32_t *>(pb + (unsigned)(((j * NT + tid) / F8) * 4));
+      sidx[j] = *reinterpret_cast<const int32_t *>(
+          pb + (unsigned)(min((j * NT + tid) / F8, ME_MAX_BATCH_GROUPS * 16 - 1) * 4));   // (eight-wave workgroups
+                                                                     // have more threads than a 64-row window has pieces)
   };
   const char *srcb = reinterpret_cast<const char *>(src);
   const unsigned row_bytes = (unsigned)c_src * 2u;

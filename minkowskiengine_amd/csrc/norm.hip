@@ -162,11 +162,15 @@ __global__ __launch_bounds__(256) void k_bn_final(const float *__restrict__ part
 constexpr int kBnRowsPerThread = 8;   // fully unrolled: 8 rows in flight per thread (2 or 4 with more workgroups
                                       // measured 2x slower: the loads in flight per thread matter, not the grid size)
 
+// `skip` (optional): the residual branch of a ResNet block — y = relu(x * a + b + skip) in ONE pass instead of a
+// batch-norm apply, an addition and a ReLU (seven passes over the matrix -> three; MinkUNet34C has 23 such blocks).
+// The normalised value is rounded to T before the addition and the sum is rounded again, exactly as the separate
+// kernels do (the fused result is bit-identical to them).
 template <typename T, int V>
 __global__ __launch_bounds__(256) void k_bn_apply(const T *__restrict__ x, int64_t n, int c,
                                                  const float *__restrict__ mean, const float *__restrict__ rstd,
                                                  const float *__restrict__ gamma, const float *__restrict__ beta,
-                                                 T *__restrict__ y, int relu) {
+                                                 T *__restrict__ y, int relu, const T *__restrict__ skip) {
   const int P = c / V;
   const int W = min(P, (int)blockDim.x);
   const int R = max(1, (int)blockDim.x / P);
@@ -185,10 +189,20 @@ __global__ __launch_bounds__(256) void k_bn_apply(const T *__restrict__ x, int64
       const int64_t r = r0 + rl + (int64_t)i * R;
       if (r < n) {
         Row<T, V> t = load_row<T, V>(x + r * c + p * V);
+        if (skip != nullptr) {
+          const Row<T, V> sk = load_row<T, V>(skip + r * c + p * V);
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-          t.v[j] = t.v[j] * a[j] + b[j];
-          if (relu) t.v[j] = fmaxf(t.v[j], 0.f);
+          for (int j = 0; j < V; ++j) {
+            const float z = (float)(T)(t.v[j] * a[j] + b[j]);    // what the unfused apply kernel would have stored
+            t.v[j] = (float)(T)(z + sk.v[j]);                     // ... and the unfused addition
+            if (relu) t.v[j] = fmaxf(t.v[j], 0.f);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < V; ++j) {
+            t.v[j] = t.v[j] * a[j] + b[j];
+            if (relu) t.v[j] = fmaxf(t.v[j], 0.f);
+          }
         }
         store_row<T, V>(y + r * c + p * V, t);
       }
@@ -205,7 +219,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_partial(const T *__restrict__ x,
                                                        const float *__restrict__ gamma,
                                                        const float *__restrict__ beta, int relu,
                                                        float *__restrict__ part_dy,
-                                                       float *__restrict__ part_dyx) {
+                                                       float *__restrict__ part_dyx, const T *__restrict__ yout) {
   extern __shared__ float s_red[];  // [R][2][c]
   const int P = c / V;
   const int R = max(1, (int)blockDim.x / P);
@@ -229,11 +243,15 @@ __global__ __launch_bounds__(256) void k_bn_bwd_partial(const T *__restrict__ x,
       for (int64_t r = r0 + rl; r < r1; r += R) {
         const Row<T, V> tx = load_row<T, V>(x + r * c + p * V);
         const Row<T, V> tg = load_row<T, V>(dy + r * c + p * V);
+        Row<T, V> ty;
+        if (yout != nullptr) ty = load_row<T, V>(yout + r * c + p * V);
 #pragma unroll
         for (int j = 0; j < V; ++j) {
           const float xh = (tx.v[j] - m[j]) * rs[j];
-          // fused ReLU: the gradient passes where the forward output xh * gamma + beta was positive
-          const float g = (relu && !(xh * ga[j] + be[j] > 0.f)) ? 0.f : tg.v[j];
+          // fused ReLU: the gradient passes where the forward output was positive — xh * gamma + beta recomputed, or
+          // (residual form: the output also holds the skip branch) the stored output itself
+          const bool pass = yout != nullptr ? ty.v[j] > 0.f : (xh * ga[j] + be[j] > 0.f);
+          const float g = (relu && !pass) ? 0.f : tg.v[j];
           s1[j] += g;
           s2[j] += g * xh;
         }
@@ -297,7 +315,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T *__restrict__ x, c
                                                      const float *__restrict__ gamma,
                                                      const float *__restrict__ sum_dy,
                                                      const float *__restrict__ sum_dyx, T *__restrict__ dx,
-                                                     const float *__restrict__ beta, int relu) {
+                                                     const float *__restrict__ beta, int relu,
+                                                     const T *__restrict__ yout, T *__restrict__ dskip) {
   const int P = c / V;
   const int W = min(P, (int)blockDim.x);
   const int R = max(1, (int)blockDim.x / P);
@@ -325,13 +344,17 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T *__restrict__ x, c
       if (r < n) {
         const Row<T, V> tx = load_row<T, V>(x + r * c + p * V);
         const Row<T, V> tg = load_row<T, V>(dy + r * c + p * V);
-        Row<T, V> out;
+        Row<T, V> ty, out, gs;
+        if (yout != nullptr) ty = load_row<T, V>(yout + r * c + p * V);
 #pragma unroll
         for (int j = 0; j < V; ++j) {
-          const float g = (relu && !(tx.v[j] * za[j] + zb[j] > 0.f)) ? 0.f : tg.v[j];
+          const bool pass = yout != nullptr ? ty.v[j] > 0.f : (tx.v[j] * za[j] + zb[j] > 0.f);
+          const float g = (relu && !pass) ? 0.f : tg.v[j];
+          gs.v[j] = g;
           out.v[j] = g * ca[j] + tx.v[j] * cb[j] + cc[j];
         }
         store_row<T, V>(dx + r * c + p * V, out);
+        if (dskip != nullptr) store_row<T, V>(dskip + r * c + p * V, gs);   // gradient of the residual branch
       }
     }
   }
@@ -368,15 +391,15 @@ static int bn_stats(const T *x, int64_t n, int c, float eps, float momentum, flo
 
 template <typename T>
 static int bn_apply(const T *x, int64_t n, int c, const float *mean, const float *rstd, const float *gamma,
-                    const float *beta, T *y, int relu, hipStream_t stream) {
+                    const float *beta, T *y, int relu, hipStream_t stream, const T *skip = nullptr) {
   constexpr int W = 16 / (int)sizeof(T);  // channels per 16-byte access
-  const bool aligned = (uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0;
+  const bool aligned = (uintptr_t)x % 16 == 0 && (uintptr_t)y % 16 == 0 && (uintptr_t)skip % 16 == 0;
   const int v = (aligned && c % W == 0) ? W : ((aligned && c % 4 == 0) ? 4 : 1);
   const int pieces = c / v;
   const dim3 grid((unsigned)ceil_div(n, (int64_t)(pieces >= 256 ? 1 : 256 / pieces) * kBnRowsPerThread));
-  if (v == W) hipLaunchKernelGGL((k_bn_apply<T, W>), grid, dim3(256), 0, stream, x, n, c, mean, rstd, gamma, beta, y, relu);
-  else if (v == 4) hipLaunchKernelGGL((k_bn_apply<T, 4>), grid, dim3(256), 0, stream, x, n, c, mean, rstd, gamma, beta, y, relu);
-  else hipLaunchKernelGGL((k_bn_apply<T, 1>), grid, dim3(256), 0, stream, x, n, c, mean, rstd, gamma, beta, y, relu);
+  if (v == W) hipLaunchKernelGGL((k_bn_apply<T, W>), grid, dim3(256), 0, stream, x, n, c, mean, rstd, gamma, beta, y, relu, skip);
+  else if (v == 4) hipLaunchKernelGGL((k_bn_apply<T, 4>), grid, dim3(256), 0, stream, x, n, c, mean, rstd, gamma, beta, y, relu, skip);
+  else hipLaunchKernelGGL((k_bn_apply<T, 1>), grid, dim3(256), 0, stream, x, n, c, mean, rstd, gamma, beta, y, relu, skip);
   ME_LAUNCH_CHECK();
   return 0;
 }
@@ -384,11 +407,12 @@ static int bn_apply(const T *x, int64_t n, int c, const float *mean, const float
 template <typename T>
 static int bn_backward(const T *x, const T *dy, int64_t n, int c, const float *mean, const float *rstd,
                        const float *gamma, const float *beta, int relu, T *dx, float *grad_gamma, float *grad_beta,
-                       float *ws, hipStream_t stream) {
+                       float *ws, hipStream_t stream, const T *yout = nullptr, T *dskip = nullptr) {
   const int chunks = bn_chunks(n);
   float *pa = ws, *pb = ws + (int64_t)chunks * c;
   constexpr int W = 16 / (int)sizeof(T);
-  const bool vec = (c % 4) == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)dy % 16 == 0 && (uintptr_t)dx % 16 == 0;
+  const bool vec = (c % 4) == 0 && (uintptr_t)x % 16 == 0 && (uintptr_t)dy % 16 == 0 && (uintptr_t)dx % 16 == 0 &&
+                   (uintptr_t)yout % 16 == 0 && (uintptr_t)dskip % 16 == 0;
   const int v = (vec && c % W == 0) ? W : (vec ? 4 : 1);
   const int P = c / v;
   const int R = P >= 256 ? 1 : 256 / P;
@@ -396,26 +420,26 @@ static int bn_backward(const T *x, const T *dy, int64_t n, int c, const float *m
   ME_CHECK(lds <= 64 * 1024, "channel count too large for the batch-norm kernels");
   if (v == W)
     hipLaunchKernelGGL((k_bn_bwd_partial<T, W>), dim3(chunks), dim3(256), lds, stream, x, dy, n, c, chunks, mean, rstd,
-                       gamma, beta, relu, pa, pb);
+                       gamma, beta, relu, pa, pb, yout);
   else if (v == 4)
     hipLaunchKernelGGL((k_bn_bwd_partial<T, 4>), dim3(chunks), dim3(256), lds, stream, x, dy, n, c, chunks, mean, rstd,
-                       gamma, beta, relu, pa, pb);
+                       gamma, beta, relu, pa, pb, yout);
   else
     hipLaunchKernelGGL((k_bn_bwd_partial<T, 1>), dim3(chunks), dim3(256), lds, stream, x, dy, n, c, chunks, mean, rstd,
-                       gamma, beta, relu, pa, pb);
+                       gamma, beta, relu, pa, pb, yout);
   hipLaunchKernelGGL(k_bn_bwd_final, dim3((unsigned)ceil_div(c, 4)), dim3(256), 0, stream, pa, pb, c, chunks,
                      grad_beta, grad_gamma);
   const int pieces = c / v;
   const dim3 grid((unsigned)ceil_div(n, (int64_t)(pieces >= 256 ? 1 : 256 / pieces) * kBnRowsPerThread));
   if (v == W)
     hipLaunchKernelGGL((k_bn_bwd_apply<T, W>), grid, dim3(256), 0, stream, x, dy, n, c, mean, rstd, gamma, grad_beta,
-                       grad_gamma, dx, beta, relu);
+                       grad_gamma, dx, beta, relu, yout, dskip);
   else if (v == 4)
     hipLaunchKernelGGL((k_bn_bwd_apply<T, 4>), grid, dim3(256), 0, stream, x, dy, n, c, mean, rstd, gamma, grad_beta,
-                       grad_gamma, dx, beta, relu);
+                       grad_gamma, dx, beta, relu, yout, dskip);
   else
     hipLaunchKernelGGL((k_bn_bwd_apply<T, 1>), grid, dim3(256), 0, stream, x, dy, n, c, mean, rstd, gamma, grad_beta,
-                       grad_gamma, dx, beta, relu);
+                       grad_gamma, dx, beta, relu, yout, dskip);
   ME_LAUNCH_CHECK();
   return 0;
 }
@@ -454,6 +478,38 @@ int me_bn_apply(const void *x, int32_t is_bf16, int64_t n, int32_t c, const floa
                             reinterpret_cast<__bf16 *>(y), relu, stream);
   return bn_apply<float>(reinterpret_cast<const float *>(x), n, c, mean, rstd, gamma, beta,
                          reinterpret_cast<float *>(y), relu, stream);
+}
+
+int me_bn_apply_residual(const void *x, const void *skip, int32_t is_bf16, int64_t n, int32_t c, const float *mean,
+                         const float *rstd, const float *gamma, const float *beta, int32_t relu, void *y,
+                         void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ME_CHECK(c > 0 && skip != nullptr, "invalid channel count / missing residual branch");
+  if (n == 0) return 0;
+  if (is_bf16)
+    return bn_apply<__bf16>(reinterpret_cast<const __bf16 *>(x), n, c, mean, rstd, gamma, beta,
+                            reinterpret_cast<__bf16 *>(y), relu, stream, reinterpret_cast<const __bf16 *>(skip));
+  return bn_apply<float>(reinterpret_cast<const float *>(x), n, c, mean, rstd, gamma, beta,
+                         reinterpret_cast<float *>(y), relu, stream, reinterpret_cast<const float *>(skip));
+}
+
+int me_bn_backward_residual(const void *x, const void *dy, const void *yout, int32_t is_bf16, int64_t n, int32_t c,
+                            const float *mean, const float *rstd, const float *gamma, const float *beta, int32_t relu,
+                            void *dx, void *dskip, float *grad_gamma, float *grad_beta, void *workspace,
+                            int64_t workspace_bytes, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ME_CHECK(n > 0 && c > 0, "batch norm needs at least one row and one channel");
+  ME_CHECK(workspace_bytes >= me_bn_workspace_bytes(n, c), "workspace too small");
+  ME_CHECK(!relu || yout != nullptr, "the fused ReLU of the residual form needs the forward output");
+  float *ws = reinterpret_cast<float *>(workspace);
+  if (is_bf16)
+    return bn_backward<__bf16>(reinterpret_cast<const __bf16 *>(x), reinterpret_cast<const __bf16 *>(dy), n, c, mean,
+                               rstd, gamma, beta, relu, reinterpret_cast<__bf16 *>(dx), grad_gamma, grad_beta, ws,
+                               stream, relu ? reinterpret_cast<const __bf16 *>(yout) : nullptr,
+                               reinterpret_cast<__bf16 *>(dskip));
+  return bn_backward<float>(reinterpret_cast<const float *>(x), reinterpret_cast<const float *>(dy), n, c, mean, rstd,
+                            gamma, beta, relu, reinterpret_cast<float *>(dx), grad_gamma, grad_beta, ws, stream,
+                            relu ? reinterpret_cast<const float *>(yout) : nullptr, reinterpret_cast<float *>(dskip));
 }
 
 int me_bn_backward(const void *x, const void *dy, int32_t is_bf16, int64_t n, int32_t c, const float *mean,

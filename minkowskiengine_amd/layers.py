@@ -11,6 +11,7 @@ from . import backend as MEB
 from .sparse_tensor import SparseTensor
 
 _TORCH_BN = os.environ.get("ME_AMD_TORCH_BN", "0") != "0"   # 1: torch's batch-norm kernels (A/B timing)
+_FUSE_RESIDUAL = os.environ.get("ME_AMD_FUSE_RESIDUAL", "1") != "0"   # bn + residual add + relu in one kernel
 
 
 def _rewrap(x, feats):
@@ -41,6 +42,34 @@ class _BatchNormTrainFunction(Function):
         gw = gg.to(ctx.param_dtype) if ctx.param_dtype is not None else None
         gbias = gb.to(ctx.param_dtype) if ctx.has_bias else None
         return dx, gw, gbias, None, None, None, None, None, None
+
+
+class _BatchNormResidualFunction(Function):
+    """y = [relu] (batch_norm(x) + skip) on the fused kernels of csrc/norm.hip (me_bn_apply_residual /
+    me_bn_backward_residual): the tail of a ResNet block in one pass per direction."""
+
+    @staticmethod
+    def forward(ctx, x, skip, weight, bias, running_mean, running_var, momentum, eps, relu, num_batches_tracked):
+        x = x.contiguous()
+        skip = skip.contiguous()
+        w32 = weight.float() if weight is not None else None
+        b32 = bias.float() if bias is not None else None
+        mean, rstd = MEB.bn_stats(x, eps, momentum, running_mean, running_var, num_batches_tracked)
+        y = MEB.bn_apply_residual(x, skip, mean, rstd, w32, b32, relu)
+        ctx.save_for_backward(x, y if relu else None, mean, rstd, w32, b32)
+        ctx.param_dtype = weight.dtype if weight is not None else None
+        ctx.has_bias = bias is not None
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, mean, rstd, w32, b32 = ctx.saved_tensors
+        dx, dskip, gg, gb = MEB.bn_backward_residual(x, dy, y, mean, rstd, w32, b32, ctx.relu,
+                                                     need_dskip=ctx.needs_input_grad[1])
+        gw = gg.to(ctx.param_dtype) if ctx.param_dtype is not None else None
+        gbias = gb.to(ctx.param_dtype) if ctx.has_bias else None
+        return dx, dskip, gw, gbias, None, None, None, None, None, None
 
 
 class MinkowskiBatchNorm(nn.Module):
@@ -90,6 +119,27 @@ class MinkowskiBatchNorm(nn.Module):
             y = (f * a.to(f.dtype) + b.to(f.dtype)) if f.requires_grad else \
                 MEB.bn_apply(f.contiguous(), bn.running_mean, rstd, bn.weight.float() if bn.weight is not None else None,
                              bn.bias.float() if bn.bias is not None else None)
+        return _rewrap(input, y)
+
+    def forward_residual(self, input, skip, relu=True):
+        """[relu] (self(input) + skip) — the tail of a ResNet block (reference: modules/resnet_block.py:62-75 applies
+        norm, `out += residual`, relu as three operators).  Training mode on the GPU: one fused kernel per direction,
+        bit-identical to the separate operators; anything else falls back to them."""
+        assert input.coordinate_map_key == skip.coordinate_map_key, "residual add needs a shared coordinate map"
+        f, bn = input.F, self.bn
+        fused = (_FUSE_RESIDUAL and self._native(f) and (bn.training or not bn.track_running_stats)
+                 and skip.F.dtype == f.dtype and skip.F.shape == f.shape)
+        if not fused:
+            out = self.forward(input)
+            y = out.F + skip.F
+            return _rewrap(input, torch.relu(y) if relu else y)
+        rm = bn.running_mean if (bn.training and bn.track_running_stats) else None
+        rv = bn.running_var if (bn.training and bn.track_running_stats) else None
+        nbt = bn.num_batches_tracked if rm is not None else None
+        if nbt is not None and (nbt.dtype != torch.int64 or not nbt.is_cuda):
+            nbt.add_(1)
+            nbt = None
+        y = _BatchNormResidualFunction.apply(f, skip.F, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps, bool(relu), nbt)
         return _rewrap(input, y)
 
     def __repr__(self):

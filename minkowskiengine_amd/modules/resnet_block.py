@@ -14,6 +14,14 @@ def _add(a, b):
     return SparseTensor(a.F + b.F, coordinate_map_key=a.coordinate_map_key, coordinate_manager=a.coordinate_manager)
 
 
+def _norm_add_relu(norm, x, skip, relu):
+    """relu(norm(x) + skip): one fused kernel per direction when `norm` is this package's batch norm in training mode
+    (layers.MinkowskiBatchNorm.forward_residual), the three separate operators otherwise."""
+    if type(norm) is MinkowskiBatchNorm and type(relu) is MinkowskiReLU:
+        return norm.forward_residual(x, skip, relu=True)
+    return relu(_add(norm(x), skip))
+
+
 class BasicBlock(nn.Module):
     expansion = 1
 
@@ -32,9 +40,8 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         out = self.relu(self.norm1(self.conv1(x)))
-        out = self.norm2(self.conv2(out))
         skip = x if self.downsample is None else self.downsample(x)
-        return self.relu(_add(out, skip))
+        return _norm_add_relu(self.norm2, self.conv2(out), skip, self.relu)
 
 
 class Bottleneck(nn.Module):
@@ -57,6 +64,5 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         out = self.relu(self.norm1(self.conv1(x)))
         out = self.relu(self.norm2(self.conv2(out)))
-        out = self.norm3(self.conv3(out))
         skip = x if self.downsample is None else self.downsample(x)
-        return self.relu(_add(out, skip))
+        return _norm_add_relu(self.norm3, self.conv3(out), skip, self.relu)

@@ -29,9 +29,9 @@ orig_target, orig_bwd = MEB._conv_target, MEB._conv_backward
 def target(src, kernel, km, tgt, n_tgt, name="conv_target", transposed=False):
     CUR[0] = (int(kernel.shape[0]), int(kernel.shape[1]), int(kernel.shape[2]), km.n_in, km.n_out, km.n_pairs)
     return orig_target(src, kernel, km, tgt, n_tgt, name=name, transposed=transposed)
-def bwd(in_feat, grad_out, kernel, km, algo=None):
+def bwd(in_feat, grad_out, kernel, km, algo=None, **kw):
     CUR[0] = (int(kernel.shape[0]), int(kernel.shape[1]), int(kernel.shape[2]), km.n_in, km.n_out, km.n_pairs)
-    return orig_bwd(in_feat, grad_out, kernel, km, algo)
+    return orig_bwd(in_feat, grad_out, kernel, km, algo, **kw)
 def step():
     opt.zero_grad(set_to_none=True)
     crit(net(x).F.float(), labels).backward()

@@ -130,3 +130,36 @@ def test_fused_batch_norm_relu(device, dtype):
     bn.eval()
     out = relu(bn(ME.SparseTensor(x.to(device), coords.to(device))))
     assert float(out.F.min()) >= 0.0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n,c", [(5000, 32), (3001, 96), (700, 256), (2500, 20)])
+def test_fused_norm_add_relu_is_bit_identical_to_the_three_operators(device, monkeypatch, dtype, n, c):
+    """relu(bn(x) + skip) — the tail of a ResNet block — runs as ONE kernel per direction
+    (MinkowskiBatchNorm.forward_residual, csrc/norm.hip k_bn_apply / k_bn_bwd_* with the residual arguments).  Output,
+    both input gradients, the parameter gradients and the running statistics must equal those of batch norm, addition
+    and ReLU run as separate operators, bit for bit (same arithmetic, same roundings, same summation order)."""
+    import minkowskiengine_amd as ME
+    from minkowskiengine_amd import layers as L
+    g = torch.Generator().manual_seed(n + c)
+    coords = make_cloud(n, 40, 3, seed=c).to(device)
+    x0 = (torch.randn(n, c, generator=g) * 2).to(dtype)
+    s0 = torch.randn(n, c, generator=g).to(dtype)
+    gy = torch.randn(n, c, generator=g).to(dtype).to(device)
+    w, b = torch.rand(c, generator=g) + 0.5, torch.rand(c, generator=g) - 0.5
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(L, "_FUSE_RESIDUAL", fused)
+        bn = ME.MinkowskiBatchNorm(c).to(device)
+        with torch.no_grad():
+            bn.bn.weight.copy_(w)
+            bn.bn.bias.copy_(b)
+        x = x0.to(device).requires_grad_(True)
+        s = s0.to(device).requires_grad_(True)
+        y = bn.forward_residual(ME.SparseTensor(x, coords), ME.SparseTensor(s, coords), relu=True)
+        y.F.backward(gy)
+        res[fused] = (y.F.detach(), x.grad, s.grad, bn.bn.weight.grad, bn.bn.bias.grad, bn.bn.running_mean.clone(),
+                      bn.bn.running_var.clone())
+    assert float((res[True][0] == 0).float().mean()) > 0.2          # the ReLU does mask something
+    for a, b_ in zip(res[True], res[False]):
+        assert torch.equal(a, b_)
