@@ -1,9 +1,9 @@
-"""`MinkowskiEngineBackend._C` — the module object IS `minkowskiengine_amd.backend` (same enums, CoordinateMapKey,
-CoordinateMapManagerGPU_c10 / _default, <Op>{Forward,Backward}GPU functions as pybind/extern.hpp:515-838 registers
-for the hot path).  Operators outside the hot path (interpolation, channelwise convolution, spmm,
-the CPU operators) are absent: `get_minkowski_function` (MinkowskiCommon.py:110-120) raises for them."""
+"""`MinkowskiEngineBackend._C` — the operator module the reference's Python package imports (setup.py:312,
+MinkowskiEngine/__init__.py): here it IS this repository's operator module — the native C++ extension
+(minkowskiengine_amd/_me_host.so, csrc_host/) when it is built, else its Python twin minkowskiengine_amd.backend (same
+enums, CoordinateMapKey, CoordinateMapManagerGPU_*, <Op>{Forward,Backward}GPU names, argument order and meaning)."""
 import sys
 
-from minkowskiengine_amd import backend as _backend
+from minkowskiengine_amd import host as _host
 
-sys.modules[__name__] = _backend
+sys.modules[__name__] = _host.backend()

@@ -107,22 +107,34 @@ def cold_path(ME, MEB, feats, coords, dev, n, D=3, K=27, cin=64, cout=128, bf16=
     (probes N*K x key bytes + 8 B per pair written; insert N x key bytes + table + maps)."""
     out, best = {}, {}
     km = None
+    native = ME.is_native()
+    B = ME.host.backend()
+    n_pairs = 0
     for rep in range(3):
-        mgr = MEB.CoordinateMapManagerGPU_c10()
+        mgr = B.CoordinateMapManagerGPU_c10()
         (key, _), t_ins = hip_timed(lambda: mgr.insert_and_map(coords, [1] * D, ""))
-        km, t_km = hip_timed(lambda: mgr._kernel_map(key, key, [3] * D, [1] * D, [1] * D, ME.RegionType.HYPER_CUBE,
-                                                     None, False, False))
+        if native:
+            # (the native build enqueues probe + compaction and copies the pair counts asynchronously; the counts are
+            # read right here, as a first launch on the new map would)
+            n_pairs, t_km = hip_timed(lambda: mgr.kernel_map_pairs(key, key, [3] * D, [1] * D, [1] * D, 0, False, False))
+        else:
+            km, t_km = hip_timed(lambda: mgr._kernel_map(key, key, [3] * D, [1] * D, [1] * D, ME.RegionType.HYPER_CUBE,
+                                                         None, False, False))
+            n_pairs = km.n_pairs
 
         def plans():
             # the launch configurations of forward and dgrad: tile plan (+ the spatial index behind its tile order)
             for tgt, (cs, cd) in (("out", (cin, cout)), ("in", (cout, cin))):
-                MEB._conv_launch_cfg(km, tgt, n, cs, cd, bf16)
+                if native:
+                    mgr._conv_cfg(key, key, [3] * D, [1] * D, [1] * D, 0, False, tgt, cs, cd, bf16)
+                else:
+                    MEB._conv_launch_cfg(km, tgt, n, cs, cd, bf16)
         _, t_plan = hip_timed(plans)
         for name, t in (("insert_ms", t_ins), ("kernel_map_ms", t_km), ("plans_ms", t_plan)):
             best[name] = min(best.get(name, 1e9), t)
     key_bytes = 4 * (D + 1)
     out.update({k: round(v, 4) for k, v in best.items()})
-    probe_bytes = n * K * key_bytes + 8 * km.n_pairs
+    probe_bytes = n * K * key_bytes + 8 * n_pairs
     out["kernel_map_GBs"] = round(probe_bytes / (best["kernel_map_ms"] * 1e-3) / 1e9, 1)
     out["insert_GBs"] = round((n * key_bytes + 8 * 2 * n + 20 * n) / (best["insert_ms"] * 1e-3) / 1e9, 1)
     out["kernel_map_frac_of_hbm_peak"] = round(out["kernel_map_GBs"] / PEAK_HBM_GBS, 4)
@@ -262,6 +274,14 @@ def kernel_table(timer, steps):
     return out
 
 
+def set_kernel_timer(MEB, timer):
+    """per-launch HIP-event timing on: the python host's KernelTimer hook and the native host layer's own recorder"""
+    from minkowskiengine_amd import host
+    MEB.KERNEL_TIMER = timer
+    if host.native_module() is not None:
+        host.native_module().timing_enable(timer is not None)
+
+
 def run_timed(step, args, dist_utils, MEB, dev, timers_in_blocks=True):
     """-> (seconds of the MEDIAN K-step block [max over ranks], every block's seconds, KernelTimer of ALL timed
     blocks, number of timed steps).  Each block: barrier + synchronize | K steps | synchronize + barrier.
@@ -271,26 +291,29 @@ def run_timed(step, args, dist_utils, MEB, dev, timers_in_blocks=True):
     for _ in range(args.warmup):
         step()
     timer = MEB.KernelTimer()
+    timer._native_records()                       # (drop what an earlier, unrelated pass left in the native recorder)
+    timer.native.clear()
+    timer.flops.clear()
     if not timers_in_blocks:
         torch.cuda.synchronize()
-        MEB.KERNEL_TIMER = timer
+        set_kernel_timer(MEB, timer)
         for _ in range(args.steps):
             step()
         torch.cuda.synchronize()
-        MEB.KERNEL_TIMER = None
+        set_kernel_timer(MEB, None)
     blocks = []
     total = 0.0
     while True:
         dist_utils.barrier()
         torch.cuda.synchronize()
-        MEB.KERNEL_TIMER = timer if timers_in_blocks else None
+        set_kernel_timer(MEB, timer if timers_in_blocks else None)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
         torch.cuda.synchronize()
         dist_utils.barrier()
         elapsed = time.perf_counter() - t0
-        MEB.KERNEL_TIMER = None
+        set_kernel_timer(MEB, None)
         elapsed = dist_utils.max_over_ranks(elapsed, dev)      # the same value on every rank: same loop exit
         blocks.append(elapsed)
         total += elapsed
@@ -370,9 +393,13 @@ def bench_conv(args, ME, MEB, dist_utils, rank, world, dev, startup):
     torch.cuda.synchronize()
     t3 = time.perf_counter()
     cold_ms = (t3 - t0) * 1e3
-    km = x.coordinate_manager._manager._kernel_map(x.coordinate_map_key, y.coordinate_map_key, [3] * D, [1] * D,
-                                                   [1] * D, ME.RegionType.HYPER_CUBE, None, False, False)
-    n_pairs = km.n_pairs
+    mgr_ = x.coordinate_manager._manager
+    if ME.is_native():
+        n_pairs = int(mgr_.kernel_map_pairs(x.coordinate_map_key, y.coordinate_map_key, [3] * D, [1] * D, [1] * D, 0,
+                                            False, False))
+    else:
+        n_pairs = mgr_._kernel_map(x.coordinate_map_key, y.coordinate_map_key, [3] * D, [1] * D, [1] * D,
+                                   ME.RegionType.HYPER_CUBE, None, False, False).n_pairs
     grad_seed = torch.ones_like(y.F)
 
     def step():
@@ -396,7 +423,7 @@ def bench_conv(args, ME, MEB, dist_utils, rank, world, dev, startup):
         # conv_variant_bf16() of csrc/conv_bf16.hip
         kc = 128 if cin % 128 == 0 else 96 if cin % 96 == 0 else 32 if cin <= 32 else 64 if cin <= 64 else 128
     from minkowskiengine_amd import _lib
-    split = (not bf16) and MEB._use_split(_lib.load(), cin, cout)
+    split = (not bf16) and MEB._use_split(_lib.load(), cin, cout)   # (same policy in csrc_host/manager.cpp use_split)
     if split:
         # conv_variant_f32x3() of csrc/conv_f32x3.hip: fp32 operands split exactly into three bf16 terms, six bf16 MFMAs
         nc = 128 if cout % 128 == 0 else 96 if cout % 96 == 0 else 32 if cout <= 32 else 64
@@ -421,6 +448,7 @@ def bench_conv(args, ME, MEB, dist_utils, rank, world, dev, startup):
         "config": {"workload": f"single MinkowskiConvolution {D}D k=3 s=1, {n} voxels/GPU uniform in "
                                f"{ext_s}, {cin}->{cout} ch, {'bf16 features / fp32 accumulate' if bf16 else 'fp32'}, "
                                f"kernel map cached ({cfg})",
+                   "host_layer": ME.get_host(),
                    "points_per_gpu": n, "pairs_per_gpu": n_pairs, "pairs_total": int(pairs_all),
                    "parallelism": f"scene-sharded dp{world}" + (
                        f", torch DDP over {dist_utils.backend_name()} (gradient buckets overlapped with backward)"
@@ -557,6 +585,7 @@ def bench_minkunet(args, ME, MEB, dist_utils, rank, world, dev, startup):
                                                "previous backward pass"}[args.scenes]
                                + " (BASELINE configs[2]; configs[3] with N = 8)",
                    "scenes": args.scenes,
+                   "host_layer": ME.get_host(),
                    "points_per_gpu": n,
                    "parallelism": f"scene-sharded dp{world}" + (
                        f", torch DDP over {dist_utils.backend_name()} (25 MB gradient buckets overlapped with backward)"

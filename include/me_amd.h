@@ -106,7 +106,9 @@ int64_t me_kernel_map_workspace_bytes(int64_t n_out, int64_t volume);
 
 /* Pass 1: neighbour table + per-offset pair counts.
  *   nbr_dev   int32 [volume, n_out] (out): in-map row of (out row u, offset k) or -1
- *   k_offsets host int64 [volume + 1] (out): exclusive prefix of pair counts — SYNC
+ *   k_offsets host int64 [volume + 1] (out): exclusive prefix of pair counts — SYNC.  NULL (ABI 1.2): no read-back and
+ *             no synchronisation; k_offsets_dev is then required and the caller allocates the pair lists at their
+ *             upper bound n_out * volume (me_kernel_map_compact writes only the first k_offsets[volume] entries)
  *   k_offsets_dev int64 [volume + 1] on the device (out, may be NULL): the same prefix, for the kernels that
  *             take it as a device array (transpose, wgrad) — saves the caller a host-to-device copy
  * The iteration direction is the reference's: iterate OUTPUT coordinates, look up the INPUT map

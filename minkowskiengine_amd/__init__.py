@@ -10,9 +10,10 @@ __version__ = "0.1.0"
 
 from . import backend as MinkowskiEngineBackend  # noqa: F401  (the `_C`-compatible operator module)
 from .backend import (  # noqa: F401
-    BroadcastMode, ConvolutionMode, CoordinateMapKey, CoordinateMapType, GPUMemoryAllocatorType,
+    BroadcastMode, ConvolutionMode, CoordinateMapType, GPUMemoryAllocatorType,
     MinkowskiAlgorithm, PoolingMode, RegionType, cuda_version, cudart_version, get_gpu_memory_info,
     is_cuda_available)
+from .host import CoordinateMapKey, get_host, is_native, set_host  # noqa: F401  (native C++ host layer | backend.py)
 from .common import convert_to_int_list, get_minkowski_function  # noqa: F401
 from .convolution import (  # noqa: F401
     MinkowskiConvolution, MinkowskiConvolutionFunction, MinkowskiConvolutionTranspose,

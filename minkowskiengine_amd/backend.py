@@ -1089,6 +1089,7 @@ class KernelTimer:
     def __init__(self):
         self.events = {}
         self.flops = {}
+        self.native = {}     # name -> [ms] measured inside the native host layer
 
     def record(self, name, device):
         ev = torch.cuda.Event(enable_timing=True)
@@ -1099,14 +1100,29 @@ class KernelTimer:
         self.events.setdefault(name, []).append((start, end))
         self.flops[name] = self.flops.get(name, 0.0) + flops
 
+    def _native_records(self):
+        """launches timed by the native host layer (csrc_host/ops.cpp ScopedTimer) since the last call"""
+        from . import host as _host
+        nm = _host.native_module()
+        if nm is None:
+            return
+        for name, ms, flops in nm.timing_records(True):
+            self.native.setdefault(name, []).append(ms)
+            self.flops[name] = self.flops.get(name, 0.0) + flops
+
     def summary(self):
         """{name: (launches, mean ms)} — call after torch.cuda.synchronize()."""
         return {k: (len(v), sum(s.elapsed_time(e) for s, e in v) / len(v)) for k, v in self.events.items()}
 
     def totals(self):
         """{name: (launches, total ms, total algorithmic flops)} — call after torch.cuda.synchronize()."""
-        return {k: (len(v), sum(s.elapsed_time(e) for s, e in v), self.flops.get(k, 0.0))
-                for k, v in self.events.items()}
+        self._native_records()
+        out = {k: (len(v), sum(s.elapsed_time(e) for s, e in v), self.flops.get(k, 0.0))
+               for k, v in self.events.items()}
+        for k, v in self.native.items():
+            n0, t0, _ = out.get(k, (0, 0.0, 0.0))
+            out[k] = (n0 + len(v), t0 + sum(v), self.flops.get(k, 0.0))
+        return out
 
 
 KERNEL_TIMER = None  # set to a KernelTimer() to time launches

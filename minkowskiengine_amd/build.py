@@ -62,6 +62,54 @@ def build(force=False, verbose=False, extra_flags=()):
     return OUT
 
 
+# ---- native host layer: csrc_host/*.cpp -> _me_host.so (pybind11 + libtorch, host code only: g++) -------------------
+HOST_SRC = os.path.join(HERE, "csrc_host")
+HOST_OUT = os.path.join(HERE, "_me_host.so")
+HOST_OBJ_DIR = os.path.join(HOST_SRC, "build")
+
+
+def _host_flags():
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
+    inc = ce.include_paths() + ["/opt/rocm/include", sysconfig.get_paths()["include"]]
+    tl = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cflags = ["-O2", "-std=c++17", "-fPIC", "-D__HIP_PLATFORM_AMD__", "-DUSE_ROCM", "-DTORCH_EXTENSION_NAME=_me_host",
+              "-DTORCH_API_INCLUDE_EXTENSION_H", f"-D_GLIBCXX_USE_CXX11_ABI={int(torch.compiled_with_cxx11_abi())}",
+              "-Wall", "-Wno-unused-function", "-Wno-sign-compare"] + [f"-I{i}" for i in inc]
+    ldflags = ["-shared", f"-L{tl}", "-ltorch", "-ltorch_cpu", "-ltorch_python", "-lc10", "-lc10_hip", "-ltorch_hip",
+               "-L/opt/rocm/lib", "-lamdhip64", f"-L{HERE}", "-lme_amd", f"-Wl,-rpath,{tl}", "-Wl,-rpath,/opt/rocm/lib",
+               "-Wl,-rpath,$ORIGIN"]
+    return cflags, ldflags
+
+
+def build_host(force=False, verbose=False):
+    """The native operator module (MinkowskiEngineBackend._C for the hot path): pybind11 + libtorch host code over the
+    C ABI of libme_amd.so; one object per csrc_host/*.cpp, compiled in parallel with g++ (no device code)."""
+    build()
+    cxx = os.environ.get("CXX", "g++")
+    cflags, ldflags = _host_flags()
+    os.makedirs(HOST_OBJ_DIR, exist_ok=True)
+    srcs = sorted(glob.glob(os.path.join(HOST_SRC, "*.cpp")))
+    hdrs = glob.glob(os.path.join(HOST_SRC, "*.hpp")) + [os.path.join(HERE, "..", "include", "me_amd.h")]
+
+    def one(src):
+        obj = os.path.join(HOST_OBJ_DIR, os.path.splitext(os.path.basename(src))[0] + ".o")
+        if force or not os.path.exists(obj) or any(os.path.getmtime(d) > os.path.getmtime(obj) for d in [src] + hdrs):
+            cmd = [cxx] + cflags + ["-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
+        return obj
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(one, srcs))
+    if force or not os.path.exists(HOST_OUT) or any(os.path.getmtime(o) > os.path.getmtime(HOST_OUT) for o in objs) \
+            or os.path.getmtime(OUT) > os.path.getmtime(HOST_OUT):
+        subprocess.check_call([cxx] + objs + ldflags + ["-o", HOST_OUT])
+    return HOST_OUT
+
+
 CPP_EXAMPLE_SRC = os.path.join(HERE, "..", "examples", "cpp", "conv_layer.cpp")
 CPP_EXAMPLE = os.path.join(HERE, "..", "examples", "cpp", "conv_layer")
 
@@ -83,3 +131,5 @@ def build_cpp_example(force=False):
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--host" in sys.argv:
+        print(build_host(force="--force" in sys.argv, verbose=True))

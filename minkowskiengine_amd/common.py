@@ -5,7 +5,7 @@ from collections.abc import Sequence
 import numpy as np
 import torch
 
-from . import backend as MEB
+from . import host as _host
 
 
 def convert_to_int_list(arg, dimension):
@@ -28,7 +28,7 @@ def get_minkowski_function(name, variable):
     """Resolve `<Op>{GPU,CPU}` in the backend by device, as MinkowskiCommon.py:110-120 does.
     Only the GPU (MI355X) entries exist."""
     fn_name = name + get_postfix(variable)
-    fn = getattr(MEB, fn_name, None)
+    fn = getattr(_host.backend(), fn_name, None)
     if fn is None:
         raise ValueError(
             f"Function {fn_name} not available: minkowskiengine_amd implements the MI355X (GPU) path only; "

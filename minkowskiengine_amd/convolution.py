@@ -35,6 +35,18 @@ def _pad_channels(feats, kernel, cin, cout):
     return feats, kernel, (cout + po if po else None)
 
 
+def _conv_apply(conv_fn, is_transpose, feats, kernel, kernel_generator, convolution_mode, in_key, out_key, manager):
+    """One convolution with autograd: the native host layer's C++ autograd function when `manager` lives there (the
+    backward pass then never enters Python), else the reference-style Python Function."""
+    if getattr(manager, "_native", False):
+        from . import host as _host
+        return _host.native_module().conv_autograd(
+            feats, kernel, kernel_generator.kernel_size, kernel_generator.kernel_stride, kernel_generator.kernel_dilation,
+            int(kernel_generator.region_type), bool(kernel_generator.expand_coordinates), in_key, out_key,
+            manager._manager, bool(is_transpose))
+    return conv_fn.apply(feats, kernel, kernel_generator, convolution_mode, in_key, out_key, manager)
+
+
 class MinkowskiConvolutionFunction(Function):
     @staticmethod
     def forward(ctx, input_features, kernel_weights, kernel_generator, convolution_mode, in_coordinate_map_key,
@@ -139,9 +151,8 @@ class MinkowskiConvolutionBase(MinkowskiModuleBase):
                 # kernels for the skinny products of a segmentation head (200k x 96 @ 96 x 20 took 325 us)
                 feats, kernel, cpad = _pad_channels(input.F, self.kernel.unsqueeze(0), self.in_channels,
                                                     self.out_channels)
-                outfeat = self.conv.apply(feats, kernel, self.kernel_generator,
-                                          self.convolution_mode, input.coordinate_map_key, out_coordinate_map_key,
-                                          input._manager)
+                outfeat = _conv_apply(self.conv, False, feats, kernel, self.kernel_generator, self.convolution_mode,
+                                      input.coordinate_map_key, out_coordinate_map_key, input._manager)
                 if cpad is not None:
                     outfeat = outfeat[:, :self.out_channels].contiguous()
             else:
@@ -154,8 +165,9 @@ class MinkowskiConvolutionBase(MinkowskiModuleBase):
             out_coordinate_map_key = _get_coordinate_map_key(
                 input, coordinates, expand_coordinates=self.kernel_generator.expand_coordinates)
             feats, kernel, cpad = _pad_channels(input.F, self.kernel, self.in_channels, self.out_channels)
-            outfeat = self.conv.apply(feats, kernel, self.kernel_generator, self.convolution_mode,
-                                      input.coordinate_map_key, out_coordinate_map_key, input._manager)
+            outfeat = _conv_apply(self.conv, self.is_transpose, feats, kernel, self.kernel_generator,
+                                  self.convolution_mode, input.coordinate_map_key, out_coordinate_map_key,
+                                  input._manager)
             if cpad is not None:
                 outfeat = outfeat[:, :self.out_channels].contiguous()
         if self.bias is not None:

@@ -4,9 +4,9 @@ import os
 
 import torch
 
-from . import backend as MEB
-from .backend import (CoordinateMapKey, CoordinateMapType, GPUMemoryAllocatorType, MinkowskiAlgorithm,
-                      RegionType)
+from . import host as _host
+from .backend import CoordinateMapType, GPUMemoryAllocatorType, MinkowskiAlgorithm, RegionType
+from .host import CoordinateMapKey
 from .common import convert_to_int_list
 
 _allocator_type = GPUMemoryAllocatorType.PYTORCH
@@ -35,7 +35,8 @@ def _prefetch_from_previous(manager):
     """Called by SparseTensor for a freshly created manager whose coordinates have just been inserted."""
     global _last_manager
     prev = _last_manager() if _last_manager is not None else None
-    if _map_prefetch and prev is not None and prev is not manager and prev.D == manager.D:
+    if _map_prefetch and prev is not None and prev is not manager and prev.D == manager.D and \
+            prev._native == manager._native:     # (a request log belongs to the host layer that wrote it)
         manager.prefetch(prev.recipe())
     import weakref
     _last_manager = weakref.ref(manager)
@@ -73,10 +74,12 @@ class CoordinateManager:
         if coordinate_map_type == CoordinateMapType.CPU:
             raise RuntimeError("minkowskiengine_amd has no CPU coordinate map: the MI355X path keeps maps in HBM. "
                                "Pass GPU coordinates.")
-        self._CoordinateManagerClass = (MEB.CoordinateMapManagerGPU_c10
+        B = _host.backend()       # the native operator module, or backend.py (host.py)
+        self._CoordinateManagerClass = (B.CoordinateMapManagerGPU_c10
                                         if allocator_type == GPUMemoryAllocatorType.PYTORCH
-                                        else MEB.CoordinateMapManagerGPU_default)
-        self._manager = self._CoordinateManagerClass(minkowski_algorithm, num_threads)
+                                        else B.CoordinateMapManagerGPU_default)
+        self._manager = self._CoordinateManagerClass(int(minkowski_algorithm), num_threads)
+        self._native = _host.is_native()
         self.D = D
         self.minkowski_algorithm = minkowski_algorithm
 

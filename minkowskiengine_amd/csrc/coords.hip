@@ -1266,8 +1266,10 @@ int me_kernel_map_probe(const uint64_t *in_table, int64_t in_capacity, const int
     for (int d = 0; d < region->ncol - 1; ++d)
       ME_CHECK(region->kernel_size[d] % 2 == 1, "HYPER_CROSS needs odd kernel sizes");
   ME_CHECK(workspace_bytes >= me_kernel_map_workspace_bytes(n_out, volume), "workspace too small");
+  ME_CHECK(k_offsets != nullptr || k_offsets_dev != nullptr, "k_offsets (host) or k_offsets_dev must be given");
   if (n_out == 0) {
-    for (int64_t k = 0; k <= volume; ++k) k_offsets[k] = 0;
+    if (k_offsets)
+      for (int64_t k = 0; k <= volume; ++k) k_offsets[k] = 0;
     if (k_offsets_dev) ME_HIP(hipMemsetAsync(k_offsets_dev, 0, (size_t)(volume + 1) * 8, stream));
     return 0;
   }
@@ -1293,8 +1295,10 @@ int me_kernel_map_probe(const uint64_t *in_table, int64_t in_capacity, const int
   hipLaunchKernelGGL(k_kmap_koffsets, dim3((unsigned)ceil_div(volume + 1, 256)), dim3(256), 0, stream,
                      wcount, total, nw, volume, koffs);
   ME_LAUNCH_CHECK();
-  ME_HIP(hipMemcpyAsync(k_offsets, koffs, (size_t)(volume + 1) * 8, hipMemcpyDeviceToHost, stream));
-  ME_HIP(hipStreamSynchronize(stream));
+  if (k_offsets != nullptr) {   // (NULL: no read-back, no synchronisation — the caller sizes the pair lists at their bound)
+    ME_HIP(hipMemcpyAsync(k_offsets, koffs, (size_t)(volume + 1) * 8, hipMemcpyDeviceToHost, stream));
+    ME_HIP(hipStreamSynchronize(stream));
+  }
   return 0;
 }
 

@@ -1,0 +1,271 @@
+// Native host layer of the MI355X sparse-convolution hot path: the operator module the reference builds as
+// `MinkowskiEngineBackend._C` (pybind/minkowski.cu:36-68, pybind/extern.hpp:515-838), written over the C ABI of
+// include/me_amd.h.  C++ twin of minkowskiengine_amd/backend.py (which stays as the ctypes test harness): the same
+// keys, caches, launch policies and C-ABI calls, without the Python interpreter between the launches.
+//
+//   host.hpp      shared types: CoordinateMapKey, coordinate maps, kernel maps (+ tile plans), the manager
+//   manager.cpp   CoordinateMapManager (src/coordinate_map_manager.{hpp,cpp,cu}), kernel-map / plan builders
+//   ops.cpp       Convolution / ConvolutionTranspose / pooling / broadcast / pruning / batch-norm operators
+//   bind.cpp      pybind11 module + torch::autograd functions (the backward pass never enters Python)
+//
+// torch is plumbing here as in the reference's own extension: tensors for device memory (the caching allocator plays
+// the reference's c10 allocator, src/allocators.cuh:74-103), the current HIP stream, autograd.
+#pragma once
+#include <torch/extension.h>
+#include <c10/hip/HIPStream.h>
+
+#include <map>
+#include <memory>
+#include <string>
+#include <tuple>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/me_amd.h"
+
+namespace meh {
+
+using at::Tensor;
+typedef std::vector<int32_t> ivec;
+
+// ---- errors: std::runtime_error, like the reference's ASSERT (src/utils.hpp:141-150) -------------------------------
+[[noreturn]] void fail(const std::string &msg);
+inline void check(bool cond, const char *msg) {
+  if (!cond) fail(msg);
+}
+inline void check(bool cond, const std::string &msg) {
+  if (!cond) fail(msg);
+}
+void me_ok(int rc);   // throws me_last_error() when a C-ABI call failed
+
+inline void *stream_of(const c10::Device &dev) {
+  return (void *)c10::hip::getCurrentHIPStream(dev.index()).stream();
+}
+inline Tensor workspace(int64_t nbytes, const c10::Device &dev) {
+  return at::empty({nbytes < 256 ? 256 : nbytes}, at::TensorOptions().dtype(at::kByte).device(dev));
+}
+inline Tensor empty_i32(at::IntArrayRef shape, const c10::Device &dev) {
+  return at::empty(shape, at::TensorOptions().dtype(at::kInt).device(dev));
+}
+template <typename T>
+inline T *ptr(const Tensor &t) {
+  return t.defined() ? reinterpret_cast<T *>(t.data_ptr()) : nullptr;
+}
+inline void *vptr(const Tensor &t) { return t.defined() ? t.data_ptr() : nullptr; }
+
+// environment switches shared with backend.py (same names, same defaults)
+struct Policy {
+  int spatial_maps;        // ME_AMD_SPATIAL_MAPS: 1 / 0 / -1 (auto)
+  std::string tile_order;  // ME_AMD_TILE_ORDER: auto | rows | spatial
+  std::string bf16_fuse;   // ME_AMD_BF16_FUSE: auto | 1 | 0
+  int f32_split;           // ME_AMD_F32_SPLIT: 1 / 0 / -1 (auto)
+  int tile_rows, batch_groups;   // ME_AMD_TILE_ROWS / ME_AMD_BATCH_GROUPS overrides (0 = plan config)
+  bool pack_cache;         // ME_AMD_PACK_CACHE
+  static const Policy &get();
+};
+
+// ---- CoordinateMapKey (src/coordinate_map_key.hpp:44-157) -----------------------------------------------------------
+typedef std::pair<ivec, std::string> KeyT;   // coordinate_map_key_type (src/types.hpp:77-78)
+
+struct CoordinateMapKey {
+  int coordinate_size;
+  bool key_set;
+  KeyT key;
+  explicit CoordinateMapKey(int coordinate_size_) : coordinate_size(coordinate_size_), key_set(false) {}
+  CoordinateMapKey(const ivec &tensor_stride, const std::string &string_id)
+      : coordinate_size((int)tensor_stride.size() + 1), key_set(true), key(tensor_stride, string_id) {}
+  void set_key(const ivec &tensor_stride, const std::string &string_id);
+  const KeyT &get() const {
+    check(key_set, "Key not set");
+    return key;
+  }
+  bool equals(const CoordinateMapKey &o) const { return key_set && o.key_set && key == o.key; }
+  std::string repr() const;
+};
+
+// ---- device objects --------------------------------------------------------------------------------------------------
+struct SpatialIndex {     // rows of a coordinate map in supercell order (csrc/coords.hip me_spatial_index_build)
+  me_spatial_grid grid;
+  int64_t m;
+  Tensor order, pos_of_row, coords_sorted, dir_start;
+};
+
+struct CoordMap {         // one coordinate map resident in HBM (replaces CoordinateMapGPU, src/coordinate_map_gpu.cuh:47-223)
+  Tensor coords, table;
+  int64_t capacity = 0, n = 0;
+  ivec tensor_stride;
+  ivec bbox;              // column minima, then maxima; empty: none
+  int spatial_state = 0;  // 0: not tried, 1: built, -1: not available
+  std::shared_ptr<SpatialIndex> sp;
+  std::shared_ptr<SpatialIndex> spatial();
+};
+
+struct InsertResult {
+  std::shared_ptr<CoordMap> map;
+  Tensor unique_map, inverse_map;
+};
+InsertResult insert_coords(const Tensor &coords, const ivec &tensor_stride);
+
+// per-offset pair prefix read back WITHOUT stalling the build (pinned copy + event; waited for on first host use)
+struct LazyOffsets {
+  Tensor pinned;
+  void *event = nullptr;   // hipEvent_t
+  std::vector<int64_t> values;
+  bool ready = false;
+  explicit LazyOffsets(const Tensor &k_offsets_dev);
+  explicit LazyOffsets(std::vector<int64_t> v) : values(std::move(v)), ready(true) {}
+  ~LazyOffsets();
+  const std::vector<int64_t> &get();
+};
+
+struct Plan {
+  Tensor plan_src, plan_dst, batch_desc, tile_bptr, item_gptr;
+};
+
+struct ConvCfg {          // launch geometry of a (kernel map side, channel shape, dtype)
+  int tile_rows, batch_groups;
+  std::shared_ptr<Plan> plan;
+  Tensor order;           // may be undefined
+  int64_t elems;
+  bool fuse, split;
+};
+struct WgradCfg {
+  std::vector<int64_t> koffs;
+  int64_t ws_bytes;
+};
+
+struct KernelMapStore {   // buffers shared by a kernel map and its swapped view
+  std::map<std::string, Tensor> t;
+  std::map<std::string, std::shared_ptr<Plan>> plans;
+};
+
+struct KernelMap : std::enable_shared_from_this<KernelMap> {
+  int64_t volume, n_in, n_out;
+  std::shared_ptr<CoordMap> in_map, out_map;
+  std::shared_ptr<LazyOffsets> offsets;
+  Tensor k_offsets_dev, in_pairs_buf, out_pairs_buf;
+  std::shared_ptr<KernelMapStore> store;
+  bool flip = false;
+  std::map<std::string, ConvCfg> conv_cfgs;
+  std::map<std::string, WgradCfg> wgrad_cfgs;
+  std::weak_ptr<std::vector<std::string>> log;   // the owning manager's request log (build recipe) ...
+  std::string log_key;                           // ... and this map's serialised cache key in it
+
+  const std::vector<int64_t> &k_offsets() { return offsets->get(); }
+  int64_t n_pairs() { return k_offsets().back(); }
+  c10::Device device() const { return k_offsets_dev.device(); }
+  std::string name(const std::string &kind, const std::string &target) const;
+  std::shared_ptr<KernelMap> swapped();
+  // (table, order): table [volume, n_tgt] of source ROWS indexed by target POSITION; order undefined when positions are rows
+  std::pair<Tensor, Tensor> table_pos(const std::string &target);
+  Tensor table(const std::string &target);      // row-space view
+  std::string tile_order(const std::string &target, bool matrix_bound);
+  Tensor flat_order(const std::string &target, const std::string &tile_order);
+  Tensor order(const std::string &target, const std::string &tile_order);
+  std::shared_ptr<Plan> plan(const std::string &target, int tile_rows, int batch_groups, const std::string &tile_order);
+  const ConvCfg &conv_cfg(const std::string &target, int64_t n_tgt, int c_src, int c_dst, bool bf16);
+  const WgradCfg &wgrad_cfg(int c_in, int c_out, bool bf16);
+  pybind11::dict to_dict();
+};
+
+std::shared_ptr<KernelMap> build_kernel_map(const std::shared_ptr<CoordMap> &in_map,
+                                            const std::shared_ptr<CoordMap> &out_map, const me_region &region);
+me_region make_region(int ncol, int region_type, const ivec &kernel_size, const ivec &dilation, const ivec &tensor_stride);
+
+// ---- CoordinateMapManager (src/coordinate_map_manager.{hpp,cpp,cu}) ---------------------------------------------------
+typedef std::tuple<KeyT, KeyT, ivec, ivec, ivec, int, bool, bool> KernelMapKeyT;   // src/types.hpp:183-192
+
+struct CoordinateMapManager {
+  int algorithm, num_threads;
+  std::map<KeyT, std::shared_ptr<CoordMap>> maps;
+  std::vector<KeyT> map_order;      // insertion order (origin(): "any key"; __repr__)
+  std::map<KernelMapKeyT, std::shared_ptr<KernelMap>> kernel_maps;
+  std::map<KeyT, Tensor> origin_rows_cache;
+  std::map<std::pair<KeyT, KeyT>, Tensor> prune_rows;
+  std::map<std::pair<KeyT, KeyT>, std::pair<Tensor, Tensor>> stride_maps;
+
+  CoordinateMapManager(int algorithm_ = 0, int num_threads_ = 0) : algorithm(algorithm_), num_threads(num_threads_) {}
+
+  bool exists(const KeyT &k) const { return maps.count(k) != 0; }
+  std::shared_ptr<CoordMap> get(const KeyT &k) const;
+  void put(const KeyT &k, const std::shared_ptr<CoordMap> &m);
+  KeyT random_string_id(const ivec &tensor_stride, const std::string &string_id);
+  KeyT register_map(const ivec &ts, const std::shared_ptr<CoordMap> &m, const std::string &string_id);
+
+  std::tuple<KeyT, Tensor, Tensor> insert_and_map(Tensor coordinates, const ivec &tensor_stride, const std::string &string_id);
+  KeyT stride(const KeyT &in_key, const ivec &kernel_stride, const std::string &string_id);
+  std::pair<Tensor, Tensor> stride_map(const KeyT &in_key, const KeyT &strided_key);
+  std::pair<KeyT, bool> stride_region(const KeyT &in_key, const ivec &kernel_size, const ivec &kernel_dilation,
+                                      int region_type, const ivec &out_tensor_stride, bool expand_coordinates,
+                                      bool is_transpose, const ivec *region_tensor_stride);
+  KeyT prune(const KeyT &in_key, const Tensor &keep);
+  Tensor pruning_rows(const KeyT &in_key, const KeyT &out_key);
+  std::vector<Tensor> union_map(const std::vector<KeyT> &in_keys, CoordinateMapKey *out_key);
+  KeyT origin();
+  Tensor origin_rows(const KeyT &in_key);
+  std::shared_ptr<KernelMap> kernel_map(const KeyT &in_key, const KeyT &out_key, const ivec &kernel_size,
+                                        const ivec &kernel_stride, const ivec &kernel_dilation, int region_type,
+                                        bool is_transpose, bool is_pool);
+  // every strided map, kernel map, tile plan and weight-gradient geometry a network asks for, built in ONE call for a
+  // new scene (the replay of another scene's request log: DESIGN 9.8, round-3 build recipe)
+  std::shared_ptr<std::vector<std::string>> recipe_log = std::make_shared<std::vector<std::string>>();   // serialised requests
+  int64_t prefetch(const std::vector<std::string> &recipe);
+  void log_request(const std::string &r) { recipe_log->push_back(r); }
+  std::vector<Tensor> device_tensors();
+  std::string repr() const;
+};
+
+// ---- operators (ops.cpp) ----------------------------------------------------------------------------------------------
+Tensor conv_forward_km(const Tensor &in_feat, const Tensor &kernel, KernelMap &km);
+std::pair<Tensor, Tensor> conv_backward_km(const Tensor &in_feat, Tensor grad_out, const Tensor &kernel, KernelMap &km,
+                                           bool need_grad_in);
+std::shared_ptr<KernelMap> prepare_conv(const Tensor &in_feat, const Tensor &kernel, const ivec &kernel_size,
+                                        const ivec &kernel_stride, const ivec &kernel_dilation, int region_type,
+                                        bool expand_coordinates, CoordinateMapKey *in_key, CoordinateMapKey *out_key,
+                                        CoordinateMapManager *manager, bool transpose);
+
+std::pair<Tensor, Tensor> local_pooling_forward(const Tensor &in_feat, const ivec &ks, const ivec &st, const ivec &dl,
+                                                int region_type, int pooling_mode, CoordinateMapKey *in_key,
+                                                CoordinateMapKey *out_key, CoordinateMapManager *mgr);
+Tensor local_pooling_backward(const Tensor &in_feat, Tensor grad_out, const Tensor &num_nonzero, const ivec &ks,
+                              const ivec &st, const ivec &dl, int region_type, int pooling_mode,
+                              CoordinateMapKey *in_key, CoordinateMapKey *out_key, CoordinateMapManager *mgr);
+std::pair<Tensor, Tensor> local_pooling_transpose_forward(const Tensor &in_feat, const ivec &ks, const ivec &st,
+                                                          const ivec &dl, int region_type, bool generate_new_coordinates,
+                                                          int pooling_mode, CoordinateMapKey *in_key,
+                                                          CoordinateMapKey *out_key, CoordinateMapManager *mgr);
+Tensor local_pooling_transpose_backward(const Tensor &in_feat, Tensor grad_out, const Tensor &num_nonzero, const ivec &ks,
+                                        const ivec &st, const ivec &dl, int region_type, int pooling_mode,
+                                        CoordinateMapKey *in_key, CoordinateMapKey *out_key, CoordinateMapManager *mgr);
+std::pair<Tensor, Tensor> global_pooling_forward(const Tensor &in_feat, int pooling_mode, CoordinateMapKey *in_key,
+                                                 CoordinateMapKey *out_key, CoordinateMapManager *mgr);
+Tensor global_pooling_backward(const Tensor &in_feat, Tensor grad_out, const Tensor &num_nonzero, int pooling_mode,
+                               CoordinateMapKey *in_key, CoordinateMapKey *out_key, CoordinateMapManager *mgr);
+Tensor broadcast_forward(const Tensor &in_feat, const Tensor &in_feat_glob, int broadcast_mode, CoordinateMapKey *in_key,
+                         CoordinateMapKey *glob_key, CoordinateMapManager *mgr);
+std::pair<Tensor, Tensor> broadcast_backward(const Tensor &in_feat, const Tensor &in_feat_glob, Tensor grad_out,
+                                             int broadcast_mode, CoordinateMapKey *in_key, CoordinateMapKey *glob_key,
+                                             CoordinateMapManager *mgr);
+Tensor pruning_forward(const Tensor &in_feat, const Tensor &keep, CoordinateMapKey *in_key, CoordinateMapKey *out_key,
+                       CoordinateMapManager *mgr);
+Tensor pruning_backward(const Tensor &grad_out, CoordinateMapKey *in_key, CoordinateMapKey *out_key,
+                        CoordinateMapManager *mgr);
+
+// batch normalisation over feature rows (csrc/norm.hip)
+std::pair<Tensor, Tensor> bn_stats(const Tensor &x, double eps, double momentum, const Tensor &running_mean,
+                                   const Tensor &running_var, const Tensor &num_batches_tracked);
+Tensor bn_apply(const Tensor &x, const Tensor &mean, const Tensor &rstd, const Tensor &gamma, const Tensor &beta,
+                bool relu, const Tensor &skip);
+std::tuple<Tensor, Tensor, Tensor, Tensor> bn_backward(const Tensor &x, Tensor dy, const Tensor &yout, const Tensor &mean,
+                                                       const Tensor &rstd, const Tensor &gamma, const Tensor &beta,
+                                                       bool relu, bool residual, bool need_dskip);
+
+// optional per-launch timing with HIP events on the launch stream (bench.py: average duration of each hot kernel inside
+// the timed region) — C++ twin of backend.KernelTimer
+void timing_enable(bool on);
+std::vector<std::tuple<std::string, double, double>> timing_records(bool clear);   // (name, ms, algorithmic flops)
+
+// packed weight images cached per (weight tensor, direction) — C++ twin of backend._WeightPacker
+Tensor packed_weights(const Tensor &kernel, int mode, bool transposed, int c_src, int c_dst, int64_t elems);
+
+}  // namespace meh

@@ -1,0 +1,90 @@
+"""Which operator module serves the Python API: the NATIVE one (csrc_host/ -> _me_host.so: C++ manager, operators and
+autograd functions over the C ABI — what the reference builds as `MinkowskiEngineBackend._C`) or the Python twin
+(`backend.py`, ctypes over the same C ABI — the test harness that the kernel tests poke into).
+
+    ME_AMD_HOST=native   (default when _me_host.so is built)     ME_AMD_HOST=python
+    minkowskiengine_amd.set_host("native" | "python")            # switchable at run time; objects made under one host
+                                                                 # (keys, managers, sparse tensors) stay with that host
+Both run the same kernels with the same plans, so results are bit-identical (tests/test_gpu_native_host.py)."""
+import importlib.machinery
+import importlib.util
+import os
+
+from . import backend as _python_backend
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+NATIVE_PATH = os.path.join(_HERE, "_me_host.so")
+_native = None
+_native_error = None
+
+
+def native_module():
+    """-> the native operator module, or None when it is not built / cannot be loaded (reason in native_error())"""
+    global _native, _native_error
+    if _native is None and _native_error is None:
+        if not os.path.exists(NATIVE_PATH):
+            _native_error = f"{NATIVE_PATH} not built (python -c 'import __graft_entry__ as g; g.build()')"
+        else:
+            try:
+                import torch  # noqa: F401  (libtorch must be loaded first)
+                from . import _lib
+                _lib.load()       # libme_amd.so by its in-tree path (the extension links it through $ORIGIN as well)
+                loader = importlib.machinery.ExtensionFileLoader("_me_host", NATIVE_PATH)
+                spec = importlib.util.spec_from_file_location("_me_host", NATIVE_PATH, loader=loader)
+                mod = importlib.util.module_from_spec(spec)
+                loader.exec_module(mod)
+                _native = mod
+            except Exception as e:  # noqa: BLE001
+                _native_error = f"{type(e).__name__}: {e}"
+    return _native
+
+
+def native_error():
+    return _native_error
+
+
+_mode = os.environ.get("ME_AMD_HOST", "auto")
+if _mode not in ("auto", "native", "python"):
+    raise RuntimeError(f"ME_AMD_HOST must be auto, native or python, got {_mode!r}")
+if _mode == "native" and native_module() is None:
+    raise RuntimeError(f"ME_AMD_HOST=native but the native host layer is not available: {native_error()}")
+_current = "native" if (_mode != "python" and native_module() is not None) else "python"
+
+
+def get_host():
+    return _current
+
+
+def set_host(name):
+    global _current
+    if name == "native" and native_module() is None:
+        raise RuntimeError(f"native host layer not available: {native_error()}")
+    if name not in ("native", "python"):
+        raise ValueError(name)
+    _current = name
+
+
+def is_native():
+    return _current == "native"
+
+
+def backend():
+    """the operator module in charge: the native extension or minkowskiengine_amd.backend"""
+    return _native if _current == "native" else _python_backend
+
+
+def _key_types():
+    return (_python_backend.CoordinateMapKey,) + ((_native.CoordinateMapKey,) if _native is not None else ())
+
+
+class _KeyMeta(type):
+    def __call__(cls, *args, **kwargs):
+        return backend().CoordinateMapKey(*args, **kwargs)
+
+    def __instancecheck__(cls, obj):
+        return isinstance(obj, _key_types())
+
+
+class CoordinateMapKey(metaclass=_KeyMeta):
+    """`CoordinateMapKey(coordinate_size)` / `CoordinateMapKey(tensor_stride, string_id)` of the host in charge
+    (src/coordinate_map_key.hpp:44-157); isinstance() accepts the keys of either host."""

@@ -8,6 +8,7 @@ import torch.nn as nn
 from torch.autograd import Function
 
 from . import backend as MEB
+from . import host as _host
 from .sparse_tensor import SparseTensor
 
 _TORCH_BN = os.environ.get("ME_AMD_TORCH_BN", "0") != "0"   # 1: torch's batch-norm kernels (A/B timing)
@@ -107,7 +108,12 @@ class MinkowskiBatchNorm(nn.Module):
             if nbt is not None and (nbt.dtype != torch.int64 or not nbt.is_cuda):
                 nbt.add_(1)
                 nbt = None
-            y = _BatchNormTrainFunction.apply(f, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps, self.fuse_relu, nbt)
+            if getattr(input._manager, "_native", False):      # C++ autograd function of the native host layer
+                y = _host.native_module().batch_norm_train(f, None, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps,
+                                                           bool(self.fuse_relu), nbt)
+            else:
+                y = _BatchNormTrainFunction.apply(f, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps, self.fuse_relu,
+                                                  nbt)
             out = _rewrap(input, y)
             out._rectified = self.fuse_relu
             return out
@@ -139,7 +145,12 @@ class MinkowskiBatchNorm(nn.Module):
         if nbt is not None and (nbt.dtype != torch.int64 or not nbt.is_cuda):
             nbt.add_(1)
             nbt = None
-        y = _BatchNormResidualFunction.apply(f, skip.F, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps, bool(relu), nbt)
+        if getattr(input._manager, "_native", False):
+            y = _host.native_module().batch_norm_train(f, skip.F, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps,
+                                                       bool(relu), nbt)
+        else:
+            y = _BatchNormResidualFunction.apply(f, skip.F, bn.weight, bn.bias, rm, rv, bn.momentum, bn.eps, bool(relu),
+                                                 nbt)
         return _rewrap(input, y)
 
     def __repr__(self):

@@ -5,7 +5,8 @@ import torch
 from torch.autograd import Function
 from torch.nn import Module
 
-from .backend import CoordinateMapKey, PoolingMode
+from .backend import PoolingMode
+from .host import CoordinateMapKey
 from .common import get_minkowski_function
 from .kernel_generator import KernelGenerator
 from .sparse_tensor import SparseTensor, _get_coordinate_map_key

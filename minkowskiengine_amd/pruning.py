@@ -3,7 +3,7 @@ import torch
 from torch.autograd import Function
 from torch.nn import Module
 
-from .backend import CoordinateMapKey
+from .host import CoordinateMapKey
 from .common import get_minkowski_function
 from .sparse_tensor import SparseTensor
 

@@ -6,7 +6,7 @@ import warnings
 
 import torch
 
-from .backend import CoordinateMapKey
+from .host import CoordinateMapKey
 from .common import convert_to_int_list
 from .coordinate_manager import CoordinateManager
 

@@ -4,7 +4,7 @@ import torch
 from torch.autograd import Function
 from torch.nn import Module
 
-from .backend import CoordinateMapKey
+from .host import CoordinateMapKey
 from .sparse_tensor import SparseTensor
 
 
