@@ -130,7 +130,9 @@ __global__ __launch_bounds__(256) void k_pack_weights_bf16(const void *__restric
 // waves per SIMD the register budget is sized for: 3 (168 registers) for four-wave workgroups; an eight-wave
 // workgroup (128 columns) is sized for 4 (128 registers: two of them per CU) unless its weight slices need more
 // (KC = 256: 64 registers of weights alone)
-__host__ __device__ constexpr int conv_bf16_waves_per_simd(int nc, int kc) { return (nc == 128 && kc <= 128) ? 4 : (nc == 128 ? 2 : 3); }
+__host__ __device__ constexpr int conv_bf16_waves_per_simd(int nc, int kc) {
+  return (nc == 128 && kc <= 128) ? 4 : (nc == 128 ? 2 : 3);   // (96 columns: six waves, 3 per SIMD = two workgroups per CU)
+}
 
 template <int NC, int KC, bool EXACT, bool SMALL, bool FUSE = false>
 __global__ __launch_bounds__(NC * 4, conv_bf16_waves_per_simd(NC, KC)) void k_conv_tile_bf16(
@@ -581,20 +583,31 @@ static ConvVariantBf16 conv_variant_bf16(int c_src, int c_dst) {
   // barrier -> operands -> MFMA -> accumulate, ~1 us) is then paid once per 128 columns, and a 256-channel layer on
   // a 5k - 20k voxel map (MinkUNet's deepest levels: one workgroup per CU, nothing to overlap with) walks half as
   // many batches (round 3, profiles/r03_*layers*)
-  v.nc = c_dst <= 32 ? 32 : 64;
-  if (c_dst % 128 == 0) v.nc = 128;
-  if (g_bf16_nc == 32 || g_bf16_nc == 64 || g_bf16_nc == 128) v.nc = (g_bf16_nc == 32 && c_dst > 32) ? 64 : g_bf16_nc;
-  if (v.nc == 128 && c_dst <= 64) v.nc = 64;
-  v.slabs = (int)ceil_div(c_dst, v.nc);
   // widest chunk that tiles the source channels exactly (MinkUNet's 96 / 192-channel layers sit on its largest
-  // maps); otherwise the smallest chunk that covers them, or 128.  256 halves the batches of a 256-channel layer once
-  // more (64 KiB of weights per batch and slab stay in flight in registers: eight-wave workgroups only).
-  if (c_src % 256 == 0 && v.nc == 128) v.kc = 256;
-  else if (c_src % 128 == 0) v.kc = 128;
+  // maps); otherwise the smallest chunk that covers them, or 128
+  if (c_src % 128 == 0) v.kc = 128;
   else if (c_src % 96 == 0) v.kc = 96;
   else v.kc = c_src <= 32 ? 32 : (c_src <= 64 ? 64 : 128);
+  // 64 columns per workgroup whenever there are more than 32 ...; 128 columns (eight waves) where they tile the output
+  // exactly and the chunk is not 96 channels deep.  Measured per layer inside a MinkUNet34C step (round 3,
+  // profiles/r03_layers_minkunet34c_bf16_*.log; the kernel is bound by its per-batch chain, not by the gathers, so the
+  // slab width moves a layer by a few per cent only): 256 -> 256 on 21k voxels 103.6 us (64 columns) / 95.4 (128) /
+  // 91.5 (128 columns, 256-channel chunks); 64 -> 128 on 100k voxels 68 -> 70 us forward but the step 397 -> 420
+  // Mpoints/s; 192 -> 128 (96-channel chunks) 147 us with 64 columns, 161 with 128: excluded; 96 columns in one six-wave
+  // workgroup (instantiated, override only) 96 -> 96 107 us against 103 with a 64- and a 32-column slab: not used.
+  v.nc = c_dst <= 32 ? 32 : 64;
+  if (c_dst % 128 == 0 && v.kc != 96) v.nc = 128;
+  // 256-channel chunks halve the batches of a 256-channel layer (64 registers of weights per lane: one eight-wave
+  // workgroup per CU) — only where the launch is at most two slabs wide: with three (256 -> 384 input gradient, 21k
+  // voxels) the single resident workgroup per CU runs two rounds, 246 us against 158
+  if (v.nc == 128 && c_src % 256 == 0 && c_dst <= 256) v.kc = 256;
+  if (g_bf16_nc == 32 || g_bf16_nc == 64 || g_bf16_nc == 96 || g_bf16_nc == 128)
+    v.nc = (g_bf16_nc == 32 && c_dst > 32) ? 64 : g_bf16_nc;
+  if (v.nc > 64 && c_dst <= 64) v.nc = 64;
+  if (v.nc != 128 && v.kc == 256) v.kc = 128;
   if (g_bf16_kc == 32 || g_bf16_kc == 64 || g_bf16_kc == 96 || g_bf16_kc == 128 || (g_bf16_kc == 256 && v.nc == 128))
     v.kc = g_bf16_kc;
+  v.slabs = (int)ceil_div(c_dst, v.nc);
   return v;
 }
 
@@ -610,7 +623,7 @@ static int launch_conv_tile_bf16(const __bf16 *src, int c_src, const bf16x8 *wp,
                            const int32_t *, const int32_t *, __bf16 *, int64_t, int, int, int);
   kernel_t fn = small ? (exact ? &k_conv_tile_bf16<NC, KC, true, true> : &k_conv_tile_bf16<NC, KC, false, true>)
                       : (exact ? &k_conv_tile_bf16<NC, KC, true, false> : &k_conv_tile_bf16<NC, KC, false, false>);
-  if constexpr (NC <= 64 && KC <= 128) {   // batch fusion: four-wave workgroups only (sparse maps of narrow layers)
+  if constexpr (NC <= 96 && KC <= 128) {   // batch fusion: four- and six-wave workgroups (sparse maps of narrow layers)
     if (fuse)
       fn = small ? (exact ? &k_conv_tile_bf16<NC, KC, true, true, true> : &k_conv_tile_bf16<NC, KC, false, true, true>)
                  : (exact ? &k_conv_tile_bf16<NC, KC, true, false, true> : &k_conv_tile_bf16<NC, KC, false, false, true>);
@@ -725,6 +738,11 @@ static int conv_target_bf16(const uint16_t *src_, int64_t n_src, int32_t c_src, 
     if (v.kc == 96) ME_CONV_CASE(32, 96);
     if (v.kc == 64) ME_CONV_CASE(32, 64);
     ME_CONV_CASE(32, 32);
+  } else if (v.nc == 96) {
+    if (v.kc == 128) ME_CONV_CASE(96, 128);
+    if (v.kc == 96) ME_CONV_CASE(96, 96);
+    if (v.kc == 64) ME_CONV_CASE(96, 64);
+    ME_CONV_CASE(96, 32);
   } else if (v.nc == 128) {
     if (v.kc == 256) ME_CONV_CASE(128, 256);
     if (v.kc == 128) ME_CONV_CASE(128, 128);

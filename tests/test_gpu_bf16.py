@@ -213,12 +213,15 @@ def test_bf16_odd_channels_without_padding(device, monkeypatch, n, extent, D, ci
         assert_close(res[pad][2], gw)
 
 
-@pytest.mark.parametrize("cin,cout", [(256, 256), (128, 256), (64, 128), (384, 256)])
-def test_bf16_slab_width_does_not_change_a_bit(device, cin, cout):
-    """128-column workgroups (eight waves; the default where the output channels are a multiple of 128) against
+@pytest.mark.parametrize("cin,cout,shapes", [(256, 256, ((64, 128), (128, 128))), (128, 256, ((64, 128), (128, 128))),
+                                              (64, 128, ((64, 64), (128, 64))), (384, 256, ((64, 128), (128, 128))),
+                                              (96, 96, ((64, 96), (96, 96))), (128, 96, ((64, 128), (96, 128))),
+                                              (256, 128, ((128, 128), (128, 256)))])
+def test_bf16_slab_width_does_not_change_a_bit(device, cin, cout, shapes):
+    """96- and 128-column workgroups (six / eight waves; the defaults where they tile the output channels) against
     64-column ones at the same source-channel chunk: the columns of a target row are independent sums in the same
-    order, so forward and input gradient are bit-identical; a deeper chunk (256) regroups the fp32 partial sums and
-    stays within the bf16 bar of the oracle."""
+    order, so forward and input gradient are bit-identical; a deeper chunk (256 against 128) regroups the fp32 partial
+    sums and stays within the bf16 bar of the oracle, as does the policy's own choice."""
     from minkowskiengine_amd import _lib, backend as MEB
     lib = _lib.load()
     coords = make_cloud(2500, 12, 3, seed=cin + cout, batch=2, negative=True)
@@ -230,7 +233,7 @@ def test_bf16_slab_width_does_not_change_a_bit(device, cin, cout):
     w = bf16_round(torch.rand(27, cin, cout, generator=g) - 0.5)
     res = {}
     try:
-        for nc, kc in ((64, 128), (128, 128), (128, 0)):
+        for nc, kc in tuple(shapes) + ((0, 0),):
             lib.me_debug_set_bf16_shape(nc, kc)
             # (plans and packed images depend on the shape: a fresh kernel map and fresh weight tensors per setting)
             km = MEB._build_kernel_map(mgr._get(key), mgr._get(key), _lib.make_region(4, 0, [3] * 3, [1] * 3, [1] * 3))
@@ -240,9 +243,12 @@ def test_bf16_slab_width_does_not_change_a_bit(device, cin, cout):
             res[(nc, kc)] = (y.clone(), gi.clone())
     finally:
         lib.me_debug_set_bf16_shape(0, 0)
-    assert torch.equal(res[(64, 128)][0], res[(128, 128)][0]) and torch.equal(res[(64, 128)][1], res[(128, 128)][1])
     _, okm = O.kernel_map(coords.numpy(), coords.numpy(), O.make_region(3, 3))
-    assert_bf16_close(res[(128, 0)][0].float().cpu().numpy(), O.conv_forward(x.numpy(), w.numpy(), okm, len(coords)),
-                      "forward, policy shape")
-    assert_bf16_close(res[(128, 0)][1].float().cpu().numpy(),
-                      O.conv_backward(x.numpy(), gy.numpy(), w.numpy(), okm)[0], "grad_in, policy shape")
+    want_y = O.conv_forward(x.numpy(), w.numpy(), okm, len(coords))
+    want_gi = O.conv_backward(x.numpy(), gy.numpy(), w.numpy(), okm)[0]
+    a, b = shapes
+    if a[1] == b[1]:      # same chunk depth: only the slab width differs (forward; the input gradient swaps the roles)
+        assert torch.equal(res[a][0], res[b][0])
+    for shp in res:
+        assert_bf16_close(res[shp][0].float().cpu().numpy(), want_y, f"forward {shp}")
+        assert_bf16_close(res[shp][1].float().cpu().numpy(), want_gi, f"grad_in {shp}")
