@@ -261,6 +261,17 @@ int me_conv_target_f32(const float *src_feat_dev, int64_t n_src, int32_t c_src,
                        const int32_t *order_dev /* as given to me_plan_build, or NULL */, float *dst_feat_dev,
                        int64_t n_tgt, int32_t tile_rows, int32_t batch_groups, void *stream);
 
+/* The same launch with MULTI-OFFSET BATCHES (round 3): runs of single-group batches of consecutive offsets — what a
+ * sparse map's plan consists of — are staged and multiplied together, up to four offsets per barrier pair, each group
+ * with its own offset's weight slice.  For maps with fewer than ~24 pairs per (tile, offset) item; fp32 results in a
+ * fixed order (not bit-identical to me_conv_target_f32: the partial sums of a fused batch are added to the tile as a
+ * whole).  Shapes without a fused instantiation (slabs of 96 columns, chunks of 96 channels, >= 4 GiB sources) run
+ * the plain kernel. */
+int me_conv_target_f32_fused(const float *src_feat_dev, int64_t n_src, int32_t c_src, const float *packed_w_dev,
+                             int64_t volume, int32_t c_dst, const int32_t *plan_src_dev, const int32_t *plan_dst_dev,
+                             const int32_t *batch_desc_dev, const int32_t *tile_bptr_dev, const int32_t *order_dev,
+                             float *dst_feat_dev, int64_t n_tgt, int32_t tile_rows, int32_t batch_groups, void *stream);
+
 /* Plan geometry for a (target rows, channels) problem: the tile height is chosen so that tiles x column
  * slabs is just below a multiple of the GPU's resident-workgroup slots (a 100k-voxel layer is only
  * ~2 workgroup rounds long, so an unlucky tile count can idle a third of the chip) while the

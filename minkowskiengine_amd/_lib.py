@@ -97,6 +97,8 @@ SIGNATURES = {
     "me_conv_pack_weights_f32": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "me_conv_target_f32": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp,
                                           c_vp, c_i64, c_i32, c_i32, c_vp]),
+    "me_conv_target_f32_fused": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                                c_vp, c_i64, c_i32, c_i32, c_vp]),
     "me_conv_plan_config": (ctypes.c_int, [c_i64, c_i64, c_i64, c_i32, c_i32, _P_I32, _P_I32]),
     "me_transpose_kernel_f32": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
     "me_conv_wgrad_workspace_bytes": (c_i64, [_P_I64, c_i64, c_i32, c_i32]),

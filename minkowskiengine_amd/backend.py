@@ -1035,6 +1035,8 @@ CoordinateMapManagerGPU_default = CoordinateMapManagerGPU_c10
 # profiles/r02_bench_bf16_batch_fusion.log); "1" / "0" force
 _BF16_FUSE = os.environ.get("ME_AMD_BF16_FUSE", "auto")
 _BF16_FUSE_MAX_PAIRS_PER_ITEM = 24.0
+# fp32-MFMA tile kernel with multi-offset batches (me_conv_target_f32_fused): the same density rule; "0" disables
+_F32_FUSE = os.environ.get("ME_AMD_F32_FUSE", "1") != "0"
 _BF16_GATHER = os.environ.get("ME_AMD_BF16_GATHER", "0") != "0"   # bf16: output-stationary kernel (opt-in: measured slower than the tile-plan kernel)
 # fp32 features: forward / dgrad on the bf16 matrix pipe with exactly split operands (csrc/conv_f32x3.hip; fp32-grade
 # results).  "auto": where it measured faster than the fp32-MFMA kernel k_conv_tile_f32 — layers with
@@ -1384,7 +1386,8 @@ def _conv_target(src_feat, kernel, km, target, n_tgt, name="conv_target", transp
         packed = torch.empty(elems, dtype=torch.float32, device=dev)
         _lib.check(lib.me_conv_pack_weights_f32(kernel.data_ptr(), volume, c_src, c_dst, 1 if transposed else 0,
                                                 packed.data_ptr(), stream))
-        _timed(name, dev, lambda: _lib.check(lib.me_conv_target_f32(
+        fn32 = lib.me_conv_target_f32_fused if (fuse and _F32_FUSE) else lib.me_conv_target_f32
+        _timed(name, dev, lambda: _lib.check(fn32(
             src_feat.data_ptr(), src_feat.shape[0], c_src, packed.data_ptr(), km.volume, c_dst, p_src, p_dst, p_desc,
             p_bptr, p_order, out.data_ptr(), n_tgt, tile_rows, batch_groups, stream)), flops=flops)
     return out

@@ -113,6 +113,52 @@ __device__ __forceinline__ void mma_groups(const float *__restrict__ a0p, const 
   for (int r = 0; r < R; ++r) *reinterpret_cast<f32x4 *>(accp + d[r]) = acc[r];
 }
 
+// n single-group batches of DIFFERENT offsets staged together (multi-offset batch, round 3): group r multiplies with its
+// own offset's weights w[r].  On a sparse map a (tile, offset) item holds one half-empty 16-row group, and a batch of
+// one group pays the whole chain (index window -> gather -> stage -> two barriers -> operands -> 8 .. 16 MFMAs ->
+// accumulate) for 256 .. 512 cycles of matrix work: config 5 (K = 81, 4.6 pairs per voxel) ran 81 such batches per tile
+// at 18 % of the fp32 MFMA peak.  Four groups per batch give the matrix pipe 4x the work per chain.  Two groups of a
+// batch may hit the SAME target row (different offsets), so the accumulators start from zero, all MFMAs run on
+// independent chains, and the tile is updated group by group in batch order (LDS operations of a wave execute in order:
+// a read issued behind the previous group's write sees it).  The sum of a row is old + (x_0 w_0 + x_1 w_1 + ...) per
+// group in plan order: fixed order, bitwise reproducible (not bit-identical to the unfused kernel, whose accumulators
+// start from the tile).
+template <int M, int KQ, int A_LD, int ACC_LD>
+__device__ __forceinline__ void mma_singles_f32(const float *__restrict__ a0p, const int (&pofs)[KQ / 4],
+                                                const float (&w)[M][KQ], int n, const int32_t *__restrict__ dstp,
+                                                float *__restrict__ accp) {
+  int d[M];
+  f32x4 a[KQ / 4][M];
+  f32x4 acc[M];
+#pragma unroll
+  for (int r = 0; r < M; ++r) {
+    d[r] = (int)__umul24((unsigned)dstp[r * 16], (unsigned)ACC_LD);
+    acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int s4 = 0; s4 < KQ / 4; ++s4) {
+#pragma unroll
+    for (int r = 0; r < M; ++r) a[s4][r] = *reinterpret_cast<const f32x4 *>(a0p + r * 16 * A_LD + pofs[s4]);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int s4 = 0; s4 < KQ / 4; ++s4) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int r = 0; r < M; ++r)
+        if (r < n) acc[r] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[r][s4 * 4 + j], a[s4][r][j], acc[r], 0, 0, 0);   // wave-uniform
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < M; ++r) {
+    if (r < n) {
+      const f32x4 old = *reinterpret_cast<const f32x4 *>(accp + d[r]);
+      *reinterpret_cast<f32x4 *>(accp + d[r]) = old + acc[r];
+    }
+  }
+}
+
 // Packed weights: the exact register image of the kernel.  For offset k, source-channel chunk c,
 // 16-column block cb and k-step quad v, lane (q = lane >> 4, i16 = lane & 15) finds its four weights
 //   W[k][c*KC + (4*v + q)*4 + j][cb*16 + i16],  j = 0..3      (piece 4*v + q of the staged row)
@@ -188,8 +234,10 @@ __device__ unsigned long long d_conv_timing[8];
 // a v_add_u32 costs ~5 cycles and a global_load_dwordx4 ~17 cycles of matrix time, in the same wave or in a
 // neighbour).  Occupancy hides latencies but not instruction issue, so every VALU / VMEM instruction of the loop is
 // paid for in matrix time.
-template <int NC, int KC, bool EXACT, int VAR, bool SMALL = false>
-__global__ __launch_bounds__(NC * 4, ((NC >= 96 || KC == 96) ? 2 : 3)) void k_conv_tile_f32(
+// (the fused instantiation of the two-wave, 64-channel shape — config 5's input gradient — needs 200 registers for the
+// weight slices of two offsets in use and two in flight: two waves per SIMD instead of spilling)
+template <int NC, int KC, bool EXACT, int VAR, bool SMALL = false, bool FUSE = false>
+__global__ __launch_bounds__(NC * 4, ((NC >= 96 || KC == 96 || (FUSE && NC == 32 && KC == 64)) ? 2 : 3)) void k_conv_tile_f32(
     const float *__restrict__ src, int c_src, const f32x4 *__restrict__ wp, int c_dst,
     const int32_t *__restrict__ plan_src, const int32_t *__restrict__ plan_dst,
     const int32_t *__restrict__ batch_desc, const int32_t *__restrict__ tile_bptr,
@@ -372,7 +420,116 @@ __global__ __launch_bounds__(NC * 4, ((NC >= 96 || KC == 96) ? 2 : 3)) void k_co
     }
   };
 
-  if (n_it > 0) {
+  if constexpr (FUSE) {
+    // ---- multi-offset batches (see mma_singles_f32): runs of single-group batches of consecutive offsets — contiguous
+    // in the plan — are staged and multiplied together, up to MAXSUB of them (the weights of MAXSUB offsets have to fit
+    // the registers next to the slices in flight: 4 up to 32 source channels per chunk, 2 beyond) ----
+    constexpr int MAXSUB = KQ <= 8 ? 4 : 2;
+    struct Super {
+      int chunk, g0, ng, nsub;     // source-channel chunk, first group, groups in total, sub-batches (0: none)
+      int k[MAXSUB], sg[MAXSUB];   // offset and groups of each sub-batch
+    };
+    int cur_chunk = 0, cur_r = 0;  // the next batch to hand out
+    auto next_super = [&]() {
+      Super sb;
+      const bool valid = cur_chunk < nchunks && nb > 0;
+      const int r = valid ? cur_r : max(nb - 1, 0);
+      sb.chunk = valid ? cur_chunk : max(nchunks - 1, 0);
+      const int avail = valid ? nb - cur_r : 1;
+      i32x2 d[MAXSUB];
+#pragma unroll
+      for (int j = 0; j < MAXSUB; ++j)   // (descriptors behind the tile's last batch are readable: me_plan_max_groups)
+        d[j] = *reinterpret_cast<const i32x2 *>(batch_desc + 2 * (int64_t)(b0 + r + j));
+      sb.g0 = d[0].x;
+      sb.ng = 0;
+      sb.nsub = 0;
+#pragma unroll
+      for (int j = 0; j < MAXSUB; ++j) {
+        const int g = d[j].y & 255;
+        // (only single-group batches are fused: group r <-> sub-batch r)
+        const bool take = j == 0 || (sb.nsub == j && j < avail && sb.ng == j && g == 1);
+        sb.k[j] = take ? (int)((uint32_t)d[j].y >> 8) : sb.k[j > 0 ? j - 1 : 0];
+        sb.sg[j] = take ? g : 0;
+        if (take) {
+          sb.ng += g;
+          sb.nsub = j + 1;
+        }
+      }
+      if (valid) {
+        cur_r += sb.nsub;
+        if (cur_r >= nb) {
+          cur_r = 0;
+          ++cur_chunk;
+        }
+      } else {
+        sb.nsub = 0;
+      }
+      return sb;
+    };
+    float wf[MAXSUB][KQ], wfn[MAXSUB][KQ];
+    auto load_ws = [&](const Super &sb) {
+#pragma unroll
+      for (int j = 0; j < MAXSUB; ++j) {
+        if (j == 0 || j < sb.nsub) {   // wave-uniform: a full batch loads one slice
+          const f32x4 *p = wp + ((((int64_t)sb.k[j] * nchunks + sb.chunk) * ncb + cb) * (KQ / 4)) * 64 + lane;
+#pragma unroll
+          for (int v = 0; v < KQ / 4; ++v) {
+            const f32x4 t = p[v * 64];
+            wfn[j][v * 4 + 0] = t.x;
+            wfn[j][v * 4 + 1] = t.y;
+            wfn[j][v * 4 + 2] = t.z;
+            wfn[j][v * 4 + 3] = t.w;
+          }
+        }
+      }
+    };
+    Super sA = next_super();
+    if (sA.nsub > 0) {
+      Super sB = next_super();
+      Super sC = next_super();
+      load_ws(sA);
+      load_sidx(sA.g0, 0);
+      gather(G0, sA.chunk, sA.g0, 0);
+      load_sidx(sB.g0, 0);
+      while (sA.nsub > 0) {
+        __syncthreads();
+        write_stage(G0, sA.chunk);
+#pragma unroll
+        for (int j = 0; j < MAXSUB; ++j) {
+#pragma unroll
+          for (int sx = 0; sx < KQ; ++sx) wf[j][sx] = wfn[j][sx];
+        }
+        __syncthreads();
+        load_ws(sB);
+        gather(G0, sB.chunk, sB.g0, 0);
+        load_sidx(sC.g0, 0);
+        {
+          const float *a0p = &s_a[i16 * A_LD];
+          const int32_t *dstp = &s_dst[i16];
+          float *accp = &s_acc[wave * 16 + q * 4];
+          if (sA.nsub > 1) {   // wave-uniform
+            mma_singles_f32<MAXSUB, KQ, A_LD, ACC_LD>(a0p, pofs, wf, sA.nsub, dstp, accp);
+          } else {
+            const int g = sA.sg[0];
+            if (g == 4) {
+              mma_groups<2, KQ, A_LD, ACC_LD, 0>(a0p, pofs, wf[0], dstp, accp);
+              mma_groups<2, KQ, A_LD, ACC_LD, 0>(a0p + 32 * A_LD, pofs, wf[0], dstp + 32, accp);
+            } else if (g == 3) {
+              mma_groups<2, KQ, A_LD, ACC_LD, 0>(a0p, pofs, wf[0], dstp, accp);
+              mma_groups<1, KQ, A_LD, ACC_LD, 0>(a0p + 32 * A_LD, pofs, wf[0], dstp + 32, accp);
+            } else if (g == 2) {
+              mma_groups<2, KQ, A_LD, ACC_LD, 0>(a0p, pofs, wf[0], dstp, accp);
+            } else {
+              mma_groups<1, KQ, A_LD, ACC_LD, 0>(a0p, pofs, wf[0], dstp, accp);
+            }
+          }
+        }
+        sA = sB;
+        sB = sC;
+        sC = next_super();
+      }
+    }
+  } else if (n_it > 0) {
     // batch cursors: A = it, B = it + 1, C = it + 2 (clamped to the last batch: the tail of a tile repeats
     // its last loads instead of branching around them)
     int chA, gA, nA, kA, chB, gB, nB, kB, chC, gC, nC, kC;
@@ -1940,7 +2097,7 @@ template <int NC, int KC, int VAR>
 static int launch_conv_tile(const float *src, int c_src, const float *wp, int c_dst, int slabs,
                             const int32_t *plan_src, const int32_t *plan_dst, const int32_t *batch_desc,
                             const int32_t *tile_bptr, const int32_t *order, float *dst, int64_t n_tgt,
-                            int tile_rows, int batch_groups, hipStream_t stream, bool small = false) {
+                            int tile_rows, int batch_groups, hipStream_t stream, bool small = false, bool fuse = false) {
   // variants 2048 + n (experiment): n KiB of unused LDS, to cap the resident workgroups per CU
   const int lds = conv_lds_bytes(NC, KC, tile_rows, batch_groups) +
                   (g_conv_variant >= 2048 && g_conv_variant < 3000 ? (g_conv_variant - 2048) * 1024 : 0);
@@ -1951,12 +2108,21 @@ static int launch_conv_tile(const float *src, int c_src, const float *wp, int c_
   small = small && kHasSmall;
   typedef void (*kernel_t)(const float *, int, const f32x4 *, int, const int32_t *, const int32_t *, const int32_t *,
                            const int32_t *, const int32_t *, float *, int64_t, int, int);
-  const kernel_t fn = small ? (exact ? &k_conv_tile_f32<NC, KC, true, VAR, kHasSmall>
-                                     : &k_conv_tile_f32<NC, KC, false, VAR, kHasSmall>)
-                            : (exact ? &k_conv_tile_f32<NC, KC, true, VAR, false>
-                                     : &k_conv_tile_f32<NC, KC, false, VAR, false>);
-  static bool attr_set[4] = {false, false, false, false};  // per instantiation
-  const int which = (small ? 2 : 0) + (exact ? 1 : 0);
+  kernel_t fn = small ? (exact ? &k_conv_tile_f32<NC, KC, true, VAR, kHasSmall>
+                               : &k_conv_tile_f32<NC, KC, false, VAR, kHasSmall>)
+                      : (exact ? &k_conv_tile_f32<NC, KC, true, VAR, false>
+                               : &k_conv_tile_f32<NC, KC, false, VAR, false>);
+  // multi-offset batches (sparse maps; host policy): narrow shapes with the small-address path only — wide layers
+  // run the split kernels, and the weights of four offsets have to fit the registers
+  constexpr bool kHasFuse = VAR == 0 && NC <= 64 && KC <= 64;
+  if constexpr (kHasFuse) {
+    if (fuse && small) fn = exact ? &k_conv_tile_f32<NC, KC, true, 0, true, true> : &k_conv_tile_f32<NC, KC, false, 0, true, true>;
+    else fuse = false;
+  } else {
+    fuse = false;
+  }
+  static bool attr_set[6] = {false, false, false, false, false, false};  // per instantiation
+  const int which = fuse ? 4 + (exact ? 1 : 0) : (small ? 2 : 0) + (exact ? 1 : 0);
   if (lds > 48 * 1024 && !attr_set[which]) {
     ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                kLdsBudget));
@@ -2282,10 +2448,10 @@ int me_conv_pack_weights_f32(const float *w, int64_t volume, int32_t c_src, int3
   return 0;
 }
 
-int me_conv_target_f32(const float *src, int64_t n_src, int32_t c_src, const float *wp, int64_t volume,
-                       int32_t c_dst, const int32_t *plan_src, const int32_t *plan_dst,
-                       const int32_t *batch_desc, const int32_t *tile_bptr, const int32_t *order, float *dst,
-                       int64_t n_tgt, int32_t tile_rows, int32_t batch_groups, void *stream_) {
+static int conv_target_f32(const float *src, int64_t n_src, int32_t c_src, const float *wp, int64_t volume,
+                           int32_t c_dst, const int32_t *plan_src, const int32_t *plan_dst,
+                           const int32_t *batch_desc, const int32_t *tile_bptr, const int32_t *order, float *dst,
+                           int64_t n_tgt, int32_t tile_rows, int32_t batch_groups, void *stream_, bool fuse) {
   hipStream_t stream = (hipStream_t)stream_;
   (void)volume;
   ME_CHECK(c_src > 0 && c_dst > 0, "channel counts must be positive");
@@ -2330,7 +2496,7 @@ int me_conv_target_f32(const float *src, int64_t n_src, int32_t c_src, const flo
     }
   }
 #endif
-#define ME_CONV_CASE(NCV, KCV) return launch_conv_tile<NCV, KCV, 0>(ME_CONV_ARGS, small)
+#define ME_CONV_CASE(NCV, KCV) return launch_conv_tile<NCV, KCV, 0>(ME_CONV_ARGS, small, fuse)
   if (v.nc == 96) {
     if (v.kc == 96) ME_CONV_CASE(96, 96);
     if (v.kc == 64) ME_CONV_CASE(96, 64);
@@ -2349,6 +2515,22 @@ int me_conv_target_f32(const float *src, int64_t n_src, int32_t c_src, const flo
   }
 #undef ME_CONV_CASE
 #undef ME_CONV_ARGS
+}
+
+int me_conv_target_f32(const float *src, int64_t n_src, int32_t c_src, const float *wp, int64_t volume,
+                       int32_t c_dst, const int32_t *plan_src, const int32_t *plan_dst,
+                       const int32_t *batch_desc, const int32_t *tile_bptr, const int32_t *order, float *dst,
+                       int64_t n_tgt, int32_t tile_rows, int32_t batch_groups, void *stream) {
+  return conv_target_f32(src, n_src, c_src, wp, volume, c_dst, plan_src, plan_dst, batch_desc, tile_bptr, order, dst,
+                         n_tgt, tile_rows, batch_groups, stream, false);
+}
+
+int me_conv_target_f32_fused(const float *src, int64_t n_src, int32_t c_src, const float *wp, int64_t volume,
+                             int32_t c_dst, const int32_t *plan_src, const int32_t *plan_dst,
+                             const int32_t *batch_desc, const int32_t *tile_bptr, const int32_t *order, float *dst,
+                             int64_t n_tgt, int32_t tile_rows, int32_t batch_groups, void *stream) {
+  return conv_target_f32(src, n_src, c_src, wp, volume, c_dst, plan_src, plan_dst, batch_desc, tile_bptr, order, dst,
+                         n_tgt, tile_rows, batch_groups, stream, true);
 }
 
 int32_t me_debug_variants_compiled(void) {

@@ -61,6 +61,7 @@ struct Policy {
   int f32_split;           // ME_AMD_F32_SPLIT: 1 / 0 / -1 (auto)
   int tile_rows, batch_groups;   // ME_AMD_TILE_ROWS / ME_AMD_BATCH_GROUPS overrides (0 = plan config)
   bool pack_cache;         // ME_AMD_PACK_CACHE
+  bool f32_fuse;           // ME_AMD_F32_FUSE
   static const Policy &get();
 };
 

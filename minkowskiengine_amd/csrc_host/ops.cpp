@@ -260,7 +260,7 @@ static Tensor conv_target(const Tensor &src, const Tensor &kernel, KernelMap &km
   Tensor packed = at::empty({cfg.elems}, at::TensorOptions().dtype(at::kFloat).device(dev));
   me_ok(me_conv_pack_weights_f32(ptr<float>(kernel), volume, c_src, c_dst, transposed ? 1 : 0, ptr<float>(packed), st));
   ScopedTimer tm(timed_name, flops, st);
-  me_ok(me_conv_target_f32(ptr<float>(src), src.size(0), c_src, ptr<float>(packed), km.volume, c_dst,
+  me_ok((cfg.fuse && Policy::get().f32_fuse ? me_conv_target_f32_fused : me_conv_target_f32)(ptr<float>(src), src.size(0), c_src, ptr<float>(packed), km.volume, c_dst,
                            ptr<int32_t>(p.plan_src), ptr<int32_t>(p.plan_dst), ptr<int32_t>(p.batch_desc),
                            ptr<int32_t>(p.tile_bptr), ptr<int32_t>(cfg.order), ptr<float>(out), n_tgt, cfg.tile_rows,
                            cfg.batch_groups, st));

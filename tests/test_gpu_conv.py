@@ -506,3 +506,37 @@ def test_nonfinite_and_tiny_inputs_follow_fp32_semantics(device, monkeypatch, pi
         assert np.array_equal(~np.isfinite(y2), ~np.isfinite(want2))
     finally:
         lib.me_debug_set_wgrad_config(0, 0)
+
+
+@pytest.mark.parametrize("n,extent,D,cin,cout", [(3000, 9, 4, 32, 64), (3000, 9, 4, 64, 32), (6000, 40, 3, 32, 32),
+                                                  (5000, 40, 3, 16, 48), (5000, 40, 3, 20, 24), (4000, 30, 3, 64, 64),
+                                                  (3000, 14, 3, 32, 64)])
+def test_multi_offset_batches_of_the_fp32_kernel_match_the_oracle(device, monkeypatch, n, extent, D, cin, cout):
+    """me_conv_target_f32_fused: runs of single-group batches of consecutive offsets (a sparse map's plan) staged and
+    multiplied together, each group with its own offset's weights.  Forward and input gradient against the oracle
+    per element (1e-4 + 1e-4 |ref|), bitwise reproducible, and the unfused kernel agrees to fp32 rounding."""
+    from minkowskiengine_amd import backend as MEB
+    monkeypatch.setattr(MEB, "_F32_SPLIT", False)
+    coords = make_cloud(n, extent, D, seed=cin + cout, batch=2, negative=True)
+    mgr = MEB.CoordinateMapManagerGPU_c10()
+    key, _ = mgr.insert_and_map(coords.to(device), [1] * D, "")
+    km = mgr._kernel_map(key, key, [3] * D, [1] * D, [1] * D, MEB.RegionType.HYPER_CUBE, None, False, False)
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(coords.shape[0], cin, generator=g) - 0.5
+    gy = torch.rand(coords.shape[0], cout, generator=g) - 0.5
+    w = torch.rand(3 ** D, cin, cout, generator=g) - 0.5
+    res = {}
+    for fuse in ("1", "1", "0"):
+        monkeypatch.setattr(MEB, "_BF16_FUSE", fuse)
+        km._launch_cache.clear()
+        y = MEB._conv_forward(x.to(device), w.to(device), km, "mfma")
+        gi = MEB._conv_target(gy.to(device), w.to(device), km, "in", km.n_in, name="d", transposed=True)
+        res.setdefault(fuse, []).append((y.clone(), gi.clone()))
+    assert torch.equal(res["1"][0][0], res["1"][1][0]) and torch.equal(res["1"][0][1], res["1"][1][1])
+    _, okm = O.kernel_map(coords.numpy(), coords.numpy(), O.make_region(D, 3))
+    want_y = O.conv_forward(x.numpy(), w.numpy(), okm, len(coords))
+    want_gi = O.conv_backward(x.numpy(), gy.numpy(), w.numpy(), okm)[0]
+    for fuse in ("1", "0"):
+        assert_close(res[fuse][0][0], want_y, what=f"forward fuse={fuse}")
+        assert_close(res[fuse][0][1], want_gi, what=f"grad_in fuse={fuse}")
+    assert_close(res["1"][0][0], res["0"][0][0].cpu().numpy(), 5e-5, 5e-5, what="fused vs unfused")
