@@ -1214,7 +1214,13 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 3)) void k_wgrad_f32(const T *_
 // and the pair indices of step s+2 are being fetched while step s is multiplied.
 constexpr int kWgStepLd = 16;  // padding elements per staged row
 
-template <int NB, int KSTEPS>
+// DEEP (round 3): TWO steps of gathered rows in flight instead of one.  The loop is bound by the latency of its row
+// gathers (24 KiB per step and workgroup, two workgroups per CU: ~30 GB/s per CU against the ~150 GB/s the vector memory
+// path delivers with enough requests outstanding), and at two waves per SIMD the register file has room for a second
+// set of staging registers: at step s the rows of step s + 1 are in flight, the rows of step s + 2 are requested and
+// the indices of step s + 3 are fetched; the loads retire in order, so ONE counted wait per step (all but the newest
+// row set) guards both the rows of step s and the indices of step s + 2.  Same sums in the same order: bit-identical.
+template <int NB, int KSTEPS, bool DEEP = false>
 __global__ __launch_bounds__(256, 2) void k_wgrad_bf16(const __bf16 *__restrict__ x, int c_in,
                                                       const __bf16 *__restrict__ dy, int c_out,
                                                       const int32_t *__restrict__ in_pairs,
@@ -1391,6 +1397,109 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_bf16(const __bf16 *__restrict_
   int64_t eC = eB;
   advance(kC, eC, cB);
   int cC = step_count(kC, eC);
+
+  if constexpr (DEEP) {
+    // second register set + second index pair; the generic lambdas below work on whichever set they are handed
+    int32_t pin2 = 0, pout2 = 0;
+    bf16x8 rx2[XP], rd2[DP];
+    auto idx_into = [&](int32_t &pi_, int32_t &po_, int64_t e) {
+      const int64_t ec = min(e + lane, n_pairs - 1);
+      const int32_t *pi = in_pairs + ec, *po = out_pairs + ec;
+      asm volatile("global_load_dword %0, %1, off" : "=v"(pi_) : "v"(pi) : "memory");
+      asm volatile("global_load_dword %0, %1, off" : "=v"(po_) : "v"(po) : "memory");
+    };
+    auto rows_into = [&](bf16x8 (&ax)[XP], bf16x8 (&ad)[DP], int32_t pi_, int32_t po_) {
+#pragma unroll
+      for (int j = 0; j < XP; ++j) {
+        const int idx = j * 256 + tid;
+        const int row = idx >> 3;
+        const int ch = ci0 + (idx & 7) * 8;
+        const int32_t r = __shfl(pi_, row, 64);
+        const __bf16 *p = x + (int64_t)r * c_in + (ch < c_in ? ch : 0);
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ax[j]) : "v"(p) : "memory");
+      }
+#pragma unroll
+      for (int j = 0; j < DP; ++j) {
+        const int idx = j * 256 + tid;
+        const int row = idx / (COB / 8);
+        const int ch = cog + (idx % (COB / 8)) * 8;
+        const int32_t r = __shfl(po_, row, 64);
+        const __bf16 *p = dy + (int64_t)r * c_out + (ch < c_out ? ch : 0);
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ad[j]) : "v"(p) : "memory");
+      }
+    };
+    auto lds_from = [&](const bf16x8 (&ax)[XP], const bf16x8 (&ad)[DP], int buf_, int cnt) {
+      const bf16x8 zero = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+#pragma unroll
+      for (int j = 0; j < XP; ++j) {
+        const int idx = j * 256 + tid;
+        const int row = idx >> 3;
+        const int ch = ci0 + (idx & 7) * 8;
+        const bool ok = row < cnt && ch < c_in;
+        *reinterpret_cast<bf16x8 *>(s_x + (buf_ * SP + row) * XLD + (idx & 7) * 8) = ok ? ax[j] : zero;
+      }
+#pragma unroll
+      for (int j = 0; j < DP; ++j) {
+        const int idx = j * 256 + tid;
+        const int row = idx / (COB / 8);
+        const int pc = idx % (COB / 8);
+        const bool ok = row < cnt && cog + pc * 8 < c_out;
+        *reinterpret_cast<bf16x8 *>(s_d + (buf_ * SP + row) * DLD + pc * 8) = ok ? ad[j] : zero;
+      }
+    };
+    // step D = three ahead (its indices are fetched while step A is multiplied)
+    int kD = kC;
+    int64_t eD = eC;
+    advance(kD, eD, cC);
+    int cD = step_count(kD, eD);
+    // prologue: indices of A and B, rows of A (set 1) and B (set 2), indices of C (pair 1)
+    idx_into(pin, pout, eA);
+    idx_into(pin2, pout2, eB);
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pin), "+v"(pout), "+v"(pin2), "+v"(pout2));
+    rows_into(rx, rd, pin, pout);
+    idx_into(pin, pout, eC);            // (issued BEFORE the rows of B: it must have arrived when they may still fly)
+    rows_into(rx2, rd2, pin2, pout2);
+    zero_acc();
+    int buf = 0;
+    int pending = -1;
+    // one step: `ax/ad` hold the rows of step A (requested two steps ago), `pi/po` the indices of step C (requested one
+    // step ago, before the rows of step B); the rows of step B — XP + DP loads — may stay in flight across the wait
+    auto step = [&](bf16x8 (&ax)[XP], bf16x8 (&ad)[DP], int32_t &pi_, int32_t &po_, int32_t &pi_next, int32_t &po_next) {
+      if (pending >= 0) {
+        flush(pending);
+        zero_acc();
+      }
+      asm volatile("s_waitcnt vmcnt(%0)" : : "n"(XP + DP) : "memory");
+#pragma unroll
+      for (int j = 0; j < XP; ++j) asm volatile("" : "+v"(ax[j]));
+#pragma unroll
+      for (int j = 0; j < DP; ++j) asm volatile("" : "+v"(ad[j]));
+      asm volatile("" : "+v"(pi_), "+v"(po_));
+      lds_from(ax, ad, buf, cA);
+      idx_into(pi_next, po_next, eD);          // indices of step D first ...
+      rows_into(ax, ad, pi_, po_);             // ... then the rows of step C into the set just stored
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      multiply(buf);
+      pending = (cB == 0 || kB != kA) ? kA : -1;
+      buf ^= 1;
+      kA = kB; eA = eB; cA = cB;
+      kB = kC; eB = eC; cB = cC;
+      kC = kD; eC = eD; cC = cD;
+      advance(kD, eD, cD);
+      cD = step_count(kD, eD);
+    };
+    while (cA > 0) {
+      // (index pairs alternate with the row sets: the rows of step C are addressed by the pair that was requested a
+      // step ago, and the pair that addressed step B — consumed a step ago — receives the indices of step D)
+      step(rx, rd, pin, pout, pin2, pout2);
+      if (cA <= 0) break;
+      step(rx2, rd2, pin2, pout2, pin, pout);
+    }
+    if (pending >= 0) flush(pending);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (loads issued for steps beyond the range target live registers)
+    return;
+  }
 
   load_idx(eA);
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(pin), "+v"(pout));
@@ -2247,14 +2356,20 @@ static int launch_wgrad_bf16(const WgradGeom &g, const __bf16 *x, int c_in, cons
                              int volume, int64_t n_pairs, float *partial, hipStream_t stream) {
   constexpr int SP = 32 * KSTEPS;
   const int lds = 2 * SP * ((64 + kWgStepLd) + (64 * NB + kWgStepLd)) * 2;
-  static bool attr_set = false;
-  if (lds > 32 * 1024 && !attr_set) {
-    ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wgrad_bf16<NB, KSTEPS>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
-    attr_set = true;
+  // two steps of rows in flight: built and measured in round 3, NOT the default — MinkUNet34C bf16 15.0 ms per step
+  // against 14.8 with one step in flight (weight-gradient launches 52.8 us on average against 49.2,
+  // profiles/r03_wgrad_bf16_two_steps_in_flight.log): the loop is not waiting for more requests in flight.
+  // me_debug_set_wgrad_config(2, ..) selects it (bit-identical results, tests/test_gpu_bf16.py).
+  const bool deep = g_wgrad_depth == 2;
+  auto fn = deep ? &k_wgrad_bf16<NB, KSTEPS, true> : &k_wgrad_bf16<NB, KSTEPS, false>;
+  static bool attr_set[2] = {false, false};
+  if (lds > 32 * 1024 && !attr_set[deep]) {
+    ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               kLdsBudget));
+    attr_set[deep] = true;
   }
   const dim3 grid((unsigned)g.ranges, (unsigned)g.n_cib, (unsigned)g.gz);
-  hipLaunchKernelGGL((k_wgrad_bf16<NB, KSTEPS>), grid, dim3(256), (size_t)lds, stream, x, c_in, dy, c_out, in_pairs,
+  hipLaunchKernelGGL(fn, grid, dim3(256), (size_t)lds, stream, x, c_in, dy, c_out, in_pairs,
                      out_pairs, k_offsets_dev, volume, n_pairs, (int)g.ranges, g.n_cob, partial);
   ME_LAUNCH_CHECK();
   return 0;

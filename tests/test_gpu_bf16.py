@@ -252,3 +252,33 @@ def test_bf16_slab_width_does_not_change_a_bit(device, cin, cout, shapes):
     for shp in res:
         assert_bf16_close(res[shp][0].float().cpu().numpy(), want_y, f"forward {shp}")
         assert_bf16_close(res[shp][1].float().cpu().numpy(), want_gi, f"grad_in {shp}")
+
+
+@pytest.mark.parametrize("n,extent,cin,cout,ks,D", [(6000, 40, 96, 96, 3, 3), (4000, 14, 64, 128, 3, 3), (300, 6, 256, 256, 3, 3),
+                                                     (3000, 9, 32, 64, 3, 4), (5000, 16, 128, 96, 2, 3), (70, 3, 64, 64, 3, 3)])
+def test_wgrad_bf16_two_steps_in_flight_is_bit_identical(device, n, extent, cin, cout, ks, D):
+    """k_wgrad_bf16<.., DEEP> (me_debug_set_wgrad_config(2, 0); measured slower, not the default): the rows of TWO
+    64-pair steps in flight (second register set, one counted wait per step) instead of one — same steps, same MFMAs,
+    same flushes: the weight gradient must be bit-identical to the shipped one-step pipeline, for ranges shorter than
+    the pipeline too, and match the oracle."""
+    from minkowskiengine_amd import backend as MEB, _lib
+    lib = _lib.load()
+    coords = make_cloud(n, extent, D, seed=cin + cout, batch=2, negative=True)
+    mgr = MEB.CoordinateMapManagerGPU_c10()
+    key, _ = mgr.insert_and_map(coords.to(device), [1] * D, "")
+    km = mgr._kernel_map(key, key, [ks] * D, [1] * D, [1] * D, MEB.RegionType.HYPER_CUBE, None, False, False)
+    g = torch.Generator().manual_seed(6)
+    x = bf16_round(torch.rand(coords.shape[0], cin, generator=g) - 0.5)
+    gy = bf16_round(torch.rand(coords.shape[0], cout, generator=g) - 0.5)
+    w = bf16_round(torch.rand(ks ** D, cin, cout, generator=g) - 0.5)
+    res = {}
+    try:
+        for depth in (0, 2):
+            lib.me_debug_set_wgrad_config(depth, 0)
+            res[depth] = MEB._conv_backward(x.to(device).bfloat16(), gy.to(device).bfloat16(), w.to(device), km, "mfma",
+                                            need_grad_in=False)[1].clone()
+    finally:
+        lib.me_debug_set_wgrad_config(0, 0)
+    assert torch.equal(res[0], res[2])
+    _, okm = O.kernel_map(coords.numpy(), coords.numpy(), O.make_region(D, ks))
+    assert_close(res[0], O.conv_backward(x.numpy(), gy.numpy(), w.numpy(), okm)[1])
