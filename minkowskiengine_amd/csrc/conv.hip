@@ -2000,11 +2000,16 @@ __global__ __launch_bounds__(64 * kWgReducePhases) void k_wgrad_reduce(const flo
                                                      const int64_t *__restrict__ koffs, int volume,
                                                      int64_t n_pairs, int n_ranges, int n_cib, int n_cob,
                                                      int c_in, int c_out, float *__restrict__ grad_w) {
+  // Round 3: a thread owns FOUR consecutive floats of the register image (one 16-byte load per slot) and a block 256 of
+  // them: a quarter of the blocks, waves and load instructions of the one-float version, which spent its time
+  // dispatching 110k four-instruction waves on a 256 x 256 layer (33 us for 23 MB of partials, longer than the
+  // weight-gradient kernel it follows: profiles/r03_pmc_bf16_layers.log).  The sums are the same sums in the same
+  // order (per element: slots of a phase in ascending order, then the phases in order): bit-identical results.
   constexpr int MB = kWgMB;
   constexpr int kImage = MB * NB * 4 * 64;
   constexpr int PH = kWgReducePhases;
   __shared__ int64_t s_r[2];
-  __shared__ float s_part[PH][64];
+  __shared__ f32x4 s_part[PH][64];
   const int k = blockIdx.y;
   const int64_t b = koffs[k], e = koffs[k + 1];
   if (threadIdx.x == 0) {
@@ -2019,21 +2024,21 @@ __global__ __launch_bounds__(64 * kWgReducePhases) void k_wgrad_reduce(const flo
   // the waves take the slots first + phase, + PH, ...; eight independent loads in flight per thread (the centre
   // offset of a sparse map owns half of all slots: its block sets the kernel's duration, and the loop is latency-bound)
   const int j = threadIdx.x & 63, phase = threadIdx.x >> 6;
-  const int64_t idx = (int64_t)blockIdx.x * 64 + j;
+  const int64_t idx = ((int64_t)blockIdx.x * 64 + j) * 4;      // first of this thread's four floats (kImage % 256 == 0)
   const int64_t per_slot = (int64_t)n_cib * n_cob * kImage;
-  float s = 0.f;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (idx < per_slot) {
     const int64_t first = s_r[0], last = s_r[1];
     const float *p = partial + idx;
     int64_t slot = first + phase;
     for (; slot + 7 * PH <= last; slot += 8 * PH) {
-      float v[8];
+      f32x4 v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = p[(slot + u * PH) * per_slot];
+      for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4 *>(p + (slot + u * PH) * per_slot);
 #pragma unroll
       for (int u = 0; u < 8; ++u) s += v[u];
     }
-    for (; slot <= last; slot += PH) s += p[slot * per_slot];
+    for (; slot <= last; slot += PH) s += *reinterpret_cast<const f32x4 *>(p + slot * per_slot);
   }
   s_part[phase][j] = s;
   __syncthreads();
@@ -2041,15 +2046,33 @@ __global__ __launch_bounds__(64 * kWgReducePhases) void k_wgrad_reduce(const flo
   s = s_part[0][j];
 #pragma unroll
   for (int ph = 1; ph < PH; ++ph) s += s_part[ph][j];   // fixed order: bitwise reproducible
-  const int lane = (int)(idx % 64);
+  // the four floats are four consecutive LANES of one register of the image (idx % 4 == 0, 64 lanes per register)
+  const int lane0 = (int)(idx % 64);
   const int reg = (int)((idx / 64) % (MB * NB * 4));
   const int cob = (int)((idx / kImage) % n_cob);
   const int cib = (int)(idx / ((int64_t)kImage * n_cob));
   const int r = reg % 4, n = (reg / 4) % NB, m = reg / (4 * NB);
-  const int i16 = lane & 15, q = lane >> 4;
+  const int q = lane0 >> 4;
   const int ci = cib * (16 * MB) + (TR ? 16 * m + 4 * q + r : MB * (4 * q + r) + m);
-  const int co = cob * (16 * NB) + (TR ? 16 * n + i16 : NB * i16 + n);
-  if (ci < c_in && co < c_out) grad_w[((int64_t)k * c_in + ci) * c_out + co] = s;
+  if (ci >= c_in) return;
+  float *row = grad_w + ((int64_t)k * c_in + ci) * c_out;
+  if (TR) {
+    // co = cob * 16 * NB + 16 * n + i16 with i16 = lane & 15: four consecutive output channels
+    const int co = cob * (16 * NB) + 16 * n + (lane0 & 15);
+    if ((c_out % 4) == 0 && co + 3 < c_out) {
+      *reinterpret_cast<f32x4 *>(row + co) = s;
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (co + t < c_out) row[co + t] = s[t];
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int co = cob * (16 * NB) + NB * ((lane0 + t) & 15) + n;
+      if (co < c_out) row[co] = s[t];
+    }
+  }
 }
 
 // =================================================================================================
@@ -2504,7 +2527,7 @@ static int wgrad_launch(const T *x, int64_t n_in, int32_t c_in, const T *dy, int
 #undef ME_WGRAD_LAUNCH
     ME_LAUNCH_CHECK();
   }
-  const dim3 rgrid((unsigned)ceil_div(g.slot_floats, 64), (unsigned)volume);
+  const dim3 rgrid((unsigned)ceil_div(g.slot_floats, 256), (unsigned)volume);
 #define ME_WGRAD_REDUCE(NBV)                                                                               \
   hipLaunchKernelGGL((k_wgrad_reduce<NBV, false>), rgrid, dim3(64 * kWgReducePhases), 0, stream, partial, k_offsets_dev, (int)volume, \
                      n_pairs > 0 ? n_pairs : 1, (int)g.ranges, g.n_cib, g.n_cob, c_in, c_out, grad_w)
@@ -2734,7 +2757,7 @@ int me_conv_wgrad_f32(const float *x, int64_t n_in, int32_t c_in, const float *d
                                                         (int)volume, n_pairs, partial, order, stream);
       if (rc != 0) return rc;
     }
-    const dim3 rgrid((unsigned)ceil_div(g.slot_floats, 64), (unsigned)volume);
+    const dim3 rgrid((unsigned)ceil_div(g.slot_floats, 256), (unsigned)volume);
     if (g.nb == 1)
       hipLaunchKernelGGL((k_wgrad_reduce<1, true>), rgrid, dim3(64 * kWgReducePhases), 0, stream, partial, k_offsets_dev,
                          (int)volume, n_pairs > 0 ? n_pairs : 1, (int)g.ranges, g.n_cib, g.n_cob, c_in, c_out, grad_w);
@@ -2764,7 +2787,7 @@ int me_conv_wgrad_f32(const float *x, int64_t n_in, int32_t c_in, const float *d
                                       partial, stream);
     if (rc != 0) return rc;
   }
-  const dim3 rgrid((unsigned)ceil_div(g.slot_floats, 64), (unsigned)volume);
+  const dim3 rgrid((unsigned)ceil_div(g.slot_floats, 256), (unsigned)volume);
   if (g.nb == 1)
     hipLaunchKernelGGL((k_wgrad_reduce<1, true>), rgrid, dim3(64 * kWgReducePhases), 0, stream, partial, k_offsets_dev, (int)volume,
                        n_pairs > 0 ? n_pairs : 1, (int)g.ranges, g.n_cib, g.n_cob, c_in, c_out, grad_w);
@@ -2817,7 +2840,7 @@ int me_conv_wgrad_bf16(const uint16_t *x_, int64_t n_in, int32_t c_in, const uin
 #undef ME_WG16
     if (rc != 0) return rc;
   }
-  const dim3 rgrid((unsigned)ceil_div(g.slot_floats, 64), (unsigned)volume);
+  const dim3 rgrid((unsigned)ceil_div(g.slot_floats, 256), (unsigned)volume);
 #define ME_WGRAD_REDUCE_TR(NBV)                                                                               \
   hipLaunchKernelGGL((k_wgrad_reduce<NBV, true>), rgrid, dim3(64 * kWgReducePhases), 0, stream, partial, k_offsets_dev, (int)volume, \
                      n_pairs > 0 ? n_pairs : 1, (int)g.ranges, g.n_cib, g.n_cob, c_in, c_out, grad_w)
