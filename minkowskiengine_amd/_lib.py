@@ -168,6 +168,7 @@ DEBUG_SIGNATURES = {
     "me_debug_set_wgrad_config": (None, [ctypes.c_int, ctypes.c_int]),
     "me_debug_set_wgrad_order": (None, [ctypes.c_int]),
     "me_debug_set_bf16_shape": (None, [ctypes.c_int, ctypes.c_int]),
+    "me_debug_set_bf16_deep": (None, [ctypes.c_int]),
 }
 
 _lib = None

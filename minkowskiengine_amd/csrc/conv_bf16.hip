@@ -134,8 +134,13 @@ __host__ __device__ constexpr int conv_bf16_waves_per_simd(int nc, int kc) {
   return (nc == 128 && kc <= 128) ? 4 : (nc == 128 ? 2 : 3);   // (96 columns: six waves, 3 per SIMD = two workgroups per CU)
 }
 
-template <int NC, int KC, bool EXACT, bool SMALL, bool FUSE = false>
-__global__ __launch_bounds__(NC * 4, conv_bf16_waves_per_simd(NC, KC)) void k_conv_tile_bf16(
+// DEEP (round 3): the gathers and weights of the batch after next are requested while a batch multiplies — two
+// register sets, the loop unrolled by two.  For launches that leave ONE workgroup per CU (a 256-channel chunk's 64
+// weight registers per lane; a coarse level's 128 - 256 tiles): nothing else hides the L2 latency of the next
+// batch's 32 - 64 KB weight slice there, and a batch of one or two groups lasted one memory round trip (2 us on the
+// 5k-voxel 256 -> 256 layers for ~0.2 us of matrix work).  Same sums in the same order: bit-identical to the plain loop.
+template <int NC, int KC, bool EXACT, bool SMALL, bool FUSE = false, bool DEEP = false>
+__global__ __launch_bounds__(NC * 4, DEEP ? 2 : conv_bf16_waves_per_simd(NC, KC)) void k_conv_tile_bf16(
     const __bf16 *__restrict__ src, int c_src, const bf16x8 *__restrict__ wp, int c_dst,
     const int32_t *__restrict__ plan_src, const int32_t *__restrict__ plan_dst,
     const int32_t *__restrict__ batch_desc, const int32_t *__restrict__ tile_bptr,
@@ -258,7 +263,7 @@ __global__ __launch_bounds__(NC * 4, conv_bf16_waves_per_simd(NC, KC)) void k_co
   };
   const char *srcb = reinterpret_cast<const char *>(src);
   const unsigned row_bytes = (unsigned)c_src * 2u;
-  auto gather = [&](int chunk, int g0) {
+  auto gather = [&](int chunk, int g0, bf16x8 (&stage)[ITER], int32_t &dstv) {
     const int c0 = chunk * KC;
     dstv = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(plan_dst + (int64_t)g0 * 16) +
                                              (unsigned)(min(tid, ME_MAX_BATCH_GROUPS * 16 - 1) * 4));
@@ -285,7 +290,7 @@ __global__ __launch_bounds__(NC * 4, conv_bf16_waves_per_simd(NC, KC)) void k_co
       }
     }
   };
-  auto write_stage = [&](int chunk) {
+  auto write_stage = [&](int chunk, const bf16x8 (&stage)[ITER], int32_t dstv) {
     const int c0 = chunk * KC;
 #pragma unroll
     for (int j = 0; j < ITER; ++j) {
@@ -303,7 +308,7 @@ __global__ __launch_bounds__(NC * 4, conv_bf16_waves_per_simd(NC, KC)) void k_co
     if (tid < cap_rows) s_dst[tid] = dstv;
   };
   // weights of every sub-batch of a super-batch (wave-uniform branches: a dense batch loads one slice)
-  auto load_w = [&](const Super &sb) {
+  auto load_w = [&](const Super &sb, bf16x8 (&wnxt)[MAXSUB][KS]) {
 #pragma unroll
     for (int j = 0; j < MAXSUB; ++j) {
       if (j == 0 || j < sb.nsub) {
@@ -314,46 +319,102 @@ __global__ __launch_bounds__(NC * 4, conv_bf16_waves_per_simd(NC, KC)) void k_co
     }
   };
 
+  auto multiply = [&](const Super &sb, const bf16x8 (&wreg)[MAXSUB][KS]) {
+    const __bf16 *a0p = &s_a[i16 * A_LD + q * 8];
+    const int32_t *dstp = &s_dst[i16];
+    float *accp = &s_acc[wave * 16 + q * 4];
+    if (MAXSUB > 1 && sb.nsub > 1) {   // wave-uniform
+      mma_singles_bf16<MAXSUB, KS, A_LD, ACC_LD>(a0p, wreg, sb.nsub, dstp, accp);
+    } else {
+      const int g = sb.sg[0];
+      if (g == 4) {
+        mma_groups_bf16<4, KS, A_LD, ACC_LD>(a0p, wreg[0], dstp, accp);
+      } else if (g == 3) {
+        mma_groups_bf16<3, KS, A_LD, ACC_LD>(a0p, wreg[0], dstp, accp);
+      } else if (g == 2) {
+        mma_groups_bf16<2, KS, A_LD, ACC_LD>(a0p, wreg[0], dstp, accp);
+      } else {
+        mma_groups_bf16<1, KS, A_LD, ACC_LD>(a0p, wreg[0], dstp, accp);
+      }
+    }
+  };
+
   Super sA = next_super();
-  if (sA.nsub > 0) {
+  if constexpr (DEEP) {
+    static_assert(EXACT && SMALL, "the deep pipeline: whole chunks, 32-bit offsets");
+    if (sA.nsub > 0) {
+      bf16x8 stage1[ITER], wnxt1[MAXSUB][KS];
+      int32_t dstv1 = tile_rows;
+      Super sB = next_super();
+      Super sC = next_super();
+      Super sD = next_super();
+      load_sidx(sA.g0);
+      load_w(sA, wnxt);
+      gather(sA.chunk, sA.g0, stage, dstv);
+      __builtin_amdgcn_sched_barrier(0);   // set 0 strictly older than set 1: the loop's counted waits merge with this path
+      load_sidx(sB.g0);
+      load_w(sB, wnxt1);
+      gather(sB.chunk, sB.g0, stage1, dstv1);
+      load_sidx(sC.g0);
+      // one step: stage and multiply batch A from register set (st, dv, wn); refill the set with batch C.  The
+      // index window of batch D is requested BEFORE the refill: the gather of the next step then waits for loads
+      // older than this refill (vmcnt counts in order), not for the refill itself
+      auto step = [&](bf16x8 (&st)[ITER], int32_t &dv, bf16x8 (&wn)[MAXSUB][KS]) {
+        __syncthreads();
+        write_stage(sA.chunk, st, dv);
+        __syncthreads();
+        int32_t sidx_c[ITER];
+#pragma unroll
+        for (int j = 0; j < ITER; ++j) sidx_c[j] = sidx[j];
+        load_sidx(sD.g0);
+        {   // gather(sC) from the indices loaded one step ago
+          const int c0 = sC.chunk * KC;
+          dv = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(plan_dst + (int64_t)sC.g0 * 16) +
+                                                  (unsigned)(min(tid, ME_MAX_BATCH_GROUPS * 16 - 1) * 4));
+#pragma unroll
+          for (int j = 0; j < ITER; ++j) {
+            const int ch = c0 + ((j * NT + tid) % F8) * 8;
+            const unsigned off = __umul24((unsigned)max(sidx_c[j], 0), row_bytes) + (unsigned)ch * 2u;
+            st[j] = *reinterpret_cast<const bf16x8 *>(srcb + off);
+          }
+        }
+        // the set's weights are multiplied in place and replaced behind the MFMAs (a copy to a third set would
+        // make the refill wait at the loop's back edge)
+        multiply(sA, wn);
+        load_w(sC, wn);
+        sA = sB;
+        sB = sC;
+        sC = sD;
+        sD = next_super();
+      };
+      while (true) {
+        step(stage, dstv, wnxt);
+        if (sA.nsub == 0) break;
+        step(stage1, dstv1, wnxt1);
+        if (sA.nsub == 0) break;
+      }
+    }
+  } else if (sA.nsub > 0) {
     Super sB = next_super();
     Super sC = next_super();
-    load_w(sA);
+    load_w(sA, wnxt);
     load_sidx(sA.g0);
-    gather(sA.chunk, sA.g0);
+    gather(sA.chunk, sA.g0, stage, dstv);
     load_sidx(sB.g0);
 
     while (sA.nsub > 0) {
       __syncthreads();
-      write_stage(sA.chunk);
+      write_stage(sA.chunk, stage, dstv);
 #pragma unroll
       for (int j = 0; j < MAXSUB; ++j) {
 #pragma unroll
         for (int sx = 0; sx < KS; ++sx) wreg[j][sx] = wnxt[j][sx];
       }
       __syncthreads();
-      load_w(sB);
-      gather(sB.chunk, sB.g0);
+      load_w(sB, wnxt);
+      gather(sB.chunk, sB.g0, stage, dstv);
       load_sidx(sC.g0);
-      {
-        const __bf16 *a0p = &s_a[i16 * A_LD + q * 8];
-        const int32_t *dstp = &s_dst[i16];
-        float *accp = &s_acc[wave * 16 + q * 4];
-        if (MAXSUB > 1 && sA.nsub > 1) {   // wave-uniform
-          mma_singles_bf16<MAXSUB, KS, A_LD, ACC_LD>(a0p, wreg, sA.nsub, dstp, accp);
-        } else {
-          const int g = sA.sg[0];
-          if (g == 4) {
-            mma_groups_bf16<4, KS, A_LD, ACC_LD>(a0p, wreg[0], dstp, accp);
-          } else if (g == 3) {
-            mma_groups_bf16<3, KS, A_LD, ACC_LD>(a0p, wreg[0], dstp, accp);
-          } else if (g == 2) {
-            mma_groups_bf16<2, KS, A_LD, ACC_LD>(a0p, wreg[0], dstp, accp);
-          } else {
-            mma_groups_bf16<1, KS, A_LD, ACC_LD>(a0p, wreg[0], dstp, accp);
-          }
-        }
-      }
+      multiply(sA, wreg);
       sA = sB;
       sB = sC;
       sC = next_super();
@@ -574,6 +635,7 @@ struct ConvVariantBf16 {
 };
 
 int g_bf16_nc = 0, g_bf16_kc = 0;   // me_debug_set_bf16_shape: tuning overrides of the slab width / chunk depth (0 = policy)
+int g_bf16_deep = -1;               // me_debug_set_bf16_deep: -1 policy, 0 never, 1 wherever instantiated
 
 static ConvVariantBf16 conv_variant_bf16(int c_src, int c_dst) {
   ConvVariantBf16 v;
@@ -630,8 +692,20 @@ static int launch_conv_tile_bf16(const __bf16 *src, int c_src, const bf16x8 *wp,
   } else {
     fuse = false;
   }
-  static bool attr_set[8] = {false, false, false, false, false, false, false, false};  // per instantiation
-  const int which = (fuse ? 4 : 0) + (small ? 2 : 0) + (exact ? 1 : 0);
+  // deep pipeline (see k_conv_tile_bf16): where one workgroup per CU is all a launch has — a 256-channel chunk (its
+  // registers and LDS allow no second one), or at most ~1.25 workgroups per CU in the grid
+  bool deep = false;
+  if constexpr (NC != 96) {
+    deep = exact && small && (g_bf16_deep >= 0 ? g_bf16_deep != 0 : NC == 128);
+    if (deep) {
+      fn = &k_conv_tile_bf16<NC, KC, true, true, false, true>;
+      if constexpr (NC <= 96 && KC <= 128) {
+        if (fuse) fn = &k_conv_tile_bf16<NC, KC, true, true, true, true>;
+      }
+    }
+  }
+  static bool attr_set[16] = {};  // per instantiation
+  const int which = (deep ? 8 : 0) + (fuse ? 4 : 0) + (small ? 2 : 0) + (exact ? 1 : 0);
   if (lds > 48 * 1024 && !attr_set[which]) {
     ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                kLdsBudget));
@@ -678,6 +752,8 @@ void me_debug_set_bf16_shape(int nc, int kc) {
   g_bf16_nc = nc;
   g_bf16_kc = kc;
 }
+
+void me_debug_set_bf16_deep(int deep) { g_bf16_deep = deep; }
 
 int32_t me_conv_pack_chunk_bf16(int32_t c_src, int32_t c_dst) {
   return (c_src > 0 && c_dst > 0) ? conv_variant_bf16(c_src, c_dst).kc : 0;

@@ -24,6 +24,8 @@ int me_debug_conv_timing_f32x3(uint64_t *out8, int32_t reset);
 /* bf16 tile kernel: columns per workgroup (32 / 64 / 128) and source-channel chunk (32 / 64 / 96 / 128 / 256) instead
  * of the policy of conv_variant_bf16 (0 = policy); plans and packed weights follow (set it before the first call). */
 void me_debug_set_bf16_shape(int nc, int kc);
+/* deep (two batches ahead) pipeline of the eight-wave bf16 tile kernels: -1 policy, 0 never, 1 wherever instantiated */
+void me_debug_set_bf16_deep(int deep);
 /* Weight-gradient kernels: depth 2 = k_wgrad_bf16 with two steps of rows in flight (round-3 experiment, bit-identical,
  * slower); depth 4 / 8 = prefetch ring depth of k_wgrad_f32 (steps of 4 pairs); depth -1 = bf16 rows
  * through the fp32-MFMA kernel instead of k_wgrad_bf16; -2 = fp32 rows through the LDS-staged kernel; -3 / -4 = fp32

@@ -254,6 +254,40 @@ def test_bf16_slab_width_does_not_change_a_bit(device, cin, cout, shapes):
         assert_bf16_close(res[shp][1].float().cpu().numpy(), want_gi, f"grad_in {shp}")
 
 
+@pytest.mark.parametrize("n,extent,cin,cout,ks,D", [(5000, 16, 256, 256, 3, 3), (300, 6, 256, 256, 3, 3), (4000, 40, 128, 128, 3, 3),
+                                                     (2500, 12, 256, 128, 3, 3), (1500, 8, 384, 256, 3, 3), (70, 3, 128, 256, 3, 3),
+                                                     (2000, 9, 256, 256, 2, 4), (900, 30, 512, 256, 3, 3),
+                                                     (6000, 40, 96, 96, 3, 3), (4000, 14, 64, 64, 3, 3), (3000, 10, 32, 64, 3, 4),
+                                                     (6000, 40, 128, 96, 3, 3), (5000, 30, 32, 32, 3, 3), (3000, 12, 192, 128, 3, 3)])
+def test_bf16_deep_pipeline_is_bit_identical(device, n, extent, cin, cout, ks, D):
+    """k_conv_tile_bf16<.., DEEP>: gathers and weights of the batch AFTER NEXT in flight (two register sets, loop
+    unrolled by two).  Same batches, same MFMAs in the same order: forward and input gradient must be bit-identical with
+    the pipeline forced on (1), off (0) and chosen by the policy (-1), on dense and sparse (batch-fused) maps, tiles of
+    one batch, an odd and an even number of batches, several source-channel chunks, every slab width."""
+    from minkowskiengine_amd import _lib, backend as MEB
+    lib = _lib.load()
+    coords = make_cloud(n, extent, D, seed=cin + cout + n, batch=2, negative=True)
+    mgr = MEB.CoordinateMapManagerGPU_c10()
+    key, _ = mgr.insert_and_map(coords.to(device), [1] * D, "")
+    km = mgr._kernel_map(key, key, [ks] * D, [1] * D, [1] * D, MEB.RegionType.HYPER_CUBE, None, False, False)
+    g = torch.Generator().manual_seed(11)
+    x = (torch.rand(coords.shape[0], cin, generator=g) - 0.5).to(device).bfloat16()
+    gy = (torch.rand(coords.shape[0], cout, generator=g) - 0.5).to(device).bfloat16()
+    w = (torch.rand(ks ** D, cin, cout, generator=g) - 0.5).to(device)
+    res = {}
+    try:
+        for deep in (1, 0, -1):
+            lib.me_debug_set_bf16_deep(deep)
+            y = MEB._conv_forward(x, w, km, "mfma")
+            gi = MEB._conv_target(gy, w, km, "in", km.n_in, name="d", transposed=True)
+            res[deep] = (y.clone(), gi.clone())
+    finally:
+        lib.me_debug_set_bf16_deep(-1)
+    for deep in (1, -1):
+        assert torch.equal(res[deep][0], res[0][0]) and torch.equal(res[deep][1], res[0][1]), deep
+    assert torch.isfinite(res[1][0].float()).all() and float(res[1][0].float().abs().max()) > 0
+
+
 @pytest.mark.parametrize("n,extent,cin,cout,ks,D", [(6000, 40, 96, 96, 3, 3), (4000, 14, 64, 128, 3, 3), (300, 6, 256, 256, 3, 3),
                                                      (3000, 9, 32, 64, 3, 4), (5000, 16, 128, 96, 2, 3), (70, 3, 64, 64, 3, 3)])
 def test_wgrad_bf16_two_steps_in_flight_is_bit_identical(device, n, extent, cin, cout, ks, D):
