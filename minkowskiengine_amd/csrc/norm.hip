@@ -200,14 +200,20 @@ __global__ __launch_bounds__(256) void k_bn_final(const float *__restrict__ part
 #pragma unroll
   for (int i = 0; i < L; ++i) {
     const int g = lane + i * 64;
-    pm[i] = g < chunks ? part_mean[(int64_t)g * c + ch] : 0.f;
-    pq[i] = g < chunks ? part_m2[(int64_t)g * c + ch] : 0.f;
+    const int64_t gc = min(g, chunks - 1);   // unconditional loads (a conditional one costs a branch and a full wait)
+    pm[i] = part_mean[gc * c + ch];
+    pq[i] = part_m2[gc * c + ch];
   }
+  // rows of chunk g = chunk_begin(g + 1) - chunk_begin(g) = q + ((g + 1) * rem) / G - (g * rem) / G with n = q * G + rem:
+  // one 64-bit division per thread instead of two per chunk (they were most of this kernel's instructions)
+  const int64_t cq_rows = n / chunks;
+  const uint32_t rem = (uint32_t)(n - cq_rows * chunks), G = (uint32_t)chunks;
 #pragma unroll
   for (int i = 0; i < L; ++i) {
     const int g = lane + i * 64;
     if (g < chunks) {
-      const float bn = (float)(chunk_begin(g + 1, n, chunks) - chunk_begin(g, n, chunks));
+      const uint32_t extra = ((uint32_t)(g + 1) * rem) / G - ((uint32_t)g * rem) / G;
+      const float bn = (float)(cq_rows + extra);
       chan_merge(cn, cm, cq, bn, pm[i], pq[i]);
     }
   }
@@ -392,8 +398,9 @@ __global__ __launch_bounds__(256) void k_bn_bwd_final(const float *__restrict__ 
 #pragma unroll
   for (int i = 0; i < L; ++i) {
     const int g = lane + i * 64;
-    pa[i] = g < chunks ? part_dy[(int64_t)g * c + ch] : 0.f;
-    pb[i] = g < chunks ? part_dyx[(int64_t)g * c + ch] : 0.f;
+    const int64_t gc = min(g, chunks - 1);
+    pa[i] = part_dy[gc * c + ch];
+    pb[i] = part_dyx[gc * c + ch];
   }
 #pragma unroll
   for (int i = 0; i < L; ++i) {
