@@ -663,7 +663,12 @@ static ConvVariantBf16 conv_variant_bf16(int c_src, int c_dst) {
   // workgroup per CU) — only where the launch is at most two slabs wide: with three (256 -> 384 input gradient, 21k
   // voxels) the single resident workgroup per CU runs two rounds, 246 us against 158
   if (v.nc == 128 && c_src % 256 == 0 && c_dst <= 256) v.kc = 256;
-  if (g_bf16_nc == 32 || g_bf16_nc == 64 || g_bf16_nc == 96 || g_bf16_nc == 128)
+#ifdef ME_DEBUG_VARIANTS
+  constexpr bool kHas96 = true;    // six-wave workgroups: measured, not used by the policy, instantiated for the tuning build only
+#else
+  constexpr bool kHas96 = false;
+#endif
+  if (g_bf16_nc == 32 || g_bf16_nc == 64 || (g_bf16_nc == 96 && kHas96) || g_bf16_nc == 128)
     v.nc = (g_bf16_nc == 32 && c_dst > 32) ? 64 : g_bf16_nc;
   if (v.nc > 64 && c_dst <= 64) v.nc = 64;
   if (v.nc != 128 && v.kc == 256) v.kc = 128;
@@ -695,7 +700,15 @@ static int launch_conv_tile_bf16(const __bf16 *src, int c_src, const bf16x8 *wp,
   // deep pipeline (see k_conv_tile_bf16): where one workgroup per CU is all a launch has — a 256-channel chunk (its
   // registers and LDS allow no second one), or at most ~1.25 workgroups per CU in the grid
   bool deep = false;
-  if constexpr (NC != 96) {
+  // (measured on four-wave workgroups too — profiles/r03_layers_minkunet34c_bf16_deep_all_widths.log: -5 % on the
+  // denser 96-channel layers, +10 % on the sparse ones, whose three workgroups per CU it reduces to two — and
+  // instantiated for them in the tuning build only)
+#ifdef ME_DEBUG_VARIANTS
+  constexpr bool kDeepNarrow = NC != 96;
+#else
+  constexpr bool kDeepNarrow = false;
+#endif
+  if constexpr (NC == 128 || kDeepNarrow) {
     deep = exact && small && (g_bf16_deep >= 0 ? g_bf16_deep != 0 : NC == 128);
     if (deep) {
       fn = &k_conv_tile_bf16<NC, KC, true, true, false, true>;
@@ -814,11 +827,13 @@ static int conv_target_bf16(const uint16_t *src_, int64_t n_src, int32_t c_src, 
     if (v.kc == 96) ME_CONV_CASE(32, 96);
     if (v.kc == 64) ME_CONV_CASE(32, 64);
     ME_CONV_CASE(32, 32);
+#ifdef ME_DEBUG_VARIANTS
   } else if (v.nc == 96) {
     if (v.kc == 128) ME_CONV_CASE(96, 128);
     if (v.kc == 96) ME_CONV_CASE(96, 96);
     if (v.kc == 64) ME_CONV_CASE(96, 64);
     ME_CONV_CASE(96, 32);
+#endif
   } else if (v.nc == 128) {
     if (v.kc == 256) ME_CONV_CASE(128, 256);
     if (v.kc == 128) ME_CONV_CASE(128, 128);
