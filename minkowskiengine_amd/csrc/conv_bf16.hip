@@ -19,6 +19,12 @@
 
 namespace me {
 
+// ME_BF16_TIMING (tagged tuning builds only: scripts/ablate_bf16_tile.sh): s_memtime cycles of wave 0 of every workgroup
+// per phase of k_conv_tile_bf16, summed over all launches since the last reset (me_debug_bf16_timing).  Slots 0-9: deep
+// pipeline, 10-19: plain loop — barrier A, stage write (with its wait for the gathers), barrier B, load issue, multiply,
+// weight refill + next descriptors, prologue, epilogue, batches, workgroups.
+__device__ unsigned long long d_bf16_timing[20];
+
 // stage row stride in elements: KC + 16 (32 bytes of padding: the 16 (row, piece) accesses of every lane group in
 // which the LDS serves a ds_read_b128 — {0-3,12-15,20-27}, ... — then fall on 16 distinct 16-byte bank slots; with 16
 // bytes of padding, the round-1 layout, they were 2-way conflicting)
@@ -26,6 +32,13 @@ __host__ __device__ constexpr int conv_bf16_lds_bytes(int nc, int kc, int tile_r
   return (tile_rows + 1) * (nc + kAccPad) * 4 + batch_groups * 16 * ((kc + 16) * 2 + 4);
 }
 
+// Timing ablations (round 3; INVALID results, never defined by the build scripts: scripts/ablate_bf16_tile.sh compiles
+// tagged libraries with them): ME_ABL_NO_AREAD (no LDS operand reads), ME_ABL_NO_ACC (accumulators written without the
+// read), ME_ABL_NO_MFMA, ME_ABL_NO_STAGE (no stage writes), ME_ABL_NO_GATHER (every gather hits 64 cached rows),
+// ME_ABL_NO_WLOAD (every batch loads offset 0's weights).  Result on MinkUNet34C's layers
+// (profiles/r03_ablation_bf16_tile_kernel.log): all LDS traffic together is 9 % of the forward + dgrad time, MFMAs +
+// LDS + stage writes + memory misses together 22 %; the rest is the per-batch skeleton (two barriers, descriptor /
+// index / address arithmetic of ~300 instructions per wave and batch, tile prologue and epilogue).
 // R groups of one offset: per 32-channel step one ds_read_b128 per group and one MFMA, issued
 // "transposed" (A = weights, B = gathered rows) so a lane ends with 4 consecutive output columns of one
 // target row; then all accumulator reads, then all writes (distinct rows within a batch).
@@ -42,15 +55,28 @@ __device__ __forceinline__ void mma_groups_bf16(const __bf16 *__restrict__ a0p, 
   for (int s = 0; s < KS; ++s) {
     bf16x8 a[R];
 #pragma unroll
+#ifdef ME_ABL_NO_AREAD   /* timing ablation (INVALID results): no LDS operand reads */
+    for (int r = 0; r < R; ++r) a[r] = wreg[(s + r) % KS];
+#else
     for (int r = 0; r < R; ++r) a[r] = *reinterpret_cast<const bf16x8 *>(a0p + r * 16 * A_LD + s * 32);
+#endif
 #pragma unroll
+#ifdef ME_ABL_NO_MFMA
+    for (int r = 0; r < R; ++r) acc[r][0] += (float)a[r][0] + (float)wreg[s][0];
+#else
     for (int r = 0; r < R; ++r) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[s], a[r], acc[r], 0, 0, 0);
+#endif
   }
+#ifdef ME_ABL_NO_ACC     /* timing ablation (INVALID results): accumulators written without the read */
+#pragma unroll
+  for (int r = 0; r < R; ++r) *reinterpret_cast<f32x4 *>(accp + d[r]) = acc[r];
+#else
   f32x4 old[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) old[r] = *reinterpret_cast<const f32x4 *>(accp + d[r]);
 #pragma unroll
   for (int r = 0; r < R; ++r) *reinterpret_cast<f32x4 *>(accp + d[r]) = old[r] + acc[r];
+#endif
 }
 
 // n single-group batches of DIFFERENT offsets staged together (batch fusion): group r multiplies with its own
@@ -177,6 +203,20 @@ __global__ __launch_bounds__(NC * 4, DEEP ? 2 : conv_bf16_waves_per_simd(NC, KC)
   const int ncb = (c_dst + 15) / 16;
   const int cb = min(col_base / 16 + wave, ncb - 1);
 
+#ifdef ME_BF16_TIMING
+  unsigned long long tm[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_prev = __builtin_amdgcn_s_memtime();
+#define ME_TICK(slot)                                                  \
+  do {                                                                 \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();      \
+    tm[slot] += now_ - t_prev;                                         \
+    t_prev = now_;                                                     \
+  } while (0)
+#define ME_COUNT(slot) (tm[slot] += 1)
+#else
+#define ME_TICK(slot) do {} while (0)
+#define ME_COUNT(slot) do {} while (0)
+#endif
   for (int x = tid; x < (tile_rows + 1) * ACC_LD / 4; x += NT)
     reinterpret_cast<f32x4 *>(s_acc)[x] = f32x4{0.f, 0.f, 0.f, 0.f};
   // the rows this tile's positions stand for (tiles of a position-space map): requested now, parked in the free
@@ -270,7 +310,11 @@ __global__ __launch_bounds__(NC * 4, DEEP ? 2 : conv_bf16_waves_per_simd(NC, KC)
 #pragma unroll
     for (int j = 0; j < ITER; ++j) {
       const int ch = c0 + ((j * NT + tid) % F8) * 8;
+#ifdef ME_ABL_NO_GATHER
+      const int sr = max(sidx[j], 0) & 63;
+#else
       const int sr = max(sidx[j], 0);
+#endif
       if (SMALL && (EXACT || vec_ok)) {
         const unsigned off = __umul24((unsigned)sr, row_bytes) + (unsigned)(EXACT ? ch : min(ch, c_src - 8)) * 2u;
         stage[j] = *reinterpret_cast<const bf16x8 *>(srcb + off);
@@ -303,7 +347,11 @@ __global__ __launch_bounds__(NC * 4, DEEP ? 2 : conv_bf16_waves_per_simd(NC, KC)
         for (int e = 0; e < 8; ++e)
           if (ch + e >= c_src) t[e] = (__bf16)0.f;
       }
+#ifdef ME_ABL_NO_STAGE
+      if (r < cap_rows && t[0] == (__bf16)1234.5f) *reinterpret_cast<bf16x8 *>(&s_a[r * A_LD + (idx % F8) * 8]) = t;
+#else
       if (r < cap_rows) *reinterpret_cast<bf16x8 *>(&s_a[r * A_LD + (idx % F8) * 8]) = t;
+#endif
     }
     if (tid < cap_rows) s_dst[tid] = dstv;
   };
@@ -312,7 +360,11 @@ __global__ __launch_bounds__(NC * 4, DEEP ? 2 : conv_bf16_waves_per_simd(NC, KC)
 #pragma unroll
     for (int j = 0; j < MAXSUB; ++j) {
       if (j == 0 || j < sb.nsub) {
+#ifdef ME_ABL_NO_WLOAD
+        const bf16x8 *p = wp + ((((int64_t)0 * nchunks + 0) * ncb + cb) * KS) * 64 + lane;
+#else
         const bf16x8 *p = wp + ((((int64_t)sb.k[j] * nchunks + sb.chunk) * ncb + cb) * KS) * 64 + lane;
+#endif
 #pragma unroll
         for (int v = 0; v < KS; ++v) wnxt[j][v] = p[v * 64];
       }
@@ -359,10 +411,14 @@ __global__ __launch_bounds__(NC * 4, DEEP ? 2 : conv_bf16_waves_per_simd(NC, KC)
       // one step: stage and multiply batch A from register set (st, dv, wn); refill the set with batch C.  The
       // index window of batch D is requested BEFORE the refill: the gather of the next step then waits for loads
       // older than this refill (vmcnt counts in order), not for the refill itself
+      ME_TICK(6);
       auto step = [&](bf16x8 (&st)[ITER], int32_t &dv, bf16x8 (&wn)[MAXSUB][KS]) {
         __syncthreads();
+        ME_TICK(0);
         write_stage(sA.chunk, st, dv);
+        ME_TICK(1);
         __syncthreads();
+        ME_TICK(2);
         int32_t sidx_c[ITER];
 #pragma unroll
         for (int j = 0; j < ITER; ++j) sidx_c[j] = sidx[j];
@@ -374,18 +430,26 @@ __global__ __launch_bounds__(NC * 4, DEEP ? 2 : conv_bf16_waves_per_simd(NC, KC)
 #pragma unroll
           for (int j = 0; j < ITER; ++j) {
             const int ch = c0 + ((j * NT + tid) % F8) * 8;
+#ifdef ME_ABL_NO_GATHER
+            const unsigned off = __umul24((unsigned)(max(sidx_c[j], 0) & 63), row_bytes) + (unsigned)ch * 2u;
+#else
             const unsigned off = __umul24((unsigned)max(sidx_c[j], 0), row_bytes) + (unsigned)ch * 2u;
+#endif
             st[j] = *reinterpret_cast<const bf16x8 *>(srcb + off);
           }
         }
         // the set's weights are multiplied in place and replaced behind the MFMAs (a copy to a third set would
         // make the refill wait at the loop's back edge)
+        ME_TICK(3);
         multiply(sA, wn);
+        ME_TICK(4);
         load_w(sC, wn);
         sA = sB;
         sB = sC;
         sC = sD;
         sD = next_super();
+        ME_TICK(5);
+        ME_COUNT(8);
       };
       while (true) {
         step(stage, dstv, wnxt);
@@ -402,22 +466,30 @@ __global__ __launch_bounds__(NC * 4, DEEP ? 2 : conv_bf16_waves_per_simd(NC, KC)
     gather(sA.chunk, sA.g0, stage, dstv);
     load_sidx(sB.g0);
 
+    ME_TICK(6);
     while (sA.nsub > 0) {
       __syncthreads();
+      ME_TICK(0);
       write_stage(sA.chunk, stage, dstv);
 #pragma unroll
       for (int j = 0; j < MAXSUB; ++j) {
 #pragma unroll
         for (int sx = 0; sx < KS; ++sx) wreg[j][sx] = wnxt[j][sx];
       }
+      ME_TICK(1);
       __syncthreads();
+      ME_TICK(2);
       load_w(sB, wnxt);
       gather(sB.chunk, sB.g0, stage, dstv);
       load_sidx(sC.g0);
+      ME_TICK(3);
       multiply(sA, wreg);
+      ME_TICK(4);
       sA = sB;
       sB = sC;
       sC = next_super();
+      ME_TICK(5);
+      ME_COUNT(8);
     }
   }
   __syncthreads();
@@ -451,6 +523,17 @@ __global__ __launch_bounds__(NC * 4, DEEP ? 2 : conv_bf16_waves_per_simd(NC, KC)
       }
     }
   }
+#ifdef ME_BF16_TIMING
+  __builtin_amdgcn_s_waitcnt(0);
+  ME_TICK(7);
+  ME_COUNT(9);
+  if (tid == 0) {
+#pragma unroll
+    for (int sl = 0; sl < 10; ++sl) atomicAdd(&d_bf16_timing[(DEEP ? 0 : 10) + sl], tm[sl]);
+  }
+#endif
+#undef ME_TICK
+#undef ME_COUNT
 }
 
 // =================================================================================================
@@ -767,6 +850,19 @@ void me_debug_set_bf16_shape(int nc, int kc) {
 }
 
 void me_debug_set_bf16_deep(int deep) { g_bf16_deep = deep; }
+
+int me_debug_bf16_timing(uint64_t *out20, int32_t reset) {
+  if (out20 != nullptr) {
+    unsigned long long h[20];
+    ME_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(d_bf16_timing), sizeof(h)));
+    for (int i = 0; i < 20; ++i) out20[i] = h[i];
+  }
+  if (reset) {
+    unsigned long long z[20] = {};
+    ME_HIP(hipMemcpyToSymbol(HIP_SYMBOL(d_bf16_timing), z, sizeof(z)));
+  }
+  return 0;
+}
 
 int32_t me_conv_pack_chunk_bf16(int32_t c_src, int32_t c_dst) {
   return (c_src > 0 && c_dst > 0) ? conv_variant_bf16(c_src, c_dst).kc : 0;

@@ -26,6 +26,10 @@ int me_debug_conv_timing_f32x3(uint64_t *out8, int32_t reset);
 void me_debug_set_bf16_shape(int nc, int kc);
 /* deep (two batches ahead) pipeline of the eight-wave bf16 tile kernels: -1 policy, 0 never, 1 wherever instantiated */
 void me_debug_set_bf16_deep(int deep);
+/* phase counters of k_conv_tile_bf16 (all zero unless the library was compiled with -DME_BF16_TIMING): 20 uint64,
+ * slots 0-9 deep pipeline / 10-19 plain loop: barrier A, stage write + wait, barrier B, load issue, multiply, refill +
+ * descriptors, prologue, epilogue (s_memtime cycles of wave 0 of every workgroup), batches, workgroups */
+int me_debug_bf16_timing(uint64_t *out20, int32_t reset);
 /* Weight-gradient kernels: depth 2 = k_wgrad_bf16 with two steps of rows in flight (round-3 experiment, bit-identical,
  * slower); depth 4 / 8 = prefetch ring depth of k_wgrad_f32 (steps of 4 pairs); depth -1 = bf16 rows
  * through the fp32-MFMA kernel instead of k_wgrad_bf16; -2 = fp32 rows through the LDS-staged kernel; -3 / -4 = fp32
