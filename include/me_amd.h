@@ -47,7 +47,9 @@ typedef struct me_region {
  *   1.1        round 2: tile_bptr_dev grew to 2 * num_tiles + 1 int32 (dispatch order behind the batch ranges) — an
  *              ABI change without a size argument; LDS-bucketed kernel-map build; split fp32 kernels
  *   1.2 (120)  round 3: me_plan_tile_bptr_elems sizes that buffer; me_debug_* hooks left this header
- *              (csrc/me_amd_debug.h: tests / tuning only) */
+ *              (csrc/me_amd_debug.h: tests / tuning only)
+ *   1.3 (130)  round 3: batch-norm statistics in the convolution's epilogue (me_conv_target_bf16_stats,
+ *              me_conv_stats_supported_bf16, me_bn_stats_from_tiles) */
 int me_version(void);
 const char *me_last_error(void);
 /* kernel volume of a region: src/kernel_region.hpp:250-270 (set_volume) */
@@ -331,6 +333,20 @@ int me_conv_target_bf16_fused(const uint16_t *src_feat_dev, int64_t n_src, int32
                               const int32_t *batch_desc_dev, const int32_t *tile_bptr_dev,
                               const int32_t *order_dev, uint16_t *dst_feat_dev,
                               int64_t n_tgt, int32_t tile_rows, int32_t batch_groups, void *stream);
+/* The same launch (fused != 0: the batch-fusion instantiation) that ALSO leaves the batch-norm statistics of its output
+ * behind: per tile and output channel the mean and M2 = sum (y - mean)^2 of the rounded values it stores, in
+ * part_mean_dev / part_m2_dev [ceil(n_tgt / tile_rows)][c_dst] floats (slot = tile index, every slot written).  In the
+ * reference batch norm is a separate torch operator on the feature matrix (MinkowskiEngine/MinkowskiNormalization.py:
+ * 51-98); me_bn_stats_from_tiles turns these partials into its mean / rstd without reading the matrix again.
+ * me_conv_stats_supported_bf16: 1 when the tile shape chosen for (c_src, c_dst) has the epilogue. */
+int32_t me_conv_stats_supported_bf16(int32_t c_src, int32_t c_dst);
+int me_conv_target_bf16_stats(const uint16_t *src_feat_dev, int64_t n_src, int32_t c_src,
+                              const uint16_t *packed_w_dev, int64_t volume, int32_t c_dst,
+                              const int32_t *plan_src_dev, const int32_t *plan_dst_dev,
+                              const int32_t *batch_desc_dev, const int32_t *tile_bptr_dev,
+                              const int32_t *order_dev, uint16_t *dst_feat_dev,
+                              int64_t n_tgt, int32_t tile_rows, int32_t batch_groups, int32_t fused,
+                              float *part_mean_dev, float *part_m2_dev, void *stream);
 int64_t me_conv_wgrad_workspace_bytes_bf16(const int64_t *k_offsets, int64_t volume, int32_t c_in, int32_t c_out);
 int me_conv_wgrad_bf16(const uint16_t *x_dev, int64_t n_in, int32_t c_in, const uint16_t *dy_dev, int64_t n_out,
                        int32_t c_out,
@@ -509,6 +525,13 @@ int me_bn_backward(const void *x_dev, const void *dy_dev, int32_t is_bf16, int64
                    const float *mean_dev, const float *rstd_dev, const float *gamma_dev, const float *beta_dev,
                    int32_t relu, void *dx_dev, float *grad_gamma_dev, float *grad_beta_dev, void *workspace_dev,
                    int64_t workspace_bytes, void *stream);
+/* Statistics of a matrix whose per-tile (mean, M2) partials a convolution already wrote (me_conv_target_bf16_stats):
+ * tile g = rows [g * tile_rows, min((g + 1) * tile_rows, n)), partials [ceil(n / tile_rows)][c] floats each.  Same
+ * outputs and running-statistics update as me_bn_stats, without reading the matrix (one small launch). */
+int me_bn_stats_from_tiles(const float *part_mean_dev, const float *part_m2_dev, int64_t n, int32_t c,
+                           int32_t tile_rows, float eps, float momentum, float *mean_dev, float *rstd_dev,
+                           float *running_mean_dev, float *running_var_dev, int64_t *num_batches_tracked_dev,
+                           void *stream);
 /* Residual form (a ResNet block's `relu(bn(conv(x)) + skip)`): y = [relu] (T(x * a + b) + skip) in one pass, bit-identical
  * to me_bn_apply followed by an addition and a ReLU; the backward pass masks dy where the stored output `yout` is not
  * positive (relu != 0), writes the masked gradient to dskip (the residual branch's gradient; may be NULL) and dx. */

@@ -107,6 +107,8 @@ SIGNATURES = {
     "me_bn_workspace_bytes": (c_i64, [c_i64, c_i32]),
     "me_bn_stats": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i32, ctypes.c_float, ctypes.c_float, c_vp, c_vp, c_vp, c_vp,
                                    c_vp, c_vp, c_i64, c_vp]),
+    "me_bn_stats_from_tiles": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_i32, ctypes.c_float, ctypes.c_float, c_vp, c_vp,
+                                              c_vp, c_vp, c_vp, c_vp]),
     "me_bn_apply": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "me_bn_backward": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp,
                                       c_vp, c_i64, c_vp]),
@@ -133,6 +135,9 @@ SIGNATURES = {
                                            c_vp, c_i64, c_i32, c_i32, c_vp]),
     "me_conv_target_bf16_fused": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp,
                                            c_vp, c_i64, c_i32, c_i32, c_vp]),
+    "me_conv_stats_supported_bf16": (c_i32, [c_i32, c_i32]),
+    "me_conv_target_bf16_stats": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                           c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "me_conv_gather_supported_bf16": (c_i32, [c_i32, c_i32]),
     "me_conv_gather_weight_elems_bf16": (c_i64, [c_i64, c_i32, c_i32]),
     "me_conv_gather_pack_weights_bf16": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),

@@ -17,6 +17,7 @@ implementation here: CPU tensors are rejected (the reference's CPU path is the t
 import ctypes
 import enum
 import os
+import weakref
 import random
 import string
 
@@ -1366,6 +1367,18 @@ def _conv_target(src_feat, kernel, km, target, n_tgt, name="conv_target", transp
                 _lib.check(lib.me_conv_pack_weights_bf16(kernel.data_ptr(), 1 if kernel.dtype == torch.float32 else 0,
                                                          volume, c_src, c_dst, 1 if transposed else 0,
                                                          packed.data_ptr(), stream))
+            if (_CONV_BN_STATS and _BN_STATS_HINT[0] and name == "conv_forward" and n_tgt > 0
+                    and lib.me_conv_stats_supported_bf16(c_src, c_dst)):
+                # batch-norm statistics in the epilogue: the tiles' (mean, M2) partials ride along with the output
+                # (bn_stats picks them up when this very tensor is normalised next: _BN_PARTIALS)
+                n_tiles = -(-n_tgt // tile_rows)
+                part = torch.empty(2, n_tiles, c_dst, dtype=torch.float32, device=dev)
+                _timed(name, dev, lambda: _lib.check(lib.me_conv_target_bf16_stats(
+                    src_feat.data_ptr(), src_feat.shape[0], c_src, packed.data_ptr(), km.volume, c_dst, p_src, p_dst,
+                    p_desc, p_bptr, p_order, out.data_ptr(), n_tgt, tile_rows, batch_groups, 1 if fuse else 0,
+                    part[0].data_ptr(), part[1].data_ptr(), stream)), flops=flops)
+                _bn_partials_put(out, part, tile_rows)
+                return out
             fn = lib.me_conv_target_bf16_fused if fuse else lib.me_conv_target_bf16
             _timed(name, dev, lambda: _lib.check(fn(
                 src_feat.data_ptr(), src_feat.shape[0], c_src, packed.data_ptr(), km.volume, c_dst, p_src, p_dst,
@@ -1814,6 +1827,38 @@ def _bn_check(x):
     _check(x.shape[0] > 0, "batch norm needs at least one row")
 
 
+# Statistics a convolution left behind for the batch norm that follows it (me_conv_target_bf16_stats): keyed by the
+# output's storage address, valid for THAT tensor object at THAT version only (weak reference + version counter: a
+# recycled address, a view, an in-place update or a channel slice simply misses and bn_stats reads the matrix).  One
+# entry per live convolution output; consumed (popped) by the first bn_stats on it.
+_CONV_BN_STATS = os.environ.get("ME_AMD_CONV_BN_STATS", "1") != "0"
+_BN_PARTIALS = {}
+_BN_STATS_HINT = [False]     # set by the convolution module around its forward call: True in training mode
+
+
+def conv_bn_stats_hint(flag):
+    """MinkowskiConvolution tells the operator whether a training-mode batch norm may follow (module.training): the
+    operator interface of the reference has no argument for it."""
+    _BN_STATS_HINT[0] = bool(flag)
+
+
+def _bn_partials_put(out, part, tile_rows):
+    if len(_BN_PARTIALS) > 256:      # outputs that were never normalised (their tensors are long gone)
+        for k in [k for k, v in _BN_PARTIALS.items() if v[0]() is None]:
+            del _BN_PARTIALS[k]
+    _BN_PARTIALS[out.data_ptr()] = (weakref.ref(out), out._version, part, int(tile_rows), tuple(out.shape))
+
+
+def _bn_partials_take(x):
+    ent = _BN_PARTIALS.pop(x.data_ptr(), None) if _BN_PARTIALS else None
+    if ent is None:
+        return None
+    ref, version, part, tile_rows, shape = ent
+    if ref() is not x or x._version != version or tuple(x.shape) != shape:
+        return None
+    return part, tile_rows
+
+
 def bn_stats(x, eps, momentum, running_mean=None, running_var=None, num_batches_tracked=None):
     """-> (mean, rstd) float32 [c] of the batch; running statistics updated in place when given (and the int64
     num_batches_tracked buffer incremented by the same kernel)."""
@@ -1823,6 +1868,14 @@ def bn_stats(x, eps, momentum, running_mean=None, running_var=None, num_batches_
     n, c = int(x.shape[0]), int(x.shape[1])
     mean = torch.empty(c, dtype=torch.float32, device=dev)
     rstd = torch.empty(c, dtype=torch.float32, device=dev)
+    got = _bn_partials_take(x)
+    if got is not None:
+        part, tile_rows = got
+        with _on(dev):
+            _lib.check(lib.me_bn_stats_from_tiles(part[0].data_ptr(), part[1].data_ptr(), n, c, tile_rows, float(eps),
+                                                  float(momentum), _ptr(mean), _ptr(rstd), _ptr(running_mean),
+                                                  _ptr(running_var), _ptr(num_batches_tracked), _stream(dev)))
+        return mean, rstd
     ws = _workspace(int(lib.me_bn_workspace_bytes(n, c)), dev)
     with _on(dev):
         _lib.check(lib.me_bn_stats(_ptr(x), 1 if x.dtype == torch.bfloat16 else 0, n, c, float(eps),

@@ -35,15 +35,21 @@ def _pad_channels(feats, kernel, cin, cout):
     return feats, kernel, (cout + po if po else None)
 
 
-def _conv_apply(conv_fn, is_transpose, feats, kernel, kernel_generator, convolution_mode, in_key, out_key, manager):
+def _conv_apply(conv_fn, is_transpose, feats, kernel, kernel_generator, convolution_mode, in_key, out_key, manager,
+                training=False):
     """One convolution with autograd: the native host layer's C++ autograd function when `manager` lives there (the
     backward pass then never enters Python), else the reference-style Python Function."""
+    # (a training-mode batch norm may follow: bf16 forward launches then leave their tiles' statistics behind)
+    want_stats = bool(training) and feats.dtype == torch.bfloat16
     if getattr(manager, "_native", False):
         from . import host as _host
+        _host.native_module().conv_bn_stats_hint(want_stats)
         return _host.native_module().conv_autograd(
             feats, kernel, kernel_generator.kernel_size, kernel_generator.kernel_stride, kernel_generator.kernel_dilation,
             int(kernel_generator.region_type), bool(kernel_generator.expand_coordinates), in_key, out_key,
             manager._manager, bool(is_transpose))
+    from . import backend as _backend
+    _backend.conv_bn_stats_hint(want_stats)
     return conv_fn.apply(feats, kernel, kernel_generator, convolution_mode, in_key, out_key, manager)
 
 
@@ -152,7 +158,7 @@ class MinkowskiConvolutionBase(MinkowskiModuleBase):
                 feats, kernel, cpad = _pad_channels(input.F, self.kernel.unsqueeze(0), self.in_channels,
                                                     self.out_channels)
                 outfeat = _conv_apply(self.conv, False, feats, kernel, self.kernel_generator, self.convolution_mode,
-                                      input.coordinate_map_key, out_coordinate_map_key, input._manager)
+                                      input.coordinate_map_key, out_coordinate_map_key, input._manager, self.training)
                 if cpad is not None:
                     outfeat = outfeat[:, :self.out_channels].contiguous()
             else:
@@ -167,7 +173,7 @@ class MinkowskiConvolutionBase(MinkowskiModuleBase):
             feats, kernel, cpad = _pad_channels(input.F, self.kernel, self.in_channels, self.out_channels)
             outfeat = _conv_apply(self.conv, self.is_transpose, feats, kernel, self.kernel_generator,
                                   self.convolution_mode, input.coordinate_map_key, out_coordinate_map_key,
-                                  input._manager)
+                                  input._manager, self.training)
             if cpad is not None:
                 outfeat = outfeat[:, :self.out_channels].contiguous()
         if self.bias is not None:

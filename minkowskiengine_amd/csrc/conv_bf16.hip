@@ -171,7 +171,7 @@ __global__ __launch_bounds__(NC * 4, DEEP ? 2 : conv_bf16_waves_per_simd(NC, KC)
     const int32_t *__restrict__ plan_src, const int32_t *__restrict__ plan_dst,
     const int32_t *__restrict__ batch_desc, const int32_t *__restrict__ tile_bptr,
     const int32_t *__restrict__ order, __bf16 *__restrict__ dst, int64_t n_tgt, int tile_rows, int batch_groups,
-    int fuse) {
+    int fuse, float *__restrict__ stat_mean, float *__restrict__ stat_m2) {
   typedef int i32x2 __attribute__((ext_vector_type(2)));
   constexpr int WAVES = NC / 16;
   constexpr int NT = WAVES * 64;
@@ -505,21 +505,83 @@ __global__ __launch_bounds__(NC * 4, DEEP ? 2 : conv_bf16_waves_per_simd(NC, KC)
       if (j * NT + tid < tile_rows) s_ord[j * NT + tid] = my_ord[j];
     __syncthreads();
   }
+  // Batch-norm statistics of the tile (round 3): when the host passes stat_mean / stat_m2, the
+  // store loop also accumulates, per output column, the sum and the sum of squares of the ROUNDED values it stores
+  // (shifted by the tile's first row, as k_bn_partial shifts by its chunk's first row), and the tile's (mean, M2) go
+  // to slot `tile` of the partials: the batch norm that follows merges the tiles (k_bn_final_tiles) instead of
+  // reading the matrix again.  Fixed order (thread's rows ascending, xor-shuffle tree, waves ascending): reproducible.
+  constexpr int G4 = NC / 4;                       // threads per tile row = four-column groups
+  constexpr bool kStats = NC == 32 || NC == 64 || NC == 128;   // (G4 a power of two: the shuffle tree)
+  const bool do_stats = kStats && stat_mean != nullptr;        // uniform
+  float st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+  if (do_stats) {
+    const f32x4 v0 = *reinterpret_cast<const f32x4 *>(&s_acc[(tid % G4) * 4]);   // row 0 of the tile
+#pragma unroll
+    for (int t = 0; t < 4; ++t) sh[t] = (float)(__bf16)v0[t];
+  }
   for (int x = tid; x < tile_rows * NC / 4; x += NT) {
     const int row = x / (NC / 4);
     const int c4 = x % (NC / 4);
     const int cc = col_base + c4 * 4;
-    if (row < rows_here && cc < c_dst) {
+    if (row < rows_here && (cc < c_dst || do_stats)) {
       const f32x4 v = *reinterpret_cast<const f32x4 *>(&s_acc[row * ACC_LD + c4 * 4]);
-      const int64_t grow = order ? (int64_t)s_ord[row] : row0 + row;
-      __bf16 *o = dst + grow * c_dst + cc;
-      if (vec_out) {
-        *reinterpret_cast<bf16x4 *>(o) = bf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
-      } else {
-        o[0] = (__bf16)v.x;
-        if (cc + 1 < c_dst) o[1] = (__bf16)v.y;
-        if (cc + 2 < c_dst) o[2] = (__bf16)v.z;
-        if (cc + 3 < c_dst) o[3] = (__bf16)v.w;
+      const bf16x4 vb = bf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+      if (do_stats) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float d = (float)vb[t] - sh[t];
+          st1[t] += d;
+          st2[t] = fmaf(d, d, st2[t]);
+        }
+      }
+      if (cc < c_dst) {
+        const int64_t grow = order ? (int64_t)s_ord[row] : row0 + row;
+        __bf16 *o = dst + grow * c_dst + cc;
+        if (vec_out) {
+          *reinterpret_cast<bf16x4 *>(o) = vb;
+        } else {
+          o[0] = vb[0];
+          if (cc + 1 < c_dst) o[1] = vb[1];
+          if (cc + 2 < c_dst) o[2] = vb[2];
+          if (cc + 3 < c_dst) o[3] = vb[3];
+        }
+      }
+    }
+  }
+  if constexpr (kStats) {
+    if (do_stats) {
+      // lanes l, l + G4, l + 2 G4, ... of a wave hold the same four columns
+#pragma unroll
+      for (int off = G4; off < 64; off <<= 1) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          st1[t] += __shfl_xor(st1[t], off, 64);
+          st2[t] += __shfl_xor(st2[t], off, 64);
+        }
+      }
+      __syncthreads();                              // every wave is done with the accumulator tile
+      float *s_st = s_acc + ACC_LD;                 // [WAVES][G4][8] behind row 0 (NC * NC / 8 floats <= 16 rows)
+      if (lane < G4) {
+        float *w = s_st + (wave * G4 + lane) * 8;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          w[t] = st1[t];
+          w[4 + t] = st2[t];
+        }
+      }
+      __syncthreads();
+      if (tid < NC && col_base + tid < c_dst) {
+        const int c4 = tid >> 2, t = tid & 3;
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+          a += s_st[(w * G4 + c4) * 8 + t];
+          b += s_st[(w * G4 + c4) * 8 + 4 + t];
+        }
+        const float shift = (float)(__bf16)s_acc[tid];
+        const float cnt = (float)rows_here, m = a / cnt;
+        stat_mean[(int64_t)tile * c_dst + col_base + tid] = shift + m;
+        stat_m2[(int64_t)tile * c_dst + col_base + tid] = fmaxf(b - a * m, 0.f);
       }
     }
   }
@@ -765,12 +827,13 @@ template <int NC, int KC>
 static int launch_conv_tile_bf16(const __bf16 *src, int c_src, const bf16x8 *wp, int c_dst, int slabs,
                                  const int32_t *plan_src, const int32_t *plan_dst, const int32_t *batch_desc,
                                  const int32_t *tile_bptr, const int32_t *order, __bf16 *dst, int64_t n_tgt,
-                                 int tile_rows, int batch_groups, hipStream_t stream, bool small, bool fuse = false) {
+                                 int tile_rows, int batch_groups, hipStream_t stream, bool small, bool fuse = false,
+                                 float *stat_mean = nullptr, float *stat_m2 = nullptr) {
   const int lds = conv_bf16_lds_bytes(NC, KC, tile_rows, batch_groups);
   ME_CHECK(lds <= kLdsBudget, "tile_rows / batch_groups too large for the LDS of one workgroup");
   const bool exact = (c_src % KC) == 0;
   typedef void (*kernel_t)(const __bf16 *, int, const bf16x8 *, int, const int32_t *, const int32_t *, const int32_t *,
-                           const int32_t *, const int32_t *, __bf16 *, int64_t, int, int, int);
+                           const int32_t *, const int32_t *, __bf16 *, int64_t, int, int, int, float *, float *);
   kernel_t fn = small ? (exact ? &k_conv_tile_bf16<NC, KC, true, true> : &k_conv_tile_bf16<NC, KC, false, true>)
                       : (exact ? &k_conv_tile_bf16<NC, KC, true, false> : &k_conv_tile_bf16<NC, KC, false, false>);
   if constexpr (NC <= 96 && KC <= 128) {   // batch fusion: four- and six-wave workgroups (sparse maps of narrow layers)
@@ -809,7 +872,7 @@ static int launch_conv_tile_bf16(const __bf16 *src, int c_src, const bf16x8 *wp,
   }
   const dim3 grid((unsigned)ceil_div(n_tgt, tile_rows), (unsigned)slabs);
   hipLaunchKernelGGL(fn, grid, dim3(NC * 4), (size_t)lds, stream, src, c_src, wp, c_dst, plan_src, plan_dst, batch_desc,
-                     tile_bptr, order, dst, n_tgt, tile_rows, batch_groups, g_conv_variant == 7 ? 0 : 1);
+                     tile_bptr, order, dst, n_tgt, tile_rows, batch_groups, g_conv_variant == 7 ? 0 : 1, stat_mean, stat_m2);
   ME_LAUNCH_CHECK();
   return 0;
 }
@@ -900,9 +963,11 @@ int me_conv_pack_weights_bf16(const void *w, int32_t w_is_f32, int64_t volume, i
 static int conv_target_bf16(const uint16_t *src_, int64_t n_src, int32_t c_src, const uint16_t *wp_, int64_t volume,
                             int32_t c_dst, const int32_t *plan_src, const int32_t *plan_dst,
                             const int32_t *batch_desc, const int32_t *tile_bptr, const int32_t *order, uint16_t *dst_,
-                            int64_t n_tgt, int32_t tile_rows, int32_t batch_groups, void *stream_, bool fuse) {
+                            int64_t n_tgt, int32_t tile_rows, int32_t batch_groups, void *stream_, bool fuse,
+                            float *stat_mean = nullptr, float *stat_m2 = nullptr) {
   hipStream_t stream = (hipStream_t)stream_;
   (void)volume;
+  ME_CHECK((stat_mean == nullptr) == (stat_m2 == nullptr), "both statistics buffers or none");
   // 32-bit byte offsets with a 24-bit row multiply need a source matrix below 4 GiB
   const bool small = n_src > 0 && n_src < (1ll << 24) && n_src * c_src * 2 < (1ll << 32) && g_conv_variant != 6;
   ME_CHECK(c_src > 0 && c_dst > 0, "channel counts must be positive");
@@ -917,7 +982,8 @@ static int conv_target_bf16(const uint16_t *src_, int64_t n_src, int32_t c_src, 
   const ConvVariantBf16 v = conv_variant_bf16(c_src, c_dst);
 #define ME_CONV_CASE(NCV, KCV)                                                                                   \
   return launch_conv_tile_bf16<NCV, KCV>(src, c_src, wp, c_dst, v.slabs, plan_src, plan_dst, batch_desc, tile_bptr, \
-                                         order, dst, n_tgt, tile_rows, batch_groups, stream, small, fuse)
+                                         order, dst, n_tgt, tile_rows, batch_groups, stream, small, fuse, stat_mean,   \
+                                         stat_m2)
   if (v.nc == 32) {
     if (v.kc == 128) ME_CONV_CASE(32, 128);
     if (v.kc == 96) ME_CONV_CASE(32, 96);
@@ -959,6 +1025,23 @@ int me_conv_target_bf16_fused(const uint16_t *src, int64_t n_src, int32_t c_src,
                               int64_t n_tgt, int32_t tile_rows, int32_t batch_groups, void *stream) {
   return conv_target_bf16(src, n_src, c_src, wp, volume, c_dst, plan_src, plan_dst, batch_desc, tile_bptr, order, dst,
                           n_tgt, tile_rows, batch_groups, stream, true);
+}
+
+int32_t me_conv_stats_supported_bf16(int32_t c_src, int32_t c_dst) {
+  if (c_src <= 0 || c_dst <= 0) return 0;
+  const int nc = conv_variant_bf16(c_src, c_dst).nc;
+  return (nc == 32 || nc == 64 || nc == 128) ? 1 : 0;
+}
+
+int me_conv_target_bf16_stats(const uint16_t *src, int64_t n_src, int32_t c_src, const uint16_t *wp, int64_t volume,
+                              int32_t c_dst, const int32_t *plan_src, const int32_t *plan_dst,
+                              const int32_t *batch_desc, const int32_t *tile_bptr, const int32_t *order, uint16_t *dst,
+                              int64_t n_tgt, int32_t tile_rows, int32_t batch_groups, int32_t fused, float *part_mean,
+                              float *part_m2, void *stream) {
+  ME_CHECK(part_mean != nullptr && part_m2 != nullptr, "the statistics buffers must be given");
+  ME_CHECK(me_conv_stats_supported_bf16(c_src, c_dst), "no statistics epilogue for this tile shape");
+  return conv_target_bf16(src, n_src, c_src, wp, volume, c_dst, plan_src, plan_dst, batch_desc, tile_bptr, order, dst,
+                          n_tgt, tile_rows, batch_groups, stream, fused != 0, part_mean, part_m2);
 }
 
 }  // extern "C"

@@ -179,12 +179,14 @@ __device__ __forceinline__ void chan_merge(float &cn, float &cm, float &cq, floa
   }
 }
 
+// tile_rows > 0: the partials are those of a convolution's tiles (k_conv_tile_bf16's statistics epilogue: tile g
+// holds rows [g * tile_rows, min((g + 1) * tile_rows, n)), any number of tiles); 0: k_bn_partial's equal chunks.
 __global__ __launch_bounds__(256) void k_bn_final(const float *__restrict__ part_mean,
                                                  const float *__restrict__ part_m2, int64_t n, int c, int chunks,
                                                  float eps, float momentum, float *__restrict__ mean_out,
                                                  float *__restrict__ rstd_out, float *__restrict__ running_mean,
                                                  float *__restrict__ running_var,
-                                                 int64_t *__restrict__ num_batches_tracked) {
+                                                 int64_t *__restrict__ num_batches_tracked, int tile_rows) {
   const int lane = threadIdx.x & 63;
   const int ch = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (num_batches_tracked != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
@@ -195,26 +197,33 @@ __global__ __launch_bounds__(256) void k_bn_final(const float *__restrict__ part
     rv_old = running_var[ch];
   }
   float cn = 0.f, cm = 0.f, cq = 0.f;
-  constexpr int L = kBnMaxChunks / 64;   // chunks per lane: all partials requested before the (dependent) merges
-  float pm[L], pq[L];
-#pragma unroll
-  for (int i = 0; i < L; ++i) {
-    const int g = lane + i * 64;
-    const int64_t gc = min(g, chunks - 1);   // unconditional loads (a conditional one costs a branch and a full wait)
-    pm[i] = part_mean[gc * c + ch];
-    pq[i] = part_m2[gc * c + ch];
-  }
+  constexpr int L = kBnMaxChunks / 64;   // chunks per lane and pass: all partials requested before the (dependent) merges
   // rows of chunk g = chunk_begin(g + 1) - chunk_begin(g) = q + ((g + 1) * rem) / G - (g * rem) / G with n = q * G + rem:
   // one 64-bit division per thread instead of two per chunk (they were most of this kernel's instructions)
-  const int64_t cq_rows = n / chunks;
+  const int64_t cq_rows = tile_rows > 0 ? 0 : n / chunks;
   const uint32_t rem = (uint32_t)(n - cq_rows * chunks), G = (uint32_t)chunks;
+  for (int g0 = 0; g0 < chunks; g0 += 64 * L) {   // one pass unless a convolution had more than 512 tiles
+    float pm[L], pq[L];
 #pragma unroll
-  for (int i = 0; i < L; ++i) {
-    const int g = lane + i * 64;
-    if (g < chunks) {
-      const uint32_t extra = ((uint32_t)(g + 1) * rem) / G - ((uint32_t)g * rem) / G;
-      const float bn = (float)(cq_rows + extra);
-      chan_merge(cn, cm, cq, bn, pm[i], pq[i]);
+    for (int i = 0; i < L; ++i) {
+      const int g = g0 + lane + i * 64;
+      const int64_t gc = min(g, chunks - 1);   // unconditional loads (a conditional one costs a branch and a full wait)
+      pm[i] = part_mean[gc * c + ch];
+      pq[i] = part_m2[gc * c + ch];
+    }
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+      const int g = g0 + lane + i * 64;
+      if (g < chunks) {
+        float bn;
+        if (tile_rows > 0) {
+          bn = (float)min((int64_t)tile_rows, n - (int64_t)g * tile_rows);
+        } else {
+          const uint32_t extra = ((uint32_t)(g + 1) * rem) / G - ((uint32_t)g * rem) / G;
+          bn = (float)(cq_rows + extra);
+        }
+        chan_merge(cn, cm, cq, bn, pm[i], pq[i]);
+      }
     }
   }
 #pragma unroll
@@ -516,7 +525,7 @@ static int bn_stats(const T *x, int64_t n, int c, float eps, float momentum, flo
   else if (v == 4) hipLaunchKernelGGL((k_bn_partial<T, 4>), dim3(chunks), dim3(256), lds, stream, x, n, c, chunks, pm, pq);
   else hipLaunchKernelGGL((k_bn_partial<T, 1>), dim3(chunks), dim3(256), lds, stream, x, n, c, chunks, pm, pq);
   hipLaunchKernelGGL(k_bn_final, dim3((unsigned)ceil_div(c, 4)), dim3(256), 0, stream, pm, pq, n, c, chunks, eps,
-                     momentum, mean, rstd, running_mean, running_var, num_batches_tracked);
+                     momentum, mean, rstd, running_mean, running_var, num_batches_tracked, 0);
   ME_LAUNCH_CHECK();
   return 0;
 }
@@ -616,6 +625,21 @@ int me_bn_stats(const void *x, int32_t is_bf16, int64_t n, int32_t c, float eps,
                             running_var, num_batches_tracked, ws, stream);
   return bn_stats<float>(reinterpret_cast<const float *>(x), n, c, eps, momentum, mean, rstd, running_mean,
                          running_var, num_batches_tracked, ws, stream);
+}
+
+int me_bn_stats_from_tiles(const float *part_mean, const float *part_m2, int64_t n, int32_t c, int32_t tile_rows,
+                           float eps, float momentum, float *mean, float *rstd, float *running_mean,
+                           float *running_var, int64_t *num_batches_tracked, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ME_CHECK(n > 0 && c > 0 && tile_rows > 0, "batch norm needs at least one row, one channel and a tile height");
+  ME_CHECK(part_mean != nullptr && part_m2 != nullptr, "the tile partials must be given");
+  const int64_t tiles = ceil_div(n, (int64_t)tile_rows);
+  ME_CHECK(tiles < (1ll << 30), "too many tiles");
+  hipLaunchKernelGGL(k_bn_final, dim3((unsigned)ceil_div(c, 4)), dim3(256), 0, stream, part_mean, part_m2, n, c,
+                     (int)tiles, eps, momentum, mean, rstd, running_mean, running_var, num_batches_tracked,
+                     (int)tile_rows);
+  ME_LAUNCH_CHECK();
+  return 0;
 }
 
 int me_bn_apply(const void *x, int32_t is_bf16, int64_t n, int32_t c, const float *mean, const float *rstd,

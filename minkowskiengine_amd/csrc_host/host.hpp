@@ -62,6 +62,7 @@ struct Policy {
   int tile_rows, batch_groups;   // ME_AMD_TILE_ROWS / ME_AMD_BATCH_GROUPS overrides (0 = plan config)
   bool pack_cache;         // ME_AMD_PACK_CACHE
   bool f32_fuse;           // ME_AMD_F32_FUSE
+  bool conv_bn_stats;      // ME_AMD_CONV_BN_STATS: batch-norm statistics in the bf16 convolution's epilogue
   static const Policy &get();
 };
 
@@ -253,6 +254,8 @@ Tensor pruning_backward(const Tensor &grad_out, CoordinateMapKey *in_key, Coordi
                         CoordinateMapManager *mgr);
 
 // batch normalisation over feature rows (csrc/norm.hip)
+void conv_bn_stats_hint(bool flag);   // the convolution module's training flag (a training-mode batch norm may follow)
+void set_conv_bn_stats(int enabled);  // -1: ME_AMD_CONV_BN_STATS, 0 / 1: override (tests)
 std::pair<Tensor, Tensor> bn_stats(const Tensor &x, double eps, double momentum, const Tensor &running_mean,
                                    const Tensor &running_var, const Tensor &num_batches_tracked);
 Tensor bn_apply(const Tensor &x, const Tensor &mean, const Tensor &rstd, const Tensor &gamma, const Tensor &beta,

@@ -38,6 +38,7 @@ const Policy &Policy::get() {
     q.batch_groups = std::atoi(env_str("ME_AMD_BATCH_GROUPS", "0").c_str());
     q.pack_cache = env_str("ME_AMD_PACK_CACHE", "1") != "0";
     q.f32_fuse = env_str("ME_AMD_F32_FUSE", "1") != "0";
+    q.conv_bn_stats = env_str("ME_AMD_CONV_BN_STATS", "1") != "0";
     return q;
   }();
   return p;

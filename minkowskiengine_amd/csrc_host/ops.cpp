@@ -6,6 +6,8 @@
 #include <c10/util/intrusive_ptr.h>
 #include <hip/hip_runtime_api.h>
 
+#include <mutex>
+
 namespace meh {
 
 static void check_feat(const char *name, const Tensor &t) {
@@ -206,6 +208,53 @@ std::vector<std::tuple<std::string, double, double>> timing_records(bool clear) 
   return out;
 }
 
+// ---- statistics a convolution leaves behind for the batch norm that follows (me_conv_target_bf16_stats) ----------------
+// Keyed by the output's storage address; valid for THAT TensorImpl at THAT version only (a recycled address, a view, an
+// in-place update or a channel slice misses and bn_stats reads the matrix).  Consumed by the first bn_stats on it.
+namespace {
+struct BnPartials {
+  c10::weak_intrusive_ptr<c10::TensorImpl> owner;
+  uint32_t version;
+  Tensor part;   // [2][tiles][c] float
+  int tile_rows;
+};
+std::unordered_map<const void *, BnPartials> g_bn_partials;
+std::mutex g_bn_partials_mu;
+bool g_conv_bn_stats_hint = false;
+int g_conv_bn_stats_enabled = -1;   // -1: Policy (ME_AMD_CONV_BN_STATS), 0 / 1: set_conv_bn_stats (tests)
+
+void bn_partials_put(const Tensor &out, const Tensor &part, int tile_rows) {
+  std::lock_guard<std::mutex> lk(g_bn_partials_mu);
+  if (g_bn_partials.size() > 256) {   // outputs that were never normalised (their tensors are long gone)
+    for (auto it = g_bn_partials.begin(); it != g_bn_partials.end();)
+      it = it->second.owner.expired() ? g_bn_partials.erase(it) : std::next(it);
+  }
+  g_bn_partials.erase(out.data_ptr());
+  g_bn_partials.emplace(out.data_ptr(), BnPartials{c10::weak_intrusive_ptr<c10::TensorImpl>(out.getIntrusivePtr()),
+                                                   out._version(), part, tile_rows});
+}
+
+bool bn_partials_take(const Tensor &x, Tensor &part, int &tile_rows) {
+  std::lock_guard<std::mutex> lk(g_bn_partials_mu);
+  auto it = g_bn_partials.find(x.data_ptr());
+  if (it == g_bn_partials.end()) return false;
+  BnPartials e = std::move(it->second);
+  g_bn_partials.erase(it);
+  auto owner = e.owner.lock();
+  if (!owner || owner.get() != x.unsafeGetTensorImpl() || x._version() != e.version) return false;
+  if (e.part.size(2) != x.size(1)) return false;
+  part = e.part;
+  tile_rows = e.tile_rows;
+  return true;
+}
+}  // namespace
+
+void conv_bn_stats_hint(bool flag) { g_conv_bn_stats_hint = flag; }
+void set_conv_bn_stats(int enabled) { g_conv_bn_stats_enabled = enabled; }
+static bool conv_bn_stats_enabled() {
+  return g_conv_bn_stats_enabled >= 0 ? g_conv_bn_stats_enabled != 0 : Policy::get().conv_bn_stats;
+}
+
 // ---- convolution ----------------------------------------------------------------------------------------------------------
 // dst[t] = sum over plan entries of src[s] @ W[k]; transposed (dgrad): W[k] = kernel[k]^T
 static Tensor conv_target(const Tensor &src, const Tensor &kernel, KernelMap &km, const std::string &target, int64_t n_tgt,
@@ -232,6 +281,23 @@ static Tensor conv_target(const Tensor &src, const Tensor &kernel, KernelMap &km
       packed = at::empty({cfg.elems}, at::TensorOptions().dtype(at::kBFloat16).device(dev));
       me_ok(me_conv_pack_weights_bf16(kernel.data_ptr(), kernel.scalar_type() == at::kFloat ? 1 : 0, volume, c_src, c_dst,
                                       transposed ? 1 : 0, ptr<uint16_t>(packed), st));
+    }
+    // (forward launches only: target "out", weights not transposed — the input gradient feeds no batch norm)
+    if (!transposed && target == "out" && g_conv_bn_stats_hint && conv_bn_stats_enabled() &&
+        me_conv_stats_supported_bf16(c_src, c_dst)) {
+      // batch-norm statistics in the epilogue (csrc/conv_bf16.hip): the tiles' partials ride along with the output
+      const int64_t tiles = (n_tgt + cfg.tile_rows - 1) / cfg.tile_rows;
+      Tensor part = at::empty({2, tiles, (int64_t)c_dst}, at::TensorOptions().dtype(at::kFloat).device(dev));
+      {
+        ScopedTimer tm(timed_name, flops, st);
+        me_ok(me_conv_target_bf16_stats(
+            ptr<uint16_t>(src), src.size(0), c_src, ptr<uint16_t>(packed), km.volume, c_dst, ptr<int32_t>(p.plan_src),
+            ptr<int32_t>(p.plan_dst), ptr<int32_t>(p.batch_desc), ptr<int32_t>(p.tile_bptr), ptr<int32_t>(cfg.order),
+            ptr<uint16_t>(out), n_tgt, cfg.tile_rows, cfg.batch_groups, cfg.fuse ? 1 : 0, ptr<float>(part),
+            ptr<float>(part) + tiles * c_dst, st));
+      }
+      bn_partials_put(out, part, cfg.tile_rows);
+      return out;
     }
     ScopedTimer tm(timed_name, flops, st);
     me_ok((cfg.fuse ? me_conv_target_bf16_fused : me_conv_target_bf16)(
@@ -621,8 +687,17 @@ std::pair<Tensor, Tensor> bn_stats(const Tensor &x, double eps, double momentum,
   const int c = (int)x.size(1);
   Tensor mean = at::empty({c}, at::TensorOptions().dtype(at::kFloat).device(dev));
   Tensor rstd = at::empty({c}, at::TensorOptions().dtype(at::kFloat).device(dev));
-  Tensor ws = workspace(me_bn_workspace_bytes(n, c), dev);
   c10::DeviceGuard guard(dev);
+  Tensor part;
+  int tile_rows = 0;
+  if (bn_partials_take(x, part, tile_rows)) {   // the producing convolution already summed its tiles
+    const int64_t tiles = part.size(1);
+    me_ok(me_bn_stats_from_tiles(ptr<float>(part), ptr<float>(part) + tiles * c, n, c, tile_rows, (float)eps,
+                                 (float)momentum, ptr<float>(mean), ptr<float>(rstd), ptr<float>(running_mean),
+                                 ptr<float>(running_var), ptr<int64_t>(num_batches_tracked), stream_of(dev)));
+    return {mean, rstd};
+  }
+  Tensor ws = workspace(me_bn_workspace_bytes(n, c), dev);
   me_ok(me_bn_stats(x.data_ptr(), x.scalar_type() == at::kBFloat16 ? 1 : 0, n, c, (float)eps, (float)momentum,
                     ptr<float>(mean), ptr<float>(rstd), ptr<float>(running_mean), ptr<float>(running_var),
                     ptr<int64_t>(num_batches_tracked), vptr(ws), ws.numel(), stream_of(dev)));

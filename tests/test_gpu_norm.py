@@ -163,3 +163,98 @@ def test_fused_norm_add_relu_is_bit_identical_to_the_three_operators(device, mon
     assert float((res[True][0] == 0).float().mean()) > 0.2          # the ReLU does mask something
     for a, b_ in zip(res[True], res[False]):
         assert torch.equal(a, b_)
+
+
+@pytest.mark.parametrize("n,extent,D,cin,cout,ks", [(6000, 40, 3, 96, 96, 3), (4000, 14, 3, 64, 128, 3), (300, 6, 3, 256, 256, 3),
+                                                    (3000, 9, 4, 32, 64, 3), (5000, 16, 3, 128, 96, 2), (70, 3, 3, 64, 64, 3),
+                                                    (5000, 30, 3, 32, 32, 3), (2500, 12, 3, 256, 128, 3), (20000, 60, 3, 16, 32, 3)])
+def test_convolution_epilogue_statistics_equal_a_pass_over_the_output(device, n, extent, D, cin, cout, ks):
+    """me_conv_target_bf16_stats: the bf16 forward launch leaves the (mean, M2) of every tile and
+    output channel behind, and me_bn_stats_from_tiles merges them into the batch norm's mean / rstd / running statistics
+    without reading the matrix.  The convolution's output is bit-identical with and without the epilogue; the statistics
+    equal those of k_bn_partial's pass over that output up to the regrouping of fp32 partial sums (1e-5 relative + 1e-6
+    on the mean, 1e-4 on rstd), for every slab width, the fused and the deep instantiation, one-tile and many-tile maps."""
+    from minkowskiengine_amd import backend as MEB
+    coords = make_cloud(n, extent, D, seed=cin + cout + n, batch=2, negative=True)
+    mgr = MEB.CoordinateMapManagerGPU_c10()
+    key, _ = mgr.insert_and_map(coords.to(device), [1] * D, "")
+    km = mgr._kernel_map(key, key, [ks] * D, [1] * D, [1] * D, MEB.RegionType.HYPER_CUBE, None, False, False)
+    g = torch.Generator().manual_seed(21)
+    x = (torch.rand(coords.shape[0], cin, generator=g) - 0.3).to(device).bfloat16()
+    w = (torch.rand(ks ** D, cin, cout, generator=g) - 0.5).to(device)
+    try:
+        MEB.conv_bn_stats_hint(False)
+        y0 = MEB._conv_forward(x, w, km, "mfma")
+        assert not MEB._BN_PARTIALS
+        MEB.conv_bn_stats_hint(True)
+        y1 = MEB._conv_forward(x, w, km, "mfma")
+    finally:
+        MEB.conv_bn_stats_hint(False)
+    assert torch.equal(y0, y1)
+    assert y1.data_ptr() in MEB._BN_PARTIALS
+    rm0, rv0 = torch.zeros(cout, device=device), torch.ones(cout, device=device)
+    rm1, rv1 = rm0.clone(), rv0.clone()
+    nb0, nb1 = torch.zeros((), dtype=torch.int64, device=device), torch.zeros((), dtype=torch.int64, device=device)
+    mean1, rstd1 = MEB.bn_stats(y1, 1e-5, 0.1, rm1, rv1, nb1)          # from the tiles (the entry is consumed)
+    assert not MEB._BN_PARTIALS
+    mean0, rstd0 = MEB.bn_stats(y0, 1e-5, 0.1, rm0, rv0, nb0)          # a pass over the matrix
+    ref = y0.double()
+    assert close(mean0, ref.mean(0), 1e-5) and close(mean1, ref.mean(0), 1e-5)
+    scale = float(ref.abs().max())
+    assert float((mean1 - mean0).abs().max()) <= 1e-5 * scale + 1e-6
+    assert float(((rstd1 - rstd0) / rstd0).abs().max()) <= 1e-4
+    assert float((rm1 - rm0).abs().max()) <= 1e-5 * scale + 1e-6 and float(((rv1 - rv0) / rv0).abs().max()) <= 1e-4
+    assert int(nb1) == 1 and int(nb0) == 1
+    # the statistics belong to that tensor at that version: a modified, sliced or different tensor reads the matrix
+    MEB.conv_bn_stats_hint(True)
+    try:
+        y2 = MEB._conv_forward(x, w, km, "mfma")
+        y2.add_(1.0)
+        assert MEB._bn_partials_take(y2) is None
+        y3 = MEB._conv_forward(x, w, km, "mfma")
+        assert MEB._bn_partials_take(y3[:, : cout // 2].contiguous()) is None
+        assert MEB._bn_partials_take(y3) is not None and MEB._bn_partials_take(y3) is None
+    finally:
+        MEB.conv_bn_stats_hint(False)
+        MEB._BN_PARTIALS.clear()
+
+
+@pytest.mark.parametrize("native", [False, True])
+def test_conv_batchnorm_pair_uses_the_epilogue_statistics(device, native, monkeypatch):
+    """MinkowskiConvolution -> MinkowskiBatchNorm in training mode, bf16, on both host layers: with the epilogue
+    statistics (default) the pair runs without k_bn_partial and agrees with the two-pass pair to bf16 rounding of the
+    normalised output; the gradient flows as before."""
+    import minkowskiengine_amd as ME
+    from minkowskiengine_amd import backend as MEB, host as H
+    if native and H.native_module() is None:
+        pytest.skip("native host layer not built")
+    prev = H.get_host()
+    H.set_host("native" if native else "python")
+    try:
+        coords = make_cloud(8000, 30, 3, seed=5, batch=2).to(device)
+        g = torch.Generator().manual_seed(9)
+        f0 = torch.rand(coords.shape[0], 64, generator=g).to(device).bfloat16()
+        res = {}
+        for fused in (True, False):
+            monkeypatch.setattr(MEB, "_CONV_BN_STATS", fused)
+            if native:
+                H.native_module().set_conv_bn_stats(1 if fused else 0)
+            torch.manual_seed(3)
+            conv = ME.MinkowskiConvolution(64, 128, kernel_size=3, dimension=3).to(device)
+            bn = ME.MinkowskiBatchNorm(128).to(device)
+            f = f0.clone().requires_grad_(True)
+            y = bn(conv(ME.SparseTensor(f, coords)))
+            y.F.float().square().mean().backward()
+            res[fused] = (y.F.detach().float(), f.grad.float(), bn.bn.running_mean.clone(), bn.bn.running_var.clone())
+            if fused and not native:
+                assert not MEB._BN_PARTIALS, "the batch norm consumed the convolution's statistics"
+        a, b = res[True], res[False]
+        scale = float(b[0].abs().max())
+        assert float((a[0] - b[0]).abs().max()) <= 2.0 ** -7 * scale        # one bf16 ulp of the largest output
+        assert float((a[1] - b[1]).abs().max()) <= 0.02 * float(b[1].abs().max()) + 1e-6
+        assert float((a[2] - b[2]).abs().max()) <= 1e-5 * scale + 1e-6
+        assert float(((a[3] - b[3]) / b[3]).abs().max()) <= 1e-4
+    finally:
+        if native:
+            H.native_module().set_conv_bn_stats(-1)
+        H.set_host(prev)
