@@ -513,7 +513,7 @@ class KernelMapGPU:
 
 
 # Kernel-map build: "auto" = the LDS-bucketed build (spatial index + k_kmap_probe_lds, position-space tables) where it
-# pays — measured (profiles/r02_kmap_build.log): 2.1x faster than the flat-table probe on config 5 (K = 81, 32 M
+# pays — measured (profiles/r02_rocprof_kernel_stats_kmap_{conv3d,conv4d}_{flat,lds}.csv): 2.1x faster than the flat-table probe on config 5 (K = 81, 32 M
 # probes), on par on config 2 (K = 27, 2.7 M probes), where the one-off spatial index of the map (~110 us) makes the
 # cold path slower; True / False (ME_AMD_SPATIAL_MAPS=1 / 0) force one path.
 _SPATIAL_MAPS = {"1": True, "0": False}.get(os.environ.get("ME_AMD_SPATIAL_MAPS", "auto"), "auto")
@@ -1843,10 +1843,13 @@ def conv_bn_stats_hint(flag):
 
 
 def _bn_partials_put(out, part, tile_rows):
-    if len(_BN_PARTIALS) > 256:      # outputs that were never normalised (their tensors are long gone)
-        for k in [k for k, v in _BN_PARTIALS.items() if v[0]() is None]:
-            del _BN_PARTIALS[k]
-    _BN_PARTIALS[out.data_ptr()] = (weakref.ref(out), out._version, part, int(tile_rows), tuple(out.shape))
+    key = out.data_ptr()
+
+    def _gone(ref, key=key):     # the output was never normalised and has been collected: drop its entry
+        ent = _BN_PARTIALS.get(key)
+        if ent is not None and ent[0] is ref:
+            del _BN_PARTIALS[key]
+    _BN_PARTIALS[key] = (weakref.ref(out, _gone), out._version, part, int(tile_rows), tuple(out.shape))
 
 
 def _bn_partials_take(x):

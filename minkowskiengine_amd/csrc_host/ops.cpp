@@ -225,7 +225,7 @@ int g_conv_bn_stats_enabled = -1;   // -1: Policy (ME_AMD_CONV_BN_STATS), 0 / 1:
 
 void bn_partials_put(const Tensor &out, const Tensor &part, int tile_rows) {
   std::lock_guard<std::mutex> lk(g_bn_partials_mu);
-  if (g_bn_partials.size() > 256) {   // outputs that were never normalised (their tensors are long gone)
+  if (g_bn_partials.size() > 32) {    // outputs that were never normalised (their tensors are long gone)
     for (auto it = g_bn_partials.begin(); it != g_bn_partials.end();)
       it = it->second.owner.expired() ? g_bn_partials.erase(it) : std::next(it);
   }

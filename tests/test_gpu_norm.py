@@ -182,6 +182,7 @@ def test_convolution_epilogue_statistics_equal_a_pass_over_the_output(device, n,
     g = torch.Generator().manual_seed(21)
     x = (torch.rand(coords.shape[0], cin, generator=g) - 0.3).to(device).bfloat16()
     w = (torch.rand(ks ** D, cin, cout, generator=g) - 0.5).to(device)
+    MEB._BN_PARTIALS.clear()
     try:
         MEB.conv_bn_stats_hint(False)
         y0 = MEB._conv_forward(x, w, km, "mfma")
@@ -214,6 +215,10 @@ def test_convolution_epilogue_statistics_equal_a_pass_over_the_output(device, n,
         y3 = MEB._conv_forward(x, w, km, "mfma")
         assert MEB._bn_partials_take(y3[:, : cout // 2].contiguous()) is None
         assert MEB._bn_partials_take(y3) is not None and MEB._bn_partials_take(y3) is None
+        y4 = MEB._conv_forward(x, w, km, "mfma")
+        assert len(MEB._BN_PARTIALS) == 1
+        del y4                                    # never normalised: its entry goes with the tensor
+        assert not MEB._BN_PARTIALS
     finally:
         MEB.conv_bn_stats_hint(False)
         MEB._BN_PARTIALS.clear()
@@ -231,6 +236,7 @@ def test_conv_batchnorm_pair_uses_the_epilogue_statistics(device, native, monkey
     prev = H.get_host()
     H.set_host("native" if native else "python")
     try:
+        MEB._BN_PARTIALS.clear()
         coords = make_cloud(8000, 30, 3, seed=5, batch=2).to(device)
         g = torch.Generator().manual_seed(9)
         f0 = torch.rand(coords.shape[0], 64, generator=g).to(device).bfloat16()
