@@ -98,3 +98,32 @@ def test_tile_order_policy(monkeypatch):
     monkeypatch.setattr(MEB, "_TILE_ORDER", "auto")
     monkeypatch.setattr(MEB, "_SPATIAL_TILES", False)
     assert small.order("out", "spatial") is None and small.order("out") is None
+
+
+def test_conv_statistics_registry_belongs_to_one_tensor_at_one_version():
+    """backend._BN_PARTIALS hands a convolution's epilogue statistics to the batch norm that follows: an entry is valid
+    for the very tensor object it was registered for, at the version it had; it is consumed by the first take, missed by
+    a modified / other / re-allocated tensor, and dropped when its tensor is collected (host logic: CPU tensors do)."""
+    import torch
+    from minkowskiengine_amd import backend as MEB
+    MEB._BN_PARTIALS.clear()
+    y = torch.zeros(10, 8)
+    part = torch.zeros(2, 1, 8)
+    MEB._bn_partials_put(y, part, 16)
+    assert MEB._bn_partials_take(torch.zeros(10, 8)) is None           # another tensor
+    got = MEB._bn_partials_take(y)
+    assert got is not None and got[0] is part and got[1] == 16
+    assert MEB._bn_partials_take(y) is None                            # consumed
+    MEB._bn_partials_put(y, part, 16)
+    y.add_(1.0)                                                        # modified in place: version counter moved
+    assert MEB._bn_partials_take(y) is None and not MEB._BN_PARTIALS
+    MEB._bn_partials_put(y, part, 16)
+    assert MEB._bn_partials_take(y[:, :4]) is None                     # a view of it (same storage address) is not it
+    z = torch.zeros(10, 8)
+    MEB._bn_partials_put(z, part, 16)
+    assert len(MEB._BN_PARTIALS) == 1
+    del z                                                              # never normalised: the entry goes with it
+    assert not MEB._BN_PARTIALS
+    MEB.conv_bn_stats_hint(True)
+    assert MEB._BN_STATS_HINT[0] is True
+    MEB.conv_bn_stats_hint(False)
