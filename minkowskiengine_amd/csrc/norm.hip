@@ -166,18 +166,9 @@ __global__ __launch_bounds__(256) void k_bn_partial(const T *__restrict__ x, int
   }
 }
 
-// Combine the chunks of each channel (Chan et al.): ONE WAVE per channel (4 channels per block); lane l merges
-// chunks l, l + 64, ... in order, then the 64 lane results are merged in a fixed shuffle tree (the formula is
-// associative, the tree is the same every run: bitwise reproducible).  Writes mean, rstd (biased variance +
-// eps) and updates the running statistics (unbiased variance, torch's convention).
-__device__ __forceinline__ void chan_merge(float &cn, float &cm, float &cq, float bn, float bm, float bq) {
-  if (bn > 0.f) {
-    const float tot = cn + bn, d = bm - cm;
-    cm += d * (bn / tot);
-    cq += bq + d * d * (cn * bn / tot);
-    cn = tot;
-  }
-}
+// Combine the chunks of each channel: ONE WAVE per channel (4 channels per block); lane l takes chunks l, l + 64, ...
+// in order, then the 64 lane results are added in a fixed shuffle tree (the same every run: bitwise reproducible).
+// Writes mean, rstd (biased variance + eps) and updates the running statistics (unbiased variance, torch's convention).
 
 // tile_rows > 0: the partials are those of a convolution's tiles (k_conv_tile_bf16's statistics epilogue: tile g
 // holds rows [g * tile_rows, min((g + 1) * tile_rows, n)), any number of tiles); 0: k_bn_partial's equal chunks.
@@ -196,12 +187,18 @@ __global__ __launch_bounds__(256) void k_bn_final(const float *__restrict__ part
     rm_old = running_mean[ch];
     rv_old = running_var[ch];
   }
-  float cn = 0.f, cm = 0.f, cq = 0.f;
-  constexpr int L = kBnMaxChunks / 64;   // chunks per lane and pass: all partials requested before the (dependent) merges
+  // Merge of the chunks (round 3, second form): every chunk's mean is taken relative to ONE shift — chunk 0's mean, the
+  // same for all lanes — so the merge is three weighted sums, A = sum n_g d_g, B = sum (M2_g + n_g d_g^2), N = sum n_g with
+  // d_g = mean_g - shift, added lane by lane and then across the lanes in a fixed shuffle tree; mean = shift + A / N,
+  // M2 = B - A^2 / N.  No division inside the loop or the tree (Chan's pairwise update costs two per merge: 16 merges
+  // per lane + 6 tree levels were ~3 us of this kernel's 7).  Fixed order: bitwise reproducible.
+  constexpr int L = kBnMaxChunks / 64;   // chunks per lane and pass: all partials requested before they are used
   // rows of chunk g = chunk_begin(g + 1) - chunk_begin(g) = q + ((g + 1) * rem) / G - (g * rem) / G with n = q * G + rem:
-  // one 64-bit division per thread instead of two per chunk (they were most of this kernel's instructions)
+  // one 64-bit division per thread instead of two per chunk
   const int64_t cq_rows = tile_rows > 0 ? 0 : n / chunks;
   const uint32_t rem = (uint32_t)(n - cq_rows * chunks), G = (uint32_t)chunks;
+  const float shift = part_mean[ch];     // chunk 0 (every lane reads the same word)
+  float sa = 0.f, sb = 0.f, sn = 0.f;
   for (int g0 = 0; g0 < chunks; g0 += 64 * L) {   // one pass unless a convolution had more than 512 tiles
     float pm[L], pq[L];
 #pragma unroll
@@ -214,23 +211,33 @@ __global__ __launch_bounds__(256) void k_bn_final(const float *__restrict__ part
 #pragma unroll
     for (int i = 0; i < L; ++i) {
       const int g = g0 + lane + i * 64;
-      if (g < chunks) {
-        float bn;
-        if (tile_rows > 0) {
-          bn = (float)min((int64_t)tile_rows, n - (int64_t)g * tile_rows);
-        } else {
-          const uint32_t extra = ((uint32_t)(g + 1) * rem) / G - ((uint32_t)g * rem) / G;
-          bn = (float)(cq_rows + extra);
-        }
-        chan_merge(cn, cm, cq, bn, pm[i], pq[i]);
+      float bn;
+      if (tile_rows > 0) {
+        bn = (float)min((int64_t)tile_rows, n - (int64_t)g * tile_rows);
+      } else {
+        const uint32_t extra = ((uint32_t)(g + 1) * rem) / G - ((uint32_t)g * rem) / G;
+        bn = (float)(cq_rows + extra);
       }
+      if (g >= chunks) bn = 0.f;
+      const float d = pm[i] - shift;
+      sa = fmaf(bn, d, sa);
+      sb += g < chunks ? fmaf(bn * d, d, pq[i]) : 0.f;
+      sn += bn;
     }
   }
 #pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {  // lane l absorbs lane l + off: chunk order is preserved
-    const float bn = __shfl_down(cn, off, 64), bm = __shfl_down(cm, off, 64), bq = __shfl_down(cq, off, 64);
-    if ((lane & (2 * off - 1)) == 0) chan_merge(cn, cm, cq, bn, bm, bq);
+  for (int off = 1; off < 64; off <<= 1) {  // lane l absorbs lane l + off: a fixed tree
+    const float ta = __shfl_down(sa, off, 64), tb = __shfl_down(sb, off, 64), tn = __shfl_down(sn, off, 64);
+    if ((lane & (2 * off - 1)) == 0) {
+      sa += ta;
+      sb += tb;
+      sn += tn;
+    }
   }
+  const float cn = sn;
+  const float am = cn > 0.f ? sa / cn : 0.f;
+  const float cm = shift + am;
+  const float cq = fmaxf(sb - sa * am, 0.f);
   if (lane != 0) return;
   const float var = cn > 0.f ? cq / cn : 0.f;
   mean_out[ch] = cm;
