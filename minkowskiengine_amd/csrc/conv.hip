@@ -1214,13 +1214,14 @@ __global__ __launch_bounds__(256, (NB == 4 ? 2 : 3)) void k_wgrad_f32(const T *_
 // and the pair indices of step s+2 are being fetched while step s is multiplied.
 constexpr int kWgStepLd = 16;  // padding elements per staged row
 
-// DEEP (round 3): TWO steps of gathered rows in flight instead of one.  The loop is bound by the latency of its row
-// gathers (24 KiB per step and workgroup, two workgroups per CU: ~30 GB/s per CU against the ~150 GB/s the vector memory
-// path delivers with enough requests outstanding), and at two waves per SIMD the register file has room for a second
-// set of staging registers: at step s the rows of step s + 1 are in flight, the rows of step s + 2 are requested and
-// the indices of step s + 3 are fetched; the loads retire in order, so ONE counted wait per step (all but the newest
-// row set) guards both the rows of step s and the indices of step s + 2.  Same sums in the same order: bit-identical.
-template <int NB, int KSTEPS, bool DEEP = false>
+// (Round 3 also built a variant with TWO steps of gathered rows in flight — second register set, one counted wait per step,
+// bit-identical — and measured it 3 - 6 % slower, profiles/r03_wgrad_bf16_two_steps_in_flight.log: the loop is not waiting
+// for more requests in flight.  Removed again.)
+// MB: 16-channel blocks of INPUT channels per workgroup — 4 (64 channels) or 8 (128).  The kernel is bound by its gathers
+// (config 2: 326 MB fetched for 45 MB of rows, TCC hit rate 13 %, profiles/r03_pmc_traffic_bf16.log): every x slice is
+// gathered once per block of output channels and every dy slice once per block of input channels, so a 128 x 128 block
+// moves 2/3 of the bytes of a 64 x 128 one per multiply-add (64 accumulator registers instead of 32).
+template <int NB, int KSTEPS, int MB = 4>
 __global__ __launch_bounds__(256, 2) void k_wgrad_bf16(const __bf16 *__restrict__ x, int c_in,
                                                       const __bf16 *__restrict__ dy, int c_out,
                                                       const int32_t *__restrict__ in_pairs,
@@ -1229,12 +1230,14 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_bf16(const __bf16 *__restrict_
                                                       int64_t n_pairs, int n_ranges, int n_cob,
                                                       float *__restrict__ partial) {
   typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
-  constexpr int MB = 4;
+  static_assert(MB == 4 || MB == 8, "input-channel blocks per workgroup");
+  constexpr int CI = 16 * MB;            // input channels per workgroup
+  constexpr int XQ = CI / 8;             // 16-byte pieces per staged x row
   constexpr int SP = 32 * KSTEPS;        // pairs per step (<= 64: one index register per wave)
   constexpr int COB = 64 * NB;           // output channels per workgroup
-  constexpr int XLD = 64 + kWgStepLd;    // elements
+  constexpr int XLD = CI + kWgStepLd;    // elements
   constexpr int DLD = COB + kWgStepLd;
-  constexpr int XP = SP * 8 / 256;       // 16-byte x pieces per thread and step
+  constexpr int XP = SP * XQ / 256;      // 16-byte x pieces per thread and step
   constexpr int DP = SP * (COB / 8) / 256;
   static_assert(SP <= 64 && XP >= 1, "step size");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1246,7 +1249,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_bf16(const __bf16 *__restrict_
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int i16 = lane & 15, q = lane >> 4;
   const int range = blockIdx.x;
-  const int ci0 = blockIdx.y * 64;
+  const int ci0 = blockIdx.y * CI;
   const int cog = blockIdx.z * COB;                           // first output channel of the workgroup
   const int cob = blockIdx.z * 4 + wave;                      // this wave's block of 16*NB output channels
   const int64_t e_lo = n_pairs * range / n_ranges;
@@ -1295,8 +1298,8 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_bf16(const __bf16 *__restrict_
 #pragma unroll
     for (int j = 0; j < XP; ++j) {
       const int idx = j * 256 + tid;
-      const int row = idx >> 3;
-      const int ch = ci0 + (idx & 7) * 8;
+      const int row = idx / XQ;
+      const int ch = ci0 + (idx % XQ) * 8;
       const int32_t r = __shfl(pin, row, 64);
       const __bf16 *p = x + (int64_t)r * c_in + (ch < c_in ? ch : 0);
       asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(rx[j]) : "v"(p) : "memory");
@@ -1323,10 +1326,10 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_bf16(const __bf16 *__restrict_
 #pragma unroll
     for (int j = 0; j < XP; ++j) {
       const int idx = j * 256 + tid;
-      const int row = idx >> 3;
-      const int ch = ci0 + (idx & 7) * 8;
+      const int row = idx / XQ;
+      const int ch = ci0 + (idx % XQ) * 8;
       const bool ok = row < cnt && ch < c_in;                // pairs beyond the step / channels beyond c_in: zeros
-      *reinterpret_cast<bf16x8 *>(s_x + (buf * SP + row) * XLD + (idx & 7) * 8) = ok ? rx[j] : zero;
+      *reinterpret_cast<bf16x8 *>(s_x + (buf * SP + row) * XLD + (idx % XQ) * 8) = ok ? rx[j] : zero;
     }
 #pragma unroll
     for (int j = 0; j < DP; ++j) {
@@ -1398,109 +1401,6 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_bf16(const __bf16 *__restrict_
   advance(kC, eC, cB);
   int cC = step_count(kC, eC);
 
-  if constexpr (DEEP) {
-    // second register set + second index pair; the generic lambdas below work on whichever set they are handed
-    int32_t pin2 = 0, pout2 = 0;
-    bf16x8 rx2[XP], rd2[DP];
-    auto idx_into = [&](int32_t &pi_, int32_t &po_, int64_t e) {
-      const int64_t ec = min(e + lane, n_pairs - 1);
-      const int32_t *pi = in_pairs + ec, *po = out_pairs + ec;
-      asm volatile("global_load_dword %0, %1, off" : "=v"(pi_) : "v"(pi) : "memory");
-      asm volatile("global_load_dword %0, %1, off" : "=v"(po_) : "v"(po) : "memory");
-    };
-    auto rows_into = [&](bf16x8 (&ax)[XP], bf16x8 (&ad)[DP], int32_t pi_, int32_t po_) {
-#pragma unroll
-      for (int j = 0; j < XP; ++j) {
-        const int idx = j * 256 + tid;
-        const int row = idx >> 3;
-        const int ch = ci0 + (idx & 7) * 8;
-        const int32_t r = __shfl(pi_, row, 64);
-        const __bf16 *p = x + (int64_t)r * c_in + (ch < c_in ? ch : 0);
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ax[j]) : "v"(p) : "memory");
-      }
-#pragma unroll
-      for (int j = 0; j < DP; ++j) {
-        const int idx = j * 256 + tid;
-        const int row = idx / (COB / 8);
-        const int ch = cog + (idx % (COB / 8)) * 8;
-        const int32_t r = __shfl(po_, row, 64);
-        const __bf16 *p = dy + (int64_t)r * c_out + (ch < c_out ? ch : 0);
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ad[j]) : "v"(p) : "memory");
-      }
-    };
-    auto lds_from = [&](const bf16x8 (&ax)[XP], const bf16x8 (&ad)[DP], int buf_, int cnt) {
-      const bf16x8 zero = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
-#pragma unroll
-      for (int j = 0; j < XP; ++j) {
-        const int idx = j * 256 + tid;
-        const int row = idx >> 3;
-        const int ch = ci0 + (idx & 7) * 8;
-        const bool ok = row < cnt && ch < c_in;
-        *reinterpret_cast<bf16x8 *>(s_x + (buf_ * SP + row) * XLD + (idx & 7) * 8) = ok ? ax[j] : zero;
-      }
-#pragma unroll
-      for (int j = 0; j < DP; ++j) {
-        const int idx = j * 256 + tid;
-        const int row = idx / (COB / 8);
-        const int pc = idx % (COB / 8);
-        const bool ok = row < cnt && cog + pc * 8 < c_out;
-        *reinterpret_cast<bf16x8 *>(s_d + (buf_ * SP + row) * DLD + pc * 8) = ok ? ad[j] : zero;
-      }
-    };
-    // step D = three ahead (its indices are fetched while step A is multiplied)
-    int kD = kC;
-    int64_t eD = eC;
-    advance(kD, eD, cC);
-    int cD = step_count(kD, eD);
-    // prologue: indices of A and B, rows of A (set 1) and B (set 2), indices of C (pair 1)
-    idx_into(pin, pout, eA);
-    idx_into(pin2, pout2, eB);
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pin), "+v"(pout), "+v"(pin2), "+v"(pout2));
-    rows_into(rx, rd, pin, pout);
-    idx_into(pin, pout, eC);            // (issued BEFORE the rows of B: it must have arrived when they may still fly)
-    rows_into(rx2, rd2, pin2, pout2);
-    zero_acc();
-    int buf = 0;
-    int pending = -1;
-    // one step: `ax/ad` hold the rows of step A (requested two steps ago), `pi/po` the indices of step C (requested one
-    // step ago, before the rows of step B); the rows of step B — XP + DP loads — may stay in flight across the wait
-    auto step = [&](bf16x8 (&ax)[XP], bf16x8 (&ad)[DP], int32_t &pi_, int32_t &po_, int32_t &pi_next, int32_t &po_next) {
-      if (pending >= 0) {
-        flush(pending);
-        zero_acc();
-      }
-      asm volatile("s_waitcnt vmcnt(%0)" : : "n"(XP + DP) : "memory");
-#pragma unroll
-      for (int j = 0; j < XP; ++j) asm volatile("" : "+v"(ax[j]));
-#pragma unroll
-      for (int j = 0; j < DP; ++j) asm volatile("" : "+v"(ad[j]));
-      asm volatile("" : "+v"(pi_), "+v"(po_));
-      lds_from(ax, ad, buf, cA);
-      idx_into(pi_next, po_next, eD);          // indices of step D first ...
-      rows_into(ax, ad, pi_, po_);             // ... then the rows of step C into the set just stored
-      __builtin_amdgcn_sched_barrier(0);
-      __syncthreads();
-      multiply(buf);
-      pending = (cB == 0 || kB != kA) ? kA : -1;
-      buf ^= 1;
-      kA = kB; eA = eB; cA = cB;
-      kB = kC; eB = eC; cB = cC;
-      kC = kD; eC = eD; cC = cD;
-      advance(kD, eD, cD);
-      cD = step_count(kD, eD);
-    };
-    while (cA > 0) {
-      // (index pairs alternate with the row sets: the rows of step C are addressed by the pair that was requested a
-      // step ago, and the pair that addressed step B — consumed a step ago — receives the indices of step D)
-      step(rx, rd, pin, pout, pin2, pout2);
-      if (cA <= 0) break;
-      step(rx2, rd2, pin2, pout2, pin, pout);
-    }
-    if (pending >= 0) flush(pending);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (loads issued for steps beyond the range target live registers)
-    return;
-  }
-
   load_idx(eA);
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(pin), "+v"(pout));
   load_rows();          // rows of step A
@@ -1529,6 +1429,11 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_bf16(const __bf16 *__restrict_
     advance(kC, eC, cC);
     cC = step_count(kC, eC);
   }
+  // The last iteration requested rows and indices of steps beyond the range (asm loads the compiler knows nothing
+  // about): they must have LANDED, with their destination registers still reserved, before the final flush — hipcc
+  // otherwise recycles those registers for the flush's store addresses and the late data turns them into wild
+  // pointers (round 3: GPU memory faults of the 128-channel variant on busy chips; round 1's <4, 1> the same way).
+  wait_rows();
   if (pending >= 0) flush(pending);
 }
 
@@ -1773,6 +1678,11 @@ __global__ __launch_bounds__(256, 3) void k_wgrad_f32x3(const float *__restrict_
     advance(kC, eC, cC);
     cC = step_count(kC, eC);
   }
+  // The last iteration requested rows and indices of steps beyond the range (asm loads the compiler knows nothing
+  // about): they must have LANDED, with their destination registers still reserved, before the final flush — hipcc
+  // otherwise recycles those registers for the flush's store addresses and the late data turns them into wild
+  // pointers (round 3: GPU memory faults of the 128-channel variant on busy chips; round 1's <4, 1> the same way).
+  wait_rows();
   if (pending >= 0) flush(pending);
 }
 
@@ -1976,6 +1886,11 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_lds_f32(const float *__restric
     advance(kC, eC, cC);
     cC = step_count(kC, eC);
   }
+  // The last iteration requested rows and indices of steps beyond the range (asm loads the compiler knows nothing
+  // about): they must have LANDED, with their destination registers still reserved, before the final flush — hipcc
+  // otherwise recycles those registers for the flush's store addresses and the late data turns them into wild
+  // pointers (round 3: GPU memory faults of the 128-channel variant on busy chips; round 1's <4, 1> the same way).
+  wait_rows();
   if (pending >= 0) flush(pending);
 }
 
@@ -1995,7 +1910,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_lds_f32(const float *__restric
 constexpr int kWgReducePhases = 4;   // waves per block of k_wgrad_reduce (16 measured slower: most offsets own ~10
                                      // slots, and 4x the waves cost more than the long chain of the centre offset saves)
 
-template <int NB, bool TR>
+template <int NB, bool TR, int MB = kWgMB>
 __global__ __launch_bounds__(64 * kWgReducePhases) void k_wgrad_reduce(const float *__restrict__ partial,
                                                      const int64_t *__restrict__ koffs, int volume,
                                                      int64_t n_pairs, int n_ranges, int n_cib, int n_cob,
@@ -2005,7 +1920,7 @@ __global__ __launch_bounds__(64 * kWgReducePhases) void k_wgrad_reduce(const flo
   // dispatching 110k four-instruction waves on a 256 x 256 layer (33 us for 23 MB of partials, longer than the
   // weight-gradient kernel it follows: profiles/r03_pmc_bf16_layers.log).  The sums are the same sums in the same
   // order (per element: slots of a phase in ascending order, then the phases in order): bit-identical results.
-  constexpr int MB = kWgMB;
+  static_assert(MB == 4 || MB == 8, "input-channel blocks per workgroup");
   constexpr int kImage = MB * NB * 4 * 64;
   constexpr int PH = kWgReducePhases;
   __shared__ int64_t s_r[2];
@@ -2354,13 +2269,23 @@ static WgradGeom wgrad_geom(int64_t n_pairs, int64_t volume, int c_in, int c_out
 
 // geometry of the LDS-staged kernels (k_wgrad_bf16, k_wgrad_lds_f32): always four waves side by side along the
 // output channels
-static WgradGeom wgrad_geom_staged(int64_t n_pairs, int c_in, int c_out, int wpc_default = 2) {
+int g_wgrad_mb = 0;   // me_debug_set_wgrad_mb: 0 = policy, 4 / 8 = input-channel blocks per workgroup of k_wgrad_bf16
+
+// 128 x 128 blocks where at least two of them stand side by side along the input channels (c_in >= 192): measured per
+// layer inside a MinkUNet34C step (gpurun_out/r04r): 384 -> 256 201 -> 151 us, 192 -> 128 157 -> 107, 256 -> 256 on 21k
+// voxels 80 -> 71; with ONE block (c_in = 128) the doubled range count costs more than the bytes save (32 -> 34 us).
+static int wgrad_bf16_mb(int c_in, int c_out) {
+  if (g_wgrad_mb == 4 || g_wgrad_mb == 8) return (g_wgrad_mb == 8 && c_out > 64) ? 8 : 4;
+  return (c_in >= 192 && c_out > 64) ? 8 : 4;
+}
+
+static WgradGeom wgrad_geom_staged(int64_t n_pairs, int c_in, int c_out, int wpc_default = 2, int mb = kWgMB) {
   WgradGeom g;
   // 64 or 128 output channels per workgroup; wider layers take several workgroup columns (grid.z) that
   // re-gather the x rows (the <4, 1> instantiation — 256 channels, 32-pair steps — faulted on the GPU and is
   // not used; its cause was not found in round 1)
   g.nb = c_out <= 64 ? 1 : 2;
-  g.n_cib = (int)ceil_div(c_in, 16 * kWgMB);
+  g.n_cib = (int)ceil_div(c_in, 16 * mb);
   g.n_cob = (int)ceil_div(c_out, 16 * g.nb);
   g.waves = 4;
   g.gz = (int)ceil_div(g.n_cob, 4);
@@ -2369,27 +2294,22 @@ static WgradGeom wgrad_geom_staged(int64_t n_pairs, int c_in, int c_out, int wpc
   if (r > n_pairs / 64) r = n_pairs / 64;
   if (r < 1) r = 1;
   g.ranges = r;
-  g.slot_floats = (int64_t)g.n_cib * g.n_cob * (kWgMB * g.nb * 4 * 64);
+  g.slot_floats = (int64_t)g.n_cib * g.n_cob * (mb * g.nb * 4 * 64);
   return g;
 }
 
-template <int NB, int KSTEPS>
+template <int NB, int KSTEPS, int MB = kWgMB>
 static int launch_wgrad_bf16(const WgradGeom &g, const __bf16 *x, int c_in, const __bf16 *dy, int c_out,
                              const int32_t *in_pairs, const int32_t *out_pairs, const int64_t *k_offsets_dev,
                              int volume, int64_t n_pairs, float *partial, hipStream_t stream) {
   constexpr int SP = 32 * KSTEPS;
-  const int lds = 2 * SP * ((64 + kWgStepLd) + (64 * NB + kWgStepLd)) * 2;
-  // two steps of rows in flight: built and measured in round 3, NOT the default — MinkUNet34C bf16 15.0 ms per step
-  // against 14.8 with one step in flight (weight-gradient launches 52.8 us on average against 49.2,
-  // profiles/r03_wgrad_bf16_two_steps_in_flight.log): the loop is not waiting for more requests in flight.
-  // me_debug_set_wgrad_config(2, ..) selects it (bit-identical results, tests/test_gpu_bf16.py).
-  const bool deep = g_wgrad_depth == 2;
-  auto fn = deep ? &k_wgrad_bf16<NB, KSTEPS, true> : &k_wgrad_bf16<NB, KSTEPS, false>;
-  static bool attr_set[2] = {false, false};
-  if (lds > 32 * 1024 && !attr_set[deep]) {
+  const int lds = 2 * SP * ((16 * MB + kWgStepLd) + (64 * NB + kWgStepLd)) * 2;
+  auto fn = &k_wgrad_bf16<NB, KSTEPS, MB>;
+  static bool attr_set = false;   // per instantiation
+  if (lds > 32 * 1024 && !attr_set) {
     ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                kLdsBudget));
-    attr_set[deep] = true;
+    attr_set = true;
   }
   const dim3 grid((unsigned)g.ranges, (unsigned)g.n_cib, (unsigned)g.gz);
   hipLaunchKernelGGL(fn, grid, dim3(256), (size_t)lds, stream, x, c_in, dy, c_out, in_pairs,
@@ -2726,6 +2646,7 @@ int64_t me_conv_wgrad_workspace_bytes(const int64_t *k_offsets, int64_t volume, 
 }
 
 void me_debug_set_wgrad_order(int mode) { g_wgrad_order = mode; }
+void me_debug_set_wgrad_mb(int mb) { g_wgrad_mb = mb; }
 
 void me_debug_set_wgrad_config(int depth, int wgs_per_cu) {
   g_wgrad_depth = depth;
@@ -2804,9 +2725,12 @@ extern "C" {
 
 int64_t me_conv_wgrad_workspace_bytes_bf16(const int64_t *k_offsets, int64_t volume, int32_t c_in, int32_t c_out) {
   if (volume < 1 || c_in <= 0 || c_out <= 0) return 256;
-  // the larger of the two kernels' needs (channel counts that are not multiples of 8 take k_wgrad_f32<__bf16>)
-  const WgradGeom g = wgrad_geom_staged(k_offsets[volume], c_in, c_out);
-  const int64_t a = align_up((g.ranges + volume) * g.slot_floats * 4, 256);
+  // the larger of the kernels' needs (channel counts that are not multiples of 8 take k_wgrad_f32<__bf16>)
+  const WgradGeom g4 = wgrad_geom_staged(k_offsets[volume], c_in, c_out, 2, 4);
+  const WgradGeom g8 = wgrad_geom_staged(k_offsets[volume], c_in, c_out, 2, 8);
+  const int64_t a4 = align_up((g4.ranges + volume) * g4.slot_floats * 4, 256);
+  const int64_t a8 = align_up((g8.ranges + volume) * g8.slot_floats * 4, 256);
+  const int64_t a = a4 > a8 ? a4 : a8;
   const int64_t b = me_conv_wgrad_workspace_bytes(k_offsets, volume, c_in, c_out);
   return a > b ? a : b;
 }
@@ -2828,24 +2752,27 @@ int me_conv_wgrad_bf16(const uint16_t *x_, int64_t n_in, int32_t c_in, const uin
   ME_CHECK(volume >= 1 && volume <= 65535, "kernel volume out of range");
   ME_CHECK((uintptr_t)x % 16 == 0 && (uintptr_t)dy % 16 == 0, "feature pointers must be 16-byte aligned");
   const int64_t n_pairs = k_offsets[volume];
-  const WgradGeom g = wgrad_geom_staged(n_pairs, c_in, c_out);
+  const int mb = wgrad_bf16_mb(c_in, c_out);
+  const WgradGeom g = wgrad_geom_staged(n_pairs, c_in, c_out, 2, mb);
   float *partial = reinterpret_cast<float *>(workspace);
   if (n_pairs > 0) {
     int rc;
-#define ME_WG16(NBV, KSV)                                                                                      \
-  launch_wgrad_bf16<NBV, KSV>(g, x, c_in, dy, c_out, in_pairs, out_pairs, k_offsets_dev, (int)volume, n_pairs, \
-                              partial, stream)
-    if (g.nb == 1) rc = ME_WG16(1, 2);
-    else rc = ME_WG16(2, 2);
+#define ME_WG16(NBV, KSV, MBV)                                                                                      \
+  launch_wgrad_bf16<NBV, KSV, MBV>(g, x, c_in, dy, c_out, in_pairs, out_pairs, k_offsets_dev, (int)volume, n_pairs, \
+                                   partial, stream)
+    if (g.nb == 1) rc = ME_WG16(1, 2, 4);
+    else if (mb == 8) rc = ME_WG16(2, 2, 8);
+    else rc = ME_WG16(2, 2, 4);
 #undef ME_WG16
     if (rc != 0) return rc;
   }
   const dim3 rgrid((unsigned)ceil_div(g.slot_floats, 256), (unsigned)volume);
-#define ME_WGRAD_REDUCE_TR(NBV)                                                                               \
-  hipLaunchKernelGGL((k_wgrad_reduce<NBV, true>), rgrid, dim3(64 * kWgReducePhases), 0, stream, partial, k_offsets_dev, (int)volume, \
+#define ME_WGRAD_REDUCE_TR(NBV, MBV)                                                                               \
+  hipLaunchKernelGGL((k_wgrad_reduce<NBV, true, MBV>), rgrid, dim3(64 * kWgReducePhases), 0, stream, partial, k_offsets_dev, (int)volume, \
                      n_pairs > 0 ? n_pairs : 1, (int)g.ranges, g.n_cib, g.n_cob, c_in, c_out, grad_w)
-  if (g.nb == 1) ME_WGRAD_REDUCE_TR(1);
-  else ME_WGRAD_REDUCE_TR(2);
+  if (g.nb == 1) ME_WGRAD_REDUCE_TR(1, 4);
+  else if (mb == 8) ME_WGRAD_REDUCE_TR(2, 8);
+  else ME_WGRAD_REDUCE_TR(2, 4);
 #undef ME_WGRAD_REDUCE_TR
   ME_LAUNCH_CHECK();
   return 0;

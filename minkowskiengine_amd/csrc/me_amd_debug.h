@@ -30,14 +30,15 @@ void me_debug_set_bf16_deep(int deep);
  * slots 0-9 deep pipeline / 10-19 plain loop: barrier A, stage write + wait, barrier B, load issue, multiply, refill +
  * descriptors, prologue, epilogue (s_memtime cycles of wave 0 of every workgroup), batches, workgroups */
 int me_debug_bf16_timing(uint64_t *out20, int32_t reset);
-/* Weight-gradient kernels: depth 2 = k_wgrad_bf16 with two steps of rows in flight (round-3 experiment, bit-identical,
- * slower); depth 4 / 8 = prefetch ring depth of k_wgrad_f32 (steps of 4 pairs); depth -1 = bf16 rows
+/* Weight-gradient kernels: depth 4 / 8 = prefetch ring depth of k_wgrad_f32 (steps of 4 pairs); depth -1 = bf16 rows
  * through the fp32-MFMA kernel instead of k_wgrad_bf16; -2 = fp32 rows through the LDS-staged kernel; -3 / -4 = fp32
  * rows through the fp32-MFMA / the split kernel; wgs_per_cu = resident workgroups per CU the ranges are sized for;
  * 0 = shipped defaults. */
 void me_debug_set_wgrad_config(int depth, int wgs_per_cu);
 /* 0 (default): ranges of the same list fraction go to the same XCD (WgRangeOrder, conv.hip); -1: launch order */
 void me_debug_set_wgrad_order(int mode);
+/* k_wgrad_bf16: input-channel blocks of 16 per workgroup — 0 policy (8 where c_in >= 192 and c_out > 64), 4, 8 */
+void me_debug_set_wgrad_mb(int mb);
 
 #ifdef __cplusplus
 }
