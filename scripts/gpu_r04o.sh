@@ -1,7 +1,7 @@
 #!/bin/bash
 # last check of the round on the force-rebuilt libraries: full GPU suite, smoke, default line, MinkUNet34C bf16 line + stats
 set +e
-OUT=$PWD/gpurun_out/r03_final2
+OUT=$PWD/gpurun_out/r03_final3
 mkdir -p $OUT
 export TMPDIR=/tmp
 REPO=$PWD
