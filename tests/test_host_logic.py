@@ -127,3 +127,29 @@ def test_conv_statistics_registry_belongs_to_one_tensor_at_one_version():
     MEB.conv_bn_stats_hint(True)
     assert MEB._BN_STATS_HINT[0] is True
     MEB.conv_bn_stats_hint(False)
+
+
+def test_bf16_tile_shape_policy_is_the_documented_one():
+    """conv_variant_bf16 through its host-side queries (no GPU needed: the policy functions are plain host code): the
+    source-channel chunk per layer shape (256-channel chunks where a launch is at most two 128-column slabs
+    wide, 96 for 96 / 192-channel layers, else 32 / 64 / 128), the statistics epilogue for every default shape, packed
+    image sizes padded to the chunk, tile heights inside the ABI's range, and the library version of the header."""
+    import ctypes
+    import os
+    import re
+    from minkowskiengine_amd import _lib
+    lib = _lib.load()
+    want_kc = {(256, 256): 256, (96, 96): 96, (64, 128): 64, (128, 64): 128, (3, 32): 32, (8, 32): 32, (384, 256): 128,
+               (256, 384): 128, (192, 128): 96, (128, 96): 128, (32, 32): 32, (20, 24): 32, (128, 128): 128, (64, 64): 64}
+    for (cs, cd), kc in want_kc.items():
+        assert lib.me_conv_pack_chunk_bf16(cs, cd) == kc, (cs, cd)
+        assert lib.me_conv_stats_supported_bf16(cs, cd) == 1, (cs, cd)
+        pad = lambda v, m: -(-v // m) * m
+        assert lib.me_conv_packed_weight_elems_bf16(27, cs, cd) == 27 * pad(cs, kc) * pad(cd, 16)
+        t, g = ctypes.c_int32(), ctypes.c_int32()
+        assert lib.me_conv_plan_config_bf16(21176, 27, 223174, cs, cd, ctypes.byref(t), ctypes.byref(g)) == 0
+        assert 16 <= t.value <= 256 and 1 <= g.value <= 4
+    assert lib.me_conv_pack_chunk_bf16(0, 8) == 0 and lib.me_conv_stats_supported_bf16(0, 8) == 0
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "me_amd.h")).read()
+    latest = max(int(v) for v in re.findall(r"\((\d{3})\)\s+round", header))
+    assert lib.me_version() == latest
