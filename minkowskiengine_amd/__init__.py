@@ -13,7 +13,8 @@ from .backend import (  # noqa: F401
     BroadcastMode, ConvolutionMode, CoordinateMapType, GPUMemoryAllocatorType,
     MinkowskiAlgorithm, PoolingMode, RegionType, cuda_version, cudart_version, get_gpu_memory_info,
     is_cuda_available)
-from .host import CoordinateMapKey, get_host, is_native, set_host  # noqa: F401  (native C++ host layer | backend.py)
+from .host import (  # noqa: F401  (native C++ host layer | backend.py)
+    CoordinateMapKey, get_host, invalidate_packed_weights, is_native, set_host)
 from .common import convert_to_int_list, get_minkowski_function  # noqa: F401
 from .convolution import (  # noqa: F401
     MinkowskiConvolution, MinkowskiConvolutionFunction, MinkowskiConvolutionTranspose,
@@ -38,3 +39,21 @@ from .sparse_tensor import (  # noqa: F401
     global_coordinate_manager, set_global_coordinate_manager, set_sparse_tensor_operation_mode,
     sparse_tensor_operation_mode)
 from . import utils  # noqa: F401
+
+
+def _install_optimizer_hook():
+    """The weight-image cache is validated by tensor version counters, which writes through `p.data` do not bump
+    (Apex / DeepSpeed-style optimizers update that way).  Every torch.optim.Optimizer step therefore advances the
+    cache epoch: the first convolution after it repacks all images in one launch — which a training step does anyway.
+    ME_AMD_PACK_CACHE_HOOK=0 leaves the cache to the version counters alone."""
+    import os
+    if os.environ.get("ME_AMD_PACK_CACHE_HOOK", "1") == "0":
+        return
+    try:
+        from torch.optim.optimizer import register_optimizer_step_post_hook
+    except ImportError:  # pragma: no cover  (torch < 2.0)
+        return
+    register_optimizer_step_post_hook(lambda opt, args, kwargs: invalidate_packed_weights())
+
+
+_install_optimizer_hook()

@@ -1200,7 +1200,7 @@ _PACK_CACHE = os.environ.get("ME_AMD_PACK_CACHE", "1") != "0"   # "0": pack per 
 
 
 class _PackEntry:
-    __slots__ = ("ref", "ptr", "shape", "dtype", "mode", "transposed", "version", "packed", "job")
+    __slots__ = ("ref", "ptr", "shape", "dtype", "mode", "transposed", "version", "epoch", "packed", "job")
 
 
 class _WeightPacker:
@@ -1213,6 +1213,9 @@ class _WeightPacker:
     images whose weight has moved on are repacked together by me_conv_pack_weights_multi: in a training loop that is
     the first convolution after the optimizer step — one launch per step instead of two per layer (MinkUNet34C: 126),
     with the job table cached on the device while the set of stale images repeats.
+    The version counter does NOT see writes through `.data` (`p.data.add_(1)` leaves `p._version` alone): code that
+    updates weights that way calls `invalidate_packed_weights()`; the package does so itself after every
+    `torch.optim` step (global step post-hook, `__init__.py`).  An image is valid for (version, epoch).
     Entries hold only a weak reference to the weight: a temporary weight tensor (tests, functional calls) is packed
     per call as before.  Not for concurrent use of one layer from two streams (the image buffer is reused in place;
     stream order protects the previous step's launches)."""
@@ -1231,7 +1234,7 @@ class _WeightPacker:
         key = (kernel.data_ptr(), mode, bool(transposed))
         ent = self.entries.get(key)
         if ent is not None and self._alive(ent) and ent.shape == tuple(kernel.shape) and ent.dtype == kernel.dtype:
-            if ent.version == kernel._version:
+            if ent.version == kernel._version and ent.epoch == _PACK_EPOCH[0]:
                 return ent.packed
         else:
             import weakref
@@ -1244,7 +1247,7 @@ class _WeightPacker:
             anchor = base if (base is not None and base.data_ptr() == kernel.data_ptr() and
                               base.numel() == kernel.numel()) else kernel
             ent.ref, ent.ptr, ent.shape, ent.dtype = weakref.ref(anchor), kernel.data_ptr(), tuple(kernel.shape), kernel.dtype
-            ent.mode, ent.transposed, ent.version = mode, bool(transposed), None
+            ent.mode, ent.transposed, ent.version, ent.epoch = mode, bool(transposed), None, -1
             ent.packed = torch.empty(elems, dtype=torch.bfloat16, device=self.dev)
             job = _lib.MePackJob()
             job.w, job.wp, job.volume = ent.ptr, ent.packed.data_ptr(), int(kernel.shape[0])
@@ -1268,12 +1271,13 @@ class _WeightPacker:
             else:
                 _lib.check(lib.me_conv_pack_weights_f32x3(job.w, job.volume, job.c_src, job.c_dst, job.transposed,
                                                           job.wp, _stream(self.dev)))
-        ent.version = version
+        ent.version, ent.epoch = version, _PACK_EPOCH[0]
 
     def _repack_stale(self, wanted, kernel):
         # a NEW entry (first use of a weight tensor, or a temporary one — a padded / reshaped copy made per step) is
         # packed on its own, so that the set of established images — and with it the cached job table — repeats from
         # step to step
+        epoch = _PACK_EPOCH[0]
         if wanted.version is None:
             self._pack_one(wanted, kernel._version)
         stale = []
@@ -1281,12 +1285,15 @@ class _WeightPacker:
             if ent.version is None:
                 continue
             t = kernel if ent is wanted else ent.ref()
-            if t is not None and t.data_ptr() == ent.ptr and t._version != ent.version:
+            if t is not None and t.data_ptr() == ent.ptr and (t._version != ent.version or ent.epoch != epoch):
                 stale.append((ent, t._version))
         if not stale:
             return
-        if len(stale) > 1024:
-            stale = stale[-1024:]
+        if len(stale) > 1024:       # (the wanted image is never the one that is dropped)
+            keep = stale[-1024:]
+            if not any(e is wanted for e, _ in keep):
+                keep[0:1] = [s for s in stale if s[0] is wanted][:1] or keep[0:1]
+            stale = keep
         lib = _lib.load()
         if len(stale) == 1:
             self._pack_one(stale[0][0], stale[0][1])
@@ -1305,10 +1312,18 @@ class _WeightPacker:
             _lib.check(lib.me_conv_pack_weights_multi(jb.data_ptr(), len(stale), pf.data_ptr(), total,
                                                       _stream(self.dev)))
         for e, v in stale:
-            e.version = v
+            e.version, e.epoch = v, epoch
 
 
 _PACKERS = {}
+_PACK_EPOCH = [0]
+
+
+def invalidate_packed_weights():
+    """Every cached weight image is repacked at its next use.  For weight updates the tensor version counter cannot
+    see — writes through `p.data` (Apex / DeepSpeed-style optimizers, EMA, clipping); in-place operations on the
+    parameter itself (`with torch.no_grad(): p.add_(...)`, `copy_`, torch.optim) are seen without it."""
+    _PACK_EPOCH[0] += 1
 
 
 def _packed_weights(kernel, mode, transposed, c_src, c_dst, elems):
@@ -1862,13 +1877,35 @@ def _bn_partials_take(x):
     return part, tile_rows
 
 
+def _bn_stat_ok(t, c):
+    return t is None or (t.is_cuda and t.is_contiguous() and t.dtype == torch.float32 and t.numel() == c)
+
+
+def _bn_check_vec(name, t, c):
+    _check(_bn_stat_ok(t, c), f"{name} must be a contiguous float32 GPU vector of one value per channel")
+
+
 def bn_stats(x, eps, momentum, running_mean=None, running_var=None, num_batches_tracked=None):
     """-> (mean, rstd) float32 [c] of the batch; running statistics updated in place when given (and the int64
-    num_batches_tracked buffer incremented by the same kernel)."""
+    num_batches_tracked buffer incremented by the same kernel).  The kernels read and write the running statistics as
+    float32 [c]: buffers of another dtype / layout (bf16 after `model.bfloat16()`) go through float32 temporaries
+    that are copied back, a counter that is not an int64 GPU scalar is incremented by torch."""
     _bn_check(x)
     lib = _lib.load()
     dev = x.device
     n, c = int(x.shape[0]), int(x.shape[1])
+    _check((running_mean is None) == (running_var is None), "running_mean and running_var: both or none")
+    _check(running_mean is None or (running_mean.numel() == c and running_var.numel() == c),
+           "running statistics must hold one value per channel")
+    rm_user, rv_user = running_mean, running_var
+    direct = _bn_stat_ok(running_mean, c) and _bn_stat_ok(running_var, c)
+    if not direct:
+        running_mean = rm_user.to(device=dev, dtype=torch.float32).contiguous().clone()
+        running_var = rv_user.to(device=dev, dtype=torch.float32).contiguous().clone()
+    if num_batches_tracked is not None and not (num_batches_tracked.is_cuda and num_batches_tracked.dtype == torch.int64
+                                                and num_batches_tracked.numel() == 1):
+        num_batches_tracked.add_(1)
+        num_batches_tracked = None
     mean = torch.empty(c, dtype=torch.float32, device=dev)
     rstd = torch.empty(c, dtype=torch.float32, device=dev)
     got = _bn_partials_take(x)
@@ -1878,17 +1915,28 @@ def bn_stats(x, eps, momentum, running_mean=None, running_var=None, num_batches_
             _lib.check(lib.me_bn_stats_from_tiles(part[0].data_ptr(), part[1].data_ptr(), n, c, tile_rows, float(eps),
                                                   float(momentum), _ptr(mean), _ptr(rstd), _ptr(running_mean),
                                                   _ptr(running_var), _ptr(num_batches_tracked), _stream(dev)))
-        return mean, rstd
-    ws = _workspace(int(lib.me_bn_workspace_bytes(n, c)), dev)
-    with _on(dev):
-        _lib.check(lib.me_bn_stats(_ptr(x), 1 if x.dtype == torch.bfloat16 else 0, n, c, float(eps),
-                                   float(momentum), _ptr(mean), _ptr(rstd), _ptr(running_mean), _ptr(running_var),
-                                   _ptr(num_batches_tracked), _ptr(ws), ws.numel(), _stream(dev)))
+    else:
+        ws = _workspace(int(lib.me_bn_workspace_bytes(n, c)), dev)
+        with _on(dev):
+            _lib.check(lib.me_bn_stats(_ptr(x), 1 if x.dtype == torch.bfloat16 else 0, n, c, float(eps),
+                                       float(momentum), _ptr(mean), _ptr(rstd), _ptr(running_mean), _ptr(running_var),
+                                       _ptr(num_batches_tracked), _ptr(ws), ws.numel(), _stream(dev)))
+    if not direct:
+        rm_user.copy_(running_mean)
+        rv_user.copy_(running_var)
     return mean, rstd
+
+
+def _bn_check_params(x, mean, rstd, gamma, beta):
+    c = int(x.shape[1])
+    _check(mean is not None and rstd is not None, "batch norm needs mean and rstd")
+    for name, t in (("mean", mean), ("rstd", rstd), ("gamma", gamma), ("beta", beta)):
+        _bn_check_vec(name, t, c)
 
 
 def bn_apply(x, mean, rstd, gamma, beta, relu=False):
     _bn_check(x)
+    _bn_check_params(x, mean, rstd, gamma, beta)
     lib = _lib.load()
     dev = x.device
     y = torch.empty_like(x)
@@ -1903,6 +1951,7 @@ def bn_apply_residual(x, skip, mean, rstd, gamma, beta, relu=True):
     """y = [relu] (bn(x) + skip): batch-norm apply, residual addition and ReLU of a ResNet block in one pass
     (bit-identical to the three separate kernels)."""
     _bn_check(x)
+    _bn_check_params(x, mean, rstd, gamma, beta)
     _check(skip.shape == x.shape and skip.dtype == x.dtype and skip.is_contiguous(), "residual branch must match x")
     lib = _lib.load()
     dev = x.device
@@ -1918,6 +1967,7 @@ def bn_backward_residual(x, dy, yout, mean, rstd, gamma, beta=None, relu=True, n
     """-> (dx, dskip, grad_gamma, grad_beta) of y = [relu] (bn(x) + skip); dskip is the (ReLU-masked) incoming
     gradient, dy itself without ReLU."""
     _bn_check(x)
+    _bn_check_params(x, mean, rstd, gamma, beta)
     lib = _lib.load()
     dev = x.device
     n, c = int(x.shape[0]), int(x.shape[1])
@@ -1940,6 +1990,7 @@ def bn_backward_residual(x, dy, yout, mean, rstd, gamma, beta=None, relu=True, n
 def bn_backward(x, dy, mean, rstd, gamma, beta=None, relu=False):
     """-> (dx, grad_gamma, grad_beta) of training-mode batch norm (followed by a fused ReLU when `relu`)."""
     _bn_check(x)
+    _bn_check_params(x, mean, rstd, gamma, beta)
     lib = _lib.load()
     dev = x.device
     n, c = int(x.shape[0]), int(x.shape[1])

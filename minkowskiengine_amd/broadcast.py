@@ -18,7 +18,7 @@ class MinkowskiBroadcastFunction(Function):
         input_features_global = input_features_global.contiguous()
         ctx.saved_vars = (input_features, input_features_global, operation_type, in_coords_key, glob_coords_key,
                           coords_manager)
-        fw_fn = get_minkowski_function("BroadcastForward", input_features)
+        fw_fn = get_minkowski_function("BroadcastForward", input_features, in_coords_key)
         return fw_fn(input_features, input_features_global, operation_type, in_coords_key, glob_coords_key,
                      coords_manager._manager)
 
@@ -27,7 +27,7 @@ class MinkowskiBroadcastFunction(Function):
         if not grad_out_feat.is_contiguous():
             grad_out_feat = grad_out_feat.contiguous()
         input_features, input_features_global, operation_type, in_key, glob_key, coords_manager = ctx.saved_vars
-        bw_fn = get_minkowski_function("BroadcastBackward", grad_out_feat)
+        bw_fn = get_minkowski_function("BroadcastBackward", grad_out_feat, in_key)
         grad_in_feat, grad_in_feat_glob = bw_fn(input_features, input_features_global, grad_out_feat,
                                                 operation_type, in_key, glob_key, coords_manager._manager)
         return grad_in_feat, grad_in_feat_glob, None, None, None, None

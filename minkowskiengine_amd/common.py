@@ -24,11 +24,12 @@ def get_postfix(tensor):
     return "GPU" if tensor.is_cuda else "CPU"
 
 
-def get_minkowski_function(name, variable):
+def get_minkowski_function(name, variable, owner=None):
     """Resolve `<Op>{GPU,CPU}` in the backend by device, as MinkowskiCommon.py:110-120 does.
-    Only the GPU (MI355X) entries exist."""
+    Only the GPU (MI355X) entries exist.  `owner` (a coordinate map key or manager of the call): the operator comes
+    from the host layer that made it — objects made under one host keep working after set_host()."""
     fn_name = name + get_postfix(variable)
-    fn = getattr(_host.backend(), fn_name, None)
+    fn = getattr(_host.backend_of(owner) if owner is not None else _host.backend(), fn_name, None)
     if fn is None:
         raise ValueError(
             f"Function {fn_name} not available: minkowskiengine_amd implements the MI355X (GPU) path only; "

@@ -9,7 +9,8 @@ import torch
 from torch.autograd import Function
 from torch.nn import Module, Parameter
 
-from .backend import ConvolutionMode, CoordinateMapKey, RegionType
+from . import host as _host
+from .backend import ConvolutionMode, CoordinateMapKey, RegionType  # noqa: F401
 from .common import get_minkowski_function
 from .kernel_generator import KernelGenerator
 from .sparse_tensor import SparseTensor, _get_coordinate_map_key
@@ -42,7 +43,6 @@ def _conv_apply(conv_fn, is_transpose, feats, kernel, kernel_generator, convolut
     # (a training-mode batch norm may follow: bf16 forward launches then leave their tiles' statistics behind)
     want_stats = bool(training) and feats.dtype == torch.bfloat16
     if getattr(manager, "_native", False):
-        from . import host as _host
         _host.native_module().conv_bn_stats_hint(want_stats)
         return _host.native_module().conv_autograd(
             feats, kernel, kernel_generator.kernel_size, kernel_generator.kernel_stride, kernel_generator.kernel_dilation,
@@ -58,13 +58,13 @@ class MinkowskiConvolutionFunction(Function):
     def forward(ctx, input_features, kernel_weights, kernel_generator, convolution_mode, in_coordinate_map_key,
                 out_coordinate_map_key=None, coordinate_manager=None):
         if out_coordinate_map_key is None:
-            out_coordinate_map_key = CoordinateMapKey(in_coordinate_map_key.get_coordinate_size())
+            out_coordinate_map_key = _host.key_like(in_coordinate_map_key)
         input_features = input_features.contiguous()
         ctx.input_features = input_features
         ctx.kernel_weights = kernel_weights
         ctx.misc = (kernel_generator, convolution_mode, in_coordinate_map_key, out_coordinate_map_key,
                     coordinate_manager)
-        fw_fn = get_minkowski_function("ConvolutionForward", input_features)
+        fw_fn = get_minkowski_function("ConvolutionForward", input_features, in_coordinate_map_key)
         return fw_fn(input_features, kernel_weights, kernel_generator.kernel_size, kernel_generator.kernel_stride,
                      kernel_generator.kernel_dilation, kernel_generator.region_type,
                      kernel_generator.region_offsets, kernel_generator.expand_coordinates, convolution_mode,
@@ -74,7 +74,7 @@ class MinkowskiConvolutionFunction(Function):
     def backward(ctx, grad_out_feat):
         grad_out_feat = grad_out_feat.contiguous()
         kernel_generator, convolution_mode, in_key, out_key, coordinate_manager = ctx.misc
-        bw_fn = get_minkowski_function("ConvolutionBackward", grad_out_feat)
+        bw_fn = get_minkowski_function("ConvolutionBackward", grad_out_feat, in_key)
         # (not in the reference: the input gradient is skipped when autograd does not ask for it — the first layer
         # of a network, whose input features are data)
         grad_in_feat, grad_kernel = bw_fn(ctx.input_features, grad_out_feat, ctx.kernel_weights,
@@ -90,13 +90,13 @@ class MinkowskiConvolutionTransposeFunction(Function):
     def forward(ctx, input_features, kernel_weights, kernel_generator, convolution_mode, in_coordinate_map_key,
                 out_coordinate_map_key=None, coordinate_manager=None):
         if out_coordinate_map_key is None:
-            out_coordinate_map_key = CoordinateMapKey(in_coordinate_map_key.get_coordinate_size())
+            out_coordinate_map_key = _host.key_like(in_coordinate_map_key)
         input_features = input_features.contiguous()
         ctx.input_features = input_features
         ctx.kernel_weights = kernel_weights
         ctx.misc = (kernel_generator, convolution_mode, in_coordinate_map_key, out_coordinate_map_key,
                     coordinate_manager)
-        fw_fn = get_minkowski_function("ConvolutionTransposeForward", input_features)
+        fw_fn = get_minkowski_function("ConvolutionTransposeForward", input_features, in_coordinate_map_key)
         return fw_fn(input_features, kernel_weights, kernel_generator.kernel_size, kernel_generator.kernel_stride,
                      kernel_generator.kernel_dilation, kernel_generator.region_type,
                      kernel_generator.region_offsets, kernel_generator.expand_coordinates, convolution_mode,
@@ -106,7 +106,7 @@ class MinkowskiConvolutionTransposeFunction(Function):
     def backward(ctx, grad_out_feat):
         grad_out_feat = grad_out_feat.contiguous()
         kernel_generator, convolution_mode, in_key, out_key, coordinate_manager = ctx.misc
-        bw_fn = get_minkowski_function("ConvolutionTransposeBackward", grad_out_feat)
+        bw_fn = get_minkowski_function("ConvolutionTransposeBackward", grad_out_feat, in_key)
         grad_in_feat, grad_kernel = bw_fn(ctx.input_features, grad_out_feat, ctx.kernel_weights,
                                           kernel_generator.kernel_size, kernel_generator.kernel_stride,
                                           kernel_generator.kernel_dilation, kernel_generator.region_type,
@@ -152,13 +152,16 @@ class MinkowskiConvolutionBase(MinkowskiModuleBase):
         if self.use_mm:
             # kernel volume 1, stride 1: out = F @ W on the same coordinate map (MinkowskiConvolution.py:304-308).
             out_coordinate_map_key = input.coordinate_map_key
-            if _MM_AS_CONV and not self.is_transpose and input.F.is_cuda and input.F.shape[0] > 0:
-                # run it as a one-offset convolution on this package's kernels: rocBLAS / hipBLASLt pick slow
-                # kernels for the skinny products of a segmentation head (200k x 96 @ 96 x 20 took 325 us)
+            if _MM_AS_CONV and input.F.is_cuda and input.F.shape[0] > 0:
+                # run it as a one-offset convolution on this package's kernels (no vendor BLAS on the path; rocBLAS /
+                # hipBLASLt also pick slow kernels for the skinny products of a segmentation head: 200k x 96 @ 96 x 20
+                # took 325 us).  A transposed 1x1 stride-1 layer is the same product on the same map, so it takes
+                # the non-transposed operator too.
                 feats, kernel, cpad = _pad_channels(input.F, self.kernel.unsqueeze(0), self.in_channels,
                                                     self.out_channels)
-                outfeat = _conv_apply(self.conv, False, feats, kernel, self.kernel_generator, self.convolution_mode,
-                                      input.coordinate_map_key, out_coordinate_map_key, input._manager, self.training)
+                outfeat = _conv_apply(MinkowskiConvolutionFunction, False, feats, kernel, self.kernel_generator,
+                                      self.convolution_mode, input.coordinate_map_key, out_coordinate_map_key,
+                                      input._manager, self.training)
                 if cpad is not None:
                     outfeat = outfeat[:, :self.out_channels].contiguous()
             else:
@@ -184,9 +187,9 @@ class MinkowskiConvolutionBase(MinkowskiModuleBase):
         with torch.no_grad():
             n = (self.out_channels if is_transpose else self.in_channels) * self.kernel_generator.kernel_volume
             stdv = 1.0 / math.sqrt(n)
-            self.kernel.data.uniform_(-stdv, stdv)
-            if self.bias is not None:
-                self.bias.data.uniform_(-stdv, stdv)
+            self.kernel.uniform_(-stdv, stdv)      # (in place on the parameter itself: bumps its version counter,
+            if self.bias is not None:              #  which validates the packed weight images; `.data` would not)
+                self.bias.uniform_(-stdv, stdv)
 
     def __repr__(self):
         s = f"(in={self.in_channels}, out={self.out_channels}, "

@@ -113,7 +113,7 @@ class CoordinateManager:
     def get_coordinates(self, coords_key_or_tensor_strides):
         key = coords_key_or_tensor_strides
         if not isinstance(key, CoordinateMapKey):
-            key = CoordinateMapKey(convert_to_int_list(key, self.D), "")
+            key = _host.key_like(self, convert_to_int_list(key, self.D), "")
         return self._manager.get_coordinates(key)
 
     def origin(self):
@@ -137,7 +137,7 @@ class CoordinateManager:
     def get_unique_coordinate_map_key(self, tensor_stride):
         ts = convert_to_int_list(tensor_stride, self.D)
         sid = self._manager.get_random_string_id(ts, "")
-        return CoordinateMapKey(sid[0], sid[1])
+        return _host.key_like(self, sid[0], sid[1])
 
     def get_coordinate_map_keys(self, tensor_stride):
         return self._manager.get_coordinate_map_keys(convert_to_int_list(tensor_stride, self.D))

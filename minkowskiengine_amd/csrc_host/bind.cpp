@@ -153,6 +153,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
 
   m.def("conv_bn_stats_hint", &conv_bn_stats_hint, py::arg("flag"));
   m.def("set_conv_bn_stats", &set_conv_bn_stats, py::arg("enabled"));
+  m.def("invalidate_packed_weights", &invalidate_packed_weights);
   m.def("timing_enable", &timing_enable);
   m.def("timing_records", &timing_records, py::arg("clear") = true);
   m.def("is_cuda_available", [] { return true; });

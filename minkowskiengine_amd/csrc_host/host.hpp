@@ -271,5 +271,7 @@ std::vector<std::tuple<std::string, double, double>> timing_records(bool clear);
 
 // packed weight images cached per (weight tensor, direction) — C++ twin of backend._WeightPacker
 Tensor packed_weights(const Tensor &kernel, int mode, bool transposed, int c_src, int c_dst, int64_t elems);
+// every cached image is repacked at its next use: for weight updates the version counter cannot see (`p.data` writes)
+void invalidate_packed_weights();
 
 }  // namespace meh

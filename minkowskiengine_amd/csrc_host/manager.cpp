@@ -797,8 +797,9 @@ int64_t CoordinateMapManager::prefetch(const std::vector<std::string> &recipe) {
   // copies of the per-offset prefixes, no read-back apart from the n_unique of each strided map), THEN the tile plans
   // and weight-gradient geometries, which need the pair counts on the host: by then every prefix copy is in flight
   // and the first wait covers them all — one drain of the queue per scene instead of one per layer.
+  // (The replay logs every request it serves exactly once, on its cache miss — as the layers would have — and requests
+  // that hit log nothing: the manager's own recipe stays complete, so the NEXT scene can be prefetched from this one.)
   int64_t done = 0;
-  const std::vector<std::string> saved = *recipe_log;   // (the replay must not double the log)
   std::vector<std::pair<std::shared_ptr<KernelMap>, std::vector<std::string>>> cfgs;
   for (const std::string &line : recipe) {
     const auto f = split(line, ';');
@@ -834,7 +835,6 @@ int64_t CoordinateMapManager::prefetch(const std::vector<std::string> &recipe) {
     }
     ++done;
   }
-  *recipe_log = saved;
   return done;
 }
 

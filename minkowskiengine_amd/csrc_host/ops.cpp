@@ -6,6 +6,8 @@
 #include <c10/util/intrusive_ptr.h>
 #include <hip/hip_runtime_api.h>
 
+#include <algorithm>
+#include <atomic>
 #include <mutex>
 
 namespace meh {
@@ -27,6 +29,7 @@ struct PackEntry {
   std::vector<int64_t> shape;
   at::ScalarType dtype = at::kFloat;
   int64_t version = -1;
+  int64_t epoch = -1;          // g_pack_epoch at pack time (invalidate_packed_weights)
   bool packed_once = false;
   Tensor packed;
   me_pack_job job;
@@ -41,6 +44,12 @@ struct Packer {
   std::vector<std::shared_ptr<PackEntry>> table_entries;
 };
 std::map<int, Packer> g_packers;
+// The version counter does not see writes through `.data` (p.data.add_(1) leaves p._version alone): optimizers and
+// utilities that update weights that way (Apex / DeepSpeed style, EMA, clipping) call invalidate_packed_weights(), and
+// the package does so itself after every torch.optim step (a global step post-hook, __init__.py).  An image is valid
+// for (version, epoch); the epoch only grows.  Backward runs on autograd worker threads: one mutex for the packers.
+std::atomic<int64_t> g_pack_epoch{0};
+std::mutex g_packers_mu;
 
 // version counter and liveness of the tensor an entry was made for (a full view is anchored at its base)
 bool entry_alive(const PackEntry &e, int64_t *version) {
@@ -65,8 +74,12 @@ void pack_one(PackEntry &e, const c10::Device &dev) {
 }
 }  // namespace
 
+void invalidate_packed_weights() { g_pack_epoch.fetch_add(1); }
+
 Tensor packed_weights(const Tensor &kernel, int mode, bool transposed, int c_src, int c_dst, int64_t elems) {
   const c10::Device dev = kernel.device();
+  std::lock_guard<std::mutex> lk(g_packers_mu);
+  const int64_t epoch = g_pack_epoch.load();
   Packer &pk = g_packers[dev.index()];
   const PackKey key(kernel.data_ptr(), mode, transposed);
   const int64_t cur_version = (int64_t)kernel.unsafeGetTensorImpl()->version_counter().current_version();
@@ -76,7 +89,7 @@ Tensor packed_weights(const Tensor &kernel, int mode, bool transposed, int c_src
   if (it != pk.entries.end() && entry_alive(*it->second, &v) && it->second->shape == kernel.sizes().vec() &&
       it->second->dtype == kernel.scalar_type()) {
     ent = it->second;
-    if (ent->packed_once && ent->version == cur_version) return ent->packed;
+    if (ent->packed_once && ent->version == cur_version && ent->epoch == epoch) return ent->packed;
   } else {
     if (pk.entries.size() > 4096) {
       for (auto i = pk.entries.begin(); i != pk.entries.end();) {
@@ -114,6 +127,7 @@ Tensor packed_weights(const Tensor &kernel, int mode, bool transposed, int c_src
     pack_one(*ent, dev);
     ent->packed_once = true;
     ent->version = cur_version;
+    ent->epoch = epoch;
   }
   std::vector<std::pair<std::shared_ptr<PackEntry>, int64_t>> stale;
   for (auto &kv : pk.entries) {
@@ -122,13 +136,19 @@ Tensor packed_weights(const Tensor &kernel, int mode, bool transposed, int c_src
     int64_t ev = 0;
     if (kv.second == ent) ev = cur_version;
     else if (!entry_alive(e, &ev)) continue;
-    if (ev != e.version) stale.push_back({kv.second, ev});
+    if (ev != e.version || e.epoch != epoch) stale.push_back({kv.second, ev});
   }
   if (stale.empty()) return ent->packed;
-  if (stale.size() > 1024) stale.erase(stale.begin(), stale.end() - 1024);
+  if (stale.size() > 1024) {   // (the wanted image is never the one that is dropped)
+    const bool wanted_stale = ent->version != cur_version || ent->epoch != epoch;
+    stale.erase(stale.begin(), stale.end() - 1024);
+    if (wanted_stale && std::none_of(stale.begin(), stale.end(), [&](auto &s) { return s.first == ent; }))
+      stale.front() = {ent, cur_version};
+  }
   if (stale.size() == 1) {
     pack_one(*stale[0].first, dev);
     stale[0].first->version = stale[0].second;
+    stale[0].first->epoch = epoch;
     return ent->packed;
   }
   std::vector<PackEntry *> tk;
@@ -154,7 +174,10 @@ Tensor packed_weights(const Tensor &kernel, int mode, bool transposed, int c_src
     me_ok(me_conv_pack_weights_multi((const me_pack_job *)pk.table_jobs.data_ptr(), (int)stale.size(),
                                      ptr<int64_t>(pk.table_prefix), pk.table_total, stream_of(dev)));
   }
-  for (auto &s : stale) s.first->version = s.second;
+  for (auto &s : stale) {
+    s.first->version = s.second;
+    s.first->epoch = epoch;
+  }
   return ent->packed;
 }
 
@@ -679,12 +702,40 @@ static void bn_check(const Tensor &x) {
   check(x.size(0) > 0, "batch norm needs at least one row");
 }
 
-std::pair<Tensor, Tensor> bn_stats(const Tensor &x, double eps, double momentum, const Tensor &running_mean,
-                                   const Tensor &running_var, const Tensor &num_batches_tracked) {
+// The kernels read and write the running statistics as float32 [c] and the batch counter as int64 (norm.hip).  Buffers
+// of another dtype / layout (after `model.bfloat16()` the running statistics are bf16: c floats written into a 2c-byte
+// buffer would corrupt its neighbours) go through float32 temporaries that are copied back; a counter that is not an
+// int64 GPU scalar is incremented by torch.
+static bool bn_stat_ok(const Tensor &t, int c) {
+  return !t.defined() || (t.is_cuda() && t.is_contiguous() && t.scalar_type() == at::kFloat && t.numel() == c);
+}
+
+static void bn_check_vec(const char *name, const Tensor &t, int c) {
+  check(!t.defined() || (t.is_cuda() && t.is_contiguous() && t.scalar_type() == at::kFloat && t.numel() == c),
+        std::string(name) + " must be a contiguous float32 GPU vector of one value per channel");
+}
+
+std::pair<Tensor, Tensor> bn_stats(const Tensor &x, double eps, double momentum, const Tensor &running_mean_,
+                                   const Tensor &running_var_, const Tensor &num_batches_tracked_) {
   bn_check(x);
   const c10::Device dev = x.device();
   const int64_t n = x.size(0);
   const int c = (int)x.size(1);
+  check(running_mean_.defined() == running_var_.defined(), "running_mean and running_var: both or none");
+  check(!running_mean_.defined() || (running_mean_.numel() == c && running_var_.numel() == c),
+        "running statistics must hold one value per channel");
+  const bool direct = bn_stat_ok(running_mean_, c) && bn_stat_ok(running_var_, c);
+  Tensor running_mean = running_mean_, running_var = running_var_;
+  if (!direct) {
+    running_mean = running_mean_.to(dev, at::kFloat).contiguous().clone();
+    running_var = running_var_.to(dev, at::kFloat).contiguous().clone();
+  }
+  Tensor num_batches_tracked = num_batches_tracked_;
+  if (num_batches_tracked.defined() &&
+      !(num_batches_tracked.is_cuda() && num_batches_tracked.scalar_type() == at::kLong && num_batches_tracked.numel() == 1)) {
+    num_batches_tracked_.add_(1);
+    num_batches_tracked = Tensor();
+  }
   Tensor mean = at::empty({c}, at::TensorOptions().dtype(at::kFloat).device(dev));
   Tensor rstd = at::empty({c}, at::TensorOptions().dtype(at::kFloat).device(dev));
   c10::DeviceGuard guard(dev);
@@ -695,12 +746,16 @@ std::pair<Tensor, Tensor> bn_stats(const Tensor &x, double eps, double momentum,
     me_ok(me_bn_stats_from_tiles(ptr<float>(part), ptr<float>(part) + tiles * c, n, c, tile_rows, (float)eps,
                                  (float)momentum, ptr<float>(mean), ptr<float>(rstd), ptr<float>(running_mean),
                                  ptr<float>(running_var), ptr<int64_t>(num_batches_tracked), stream_of(dev)));
-    return {mean, rstd};
+  } else {
+    Tensor ws = workspace(me_bn_workspace_bytes(n, c), dev);
+    me_ok(me_bn_stats(x.data_ptr(), x.scalar_type() == at::kBFloat16 ? 1 : 0, n, c, (float)eps, (float)momentum,
+                      ptr<float>(mean), ptr<float>(rstd), ptr<float>(running_mean), ptr<float>(running_var),
+                      ptr<int64_t>(num_batches_tracked), vptr(ws), ws.numel(), stream_of(dev)));
   }
-  Tensor ws = workspace(me_bn_workspace_bytes(n, c), dev);
-  me_ok(me_bn_stats(x.data_ptr(), x.scalar_type() == at::kBFloat16 ? 1 : 0, n, c, (float)eps, (float)momentum,
-                    ptr<float>(mean), ptr<float>(rstd), ptr<float>(running_mean), ptr<float>(running_var),
-                    ptr<int64_t>(num_batches_tracked), vptr(ws), ws.numel(), stream_of(dev)));
+  if (!direct) {
+    running_mean_.copy_(running_mean);
+    running_var_.copy_(running_var);
+  }
   return {mean, rstd};
 }
 
@@ -708,6 +763,12 @@ Tensor bn_apply(const Tensor &x, const Tensor &mean, const Tensor &rstd, const T
                 bool relu, const Tensor &skip) {
   bn_check(x);
   const c10::Device dev = x.device();
+  const int cc = (int)x.size(1);
+  bn_check_vec("mean", mean, cc);
+  bn_check_vec("rstd", rstd, cc);
+  bn_check_vec("gamma", gamma, cc);
+  bn_check_vec("beta", beta, cc);
+  check(mean.defined() && rstd.defined(), "batch norm needs mean and rstd");
   Tensor y = at::empty_like(x);
   c10::DeviceGuard guard(dev);
   const int bf = x.scalar_type() == at::kBFloat16 ? 1 : 0;
@@ -731,6 +792,11 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> bn_backward(const Tensor &x, Tensor d
   const c10::Device dev = x.device();
   const int64_t n = x.size(0);
   const int c = (int)x.size(1);
+  bn_check_vec("mean", mean, c);
+  bn_check_vec("rstd", rstd, c);
+  bn_check_vec("gamma", gamma, c);
+  bn_check_vec("beta", beta, c);
+  check(mean.defined() && rstd.defined(), "batch norm backward needs mean and rstd");
   if (dy.scalar_type() != x.scalar_type()) dy = dy.to(x.scalar_type());
   dy = dy.contiguous();
   Tensor dx = at::empty_like(x);

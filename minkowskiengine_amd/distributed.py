@@ -62,10 +62,15 @@ def shard_scenes(n_scenes, rank, world):
 def broadcast_parameters(module, src=0):
     if world_size() == 1:
         return
-    for p in module.parameters():
-        dist.broadcast(p.data, src=src)
-    for b in module.buffers():
-        dist.broadcast(b.data, src=src)
+    # (p.detach() shares p's version counter, `p.data` does not: the weight-image cache of the convolutions is keyed
+    # by it, so a broadcast into `.data` would leave stale packed weights on the receiving ranks)
+    with torch.no_grad():
+        for p in module.parameters():
+            dist.broadcast(p.detach(), src=src)
+        for b in module.buffers():
+            dist.broadcast(b.detach(), src=src)
+    from .host import invalidate_packed_weights
+    invalidate_packed_weights()
 
 
 def data_parallel(module, device=None, bucket_cap_mb=25, sync_batchnorm=False):

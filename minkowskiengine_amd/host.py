@@ -49,6 +49,11 @@ if _mode not in ("auto", "native", "python"):
 if _mode == "native" and native_module() is None:
     raise RuntimeError(f"ME_AMD_HOST=native but the native host layer is not available: {native_error()}")
 _current = "native" if (_mode != "python" and native_module() is not None) else "python"
+if _mode == "auto" and _current == "python":
+    import warnings
+    warnings.warn("minkowskiengine_amd: the native host layer (_me_host.so) is not available — "
+                  f"{native_error()} — falling back to the slower Python host (ME_AMD_HOST=python silences this, "
+                  "ME_AMD_HOST=native makes it an error)", RuntimeWarning, stacklevel=2)
 
 
 def get_host():
@@ -71,6 +76,34 @@ def is_native():
 def backend():
     """the operator module in charge: the native extension or minkowskiengine_amd.backend"""
     return _native if _current == "native" else _python_backend
+
+
+def backend_of(obj):
+    """The operator module that OWNS `obj` — a coordinate map key, a native / Python manager or the CoordinateManager
+    wrapper of either: objects stay with the host they were made under, whatever set_host() says now."""
+    if obj is not None:
+        flag = getattr(obj, "_native", None)          # CoordinateManager wrapper (coordinate_manager.py)
+        if isinstance(flag, bool):
+            return _native if flag else _python_backend
+        if _native is not None and isinstance(obj, (_native.CoordinateMapKey, _native.CoordinateMapManagerGPU_c10)):
+            return _native
+        if isinstance(obj, (_python_backend.CoordinateMapKey, _python_backend.CoordinateMapManagerGPU_c10)):
+            return _python_backend
+    return backend()
+
+
+def key_like(key, *args):
+    """A new CoordinateMapKey of the host that owns `key`: (coordinate size of `key`) by default, or the given
+    constructor arguments."""
+    return backend_of(key).CoordinateMapKey(*(args if args else (key.get_coordinate_size(),)))
+
+
+def invalidate_packed_weights():
+    """Repack every cached weight image (both hosts) at its next use: for weight updates the tensor version counter
+    cannot see, i.e. writes through `p.data`.  Called by the package after every torch.optim step."""
+    _python_backend.invalidate_packed_weights()
+    if _native is not None:
+        _native.invalidate_packed_weights()
 
 
 def _key_types():

@@ -119,12 +119,15 @@ class MinkowskiBatchNorm(nn.Module):
             return out
         else:
             # evaluation: an affine map per channel, differentiable through torch (cheap: two fused passes)
-            rstd = torch.rsqrt(bn.running_var + bn.eps)
+            # (the kernels take float32 vectors: after `model.bfloat16()` the running statistics are bf16)
+            rmean = bn.running_mean.float().contiguous()
+            rstd = torch.rsqrt(bn.running_var.float() + bn.eps).contiguous()
             a = rstd * bn.weight.float() if bn.weight is not None else rstd
-            b = (bn.bias.float() if bn.bias is not None else 0.0) - bn.running_mean * a
+            b = (bn.bias.float() if bn.bias is not None else 0.0) - rmean * a
             y = (f * a.to(f.dtype) + b.to(f.dtype)) if f.requires_grad else \
-                MEB.bn_apply(f.contiguous(), bn.running_mean, rstd, bn.weight.float() if bn.weight is not None else None,
-                             bn.bias.float() if bn.bias is not None else None)
+                MEB.bn_apply(f.contiguous(), rmean, rstd,
+                             bn.weight.float().contiguous() if bn.weight is not None else None,
+                             bn.bias.float().contiguous() if bn.bias is not None else None)
         return _rewrap(input, y)
 
     def forward_residual(self, input, skip, relu=True):

@@ -6,7 +6,8 @@ from torch.autograd import Function
 from torch.nn import Module
 
 from .backend import PoolingMode
-from .host import CoordinateMapKey
+from . import host as _host
+from .host import CoordinateMapKey  # noqa: F401
 from .common import get_minkowski_function
 from .kernel_generator import KernelGenerator
 from .sparse_tensor import SparseTensor, _get_coordinate_map_key
@@ -17,12 +18,12 @@ class MinkowskiLocalPoolingFunction(Function):
     def forward(ctx, input_features, pooling_mode, kernel_generator, in_coordinate_map_key,
                 out_coordinate_map_key=None, coordinate_manager=None):
         if out_coordinate_map_key is None:
-            out_coordinate_map_key = CoordinateMapKey(in_coordinate_map_key.get_coordinate_size())
+            out_coordinate_map_key = _host.key_like(in_coordinate_map_key)
         input_features = input_features.contiguous()
         ctx.input_features = input_features
         ctx.misc = (pooling_mode, kernel_generator, in_coordinate_map_key, out_coordinate_map_key,
                     coordinate_manager)
-        fw_fn = get_minkowski_function("LocalPoolingForward", input_features)
+        fw_fn = get_minkowski_function("LocalPoolingForward", input_features, in_coordinate_map_key)
         out_feat, num_nonzero = fw_fn(input_features, kernel_generator.kernel_size, kernel_generator.kernel_stride,
                                       kernel_generator.kernel_dilation, kernel_generator.region_type,
                                       kernel_generator.region_offsets, pooling_mode, in_coordinate_map_key,
@@ -34,7 +35,7 @@ class MinkowskiLocalPoolingFunction(Function):
     def backward(ctx, grad_out_feat):
         grad_out_feat = grad_out_feat.contiguous()
         pooling_mode, kernel_generator, in_key, out_key, coordinate_manager = ctx.misc
-        bw_fn = get_minkowski_function("LocalPoolingBackward", grad_out_feat)
+        bw_fn = get_minkowski_function("LocalPoolingBackward", grad_out_feat, in_key)
         grad_in_feat = bw_fn(ctx.input_features, grad_out_feat, ctx.num_nonzero, kernel_generator.kernel_size,
                              kernel_generator.kernel_stride, kernel_generator.kernel_dilation,
                              kernel_generator.region_type, kernel_generator.region_offsets, pooling_mode, in_key,
@@ -47,12 +48,12 @@ class MinkowskiLocalPoolingTransposeFunction(Function):
     def forward(ctx, input_features, pooling_mode, kernel_generator, in_coordinate_map_key,
                 out_coordinate_map_key=None, coordinate_manager=None):
         if out_coordinate_map_key is None:
-            out_coordinate_map_key = CoordinateMapKey(in_coordinate_map_key.get_coordinate_size())
+            out_coordinate_map_key = _host.key_like(in_coordinate_map_key)
         input_features = input_features.contiguous()
         ctx.input_features = input_features
         ctx.misc = (pooling_mode, kernel_generator, in_coordinate_map_key, out_coordinate_map_key,
                     coordinate_manager)
-        fw_fn = get_minkowski_function("LocalPoolingTransposeForward", input_features)
+        fw_fn = get_minkowski_function("LocalPoolingTransposeForward", input_features, in_coordinate_map_key)
         out_feat, num_nonzero = fw_fn(input_features, kernel_generator.kernel_size, kernel_generator.kernel_stride,
                                       kernel_generator.kernel_dilation, kernel_generator.region_type,
                                       kernel_generator.region_offsets, kernel_generator.expand_coordinates,
@@ -65,7 +66,7 @@ class MinkowskiLocalPoolingTransposeFunction(Function):
     def backward(ctx, grad_out_feat):
         grad_out_feat = grad_out_feat.contiguous()
         pooling_mode, kernel_generator, in_key, out_key, coordinate_manager = ctx.misc
-        bw_fn = get_minkowski_function("LocalPoolingTransposeBackward", grad_out_feat)
+        bw_fn = get_minkowski_function("LocalPoolingTransposeBackward", grad_out_feat, in_key)
         grad_in_feat = bw_fn(ctx.input_features, grad_out_feat, ctx.num_nonzero, kernel_generator.kernel_size,
                              kernel_generator.kernel_stride, kernel_generator.kernel_dilation,
                              kernel_generator.region_type, kernel_generator.region_offsets, pooling_mode, in_key,
@@ -159,11 +160,11 @@ class MinkowskiGlobalPoolingFunction(Function):
     def forward(ctx, input_features, pooling_mode, in_coordinate_map_key, out_coordinate_map_key=None,
                 coordinate_manager=None):
         if out_coordinate_map_key is None:
-            out_coordinate_map_key = CoordinateMapKey(in_coordinate_map_key.get_coordinate_size())
+            out_coordinate_map_key = _host.key_like(in_coordinate_map_key)
         input_features = input_features.contiguous()
         ctx.input_features = input_features
         ctx.misc = (pooling_mode, in_coordinate_map_key, out_coordinate_map_key, coordinate_manager)
-        fw_fn = get_minkowski_function("GlobalPoolingForward", input_features)
+        fw_fn = get_minkowski_function("GlobalPoolingForward", input_features, in_coordinate_map_key)
         out_feat, num_nonzero = fw_fn(input_features, pooling_mode, in_coordinate_map_key, out_coordinate_map_key,
                                       coordinate_manager._manager)
         ctx.num_nonzero = num_nonzero
@@ -173,7 +174,7 @@ class MinkowskiGlobalPoolingFunction(Function):
     def backward(ctx, grad_out_feat):
         grad_out_feat = grad_out_feat.contiguous()
         pooling_mode, in_key, out_key, coordinate_manager = ctx.misc
-        bw_fn = get_minkowski_function("GlobalPoolingBackward", grad_out_feat)
+        bw_fn = get_minkowski_function("GlobalPoolingBackward", grad_out_feat, in_key)
         grad_in_feat = bw_fn(ctx.input_features, grad_out_feat, ctx.num_nonzero, pooling_mode, in_key, out_key,
                              coordinate_manager._manager)
         return grad_in_feat, None, None, None, None

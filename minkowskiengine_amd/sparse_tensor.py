@@ -6,6 +6,7 @@ import warnings
 
 import torch
 
+from . import host as _host
 from .host import CoordinateMapKey
 from .common import convert_to_int_list
 from .coordinate_manager import CoordinateManager
@@ -97,7 +98,7 @@ class SparseTensor:
             assert features.shape[0] == coordinates.shape[0], \
                 "The number of rows in features and coordinates must match."
             assert features.is_cuda == coordinates.is_cuda, "Features and coordinates must have the same backend."
-            coordinate_map_key = CoordinateMapKey(convert_to_int_list(tensor_stride, self._D), "")
+            coordinate_map_key = _host.key_like(coordinate_manager, convert_to_int_list(tensor_stride, self._D), "")
             coordinates, features, coordinate_map_key = self.initialize_coordinates(
                 coordinates, features, coordinate_map_key)
             if own_manager:
@@ -270,10 +271,10 @@ def _get_coordinate_map_key(input, coordinates=None, tensor_stride=1, expand_coo
         assert isinstance(coordinates, (CoordinateMapKey, torch.Tensor, SparseTensor))
         if isinstance(coordinates, torch.Tensor):
             assert coordinates.ndim == 2
-            key = CoordinateMapKey(convert_to_int_list(tensor_stride, coordinates.size(1) - 1), "")
+            key = _host.key_like(input._manager, convert_to_int_list(tensor_stride, coordinates.size(1) - 1), "")
             key, _ = input._manager.insert_and_map(coordinates, *key.get_key())
             return key
         if isinstance(coordinates, SparseTensor):
             return coordinates.coordinate_map_key
         return coordinates
-    return CoordinateMapKey(input.coordinate_map_key.get_coordinate_size())
+    return _host.key_like(input.coordinate_map_key)

@@ -4,7 +4,8 @@ import torch
 from torch.autograd import Function
 from torch.nn import Module
 
-from .host import CoordinateMapKey
+from . import host as _host
+from .host import CoordinateMapKey  # noqa: F401
 from .sparse_tensor import SparseTensor
 
 
@@ -53,7 +54,7 @@ class MinkowskiUnion(Module):
             assert ref_manager == s.coordinate_manager, \
                 "Invalid coordinate manager. All inputs must have the same coordinate manager."
         in_keys = [s.coordinate_map_key for s in inputs]
-        out_key = CoordinateMapKey(ref_key.get_coordinate_size())
+        out_key = _host.key_like(ref_key)
         output = self.union.apply(in_keys, out_key, ref_manager, *[s.F for s in inputs])
         return SparseTensor(output, coordinate_map_key=out_key, coordinate_manager=ref_manager)
 

@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from .. import _lib
-from .. import backend as MEB
+from .. import host as _host
 
 
 def _device(device=None):
@@ -32,7 +32,7 @@ def unique_coordinate_map(coordinates, tensor_stride=1):
     assert isinstance(coordinates, torch.Tensor)
     src = coordinates.device
     c = coordinates.to(_device()).int().contiguous()
-    mgr = MEB.CoordinateMapManagerGPU_c10()
+    mgr = _host.backend().CoordinateMapManagerGPU_c10()      # the operator module in charge (native | Python twin)
     D = c.shape[1] - 1
     ts = [int(tensor_stride)] * D if np.isscalar(tensor_stride) else [int(t) for t in tensor_stride]
     _, (um, inv) = mgr.insert_and_map(c, ts, "")

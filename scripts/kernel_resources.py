@@ -1,6 +1,7 @@
 """Per-kernel register / scratch / LDS / occupancy table of every gfx950 kernel in csrc/*.hip, from hipcc's
 -Rpass-analysis=kernel-resource-usage remarks (compile-time facts: runs without a GPU).
-usage: python scripts/kernel_resources.py [out.txt]   (compiles each .hip once, ~4 min)"""
+usage: python scripts/kernel_resources.py [-o out.txt]   (compiles each .hip once, ~4 min)"""
+import argparse
 import glob
 import os
 import re
@@ -20,6 +21,9 @@ def demangle(names):
 
 
 def main():
+    ap = argparse.ArgumentParser(description=__doc__.splitlines()[0])
+    ap.add_argument("-o", "--output", default=None, help="write the table to this file instead of stdout")
+    args = ap.parse_args()
     rows = []
     with tempfile.TemporaryDirectory() as tmp:
         procs = []
@@ -48,8 +52,8 @@ def main():
         n = re.sub(r"\(.*", "", n).replace("void ", "")
         lines.append(" | ".join([r["file"], n] + [r.get(f, "?") for f in FIELDS]))
     text = "\n".join(lines) + "\n"
-    if len(sys.argv) > 1:
-        open(sys.argv[1], "w").write(text)
+    if args.output:
+        open(args.output, "w").write(text)
     else:
         sys.stdout.write(text)
 

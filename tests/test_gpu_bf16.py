@@ -86,7 +86,29 @@ def test_bf16_conv_forward_backward_vs_oracle(device, monkeypatch, n, extent, D,
     assert_close(conv.kernel.grad.cpu().numpy(), gw)          # fp32 accumulation of exact products
 
 
-def test_bf16_kernel_parameter(device):
+@pytest.mark.parametrize("n,extent,D,cin,cout,ks,stride,dil", BF16_CASES)
+def test_bf16_conv_vs_oracle_on_the_native_host(device, n, extent, D, cin, cout, ks, stride, dil):
+    """The same oracle comparison on the shipped default: the native C++ host layer with its own policy (shape, fusion,
+    deep pipeline, split-K decisions made in csrc_host/, not in backend.py)."""
+    import minkowskiengine_amd as ME
+    prev = ME.get_host()
+    ME.set_host("native")
+    try:
+        coords = make_cloud(n, extent, D, seed=n + cin, batch=2 if n > 100 else 1, negative=True)
+        conv, x, y, feats, gy = _run_layer(device, coords, cin, cout, ks, stride, dil)
+        assert x.coordinate_manager._native
+        in_c, out_c = coords.numpy(), y.C.cpu().numpy()
+        _, km = O.kernel_map(in_c, out_c, O.make_region(D, ks, dil, 1))
+        w = conv.kernel.detach().float().cpu().numpy()
+        assert_bf16_close(y.F.detach().float().cpu().numpy(), O.conv_forward(feats.numpy(), w, km, len(out_c)), "forward")
+        gi, gw = O.conv_backward(feats.numpy(), gy.numpy(), w, km)
+        assert_bf16_close(x.F.grad.float().cpu().numpy(), gi, "grad_in")
+        assert_close(conv.kernel.grad.cpu().numpy(), gw)
+    finally:
+        ME.set_host(prev)
+
+
+def test_bf16_kernel_parameter(device, host_layer):
     """Weights stored in bf16 (net.to(torch.bfloat16)) give the same forward bits as fp32 master weights that
     hold bf16-representable values; the weight gradient comes back in the parameter's dtype."""
     coords = make_cloud(3000, 14, 3, seed=3)
@@ -97,7 +119,7 @@ def test_bf16_kernel_parameter(device):
     assert torch.equal(a[0].kernel.grad.to(torch.bfloat16), b[0].kernel.grad)
 
 
-def test_bf16_bitwise_reproducible(device):
+def test_bf16_bitwise_reproducible(device, host_layer):
     coords = make_cloud(4000, 14, 3, seed=9)
     r1 = _run_layer(device, coords, 32, 64, 3)
     r2 = _run_layer(device, coords, 32, 64, 3)
@@ -105,7 +127,7 @@ def test_bf16_bitwise_reproducible(device):
     assert torch.equal(r1[0].kernel.grad, r2[0].kernel.grad)
 
 
-def test_bf16_transposed_conv_and_bias(device):
+def test_bf16_transposed_conv_and_bias(device, host_layer):
     """Down conv then transposed conv back onto the input map, bias and the 1x1 `use_mm` path in bf16."""
     import minkowskiengine_amd as ME
     coords = make_cloud(3000, 20, 3, seed=11)
@@ -133,7 +155,7 @@ def test_bf16_transposed_conv_and_bias(device):
     assert_bf16_close(u.F.detach().float().cpu().numpy(), ref_u, "up")
 
 
-def test_bf16_config2_full_size(device):
+def test_bf16_config2_full_size(device, host_layer):
     """BASELINE config 2 shape at full size in bf16 + linearity in exact arithmetic: features that are small
     integers keep every product and partial sum exactly representable, so conv(a + b) == conv(a) + conv(b)
     bit for bit once the outputs are integers below 2^8."""

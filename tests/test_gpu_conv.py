@@ -63,9 +63,23 @@ def test_conv_forward_backward_vs_oracle(device, monkeypatch, pipe, n, extent, D
         lib.me_debug_set_wgrad_config(0, 0)
 
 
-def _conv_case(device, n, extent, D, cin, cout, ks, stride, dil):
+@pytest.mark.parametrize("n,extent,D,cin,cout,ks,stride,dil", CONV_CASES)
+def test_conv_vs_oracle_on_the_native_host(device, n, extent, D, cin, cout, ks, stride, dil):
+    """The same oracle comparison on the shipped default: the native C++ host layer (csrc_host/) with its own
+    kernel-selection policy (split pipe where c_src * c_dst >= 8192, fp32 MFMA below, multi-offset batches by density)."""
+    import minkowskiengine_amd as ME
+    prev = ME.get_host()
+    ME.set_host("native")
+    try:
+        _conv_case(device, n, extent, D, cin, cout, ks, stride, dil, expect_native=True)
+    finally:
+        ME.set_host(prev)
+
+
+def _conv_case(device, n, extent, D, cin, cout, ks, stride, dil, expect_native=False):
     coords = make_cloud(n, extent, D, seed=n + cin, batch=2 if n > 100 else 1, negative=True)
     conv, x, y, feats, gy = _run_layer(device, coords, cin, cout, ks, stride, dil)
+    assert bool(x.coordinate_manager._native) == expect_native
     in_c = coords.numpy()
     out_c = y.C.cpu().numpy()
     if stride == 1:
@@ -135,7 +149,7 @@ def test_mfma_and_naive_kernels_agree(device):
     assert_close(b1, b0, 2e-5, 2e-5)
 
 
-def test_bitwise_reproducible(device):
+def test_bitwise_reproducible(device, host_layer):
     coords = make_cloud(4000, 14, 3, seed=9)
     r1 = _run_layer(device, coords, 32, 64, 3)
     r2 = _run_layer(device, coords, 32, 64, 3)
@@ -143,7 +157,7 @@ def test_bitwise_reproducible(device):
     assert torch.equal(r1[0].kernel.grad, r2[0].kernel.grad)
 
 
-def test_non_default_stream(device):
+def test_non_default_stream(device, host_layer):
     """Every launch goes to torch's CURRENT stream (DistributedDataParallel overlaps its collectives with the
     backward pass on side streams; users wrap steps in torch.cuda.stream): coordinate insertion, kernel map, tile
     plans, forward, dgrad, wgrad and pooling issued on a side stream — with the default stream kept busy by an
@@ -339,7 +353,7 @@ def test_matrix_bound_kernels_take_spatial_tiles(device, monkeypatch, n, extent,
     assert_close(res["auto"][1], O.conv_backward(x.numpy(), gy.numpy(), w.numpy(), okm)[0])
 
 
-def test_bias_and_use_mm(device):
+def test_bias_and_use_mm(device, host_layer):
     import minkowskiengine_amd as ME
     coords = make_cloud(500, 10, 3, seed=2).to(device)
     x = ME.SparseTensor(torch.rand(500, 8).to(device), coords)
@@ -350,7 +364,7 @@ def test_bias_and_use_mm(device):
 
 
 @pytest.mark.parametrize("path", golden_cases())
-def test_against_reference_fixtures(device, path):
+def test_against_reference_fixtures(device, host_layer, path):
     """The fixtures hold the REFERENCE's outputs (tests/golden/make_golden.py).  Row order of strided
     maps is implementation-defined in the reference, so output rows are relabelled by coordinate."""
     import minkowskiengine_amd as ME
@@ -393,7 +407,7 @@ def test_against_reference_fixtures(device, path):
         assert_close(convt.kernel.grad.cpu().numpy(), z["up_grad_kernel"])
 
 
-def test_config2_full_size(device):
+def test_config2_full_size(device, host_layer):
     """BASELINE config 2 at full size (100k voxels, 64 -> 128, k = 3): oracle values (numpy, a few
     seconds) + linearity as a size-independent property."""
     coords = make_cloud(100000, 70, 3, seed=0)
@@ -415,7 +429,7 @@ def test_config2_full_size(device):
     assert_close(lhs, rhs, 1e-4, 1e-4, "linearity")
 
 
-def test_config5_full_size(device):
+def test_config5_full_size(device, host_layer):
     """BASELINE config 5 at full size: 4-D (3-D + time) k = 3 (K = 81), 8 frames x 50k voxels in
     [0,100)^3 x [0,8), 32 -> 64 — the high-D coordinate-hash stress.  Kernel map pair sets identical to the
     oracle's per offset, features within 1e-4, plus mirror symmetry of the pair counts

@@ -10,7 +10,7 @@ import torch
 from oracle import me_oracle as O
 from helpers import GOLDEN_DIR, assert_close, make_cloud, row_mapping
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("host_layer")]   # both host layers
 
 
 def _z():

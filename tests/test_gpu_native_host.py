@@ -198,3 +198,10 @@ def test_build_recipe_replay_on_the_native_host(device, native):
     assert torch.equal(lazy[0], replayed[0])
     for u, v in zip(lazy[1], replayed[1]):
         assert torch.equal(u, v)
+    # a chain of scenes: the prefetched manager's OWN recipe is complete, so scene 3 can be prefetched from
+    # scene 2 (and 4 from 3) — not only every other scene
+    assert sorted(before) == sorted(recipe)
+    x3 = ME.SparseTensor(feats, coords)
+    assert x3.coordinate_manager.prefetch(x2.coordinate_manager.recipe()) == len(recipe)
+    x4 = ME.SparseTensor(feats, coords)
+    assert x4.coordinate_manager.prefetch(x3.coordinate_manager.recipe()) == len(recipe)

@@ -42,7 +42,7 @@ def close(a, b, tol=1e-5):
 
 @pytest.mark.parametrize("n,c,offset", [(5000, 32, 0.0), (1000, 96, 0.0), (3000, 7, 0.0), (2, 4, 0.0),
                                         (4000, 256, 0.0), (3000, 384, 0.0), (20000, 64, 300.0)])
-def test_batch_norm_matches_torch_float64(device, n, c, offset):
+def test_batch_norm_matches_torch_float64(device, host_layer, n, c, offset):
     g = torch.Generator().manual_seed(n + c)
     coords = make_cloud(n, 40, 3, seed=c)
     x = torch.randn(n, c, generator=g) * (1.0 + torch.arange(c) % 5) + offset   # offset: mean >> std
@@ -55,7 +55,7 @@ def test_batch_norm_matches_torch_float64(device, n, c, offset):
     assert close(rm, rrm, 1e-5) and close(rv, rrv, 1e-4)
 
 
-def test_batch_norm_bf16_rows(device):
+def test_batch_norm_bf16_rows(device, host_layer):
     n, c = 50000, 64
     g = torch.Generator().manual_seed(1)
     coords = make_cloud(n, 60, 3, seed=1)
@@ -71,7 +71,7 @@ def test_batch_norm_bf16_rows(device):
     assert close(dw, rdw, 1e-4) and close(db, rdb, 1e-4)
 
 
-def test_batch_norm_reproducible_and_eval(device):
+def test_batch_norm_reproducible_and_eval(device, host_layer):
     import minkowskiengine_amd as ME
     n, c = 30000, 32
     g = torch.Generator().manual_seed(2)
@@ -90,7 +90,7 @@ def test_batch_norm_reproducible_and_eval(device):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_fused_batch_norm_relu(device, dtype):
+def test_fused_batch_norm_relu(device, host_layer, dtype):
     """MinkowskiBatchNorm(fuse_relu) + MinkowskiReLU = the two separate layers (forward clamp, backward mask
     recomputed from x), against relu(BatchNorm1d(x)) in float64."""
     import minkowskiengine_amd as ME
@@ -264,3 +264,38 @@ def test_conv_batchnorm_pair_uses_the_epilogue_statistics(device, native, monkey
         if native:
             H.native_module().set_conv_bn_stats(-1)
         H.set_host(prev)
+
+
+def test_batch_norm_buffers_of_another_dtype_are_not_overrun(device, host_layer):
+    """after `model.bfloat16()` the running statistics are bf16 — c floats written into a 2c-byte buffer
+    would corrupt its neighbour.  They go through float32 temporaries; the guard rows stay intact and the statistics
+    equal the float32 module's (rounded to bf16)."""
+    import minkowskiengine_amd as ME
+    from helpers import make_cloud
+    c = 32
+    coords = make_cloud(3000, 14, 3, seed=2).to(device)
+    f = torch.rand(coords.shape[0], c, generator=torch.Generator().manual_seed(4)).to(device)
+    ref = ME.MinkowskiBatchNorm(c).to(device)
+    ref.train()
+    x32 = ME.SparseTensor(f, coords)
+    y32 = ref(x32)
+    bn = ME.MinkowskiBatchNorm(c).to(device).bfloat16()
+    assert bn.bn.running_mean.dtype == torch.bfloat16
+    # the two running buffers carved out of ONE allocation with guard values around them
+    slab = torch.full((4 * c,), 7.0, dtype=torch.bfloat16, device=device)
+    slab[c:2 * c] = 0.0
+    slab[2 * c:3 * c] = 1.0
+    bn.bn.running_mean = slab[c:2 * c]
+    bn.bn.running_var = slab[2 * c:3 * c]
+    bn.train()
+    xb = ME.SparseTensor(f.bfloat16(), coordinate_map_key=x32.coordinate_map_key, coordinate_manager=x32.coordinate_manager)
+    yb = bn(xb)
+    torch.cuda.synchronize()
+    assert bool((slab[:c] == 7.0).all()) and bool((slab[3 * c:] == 7.0).all()), "wrote past the running statistics"
+    assert torch.allclose(bn.bn.running_mean.float(), ref.bn.running_mean, atol=1e-2)
+    assert torch.allclose(bn.bn.running_var.float(), ref.bn.running_var, atol=1e-2)
+    assert int(bn.bn.num_batches_tracked) == 1
+    assert torch.allclose(yb.F.float(), y32.F, atol=0.06)
+    bn.eval()
+    ye = bn(xb)                                                # evaluation with bf16 buffers: float32 vectors inside
+    assert ye.F.dtype == torch.bfloat16 and bool(torch.isfinite(ye.F.float()).all())

@@ -96,3 +96,83 @@ def test_cached_images_follow_weight_updates_and_temporaries(device, dtype, monk
     assert not torch.equal(outs[True][2], outs[True][3])
     for a, b in zip(outs[True], outs[False]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_data_writes_need_the_invalidate_call_and_optimizer_steps_do_not(device, host_layer, dtype):
+    """a write through `p.data` does not bump the version counter the cache is validated by.  The cache
+    epoch covers it: `invalidate_packed_weights()` (explicit), every torch.optim step (global post-hook) and
+    distributed.broadcast_parameters.  After either, the layer's output equals a fresh layer's with the same weights."""
+    import minkowskiengine_amd as ME
+    coords = make_cloud(3000, 14, 3, seed=2).to(device)
+    feats = torch.rand(coords.shape[0], 64, generator=torch.Generator().manual_seed(1)).to(device).to(dtype)
+    x = ME.SparseTensor(feats, coords)
+    conv = ME.MinkowskiConvolution(64, 128, kernel_size=3, dimension=3).to(device)
+
+    def fresh(w):
+        c = ME.MinkowskiConvolution(64, 128, kernel_size=3, dimension=3).to(device)
+        with torch.no_grad():
+            c.kernel.copy_(w)
+        return c(ME.SparseTensor(feats, coordinate_map_key=x.coordinate_map_key,
+                                 coordinate_manager=x.coordinate_manager)).F
+
+    y0 = conv(x).F.clone()
+    v = conv.kernel._version
+    conv.kernel.data.add_(0.125)                               # invisible to the version counter
+    assert conv.kernel._version == v
+    ME.invalidate_packed_weights()
+    y1 = conv(x).F.clone()
+    assert not torch.equal(y0, y1) and torch.equal(y1, fresh(conv.kernel.detach()))
+    # an optimizer that writes through .data (Apex / DeepSpeed style): the step post-hook advances the epoch
+    class DataSGD(torch.optim.Optimizer):
+        def __init__(self, params):
+            super().__init__(params, {})
+
+        def step(self, closure=None):
+            for gr in self.param_groups:
+                for p in gr["params"]:
+                    p.data.mul_(0.5)
+    opt = DataSGD(conv.parameters())
+    v = conv.kernel._version
+    opt.step()
+    assert conv.kernel._version == v
+    y2 = conv(x).F.clone()
+    assert not torch.equal(y1, y2) and torch.equal(y2, fresh(conv.kernel.detach()))
+    # reset_parameters writes in place on the parameter itself: seen by the version counter
+    torch.manual_seed(3)
+    conv.reset_parameters()
+    assert conv.kernel._version > v
+    assert torch.equal(conv(x).F, fresh(conv.kernel.detach()))
+
+
+def test_objects_stay_with_the_host_that_made_them(device):
+    """operators and new keys are resolved from the input tensor's manager / key, not from the global host
+    switch — a SparseTensor made under one host keeps working after set_host() (pooling, broadcast, pruning, union,
+    convolution, batch norm)."""
+    import minkowskiengine_amd as ME
+    coords = make_cloud(2000, 12, 3, seed=4, batch=2).to(device)
+    feats = torch.rand(coords.shape[0], 16, generator=torch.Generator().manual_seed(2)).to(device)
+    prev = ME.get_host()
+    results = {}
+    try:
+        for made_under, run_under in (("python", "native"), ("native", "python"), ("python", "python")):
+            ME.set_host(made_under)
+            x = ME.SparseTensor(feats, coords)
+            conv = ME.MinkowskiConvolution(16, 16, kernel_size=2, stride=2, dimension=3).to(device)
+            torch.manual_seed(0)
+            conv.reset_parameters()
+            ME.set_host(run_under)
+            y = conv(x)
+            p = ME.MinkowskiMaxPooling(kernel_size=3, stride=2, dimension=3)(x)
+            b = ME.MinkowskiBroadcastMultiplication()(x, ME.MinkowskiGlobalAvgPooling()(x))
+            pr = ME.MinkowskiPruning()(x, x.F[:, 0] > 0.5)
+            u = ME.MinkowskiUnion()(x, pr)
+            n = ME.MinkowskiBatchNorm(16).to(device)(y)
+            results[(made_under, run_under)] = [t.F.clone() for t in (y, p, b, pr, u, n)]
+            assert bool(x.coordinate_manager._native) == (made_under == "native")
+    finally:
+        ME.set_host(prev)
+    base = results[("python", "python")]
+    for k, r in results.items():
+        for a, c in zip(base, r):
+            assert torch.equal(a, c), k

@@ -12,7 +12,7 @@ import torch
 from oracle import me_oracle as O
 from helpers import GOLDEN_DIR, make_cloud, row_mapping
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("host_layer")]   # both host layers
 POOL_CASES = sorted(glob.glob(os.path.join(GOLDEN_DIR, "pool_*.npz")))
 
 

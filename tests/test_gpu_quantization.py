@@ -10,7 +10,7 @@ import torch
 from oracle import me_oracle as O
 from helpers import GOLDEN_DIR
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("host_layer")]   # both host layers
 
 
 def test_sparse_quantize_matches_reference_fixture(device):

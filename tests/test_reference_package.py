@@ -162,6 +162,46 @@ print("GPU_OK")
 
 @pytest.mark.gpu
 @needs_ref
-def test_reference_package_runs_on_the_hip_kernels():
-    out = subprocess.run([sys.executable, "-c", _GPU.format(root=ROOT)], capture_output=True, text=True, timeout=900)
-    assert "GPU_OK" in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])
+@pytest.mark.parametrize("host", ["python", "native"])
+def test_reference_package_runs_on_the_hip_kernels(host):
+    """The reference's unmodified Python package over `MinkowskiEngineBackend._C` = the Python twin, and = the native
+    C++ extension (the product default, what the reference's own `_C` is: a pybind11 module)."""
+    env = dict(os.environ, ME_AMD_HOST=host)
+    script = _GPU.format(root=ROOT) + f"\nassert OURS.get_host() == {host!r} and getattr(C, '_host', 'python') == {host!r}\nprint('HOST_OK')\n"
+    out = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=900, env=env)
+    assert "GPU_OK" in out.stdout and "HOST_OK" in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])
+
+
+_IMPORT_NATIVE = r"""
+import sys
+sys.path.insert(0, {root!r})
+import MinkowskiEngineBackend._C as C
+assert getattr(C, "_host", None) == "native", C
+for name in ("CoordinateMapKey", "CoordinateMapManagerGPU_c10", "CoordinateMapManagerGPU_default", "RegionType",
+             "PoolingMode", "BroadcastMode", "ConvolutionMode", "MinkowskiAlgorithm", "CoordinateMapType",
+             "GPUMemoryAllocatorType", "is_cuda_available", "cuda_version", "cudart_version", "get_gpu_memory_info",
+             "ConvolutionForwardGPU", "ConvolutionBackwardGPU", "ConvolutionTransposeForwardGPU",
+             "ConvolutionTransposeBackwardGPU", "LocalPoolingForwardGPU", "LocalPoolingBackwardGPU",
+             "LocalPoolingTransposeForwardGPU", "LocalPoolingTransposeBackwardGPU", "GlobalPoolingForwardGPU",
+             "GlobalPoolingBackwardGPU", "BroadcastForwardGPU", "BroadcastBackwardGPU", "PruningForwardGPU",
+             "PruningBackwardGPU"):
+    assert hasattr(C, name), name
+from oracle import ref
+ME = ref.import_reference_package(backend=C)
+mgr = ME.CoordinateManager(D=3)
+assert type(mgr._manager).__name__ == "CoordinateMapManagerGPU_c10"
+key = ME.CoordinateMapKey([1, 1, 1], "")
+assert key.get_key() == ([1, 1, 1], "") and key.is_key_set()
+conv = ME.MinkowskiConvolution(4, 8, kernel_size=3, dimension=3)
+print("IMPORT_OK", ME.__version__)
+"""
+
+
+@needs_ref
+def test_reference_package_imports_on_the_native_module():
+    """CPU leg of the above: with ME_AMD_HOST=native `MinkowskiEngineBackend._C` IS the compiled extension, exports the
+    reference's operator / class / enum names, and the reference's Python package imports and constructs on it."""
+    env = dict(os.environ, ME_AMD_HOST="native")
+    out = subprocess.run([sys.executable, "-c", _IMPORT_NATIVE.format(root=ROOT)], capture_output=True, text=True,
+                         timeout=600, env=env)
+    assert "IMPORT_OK" in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])
