@@ -282,6 +282,50 @@ def set_kernel_timer(MEB, timer):
         host.native_module().timing_enable(timer is not None)
 
 
+LAST_RUN = {}    # side results of the last run_timed call: per-rank times of the reported block
+
+
+def timed_block(step, steps, dist_utils, dev, reps=3):
+    """median over `reps` of [barrier + synchronize | `steps` steps | synchronize + barrier], max over ranks -> seconds"""
+    out = []
+    for _ in range(reps):
+        dist_utils.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dist_utils.barrier()
+        out.append(dist_utils.max_over_ranks(time.perf_counter() - t0, dev))
+    return sorted(out)[(len(out) - 1) // 2]
+
+
+def allreduce_probe(n_bytes_total, dist_utils, dev, dtype=torch.float32, bucket_bytes=25 * 1024 * 1024, reps=5):
+    """One gradient exchange on its own: the model's gradient bytes all-reduced in DDP-sized flat buckets with nothing
+    else on the device, HIP-event timed on the collective's stream of record (the current stream waits for it) ->
+    (ms for all buckets [max over ranks], bucket count).  The reference point for what the step could hide."""
+    import torch.distributed as dist
+    esz = torch.empty(0, dtype=dtype).element_size()
+    sizes, left = [], n_bytes_total
+    while left > 0:
+        sizes.append(min(left, bucket_bytes))
+        left -= sizes[-1]
+    bufs = [torch.zeros(max(1, b // esz), dtype=dtype, device=dev) for b in sizes]
+    best = None
+    for _ in range(reps + 1):
+        dist_utils.barrier()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for b in bufs:
+            dist.all_reduce(b)
+        e.record()
+        torch.cuda.synchronize()
+        t = s.elapsed_time(e)
+        best = t if best is None else min(best, t)
+    return dist_utils.max_over_ranks(best, dev), len(sizes)
+
+
 def run_timed(step, args, dist_utils, MEB, dev, timers_in_blocks=True):
     """-> (seconds of the MEDIAN K-step block [max over ranks], every block's seconds, KernelTimer of ALL timed
     blocks, number of timed steps).  Each block: barrier + synchronize | K steps | synchronize + barrier.
@@ -301,7 +345,7 @@ def run_timed(step, args, dist_utils, MEB, dev, timers_in_blocks=True):
             step()
         torch.cuda.synchronize()
         set_kernel_timer(MEB, None)
-    blocks = []
+    blocks, local = [], []
     total = 0.0
     while True:
         dist_utils.barrier()
@@ -311,16 +355,20 @@ def run_timed(step, args, dist_utils, MEB, dev, timers_in_blocks=True):
         for _ in range(args.steps):
             step()
         torch.cuda.synchronize()
+        own = time.perf_counter() - t0                         # this rank's own K steps (before it waits for the others)
         dist_utils.barrier()
         elapsed = time.perf_counter() - t0
         set_kernel_timer(MEB, None)
         elapsed = dist_utils.max_over_ranks(elapsed, dev)      # the same value on every rank: same loop exit
         blocks.append(elapsed)
+        local.append(own)
         total += elapsed
         if (total >= args.min_time and len(blocks) >= args.min_blocks) or len(blocks) >= args.max_blocks:
             break
     srt = sorted(blocks)
     median = srt[(len(srt) - 1) // 2]      # lower median: a measured block, never an interpolation
+    LAST_RUN["per_rank_ms_per_step"] = [round(v / args.steps * 1e3, 4) for v in
+                                        dist_utils.gather_over_ranks(local[blocks.index(median)], dev)]
     return median, blocks, timer, args.steps * (len(blocks) if timers_in_blocks else 1)
 
 
@@ -402,15 +450,55 @@ def bench_conv(args, ME, MEB, dist_utils, rank, world, dev, startup):
                                    ME.RegionType.HYPER_CUBE, None, False, False).n_pairs
     grad_seed = torch.ones_like(y.F)
 
-    def step():
-        conv.kernel.grad = None
+    def step(zero=True):
+        if zero:
+            conv.kernel.grad = None
         x.F.grad = None
         out = net(x)
         out.F.backward(grad_seed)
 
     best, blocks, timer, timed_steps = run_timed(step, args, dist_utils, MEB, dev)
+    per_rank = LAST_RUN.get("per_rank_ms_per_step")
     total_points = dist_utils.sum_over_ranks(n, dev)
     pairs_all = dist_utils.sum_over_ranks(n_pairs, dev)
+    multi = None
+    if world > 1:
+        # What the one-layer headline hides nothing behind: its 0.88 MB all-reduce starts when the ONLY layer's backward
+        # is done.  Beside the synchronous step: the same step without the exchange (DDP.no_sync), the exchange on its
+        # own, and a gradient-accumulation window (A - 1 micro-steps under no_sync, the A-th reduces) — the loop a
+        # one-layer data-parallel job would actually run.
+        def step_nosync(zero=True):
+            with dist_utils.no_sync(net):
+                step(zero)
+        A = max(2, args.accum)
+
+        def window():
+            for i in range(A):                      # gradients accumulate over the window, the last micro-step reduces
+                if i + 1 < A:
+                    step_nosync(zero=(i == 0))
+                else:
+                    step(zero=False)
+        t_nosync = timed_block(step_nosync, args.steps, dist_utils, dev)
+        t_window = timed_block(window, max(1, args.steps // A), dist_utils, dev)
+        ar_ms, n_buckets = allreduce_probe(conv.kernel.numel() * 4, dist_utils, dev)
+        ms_sync = best / args.steps * 1e3
+        ms_nosync = t_nosync / args.steps * 1e3
+        ms_window = t_window / (max(1, args.steps // A) * A) * 1e3
+        multi = dict(dist_utils.collective_info(),
+                     per_rank_ms_per_step=per_rank,
+                     no_sync_ms_per_step=round(ms_nosync, 4),
+                     allreduce_ms={"standalone": round(ar_ms, 4), "buckets": n_buckets,
+                                   "bytes": int(conv.kernel.numel() * 4),
+                                   "exposed_in_step": round(ms_sync - ms_nosync, 4)},
+                     parallel_efficiency=round(ms_nosync / ms_sync, 4),
+                     accumulation={"window": A, "ms_per_micro_step": round(ms_window, 4),
+                                   "value": round(total_points / (ms_window * 1e-3) / 1e6, 3),
+                                   "parallel_efficiency": round(ms_nosync / ms_window, 4),
+                                   "note": f"{A - 1} micro-steps under DDP.no_sync, the {A}-th all-reduces the accumulated "
+                                           "gradient: value = voxels of all ranks per micro-step time"},
+                     note="parallel_efficiency = step time without the gradient exchange (DDP.no_sync, max over ranks) / "
+                          "step time with it, on THIS world size — the share of the step that is not exposed exchange; "
+                          "the 1 -> N scaling efficiency is the driver's to compute from the per-N values")
     cold = cold_path(ME, MEB, feats, coords.to(dev), dev, n, D, K, cin, cout, args.dtype == "bf16") if rank == 0 else None
     if rank != 0:
         return None
@@ -455,6 +543,7 @@ def bench_conv(args, ME, MEB, dist_utils, rank, world, dev, startup):
                        if world > 1 else ""),
                    "imbalance": bool(args.imbalance and world > 1),
                    "oversubscribed": world > max(1, dist_utils.visible_gpus())},
+        "multi_gpu": multi,
         "timing": {"blocks": len(blocks), "steps_per_block": args.steps,
                    "blocks_ms_per_step": [round(b / args.steps * 1e3, 4) for b in blocks],
                    "timed_region_s": round(sum(blocks), 4),
@@ -560,7 +649,31 @@ def bench_minkunet(args, ME, MEB, dist_utils, rank, world, dev, startup):
     # (per-launch HIP events — ~130 event pairs per step — stay out of the timed blocks: the kernel table comes from ONE
     # extra, untimed block, so that `ms_per_step` is the step a training loop would see)
     best, blocks, timer, timed_steps = run_timed(step, args, dist_utils, MEB, dev, timers_in_blocks=False)
+    per_rank = LAST_RUN.get("per_rank_ms_per_step")
     total_points = dist_utils.sum_over_ranks(n, dev)
+    multi = None
+    if world > 1:
+        # BASELINE configs[3]: what the exchange costs THIS step — the step without it (DDP.no_sync: same kernels, no
+        # collectives), the 151 MB of gradients all-reduced on their own, and the difference the bucketed overlap leaves
+        def step_nosync():
+            with dist_utils.no_sync(net):
+                step()
+        t_nosync = timed_block(step_nosync, args.steps, dist_utils, dev)
+        grad_bytes = sum(p.numel() * p.element_size() for p in model.parameters() if p.requires_grad)
+        ar_ms, n_buckets = allreduce_probe(grad_bytes, dist_utils, dev)
+        ms_sync, ms_nosync = best / args.steps * 1e3, t_nosync / args.steps * 1e3
+        multi = dict(dist_utils.collective_info(),
+                     per_rank_ms_per_step=per_rank,
+                     per_rank_points=[int(v) for v in dist_utils.gather_over_ranks(n, dev)],
+                     no_sync_ms_per_step=round(ms_nosync, 3),
+                     allreduce_ms={"standalone": round(ar_ms, 3), "buckets": n_buckets, "bytes": int(grad_bytes),
+                                   "exposed_in_step": round(ms_sync - ms_nosync, 3),
+                                   "hidden_by_overlap": round(max(0.0, ar_ms - (ms_sync - ms_nosync)), 3)},
+                     parallel_efficiency=round(ms_nosync / ms_sync, 4),
+                     sync_bn=bool(args.sync_bn), imbalance=bool(args.imbalance),
+                     note="parallel_efficiency = step time without the gradient exchange (DDP.no_sync, max over ranks) / "
+                          "step time with it on THIS world size; allreduce_ms.standalone = all gradient buckets reduced "
+                          "with nothing else running (HIP events), exposed_in_step = what the overlapped step still pays")
     # the same step replayed from a hipGraph (maps cached: fixed shapes and addresses) — the GPU time of the step with
     # the host out of the way; reported beside the eager figure, never instead of it
     graph_ms = None
@@ -610,6 +723,7 @@ def bench_minkunet(args, ME, MEB, dist_utils, rank, world, dev, startup):
                    "hip_graph": graphed,
                    "imbalance": bool(args.imbalance and world > 1),
                    "oversubscribed": world > max(1, dist_utils.visible_gpus())},
+        "multi_gpu": multi,
         "timing": {"blocks": len(blocks), "steps_per_block": args.steps,
                    "blocks_ms_per_step": [round(b / args.steps * 1e3, 3) for b in blocks],
                    "timed_region_s": round(sum(blocks), 4),
@@ -648,16 +762,22 @@ def extra_workloads(args, ME, MEB, dist_utils, rank, world, dev, startup):
     the 200k-voxel scene, configs[4] the 4-D convolution.  Each entry carries its own roofline and its own
     reference-CPU baseline; short blocks (the driver's run has to stay within a few minutes)."""
     out = {}
-    plan = (("minkunet34c_bf16_200k", dict(workload="minkunet", dtype="bf16", steps=5, warmup=2, min_time=0.15,
-                                            cpu_budget=min(args.cpu_budget, 1.0))),
-            ("conv4d_f32_400k", dict(workload="conv4d", dtype="f32", steps=10, warmup=3, min_time=0.1,
-                                     cpu_budget=min(args.cpu_budget, 4.0))))
+    if world == 1:
+        plan = (("minkunet34c_bf16_200k", dict(workload="minkunet", dtype="bf16", steps=5, warmup=2, min_time=0.15,
+                                                cpu_budget=min(args.cpu_budget, 1.0))),
+                ("conv4d_f32_400k", dict(workload="conv4d", dtype="f32", steps=10, warmup=3, min_time=0.1,
+                                         cpu_budget=min(args.cpu_budget, 4.0))))
+    else:
+        # N > 1 (the driver's scaling run): BASELINE configs[3] — MinkUNet34C, one 200k-voxel scene per rank, torch DDP
+        # over RCCL — with the exchange priced (multi_gpu); --sync-bn / --imbalance of the command line carry over
+        plan = (("minkunet34c_bf16_ddp", dict(workload="minkunet", dtype="bf16", steps=5, warmup=2, min_time=0.15,
+                                               cpu_budget=0.0, sync_bn=args.sync_bn, imbalance=args.imbalance)),)
     for name, over in plan:
         a = argparse.Namespace(**vars(args))
-        for k, v in over.items():
-            setattr(a, k, v)
         a.points = a.cin = a.cout = 0
         a.scenes, a.graph, a.sync_bn, a.imbalance = "cached", False, False, False
+        for k, v in over.items():
+            setattr(a, k, v)
         t0 = time.perf_counter()
         try:
             full = (bench_minkunet if a.workload == "minkunet" else bench_conv)(a, ME, MEB, dist_utils, rank, world, dev,
@@ -669,10 +789,10 @@ def extra_workloads(args, ME, MEB, dist_utils, rank, world, dev, startup):
             torch.cuda.empty_cache()
         if full is None:
             continue
-        keep = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype", "roofline", "cpu_baseline",
-                "speedup_vs_cpu_baseline", "cold_ms", "hip_graph")
+        keep = ("metric", "value", "unit", "n_gpus", "ms_per_step", "steps", "warmup", "dtype", "roofline", "cpu_baseline",
+                "speedup_vs_cpu_baseline", "cold_ms", "hip_graph", "multi_gpu")
         ent = {k: full[k] for k in keep if k in full}
-        ent["config"] = {"workload": full["config"]["workload"]}
+        ent["config"] = {"workload": full["config"]["workload"], "parallelism": full["config"].get("parallelism")}
         ent["kernels"] = {k: {"avg_ms": v["avg_ms"], "tflops": v["tflops"]} for k, v in full.get("kernels", {}).items()}
         if "cold" in full and full["cold"]:
             ent["cold"] = {k: full["cold"][k] for k in ("insert_ms", "kernel_map_ms", "plans_ms", "kernel_map_GBs")
@@ -730,6 +850,9 @@ def main():
                          "conv) under `workloads` (auto: with the default single-GPU headline run only)")
     ap.add_argument("--cpu-capped", action="store_true",
                     help="minkunet: also time the reference CPU layers under its own 16-thread cap (doubles the CPU time)")
+    ap.add_argument("--accum", type=int, default=4,
+                    help="N > 1, conv workloads: length of the gradient-accumulation window reported under "
+                         "multi_gpu.accumulation (A - 1 micro-steps under DDP.no_sync, the A-th all-reduces)")
     ap.add_argument("--imbalance", action="store_true",
                     help="N > 1: ranks get scenes of different sizes, 0.75x .. 1.25x the nominal voxel count (real scans "
                          "differ in size: the scaling risk SURVEY 8(e) names); value still counts the voxels of all ranks")
@@ -776,10 +899,13 @@ def main():
         lib.me_debug_set_bf16_shape(*[int(v) for v in args.debug_bf16_shape.split(",")])
     fn = bench_minkunet if args.workload == "minkunet" else bench_conv
     line = fn(args, ME, MEB, dist_utils, rank, world, dev, startup)
-    default_headline = (args.workload == "conv3d" and args.dtype == "f32" and world == 1 and not args.points and
+    default_headline = (args.workload == "conv3d" and args.dtype == "f32" and not args.points and
                         not args.cin and not args.cout and args.extent == 70)
     if args.extra_workloads == "on" or (args.extra_workloads == "auto" and default_headline):
-        line["workloads"] = extra_workloads(args, ME, MEB, dist_utils, rank, world, dev, startup)
+        # (every rank takes part: the N > 1 entry is a collective workload; only rank 0 holds a line to attach it to)
+        extra = extra_workloads(args, ME, MEB, dist_utils, rank, world, dev, startup)
+        if line is not None:
+            line["workloads"] = extra
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -147,6 +147,39 @@ def sum_over_ranks(value, device=None):
     return _reduce_scalar(value, dist.ReduceOp.SUM, device)
 
 
+def gather_over_ranks(value, device=None):
+    """-> [value of rank 0, value of rank 1, ...] of a python float, on every rank"""
+    w = world_size()
+    if w == 1:
+        return [float(value)]
+    if device is None and backend_name() == "nccl":
+        device = torch.device("cuda", torch.cuda.current_device())
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(w)]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
+
+
+def collective_info():
+    """what the JSON line of bench.py records about the exchange layer: backend as torch.distributed reports it, the
+    world size the process group reports, and the RCCL version when the backend is "nccl" (= RCCL on ROCm)"""
+    info = {"backend": backend_name(), "world_size_reported": world_size()}
+    if info["backend"] == "nccl":
+        try:
+            info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:  # noqa: BLE001
+            info["rccl_version"] = None
+    return info
+
+
+def no_sync(module):
+    """context manager: backward passes inside it do NOT all-reduce (DistributedDataParallel.no_sync — gradient
+    accumulation windows); a no-op for an unwrapped module (one rank)"""
+    import contextlib
+    fn = getattr(module, "no_sync", None)
+    return fn() if callable(fn) and world_size() > 1 else contextlib.nullcontext()
+
+
 def barrier():
     if world_size() > 1:
         dist.barrier()

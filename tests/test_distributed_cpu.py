@@ -64,9 +64,21 @@ def _worker(rank, world, port, out):
     ddp_out = (lin.weight.detach().sum().item(), lin.weight.grad.mean().item())
     t = D.max_over_ranks(0.5 + rank)
     s = D.sum_over_ranks(len(scenes))
+    # what bench.py --gpus N records about the exchange (round 4): per-rank values, the collective layer, and a
+    # gradient-accumulation window under DDP.no_sync — the micro-step inside it leaves the gradients un-reduced
+    gathered = D.gather_over_ranks(10.0 + rank)
+    info = D.collective_info()
+    lin.weight.grad = None
+    with D.no_sync(ddp):
+        ddp(x).sum().backward()
+    local_grad = lin.weight.grad.mean().item()             # this rank's own gradient: 4 * (rank + 1)
+    ddp(x).sum().backward()                                # the closing micro-step reduces the ACCUMULATED gradient
+    window_grad = lin.weight.grad.mean().item()
+    with D.no_sync(lin):                                   # an unwrapped module: a no-op context
+        pass
     D.barrier()
     out[rank] = (conv.kernel.detach().sum().item(), conv.kernel.grad.mean().item(), conv.bias.grad.mean().item(),
-                 t, s, scenes, mixed, ddp_out)
+                 t, s, scenes, mixed, ddp_out, gathered, info, local_grad, window_grad)
     torch.distributed.destroy_process_group()
 
 
@@ -84,6 +96,10 @@ def test_two_rank_gloo():
     assert a[6] == b[6] == (1.5, 1.5, True, 1.5, 2.0), (a[6], b[6])
     assert a[7][0] == b[7][0], "DDP did not broadcast the parameters"
     assert a[7][1] == b[7][1] == pytest.approx(4 * 1.5), (a[7], b[7])   # d(sum)/dW = sum of inputs, averaged
+    assert a[8] == b[8] == [10.0, 11.0]
+    assert a[9] == b[9] == {"backend": "gloo", "world_size_reported": 2}
+    assert a[10] == pytest.approx(4.0) and b[10] == pytest.approx(8.0), "no_sync reduced the gradient"
+    assert a[11] == b[11] == pytest.approx(2 * 4 * 1.5), "the window's closing step must reduce the accumulated gradient"
 
 
 def test_backend_choice():
