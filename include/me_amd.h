@@ -49,7 +49,9 @@ typedef struct me_region {
  *   1.2 (120)  round 3: me_plan_tile_bptr_elems sizes that buffer; me_debug_* hooks left this header
  *              (csrc/me_amd_debug.h: tests / tuning only)
  *   1.3 (130)  round 3: batch-norm statistics in the convolution's epilogue (me_conv_target_bf16_stats,
- *              me_conv_stats_supported_bf16, me_bn_stats_from_tiles) */
+ *              me_conv_stats_supported_bf16, me_bn_stats_from_tiles)
+ *   1.4 (140)  round 4: split-K launches of the bf16 convolution for small coordinate maps
+ *              (me_conv_plan_config_bf16_ex, me_conv_splitk_workspace_bytes, me_conv_target_bf16_ex) */
 int me_version(void);
 const char *me_last_error(void);
 /* kernel volume of a region: src/kernel_region.hpp:250-270 (set_volume) */
@@ -347,6 +349,25 @@ int me_conv_target_bf16_stats(const uint16_t *src_feat_dev, int64_t n_src, int32
                               const int32_t *order_dev, uint16_t *dst_feat_dev,
                               int64_t n_tgt, int32_t tile_rows, int32_t batch_groups, int32_t fused,
                               float *part_mean_dev, float *part_m2_dev, void *stream);
+/* Split-K launches (round 4).  The reference runs one GEMM per kernel offset and adds into the output with atomics
+ * (src/convolution_kernel.cu:320-496); here a workgroup owns a tile of target rows and walks all offsets — which on a
+ * SMALL coordinate map (MinkUNet's 5k-voxel level) means 128 tiles of 39 rows that each stream the whole packed weight
+ * tensor.  me_conv_plan_config_bf16_ex is me_conv_plan_config_bf16 that may also answer split_k = G > 1 with G-times
+ * taller tiles: the launch then has G offset groups per tile, every workgroup walks K / G offsets, the groups' fp32
+ * tiles go through `workspace_dev` (me_conv_splitk_workspace_bytes) and a second kernel adds them in group order,
+ * rounds once and stores (same semantics: fp32 sums in a fixed order, one rounding; NOT the bits of the unsplit launch).
+ * me_conv_target_bf16_ex is the one entry point of the bf16 forward / dgrad launch: fused / statistics / split-K by
+ * argument (split_k = 1, workspace NULL, part_* NULL: me_conv_target_bf16). */
+int me_conv_plan_config_bf16_ex(int64_t n_tgt, int64_t volume, int64_t n_pairs, int32_t c_src, int32_t c_dst,
+                                int32_t *tile_rows, int32_t *batch_groups, int32_t *split_k);
+int64_t me_conv_splitk_workspace_bytes(int64_t n_tgt, int32_t tile_rows, int32_t c_dst, int32_t split_k);
+int me_conv_target_bf16_ex(const uint16_t *src_feat_dev, int64_t n_src, int32_t c_src,
+                           const uint16_t *packed_w_dev, int64_t volume, int32_t c_dst,
+                           const int32_t *plan_src_dev, const int32_t *plan_dst_dev,
+                           const int32_t *batch_desc_dev, const int32_t *tile_bptr_dev,
+                           const int32_t *order_dev, uint16_t *dst_feat_dev,
+                           int64_t n_tgt, int32_t tile_rows, int32_t batch_groups, int32_t fused, int32_t split_k,
+                           void *workspace_dev, float *part_mean_dev, float *part_m2_dev, void *stream);
 int64_t me_conv_wgrad_workspace_bytes_bf16(const int64_t *k_offsets, int64_t volume, int32_t c_in, int32_t c_out);
 int me_conv_wgrad_bf16(const uint16_t *x_dev, int64_t n_in, int32_t c_in, const uint16_t *dy_dev, int64_t n_out,
                        int32_t c_out,

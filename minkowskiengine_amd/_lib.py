@@ -138,6 +138,10 @@ SIGNATURES = {
     "me_conv_stats_supported_bf16": (c_i32, [c_i32, c_i32]),
     "me_conv_target_bf16_stats": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp,
                                            c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "me_conv_plan_config_bf16_ex": (ctypes.c_int, [c_i64, c_i64, c_i64, c_i32, c_i32, _P_I32, _P_I32, _P_I32]),
+    "me_conv_splitk_workspace_bytes": (c_i64, [c_i64, c_i32, c_i32, c_i32]),
+    "me_conv_target_bf16_ex": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                              c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "me_conv_gather_supported_bf16": (c_i32, [c_i32, c_i32]),
     "me_conv_gather_weight_elems_bf16": (c_i64, [c_i64, c_i32, c_i32]),
     "me_conv_gather_pack_weights_bf16": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
@@ -175,6 +179,7 @@ DEBUG_SIGNATURES = {
     "me_debug_set_wgrad_mb": (None, [ctypes.c_int]),
     "me_debug_set_bf16_shape": (None, [ctypes.c_int, ctypes.c_int]),
     "me_debug_set_bf16_deep": (None, [ctypes.c_int]),
+    "me_debug_set_bf16_splitk": (None, [ctypes.c_int]),
     "me_debug_bf16_timing": (ctypes.c_int, [c_vp, c_i32]),
 }
 

@@ -1140,13 +1140,23 @@ def _timed(name, device, launch, flops=0.0):
     return r
 
 
-def plan_config(n_tgt, volume, n_pairs, c_src, c_dst, bf16=False, split=False):
-    """(tile_rows, batch_groups) of the tile plan for a (target rows, channels) problem."""
+def plan_config(n_tgt, volume, n_pairs, c_src, c_dst, bf16=False, split=False, with_split_k=False):
+    """(tile_rows, batch_groups) of the tile plan for a (target rows, channels) problem; with_split_k: + the number of
+    offset groups of a split-K launch (bf16 features on small maps, me_conv_plan_config_bf16_ex; 1 = not split)."""
     lib = _lib.load()
-    t, g = ctypes.c_int32(0), ctypes.c_int32(0)
-    fn = lib.me_conv_plan_config_bf16 if bf16 else (lib.me_conv_plan_config_f32x3 if split else lib.me_conv_plan_config)
-    _lib.check(fn(n_tgt, volume, n_pairs, c_src, c_dst, ctypes.byref(t), ctypes.byref(g)))
-    return _TILE_ROWS or int(t.value), _BATCH_GROUPS or int(g.value)
+    t, g, sk = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_int32(1)
+    if bf16:
+        _lib.check(lib.me_conv_plan_config_bf16_ex(n_tgt, volume, n_pairs, c_src, c_dst, ctypes.byref(t), ctypes.byref(g),
+                                                   ctypes.byref(sk)))
+        if _TILE_ROWS or _BATCH_GROUPS:      # geometry overrides (tests / tuning): the unsplit launch on them
+            _lib.check(lib.me_conv_plan_config_bf16(n_tgt, volume, n_pairs, c_src, c_dst, ctypes.byref(t),
+                                                    ctypes.byref(g)))
+            sk = ctypes.c_int32(1)
+    else:
+        fn = lib.me_conv_plan_config_f32x3 if split else lib.me_conv_plan_config
+        _lib.check(fn(n_tgt, volume, n_pairs, c_src, c_dst, ctypes.byref(t), ctypes.byref(g)))
+    out = (_TILE_ROWS or int(t.value), _BATCH_GROUPS or int(g.value))
+    return out + (int(sk.value),) if with_split_k else out
 
 
 def _conv_launch_cfg(km, target, n_tgt, c_src, c_dst, bf16):
@@ -1158,7 +1168,8 @@ def _conv_launch_cfg(km, target, n_tgt, c_src, c_dst, bf16):
     ck = (target, c_src, c_dst, bf16, split, _TILE_ROWS, _BATCH_GROUPS, _SPATIAL_TILES)
     cfg = km._launch_cache.get(ck)
     if cfg is None:
-        tile_rows, batch_groups = plan_config(n_tgt, km.volume, km.n_pairs, c_src, c_dst, bf16, split)
+        tile_rows, batch_groups, split_k = plan_config(n_tgt, km.volume, km.n_pairs, c_src, c_dst, bf16, split,
+                                                       with_split_k=True)
         tile_order = km._tile_order(target, matrix_bound=split)
         plan_src, plan_dst, batch_desc, tile_bptr, _ = km.plan(target, tile_rows, batch_groups, tile_order)
         elems = int((lib.me_conv_packed_weight_elems_bf16 if bf16 else
@@ -1169,8 +1180,10 @@ def _conv_launch_cfg(km, target, n_tgt, c_src, c_dst, bf16):
         n_tiles = -(-n_tgt // tile_rows)
         per_item = (km.n_pairs - min(km.n_in, km.n_out)) / max(1, (volume - 1) * n_tiles) if volume > 1 else 1e9
         fuse = {"1": True, "0": False}.get(_BF16_FUSE, per_item < _BF16_FUSE_MAX_PAIRS_PER_ITEM)
+        if split_k > 1:
+            fuse = False
         cfg = (tile_rows, batch_groups, plan_src, plan_dst, batch_desc, tile_bptr, order, elems,
-               _ptr(plan_src), _ptr(plan_dst), _ptr(batch_desc), _ptr(tile_bptr), _ptr(order), fuse)
+               _ptr(plan_src), _ptr(plan_dst), _ptr(batch_desc), _ptr(tile_bptr), _ptr(order), fuse, split_k)
         km._launch_cache[ck] = cfg
         if km._recipe is not None:
             km._recipe.append(("conv_cfg", km._recipe_key, target, c_src, c_dst, bool(bf16)))
@@ -1368,7 +1381,7 @@ def _conv_target(src_feat, kernel, km, target, n_tgt, name="conv_target", transp
                 out.data_ptr(), n_tgt, stream)), flops=2.0 * km.n_pairs * c_src * c_dst if KERNEL_TIMER else 0.0)
         return out
     split, cfg = _conv_launch_cfg(km, target, n_tgt, c_src, c_dst, bf16)
-    tile_rows, batch_groups, _, _, _, _, _, elems, p_src, p_dst, p_desc, p_bptr, p_order, fuse = cfg
+    tile_rows, batch_groups, _, _, _, _, _, elems, p_src, p_dst, p_desc, p_bptr, p_order, fuse, split_k = cfg
     flops = 2.0 * km.n_pairs * c_src * c_dst
     stream = _stream(dev)
     with _on(dev):
@@ -1382,22 +1395,27 @@ def _conv_target(src_feat, kernel, km, target, n_tgt, name="conv_target", transp
                 _lib.check(lib.me_conv_pack_weights_bf16(kernel.data_ptr(), 1 if kernel.dtype == torch.float32 else 0,
                                                          volume, c_src, c_dst, 1 if transposed else 0,
                                                          packed.data_ptr(), stream))
-            if (_CONV_BN_STATS and _BN_STATS_HINT[0] and name == "conv_forward" and n_tgt > 0
-                    and lib.me_conv_stats_supported_bf16(c_src, c_dst)):
-                # batch-norm statistics in the epilogue: the tiles' (mean, M2) partials ride along with the output
-                # (bn_stats picks them up when this very tensor is normalised next: _BN_PARTIALS)
+            # one entry point for the bf16 forward / dgrad launch (me_conv_target_bf16_ex): batch fusion, the batch-norm
+            # statistics of the output and split-K (small maps: G offset groups through an fp32 workspace) by argument
+            want_stats = bool(_CONV_BN_STATS and _BN_STATS_HINT[0] and name == "conv_forward" and n_tgt > 0
+                              and lib.me_conv_stats_supported_bf16(c_src, c_dst))
+            part = None
+            if want_stats:
+                # the tiles' (mean, M2) partials ride along with the output (bn_stats picks them up when this very
+                # tensor is normalised next: _BN_PARTIALS)
                 n_tiles = -(-n_tgt // tile_rows)
                 part = torch.empty(2, n_tiles, c_dst, dtype=torch.float32, device=dev)
-                _timed(name, dev, lambda: _lib.check(lib.me_conv_target_bf16_stats(
-                    src_feat.data_ptr(), src_feat.shape[0], c_src, packed.data_ptr(), km.volume, c_dst, p_src, p_dst,
-                    p_desc, p_bptr, p_order, out.data_ptr(), n_tgt, tile_rows, batch_groups, 1 if fuse else 0,
-                    part[0].data_ptr(), part[1].data_ptr(), stream)), flops=flops)
-                _bn_partials_put(out, part, tile_rows)
-                return out
-            fn = lib.me_conv_target_bf16_fused if fuse else lib.me_conv_target_bf16
-            _timed(name, dev, lambda: _lib.check(fn(
+            ws = None
+            if split_k > 1:
+                ws = torch.empty(int(lib.me_conv_splitk_workspace_bytes(n_tgt, tile_rows, c_dst, split_k)) // 4,
+                                 dtype=torch.float32, device=dev)
+            _timed(name, dev, lambda: _lib.check(lib.me_conv_target_bf16_ex(
                 src_feat.data_ptr(), src_feat.shape[0], c_src, packed.data_ptr(), km.volume, c_dst, p_src, p_dst,
-                p_desc, p_bptr, p_order, out.data_ptr(), n_tgt, tile_rows, batch_groups, stream)), flops=flops)
+                p_desc, p_bptr, p_order, out.data_ptr(), n_tgt, tile_rows, batch_groups, 1 if fuse else 0, split_k,
+                _ptr(ws), part[0].data_ptr() if want_stats else None, part[1].data_ptr() if want_stats else None,
+                stream)), flops=flops)
+            if want_stats:
+                _bn_partials_put(out, part, tile_rows)
             return out
         _check(kernel.dtype == torch.float32, "float32 features need a float32 kernel, got", kernel.dtype)
         if split:

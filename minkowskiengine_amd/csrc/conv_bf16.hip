@@ -165,13 +165,22 @@ __host__ __device__ constexpr int conv_bf16_waves_per_simd(int nc, int kc) {
 // weight registers per lane; a coarse level's 128 - 256 tiles): nothing else hides the L2 latency of the next
 // batch's 32 - 64 KB weight slice there, and a batch of one or two groups lasted one memory round trip (2 us on the
 // 5k-voxel 256 -> 256 layers for ~0.2 us of matrix work).  Same sums in the same order: bit-identical to the plain loop.
-template <int NC, int KC, bool EXACT, bool SMALL, bool FUSE = false, bool DEEP = false>
+//
+// SPLITK (round 4): the coarse MinkUNet levels (256 -> 256 channels on 5k voxels: 128 tiles of 39
+// rows) stream the WHOLE packed weight tensor once per tile — 27 x 64 KB per workgroup, 453 MB of L2 -> CU traffic for a
+// 3.5 MB tensor, and one L2 round trip per batch of one or two 16-row groups.  With SPLITK the launch has gridDim.z = G
+// offset groups: workgroup (tile, slab, g) walks only the batches of offsets [g K / G, (g + 1) K / G) of a G-times
+// taller tile (same number of workgroups, 1 / G of the weight bytes and fuller batches per workgroup), and stores its
+// fp32 accumulator tile to `partial[g]`; k_conv_splitk_reduce adds the G partial tiles in group order, rounds to bf16
+// once and writes the rows (and the batch-norm statistics of the tile).  The sum of a target row is
+// ((offsets of group 0) + (group 1)) + ... in fp32: a fixed order — reproducible, not the unsplit kernel's order.
+template <int NC, int KC, bool EXACT, bool SMALL, bool FUSE = false, bool DEEP = false, bool SPLITK = false>
 __global__ __launch_bounds__(NC * 4, DEEP ? 2 : conv_bf16_waves_per_simd(NC, KC)) void k_conv_tile_bf16(
     const __bf16 *__restrict__ src, int c_src, const bf16x8 *__restrict__ wp, int c_dst,
     const int32_t *__restrict__ plan_src, const int32_t *__restrict__ plan_dst,
     const int32_t *__restrict__ batch_desc, const int32_t *__restrict__ tile_bptr,
     const int32_t *__restrict__ order, __bf16 *__restrict__ dst, int64_t n_tgt, int tile_rows, int batch_groups,
-    int fuse, float *__restrict__ stat_mean, float *__restrict__ stat_m2) {
+    int fuse, float *__restrict__ stat_mean, float *__restrict__ stat_m2, float *__restrict__ partial, int volume) {
   typedef int i32x2 __attribute__((ext_vector_type(2)));
   constexpr int WAVES = NC / 16;
   constexpr int NT = WAVES * 64;
@@ -230,8 +239,29 @@ __global__ __launch_bounds__(NC * 4, DEEP ? 2 : conv_bf16_waves_per_simd(NC, KC)
                     ? order[(int64_t)tile * tile_rows + r] : 0;
   }
 
-  const int b0 = tile_bptr[tile];
-  const int nb = tile_bptr[tile + 1] - b0;
+  int b0 = tile_bptr[tile];
+  int nb = tile_bptr[tile + 1] - b0;
+  if constexpr (SPLITK) {
+    // the tile's batches are listed by ascending offset (k_plan_fill): this workgroup's offsets are a sub-range
+    const int k_lo = (int)(((int64_t)blockIdx.z * volume) / gridDim.z);
+    const int k_hi = (int)(((int64_t)(blockIdx.z + 1) * volume) / gridDim.z);
+    int32_t *s_rng = reinterpret_cast<int32_t *>(smem + conv_bf16_lds_bytes(NC, KC, tile_rows, batch_groups));
+    if (tid == 0) {
+      s_rng[0] = nb;
+      s_rng[1] = nb;
+    }
+    __syncthreads();
+    for (int b = tid; b < nb; b += NT) {
+      const int k = (int)((uint32_t)batch_desc[2 * (int64_t)(b0 + b) + 1] >> 8);
+      const int kp = b > 0 ? (int)((uint32_t)batch_desc[2 * (int64_t)(b0 + b - 1) + 1] >> 8) : -1;
+      if (k >= k_lo && kp < k_lo) s_rng[0] = b;
+      if (k >= k_hi && kp < k_hi) s_rng[1] = b;
+    }
+    __syncthreads();
+    const int r_lo = s_rng[0], r_hi = s_rng[1];
+    b0 += r_lo;
+    nb = r_hi - r_lo;
+  }
 
   // Batch fusion (round 2).  On sparse maps most (tile, offset) items hold ONE 16-row group — MinkUNet's stride-1
   // level: 7 - 11 pairs per item; config 5: 11 — and a batch of one group pays the two barriers, the stage write,
@@ -494,6 +524,19 @@ __global__ __launch_bounds__(NC * 4, DEEP ? 2 : conv_bf16_waves_per_simd(NC, KC)
   }
   __syncthreads();
 
+  if constexpr (SPLITK) {
+    // the fp32 accumulator tile of this offset group, rows in tile (position) order; k_conv_splitk_reduce finishes
+    const int64_t rows_all = (int64_t)gridDim.x * tile_rows;
+    float *pt = partial + ((int64_t)blockIdx.z * rows_all + (int64_t)tile * tile_rows) * c_dst + col_base;
+    for (int x = tid; x < tile_rows * NC / 4; x += NT) {
+      const int row = x / (NC / 4);
+      const int c4 = x % (NC / 4);
+      if (col_base + c4 * 4 < c_dst)
+        *reinterpret_cast<f32x4 *>(pt + (int64_t)row * c_dst + c4 * 4) =
+            *reinterpret_cast<const f32x4 *>(&s_acc[row * ACC_LD + c4 * 4]);
+    }
+    return;
+  }
   // every target row of the tile is written exactly once, rounded to bf16 (RNE)
   const int64_t row0 = (int64_t)tile * tile_rows;
   const int rows_here = (int)min((int64_t)tile_rows, n_tgt - row0);
@@ -596,6 +639,102 @@ __global__ __launch_bounds__(NC * 4, DEEP ? 2 : conv_bf16_waves_per_simd(NC, KC)
 #endif
 #undef ME_TICK
 #undef ME_COUNT
+}
+
+// Second phase of a SPLITK launch: out[row] = bf16(sum over offset groups g of partial[g][row]) — fp32 adds in group
+// order, one rounding — for one (tile, column slab) per workgroup, and the tile's batch-norm statistics exactly as the
+// unsplit kernel's store loop forms them (shifted by the tile's first row; thread's rows ascending, xor-shuffle tree,
+// waves ascending).  HBM / L2 streaming: G x tile x NC x 4 bytes in, tile x NC x 2 out.
+template <int NC, int G>
+__global__ __launch_bounds__(NC * 4) void k_conv_splitk_reduce(const float *__restrict__ partial, int c_dst,
+                                                              const int32_t *__restrict__ order,
+                                                              __bf16 *__restrict__ dst, int64_t n_tgt, int tile_rows,
+                                                              float *__restrict__ stat_mean,
+                                                              float *__restrict__ stat_m2) {
+  constexpr int WAVES = NC / 16, NT = WAVES * 64, G4 = NC / 4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *s_st = reinterpret_cast<float *>(smem);                 // [WAVES][G4][8]
+  float *s_shift = s_st + WAVES * G4 * 8;                        // [NC]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = blockIdx.x;
+  const int col_base = blockIdx.y * NC;
+  const int64_t row0 = (int64_t)tile * tile_rows;
+  const int rows_here = (int)min((int64_t)tile_rows, n_tgt - row0);
+  const int64_t gstride = (int64_t)gridDim.x * tile_rows * c_dst;   // one offset group's partial matrix
+  const bool do_stats = stat_mean != nullptr;                       // uniform
+  auto row_sum = [&](int row, int cc) {
+    const float *p = partial + (row0 + row) * c_dst + cc;
+    f32x4 v[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) v[g] = *reinterpret_cast<const f32x4 *>(p + g * gstride);
+    f32x4 a = v[0];
+#pragma unroll
+    for (int g = 1; g < G; ++g) a += v[g];
+    return a;
+  };
+  float st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+  const int my_c4 = tid % G4;
+  const bool col_ok = col_base + my_c4 * 4 < c_dst;
+  if (do_stats && col_ok) {
+    const f32x4 v0 = row_sum(0, col_base + my_c4 * 4);             // row 0 of the tile
+#pragma unroll
+    for (int t = 0; t < 4; ++t) sh[t] = (float)(__bf16)v0[t];
+    if (tid < G4) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) s_shift[tid * 4 + t] = sh[t];
+    }
+  }
+  for (int x = tid; x < tile_rows * NC / 4; x += NT) {
+    const int row = x / G4;            // (x % G4 == tid % G4: NT is a multiple of G4)
+    const int cc = col_base + my_c4 * 4;
+    if (row < rows_here && col_ok) {
+      const f32x4 v = row_sum(row, cc);
+      const bf16x4 vb = bf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+      if (do_stats) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float d = (float)vb[t] - sh[t];
+          st1[t] += d;
+          st2[t] = fmaf(d, d, st2[t]);
+        }
+      }
+      const int64_t grow = order ? (int64_t)order[row0 + row] : row0 + row;
+      *reinterpret_cast<bf16x4 *>(dst + grow * c_dst + cc) = vb;
+    }
+  }
+  if (do_stats) {
+#pragma unroll
+    for (int off = G4; off < 64; off <<= 1) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        st1[t] += __shfl_xor(st1[t], off, 64);
+        st2[t] += __shfl_xor(st2[t], off, 64);
+      }
+    }
+    if (lane < G4) {
+      float *w = s_st + (wave * G4 + lane) * 8;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        w[t] = st1[t];
+        w[4 + t] = st2[t];
+      }
+    }
+    __syncthreads();
+    if (tid < NC && col_base + tid < c_dst) {
+      const int c4 = tid >> 2, t = tid & 3;
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) {
+        a += s_st[(w * G4 + c4) * 8 + t];
+        b += s_st[(w * G4 + c4) * 8 + 4 + t];
+      }
+      const float shift = s_shift[tid];
+      const float cnt = (float)rows_here, m = a / cnt;
+      stat_mean[(int64_t)tile * c_dst + col_base + tid] = shift + m;
+      stat_m2[(int64_t)tile * c_dst + col_base + tid] = fmaxf(b - a * m, 0.f);
+    }
+  }
 }
 
 // =================================================================================================
@@ -781,6 +920,8 @@ struct ConvVariantBf16 {
 
 int g_bf16_nc = 0, g_bf16_kc = 0;   // me_debug_set_bf16_shape: tuning overrides of the slab width / chunk depth (0 = policy)
 int g_bf16_deep = -1;               // me_debug_set_bf16_deep: -1 policy, 0 never, 1 wherever instantiated
+int g_bf16_splitk = -1;             // me_debug_set_bf16_splitk: -1 policy, 0 / 1 never, G >= 2: G offset groups where eligible
+constexpr int kSplitKMaxTileRows = 64;   // policy: split launches whose unsplit tiles are at most this tall
 
 static ConvVariantBf16 conv_variant_bf16(int c_src, int c_dst) {
   ConvVariantBf16 v;
@@ -828,12 +969,14 @@ static int launch_conv_tile_bf16(const __bf16 *src, int c_src, const bf16x8 *wp,
                                  const int32_t *plan_src, const int32_t *plan_dst, const int32_t *batch_desc,
                                  const int32_t *tile_bptr, const int32_t *order, __bf16 *dst, int64_t n_tgt,
                                  int tile_rows, int batch_groups, hipStream_t stream, bool small, bool fuse = false,
-                                 float *stat_mean = nullptr, float *stat_m2 = nullptr) {
-  const int lds = conv_bf16_lds_bytes(NC, KC, tile_rows, batch_groups);
+                                 float *stat_mean = nullptr, float *stat_m2 = nullptr, int split_k = 1,
+                                 float *partial = nullptr, int volume = 0) {
+  const int lds = conv_bf16_lds_bytes(NC, KC, tile_rows, batch_groups) + (split_k > 1 ? 16 : 0);
   ME_CHECK(lds <= kLdsBudget, "tile_rows / batch_groups too large for the LDS of one workgroup");
   const bool exact = (c_src % KC) == 0;
   typedef void (*kernel_t)(const __bf16 *, int, const bf16x8 *, int, const int32_t *, const int32_t *, const int32_t *,
-                           const int32_t *, const int32_t *, __bf16 *, int64_t, int, int, int, float *, float *);
+                           const int32_t *, const int32_t *, __bf16 *, int64_t, int, int, int, float *, float *, float *,
+                           int);
   kernel_t fn = small ? (exact ? &k_conv_tile_bf16<NC, KC, true, true> : &k_conv_tile_bf16<NC, KC, false, true>)
                       : (exact ? &k_conv_tile_bf16<NC, KC, true, false> : &k_conv_tile_bf16<NC, KC, false, false>);
   if constexpr (NC <= 96 && KC <= 128) {   // batch fusion: four- and six-wave workgroups (sparse maps of narrow layers)
@@ -863,17 +1006,50 @@ static int launch_conv_tile_bf16(const __bf16 *src, int c_src, const bf16x8 *wp,
       }
     }
   }
-  static bool attr_set[16] = {};  // per instantiation
-  const int which = (deep ? 8 : 0) + (fuse ? 4 : 0) + (small ? 2 : 0) + (exact ? 1 : 0);
+  // split-K (see k_conv_tile_bf16): eight-wave deep-pipeline launches only; the statistics move to the reduce kernel
+  bool splitk = false;
+  if constexpr (NC == 128 && (KC == 64 || KC == 128 || KC == 256)) {
+    // (a plan made for split-K is an ordinary plan with taller tiles: a launch that turns out not to be eligible —
+    // 64-bit gather addresses, deep pipeline switched off — runs it unsplit)
+    if (split_k > 1 && deep && !fuse && volume >= split_k && c_dst % 16 == 0 && split_k <= 8) {
+      ME_CHECK(partial != nullptr, "split-K needs its workspace (me_conv_splitk_workspace_bytes)");
+      fn = &k_conv_tile_bf16<NC, KC, true, true, false, true, true>;
+      splitk = true;
+    }
+  }
+  if (!splitk) split_k = 1;
+  static bool attr_set[32] = {};  // per instantiation
+  const int which = (splitk ? 16 : 0) + (deep ? 8 : 0) + (fuse ? 4 : 0) + (small ? 2 : 0) + (exact ? 1 : 0);
   if (lds > 48 * 1024 && !attr_set[which]) {
     ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                kLdsBudget));
     attr_set[which] = true;
   }
-  const dim3 grid((unsigned)ceil_div(n_tgt, tile_rows), (unsigned)slabs);
+  const unsigned n_tiles = (unsigned)ceil_div(n_tgt, tile_rows);
+  const dim3 grid(n_tiles, (unsigned)slabs, (unsigned)(splitk ? split_k : 1));
   hipLaunchKernelGGL(fn, grid, dim3(NC * 4), (size_t)lds, stream, src, c_src, wp, c_dst, plan_src, plan_dst, batch_desc,
-                     tile_bptr, order, dst, n_tgt, tile_rows, batch_groups, g_conv_variant == 7 ? 0 : 1, stat_mean, stat_m2);
+                     tile_bptr, order, dst, n_tgt, tile_rows, batch_groups, g_conv_variant == 7 ? 0 : 1,
+                     splitk ? nullptr : stat_mean, splitk ? nullptr : stat_m2, partial, volume);
   ME_LAUNCH_CHECK();
+  if constexpr (NC == 128) {
+    if (splitk) {
+      typedef void (*reduce_t)(const float *, int, const int32_t *, __bf16 *, int64_t, int, float *, float *);
+      reduce_t rf = nullptr;
+      switch (split_k) {
+        case 2: rf = &k_conv_splitk_reduce<128, 2>; break;
+        case 3: rf = &k_conv_splitk_reduce<128, 3>; break;
+        case 4: rf = &k_conv_splitk_reduce<128, 4>; break;
+        case 5: rf = &k_conv_splitk_reduce<128, 5>; break;
+        case 6: rf = &k_conv_splitk_reduce<128, 6>; break;
+        case 7: rf = &k_conv_splitk_reduce<128, 7>; break;
+        default: rf = &k_conv_splitk_reduce<128, 8>; break;
+      }
+      constexpr int kReduceLds = (128 / 16) * (128 / 4) * 8 * 4 + 128 * 4;
+      hipLaunchKernelGGL(rf, dim3(n_tiles, (unsigned)slabs), dim3(512), (size_t)kReduceLds, stream, partial, c_dst, order,
+                         dst, n_tgt, tile_rows, stat_mean, stat_m2);
+      ME_LAUNCH_CHECK();
+    }
+  }
   return 0;
 }
 
@@ -900,6 +1076,47 @@ int me_conv_plan_config_bf16(int64_t n_tgt, int64_t volume, int64_t n_pairs, int
   *tile_rows = plan_tile_rows(s, n_tgt, volume, n_pairs);
   return 0;
 }
+
+// Split-K policy (see k_conv_tile_bf16): a launch whose tiles are short because the map is small — 128 tiles of 39 rows
+// for 256 -> 256 channels on 4,977 voxels — spends its time streaming the packed weights (27 x 64 KB per workgroup at
+// the ~42 B / clk / CU all CUs get out of the L2s together: scripts/ubench/l2_stream.hip, 17.5 us per walk).  G offset
+// groups on G-times taller tiles keep the workgroup count and divide the weight bytes of a workgroup by G.
+int me_conv_plan_config_bf16_ex(int64_t n_tgt, int64_t volume, int64_t n_pairs, int32_t c_src, int32_t c_dst,
+                                int32_t *tile_rows, int32_t *batch_groups, int32_t *split_k) {
+  ME_CHECK(split_k != nullptr, "output pointers must not be null");
+  *split_k = 1;
+  const int rc = me_conv_plan_config_bf16(n_tgt, volume, n_pairs, c_src, c_dst, tile_rows, batch_groups);
+  if (rc != 0 || n_tgt <= 0 || volume < 2 || g_bf16_splitk == 0 || g_bf16_splitk == 1 || g_bf16_deep == 0) return rc;
+  const ConvVariantBf16 v = conv_variant_bf16(c_src, c_dst);
+  if (v.nc != 128 || (v.kc != 64 && v.kc != 128 && v.kc != 256) || c_src % v.kc != 0 || c_dst % 16 != 0) return 0;
+  const int t0 = *tile_rows;
+  const int64_t tiles0 = ceil_div(n_tgt, t0);
+  const int gmax = (int)std::min<int64_t>(volume, 8);
+  int g = 1;
+  if (g_bf16_splitk >= 2) {
+    g = std::min(g_bf16_splitk, gmax);
+  } else if (t0 <= kSplitKMaxTileRows && tiles0 * v.slabs <= (int64_t)device_cu_count() * 3 / 2) {
+    g = std::min(gmax, std::max(1, 240 / t0));
+  }
+  if (g < 2) return 0;
+  // the tallest tile the LDS holds next to a full stage buffer
+  const int cap = std::min<int>(ME_MAX_TILE_ROWS,
+                                (kLdsBudget - 16 - ME_MAX_BATCH_GROUPS * 16 * ((v.kc + 16) * 2 + 4)) / ((v.nc + kAccPad) * 4) - 1);
+  const int64_t tiles = std::max<int64_t>(ceil_div(tiles0, g), ceil_div(n_tgt, cap));
+  const int t = (int)std::max<int64_t>(ME_GROUP_ROWS, ceil_div(n_tgt, tiles));
+  if (t <= t0) return 0;
+  *tile_rows = t;
+  *batch_groups = ME_MAX_BATCH_GROUPS;
+  *split_k = g;
+  return 0;
+}
+
+int64_t me_conv_splitk_workspace_bytes(int64_t n_tgt, int32_t tile_rows, int32_t c_dst, int32_t split_k) {
+  if (split_k <= 1 || n_tgt <= 0 || tile_rows <= 0 || c_dst <= 0) return 0;
+  return (int64_t)split_k * ceil_div(n_tgt, tile_rows) * tile_rows * c_dst * 4;
+}
+
+void me_debug_set_bf16_splitk(int g) { g_bf16_splitk = g; }
 
 int64_t me_conv_packed_weight_elems_bf16(int64_t volume, int32_t c_src, int32_t c_dst) {
   if (volume <= 0 || c_src <= 0 || c_dst <= 0) return 0;
@@ -964,9 +1181,9 @@ static int conv_target_bf16(const uint16_t *src_, int64_t n_src, int32_t c_src, 
                             int32_t c_dst, const int32_t *plan_src, const int32_t *plan_dst,
                             const int32_t *batch_desc, const int32_t *tile_bptr, const int32_t *order, uint16_t *dst_,
                             int64_t n_tgt, int32_t tile_rows, int32_t batch_groups, void *stream_, bool fuse,
-                            float *stat_mean = nullptr, float *stat_m2 = nullptr) {
+                            float *stat_mean = nullptr, float *stat_m2 = nullptr, int split_k = 1,
+                            float *partial = nullptr) {
   hipStream_t stream = (hipStream_t)stream_;
-  (void)volume;
   ME_CHECK((stat_mean == nullptr) == (stat_m2 == nullptr), "both statistics buffers or none");
   // 32-bit byte offsets with a 24-bit row multiply need a source matrix below 4 GiB
   const bool small = n_src > 0 && n_src < (1ll << 24) && n_src * c_src * 2 < (1ll << 32) && g_conv_variant != 6;
@@ -983,7 +1200,7 @@ static int conv_target_bf16(const uint16_t *src_, int64_t n_src, int32_t c_src, 
 #define ME_CONV_CASE(NCV, KCV)                                                                                   \
   return launch_conv_tile_bf16<NCV, KCV>(src, c_src, wp, c_dst, v.slabs, plan_src, plan_dst, batch_desc, tile_bptr, \
                                          order, dst, n_tgt, tile_rows, batch_groups, stream, small, fuse, stat_mean,   \
-                                         stat_m2)
+                                         stat_m2, split_k, partial, (int)volume)
   if (v.nc == 32) {
     if (v.kc == 128) ME_CONV_CASE(32, 128);
     if (v.kc == 96) ME_CONV_CASE(32, 96);
@@ -1048,6 +1265,19 @@ int me_conv_target_bf16_stats(const uint16_t *src, int64_t n_src, int32_t c_src,
 
 
 extern "C" {
+
+int me_conv_target_bf16_ex(const uint16_t *src, int64_t n_src, int32_t c_src, const uint16_t *wp, int64_t volume,
+                           int32_t c_dst, const int32_t *plan_src, const int32_t *plan_dst, const int32_t *batch_desc,
+                           const int32_t *tile_bptr, const int32_t *order, uint16_t *dst, int64_t n_tgt,
+                           int32_t tile_rows, int32_t batch_groups, int32_t fused, int32_t split_k, void *workspace,
+                           float *part_mean, float *part_m2, void *stream) {
+  ME_CHECK(split_k >= 1 && split_k <= 8, "split_k out of range");
+  ME_CHECK(split_k == 1 || workspace != nullptr, "split-K needs its workspace (me_conv_splitk_workspace_bytes)");
+  ME_CHECK(part_mean == nullptr || me_conv_stats_supported_bf16(c_src, c_dst), "no statistics epilogue for this tile shape");
+  return conv_target_bf16(src, n_src, c_src, wp, volume, c_dst, plan_src, plan_dst, batch_desc, tile_bptr, order, dst,
+                          n_tgt, tile_rows, batch_groups, stream, fused != 0, part_mean, part_m2, split_k,
+                          reinterpret_cast<float *>(workspace));
+}
 
 int32_t me_conv_gather_supported_bf16(int32_t c_src, int32_t c_dst) { return conv_gather_cb(c_src, c_dst) > 0 ? 1 : 0; }
 

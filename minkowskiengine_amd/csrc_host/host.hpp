@@ -130,6 +130,7 @@ struct ConvCfg {          // launch geometry of a (kernel map side, channel shap
   Tensor order;           // may be undefined
   int64_t elems;
   bool fuse, split;
+  int split_k = 1;        // offset groups of a split-K launch (bf16 features on small maps; 1: not split)
 };
 struct WgradCfg {
   std::vector<int64_t> koffs;

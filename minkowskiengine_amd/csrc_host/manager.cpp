@@ -320,13 +320,17 @@ const ConvCfg &KernelMap::conv_cfg(const std::string &target, int64_t n_tgt, int
   if (it != conv_cfgs.end()) return it->second;
   // the plan geometry depends on the pair count (density): the one host value a first launch on a new map waits for
   const int64_t np = n_pairs();
-  int32_t t = 0, g = 0;
-  me_ok((bf16 ? me_conv_plan_config_bf16 : (split ? me_conv_plan_config_f32x3 : me_conv_plan_config))(
-      n_tgt, volume, np, c_src, c_dst, &t, &g));
+  int32_t t = 0, g = 0, sk = 1;
+  if (bf16 && !pol.tile_rows && !pol.batch_groups)
+    me_ok(me_conv_plan_config_bf16_ex(n_tgt, volume, np, c_src, c_dst, &t, &g, &sk));   // may answer a split-K geometry
+  else
+    me_ok((bf16 ? me_conv_plan_config_bf16 : (split ? me_conv_plan_config_f32x3 : me_conv_plan_config))(
+        n_tgt, volume, np, c_src, c_dst, &t, &g));
   ConvCfg c;
   c.tile_rows = pol.tile_rows ? pol.tile_rows : t;
   c.batch_groups = pol.batch_groups ? pol.batch_groups : g;
   c.split = split;
+  c.split_k = sk;
   const std::string to = tile_order(target, split);
   c.plan = plan(target, c.tile_rows, c.batch_groups, to);
   c.elems = (bf16 ? me_conv_packed_weight_elems_bf16
@@ -336,6 +340,7 @@ const ConvCfg &KernelMap::conv_cfg(const std::string &target, int64_t n_tgt, int
   const double per_item = volume > 1 ? (double)(np - std::min(n_in, n_out)) / std::max<int64_t>(1, (volume - 1) * n_tiles)
                                      : 1e9;
   c.fuse = pol.bf16_fuse == "1" ? true : (pol.bf16_fuse == "0" ? false : per_item < 24.0);
+  if (c.split_k > 1) c.fuse = false;
   if (auto lg = log.lock())
     lg->push_back("conv_cfg;" + log_key + ";" + target + ";" + std::to_string(c_src) + ";" + std::to_string(c_dst) + ";" +
                   (bf16 ? "1" : "0"));

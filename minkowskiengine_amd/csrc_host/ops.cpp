@@ -305,28 +305,30 @@ static Tensor conv_target(const Tensor &src, const Tensor &kernel, KernelMap &km
       me_ok(me_conv_pack_weights_bf16(kernel.data_ptr(), kernel.scalar_type() == at::kFloat ? 1 : 0, volume, c_src, c_dst,
                                       transposed ? 1 : 0, ptr<uint16_t>(packed), st));
     }
-    // (forward launches only: target "out", weights not transposed — the input gradient feeds no batch norm)
-    if (!transposed && target == "out" && g_conv_bn_stats_hint && conv_bn_stats_enabled() &&
-        me_conv_stats_supported_bf16(c_src, c_dst)) {
-      // batch-norm statistics in the epilogue (csrc/conv_bf16.hip): the tiles' partials ride along with the output
-      const int64_t tiles = (n_tgt + cfg.tile_rows - 1) / cfg.tile_rows;
-      Tensor part = at::empty({2, tiles, (int64_t)c_dst}, at::TensorOptions().dtype(at::kFloat).device(dev));
-      {
-        ScopedTimer tm(timed_name, flops, st);
-        me_ok(me_conv_target_bf16_stats(
-            ptr<uint16_t>(src), src.size(0), c_src, ptr<uint16_t>(packed), km.volume, c_dst, ptr<int32_t>(p.plan_src),
-            ptr<int32_t>(p.plan_dst), ptr<int32_t>(p.batch_desc), ptr<int32_t>(p.tile_bptr), ptr<int32_t>(cfg.order),
-            ptr<uint16_t>(out), n_tgt, cfg.tile_rows, cfg.batch_groups, cfg.fuse ? 1 : 0, ptr<float>(part),
-            ptr<float>(part) + tiles * c_dst, st));
-      }
-      bn_partials_put(out, part, cfg.tile_rows);
-      return out;
+    // One entry point for the bf16 forward / dgrad launch (me_conv_target_bf16_ex): batch fusion, the batch-norm
+    // statistics of the output (forward launches only: target "out", weights not transposed — the input gradient feeds
+    // no batch norm) and split-K (small maps: offset groups through an fp32 workspace) by argument.
+    const bool want_stats = !transposed && target == "out" && g_conv_bn_stats_hint && conv_bn_stats_enabled() &&
+                            me_conv_stats_supported_bf16(c_src, c_dst);
+    Tensor part, ws;
+    int64_t tiles = 0;
+    if (want_stats) {
+      // the tiles' (mean, M2) partials ride along with the output (bn_stats consumes them: bn_partials_take)
+      tiles = (n_tgt + cfg.tile_rows - 1) / cfg.tile_rows;
+      part = at::empty({2, tiles, (int64_t)c_dst}, at::TensorOptions().dtype(at::kFloat).device(dev));
     }
-    ScopedTimer tm(timed_name, flops, st);
-    me_ok((cfg.fuse ? me_conv_target_bf16_fused : me_conv_target_bf16)(
-        ptr<uint16_t>(src), src.size(0), c_src, ptr<uint16_t>(packed), km.volume, c_dst, ptr<int32_t>(p.plan_src),
-        ptr<int32_t>(p.plan_dst), ptr<int32_t>(p.batch_desc), ptr<int32_t>(p.tile_bptr), ptr<int32_t>(cfg.order),
-        ptr<uint16_t>(out), n_tgt, cfg.tile_rows, cfg.batch_groups, st));
+    if (cfg.split_k > 1)
+      ws = at::empty({me_conv_splitk_workspace_bytes(n_tgt, cfg.tile_rows, c_dst, cfg.split_k) / 4},
+                     at::TensorOptions().dtype(at::kFloat).device(dev));
+    {
+      ScopedTimer tm(timed_name, flops, st);
+      me_ok(me_conv_target_bf16_ex(
+          ptr<uint16_t>(src), src.size(0), c_src, ptr<uint16_t>(packed), km.volume, c_dst, ptr<int32_t>(p.plan_src),
+          ptr<int32_t>(p.plan_dst), ptr<int32_t>(p.batch_desc), ptr<int32_t>(p.tile_bptr), ptr<int32_t>(cfg.order),
+          ptr<uint16_t>(out), n_tgt, cfg.tile_rows, cfg.batch_groups, cfg.fuse ? 1 : 0, cfg.split_k, vptr(ws),
+          want_stats ? ptr<float>(part) : nullptr, want_stats ? ptr<float>(part) + tiles * c_dst : nullptr, st));
+    }
+    if (want_stats) bn_partials_put(out, part, cfg.tile_rows);
     return out;
   }
   check(kernel.scalar_type() == at::kFloat, "float32 features need a float32 kernel");

@@ -19,6 +19,9 @@ if os.environ.get("WGRAD_MB"):       # 4 / 8: input-channel blocks per workgroup
 if os.environ.get("BF16_DEEP"):      # -1 policy / 0 never / 1 wherever instantiated: deep pipeline of the eight-wave kernels
     from minkowskiengine_amd import _lib
     _lib.load().me_debug_set_bf16_deep(int(os.environ["BF16_DEEP"]))
+if os.environ.get("BF16_SPLITK"):    # -1 policy / 0 never / G: offset groups of the split-K launches (small maps)
+    from minkowskiengine_amd import _lib
+    _lib.load().me_debug_set_bf16_splitk(int(os.environ["BF16_SPLITK"]))
 dev = torch.device("cuda:0")
 dt = torch.bfloat16 if os.environ.get("DTYPE", "bf16") == "bf16" else torch.float32
 coords = MU.synthetic_scene(200000, seed=0).to(dev)

@@ -15,6 +15,19 @@ from helpers import assert_close, make_cloud
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture
+def no_split_k():
+    """The bit-identity tests compare schedules of the UNSPLIT kernel (slab width, deep pipeline, batch fusion): a
+    split-K launch (small maps, round 4) adds its offset groups in another order.  Off for the test, policy after."""
+    from minkowskiengine_amd import _lib
+    lib = _lib.load()
+    lib.me_debug_set_bf16_splitk(0)
+    try:
+        yield
+    finally:
+        lib.me_debug_set_bf16_splitk(-1)
+
+
 def bf16_round(t):
     return t.to(torch.bfloat16).to(torch.float32)
 
@@ -186,7 +199,7 @@ def test_bf16_config2_full_size(device, host_layer):
 
 @pytest.mark.parametrize("n,extent,cin,cout,ks,D", [(6000, 40, 96, 96, 3, 3), (6000, 40, 32, 64, 3, 3), (4000, 14, 64, 128, 3, 3),
                                                      (3000, 10, 32, 64, 3, 4), (5000, 40, 128, 96, 3, 3)])
-def test_batch_fusion_is_bit_identical(device, monkeypatch, n, extent, cin, cout, ks, D):
+def test_batch_fusion_is_bit_identical(device, no_split_k, monkeypatch, n, extent, cin, cout, ks, D):
     """k_conv_tile_bf16 stages consecutive small batches of a tile together (up to four offsets per barrier pair on
     sparse maps); the sub-batches are multiplied and accumulated in the order of the unfused loop, so forward and
     input-gradient results must be BIT-identical with fusion (me_conv_target_bf16_fused) and without (me_conv_target_bf16)."""
@@ -239,7 +252,7 @@ def test_bf16_odd_channels_without_padding(device, monkeypatch, n, extent, D, ci
                                               (64, 128, ((64, 64), (128, 64))), (384, 256, ((64, 128), (128, 128))),
                                               (96, 96, ((64, 96), (96, 96))), (128, 96, ((64, 128), (96, 128))),
                                               (256, 128, ((128, 128), (128, 256)))])
-def test_bf16_slab_width_does_not_change_a_bit(device, cin, cout, shapes):
+def test_bf16_slab_width_does_not_change_a_bit(device, no_split_k, cin, cout, shapes):
     """96- and 128-column workgroups (six / eight waves; the defaults where they tile the output channels) against
     64-column ones at the same source-channel chunk: the columns of a target row are independent sums in the same
     order, so forward and input gradient are bit-identical; a deeper chunk (256 against 128) regroups the fp32 partial
@@ -281,7 +294,7 @@ def test_bf16_slab_width_does_not_change_a_bit(device, cin, cout, shapes):
                                                      (2000, 9, 256, 256, 2, 4), (900, 30, 512, 256, 3, 3),
                                                      (6000, 40, 96, 96, 3, 3), (4000, 14, 64, 64, 3, 3), (3000, 10, 32, 64, 3, 4),
                                                      (6000, 40, 128, 96, 3, 3), (5000, 30, 32, 32, 3, 3), (3000, 12, 192, 128, 3, 3)])
-def test_bf16_deep_pipeline_is_bit_identical(device, n, extent, cin, cout, ks, D):
+def test_bf16_deep_pipeline_is_bit_identical(device, no_split_k, n, extent, cin, cout, ks, D):
     """k_conv_tile_bf16<.., DEEP>: gathers and weights of the batch AFTER NEXT in flight (two register sets, loop
     unrolled by two).  Same batches, same MFMAs in the same order: forward and input gradient must be bit-identical with
     the pipeline forced on (1), off (0) and chosen by the policy (-1), on dense and sparse (batch-fused) maps, tiles of
@@ -344,3 +357,88 @@ def test_wgrad_bf16_128_channel_blocks_match_the_64_channel_ones(device, n, exte
     want = O.conv_backward(x.numpy(), gy.numpy(), w.numpy(), okm)[1]
     assert_close(res[4], want)
     assert_close(res[8], want)
+
+
+@pytest.mark.parametrize("n,extent,cin,cout,ks,D", [(1500, 10, 256, 256, 3, 3), (900, 8, 128, 256, 3, 3), (2500, 12, 256, 128, 3, 3),
+                                                     (300, 6, 256, 256, 3, 3), (5000, 16, 128, 128, 3, 3), (1200, 9, 384, 256, 3, 3),
+                                                     (2000, 9, 64, 128, 2, 4), (70, 3, 128, 256, 3, 3)])
+def test_bf16_split_k_matches_the_oracle(device, n, extent, cin, cout, ks, D):
+    """Split-K launches of k_conv_tile_bf16 (round 4): G offset groups per tile through an fp32 workspace, added in group
+    order by k_conv_splitk_reduce.  For every G in 2 .. 8 (and the policy's choice): forward and input gradient within
+    the bf16 bar of the oracle, bit-identical from run to run, the tile geometry really split (taller tiles than the
+    unsplit plan), and — because groups only regroup fp32 partial sums — within fp32 rounding of the unsplit launch."""
+    from minkowskiengine_amd import _lib, backend as MEB
+    lib = _lib.load()
+    coords = make_cloud(n, extent, D, seed=cin + cout + n, batch=2, negative=True)
+    g = torch.Generator().manual_seed(13)
+    x = bf16_round(torch.rand(coords.shape[0], cin, generator=g) - 0.5)
+    gy = bf16_round(torch.rand(coords.shape[0], cout, generator=g) - 0.5)
+    w = bf16_round(torch.rand(ks ** D, cin, cout, generator=g) - 0.5)
+    _, okm = O.kernel_map(coords.numpy(), coords.numpy(), O.make_region(D, ks))
+    want_y = O.conv_forward(x.numpy(), w.numpy(), okm, len(coords))
+    want_gi = O.conv_backward(x.numpy(), gy.numpy(), w.numpy(), okm)[0]
+    res, geo = {}, {}
+    try:
+        for G in (0, 2, 3, 4, 6, 8, -1):
+            lib.me_debug_set_bf16_splitk(G)
+            mgr = MEB.CoordinateMapManagerGPU_c10()          # (plans depend on the setting: a fresh kernel map each)
+            key, _ = mgr.insert_and_map(coords.to(device), [1] * D, "")
+            km = mgr._kernel_map(key, key, [ks] * D, [1] * D, [1] * D, MEB.RegionType.HYPER_CUBE, None, False, False)
+            wd = w.clone().to(device)
+            runs = []
+            for _ in range(2):
+                y = MEB._conv_forward(x.to(device).bfloat16(), wd, km, "mfma")
+                gi = MEB._conv_target(gy.to(device).bfloat16(), wd, km, "in", km.n_in, name="d", transposed=True)
+                runs.append((y.clone(), gi.clone()))
+            assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1]), f"G={G}: not reproducible"
+            res[G] = runs[0]
+            geo[G] = MEB.plan_config(km.n_out, km.volume, km.n_pairs, cin, cout, True, False, with_split_k=True)
+    finally:
+        lib.me_debug_set_bf16_splitk(-1)
+    assert geo[0][2] == 1
+    vol = ks ** D
+    for G in (2, 3, 4, 6, 8):
+        if cout % 128 == 0:                     # eligible shapes: 128-column slabs
+            assert geo[G][2] == min(G, vol, 8) and geo[G][0] > geo[0][0], (G, geo[G], geo[0])
+        else:
+            assert geo[G][2] == 1
+    for G, (y, gi) in res.items():
+        assert_bf16_close(y.float().cpu().numpy(), want_y, f"forward G={G}")
+        assert_bf16_close(gi.float().cpu().numpy(), want_gi, f"grad_in G={G}")
+        # regrouped fp32 sums, one rounding: at most one bf16 ulp from the unsplit launch, and only on a few elements
+        d = (y.float() - res[0][0].float()).abs()
+        assert float(d.max()) <= 2.0 ** -7 * float(res[0][0].float().abs().max())
+        assert float((d > 0).float().mean()) < 0.05, f"G={G}: too many elements differ from the unsplit launch"
+
+
+def test_bf16_split_k_policy_and_statistics(device, host_layer, monkeypatch):
+    """The policy splits the coarse MinkUNet levels (256 channels on a few thousand voxels) and nothing large; a
+    convolution -> batch-norm pair on a split launch takes the tiles' statistics from the REDUCE kernel and equals the
+    pair with the epilogue statistics switched off (a pass over the output), on both host layers."""
+    import minkowskiengine_amd as ME
+    from minkowskiengine_amd import backend as MEB, host as H
+    t_small = MEB.plan_config(4977, 27, 66569, 256, 256, True, False, with_split_k=True)
+    t_large = MEB.plan_config(79572, 27, 718104, 128, 128, True, False, with_split_k=True)
+    assert t_small[2] >= 2 and t_small[0] > 100 and t_large[2] == 1, (t_small, t_large)
+    coords = make_cloud(3000, 12, 3, seed=21, batch=2).to(device)
+    assert MEB.plan_config(coords.shape[0], 27, 30000, 128, 256, True, False, with_split_k=True)[2] >= 2
+    f = (torch.rand(coords.shape[0], 128, generator=torch.Generator().manual_seed(3)) - 0.5).to(device).bfloat16()
+    outs = {}
+    try:
+        for stats in (True, False):
+            monkeypatch.setattr(MEB, "_CONV_BN_STATS", stats)
+            if ME.is_native():
+                H.native_module().set_conv_bn_stats(1 if stats else 0)
+            torch.manual_seed(0)
+            conv = ME.MinkowskiConvolution(128, 256, kernel_size=3, dimension=3).to(device)
+            bn = ME.MinkowskiBatchNorm(256).to(device)
+            y = bn(conv(ME.SparseTensor(f, coords)))
+            outs[stats] = (y.F.detach().float().clone(), bn.bn.running_mean.clone(), bn.bn.running_var.clone())
+    finally:
+        if ME.is_native():
+            H.native_module().set_conv_bn_stats(-1)
+    a, b = outs[True], outs[False]
+    scale = float(b[0].abs().max())
+    assert float((a[0] - b[0]).abs().max()) <= 2.0 ** -7 * scale
+    assert float((a[1] - b[1]).abs().max()) <= 1e-5 * scale + 1e-6
+    assert float(((a[2] - b[2]) / b[2]).abs().max()) <= 1e-4
