@@ -51,7 +51,8 @@ typedef struct me_region {
  *   1.3 (130)  round 3: batch-norm statistics in the convolution's epilogue (me_conv_target_bf16_stats,
  *              me_conv_stats_supported_bf16, me_bn_stats_from_tiles)
  *   1.4 (140)  round 4: split-K launches of the bf16 convolution for small coordinate maps
- *              (me_conv_plan_config_bf16_ex, me_conv_splitk_workspace_bytes, me_conv_target_bf16_ex) */
+ *              (me_conv_plan_config_bf16_ex, me_conv_splitk_workspace_bytes, me_conv_target_bf16_ex); float64
+ *              features (me_conv_target_f64, me_conv_wgrad_f64, me_pool_*_f64, me_global_pool_f64, me_broadcast_f64) */
 int me_version(void);
 const char *me_last_error(void);
 /* kernel volume of a region: src/kernel_region.hpp:250-270 (set_volume) */
@@ -375,6 +376,36 @@ int me_conv_wgrad_bf16(const uint16_t *x_dev, int64_t n_in, int32_t c_in, const 
                        const int64_t *k_offsets /* host */, const int64_t *k_offsets_dev,
                        int64_t volume, float *grad_w_dev, void *workspace_dev,
                        int64_t workspace_bytes, void *stream);
+
+/* ---- float64 features (round 4) ----------------------------------------------------------------------------------------
+ * The reference instantiates its feature operators for float and double (AT_DISPATCH_FLOATING_TYPES,
+ * src/convolution_gpu.cu:137-155; the pooling / broadcast units alike) and its own tests are float64 gradchecks
+ * (MinkowskiEngine/utils/gradcheck.py:34-57).  csrc/f64.hip is that instantiation: plain double FMAs, one thread per
+ * output element on the dense neighbour tables / pair lists, deterministic (offsets ascending, then channels) —
+ * a yardstick, not a hot path.
+ *   me_conv_target_f64: dst[t] = sum_k src[tbl[k][t]] @ W_k on the neighbour table tbl int32 [volume, n_tgt] (source row
+ *                       of (offset, target row) or -1); w_dev is the kernel [K, c_src, c_dst], or with transposed != 0
+ *                       the FORWARD kernel [K, c_dst, c_src] read transposed (input gradient).
+ *   me_conv_wgrad_f64:  grad_w [K, c_in, c_out] from the pair lists (k_offsets_dev: device prefix).
+ *   me_pool_*_f64, me_global_pool_f64 (no workspace), me_broadcast_f64: arguments as their _f32 twins, double rows;
+ *                       counts stay float32, argmax / masks int32. */
+int me_conv_target_f64(const double *src_feat_dev, int64_t n_src, int32_t c_src, const double *w_dev, int32_t transposed,
+                       int64_t volume, int32_t c_dst, const int32_t *tbl_dev, double *dst_feat_dev, int64_t n_tgt,
+                       void *stream);
+int me_conv_wgrad_f64(const double *x_dev, int32_t c_in, const double *dy_dev, int32_t c_out, const int32_t *in_pairs_dev,
+                      const int32_t *out_pairs_dev, const int64_t *k_offsets_dev, int64_t volume, double *grad_w_dev,
+                      void *stream);
+int me_pool_sum_f64(const double *src_dev, int32_t c, const int32_t *tbl_dev, int64_t n_tgt, int64_t volume,
+                    const float *src_count_dev, int32_t average, double *dst_dev, float *dst_count_dev, void *stream);
+int me_pool_max_f64(const double *src_dev, int32_t c, const int32_t *tbl_dev, int64_t n_tgt, int64_t volume,
+                    double *dst_dev, int32_t *mask_dev, void *stream);
+int me_pool_max_backward_f64(const double *grad_out_dev, int32_t c, const int32_t *tbl_in_dev, int64_t n_in,
+                             int64_t volume, const int32_t *mask_dev, double *grad_in_dev, void *stream);
+int me_global_pool_f64(const double *src_dev, const double *src2_dev, int32_t c, const int32_t *batch_row_dev, int64_t n,
+                       int32_t n_batch, int32_t mode, double *dst_dev, int32_t *dst_arg_dev, float *dst_count_dev,
+                       void *stream);
+int me_broadcast_f64(const double *in_dev, const double *glob_dev, const int32_t *batch_row_dev, int64_t n, int32_t c,
+                     int32_t multiply, double *out_dev, void *stream);
 
 /* Output-stationary bf16 convolution (k_conv_gather_bf16): the target rows' fp32 accumulators stay in registers for
  * all kernel offsets, absent neighbours multiply as zero rows (bf16 MFMAs cost 1/16 of fp32 ones: the waste is cheaper

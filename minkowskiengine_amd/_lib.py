@@ -149,6 +149,13 @@ SIGNATURES = {
     "me_conv_wgrad_workspace_bytes_bf16": (c_i64, [_P_I64, c_i64, c_i32, c_i32]),
     "me_conv_wgrad_bf16": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, _P_I64, c_vp, c_i64, c_vp,
                                           c_vp, c_i64, c_vp]),
+    "me_conv_target_f64": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, c_i64, c_vp]),
+    "me_conv_wgrad_f64": (ctypes.c_int, [c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "me_pool_sum_f64": (ctypes.c_int, [c_vp, c_i32, c_vp, c_i64, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp]),
+    "me_pool_max_f64": (ctypes.c_int, [c_vp, c_i32, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp]),
+    "me_pool_max_backward_f64": (ctypes.c_int, [c_vp, c_i32, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp]),
+    "me_global_pool_f64": (ctypes.c_int, [c_vp, c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "me_broadcast_f64": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp]),
     "me_pool_sum_f32": (ctypes.c_int, [c_vp, c_i32, c_vp, c_i64, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "me_pool_max_f32": (ctypes.c_int, [c_vp, c_i32, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp]),
     "me_pool_max_backward_f32": (ctypes.c_int, [c_vp, c_i32, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp]),
@@ -180,6 +187,7 @@ DEBUG_SIGNATURES = {
     "me_debug_set_bf16_shape": (None, [ctypes.c_int, ctypes.c_int]),
     "me_debug_set_bf16_deep": (None, [ctypes.c_int]),
     "me_debug_set_bf16_splitk": (None, [ctypes.c_int]),
+    "me_debug_set_bf16_splitk_mode": (None, [ctypes.c_int]),
     "me_debug_bf16_timing": (ctypes.c_int, [c_vp, c_i32]),
 }
 

@@ -1081,7 +1081,8 @@ _SPATIAL_TILES = os.environ.get("ME_AMD_SPATIAL_TILES", "0") != "0"  # tiles of 
 def _check_feat(name, t):
     _check(t.is_contiguous(), name, "must be contiguous")
     _check(t.is_cuda, name, "must be CUDA (ROCm) — the MI355X path has no CPU implementation")
-    _check(t.dtype in (torch.float32, torch.bfloat16), name, "must be float32 or bfloat16, got", t.dtype)
+    _check(t.dtype in (torch.float32, torch.bfloat16, torch.float64), name,
+           "must be float32, bfloat16 or float64, got", t.dtype)
 
 
 class KernelTimer:
@@ -1360,6 +1361,17 @@ def _conv_target(src_feat, kernel, km, target, n_tgt, name="conv_target", transp
     out = torch.empty((n_tgt, c_dst), dtype=src_feat.dtype, device=dev)
     if n_tgt == 0:
         return out
+    if src_feat.dtype == torch.float64:
+        # float64 features (the reference's AT_DISPATCH_FLOATING_TYPES double instantiation, src/convolution_gpu.cu:
+        # 137-155; its gradcheck dtype): csrc/f64.hip — plain double FMAs on the neighbour table, no plan, no packing
+        _check(kernel.dtype == torch.float64, "float64 features need a float64 kernel, got", kernel.dtype)
+        tbl = km.table(target)
+        with _on(dev):
+            _timed(name, dev, lambda: _lib.check(lib.me_conv_target_f64(
+                src_feat.data_ptr(), src_feat.shape[0], c_src, kernel.contiguous().data_ptr(), 1 if transposed else 0,
+                volume, c_dst, _ptr(tbl), out.data_ptr(), n_tgt, _stream(dev))),
+                flops=2.0 * km.n_pairs * c_src * c_dst if KERNEL_TIMER else 0.0)
+        return out
     if bf16 and _BF16_GATHER and lib.me_conv_gather_supported_bf16(c_src, c_dst):
         # output-stationary kernel on the neighbour table itself (no tile plan): csrc/conv_bf16.hip k_conv_gather_bf16
         _check(kernel.dtype in (torch.float32, torch.bfloat16), "kernel must be float32 or bfloat16")
@@ -1462,8 +1474,19 @@ def _conv_backward(in_feat, grad_out, kernel, km, algo=None, need_grad_in=True):
     if grad_out.dtype != in_feat.dtype:
         grad_out = grad_out.to(in_feat.dtype)
     bf16 = in_feat.dtype == torch.bfloat16
+    if in_feat.dtype == torch.float64:     # csrc/f64.hip: deterministic double sums over the pair lists / the table
+        _check(kernel.dtype == torch.float64, "float64 features need a float64 kernel, got", kernel.dtype)
+        grad_w = torch.empty(kernel.shape, dtype=torch.float64, device=dev)
+        in_feat, grad_out = in_feat.contiguous(), grad_out.contiguous()
+        with _on(dev):
+            _lib.check(lib.me_conv_wgrad_f64(in_feat.data_ptr(), c_in, grad_out.data_ptr(), c_out, _ptr(km.in_pairs_buf),
+                                             _ptr(km.out_pairs_buf), _ptr(km.k_offsets_dev), volume, grad_w.data_ptr(),
+                                             _stream(dev)))
+        grad_in = _conv_target(grad_out, kernel, km, "in", km.n_in, name="conv_dgrad", transposed=True) \
+            if need_grad_in else None
+        return grad_in, grad_w
     if algo == "naive":
-        _check(not bf16, "the cross-check kernels are float32 only")
+        _check(in_feat.dtype == torch.float32, "the cross-check kernels are float32 only")
         grad_in = torch.zeros((km.n_in, c_in), dtype=torch.float32, device=dev)
         grad_w = torch.zeros_like(kernel)
         with _on(dev):
@@ -1623,12 +1646,17 @@ def _pool_sum(src, tbl, n_tgt, volume, src_count=None, average=False, want_count
     cnt = torch.empty(max(n_tgt, 1), dtype=torch.float32, device=dev)[:n_tgt] if want_count else None
     if src_count is not None:
         _check(src_count.dtype == torch.float32, "num_nonzero must be float32")
-    fn = lib.me_pool_sum_bf16 if src.dtype == torch.bfloat16 else lib.me_pool_sum_f32
+    fn = _by_dtype(lib, "pool_sum", src)
     with _on(dev):
         _timed("pool_sum", dev, lambda: _lib.check(fn(
             _ptr(src), c, _ptr(tbl), n_tgt, volume, _ptr(src_count), 1 if average else 0, _ptr(out), _ptr(cnt),
             _stream(dev))))
     return out, cnt
+
+
+def _by_dtype(lib, base, t):
+    """`me_<base>_{f32,bf16,f64}` for a tensor's dtype (float64: csrc/f64.hip, the reference's double instantiation)"""
+    return getattr(lib, f"me_{base}_" + {torch.float32: "f32", torch.bfloat16: "bf16", torch.float64: "f64"}[t.dtype])
 
 
 def _prepare_pool(in_feat, kernel_stride, in_key, out_key, manager, transpose):
@@ -1662,7 +1690,7 @@ def LocalPoolingForwardGPU(in_feat, kernel_size, kernel_stride, kernel_dilation,
         c = int(in_feat.shape[1])
         out = torch.empty((km.n_out, c), dtype=in_feat.dtype, device=dev)
         mask = torch.empty((km.n_out, c), dtype=torch.int32, device=dev)
-        fn = lib.me_pool_max_bf16 if in_feat.dtype == torch.bfloat16 else lib.me_pool_max_f32
+        fn = _by_dtype(lib, "pool_max", in_feat)
         with _on(dev):
             _timed("pool_max", dev, lambda: _lib.check(fn(
                 _ptr(in_feat), c, _ptr(km.table("out")), km.n_out, km.volume, _ptr(out), _ptr(mask), _stream(dev))))
@@ -1694,7 +1722,7 @@ def LocalPoolingBackwardGPU(in_feat, grad_out_feat, num_nonzero, kernel_size, ke
         c = int(in_feat.shape[1])
         _check(num_nonzero.dtype == torch.int32, "the max-pooling mask must be int32")
         grad_in = torch.empty((km.n_in, c), dtype=in_feat.dtype, device=dev)
-        fn = lib.me_pool_max_backward_bf16 if in_feat.dtype == torch.bfloat16 else lib.me_pool_max_backward_f32
+        fn = _by_dtype(lib, "pool_max_backward", in_feat)
         with _on(dev):
             _lib.check(fn(_ptr(grad_out_feat), c, _ptr(km.table("in")), km.n_in, km.volume,
                           _ptr(num_nonzero), _ptr(grad_in), _stream(dev)))
@@ -1746,9 +1774,15 @@ def _global_pool(src, src2, rows, n_batch, mode):
     if src2 is not None:
         _same_dtype("the second factor", src2, src)
     # the kernels reduce in fp32 and write fp32 [n_batch, c]; bf16 inputs get their (tiny) result rounded here
-    out = torch.empty((n_batch, c), dtype=torch.float32, device=dev)
+    f64 = src.dtype == torch.float64
+    out = torch.empty((n_batch, c), dtype=torch.float64 if f64 else torch.float32, device=dev)
     arg = torch.empty((n_batch, c), dtype=torch.int32, device=dev) if mode == 2 else None
     cnt = torch.empty(n_batch, dtype=torch.float32, device=dev) if mode != 2 else None
+    if f64:
+        with _on(dev):
+            _lib.check(lib.me_global_pool_f64(_ptr(src), _ptr(src2), c, _ptr(rows), n, n_batch, mode, _ptr(out), _ptr(arg),
+                                              _ptr(cnt), _stream(dev)))
+        return out, arg, cnt
     ws = _workspace(lib.me_global_pool_workspace_bytes(n, n_batch, c), dev)
     fn = lib.me_global_pool_bf16 if src.dtype == torch.bfloat16 else lib.me_global_pool_f32
     with _on(dev):
@@ -1785,7 +1819,7 @@ def _broadcast(in_feat, glob, rows, n, c, multiply):
     if in_feat is not None:
         _same_dtype("in_feat", in_feat, glob)
     out = torch.empty((n, c), dtype=glob.dtype, device=dev)
-    fn = lib.me_broadcast_bf16 if glob.dtype == torch.bfloat16 else lib.me_broadcast_f32
+    fn = _by_dtype(lib, "broadcast", glob)
     with _on(dev):
         _lib.check(fn(_ptr(in_feat), _ptr(glob), _ptr(rows), n, c, 1 if multiply else 0, _ptr(out), _stream(dev)))
     return out
@@ -1809,7 +1843,8 @@ def GlobalPoolingBackwardGPU(in_feat, grad_out_feat, num_nonzero, pooling_mode, 
         return grad_in
     g = grad_out_feat
     if mode in _GLOBAL_AVG:
-        g = (g.float() / num_nonzero.clamp_min(1.0)[:, None]).to(in_feat.dtype).contiguous()
+        g = ((g if g.dtype == torch.float64 else g.float()) / num_nonzero.clamp_min(1.0)[:, None]) \
+            .to(in_feat.dtype).contiguous()
     rows = manager._origin_rows(in_key)
     return _broadcast(None, g, rows, n, c, False)
 

@@ -921,6 +921,7 @@ struct ConvVariantBf16 {
 int g_bf16_nc = 0, g_bf16_kc = 0;   // me_debug_set_bf16_shape: tuning overrides of the slab width / chunk depth (0 = policy)
 int g_bf16_deep = -1;               // me_debug_set_bf16_deep: -1 policy, 0 never, 1 wherever instantiated
 int g_bf16_splitk = -1;             // me_debug_set_bf16_splitk: -1 policy, 0 / 1 never, G >= 2: G offset groups where eligible
+int g_bf16_splitk_same_tiles = 0;   // me_debug_set_bf16_splitk_mode: 1 = forced groups keep the unsplit tile height (G x the workgroups)
 constexpr int kSplitKMaxTileRows = 64;   // policy: split launches whose unsplit tiles are at most this tall
 
 static ConvVariantBf16 conv_variant_bf16(int c_src, int c_dst) {
@@ -1099,6 +1100,10 @@ int me_conv_plan_config_bf16_ex(int64_t n_tgt, int64_t volume, int64_t n_pairs, 
     g = std::min(gmax, std::max(1, 240 / t0));
   }
   if (g < 2) return 0;
+  if (g_bf16_splitk >= 2 && g_bf16_splitk_same_tiles) {   // tuning: more workgroups (occupancy) instead of taller tiles
+    *split_k = g;
+    return 0;
+  }
   // the tallest tile the LDS holds next to a full stage buffer
   const int cap = std::min<int>(ME_MAX_TILE_ROWS,
                                 (kLdsBudget - 16 - ME_MAX_BATCH_GROUPS * 16 * ((v.kc + 16) * 2 + 4)) / ((v.nc + kAccPad) * 4) - 1);
@@ -1117,6 +1122,7 @@ int64_t me_conv_splitk_workspace_bytes(int64_t n_tgt, int32_t tile_rows, int32_t
 }
 
 void me_debug_set_bf16_splitk(int g) { g_bf16_splitk = g; }
+void me_debug_set_bf16_splitk_mode(int same_tiles) { g_bf16_splitk_same_tiles = same_tiles; }
 
 int64_t me_conv_packed_weight_elems_bf16(int64_t volume, int32_t c_src, int32_t c_dst) {
   if (volume <= 0 || c_src <= 0 || c_dst <= 0) return 0;

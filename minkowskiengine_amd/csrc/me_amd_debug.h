@@ -29,6 +29,9 @@ void me_debug_set_bf16_deep(int deep);
 /* split-K of the eight-wave bf16 tile kernels: -1 policy, 0 / 1 never, G = 2..8: G offset groups wherever eligible
  * (set it before the plans are made: me_conv_plan_config_bf16_ex answers with it) */
 void me_debug_set_bf16_splitk(int g);
+/* 1: forced offset groups keep the tile height of the unsplit plan (G times the workgroups: occupancy instead of weight
+ * bytes); 0 (default): G-times taller tiles */
+void me_debug_set_bf16_splitk_mode(int same_tiles);
 /* phase counters of k_conv_tile_bf16 (all zero unless the library was compiled with -DME_BF16_TIMING): 20 uint64,
  * slots 0-9 deep pipeline / 10-19 plain loop: barrier A, stage write + wait, barrier B, load issue, multiply, refill +
  * descriptors, prologue, epilogue (s_memtime cycles of wave 0 of every workgroup), batches, workgroups */

@@ -15,8 +15,8 @@ namespace meh {
 static void check_feat(const char *name, const Tensor &t) {
   check(t.is_contiguous(), std::string(name) + " must be contiguous");
   check(t.is_cuda(), std::string(name) + " must be CUDA (ROCm) — the MI355X path has no CPU implementation");
-  check(t.scalar_type() == at::kFloat || t.scalar_type() == at::kBFloat16,
-        std::string(name) + " must be float32 or bfloat16");
+  check(t.scalar_type() == at::kFloat || t.scalar_type() == at::kBFloat16 || t.scalar_type() == at::kDouble,
+        std::string(name) + " must be float32, bfloat16 or float64");
 }
 
 // ---- packed weight images: cached per (weight storage, direction), validated by the tensor's version counter ------------
@@ -289,6 +289,19 @@ static Tensor conv_target(const Tensor &src, const Tensor &kernel, KernelMap &km
   const bool bf16 = src.scalar_type() == at::kBFloat16;
   Tensor out = at::empty({n_tgt, c_dst}, src.options());
   if (n_tgt == 0) return out;
+  if (src.scalar_type() == at::kDouble) {
+    // float64 features (the reference's double instantiation, src/convolution_gpu.cu:137-155 — its gradcheck dtype):
+    // csrc/f64.hip, plain double FMAs on the neighbour table; no plan, no packed weights
+    check(kernel.scalar_type() == at::kDouble, "float64 features need a float64 kernel");
+    Tensor tbl = km.table(target);
+    Tensor w = kernel.contiguous();
+    c10::DeviceGuard guard(dev);
+    void *st = stream_of(dev);
+    ScopedTimer tm(transposed ? "conv_dgrad" : "conv_forward", g_timing ? 2.0 * (double)km.n_pairs() * c_src * c_dst : 0.0, st);
+    me_ok(me_conv_target_f64(ptr<double>(src), src.size(0), c_src, ptr<double>(w), transposed ? 1 : 0, volume, c_dst,
+                             ptr<int32_t>(tbl), ptr<double>(out), n_tgt, st));
+    return out;
+  }
   const ConvCfg &cfg = km.conv_cfg(target, n_tgt, c_src, c_dst, bf16);
   const Plan &p = *cfg.plan;
   c10::DeviceGuard guard(dev);
@@ -372,6 +385,16 @@ std::pair<Tensor, Tensor> conv_backward_km(const Tensor &in_feat, Tensor grad_ou
   // dgrad: the same target-stationary kernel; the weights are packed transposed per offset
   Tensor grad_in;
   if (need_grad_in) grad_in = conv_target(grad_out, kernel, km, "in", km.n_in, true);
+  if (in_feat.scalar_type() == at::kDouble) {   // csrc/f64.hip: sequential double sums over the pairs of each offset
+    check(kernel.scalar_type() == at::kDouble, "float64 features need a float64 kernel");
+    Tensor gw = at::empty(kernel.sizes(), kernel.options());
+    Tensor x = in_feat.contiguous(), dy = grad_out.contiguous();
+    c10::DeviceGuard guard(dev);
+    me_ok(me_conv_wgrad_f64(ptr<double>(x), c_in, ptr<double>(dy), c_out, ptr<int32_t>(km.in_pairs_buf),
+                            ptr<int32_t>(km.out_pairs_buf), ptr<int64_t>(km.k_offsets_dev), volume, ptr<double>(gw),
+                            stream_of(dev)));
+    return {grad_in, gw};
+  }
   // wgrad: always accumulated and reduced in fp32; handed back in the kernel's dtype
   Tensor grad_w = at::empty(kernel.sizes(), at::TensorOptions().dtype(at::kFloat).device(dev));
   const WgradCfg &w = km.wgrad_cfg(c_in, c_out, bf16);
@@ -449,7 +472,10 @@ static std::pair<Tensor, Tensor> pool_sum(const Tensor &src, const Tensor &tbl, 
   if (want_count) cnt = at::empty({n_tgt > 0 ? n_tgt : 1}, at::TensorOptions().dtype(at::kFloat).device(dev)).narrow(0, 0, n_tgt);
   if (src_count.defined()) check(src_count.scalar_type() == at::kFloat, "num_nonzero must be float32");
   c10::DeviceGuard guard(dev);
-  if (src.scalar_type() == at::kBFloat16)
+  if (src.scalar_type() == at::kDouble)
+    me_ok(me_pool_sum_f64(ptr<double>(src), c, ptr<int32_t>(tbl), n_tgt, volume, ptr<float>(src_count), average ? 1 : 0,
+                          ptr<double>(out), ptr<float>(cnt), stream_of(dev)));
+  else if (src.scalar_type() == at::kBFloat16)
     me_ok(me_pool_sum_bf16(ptr<uint16_t>(src), c, ptr<int32_t>(tbl), n_tgt, volume, ptr<float>(src_count), average ? 1 : 0,
                            ptr<uint16_t>(out), ptr<float>(cnt), stream_of(dev)));
   else
@@ -492,7 +518,10 @@ std::pair<Tensor, Tensor> local_pooling_forward(const Tensor &in_feat, const ive
     Tensor mask = empty_i32({km->n_out, c}, dev);
     Tensor tbl = km->table("out");
     c10::DeviceGuard guard(dev);
-    if (in_feat.scalar_type() == at::kBFloat16)
+    if (in_feat.scalar_type() == at::kDouble)
+      me_ok(me_pool_max_f64(ptr<double>(in_feat), c, ptr<int32_t>(tbl), km->n_out, km->volume, ptr<double>(out),
+                            ptr<int32_t>(mask), stream_of(dev)));
+    else if (in_feat.scalar_type() == at::kBFloat16)
       me_ok(me_pool_max_bf16(ptr<uint16_t>(in_feat), c, ptr<int32_t>(tbl), km->n_out, km->volume, ptr<uint16_t>(out),
                              ptr<int32_t>(mask), stream_of(dev)));
     else
@@ -523,7 +552,10 @@ Tensor local_pooling_backward(const Tensor &in_feat, Tensor grad_out, const Tens
     Tensor grad_in = at::empty({km->n_in, c}, in_feat.options());
     Tensor tbl = km->table("in");
     c10::DeviceGuard guard(dev);
-    if (in_feat.scalar_type() == at::kBFloat16)
+    if (in_feat.scalar_type() == at::kDouble)
+      me_ok(me_pool_max_backward_f64(ptr<double>(grad_out), c, ptr<int32_t>(tbl), km->n_in, km->volume,
+                                     ptr<int32_t>(num_nonzero), ptr<double>(grad_in), stream_of(dev)));
+    else if (in_feat.scalar_type() == at::kBFloat16)
       me_ok(me_pool_max_backward_bf16(ptr<uint16_t>(grad_out), c, ptr<int32_t>(tbl), km->n_in, km->volume,
                                       ptr<int32_t>(num_nonzero), ptr<uint16_t>(grad_in), stream_of(dev)));
     else
@@ -565,10 +597,17 @@ static std::tuple<Tensor, Tensor, Tensor> global_pool(const Tensor &src, const T
   const int64_t n = src.size(0);
   const int c = (int)src.size(1);
   if (src2.defined()) check(src2.scalar_type() == src.scalar_type(), "the second factor must have the dtype of the input features");
-  Tensor out = at::empty({n_batch, c}, at::TensorOptions().dtype(at::kFloat).device(dev));
+  const bool f64 = src.scalar_type() == at::kDouble;
+  Tensor out = at::empty({n_batch, c}, at::TensorOptions().dtype(f64 ? at::kDouble : at::kFloat).device(dev));
   Tensor arg, cnt;
   if (mode == 2) arg = empty_i32({n_batch, c}, dev);
   else cnt = at::empty({n_batch}, at::TensorOptions().dtype(at::kFloat).device(dev));
+  if (f64) {
+    c10::DeviceGuard guard(dev);
+    me_ok(me_global_pool_f64(ptr<double>(src), ptr<double>(src2), c, ptr<int32_t>(rows), n, (int)n_batch, mode,
+                             ptr<double>(out), ptr<int32_t>(arg), ptr<float>(cnt), stream_of(dev)));
+    return {out, arg, cnt};
+  }
   Tensor ws = workspace(me_global_pool_workspace_bytes(n, (int)n_batch, c), dev);
   {
     c10::DeviceGuard guard(dev);
@@ -606,7 +645,10 @@ static Tensor broadcast(const Tensor &in_feat, const Tensor &glob, const Tensor 
   if (in_feat.defined()) check(in_feat.scalar_type() == glob.scalar_type(), "in_feat must have the dtype of the input features");
   Tensor out = at::empty({n, c}, glob.options());
   c10::DeviceGuard guard(dev);
-  if (glob.scalar_type() == at::kBFloat16)
+  if (glob.scalar_type() == at::kDouble)
+    me_ok(me_broadcast_f64(ptr<double>(in_feat), ptr<double>(glob), ptr<int32_t>(rows), n, c, multiply ? 1 : 0,
+                           ptr<double>(out), stream_of(dev)));
+  else if (glob.scalar_type() == at::kBFloat16)
     me_ok(me_broadcast_bf16(ptr<uint16_t>(in_feat), ptr<uint16_t>(glob), ptr<int32_t>(rows), n, c, multiply ? 1 : 0,
                             ptr<uint16_t>(out), stream_of(dev)));
   else
@@ -633,7 +675,9 @@ Tensor global_pooling_backward(const Tensor &in_feat, Tensor grad_out, const Ten
     return grad_in;
   }
   Tensor g = grad_out;
-  if (m == 1) g = (g.to(at::kFloat) / num_nonzero.clamp_min(1.0).unsqueeze(1)).to(in_feat.scalar_type()).contiguous();
+  if (m == 1)
+    g = ((g.scalar_type() == at::kDouble ? g : g.to(at::kFloat)) / num_nonzero.clamp_min(1.0).unsqueeze(1))
+            .to(in_feat.scalar_type()).contiguous();
   Tensor rows = mgr->origin_rows(in_key->get());
   return broadcast(Tensor(), g, rows, n, c, false);
 }

@@ -1,6 +1,7 @@
-"""Split-K sweep of the bf16 tile kernel on the coarse MinkUNet34C levels of the 200k-voxel scene (tensor strides 8 and
-16: 21k / 5k voxels): us per forward launch for G = 0 (unsplit) .. 8 offset groups, per channel shape.
-usage: python scripts/splitk_sweep.py  (GPU)"""
+"""Split-K / shape sweep of the bf16 tile kernel on the coarse MinkUNet34C levels of the 200k-voxel scene (tensor strides
+8 and 16: 21k / 5k voxels): us per forward launch per configuration.  A configuration is "nc,kc,G,mode" — slab width and
+chunk depth overrides (0 = policy), offset groups (0 = unsplit, -1 = policy), mode 1 = keep the unsplit tile height.
+usage: CONFIGS="0,0,0,0;0,0,2,0;128,128,2,1" python scripts/splitk_sweep.py  (GPU)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "examples"))
@@ -18,19 +19,24 @@ key = k1
 for ts in (2, 4, 8, 16):
     key = mgr0.stride(key, [2, 2, 2], "")
     levels[ts] = mgr0.get_coordinates(key).clone()
-SHAPES = {16: [(256, 256), (128, 256), (256, 128)], 8: [(128, 128), (256, 256), (384, 256), (256, 384), (64, 128), (128, 64)],
-          4: [(128, 128), (192, 128)]}
-GS = [int(g) for g in os.environ.get("GS", "0,2,3,4,6,8").split(",")]
-print(f"{'level':>6s} {'rows':>7s} {'cin->cout':>10s} " + " ".join(f"{'G=' + str(g):>16s}" for g in GS))
+ALL = {16: [(256, 256), (128, 256), (256, 128)], 8: [(128, 128), (256, 256), (384, 256), (256, 384)], 4: [(128, 128)]}
+want = os.environ.get("LEVELS", "16,8")
+SHAPES = {int(l): ALL[int(l)] for l in want.split(",")}
+CONFIGS = [tuple(int(v) for v in c.split(",")) for c in
+           os.environ.get("CONFIGS", "0,0,0,0;0,0,2,0;0,0,4,0;128,128,0,0;128,128,2,1;128,128,3,1;128,128,2,0").split(";")]
+REPS = int(os.environ.get("REPS", "20"))
+print(f"{'level':>6s} {'rows':>7s} {'cin->cout':>10s} " + " ".join(f"{'/'.join(str(v) for v in c):>18s}" for c in CONFIGS))
 for ts, shapes in SHAPES.items():
     c = levels[ts]
     for cin, cout in shapes:
         g = torch.Generator().manual_seed(1)
         x = (torch.rand(c.shape[0], cin, generator=g) - 0.5).to(dev).bfloat16()
-        w = (torch.rand(27, cin, cout, generator=g) - 0.5).to(dev)
         cells = []
-        for G in GS:
+        for nc, kc, G, mode in CONFIGS:
+            lib.me_debug_set_bf16_shape(nc, kc)
             lib.me_debug_set_bf16_splitk(G)
+            lib.me_debug_set_bf16_splitk_mode(mode)
+            w = (torch.rand(27, cin, cout, generator=g) - 0.5).to(dev)      # (packed images depend on the shape)
             mgr = MEB.CoordinateMapManagerGPU_c10()
             key, _ = mgr.insert_and_map(c, [ts] * 3, "")
             km = mgr._kernel_map(key, key, [3] * 3, [1] * 3, [1] * 3, MEB.RegionType.HYPER_CUBE, None, False, False)
@@ -40,10 +46,12 @@ for ts, shapes in SHAPES.items():
             torch.cuda.synchronize()
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            for _ in range(20):
+            for _ in range(REPS):
                 MEB._conv_forward(x, w, km, "mfma")
             e.record()
             torch.cuda.synchronize()
-            cells.append(f"{s.elapsed_time(e) / 20 * 1e3:7.1f} T{T:<3d} g{sk}")
-        print(f"{ts:6d} {c.shape[0]:7d} {str(cin) + '->' + str(cout):>10s} " + " ".join(f"{v:>16s}" for v in cells), flush=True)
+            cells.append(f"{s.elapsed_time(e) / REPS * 1e3:7.1f} T{T:<3d} g{sk}")
+        print(f"{ts:6d} {c.shape[0]:7d} {str(cin) + '->' + str(cout):>10s} " + " ".join(f"{v:>18s}" for v in cells), flush=True)
 lib.me_debug_set_bf16_splitk(-1)
+lib.me_debug_set_bf16_splitk_mode(0)
+lib.me_debug_set_bf16_shape(0, 0)
