@@ -922,7 +922,7 @@ int g_bf16_nc = 0, g_bf16_kc = 0;   // me_debug_set_bf16_shape: tuning overrides
 int g_bf16_deep = -1;               // me_debug_set_bf16_deep: -1 policy, 0 never, 1 wherever instantiated
 int g_bf16_splitk = -1;             // me_debug_set_bf16_splitk: -1 policy, 0 / 1 never, G >= 2: G offset groups where eligible
 int g_bf16_splitk_same_tiles = 0;   // me_debug_set_bf16_splitk_mode: 1 = forced groups keep the unsplit tile height (G x the workgroups)
-constexpr int kSplitKMaxTileRows = 64;   // policy: split launches whose unsplit tiles are at most this tall
+constexpr int kSplitKMaxTileRows = 48;   // policy: split launches whose unsplit tiles are at most this tall
 
 static ConvVariantBf16 conv_variant_bf16(int c_src, int c_dst) {
   ConvVariantBf16 v;
@@ -1096,8 +1096,16 @@ int me_conv_plan_config_bf16_ex(int64_t n_tgt, int64_t volume, int64_t n_pairs, 
   int g = 1;
   if (g_bf16_splitk >= 2) {
     g = std::min(g_bf16_splitk, gmax);
-  } else if (t0 <= kSplitKMaxTileRows && tiles0 * v.slabs <= (int64_t)device_cu_count() * 3 / 2) {
-    g = std::min(gmax, std::max(1, 240 / t0));
+  } else if (v.kc == 256 && t0 <= kSplitKMaxTileRows && tiles0 * v.slabs <= (int64_t)device_cu_count() * 3 / 2) {
+    // Measured on the 4,977-voxel level of the MinkUNet34C scene (profiles/r04_splitk_sweep.log, us per launch):
+    //   256 -> 256 (T 39): unsplit 44.0, G = 2 36.3, G = 4 38.6;   256 -> 128 (T 20): 38.4, G = 2 29.2, G = 4 25.2;
+    //   128 -> 256 (128-channel chunks): 26.8 unsplit, 27.6 / 30.7 split — half the weight bytes per batch, nothing to
+    //   gain; every split of the 21k-voxel level lost 10 - 40 % (its tiles are tall already, the reduce pass is not free).
+    // Twice the workgroups per CU on the SAME tiles changed nothing (44.5): the launch is bound by the weight bytes the
+    // L2s deliver, not by latency.  So: 256-channel chunks only, tiles of ~80 rows, and never more workgroups than CUs
+    // (a second round costs more than the split saves: G = 3 and 6 measured 46 - 51 us).
+    g = std::min(gmax, std::max(2, std::min(4, (80 + t0 / 2) / t0)));
+    while (g > 1 && ceil_div(tiles0, g) * v.slabs * g > (int64_t)device_cu_count()) --g;
   }
   if (g < 2) return 0;
   if (g_bf16_splitk >= 2 && g_bf16_splitk_same_tiles) {   // tuning: more workgroups (occupancy) instead of taller tiles
