@@ -67,3 +67,29 @@ def test_headline_line_is_config_2_in_fp32():
     assert "100000 voxels" in d["config"]["workload"] and "64->128" in d["config"]["workload"]
     assert d["cpu_baseline"]["kind"] == "reference"
     assert d["roofline"]["traffic"] > 0 and d["roofline"]["kernel"].startswith("k_conv_tile_f32")
+
+
+def test_multi_gpu_line_carries_the_exchange_and_the_ddp_workload():
+    """under --gpus N > 1 the line prices the gradient exchange (per-rank times, the step without the
+    all-reduce, the all-reduce on its own, what the overlapped step still pays, an accumulation window), names the
+    collective layer as torch.distributed reports it, and attaches BASELINE configs[3] — MinkUNet34C under DDP — as
+    `workloads.minkunet34c_bf16_ddp`.  Checked on the committed 2-ranks-on-one-GPU run (gloo; RCCL refuses two ranks on
+    one device): profiles/r04_bench_n2_1gpu_gloo.json."""
+    with open(os.path.join(ROOT, "profiles", "r04_bench_n2_1gpu_gloo.json")) as f:
+        d = json.loads(f.read().strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["config"]["oversubscribed"] is True and d["scaling"] == "weak"
+    for entry, grad_bytes in ((d, 27 * 64 * 128 * 4), (d["workloads"]["minkunet34c_bf16_ddp"], 37856052 * 4)):
+        m = entry["multi_gpu"]
+        assert m["backend"] == "gloo" and m["world_size_reported"] == 2
+        assert len(m["per_rank_ms_per_step"]) == 2 and all(v > 0 for v in m["per_rank_ms_per_step"])
+        assert m["allreduce_ms"]["bytes"] == grad_bytes and m["allreduce_ms"]["standalone"] > 0
+        assert 0 < m["no_sync_ms_per_step"] <= entry["ms_per_step"] * 1.05
+        assert abs(m["parallel_efficiency"] - m["no_sync_ms_per_step"] / entry["ms_per_step"]) < 0.01
+        assert abs(m["allreduce_ms"]["exposed_in_step"] - (entry["ms_per_step"] - m["no_sync_ms_per_step"])) < 0.02 * entry["ms_per_step"]
+    acc = d["multi_gpu"]["accumulation"]
+    assert acc["window"] == 4 and acc["ms_per_micro_step"] < d["ms_per_step"]      # 3 of 4 micro-steps skip the exchange
+    w = d["workloads"]["minkunet34c_bf16_ddp"]
+    assert w["n_gpus"] == 2 and w["dtype"] == "bf16" and "DDP" in w["config"]["parallelism"]
+    assert w["multi_gpu"]["per_rank_points"] == [200000, 200000]
+    pts = 2 * 200000
+    assert abs(w["value"] - pts / (w["ms_per_step"] * 1e-3) / 1e6) < 0.01 * w["value"]
