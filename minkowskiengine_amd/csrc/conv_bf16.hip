@@ -641,6 +641,264 @@ __global__ __launch_bounds__(NC * 4, DEEP ? 2 : conv_bf16_waves_per_simd(NC, KC)
 #undef ME_COUNT
 }
 
+// =================================================================================================
+// k_conv_off_bf16 (round 4): the same plan, the same sums — another schedule ("offset-synchronous")
+// =================================================================================================
+// k_conv_tile_bf16 splits a batch by COLUMNS: every wave multiplies all staged rows of the batch by its own 16 columns,
+// so a batch is barrier -> stage write -> barrier -> eight short multiplies, and a tile is a chain of 27+ such batches
+// (~3,200 cycles each whatever their size: r03 phase counters) with the matrix pipe busy 14 % of the time.  Here the
+// waves of a workgroup split an item — the groups of ONE offset of the tile — by ROWS first:
+//   * the offset's weight slice (KC x NC, the packed MFMA image, one contiguous block) is copied to LDS once per item
+//     and workgroup, double-buffered, its loads requested one item ahead;
+//   * wave (gw, cw) takes the groups g0 + gw, g0 + gw + GW, ... of the item and the column blocks [cw CBW, (cw + 1) CBW):
+//     it gathers its 16 rows STRAIGHT into the MFMA B operand (lane (row, q) loads its 8 channels per k-step: 16 bytes,
+//     four lanes cover a row's 64-byte piece) — no stage buffer, no stage write, no barrier between gather and
+//     multiply — reads the A operand (weights) from LDS, runs its KS x CBW MFMAs and adds the 16 x (16 CBW) block into
+//     the LDS accumulator tile;
+//   * ONE barrier per non-empty item: it publishes the weight slice and separates the accumulator updates of
+//     consecutive offsets (rows of one offset are distinct, so waves never collide inside an item).
+// Rows of the next group (and their indices one group further) are in flight while a group multiplies; waves drift
+// apart inside an item, so one wave's gather wait is another's multiply.
+// Same additions in the same order as k_conv_tile_bf16 (chunk-major, offsets ascending, one zero-initialised MFMA chain
+// over the k-steps per group, then one add into the tile): results are BIT-IDENTICAL to it
+// (tests/test_gpu_bf16.py::test_offset_synchronous_kernel_is_bit_identical).
+// Requirements (else the column-split kernel runs): c_src % KC == 0, c_dst % NC == 0, 32-bit gather offsets.
+__host__ __device__ constexpr int conv_off_lds_bytes(int nc, int kc, int tile_rows, int volume) {
+  return (tile_rows + 1) * (nc + kAccPad) * 4 + 2 * kc * nc * 2 + (volume + 2) * 4;
+}
+
+template <int NC, int KC, int GW, int CBW>
+__global__ __launch_bounds__(GW * (NC / 16 / CBW) * 64, 4) void k_conv_off_bf16(
+    const __bf16 *__restrict__ src, int c_src, const bf16x8 *__restrict__ wp, int c_dst,
+    const int32_t *__restrict__ plan_src, const int32_t *__restrict__ plan_dst,
+    const int32_t *__restrict__ batch_desc, const int32_t *__restrict__ tile_bptr,
+    const int32_t *__restrict__ order, __bf16 *__restrict__ dst, int64_t n_tgt, int tile_rows, int volume,
+    float *__restrict__ stat_mean, float *__restrict__ stat_m2) {
+  constexpr int NCB = NC / 16;            // column blocks of the slab
+  constexpr int CW = NCB / CBW;           // column parts
+  constexpr int WAVES = GW * CW;
+  constexpr int NT = WAVES * 64;
+  constexpr int KS = KC / 32;
+  constexpr int ACC_LD = NC + kAccPad;
+  constexpr int WELEMS = KS * NCB * 64;   // 16-byte elements of one weight slice
+  constexpr int WPT = (WELEMS + NT - 1) / NT;
+  static_assert(NCB % CBW == 0 && KC % 32 == 0, "shape");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *s_acc = reinterpret_cast<float *>(smem);                                        // [(tile_rows + 1) x ACC_LD]
+  bf16x8 *s_w = reinterpret_cast<bf16x8 *>(s_acc + (tile_rows + 1) * ACC_LD);            // [2][WELEMS]
+  int32_t *s_g = reinterpret_cast<int32_t *>(s_w + 2 * WELEMS);                          // [volume + 1] first group of item k
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int gw = wave / CW, cw = wave % CW;
+  const int i16 = lane & 15, q = lane >> 4;
+  const int tile = tile_bptr[gridDim.x + 1 + blockIdx.x];
+  const int col_base = blockIdx.y * NC;
+  const int nchunks = c_src / KC;
+  const int ncb = (c_dst + 15) / 16;
+
+  for (int x = tid; x < (tile_rows + 1) * ACC_LD / 4; x += NT)
+    reinterpret_cast<f32x4 *>(s_acc)[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // first group of every item of the tile, from the tile's batch descriptors (batches are listed by ascending offset,
+  // an item's groups are contiguous): s_g[k] .. s_g[k + 1]
+  const int b0 = tile_bptr[tile], nb = tile_bptr[tile + 1] - b0;
+  for (int k = tid; k <= volume; k += NT) s_g[k] = -1;
+  __syncthreads();
+  for (int b = tid; b < nb; b += NT) {
+    const int2 d = *reinterpret_cast<const int2 *>(batch_desc + 2 * (int64_t)(b0 + b));
+    const int k = (int)((uint32_t)d.y >> 8);
+    const int kp = b > 0 ? (int)((uint32_t)batch_desc[2 * (int64_t)(b0 + b - 1) + 1] >> 8) : -1;
+    if (k != kp) s_g[k] = d.x;
+    if (b == nb - 1) s_g[volume] = d.x + (d.y & 255);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    if (nb == 0) s_g[volume] = 0;
+    for (int k = volume - 1; k >= 0; --k)
+      if (s_g[k] < 0) s_g[k] = s_g[k + 1];
+  }
+  __syncthreads();
+
+  const char *srcb = reinterpret_cast<const char *>(src);
+  const unsigned row_bytes = (unsigned)c_src * 2u;
+  const int32_t *dsts = plan_dst + i16;
+
+  // ---- this wave's stream of groups: (offset, group) in plan order, its row indices two groups ahead, its rows one ----
+  struct Cursor {
+    int k, g;         // offset, group (k == volume: the stream has ended)
+  };
+  auto sg = [&](int k) { return __builtin_amdgcn_readfirstlane(s_g[k]); };   // (wave-uniform: keep it scalar)
+  auto first_from = [&](int k) {   // first group of this wave at or after offset k
+    Cursor c;
+    c.k = k;
+    c.g = 0;
+    while (c.k < volume) {
+      const int g = sg(c.k) + gw;
+      if (g < sg(c.k + 1)) {
+        c.g = g;
+        break;
+      }
+      ++c.k;
+    }
+    return c;
+  };
+  auto advance = [&](Cursor c) {
+    if (c.k >= volume) return c;
+    c.g += GW;
+    if (c.g < sg(c.k + 1)) return c;
+    return first_from(c.k + 1);
+  };
+  auto load_index = [&](const Cursor &c, int32_t &sidx, int32_t &didx) {
+    const int g = c.k < volume ? c.g : 0;                 // (a finished stream keeps loading group 0 of the plan: valid memory)
+    sidx = plan_src[(int64_t)g * 16 + i16];
+    didx = dsts[(int64_t)g * 16];
+  };
+  auto load_rows = [&](int32_t sidx, int chunk, bf16x8 (&b)[KS]) {
+    const unsigned off = __umul24((unsigned)max(sidx, 0), row_bytes) + (unsigned)(chunk * KC + q * 8) * 2u;
+#pragma unroll
+    for (int v = 0; v < KS; ++v) b[v] = *reinterpret_cast<const bf16x8 *>(srcb + off + v * 64);
+  };
+
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    // weights of the first non-empty item of this pass
+    int kw = 0;
+    while (kw < volume && sg(kw) == sg(kw + 1)) ++kw;
+    bf16x8 wq[WPT];
+    auto load_w = [&](int k) {
+      const bf16x8 *p = wp + ((((int64_t)min(k, volume - 1) * nchunks + chunk) * ncb + col_base / 16) * KS) * 64;
+#pragma unroll
+      for (int j = 0; j < WPT; ++j) wq[j] = p[min(j * NT + tid, WELEMS - 1)];
+    };
+    load_w(kw);
+    Cursor cur = first_from(0), nxt = advance(cur), nn = advance(nxt);
+    int32_t s_cur, d_cur, s_nxt, d_nxt, s_nn, d_nn;
+    bf16x8 b_cur[KS], b_nxt[KS];
+    load_index(cur, s_cur, d_cur);
+    load_index(nxt, s_nxt, d_nxt);
+    load_index(nn, s_nn, d_nn);
+    load_rows(s_cur, chunk, b_cur);
+    load_rows(s_nxt, chunk, b_nxt);
+    int buf = 0;
+    for (int k = kw; k < volume;) {
+      // publish this item's weights (requested one item ago); the barrier also separates the accumulator updates of
+      // consecutive offsets
+      bf16x8 *wdst = s_w + buf * WELEMS;
+#pragma unroll
+      for (int j = 0; j < WPT; ++j)
+        if (j * NT + tid < WELEMS) wdst[j * NT + tid] = wq[j];
+      int kn = k + 1;
+      while (kn < volume && sg(kn) == sg(kn + 1)) ++kn;
+      __syncthreads();
+      load_w(kn);                                           // next non-empty item (clamped past the end: unused)
+      const bf16x8 *wa = s_w + buf * WELEMS + (cw * CBW * KS) * 64 + lane;
+      while (cur.k == k) {
+        f32x4 acc[CBW];
+#pragma unroll
+        for (int c = 0; c < CBW; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int v = 0; v < KS; ++v) {
+#pragma unroll
+          for (int c = 0; c < CBW; ++c)
+            acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[(c * KS + v) * 64], b_cur[v], acc[c], 0, 0, 0);
+        }
+        float *ap = s_acc + (int)__umul24((unsigned)d_cur, (unsigned)ACC_LD) + cw * CBW * 16 + q * 4;
+        f32x4 old[CBW];
+#pragma unroll
+        for (int c = 0; c < CBW; ++c) old[c] = *reinterpret_cast<const f32x4 *>(ap + c * 16);
+#pragma unroll
+        for (int c = 0; c < CBW; ++c) *reinterpret_cast<f32x4 *>(ap + c * 16) = old[c] + acc[c];
+        // shift the stream: next -> current (its rows have been in flight for a whole group), request the rows of the
+        // group after it and the indices one further
+        cur = nxt;
+        nxt = nn;
+        nn = advance(nn);
+        s_cur = s_nxt;
+        d_cur = d_nxt;
+#pragma unroll
+        for (int v = 0; v < KS; ++v) b_cur[v] = b_nxt[v];
+        s_nxt = s_nn;
+        d_nxt = d_nn;
+        load_rows(s_nxt, chunk, b_nxt);
+        load_index(nn, s_nn, d_nn);
+      }
+      buf ^= 1;
+      k = kn;
+    }
+    __syncthreads();     // (the next pass rewrites the weight buffers; the last one is followed by the epilogue)
+  }
+
+  // ---- epilogue: as k_conv_tile_bf16 (every target row written once, rounded to bf16; optional tile statistics) ----
+  const int64_t row0 = (int64_t)tile * tile_rows;
+  const int rows_here = (int)min((int64_t)tile_rows, n_tgt - row0);
+  constexpr int G4 = NC / 4;
+  constexpr bool kStats = NC == 32 || NC == 64 || NC == 128;
+  const bool do_stats = kStats && stat_mean != nullptr;
+  float st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+  if (do_stats) {
+    const f32x4 v0 = *reinterpret_cast<const f32x4 *>(&s_acc[(tid % G4) * 4]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) sh[t] = (float)(__bf16)v0[t];
+  }
+  for (int x = tid; x < tile_rows * NC / 4; x += NT) {
+    const int row = x / G4;
+    const int c4 = x % G4;
+    const int cc = col_base + c4 * 4;
+    if (row < rows_here) {
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(&s_acc[row * ACC_LD + c4 * 4]);
+      const bf16x4 vb = bf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+      if (do_stats) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float d = (float)vb[t] - sh[t];
+          st1[t] += d;
+          st2[t] = fmaf(d, d, st2[t]);
+        }
+      }
+      const int64_t grow = order ? (int64_t)order[row0 + row] : row0 + row;
+      *reinterpret_cast<bf16x4 *>(dst + grow * c_dst + cc) = vb;
+    }
+  }
+  if constexpr (kStats) {
+    if (do_stats) {
+      static_assert(!kStats || NT % G4 == 0, "a thread keeps its four columns over the store loop");
+#pragma unroll
+      for (int off = G4; off < 64; off <<= 1) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          st1[t] += __shfl_xor(st1[t], off, 64);
+          st2[t] += __shfl_xor(st2[t], off, 64);
+        }
+      }
+      __syncthreads();
+      float *s_st = s_acc + ACC_LD;                 // [WAVES][G4][8] behind row 0
+      if (lane < G4) {
+        float *w = s_st + (wave * G4 + lane) * 8;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          w[t] = st1[t];
+          w[4 + t] = st2[t];
+        }
+      }
+      __syncthreads();
+      if (tid < NC && col_base + tid < c_dst) {
+        const int c4 = tid >> 2, t = tid & 3;
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+          a += s_st[(w * G4 + c4) * 8 + t];
+          b += s_st[(w * G4 + c4) * 8 + 4 + t];
+        }
+        const float shift = (float)(__bf16)s_acc[tid];
+        const float cnt = (float)rows_here, m = a / cnt;
+        stat_mean[(int64_t)tile * c_dst + col_base + tid] = shift + m;
+        stat_m2[(int64_t)tile * c_dst + col_base + tid] = fmaxf(b - a * m, 0.f);
+      }
+    }
+  }
+}
+
 // Second phase of a SPLITK launch: out[row] = bf16(sum over offset groups g of partial[g][row]) — fp32 adds in group
 // order, one rounding — for one (tile, column slab) per workgroup, and the tile's batch-norm statistics exactly as the
 // unsplit kernel's store loop forms them (shifted by the tile's first row; thread's rows ascending, xor-shuffle tree,
@@ -920,6 +1178,8 @@ struct ConvVariantBf16 {
 
 int g_bf16_nc = 0, g_bf16_kc = 0;   // me_debug_set_bf16_shape: tuning overrides of the slab width / chunk depth (0 = policy)
 int g_bf16_deep = -1;               // me_debug_set_bf16_deep: -1 policy, 0 never, 1 wherever instantiated
+int g_bf16_offsync = 0;             // me_debug_set_bf16_offsync: 0 column-split kernel (k_conv_tile_bf16), 1 offset-synchronous
+                                    // kernel where eligible, 2 / 3: the same with its other wave shapes
 int g_bf16_splitk = -1;             // me_debug_set_bf16_splitk: -1 policy, 0 / 1 never, G >= 2: G offset groups where eligible
 int g_bf16_splitk_same_tiles = 0;   // me_debug_set_bf16_splitk_mode: 1 = forced groups keep the unsplit tile height (G x the workgroups)
 constexpr int kSplitKMaxTileRows = 48;   // policy: split launches whose unsplit tiles are at most this tall
@@ -949,7 +1209,8 @@ static ConvVariantBf16 conv_variant_bf16(int c_src, int c_dst) {
   // 256-channel chunks halve the batches of a 256-channel layer (64 registers of weights per lane: one eight-wave
   // workgroup per CU) — only where the launch is at most two slabs wide: with three (256 -> 384 input gradient, 21k
   // voxels) the single resident workgroup per CU runs two rounds, 246 us against 158
-  if (v.nc == 128 && c_src % 256 == 0 && c_dst <= 256) v.kc = 256;
+  if (v.nc == 128 && c_src % 256 == 0 && c_dst <= 256 && g_bf16_offsync == 0) v.kc = 256;   // (the offset-synchronous
+                                                                // kernel keeps the slice in LDS twice: 128-channel chunks)
 #ifdef ME_DEBUG_VARIANTS
   constexpr bool kHas96 = true;    // six-wave workgroups: measured, not used by the policy, instantiated for the tuning build only
 #else
@@ -1054,6 +1315,57 @@ static int launch_conv_tile_bf16(const __bf16 *src, int c_src, const bf16x8 *wp,
   return 0;
 }
 
+// k_conv_off_bf16 for a launch, or -1 when the shape / plan is not eligible (the column-split kernel runs then)
+template <int NC, int KC, int GW, int CBW>
+static int launch_conv_off_bf16(const __bf16 *src, int c_src, const bf16x8 *wp, int c_dst, const int32_t *plan_src,
+                                const int32_t *plan_dst, const int32_t *batch_desc, const int32_t *tile_bptr,
+                                const int32_t *order, __bf16 *dst, int64_t n_tgt, int tile_rows, int volume,
+                                hipStream_t stream, float *stat_mean, float *stat_m2) {
+  const int lds = conv_off_lds_bytes(NC, KC, tile_rows, volume);
+  if (lds > kLdsBudget) return -1;
+  auto fn = &k_conv_off_bf16<NC, KC, GW, CBW>;
+  static bool attr_set = false;
+  if (lds > 48 * 1024 && !attr_set) {
+    ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
+    attr_set = true;
+  }
+  const dim3 grid((unsigned)ceil_div(n_tgt, tile_rows), (unsigned)(c_dst / NC));
+  hipLaunchKernelGGL(fn, grid, dim3(GW * (NC / 16 / CBW) * 64), (size_t)lds, stream, src, c_src, wp, c_dst, plan_src, plan_dst,
+                     batch_desc, tile_bptr, order, dst, n_tgt, tile_rows, volume, stat_mean, stat_m2);
+  ME_LAUNCH_CHECK();
+  return 0;
+}
+
+static int conv_off_dispatch(const __bf16 *src, int64_t n_src, int c_src, const bf16x8 *wp, int volume, int c_dst,
+                             const int32_t *plan_src, const int32_t *plan_dst, const int32_t *batch_desc,
+                             const int32_t *tile_bptr, const int32_t *order, __bf16 *dst, int64_t n_tgt, int tile_rows,
+                             hipStream_t stream, float *stat_mean, float *stat_m2) {
+  const ConvVariantBf16 v = conv_variant_bf16(c_src, c_dst);
+  const bool small = n_src > 0 && n_src < (1ll << 24) && n_src * c_src * 2 < (1ll << 32);
+  if (!small || c_src % v.kc != 0 || volume > 255) return -1;
+  const int nc = c_dst % 128 == 0 ? 128 : (c_dst % 96 == 0 ? 96 : (c_dst % 64 == 0 ? 64 : (c_dst % 32 == 0 ? 32 : 0)));
+  if (nc == 0) return -1;
+  if (stat_mean != nullptr && nc == 96) return -1;     // (no statistics epilogue for 96-column slabs)
+  const int shape = g_bf16_offsync;                     // 1: more group waves, 2: more column waves
+#define ME_OFF(NCV, KCV, GWV, CBWV)                                                                                   \
+  return launch_conv_off_bf16<NCV, KCV, GWV, CBWV>(src, c_src, wp, c_dst, plan_src, plan_dst, batch_desc, tile_bptr, order, \
+                                                   dst, n_tgt, tile_rows, volume, stream, stat_mean, stat_m2)
+#define ME_OFF_KC(NCV, GA, CA, GB, CB)                                      \
+  do {                                                                      \
+    if (v.kc == 128) { if (shape == 2) ME_OFF(NCV, 128, GB, CB); ME_OFF(NCV, 128, GA, CA); } \
+    if (v.kc == 96) { if (shape == 2) ME_OFF(NCV, 96, GB, CB); ME_OFF(NCV, 96, GA, CA); }   \
+    if (v.kc == 64) { if (shape == 2) ME_OFF(NCV, 64, GB, CB); ME_OFF(NCV, 64, GA, CA); }   \
+    if (v.kc == 32) { if (shape == 2) ME_OFF(NCV, 32, GB, CB); ME_OFF(NCV, 32, GA, CA); }   \
+  } while (0)
+  if (nc == 128) ME_OFF_KC(128, 4, 4, 2, 2);    // 8 waves: 4 group waves x 2 column parts | 2 x 4
+  if (nc == 96) ME_OFF_KC(96, 4, 3, 2, 3);      // 8 waves: 4 x 2 | 4 waves: 2 x 2
+  if (nc == 64) ME_OFF_KC(64, 4, 2, 8, 4);      // 8 waves: 4 x 2 | 8 x 1
+  if (nc == 32) ME_OFF_KC(32, 4, 2, 8, 2);      // 4 waves: 4 x 1 | 8 x 1
+#undef ME_OFF_KC
+#undef ME_OFF
+  return -1;
+}
+
 }  // namespace me
 
 using namespace me;
@@ -1129,6 +1441,7 @@ int64_t me_conv_splitk_workspace_bytes(int64_t n_tgt, int32_t tile_rows, int32_t
   return (int64_t)split_k * ceil_div(n_tgt, tile_rows) * tile_rows * c_dst * 4;
 }
 
+void me_debug_set_bf16_offsync(int mode) { g_bf16_offsync = mode; }
 void me_debug_set_bf16_splitk(int g) { g_bf16_splitk = g; }
 void me_debug_set_bf16_splitk_mode(int same_tiles) { g_bf16_splitk_same_tiles = same_tiles; }
 
@@ -1210,6 +1523,11 @@ static int conv_target_bf16(const uint16_t *src_, int64_t n_src, int32_t c_src, 
   const __bf16 *src = reinterpret_cast<const __bf16 *>(src_);
   const bf16x8 *wp = reinterpret_cast<const bf16x8 *>(wp_);
   __bf16 *dst = reinterpret_cast<__bf16 *>(dst_);
+  if (g_bf16_offsync != 0 && split_k <= 1) {
+    const int rc = conv_off_dispatch(src, n_src, c_src, wp, (int)volume, c_dst, plan_src, plan_dst, batch_desc, tile_bptr,
+                                     order, dst, n_tgt, tile_rows, stream, stat_mean, stat_m2);
+    if (rc != -1) return rc;
+  }
   const ConvVariantBf16 v = conv_variant_bf16(c_src, c_dst);
 #define ME_CONV_CASE(NCV, KCV)                                                                                   \
   return launch_conv_tile_bf16<NCV, KCV>(src, c_src, wp, c_dst, v.slabs, plan_src, plan_dst, batch_desc, tile_bptr, \

@@ -443,3 +443,48 @@ def test_bf16_split_k_policy_and_statistics(device, host_layer, monkeypatch):
     assert float((a[0] - b[0]).abs().max()) <= 2.0 ** -7 * scale
     assert float((a[1] - b[1]).abs().max()) <= 1e-5 * scale + 1e-6
     assert float(((a[2] - b[2]) / b[2]).abs().max()) <= 1e-4
+
+
+@pytest.mark.parametrize("n,extent,cin,cout,ks,stride,D", [
+    (5000, 16, 128, 128, 3, 1, 3), (6000, 40, 96, 96, 3, 1, 3), (4000, 14, 64, 64, 3, 1, 3), (5000, 30, 32, 32, 3, 1, 3),
+    (3000, 12, 192, 128, 3, 1, 3), (2500, 12, 256, 256, 3, 1, 3), (1500, 8, 384, 256, 3, 1, 3), (6000, 40, 128, 96, 3, 1, 3),
+    (3000, 10, 32, 64, 3, 1, 4), (4000, 14, 64, 128, 2, 2, 3), (70, 3, 128, 256, 3, 1, 3), (1, 2, 32, 32, 3, 1, 3),
+    (9000, 60, 64, 64, 3, 1, 3)])
+def test_offset_synchronous_kernel_is_bit_identical(device, no_split_k, n, extent, cin, cout, ks, stride, D):
+    """k_conv_off_bf16 (round 4): the waves of a workgroup split an item by rows (their 16 gathered rows go straight into
+    the MFMA operand, the offset's weight slice sits in LDS, one barrier per offset) instead of by columns.  The same
+    additions in the same order as k_conv_tile_bf16 on the same plan: forward and input gradient are BIT-IDENTICAL in
+    both wave shapes, on dense, sparse, strided, 4-D, several-chunk and single-row maps — and both match the oracle."""
+    from minkowskiengine_amd import _lib, backend as MEB
+    lib = _lib.load()
+    coords = make_cloud(n, extent, D, seed=cin + cout + n, batch=2 if n > 100 else 1, negative=True)
+    g = torch.Generator().manual_seed(17)
+    x = bf16_round(torch.rand(coords.shape[0], cin, generator=g) - 0.5)
+    w = bf16_round(torch.rand(ks ** D, cin, cout, generator=g) - 0.5)
+    res = {}
+    try:
+        for mode in (0, 1, 2):
+            lib.me_debug_set_bf16_offsync(mode)
+            # the offset-synchronous kernel keeps 256-channel layers in 128-channel chunks: the column-split kernel is
+            # held to the same chunking (another chunk depth regroups the fp32 sums)
+            lib.me_debug_set_bf16_shape(0, 128 if (mode == 0 and cin % 256 == 0) or (mode == 0 and cout % 256 == 0) else 0)
+            mgr = MEB.CoordinateMapManagerGPU_c10()
+            key, _ = mgr.insert_and_map(coords.to(device), [1] * D, "")
+            okey = mgr.stride(key, [stride] * D, "")
+            km = mgr._kernel_map(key, okey, [ks] * D, [stride] * D, [1] * D, MEB.RegionType.HYPER_CUBE, None, False, False)
+            wd = w.clone().to(device)
+            gy = bf16_round(torch.rand(km.n_out, cout, generator=torch.Generator().manual_seed(5)) - 0.5)
+            y = MEB._conv_forward(x.to(device).bfloat16(), wd, km, "mfma")
+            gi = MEB._conv_target(gy.to(device).bfloat16(), wd, km, "in", km.n_in, name="d", transposed=True)
+            res[mode] = (y.clone(), gi.clone(), mgr.get_coordinates(okey).cpu().numpy(), gy)
+    finally:
+        lib.me_debug_set_bf16_offsync(0)
+        lib.me_debug_set_bf16_shape(0, 0)
+    for mode in (1, 2):
+        assert torch.equal(res[mode][0], res[0][0]), f"forward, wave shape {mode}"
+        assert torch.equal(res[mode][1], res[0][1]), f"input gradient, wave shape {mode}"
+    in_c, out_c = coords.numpy(), res[0][2]
+    _, okm = O.kernel_map(in_c, out_c, O.make_region(D, ks, 1, 1))
+    assert_bf16_close(res[1][0].float().cpu().numpy(), O.conv_forward(x.numpy(), w.numpy(), okm, len(out_c)), "forward")
+    assert_bf16_close(res[1][1].float().cpu().numpy(), O.conv_backward(x.numpy(), res[0][3].numpy(), w.numpy(), okm)[0],
+                      "grad_in")
