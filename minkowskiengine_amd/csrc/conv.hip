@@ -1686,6 +1686,7 @@ __global__ __launch_bounds__(256, 3) void k_wgrad_f32x3(const float *__restrict_
   if (pending >= 0) flush(pending);
 }
 
+#ifdef ME_DEBUG_VARIANTS   // (measured at the speed of k_wgrad_f32, never the default: tuning build only)
 // The same staged design in fp32 (v_mfma_f32_16x16x4_f32, exact fp32): rows are gathered ONCE per workgroup with
 // 16-byte loads and shared by the four waves through LDS, so the matrix pipe is fed by one conflict-free
 // ds_read_b32 per operand instead of one global gather per wave — k_wgrad_f32 above re-gathers every x row in
@@ -1893,6 +1894,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_lds_f32(const float *__restric
   wait_rows();
   if (pending >= 0) flush(pending);
 }
+#endif  // ME_DEBUG_VARIANTS
 
 // grad_w[k] = sum of the register images of the ranges that touch offset k, written back through the
 // channel interleave of k_wgrad_f32.  A block sums 64 consecutive image elements; its four waves take
@@ -2318,6 +2320,7 @@ static int launch_wgrad_bf16(const WgradGeom &g, const __bf16 *x, int c_in, cons
   return 0;
 }
 
+#ifdef ME_DEBUG_VARIANTS
 template <int NB, int KSTEPS>
 static int launch_wgrad_lds_f32(const WgradGeom &g, const float *x, int c_in, const float *dy, int c_out,
                                 const int32_t *in_pairs, const int32_t *out_pairs, const int64_t *k_offsets_dev,
@@ -2336,6 +2339,7 @@ static int launch_wgrad_lds_f32(const WgradGeom &g, const float *x, int c_in, co
   ME_LAUNCH_CHECK();
   return 0;
 }
+#endif
 
 template <int NB>
 static int launch_wgrad_f32x3(const WgradGeom &g, const float *x, int c_in, const float *dy, int c_out,
@@ -2688,6 +2692,10 @@ int me_conv_wgrad_f32(const float *x, int64_t n_in, int32_t c_in, const float *d
     ME_LAUNCH_CHECK();
     return 0;
   }
+#ifndef ME_DEBUG_VARIANTS
+  return wgrad_launch<float>(x, n_in, c_in, dy, n_out, c_out, in_pairs, out_pairs, k_offsets, k_offsets_dev, volume, grad_w,
+                             workspace, workspace_bytes, stream);
+#else
   if ((c_in % 4) != 0 || (c_out % 4) != 0 || g_wgrad_depth != -2)
     return wgrad_launch<float>(x, n_in, c_in, dy, n_out, c_out, in_pairs, out_pairs, k_offsets, k_offsets_dev, volume, grad_w,
                                workspace, workspace_bytes, stream);
@@ -2717,6 +2725,7 @@ int me_conv_wgrad_f32(const float *x, int64_t n_in, int32_t c_in, const float *d
                        n_pairs > 0 ? n_pairs : 1, (int)g.ranges, g.n_cib, g.n_cob, c_in, c_out, grad_w);
   ME_LAUNCH_CHECK();
   return 0;
+#endif
 }
 
 }  // extern "C"

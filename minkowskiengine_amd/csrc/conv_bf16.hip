@@ -641,6 +641,7 @@ __global__ __launch_bounds__(NC * 4, DEEP ? 2 : conv_bf16_waves_per_simd(NC, KC)
 #undef ME_COUNT
 }
 
+#ifdef ME_DEBUG_VARIANTS   // measured 1.4 - 2.6x SLOWER than k_conv_tile_bf16 (profiles/r04_offsync_schedule_sweep.log): tuning build only
 // =================================================================================================
 // k_conv_off_bf16 (round 4): the same plan, the same sums — another schedule ("offset-synchronous")
 // =================================================================================================
@@ -899,6 +900,8 @@ __global__ __launch_bounds__(GW * (NC / 16 / CBW) * 64, 4) void k_conv_off_bf16(
   }
 }
 
+#endif  // ME_DEBUG_VARIANTS (k_conv_off_bf16)
+
 // Second phase of a SPLITK launch: out[row] = bf16(sum over offset groups g of partial[g][row]) — fp32 adds in group
 // order, one rounding — for one (tile, column slab) per workgroup, and the tile's batch-norm statistics exactly as the
 // unsplit kernel's store loop forms them (shifted by the tile's first row; thread's rows ascending, xor-shuffle tree,
@@ -995,6 +998,7 @@ __global__ __launch_bounds__(NC * 4) void k_conv_splitk_reduce(const float *__re
   }
 }
 
+#ifdef ME_DEBUG_VARIANTS   // slower than the plan kernel on every MinkUNet layer but one (docs/HISTORY.md 9.6): tuning build only
 // =================================================================================================
 // output-stationary ("gather") convolution on bf16 features: k_conv_gather_bf16 (round 2)
 // =================================================================================================
@@ -1160,6 +1164,9 @@ __global__ __launch_bounds__(256, 2) void k_conv_gather_bf16(
   }
 }
 
+#endif  // ME_DEBUG_VARIANTS (k_conv_gather_bf16)
+
+#ifdef ME_DEBUG_VARIANTS
 // column blocks per slab of the gather kernel for c_dst columns: the largest of 8, 6, 4, 2 that divides c_dst / 16;
 // 0: not eligible
 static int conv_gather_cb(int c_src, int c_dst) {
@@ -1169,6 +1176,7 @@ static int conv_gather_cb(int c_src, int c_dst) {
     if (ncb % cb == 0) return cb;
   return 0;
 }
+#endif
 
 extern int g_conv_variant;  // conv.hip: variant 6 = 64-bit gather addresses, 7 = no batch fusion
 
@@ -1315,6 +1323,7 @@ static int launch_conv_tile_bf16(const __bf16 *src, int c_src, const bf16x8 *wp,
   return 0;
 }
 
+#ifdef ME_DEBUG_VARIANTS
 // k_conv_off_bf16 for a launch, or -1 when the shape / plan is not eligible (the column-split kernel runs then)
 template <int NC, int KC, int GW, int CBW>
 static int launch_conv_off_bf16(const __bf16 *src, int c_src, const bf16x8 *wp, int c_dst, const int32_t *plan_src,
@@ -1365,6 +1374,8 @@ static int conv_off_dispatch(const __bf16 *src, int64_t n_src, int c_src, const 
 #undef ME_OFF
   return -1;
 }
+
+#endif  // ME_DEBUG_VARIANTS
 
 }  // namespace me
 
@@ -1441,7 +1452,13 @@ int64_t me_conv_splitk_workspace_bytes(int64_t n_tgt, int32_t tile_rows, int32_t
   return (int64_t)split_k * ceil_div(n_tgt, tile_rows) * tile_rows * c_dst * 4;
 }
 
-void me_debug_set_bf16_offsync(int mode) { g_bf16_offsync = mode; }
+void me_debug_set_bf16_offsync(int mode) {
+#ifdef ME_DEBUG_VARIANTS
+  g_bf16_offsync = mode;
+#else
+  (void)mode;   // (the kernel is not in the default build: the switch stays off, me_debug_variants_compiled() says so)
+#endif
+}
 void me_debug_set_bf16_splitk(int g) { g_bf16_splitk = g; }
 void me_debug_set_bf16_splitk_mode(int same_tiles) { g_bf16_splitk_same_tiles = same_tiles; }
 
@@ -1523,11 +1540,13 @@ static int conv_target_bf16(const uint16_t *src_, int64_t n_src, int32_t c_src, 
   const __bf16 *src = reinterpret_cast<const __bf16 *>(src_);
   const bf16x8 *wp = reinterpret_cast<const bf16x8 *>(wp_);
   __bf16 *dst = reinterpret_cast<__bf16 *>(dst_);
+#ifdef ME_DEBUG_VARIANTS
   if (g_bf16_offsync != 0 && split_k <= 1) {
     const int rc = conv_off_dispatch(src, n_src, c_src, wp, (int)volume, c_dst, plan_src, plan_dst, batch_desc, tile_bptr,
                                      order, dst, n_tgt, tile_rows, stream, stat_mean, stat_m2);
     if (rc != -1) return rc;
   }
+#endif
   const ConvVariantBf16 v = conv_variant_bf16(c_src, c_dst);
 #define ME_CONV_CASE(NCV, KCV)                                                                                   \
   return launch_conv_tile_bf16<NCV, KCV>(src, c_src, wp, c_dst, v.slabs, plan_src, plan_dst, batch_desc, tile_bptr, \
@@ -1611,7 +1630,15 @@ int me_conv_target_bf16_ex(const uint16_t *src, int64_t n_src, int32_t c_src, co
                           reinterpret_cast<float *>(workspace));
 }
 
-int32_t me_conv_gather_supported_bf16(int32_t c_src, int32_t c_dst) { return conv_gather_cb(c_src, c_dst) > 0 ? 1 : 0; }
+int32_t me_conv_gather_supported_bf16(int32_t c_src, int32_t c_dst) {
+#ifdef ME_DEBUG_VARIANTS
+  return conv_gather_cb(c_src, c_dst) > 0 ? 1 : 0;
+#else
+  (void)c_src;
+  (void)c_dst;
+  return 0;     // the output-stationary kernel is in the tuning build only (scripts/build_debug.sh): use me_conv_target_bf16
+#endif
+}
 
 int64_t me_conv_gather_weight_elems_bf16(int64_t volume, int32_t c_src, int32_t c_dst) {
   if (volume <= 0 || c_src <= 0 || c_dst <= 0) return 0;
@@ -1642,6 +1669,11 @@ int me_conv_gather_bf16(const uint16_t *src_, int64_t n_src, int32_t c_src, cons
                         void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   (void)n_src;
+#ifndef ME_DEBUG_VARIANTS
+  (void)src_; (void)c_src; (void)wp_; (void)volume; (void)c_dst; (void)tbl; (void)order; (void)dst_; (void)n_tgt; (void)stream;
+  ME_CHECK(false, "the output-stationary kernel is in the tuning build only (me_conv_gather_supported_bf16 == 0)");
+  return -1;
+#else
   const int cb = conv_gather_cb(c_src, c_dst);
   ME_CHECK(cb > 0, "channel counts not eligible for the gather kernel (me_conv_gather_supported_bf16)");
   ME_CHECK(volume >= 1 && volume <= 65535, "kernel volume out of range");
@@ -1662,6 +1694,7 @@ int me_conv_gather_bf16(const uint16_t *src_, int64_t n_src, int32_t c_src, cons
 #undef ME_GATHER
   ME_LAUNCH_CHECK();
   return 0;
+#endif
 }
 
 }  // extern "C"
