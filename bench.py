@@ -91,6 +91,108 @@ def pmc_traffic(kernel, n, extent, cin, cout):
         return None, None
 
 
+# ------------------------------------------------------------------------------------------------------
+# HBM-side traffic, measured in THIS run (round 4): rocprofv3 --pmc passes over a child process
+# ------------------------------------------------------------------------------------------------------
+PMC_CONV_KERNELS = ("k_conv_tile", "k_wgrad", "k_conv_splitk_reduce", "k_conv_off")
+
+
+def pmc_pass(workload, dtype, counters, steps, timeout_s):
+    """One rocprofv3 counter pass over a CHILD process of this script that runs `steps` steps of `workload` (counters
+    cannot share a run with the timed region: a PMC pass serialises the kernels).  -> {kernel name: {counter: (sum over
+    launches, launches)}} or None.  FETCH_SIZE / WRITE_SIZE need separate passes (MI355X_MICROARCH.md: TCC has 4
+    slots, FETCH_SIZE costs 3, WRITE_SIZE 2)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    out = tempfile.mkdtemp(prefix="me_pmc_", dir="/tmp")
+    cmd = [exe, "--kernel-trace", "--pmc"] + list(counters) + ["--output-format", "csv", "-d", out, "-o", "pmc", "--",
+           sys.executable, os.path.abspath(__file__), "--workload", workload, "--dtype", dtype, "--pmc-child", str(steps)]
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+        agg = {}
+        for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+            with open(f) as fh:
+                for row in csv.DictReader(fh):
+                    k = agg.setdefault(row.get("Kernel_Name", ""), {})
+                    c = k.setdefault(row["Counter_Name"], [0.0, 0])
+                    c[0] += float(row["Counter_Value"])
+                    c[1] += 1
+        return agg or None
+    except Exception:  # noqa: BLE001  (a missing profiler / a timeout must not cost the benchmark line)
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
+def measure_traffic(workload, dtype, kernel_match, steps, deadline):
+    """HBM-side bytes of the launches whose kernel name contains every string of `kernel_match` (None: all convolution
+    kernels): FETCH_SIZE x 2 (gfx950 tallies 128-byte requests at 64 B: MI355X_MICROARCH.md, HBM) + WRITE_SIZE, both in
+    KiB.  -> dict(per_launch bytes, per_step bytes, launches_per_step, fetch / write split) or None when the profiler is
+    absent, a pass failed or the time budget (`deadline`, perf_counter seconds) is used up."""
+    res = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        left = deadline - time.perf_counter()
+        if left < 20:
+            return None
+        agg = pmc_pass(workload, dtype, [counter], steps, min(left, 150))
+        if not agg:
+            return None
+        tot, n = 0.0, 0
+        for name, cs in agg.items():
+            if counter not in cs:
+                continue
+            hit = all(m in name for m in kernel_match) if kernel_match else any(m in name for m in PMC_CONV_KERNELS)
+            if hit:
+                tot += cs[counter][0]
+                n += cs[counter][1]
+        if n == 0:
+            return None
+        res[counter] = (tot * 1024.0, n)
+    fetch = 2.0 * res["FETCH_SIZE"][0]
+    write = res["WRITE_SIZE"][0]
+    n = res["FETCH_SIZE"][1]
+    return {"per_launch": int((fetch + write) / n), "per_step": int((fetch + write) / steps),
+            "launches_per_step": round(n / steps, 2), "fetch_bytes_per_launch": int(fetch / n),
+            "write_bytes_per_launch": int(write / n),
+            "source": f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one pass each over a child process "
+                      f"running {steps} steps of the workload (FETCH_SIZE doubled: gfx950 tallies 128-byte requests at 64 B)"}
+
+
+def attach_traffic(line, args, deadline):
+    """fill line['roofline']['traffic'] (and the compact workload entries) from in-run PMC passes, most important first,
+    while the budget lasts; entries that are not reached keep their cited constant / null"""
+    if args.pmc == "off":
+        return
+    r = line.get("roofline") or {}
+    tag = r.get("pmc_match")
+    if tag:
+        t = measure_traffic(args.workload, args.dtype, tag, 3, deadline)
+        if t:
+            r["traffic"] = t["per_launch"]
+            r["traffic_detail"] = t
+            r["traffic_note"] = "HBM-side bytes per launch of this kernel — " + t["source"]
+            r["traffic_over_compulsory"] = round(t["per_launch"] / r["compulsory_bytes_per_launch"], 3) \
+                if r.get("compulsory_bytes_per_launch") else None
+    for name, wl, dt in (("minkunet34c_bf16_200k", "minkunet", "bf16"), ("conv4d_f32_400k", "conv4d", "f32")):
+        ent = (line.get("workloads") or {}).get(name)
+        if not isinstance(ent, dict) or "roofline" not in ent:
+            continue
+        rr = ent["roofline"]
+        t = measure_traffic(wl, dt, rr.get("pmc_match"), 2 if wl == "minkunet" else 3, deadline)
+        if t:
+            rr["traffic"] = t["per_step"] if wl == "minkunet" else t["per_launch"]
+            rr["traffic_detail"] = t
+            rr["traffic_note"] = ("HBM-side bytes per STEP of all convolution launches — " if wl == "minkunet" else
+                                  "HBM-side bytes per launch of this kernel — ") + t["source"]
+
+
+
 def hip_timed(fn):
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -406,8 +508,12 @@ def roofline_entry(kernel, flops, compulsory_bytes, avg_ms, bf16, traffic, traff
             r.update({"peak": round(pipe_peak, 1), "frac": r["frac_of_pipe"]})
     r["traffic"] = traffic
     r["traffic_note"] = ("HBM-side bytes per launch (FETCH_SIZE x2 + WRITE_SIZE) — a CITED constant from the committed "
-                         f"rocprofv3 --pmc passes ({traffic_src}), not measured in this run" if traffic is not None else
-                         "no committed PMC pass for this workload")
+                         f"rocprofv3 --pmc passes ({traffic_src}); replaced by an in-run measurement when the run's PMC "
+                         "budget allows (--pmc)" if traffic is not None else
+                         "no committed PMC pass for this workload; measured in-run when the PMC budget allows (--pmc)")
+    # (kernel-name fragments that select this launch in a rocprofv3 counter table: attach_traffic)
+    m = kernel.split("<")
+    r["pmc_match"] = [m[0].strip() + "<" + m[1].split(">")[0].replace(",", ", ") + ","] if len(m) > 1 else [m[0].strip()]
     return r
 
 
@@ -457,6 +563,11 @@ def bench_conv(args, ME, MEB, dist_utils, rank, world, dev, startup):
         out = net(x)
         out.F.backward(grad_seed)
 
+    if getattr(args, "pmc_child_mode", False):     # profiled child (measure_traffic): the steps and nothing else
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        return None
     best, blocks, timer, timed_steps = run_timed(step, args, dist_utils, MEB, dev)
     per_rank = LAST_RUN.get("per_rank_ms_per_step")
     total_points = dist_utils.sum_over_ranks(n, dev)
@@ -634,6 +745,11 @@ def bench_minkunet(args, ME, MEB, dist_utils, rank, world, dev, startup):
             pending[0] = next_scene()
         opt.step()
 
+    if getattr(args, "pmc_child_mode", False):     # profiled child (measure_traffic): exactly `steps` steps
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        return None
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     step()
@@ -737,7 +853,9 @@ def bench_minkunet(args, ME, MEB, dist_utils, rank, world, dev, startup):
                      "peak": peak, "unit": "TFLOP/s",
                      "frac": round((achieved if achieved is not None else whole) / peak, 4),
                      "whole_step_tflops": whole, "whole_step_frac": round(whole / peak, 4),
-                     "traffic": None,
+                     "traffic": None, "pmc_match": None,
+                     "traffic_note": "HBM-side bytes per step of all convolution launches: measured in-run when the PMC "
+                                     "budget allows (--pmc)",
                      "flops_per_step": tot_flops, "conv_kernel_ms_per_step": round(tot_ms, 3)},
         "kernels": kernels,
         "cold_ms": round(cold_ms, 2),
@@ -850,6 +968,11 @@ def main():
                          "conv) under `workloads` (auto: with the default single-GPU headline run only)")
     ap.add_argument("--cpu-capped", action="store_true",
                     help="minkunet: also time the reference CPU layers under its own 16-thread cap (doubles the CPU time)")
+    ap.add_argument("--pmc", choices=("auto", "on", "off"), default="auto",
+                    help="measure roofline.traffic in this run with rocprofv3 --pmc passes over child processes (auto: "
+                         "single-GPU runs when rocprofv3 is installed; bounded by --pmc-budget)")
+    ap.add_argument("--pmc-budget", type=float, default=100.0, help="seconds the in-run PMC passes may take in total")
+    ap.add_argument("--pmc-child", type=int, default=0, help=argparse.SUPPRESS)   # internal: run N untimed steps and exit
     ap.add_argument("--accum", type=int, default=4,
                     help="N > 1, conv workloads: length of the gradient-accumulation window reported under "
                          "multi_gpu.accumulation (A - 1 micro-steps under DDP.no_sync, the A-th all-reduces)")
@@ -898,6 +1021,15 @@ def main():
     if args.debug_bf16_shape:
         lib.me_debug_set_bf16_shape(*[int(v) for v in args.debug_bf16_shape.split(",")])
     fn = bench_minkunet if args.workload == "minkunet" else bench_conv
+    if args.pmc_child:
+        # profiled child of measure_traffic(): the same workload objects, `pmc_child` untimed steps, no JSON line
+        args.steps, args.warmup, args.cpu_budget = args.pmc_child, 0, 0.0
+        args.min_time, args.min_blocks, args.max_blocks, args.no_graph_probe = 0.0, 1, 1, True
+        args.extra_workloads, args.pmc = "off", "off"
+        args.pmc_child_mode = True
+        fn(args, ME, MEB, dist_utils, rank, world, dev, startup)
+        print(f"PMC_CHILD_STEPS={args.steps}", flush=True)
+        return
     line = fn(args, ME, MEB, dist_utils, rank, world, dev, startup)
     default_headline = (args.workload == "conv3d" and args.dtype == "f32" and not args.points and
                         not args.cin and not args.cout and args.extent == 70)
@@ -906,7 +1038,13 @@ def main():
         extra = extra_workloads(args, ME, MEB, dist_utils, rank, world, dev, startup)
         if line is not None:
             line["workloads"] = extra
+    if rank == 0 and world == 1 and args.pmc != "off":
+        attach_traffic(line, args, time.perf_counter() + args.pmc_budget)
     if rank == 0:
+        for r in [line.get("roofline")] + [w.get("roofline") for w in (line.get("workloads") or {}).values()
+                                           if isinstance(w, dict)]:
+            if isinstance(r, dict):
+                r.pop("pmc_match", None)
         print(json.dumps(line), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

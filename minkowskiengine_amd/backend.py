@@ -99,6 +99,50 @@ def get_gpu_memory_info():
     return free, total
 
 
+# roctx ranges (insert / stride / kernel map / plan / forward / dgrad / wgrad) for `rocprofv3
+# --marker-trace`, when ME_AMD_ROCTX=1; the marker library is resolved at run time
+_ROCTX = None
+if os.environ.get("ME_AMD_ROCTX", "0") != "0":
+    for _name in ("librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"):
+        try:
+            _ROCTX = ctypes.CDLL(_name)
+            _ROCTX.roctxRangePushA.argtypes = [ctypes.c_char_p]
+            break
+        except (OSError, AttributeError):
+            _ROCTX = None
+
+
+class _roctx:
+    """with _roctx("me:kernel_map"): a roctx range around the launches of the block (no-op unless ME_AMD_ROCTX=1)"""
+    __slots__ = ("name",)
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if _ROCTX is not None:
+            _ROCTX.roctxRangePushA(self.name.encode())
+
+    def __exit__(self, *exc):
+        if _ROCTX is not None:
+            _ROCTX.roctxRangePop()
+        return False
+
+
+def _ranged(name):
+    """decorator: the call runs inside a roctx range (ME_AMD_ROCTX=1), else untouched"""
+    def deco(fn):
+        if _ROCTX is None:
+            return fn
+
+        def wrapped(*a, **kw):
+            with _roctx(name):
+                return fn(*a, **kw)
+        wrapped.__name__, wrapped.__doc__ = fn.__name__, fn.__doc__
+        return wrapped
+    return deco
+
+
 def _check(cond, *msg):
     if not cond:
         raise RuntimeError("assertion failed. " + " ".join(str(m) for m in msg))
@@ -469,6 +513,7 @@ class KernelMapGPU:
                 self._store[name] = torch.argsort(keys, stable=True).to(torch.int32)
         return self._store[name]
 
+    @_ranged("me:tile_plan")
     def plan(self, target, tile_rows, batch_groups, tile_order=None):
         """Tile plan with `target` rows stationary, tiles of `tile_rows` rows and batches of at most
         `batch_groups` groups: (plan_src, plan_dst, batch_desc, tile_bptr, item_gptr); built once per
@@ -651,6 +696,7 @@ class CoordinateMapManagerGPU_c10:
         return [CoordinateMapKey(list(k[0]), k[1]) for k in self._maps if k[0] == ts]
 
     # ---- maps -----------------------------------------------------------------------------------
+    @_ranged("me:insert_and_map")
     def insert_and_map(self, coordinates, tensor_stride, string_id=""):
         """src/coordinate_map_manager.cpp:349-399 -> (CoordinateMapKey, (unique_map, inverse_map))."""
         _check(isinstance(coordinates, torch.Tensor) and coordinates.dim() == 2, "coordinates must be 2-D")
@@ -670,6 +716,7 @@ class CoordinateMapManagerGPU_c10:
         self._maps[key] = cmap
         return CoordinateMapKey(list(key[0]), key[1]), (unique_map, inverse_map)
 
+    @_ranged("me:stride")
     def stride(self, in_key, kernel_stride, string_id=""):
         """py_stride: src/coordinate_map_manager.cpp:402-429 -> CoordinateMapKey of the strided map."""
         ik = self._k(in_key)
@@ -892,6 +939,7 @@ class CoordinateMapManagerGPU_c10:
         return self._get(key).n
 
     # ---- kernel maps ----------------------------------------------------------------------------
+    @_ranged("me:kernel_map")
     def _kernel_map(self, in_key, out_key, kernel_size, kernel_stride, kernel_dilation, region_type,
                     offset, is_transpose, is_pool):
         """src/coordinate_map_manager.cpp:655-823 -> KernelMapGPU (cached)."""
@@ -1133,6 +1181,13 @@ KERNEL_TIMER = None  # set to a KernelTimer() to time launches
 
 
 def _timed(name, device, launch, flops=0.0):
+    if _ROCTX is not None:
+        with _roctx("me:" + name):
+            return _timed_inner(name, device, launch, flops)
+    return _timed_inner(name, device, launch, flops)
+
+
+def _timed_inner(name, device, launch, flops=0.0):
     if KERNEL_TIMER is None:
         return launch()
     s = KERNEL_TIMER.record(name, device)

@@ -63,7 +63,16 @@ struct Policy {
   bool pack_cache;         // ME_AMD_PACK_CACHE
   bool f32_fuse;           // ME_AMD_F32_FUSE
   bool conv_bn_stats;      // ME_AMD_CONV_BN_STATS: batch-norm statistics in the bf16 convolution's epilogue
+  bool roctx;              // ME_AMD_ROCTX: roctx ranges around insert / stride / kernel map / plan / forward / dgrad / wgrad
   static const Policy &get();
+};
+
+// roctx range of a scope (ranges around the phases of the path, for `rocprofv3 --marker-trace`): the
+// marker library is resolved at run time (librocprofiler-sdk-roctx.so, else libroctx64.so) and only when ME_AMD_ROCTX=1
+struct RoctxRange {
+  bool on;
+  explicit RoctxRange(const char *name);
+  ~RoctxRange();
 };
 
 // ---- CoordinateMapKey (src/coordinate_map_key.hpp:44-157) -----------------------------------------------------------

@@ -3,6 +3,8 @@
 // (insert_and_map :349-399, stride :402-429, kernel_map :655-823), src/coordinate_map_gpu.cu, src/kernel_map.cuh.
 #include "host.hpp"
 
+#include <dlfcn.h>
+
 #include <hip/hip_runtime_api.h>
 
 #include <cstdlib>
@@ -39,9 +41,37 @@ const Policy &Policy::get() {
     q.pack_cache = env_str("ME_AMD_PACK_CACHE", "1") != "0";
     q.f32_fuse = env_str("ME_AMD_F32_FUSE", "1") != "0";
     q.conv_bn_stats = env_str("ME_AMD_CONV_BN_STATS", "1") != "0";
+    q.roctx = env_str("ME_AMD_ROCTX", "0") != "0";
     return q;
   }();
   return p;
+}
+
+namespace {
+typedef int (*roctx_push_t)(const char *);
+typedef int (*roctx_pop_t)();
+roctx_push_t g_roctx_push = nullptr;
+roctx_pop_t g_roctx_pop = nullptr;
+bool roctx_resolve() {
+  static const bool ok = [] {
+    for (const char *lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+      if (void *h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL)) {
+        g_roctx_push = (roctx_push_t)dlsym(h, "roctxRangePushA");
+        g_roctx_pop = (roctx_pop_t)dlsym(h, "roctxRangePop");
+        if (g_roctx_push && g_roctx_pop) return true;
+      }
+    }
+    return false;
+  }();
+  return ok;
+}
+}  // namespace
+
+RoctxRange::RoctxRange(const char *name) : on(Policy::get().roctx && roctx_resolve()) {
+  if (on) g_roctx_push(name);
+}
+RoctxRange::~RoctxRange() {
+  if (on) g_roctx_pop();
 }
 
 // ---- CoordinateMapKey -------------------------------------------------------------------------------------------------
@@ -280,6 +310,7 @@ std::shared_ptr<Plan> KernelMap::plan(const std::string &target, int tile_rows, 
                          "_" + tile_order_;
   auto it = store->plans.find(nm);
   if (it != store->plans.end()) return it->second;
+  RoctxRange rx("me:tile_plan");
   const c10::Device dev = device();
   const int64_t n_tgt = target == "out" ? n_out : n_in;
   auto tp = table_pos(target);
@@ -422,6 +453,7 @@ std::shared_ptr<KernelMap> build_kernel_map(const std::shared_ptr<CoordMap> &in_
                                             const std::shared_ptr<CoordMap> &out_map, const me_region &region) {
   const int64_t volume = me_region_volume(&region);
   check(volume > 0, "invalid kernel region");
+  RoctxRange rx("me:kernel_map");
   if (auto km = build_kernel_map_lds(in_map, out_map, region, volume)) return km;
   const c10::Device dev = in_map->coords.device();
   const int64_t n_out = out_map->n, n_in = in_map->n;
@@ -489,6 +521,7 @@ KeyT CoordinateMapManager::register_map(const ivec &ts, const std::shared_ptr<Co
 
 std::tuple<KeyT, Tensor, Tensor> CoordinateMapManager::insert_and_map(Tensor coordinates, const ivec &tensor_stride,
                                                                        const std::string &string_id) {
+  RoctxRange rx("me:insert_and_map");
   check(coordinates.dim() == 2, "coordinates must be 2-D");
   check(coordinates.is_contiguous(), "coordinates must be contiguous");
   check(coordinates.scalar_type() == at::kInt, "coordinates must be int32");
@@ -515,6 +548,7 @@ static std::string vec_ser(const ivec &v) {
 }
 
 KeyT CoordinateMapManager::stride(const KeyT &in_key, const ivec &kernel_stride, const std::string &string_id) {
+  RoctxRange rx("me:stride");
   check(maps.count(in_key), "coordinate map not found");
   check(kernel_stride.size() == in_key.first.size(), "stride size mismatch.");
   ivec out_ts(in_key.first.size());

@@ -191,11 +191,14 @@ struct TimedLaunch {
 bool g_timing = false;
 std::vector<TimedLaunch> g_timed;
 
-struct ScopedTimer {   // records an event pair around the launches of its scope when timing is on
-  bool on;
+struct ScopedTimer {   // records an event pair around the launches of its scope when timing is on; a roctx range always
+  bool on;                // (when ME_AMD_ROCTX=1: "me:conv_forward" / "me:conv_dgrad" / "me:conv_wgrad")
   TimedLaunch t;
   hipStream_t st;
-  ScopedTimer(const char *name, double flops, void *stream) : on(g_timing), st((hipStream_t)stream) {
+  std::string rx_name;
+  RoctxRange rx;
+  ScopedTimer(const char *name, double flops, void *stream)
+      : on(g_timing), st((hipStream_t)stream), rx_name(std::string("me:") + name), rx(rx_name.c_str()) {
     if (!on) return;
     t.name = name;
     t.flops = flops;
