@@ -568,7 +568,7 @@ _SPATIAL_MIN_PROBES = 1 << 24       # ... or maps of at least this many (row, of
 # pos_of_row), "spatial" = runs of positions in the supercell order of the target map (spatially compact tiles: 2 -
 # 2.6x less HBM-side traffic in the convolution; flat-table maps take the order from the target coordinate map's
 # spatial index).  "auto" decides per launch family (KernelMapGPU._tile_order): the fp32 kernels on the bf16 matrix
-# pipe always take spatial tiles (same speed); the others — 3 - 12 % slower on spatial tiles of uniform
+# pipe always take spatial tiles (same speed, docs/HISTORY.md 9.12); the others — 3 - 12 % slower on spatial tiles of uniform
 # random scenes — keep row tiles while the table is small enough for the plan builder's scattered reads (<= 32 MiB:
 # L2 / Infinity Cache resident) and take spatial tiles beyond (config 5: 130 MB table — the row-order plan took
 # 2.0 ms instead of 0.37)
@@ -663,7 +663,7 @@ class CoordinateMapManagerGPU_c10:
         # maps, kernel maps, tile-plan / weight-gradient configurations.  `prefetch(recipe)` replays such a list on a
         # NEW scene right after its coordinates are inserted, so that every host read-back of the build (output sizes,
         # pair counts) happens in one burst before the forward pass instead of draining the launch queue in the
-        # middle of it.
+        # middle of it (docs/HISTORY.md 9.8).
         self._recipe = []
 
     # ---- keys -----------------------------------------------------------------------------------
@@ -1016,7 +1016,7 @@ class CoordinateMapManagerGPU_c10:
     def record_stream(self, stream):
         """Tell the caching allocator that `stream` uses this manager's buffers (torch.Tensor.record_stream on each):
         needed when the maps were built on a side stream — e.g. the next scene's maps during the current step's
-        backward pass, DESIGN 9.8 — and are consumed on another one."""
+        backward pass, docs/HISTORY.md 9.8 — and are consumed on another one."""
         for t in self.device_tensors():
             t.record_stream(stream)
 
@@ -1088,7 +1088,7 @@ _BF16_FUSE_MAX_PAIRS_PER_ITEM = 24.0
 _F32_FUSE = os.environ.get("ME_AMD_F32_FUSE", "1") != "0"
 _BF16_GATHER = os.environ.get("ME_AMD_BF16_GATHER", "0") != "0"   # bf16: output-stationary kernel (opt-in: measured slower than the tile-plan kernel)
 # fp32 features: forward / dgrad on the bf16 matrix pipe with exactly split operands (csrc/conv_f32x3.hip; fp32-grade
-# results).  "auto": where it measured faster than the fp32-MFMA kernel k_conv_tile_f32 — layers with
+# results, docs/HISTORY.md 9.7).  "auto": where it measured faster than the fp32-MFMA kernel k_conv_tile_f32 — layers with
 # c_src * c_dst >= 8192 (64 -> 128 and wider: 1.1 - 1.6x on every map density tried; below that the per-batch costs of
 # three operand planes outweigh the cheaper MFMAs, profiles/r02_tune_split_policy.log); "1": wherever supported
 # (c_src % 8 == 0); "0": never.

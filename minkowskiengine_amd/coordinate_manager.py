@@ -17,7 +17,7 @@ _minkowski_algorithm = MinkowskiAlgorithm.DEFAULT
 # Map prefetch (not in the reference): when on, a SparseTensor that creates its own CoordinateManager replays, right after
 # its coordinates are inserted, the map-building requests that the PREVIOUS scene's manager served (strided maps, kernel
 # maps, tile plans) — a training loop builds the same maps for every scene, and building them in one burst keeps the
-# host read-backs of the build out of the forward pass (backend.CoordinateMapManagerGPU_c10.prefetch).
+# host read-backs of the build out of the forward pass (backend.CoordinateMapManagerGPU_c10.prefetch, docs/HISTORY.md 9.8).
 _map_prefetch = os.environ.get("ME_AMD_MAP_PREFETCH", "0") != "0"
 _last_manager = None   # weak reference to the most recent CoordinateManager made by a SparseTensor
 

@@ -74,7 +74,7 @@ __device__ __forceinline__ void mma_groups(const float *__restrict__ a0p, const 
   for (int r = 0; r < R; ++r) d[r] = (int)__umul24((unsigned)dstp[r * 16], (unsigned)ACC_LD);
   // The accumulators START from the LDS tile (the old sum is the C operand of the first MFMA) and are written back
   // after the last k-step: no zero-fill, no v_add_f32 — on gfx950 every VALU instruction costs matrix time
-  // (DESIGN.md 3.1a).  The sum of a target row is ((old + x_0 w_0) + x_1 w_1) + ... in plan order: still a fixed
+  // (docs/HISTORY.md 3.1a).  The sum of a target row is ((old + x_0 w_0) + x_1 w_1) + ... in plan order: still a fixed
   // order.  (VAR & 64: timing ablation without the LDS accumulator traffic.)
   f32x4 acc[R];
 #pragma unroll
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(NC * 4, ((NC >= 96 || KC == 96 || (FUSE && NC == 32
 // =================================================================================================
 // The same tile plan and the same arithmetic as k_conv_tile_f32 (single-offset batches of <= 4 groups of 16
 // (source row, target row) entries, W_k slice in registers, fp32 accumulator tile in LDS, wave-private columns,
-// fixed summation order), with the staging redesigned around what round 1 measured (an fp32 MFMA
+// fixed summation order), with the staging redesigned around what round 1 measured (docs/HISTORY.md 3.1a: an fp32 MFMA
 // owns its SIMD — every VALU / VMEM instruction of ANY resident wave is paid for in matrix time — and the
 // per-batch barrier pair + register staging + LDS round trips left the matrix pipe 50 % busy):
 //   * gathered rows go global -> LDS directly (global_load_lds_dwordx4, 1 KiB = 4 rows per wave instruction; the
@@ -745,7 +745,7 @@ __host__ __device__ constexpr int conv_dma_lds_bytes(int nc, int kch, int tile_r
 // NC output columns per workgroup; CBW 16-column blocks per wave (waves = NC / (16 * CBW)); KCH 64-channel source
 // chunks staged and multiplied per batch.  Measured on config 2 (profiles/r02_tune_conv_dma.log): waves of one SIMD
 // do NOT overlap each other's non-matrix work (the VALU / VMEM instructions of a wave starve while its neighbour's
-// fp32 MFMAs run), so what counts is MFMAs per barrier interval — <128, 2, 1> (forward 64 -> 128)
+// fp32 MFMAs run, docs/HISTORY.md 3.1a), so what counts is MFMAs per barrier interval — <128, 2, 1> (forward 64 -> 128)
 // and <64, 1, 2> (dgrad 128 -> 64) run ONE four-wave workgroup per CU with 128 MFMAs per wave and batch.
 template <int NC, int CBW, int KCH, int VAR>
 __global__ __launch_bounds__(NC / CBW * 4, (CBW * KCH >= 2 ? 1 : 2)) void k_conv_tile_dma_f32(

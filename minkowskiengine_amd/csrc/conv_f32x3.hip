@@ -2,7 +2,7 @@
 // EXACTLY into three bf16 terms and the product is rebuilt from six v_mfma_f32_16x16x32_bf16 ("bf16x6", the
 // 3xTF32 idea with three terms), accumulated in fp32.
 //
-// Why: an fp32 MFMA (v_mfma_f32_16x16x4_f32, 157 TFLOP/s) blocks its SIMD for every other wave and
+// Why: an fp32 MFMA (v_mfma_f32_16x16x4_f32, 157 TFLOP/s) blocks its SIMD for every other wave (docs/HISTORY.md 3.1a) and
 // k_conv_tile_f32 sits at 0.5 of that peak; the bf16 pipe is 16x faster per product and co-issues with vector
 // instructions.  Six bf16 MFMAs per 32 channels cost 96 cycles against 256 for eight fp32 MFMAs.
 //
@@ -186,7 +186,7 @@ __device__ unsigned long long d_x3_timing[8];
 //   * the waves of a workgroup are skewed ("ping-pong"): waves 0-3 multiply first and produce second, waves 4-7
 //     produce first and multiply second.  Waves w and w + 4 sit on the same SIMD, so on every SIMD one wave feeds the
 //     matrix pipe while the other issues the vector / LDS-store / load instructions of the next batch (the bf16 MFMA
-//     co-issues with them);
+//     co-issues with them, docs/HISTORY.md 3.1a);
 //   * gathered rows are two batches ahead in registers (slot = batch parity), their indices three; a wave's weights
 //     (its 16 columns, three planes) one batch ahead.  All loads are plain and unconditional so that hipcc's counted
 //     s_waitcnt leaves the younger ones in flight.

@@ -219,7 +219,7 @@ struct CoordinateMapManager {
                                         const ivec &kernel_stride, const ivec &kernel_dilation, int region_type,
                                         bool is_transpose, bool is_pool);
   // every strided map, kernel map, tile plan and weight-gradient geometry a network asks for, built in ONE call for a
-  // new scene (the replay of another scene's request log: DESIGN 9.8, round-3 build recipe)
+  // new scene (the replay of another scene's request log: docs/HISTORY.md 9.8, round-3 build recipe)
   std::shared_ptr<std::vector<std::string>> recipe_log = std::make_shared<std::vector<std::string>>();   // serialised requests
   int64_t prefetch(const std::vector<std::string> &recipe);
   void log_request(const std::string &r) { recipe_log->push_back(r); }

@@ -2,7 +2,7 @@
 //
 // The coarse MinkUNet levels (256 -> 256 channels on 5k / 21k voxels) run one workgroup per CU, and every workgroup
 // walks the whole packed weight tensor (27 offsets x 64 KB per 128-column slab) once per tile: 453 MB of L2 -> CU
-// traffic for 3.5 MB of weights.  The tile kernel sees ~30 B / clk / CU there.  Is that the chip's
+// traffic for 3.5 MB of weights.  The tile kernel sees ~30 B / clk / CU there (docs/HISTORY.md 10.4).  Is that the chip's
 // limit for this pattern, or the kernel's pipeline?  Variants (each wave loads 8 x 16 B per lane and batch, exactly
 // the kernel's weight slice):
 //   depth D      batches of loads in flight per wave (1, 2, 4), consumed by an xor chain

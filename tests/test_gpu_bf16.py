@@ -332,7 +332,7 @@ def test_wgrad_bf16_128_channel_blocks_match_the_64_channel_ones(device, n, exte
     """k_wgrad_bf16<.., MB = 8>: 128 x 128 blocks of grad_w per workgroup (two thirds of the gather bytes per
     multiply-add) against the 64 x 128 blocks.  The pair ranges differ, so the fp32 partial sums regroup: equal to fp32
     rounding (2e-5 of the largest entry), and both match the oracle; grids of more workgroups than the chip holds at
-    once (the case that exposed the in-flight-load hazard at the final flush), ranges shorter than a step
+    once (the case that exposed the in-flight-load hazard at the final flush, docs/HISTORY.md 10.9), ranges shorter than a step
     and channel counts that are no multiple of 128 included."""
     from minkowskiengine_amd import backend as MEB, _lib
     lib = _lib.load()

@@ -131,7 +131,7 @@ def test_conv_statistics_registry_belongs_to_one_tensor_at_one_version():
 
 def test_bf16_tile_shape_policy_is_the_documented_one():
     """conv_variant_bf16 through its host-side queries (no GPU needed: the policy functions are plain host code): the
-    source-channel chunk per layer shape (256-channel chunks where a launch is at most two 128-column slabs
+    source-channel chunk per layer shape (docs/HISTORY.md 10.4: 256-channel chunks where a launch is at most two 128-column slabs
     wide, 96 for 96 / 192-channel layers, else 32 / 64 / 128), the statistics epilogue for every default shape, packed
     image sizes padded to the chunk, tile heights inside the ABI's range, and the library version of the header."""
     import ctypes
