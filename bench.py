@@ -130,7 +130,7 @@ def pmc_pass(workload, dtype, counters, steps, timeout_s):
         shutil.rmtree(out, ignore_errors=True)
 
 
-def measure_traffic(workload, dtype, kernel_match, steps, deadline):
+def measure_traffic(workload, dtype, kernel_match, steps, deadline, extra_steps=0):
     """HBM-side bytes of the launches whose kernel name contains every string of `kernel_match` (None: all convolution
     kernels): FETCH_SIZE x 2 (gfx950 tallies 128-byte requests at 64 B: MI355X_MICROARCH.md, HBM) + WRITE_SIZE, both in
     KiB.  -> dict(per_launch bytes, per_step bytes, launches_per_step, fetch / write split) or None when the profiler is
@@ -157,8 +157,9 @@ def measure_traffic(workload, dtype, kernel_match, steps, deadline):
     fetch = 2.0 * res["FETCH_SIZE"][0]
     write = res["WRITE_SIZE"][0]
     n = res["FETCH_SIZE"][1]
-    return {"per_launch": int((fetch + write) / n), "per_step": int((fetch + write) / steps),
-            "launches_per_step": round(n / steps, 2), "fetch_bytes_per_launch": int(fetch / n),
+    ran = steps + extra_steps     # (the convolution workloads run one cold forward + backward before their steps)
+    return {"per_launch": int((fetch + write) / n), "per_step": int((fetch + write) / ran),
+            "launches_per_step": round(n / ran, 2), "fetch_bytes_per_launch": int(fetch / n),
             "write_bytes_per_launch": int(write / n),
             "source": f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one pass each over a child process "
                       f"running {steps} steps of the workload (FETCH_SIZE doubled: gfx950 tallies 128-byte requests at 64 B)"}
@@ -172,7 +173,7 @@ def attach_traffic(line, args, deadline):
     r = line.get("roofline") or {}
     tag = r.get("pmc_match")
     if tag:
-        t = measure_traffic(args.workload, args.dtype, tag, 3, deadline)
+        t = measure_traffic(args.workload, args.dtype, tag, 3, deadline, extra_steps=0 if args.workload == "minkunet" else 1)
         if t:
             r["traffic"] = t["per_launch"]
             r["traffic_detail"] = t
@@ -184,7 +185,8 @@ def attach_traffic(line, args, deadline):
         if not isinstance(ent, dict) or "roofline" not in ent:
             continue
         rr = ent["roofline"]
-        t = measure_traffic(wl, dt, rr.get("pmc_match"), 2 if wl == "minkunet" else 3, deadline)
+        t = measure_traffic(wl, dt, rr.get("pmc_match"), 2 if wl == "minkunet" else 3, deadline,
+                            extra_steps=0 if wl == "minkunet" else 1)
         if t:
             rr["traffic"] = t["per_step"] if wl == "minkunet" else t["per_launch"]
             rr["traffic_detail"] = t

@@ -186,6 +186,7 @@ DEBUG_SIGNATURES = {
     "me_debug_set_wgrad_mb": (None, [ctypes.c_int]),
     "me_debug_set_bf16_shape": (None, [ctypes.c_int, ctypes.c_int]),
     "me_debug_set_bf16_deep": (None, [ctypes.c_int]),
+    "me_debug_set_bf16_twobuf": (None, [ctypes.c_int]),
     "me_debug_set_bf16_offsync": (None, [ctypes.c_int]),
     "me_debug_set_bf16_splitk": (None, [ctypes.c_int]),
     "me_debug_set_bf16_splitk_mode": (None, [ctypes.c_int]),

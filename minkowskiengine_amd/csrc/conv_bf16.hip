@@ -28,8 +28,8 @@ __device__ unsigned long long d_bf16_timing[20];
 // stage row stride in elements: KC + 16 (32 bytes of padding: the 16 (row, piece) accesses of every lane group in
 // which the LDS serves a ds_read_b128 — {0-3,12-15,20-27}, ... — then fall on 16 distinct 16-byte bank slots; with 16
 // bytes of padding, the round-1 layout, they were 2-way conflicting)
-__host__ __device__ constexpr int conv_bf16_lds_bytes(int nc, int kc, int tile_rows, int batch_groups) {
-  return (tile_rows + 1) * (nc + kAccPad) * 4 + batch_groups * 16 * ((kc + 16) * 2 + 4);
+__host__ __device__ constexpr int conv_bf16_lds_bytes(int nc, int kc, int tile_rows, int batch_groups, bool two_buffers = false) {
+  return (tile_rows + 1) * (nc + kAccPad) * 4 + (two_buffers ? 2 : 1) * batch_groups * 16 * ((kc + 16) * 2 + 4);
 }
 
 // Timing ablations (round 3; INVALID results, never defined by the build scripts: scripts/ablate_bf16_tile.sh compiles
@@ -174,7 +174,14 @@ __host__ __device__ constexpr int conv_bf16_waves_per_simd(int nc, int kc) {
 // fp32 accumulator tile to `partial[g]`; k_conv_splitk_reduce adds the G partial tiles in group order, rounds to bf16
 // once and writes the rows (and the batch-norm statistics of the tile).  The sum of a target row is
 // ((offsets of group 0) + (group 1)) + ... in fp32: a fixed order — reproducible, not the unsplit kernel's order.
-template <int NC, int KC, bool EXACT, bool SMALL, bool FUSE = false, bool DEEP = false, bool SPLITK = false>
+//
+// TWOBUF (round 4, with DEEP): two stage buffers and ONE barrier per batch.  Step n: barrier -> request the rows of batch
+// n + 2 into the register set batch n just left -> multiply batch n from stage buffer n & 1 -> refill its weights ->
+// write batch n + 1 (the OTHER register set, in flight for a whole step) into stage buffer (n + 1) & 1.  The stage write
+// of a fast wave overlaps the multiplies of the slow ones instead of sitting between two barriers.  Same sums, same
+// order: bit-identical.
+template <int NC, int KC, bool EXACT, bool SMALL, bool FUSE = false, bool DEEP = false, bool SPLITK = false,
+          bool TWOBUF = false>
 __global__ __launch_bounds__(NC * 4, DEEP ? 2 : conv_bf16_waves_per_simd(NC, KC)) void k_conv_tile_bf16(
     const __bf16 *__restrict__ src, int c_src, const bf16x8 *__restrict__ wp, int c_dst,
     const int32_t *__restrict__ plan_src, const int32_t *__restrict__ plan_dst,
@@ -194,9 +201,11 @@ __global__ __launch_bounds__(NC * 4, DEEP ? 2 : conv_bf16_waves_per_simd(NC, KC)
 
   const int cap_rows = batch_groups * 16;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  static_assert(!TWOBUF || DEEP, "the second stage buffer belongs to the deep pipeline");
+  constexpr int NBUF = TWOBUF ? 2 : 1;
   float *s_acc = reinterpret_cast<float *>(smem);                           // [(tile_rows + 1) x ACC_LD]
-  __bf16 *s_a = reinterpret_cast<__bf16 *>(s_acc + (tile_rows + 1) * ACC_LD);  // [cap_rows x A_LD]
-  int32_t *s_dst = reinterpret_cast<int32_t *>(s_a + cap_rows * A_LD);      // [cap_rows]
+  __bf16 *s_a = reinterpret_cast<__bf16 *>(s_acc + (tile_rows + 1) * ACC_LD);  // [NBUF][cap_rows x A_LD]
+  int32_t *s_dst = reinterpret_cast<int32_t *>(s_a + NBUF * cap_rows * A_LD);  // [NBUF][cap_rows]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -245,7 +254,7 @@ __global__ __launch_bounds__(NC * 4, DEEP ? 2 : conv_bf16_waves_per_simd(NC, KC)
     // the tile's batches are listed by ascending offset (k_plan_fill): this workgroup's offsets are a sub-range
     const int k_lo = (int)(((int64_t)blockIdx.z * volume) / gridDim.z);
     const int k_hi = (int)(((int64_t)(blockIdx.z + 1) * volume) / gridDim.z);
-    int32_t *s_rng = reinterpret_cast<int32_t *>(smem + conv_bf16_lds_bytes(NC, KC, tile_rows, batch_groups));
+    int32_t *s_rng = reinterpret_cast<int32_t *>(smem + conv_bf16_lds_bytes(NC, KC, tile_rows, batch_groups, TWOBUF));
     if (tid == 0) {
       s_rng[0] = nb;
       s_rng[1] = nb;
@@ -364,7 +373,9 @@ __global__ __launch_bounds__(NC * 4, DEEP ? 2 : conv_bf16_waves_per_simd(NC, KC)
       }
     }
   };
-  auto write_stage = [&](int chunk, const bf16x8 (&stage)[ITER], int32_t dstv) {
+  auto write_stage = [&](int chunk, const bf16x8 (&stage)[ITER], int32_t dstv, int bufi = 0) {
+    __bf16 *sa_b = s_a + bufi * cap_rows * A_LD;       // (bufi != 0 only with TWOBUF)
+    int32_t *sd_b = s_dst + bufi * cap_rows;
     const int c0 = chunk * KC;
 #pragma unroll
     for (int j = 0; j < ITER; ++j) {
@@ -378,12 +389,12 @@ __global__ __launch_bounds__(NC * 4, DEEP ? 2 : conv_bf16_waves_per_simd(NC, KC)
           if (ch + e >= c_src) t[e] = (__bf16)0.f;
       }
 #ifdef ME_ABL_NO_STAGE
-      if (r < cap_rows && t[0] == (__bf16)1234.5f) *reinterpret_cast<bf16x8 *>(&s_a[r * A_LD + (idx % F8) * 8]) = t;
+      if (r < cap_rows && t[0] == (__bf16)1234.5f) *reinterpret_cast<bf16x8 *>(&sa_b[r * A_LD + (idx % F8) * 8]) = t;
 #else
-      if (r < cap_rows) *reinterpret_cast<bf16x8 *>(&s_a[r * A_LD + (idx % F8) * 8]) = t;
+      if (r < cap_rows) *reinterpret_cast<bf16x8 *>(&sa_b[r * A_LD + (idx % F8) * 8]) = t;
 #endif
     }
-    if (tid < cap_rows) s_dst[tid] = dstv;
+    if (tid < cap_rows) sd_b[tid] = dstv;
   };
   // weights of every sub-batch of a super-batch (wave-uniform branches: a dense batch loads one slice)
   auto load_w = [&](const Super &sb, bf16x8 (&wnxt)[MAXSUB][KS]) {
@@ -401,9 +412,9 @@ __global__ __launch_bounds__(NC * 4, DEEP ? 2 : conv_bf16_waves_per_simd(NC, KC)
     }
   };
 
-  auto multiply = [&](const Super &sb, const bf16x8 (&wreg)[MAXSUB][KS]) {
-    const __bf16 *a0p = &s_a[i16 * A_LD + q * 8];
-    const int32_t *dstp = &s_dst[i16];
+  auto multiply = [&](const Super &sb, const bf16x8 (&wreg)[MAXSUB][KS], int bufi = 0) {
+    const __bf16 *a0p = &s_a[bufi * cap_rows * A_LD + i16 * A_LD + q * 8];
+    const int32_t *dstp = &s_dst[bufi * cap_rows + i16];
     float *accp = &s_acc[wave * 16 + q * 4];
     if (MAXSUB > 1 && sb.nsub > 1) {   // wave-uniform
       mma_singles_bf16<MAXSUB, KS, A_LD, ACC_LD>(a0p, wreg, sb.nsub, dstp, accp);
@@ -481,11 +492,49 @@ __global__ __launch_bounds__(NC * 4, DEEP ? 2 : conv_bf16_waves_per_simd(NC, KC)
         ME_TICK(5);
         ME_COUNT(8);
       };
+      if constexpr (TWOBUF) {
+        write_stage(sA.chunk, stage, dstv, 0);     // batch A into stage buffer 0 (waits for its rows)
+        // one step: (st_p, dv_p, wn_p) is the register set of batch A — already staged in buffer bp —, (st_q, dv_q) holds
+        // the rows of batch B, in flight since the previous step
+        auto step2 = [&](bf16x8 (&st_p)[ITER], int32_t &dv_p, bf16x8 (&wn_p)[MAXSUB][KS], const bf16x8 (&st_q)[ITER],
+                         const int32_t &dv_q, int bp) {
+          __syncthreads();
+          int32_t sidx_c[ITER];
+#pragma unroll
+          for (int j = 0; j < ITER; ++j) sidx_c[j] = sidx[j];
+          load_sidx(sD.g0);
+          {   // rows of batch C into the set batch A has left
+            const int c0 = sC.chunk * KC;
+            dv_p = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(plan_dst + (int64_t)sC.g0 * 16) +
+                                                      (unsigned)(min(tid, ME_MAX_BATCH_GROUPS * 16 - 1) * 4));
+#pragma unroll
+            for (int j = 0; j < ITER; ++j) {
+              const int ch = c0 + ((j * NT + tid) % F8) * 8;
+              const unsigned off = __umul24((unsigned)max(sidx_c[j], 0), row_bytes) + (unsigned)ch * 2u;
+              st_p[j] = *reinterpret_cast<const bf16x8 *>(srcb + off);
+            }
+          }
+          multiply(sA, wn_p, bp);
+          load_w(sC, wn_p);
+          if (sB.nsub > 0) write_stage(sB.chunk, st_q, dv_q, bp ^ 1);   // (wave-uniform)
+          sA = sB;
+          sB = sC;
+          sC = sD;
+          sD = next_super();
+        };
+        while (true) {
+          step2(stage, dstv, wnxt, stage1, dstv1, 0);
+          if (sA.nsub == 0) break;
+          step2(stage1, dstv1, wnxt1, stage, dstv, 1);
+          if (sA.nsub == 0) break;
+        }
+      } else {
       while (true) {
         step(stage, dstv, wnxt);
         if (sA.nsub == 0) break;
         step(stage1, dstv1, wnxt1);
         if (sA.nsub == 0) break;
+      }
       }
     }
   } else if (sA.nsub > 0) {
@@ -1186,10 +1235,12 @@ struct ConvVariantBf16 {
 
 int g_bf16_nc = 0, g_bf16_kc = 0;   // me_debug_set_bf16_shape: tuning overrides of the slab width / chunk depth (0 = policy)
 int g_bf16_deep = -1;               // me_debug_set_bf16_deep: -1 policy, 0 never, 1 wherever instantiated
+int g_bf16_twobuf = -1;             // me_debug_set_bf16_twobuf: -1 policy, 0 never, 1 wherever the deep pipeline runs
 int g_bf16_offsync = 0;             // me_debug_set_bf16_offsync: 0 column-split kernel (k_conv_tile_bf16), 1 offset-synchronous
                                     // kernel where eligible, 2 / 3: the same with its other wave shapes
 int g_bf16_splitk = -1;             // me_debug_set_bf16_splitk: -1 policy, 0 / 1 never, G >= 2: G offset groups where eligible
 int g_bf16_splitk_same_tiles = 0;   // me_debug_set_bf16_splitk_mode: 1 = forced groups keep the unsplit tile height (G x the workgroups)
+constexpr bool kTwoBufDefault = false;
 constexpr int kSplitKMaxTileRows = 48;   // policy: split launches whose unsplit tiles are at most this tall
 
 static ConvVariantBf16 conv_variant_bf16(int c_src, int c_dst) {
@@ -1234,6 +1285,9 @@ static ConvVariantBf16 conv_variant_bf16(int c_src, int c_dst) {
   return v;
 }
 
+// two stage buffers + one barrier per batch for the deep-pipeline (eight-wave) launches
+static bool conv_bf16_twobuf(int nc) { return nc == 128 && (g_bf16_twobuf >= 0 ? g_bf16_twobuf != 0 : kTwoBufDefault); }
+
 template <int NC, int KC>
 static int launch_conv_tile_bf16(const __bf16 *src, int c_src, const bf16x8 *wp, int c_dst, int slabs,
                                  const int32_t *plan_src, const int32_t *plan_dst, const int32_t *batch_desc,
@@ -1241,9 +1295,13 @@ static int launch_conv_tile_bf16(const __bf16 *src, int c_src, const bf16x8 *wp,
                                  int tile_rows, int batch_groups, hipStream_t stream, bool small, bool fuse = false,
                                  float *stat_mean = nullptr, float *stat_m2 = nullptr, int split_k = 1,
                                  float *partial = nullptr, int volume = 0) {
-  const int lds = conv_bf16_lds_bytes(NC, KC, tile_rows, batch_groups) + (split_k > 1 ? 16 : 0);
-  ME_CHECK(lds <= kLdsBudget, "tile_rows / batch_groups too large for the LDS of one workgroup");
   const bool exact = (c_src % KC) == 0;
+  // (the second stage buffer of TWOBUF only where the deep pipeline will run and the tile leaves room for it)
+  const bool deep_ok = NC == 128 && exact && small && (g_bf16_deep >= 0 ? g_bf16_deep != 0 : true);
+  const bool twobuf = deep_ok && conv_bf16_twobuf(NC) &&
+                      conv_bf16_lds_bytes(NC, KC, tile_rows, batch_groups, true) + 16 <= kLdsBudget;
+  const int lds = conv_bf16_lds_bytes(NC, KC, tile_rows, batch_groups, twobuf) + (split_k > 1 ? 16 : 0);
+  ME_CHECK(lds <= kLdsBudget, "tile_rows / batch_groups too large for the LDS of one workgroup");
   typedef void (*kernel_t)(const __bf16 *, int, const bf16x8 *, int, const int32_t *, const int32_t *, const int32_t *,
                            const int32_t *, const int32_t *, __bf16 *, int64_t, int, int, int, float *, float *, float *,
                            int);
@@ -1274,6 +1332,9 @@ static int launch_conv_tile_bf16(const __bf16 *src, int c_src, const bf16x8 *wp,
       if constexpr (NC <= 96 && KC <= 128) {
         if (fuse) fn = &k_conv_tile_bf16<NC, KC, true, true, true, true>;
       }
+      if constexpr (NC == 128) {
+        if (twobuf) fn = &k_conv_tile_bf16<NC, KC, true, true, false, true, false, true>;
+      }
     }
   }
   // split-K (see k_conv_tile_bf16): eight-wave deep-pipeline launches only; the statistics move to the reduce kernel
@@ -1283,13 +1344,14 @@ static int launch_conv_tile_bf16(const __bf16 *src, int c_src, const bf16x8 *wp,
     // 64-bit gather addresses, deep pipeline switched off — runs it unsplit)
     if (split_k > 1 && deep && !fuse && volume >= split_k && c_dst % 16 == 0 && split_k <= 8) {
       ME_CHECK(partial != nullptr, "split-K needs its workspace (me_conv_splitk_workspace_bytes)");
-      fn = &k_conv_tile_bf16<NC, KC, true, true, false, true, true>;
+      fn = twobuf ? &k_conv_tile_bf16<NC, KC, true, true, false, true, true, true>
+                  : &k_conv_tile_bf16<NC, KC, true, true, false, true, true>;
       splitk = true;
     }
   }
   if (!splitk) split_k = 1;
-  static bool attr_set[32] = {};  // per instantiation
-  const int which = (splitk ? 16 : 0) + (deep ? 8 : 0) + (fuse ? 4 : 0) + (small ? 2 : 0) + (exact ? 1 : 0);
+  static bool attr_set[64] = {};  // per instantiation
+  const int which = (twobuf && deep ? 32 : 0) + (splitk ? 16 : 0) + (deep ? 8 : 0) + (fuse ? 4 : 0) + (small ? 2 : 0) + (exact ? 1 : 0);
   if (lds > 48 * 1024 && !attr_set[which]) {
     ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                kLdsBudget));
@@ -1452,6 +1514,7 @@ int64_t me_conv_splitk_workspace_bytes(int64_t n_tgt, int32_t tile_rows, int32_t
   return (int64_t)split_k * ceil_div(n_tgt, tile_rows) * tile_rows * c_dst * 4;
 }
 
+void me_debug_set_bf16_twobuf(int mode) { g_bf16_twobuf = mode; }
 void me_debug_set_bf16_offsync(int mode) {
 #ifdef ME_DEBUG_VARIANTS
   g_bf16_offsync = mode;

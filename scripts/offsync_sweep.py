@@ -23,8 +23,11 @@ ALL = {1: [(96, 96), (128, 96)], 2: [(96, 96), (32, 32), (128, 96)], 4: [(128, 1
        8: [(128, 128), (256, 256), (384, 256), (64, 128)], 16: [(256, 256), (128, 256)]}
 want = os.environ.get("LEVELS", "1,2,4,8,16")
 MODES = [int(m) for m in os.environ.get("MODES", "0,1,2").split(",")]
+KNOB = os.environ.get("KNOB", "offsync")      # which switch the modes set: offsync | twobuf | deep
+SETTER = {"offsync": lib.me_debug_set_bf16_offsync, "twobuf": lib.me_debug_set_bf16_twobuf,
+          "deep": lib.me_debug_set_bf16_deep}[KNOB]
 REPS = int(os.environ.get("REPS", "20"))
-print(f"{'level':>6s} {'rows':>7s} {'cin->cout':>10s} " + " ".join(f"{'mode ' + str(m):>14s}" for m in MODES))
+print(f"{'level':>6s} {'rows':>7s} {'cin->cout':>10s} " + " ".join(f"{KNOB + ' ' + str(m):>14s}" for m in MODES))
 for ts in [int(l) for l in want.split(",")]:
     c = levels[ts]
     for cin, cout in ALL[ts]:
@@ -32,7 +35,7 @@ for ts in [int(l) for l in want.split(",")]:
         x = (torch.rand(c.shape[0], cin, generator=g) - 0.5).to(dev).bfloat16()
         cells, outs = [], []
         for mode in MODES:
-            lib.me_debug_set_bf16_offsync(mode)
+            SETTER(mode)
             w = (torch.rand(27, cin, cout, generator=torch.Generator().manual_seed(2)) - 0.5).to(dev)
             mgr = MEB.CoordinateMapManagerGPU_c10()
             key, _ = mgr.insert_and_map(c, [ts] * 3, "")
@@ -52,5 +55,5 @@ for ts in [int(l) for l in want.split(",")]:
         same = all(abs(o - outs[0]) <= 1e-3 * abs(outs[0]) for o in outs)
         print(f"{ts:6d} {c.shape[0]:7d} {str(cin) + '->' + str(cout):>10s} " + " ".join(f"{v:>14s}" for v in cells) +
               ("" if same else "   CHECKSUM MISMATCH"), flush=True)
-lib.me_debug_set_bf16_offsync(0)
+SETTER(0 if KNOB == "offsync" else -1)
 lib.me_debug_set_bf16_splitk(-1)

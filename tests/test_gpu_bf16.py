@@ -313,14 +313,20 @@ def test_bf16_deep_pipeline_is_bit_identical(device, no_split_k, n, extent, cin,
     w = (torch.rand(ks ** D, cin, cout, generator=g) - 0.5).to(device)
     res = {}
     try:
-        for deep in (1, 0, -1):
+        # (deep, two stage buffers): TWOBUF (round 4) = the deep pipeline with ONE barrier per batch
+        for deep in (1, 0, -1, (1, 1)):
+            two = 0
+            if isinstance(deep, tuple):
+                deep, two = deep
             lib.me_debug_set_bf16_deep(deep)
+            lib.me_debug_set_bf16_twobuf(two)
             y = MEB._conv_forward(x, w, km, "mfma")
             gi = MEB._conv_target(gy, w, km, "in", km.n_in, name="d", transposed=True)
-            res[deep] = (y.clone(), gi.clone())
+            res[(deep, two) if two else deep] = (y.clone(), gi.clone())
     finally:
         lib.me_debug_set_bf16_deep(-1)
-    for deep in (1, -1):
+        lib.me_debug_set_bf16_twobuf(-1)
+    for deep in (1, -1, (1, 1)):
         assert torch.equal(res[deep][0], res[0][0]) and torch.equal(res[deep][1], res[0][1]), deep
     assert torch.isfinite(res[1][0].float()).all() and float(res[1][0].float().abs().max()) > 0
 
