@@ -342,7 +342,11 @@ __global__ __launch_bounds__(NC * 4, DEEP ? 2 : conv_bf16_waves_per_simd(NC, KC)
   };
   const char *srcb = reinterpret_cast<const char *>(src);
   const unsigned row_bytes = (unsigned)c_src * 2u;
-  auto gather = [&](int chunk, int g0, bf16x8 (&stage)[ITER], int32_t &dstv) {
+  // (rows_used: the 16 * groups rows the batch really holds.  The index window is read to its end — 64 entries, the
+  // next batches' rows behind the batch's own — and round 3 gathered them all: on the coarse levels, whose batches
+  // hold one or two groups, half of the gathered bytes were rows nobody multiplies, through a vector-memory path that
+  // IS the bound there (round 4: ~30 B / clk / CU of weights + rows per batch).  Slots beyond the batch gather row 0.)
+  auto gather = [&](int chunk, int g0, bf16x8 (&stage)[ITER], int32_t &dstv, int rows_used = ME_MAX_BATCH_GROUPS * 16) {
     const int c0 = chunk * KC;
     dstv = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(plan_dst + (int64_t)g0 * 16) +
                                              (unsigned)(min(tid, ME_MAX_BATCH_GROUPS * 16 - 1) * 4));
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(NC * 4, DEEP ? 2 : conv_bf16_waves_per_simd(NC, KC)
 #ifdef ME_ABL_NO_GATHER
       const int sr = max(sidx[j], 0) & 63;
 #else
-      const int sr = max(sidx[j], 0);
+      const int sr = (j * NT + tid) / F8 < rows_used ? max(sidx[j], 0) : 0;
 #endif
       if (SMALL && (EXACT || vec_ok)) {
         const unsigned off = __umul24((unsigned)sr, row_bytes) + (unsigned)(EXACT ? ch : min(ch, c_src - 8)) * 2u;
@@ -443,11 +447,11 @@ __global__ __launch_bounds__(NC * 4, DEEP ? 2 : conv_bf16_waves_per_simd(NC, KC)
       Super sD = next_super();
       load_sidx(sA.g0);
       load_w(sA, wnxt);
-      gather(sA.chunk, sA.g0, stage, dstv);
+      gather(sA.chunk, sA.g0, stage, dstv, sA.ng * 16);
       __builtin_amdgcn_sched_barrier(0);   // set 0 strictly older than set 1: the loop's counted waits merge with this path
       load_sidx(sB.g0);
       load_w(sB, wnxt1);
-      gather(sB.chunk, sB.g0, stage1, dstv1);
+      gather(sB.chunk, sB.g0, stage1, dstv1, sB.ng * 16);
       load_sidx(sC.g0);
       // one step: stage and multiply batch A from register set (st, dv, wn); refill the set with batch C.  The
       // index window of batch D is requested BEFORE the refill: the gather of the next step then waits for loads
@@ -474,7 +478,8 @@ __global__ __launch_bounds__(NC * 4, DEEP ? 2 : conv_bf16_waves_per_simd(NC, KC)
 #ifdef ME_ABL_NO_GATHER
             const unsigned off = __umul24((unsigned)(max(sidx_c[j], 0) & 63), row_bytes) + (unsigned)ch * 2u;
 #else
-            const unsigned off = __umul24((unsigned)max(sidx_c[j], 0), row_bytes) + (unsigned)ch * 2u;
+            const int sr = (j * NT + tid) / F8 < sC.ng * 16 ? max(sidx_c[j], 0) : 0;   // (see gather)
+            const unsigned off = __umul24((unsigned)sr, row_bytes) + (unsigned)ch * 2u;
 #endif
             st[j] = *reinterpret_cast<const bf16x8 *>(srcb + off);
           }
@@ -510,7 +515,8 @@ __global__ __launch_bounds__(NC * 4, DEEP ? 2 : conv_bf16_waves_per_simd(NC, KC)
 #pragma unroll
             for (int j = 0; j < ITER; ++j) {
               const int ch = c0 + ((j * NT + tid) % F8) * 8;
-              const unsigned off = __umul24((unsigned)max(sidx_c[j], 0), row_bytes) + (unsigned)ch * 2u;
+              const int sr = (j * NT + tid) / F8 < sC.ng * 16 ? max(sidx_c[j], 0) : 0;   // (see gather)
+              const unsigned off = __umul24((unsigned)sr, row_bytes) + (unsigned)ch * 2u;
               st_p[j] = *reinterpret_cast<const bf16x8 *>(srcb + off);
             }
           }
@@ -542,7 +548,7 @@ __global__ __launch_bounds__(NC * 4, DEEP ? 2 : conv_bf16_waves_per_simd(NC, KC)
     Super sC = next_super();
     load_w(sA, wnxt);
     load_sidx(sA.g0);
-    gather(sA.chunk, sA.g0, stage, dstv);
+    gather(sA.chunk, sA.g0, stage, dstv, sA.ng * 16);
     load_sidx(sB.g0);
 
     ME_TICK(6);
@@ -559,7 +565,7 @@ __global__ __launch_bounds__(NC * 4, DEEP ? 2 : conv_bf16_waves_per_simd(NC, KC)
       __syncthreads();
       ME_TICK(2);
       load_w(sB, wnxt);
-      gather(sB.chunk, sB.g0, stage, dstv);
+      gather(sB.chunk, sB.g0, stage, dstv, sB.ng * 16);
       load_sidx(sC.g0);
       ME_TICK(3);
       multiply(sA, wreg);
