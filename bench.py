@@ -451,10 +451,14 @@ def run_timed(step, args, dist_utils, MEB, dev, timers_in_blocks=True):
         set_kernel_timer(MEB, None)
     blocks, local = [], []
     total = 0.0
+    n_timed_blocks = 0
     while True:
         dist_utils.barrier()
         torch.cuda.synchronize()
-        set_kernel_timer(MEB, timer if timers_in_blocks else None)
+        # per-launch HIP events (two event records per hot kernel) in every `timer_blocks`-th block of the timed region
+        timed_block_now = timers_in_blocks and len(blocks) % max(1, args.timer_blocks) == 0
+        set_kernel_timer(MEB, timer if timed_block_now else None)
+        n_timed_blocks += 1 if timed_block_now else 0
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
@@ -473,7 +477,14 @@ def run_timed(step, args, dist_utils, MEB, dev, timers_in_blocks=True):
     median = srt[(len(srt) - 1) // 2]      # lower median: a measured block, never an interpolation
     LAST_RUN["per_rank_ms_per_step"] = [round(v / args.steps * 1e3, 4) for v in
                                         dist_utils.gather_over_ranks(local[blocks.index(median)], dev)]
-    return median, blocks, timer, args.steps * (len(blocks) if timers_in_blocks else 1)
+    every = max(1, args.timer_blocks)
+    with_ev = [b for i, b in enumerate(blocks) if timers_in_blocks and i % every == 0]
+    without = [b for i, b in enumerate(blocks) if not (timers_in_blocks and i % every == 0)]
+    med = lambda v: sorted(v)[(len(v) - 1) // 2] / args.steps * 1e3 if v else None   # noqa: E731
+    LAST_RUN["event_blocks"] = {"blocks_with_kernel_events": len(with_ev), "blocks_without": len(without),
+                                "median_ms_per_step_with_events": round(med(with_ev), 4) if with_ev else None,
+                                "median_ms_per_step_without": round(med(without), 4) if without else None}
+    return median, blocks, timer, args.steps * (n_timed_blocks if timers_in_blocks else 1)
 
 
 def roofline_entry(kernel, flops, compulsory_bytes, avg_ms, bf16, traffic, traffic_src, split=False):
@@ -661,7 +672,9 @@ def bench_conv(args, ME, MEB, dist_utils, rank, world, dev, startup):
                    "blocks_ms_per_step": [round(b / args.steps * 1e3, 4) for b in blocks],
                    "timed_region_s": round(sum(blocks), 4),
                    "fastest_block_ms_per_step": round(min(blocks) / args.steps * 1e3, 4),
-                   "reported": "median block (max over ranks inside each block)"},
+                   "kernel_events": LAST_RUN.get("event_blocks"),
+                   "reported": "median block (max over ranks inside each block); the per-launch HIP events behind "
+                               "`roofline` / `kernels` are recorded in every --timer-blocks-th block of the timed region"},
         "roofline": roofline_entry(f"{kname}<{nc},{kc}> (forward)", flops_per_launch,
                                    compulsory, kernels["conv_forward"]["avg_ms"], bf16, traffic, traffic_src, split),
         "kernels": kernels,
@@ -955,6 +968,11 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU baseline timing (0 = skip)")
     ap.add_argument("--min-time", type=float, default=0.2, help="keep timing K-step blocks until this many seconds")
     ap.add_argument("--min-blocks", type=int, default=3)
+    ap.add_argument("--timer-blocks", type=int, default=4,
+                    help="record the per-launch HIP events of the hot kernels in every N-th K-step block of the timed "
+                         "region (1 = every block).  Six event records per step cost the one-layer headline ~20 us of a "
+                         "0.31 ms step (profiles/r04_bench_timer_blocks.log): the kernel durations are sampled live in "
+                         "a quarter of the timed blocks, the step time is the median over all of them")
     ap.add_argument("--max-blocks", type=int, default=200)
     ap.add_argument("--backend", choices=("auto", "nccl", "gloo"), default="auto")
     ap.add_argument("--scenes", choices=("cached", "fresh", "pipelined"), default="cached",
