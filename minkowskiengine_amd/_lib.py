@@ -183,6 +183,7 @@ DEBUG_SIGNATURES = {
     "me_debug_conv_timing_f32x3": (ctypes.c_int, [c_vp, c_i32]),
     "me_debug_set_wgrad_config": (None, [ctypes.c_int, ctypes.c_int]),
     "me_debug_set_wgrad_order": (None, [ctypes.c_int]),
+    "me_debug_set_tile_dispatch": (None, [ctypes.c_int]),
     "me_debug_set_wgrad_mb": (None, [ctypes.c_int]),
     "me_debug_set_bf16_shape": (None, [ctypes.c_int, ctypes.c_int]),
     "me_debug_set_bf16_deep": (None, [ctypes.c_int]),

@@ -474,7 +474,7 @@ class KernelMapGPU:
             return native if tile_order == "spatial" else None
         return self._flat_order(target, tile_order)
 
-    def _tile_order(self, target, matrix_bound=False):
+    def _tile_order(self, target, matrix_bound=False, src_bytes=0):
         """"rows" | "spatial" for a launch family.  `matrix_bound`: the fp32 kernels on the bf16 matrix pipe
         (csrc/conv_f32x3.hip) — their tile time does not depend on how even the tiles are, so they always take the
         spatially compact tiles (config 2: 1.5 - 1.6x the compulsory HBM traffic instead of 3.2x at the same
@@ -482,7 +482,7 @@ class KernelMapGPU:
         neighbour table is small enough for the plan builder's scattered reads."""
         if _TILE_ORDER != "auto":
             return _TILE_ORDER
-        if matrix_bound:
+        if matrix_bound or (_TILE_SPATIAL_MIN_SRC_BYTES > 0 and src_bytes >= _TILE_SPATIAL_MIN_SRC_BYTES):
             return "spatial"
         n_tgt = self.n_out if target == "out" else self.n_in
         return "rows" if self.volume * n_tgt * 4 <= _TILE_ORDER_ROWS_MAX_BYTES else "spatial"
@@ -574,6 +574,11 @@ _SPATIAL_MIN_PROBES = 1 << 24       # ... or maps of at least this many (row, of
 # 2.0 ms instead of 0.37)
 _TILE_ORDER = os.environ.get("ME_AMD_TILE_ORDER", "auto")
 _TILE_ORDER_ROWS_MAX_BYTES = 32 << 20
+# ... and (round 4) the bf16 launches whose SOURCE matrix no longer fits the eight 4 MB L2s: MinkUNet34C's 96-channel
+# layers on 160k - 200k voxels (31 - 38 MB) run 8 - 13 % faster on spatial tiles (both column slabs of a tile and its
+# neighbours find the gathered rows in L2), every smaller layer 0 - 9 % slower (profiles/r04_tile_dispatch_sweep.log).
+# ME_AMD_TILE_SPATIAL_SRC_MB: the threshold in MiB, 0 = never.
+_TILE_SPATIAL_MIN_SRC_BYTES = int(os.environ.get("ME_AMD_TILE_SPATIAL_SRC_MB", "28")) << 20
 
 
 def _build_kernel_map_lds(in_map, out_map, region, volume):
@@ -1226,7 +1231,8 @@ def _conv_launch_cfg(km, target, n_tgt, c_src, c_dst, bf16):
     if cfg is None:
         tile_rows, batch_groups, split_k = plan_config(n_tgt, km.volume, km.n_pairs, c_src, c_dst, bf16, split,
                                                        with_split_k=True)
-        tile_order = km._tile_order(target, matrix_bound=split)
+        n_src = km.n_in if target == "out" else km.n_out
+        tile_order = km._tile_order(target, matrix_bound=split, src_bytes=n_src * c_src * 2 if bf16 else 0)
         plan_src, plan_dst, batch_desc, tile_bptr, _ = km.plan(target, tile_rows, batch_groups, tile_order)
         elems = int((lib.me_conv_packed_weight_elems_bf16 if bf16 else
                      (lib.me_conv_packed_weight_elems_f32x3 if split else lib.me_conv_packed_weight_elems))(

@@ -575,16 +575,31 @@ __global__ __launch_bounds__(256) void k_plan_fill(const int32_t *__restrict__ t
 // tile order the last round ends ragged (simulated makespan 1.04x / 1.11x the ideal on config 2; 1.01x sorted).
 // One workgroup: min / max of the work, a 256-bin counting sort by descending work (the order inside a bin is
 // arbitrary: it only permutes the dispatch, never a result).  perm = tile_bptr + n_tiles + 1.
+// XCD > 0 (round 4): the hardware deals workgroups to the eight XCDs round-robin by their linear index, so slot l of the
+// dispatch order runs on XCD l % 8 — and each XCD has its own 4 MB L2.  Tiles that are neighbours in the plan's tile
+// order (spatially compact tiles: neighbours in space, whose 3^D halos overlap) are therefore handed to ONE XCD: the
+// tile sequence is cut into XCD contiguous chunks (chunk x gets as many tiles as XCD x gets slots), heaviest first
+// inside a chunk, and the j-th tile of chunk x goes to slot 8 j + x.  The order only permutes the dispatch.
+// Measured (profiles/r04_tile_dispatch_sweep.log, r04_unet_tile_policy.log): 1 - 5 % on the large row-tiled bf16 layers
+// taken alone, nothing on spatial tiles, nothing on the MinkUNet34C step (11.99 vs 12.01 ms) — opt-in
+// (ME_AMD_TILE_DISPATCH=1 / me_debug_set_tile_dispatch), not the default.
+int g_tile_dispatch = 0;   // me_debug_set_tile_dispatch: 0 = heaviest first over the whole launch, 1 = XCD chunks
+
+template <int XCD>
 __global__ __launch_bounds__(1024) void k_plan_tile_order(const int32_t *__restrict__ item_gptr, int64_t volume,
                                                          int64_t n_tiles, int32_t *__restrict__ perm) {
+  constexpr int CH = XCD > 0 ? XCD : 1;          // chunks
+  constexpr int NB = 256 * CH;                   // bins: chunk-major, heavy tiles in a chunk's low bins
+  constexpr int PER = (NB + 1023) / 1024;        // bins per thread in the scan
   __shared__ int32_t s_min, s_max;
-  __shared__ uint32_t s_bin[256];
+  __shared__ uint32_t s_bin[NB];
+  __shared__ uint32_t s_wsum[16];
   const int tid = threadIdx.x;
   if (tid == 0) {
     s_min = INT32_MAX;
     s_max = 0;
   }
-  if (tid < 256) s_bin[tid] = 0;
+  for (int b = tid; b < NB; b += 1024) s_bin[b] = 0;
   __syncthreads();
   auto work_of = [&](int64_t t) { return item_gptr[(t + 1) * volume] - item_gptr[t * volume]; };
   // the first tile of every thread stays in a register (plans rarely have more tiles than the block has threads)
@@ -607,31 +622,52 @@ __global__ __launch_bounds__(1024) void k_plan_tile_order(const int32_t *__restr
   }
   __syncthreads();
   const int32_t wmin = s_min, span = max(s_max - s_min, 1);
-  auto bin = [&](int32_t w) { return 255 - (int)(((int64_t)(w - wmin) * 255) / span); };   // heavy tiles: low bins
-  for (int64_t t = tid; t < n_tiles; t += blockDim.x) atomicAdd(&s_bin[bin(work(t))], 1u);
+  // chunk x holds tiles [first(x), first(x + 1)): first(x) = slots of XCDs 0 .. x - 1 = sum of ceil((n - x') / CH)
+  auto first = [&](int x) {
+    const int64_t q = n_tiles / CH, r = n_tiles % CH;
+    return q * x + min((int64_t)x, r);
+  };
+  auto chunk_of = [&](int64_t t) {
+    if (CH == 1) return 0;
+    const int64_t q = n_tiles / CH, r = n_tiles % CH;
+    return (int)(t < (q + 1) * r ? t / (q + 1) : r + (t - (q + 1) * r) / max(q, (int64_t)1));
+  };
+  auto bin = [&](int64_t t, int32_t w) { return chunk_of(t) * 256 + 255 - (int)(((int64_t)(w - wmin) * 255) / span); };
+  for (int64_t t = tid; t < n_tiles; t += blockDim.x) atomicAdd(&s_bin[bin(t, work(t))], 1u);
   __syncthreads();
-  // exclusive scan of the 256 bins: shuffle scan inside the four waves that hold them + the wave totals (a serial
-  // scan by one thread — 256 dependent LDS round trips — was most of this kernel's 10 us)
-  __shared__ uint32_t s_wsum[4];
-  uint32_t v = 0, incl = 0;
-  if (tid < 256) {
-    v = s_bin[tid];
-    incl = v;
+  // exclusive scan of the bins: PER consecutive bins per thread, a shuffle scan inside each wave + the wave totals (a
+  // serial scan by one thread — 256 dependent LDS round trips — was most of this kernel's 10 us)
+  uint32_t v[PER], sum = 0;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t up = __shfl_up(incl, off, 64);
-      if ((tid & 63) >= off) incl += up;
+  for (int i = 0; i < PER; ++i) {
+    v[i] = tid * PER + i < NB ? s_bin[tid * PER + i] : 0u;
+    sum += v[i];
+  }
+  uint32_t incl = sum;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t up = __shfl_up(incl, off, 64);
+    if ((tid & 63) >= off) incl += up;
+  }
+  if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
+  __syncthreads();
+  uint32_t base = incl - sum;
+  for (int w = 0; w < (tid >> 6); ++w) base += s_wsum[w];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    if (tid * PER + i < NB) s_bin[tid * PER + i] = base;
+    base += v[i];
+  }
+  __syncthreads();
+  for (int64_t t = tid; t < n_tiles; t += blockDim.x) {
+    const uint32_t m = atomicAdd(&s_bin[bin(t, work(t))], 1u);   // rank in (chunk, weight) order
+    if (CH == 1) {
+      perm[m] = (int32_t)t;
+    } else {
+      const int x = chunk_of(t);
+      perm[(int64_t)(m - (uint32_t)first(x)) * CH + x] = (int32_t)t;
     }
-    if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
   }
-  __syncthreads();
-  if (tid < 256) {
-    uint32_t base = 0;
-    for (int w = 0; w < (tid >> 6); ++w) base += s_wsum[w];
-    s_bin[tid] = base + incl - v;
-  }
-  __syncthreads();
-  for (int64_t t = tid; t < n_tiles; t += blockDim.x) perm[atomicAdd(&s_bin[bin(work(t))], 1u)] = (int32_t)t;
 }
 
 // Voxel labels (the reference's quantize_label, src/quantization.cpp:140-196): a voxel keeps the label of
@@ -1332,6 +1368,8 @@ int me_kernel_map_transpose(const int32_t *in_pairs, const int32_t *out_pairs, c
   return 0;
 }
 
+void me_debug_set_tile_dispatch(int mode) { g_tile_dispatch = mode; }
+
 int64_t me_plan_num_tiles(int64_t n_tgt, int32_t tile_rows) {
   return tile_rows > 0 ? ceil_div(n_tgt, tile_rows) : -1;
 }
@@ -1384,8 +1422,18 @@ int me_plan_build(const int32_t *tbl, const int32_t *order, int64_t n_tgt, int64
                      (int)batch_groups, offs_gb, total_gb, plan_src, plan_dst, batch_desc, tile_bptr, item_gptr,
                      n_tiles);
   ME_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_plan_tile_order, dim3(1), dim3(1024), 0, stream, item_gptr, volume, n_tiles,
-                     tile_bptr + n_tiles + 1);
+  static const bool env_read = [] {   // ME_AMD_TILE_DISPATCH=1: XCD chunks from the first plan on (tuning runs)
+    const char *e = std::getenv("ME_AMD_TILE_DISPATCH");
+    if (e != nullptr && *e != 0) g_tile_dispatch = std::atoi(e);
+    return true;
+  }();
+  (void)env_read;
+  if (g_tile_dispatch == 1)
+    hipLaunchKernelGGL(k_plan_tile_order<8>, dim3(1), dim3(1024), 0, stream, item_gptr, volume, n_tiles,
+                       tile_bptr + n_tiles + 1);
+  else
+    hipLaunchKernelGGL(k_plan_tile_order<0>, dim3(1), dim3(1024), 0, stream, item_gptr, volume, n_tiles,
+                       tile_bptr + n_tiles + 1);
   ME_LAUNCH_CHECK();
   return 0;
 }

@@ -50,6 +50,8 @@ int me_debug_bf16_timing(uint64_t *out20, int32_t reset);
 void me_debug_set_wgrad_config(int depth, int wgs_per_cu);
 /* 0 (default): ranges of the same list fraction go to the same XCD (WgRangeOrder, conv.hip); -1: launch order */
 void me_debug_set_wgrad_order(int mode);
+// dispatch order of the tiles of plans built from now on: 0 = heaviest first (default), 1 = contiguous tile chunks per XCD
+void me_debug_set_tile_dispatch(int mode);
 /* k_wgrad_bf16: input-channel blocks of 16 per workgroup — 0 policy (8 where c_in >= 192 and c_out > 64), 4, 8 */
 void me_debug_set_wgrad_mb(int mb);
 

@@ -57,6 +57,7 @@ inline void *vptr(const Tensor &t) { return t.defined() ? t.data_ptr() : nullptr
 struct Policy {
   int spatial_maps;        // ME_AMD_SPATIAL_MAPS: 1 / 0 / -1 (auto)
   std::string tile_order;  // ME_AMD_TILE_ORDER: auto | rows | spatial
+  int64_t tile_spatial_src_bytes = 28ll << 20;  // ME_AMD_TILE_SPATIAL_SRC_MB: bf16 sources of at least this size take spatial tiles
   std::string bf16_fuse;   // ME_AMD_BF16_FUSE: auto | 1 | 0
   int f32_split;           // ME_AMD_F32_SPLIT: 1 / 0 / -1 (auto)
   int tile_rows, batch_groups;   // ME_AMD_TILE_ROWS / ME_AMD_BATCH_GROUPS overrides (0 = plan config)
@@ -171,7 +172,7 @@ struct KernelMap : std::enable_shared_from_this<KernelMap> {
   // (table, order): table [volume, n_tgt] of source ROWS indexed by target POSITION; order undefined when positions are rows
   std::pair<Tensor, Tensor> table_pos(const std::string &target);
   Tensor table(const std::string &target);      // row-space view
-  std::string tile_order(const std::string &target, bool matrix_bound);
+  std::string tile_order(const std::string &target, bool matrix_bound, int64_t src_bytes = 0);
   Tensor flat_order(const std::string &target, const std::string &tile_order);
   Tensor order(const std::string &target, const std::string &tile_order);
   std::shared_ptr<Plan> plan(const std::string &target, int tile_rows, int batch_groups, const std::string &tile_order);

@@ -33,6 +33,7 @@ const Policy &Policy::get() {
     const std::string sm = env_str("ME_AMD_SPATIAL_MAPS", "auto");
     q.spatial_maps = sm == "1" ? 1 : (sm == "0" ? 0 : -1);
     q.tile_order = env_str("ME_AMD_TILE_ORDER", "auto");
+    q.tile_spatial_src_bytes = (int64_t)std::atoi(env_str("ME_AMD_TILE_SPATIAL_SRC_MB", "28").c_str()) << 20;
     q.bf16_fuse = env_str("ME_AMD_BF16_FUSE", "auto");
     const std::string fs = env_str("ME_AMD_F32_SPLIT", "auto");
     q.f32_split = fs == "1" ? 1 : (fs == "0" ? 0 : -1);
@@ -281,10 +282,11 @@ Tensor KernelMap::table(const std::string &target) {
   return store->t[nm];
 }
 
-std::string KernelMap::tile_order(const std::string &target, bool matrix_bound) {
+std::string KernelMap::tile_order(const std::string &target, bool matrix_bound, int64_t src_bytes) {
   const Policy &p = Policy::get();
   if (p.tile_order != "auto") return p.tile_order;
-  if (matrix_bound) return "spatial";
+  // (bf16 launches whose source matrix no longer fits the eight L2s: see backend.py _TILE_SPATIAL_MIN_SRC_BYTES)
+  if (matrix_bound || (p.tile_spatial_src_bytes > 0 && src_bytes >= p.tile_spatial_src_bytes)) return "spatial";
   const int64_t n_tgt = target == "out" ? n_out : n_in;
   return volume * n_tgt * 4 <= (32ll << 20) ? "rows" : "spatial";
 }
@@ -362,7 +364,8 @@ const ConvCfg &KernelMap::conv_cfg(const std::string &target, int64_t n_tgt, int
   c.batch_groups = pol.batch_groups ? pol.batch_groups : g;
   c.split = split;
   c.split_k = sk;
-  const std::string to = tile_order(target, split);
+  const int64_t n_src = target == "out" ? n_in : n_out;
+  const std::string to = tile_order(target, split, bf16 ? n_src * c_src * 2 : 0);
   c.plan = plan(target, c.tile_rows, c.batch_groups, to);
   c.elems = (bf16 ? me_conv_packed_weight_elems_bf16
                   : (split ? me_conv_packed_weight_elems_f32x3 : me_conv_packed_weight_elems))(volume, c_src, c_dst);
