@@ -730,20 +730,20 @@ def bench_minkunet(args, ME, MEB, dist_utils, rank, world, dev, startup):
 
     feats_dev, coords_dev = x.F.detach(), coords.to(dev)
     pending = [None]
+    if args.scenes == "fresh":
+        # the library's recipe replay, as a training loop over new scenes would set it: each new manager rebuilds what
+        # the previous scene's network asked for in one burst (strided maps, kernel maps, then ALL tile plans in four
+        # launches: me_plan_build_multi) instead of lazily, layer by layer
+        ME.set_map_prefetch(bool(args.replay_maps))
     if args.scenes == "pipelined":
-        # a new scene every step, its maps built on a side stream during the previous step's backward pass
-        # (set_map_prefetch: the previous scene's build requests are replayed right after the coordinate insert)
-        ME.set_map_prefetch(True)
-        main_stream, side_stream = torch.cuda.current_stream(), torch.cuda.Stream()
-
-        def next_scene():
-            with torch.cuda.stream(side_stream):
-                t = ME.SparseTensor(feats_dev, coords_dev)
-            t.coordinate_manager.record_stream(main_stream)
-            ev = torch.cuda.Event()
-            ev.record(side_stream)
-            return t, ev
-        pending[0] = next_scene()
+        # a new scene every step, its maps built by a loader thread on a side stream while this thread launches the
+        # previous step (ME.utils.ScenePrefetcher: the previous scene's build requests are replayed right after the
+        # coordinate insert, all tile plans in four launches; the native host releases the GIL inside the builds)
+        def scenes_forever():
+            while True:
+                yield feats_dev, coords_dev
+        loader = ME.utils.ScenePrefetcher(scenes_forever(), depth=args.loader_depth)
+        pending[0] = iter(loader)
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -752,12 +752,11 @@ def bench_minkunet(args, ME, MEB, dist_utils, rank, world, dev, startup):
         elif args.scenes == "fresh":
             xin = ME.SparseTensor(feats_dev, coords_dev)      # coordinate maps, kernel maps, plans rebuilt lazily
         else:
-            xin, ev = pending[0]
-            main_stream.wait_event(ev)
+            xin = next(pending[0])
+            if os.environ.get("ME_BENCH_DISCARD_LOADED") == "1":   # (interference experiment: the loader runs, the step
+                xin = x                                            # trains on the cached scene)
         loss = crit(net(xin).F.float(), labels)   # mean cross-entropy over the voxels
         loss.backward()
-        if args.scenes == "pipelined":
-            pending[0] = next_scene()
         opt.step()
 
     if getattr(args, "pmc_child_mode", False):     # profiled child (measure_traffic): exactly `steps` steps
@@ -773,7 +772,7 @@ def bench_minkunet(args, ME, MEB, dist_utils, rank, world, dev, startup):
     for h in hooks:
         h.remove()
     graphed = False
-    if args.graph and args.scenes != "cached":
+    if args.graph and args.scenes != "cached" and os.environ.get("ME_BENCH_DISCARD_LOADED") != "1":
         raise SystemExit("--graph needs --scenes cached (a captured step replays fixed shapes and addresses)")
     if args.graph:
         step, graphed = capture_step(step), True
@@ -841,11 +840,17 @@ def bench_minkunet(args, ME, MEB, dist_utils, rank, world, dev, startup):
         "config": {"workload": f"MinkUNet34C (3 -> 20 classes, {n_params} parameters) "
                                f"forward + cross-entropy + backward + SGD step, {n} voxels/GPU on a union of 9 planes "
                                f"in 400^3 (SURVEY 8d), {'bf16 activations / fp32 master weights and accumulation' if bf16 else 'fp32'}, "
-                               + {"cached": "maps cached", "fresh": "a NEW scene every step (all maps and plans rebuilt)",
-                                  "pipelined": "a NEW scene every step, its maps prefetched on a side stream during the "
-                                               "previous backward pass"}[args.scenes]
+                               + {"cached": "maps cached", "fresh": "a NEW scene every step (all maps and plans rebuilt" + (", recipe replay)" if args.replay_maps
+                                                                                                    else ", lazily)"),
+                                  "pipelined": "a NEW scene every step, its maps built by a loader thread on a side stream "
+                                               "during the previous step (ME.utils.ScenePrefetcher)"}[args.scenes]
                                + " (BASELINE configs[2]; configs[3] with N = 8)",
                    "scenes": args.scenes,
+                   "map_prefetch": bool(ME.map_prefetch_enabled()),
+                   "loader": ({"depth": args.loader_depth,
+                               "build_ms_median": round(sorted(loader.build_ms)[len(loader.build_ms) // 2], 3),
+                               "consumer_wait_ms_median": round(sorted(loader.wait_ms)[len(loader.wait_ms) // 2], 3)}
+                              if args.scenes == "pipelined" else None),
                    "host_layer": ME.get_host(),
                    "points_per_gpu": n,
                    "parallelism": f"scene-sharded dp{world}" + (
@@ -977,6 +982,10 @@ def main():
     ap.add_argument("--backend", choices=("auto", "nccl", "gloo"), default="auto")
     ap.add_argument("--scenes", choices=("cached", "fresh", "pipelined"), default="cached",
                     help="minkunet: reuse one scene's maps (default, BASELINE configs[2]), or rebuild them every step")
+    ap.add_argument("--loader-depth", type=int, default=1, help="minkunet --scenes pipelined: scenes built ahead")
+    ap.add_argument("--replay-maps", action="store_true",
+                    help="minkunet --scenes fresh: replay the previous scene's build requests in one burst (recipe "
+                         "replay) instead of building lazily, layer by layer")
     ap.add_argument("--torch-loss", action="store_true",
                     help="minkunet: torch.nn.CrossEntropyLoss instead of examples/minkunet.py::cross_entropy (same math)")
     ap.add_argument("--sync-bn", action="store_true", help="minkunet, N > 1: MinkowskiSyncBatchNorm (reference recipe)")

@@ -52,7 +52,8 @@ typedef struct me_region {
  *              me_conv_stats_supported_bf16, me_bn_stats_from_tiles)
  *   1.4 (140)  round 4: split-K launches of the bf16 convolution for small coordinate maps
  *              (me_conv_plan_config_bf16_ex, me_conv_splitk_workspace_bytes, me_conv_target_bf16_ex); float64
- *              features (me_conv_target_f64, me_conv_wgrad_f64, me_pool_*_f64, me_global_pool_f64, me_broadcast_f64) */
+ *              features (me_conv_target_f64, me_conv_wgrad_f64, me_pool_*_f64, me_global_pool_f64, me_broadcast_f64);
+ *              all tile plans of a scene in four launches (me_plan_job, me_plan_jobs_init, me_plan_build_multi) */
 int me_version(void);
 const char *me_last_error(void);
 /* kernel volume of a region: src/kernel_region.hpp:250-270 (set_volume) */
@@ -240,6 +241,27 @@ int me_plan_build(const int32_t *tbl_dev, const int32_t *order_dev, int64_t n_tg
                   int32_t tile_rows, int32_t batch_groups, int32_t *plan_src_dev, int32_t *plan_dst_dev,
                   int32_t *batch_desc_dev, int32_t *tile_bptr_dev, int32_t *item_gptr_dev,
                   void *workspace_dev, int64_t workspace_bytes, void *stream);
+
+/* Every plan of a scene at once (ABI 1.4).  A network on a NEW scene builds ~45 plans (MinkUNet34C: 10 kernel maps x
+ * forward / input gradient x tile geometries); me_plan_build is 4 launches + 2 memsets each, on mostly idle hardware.
+ * me_plan_build_multi walks a table of jobs in 4 launches: the arrays it writes are those of me_plan_build, bit for bit.
+ * What the reference does at this point: one thrust sort + scan per kernel map (src/kernel_map.cuh:313-405).
+ *   me_plan_jobs_init       fills n_tiles / n_items / item_base of every job (host) -> total items, -1: invalid geometry
+ *   jobs_host / jobs_dev    the SAME initialised table in host memory (launch geometry, argument checks) and in device
+ *                           memory (read by the kernels; uploaded by the caller on `stream`)
+ *   workspace_dev           me_plan_multi_workspace_bytes(total items) */
+typedef struct me_plan_job {
+  const int32_t *tbl;       /* device: [volume, n_tgt], as me_plan_build */
+  const int32_t *order;     /* device: [n_tgt] or NULL */
+  int64_t n_tgt, volume;
+  int32_t tile_rows, batch_groups;
+  int32_t *plan_src, *plan_dst, *batch_desc, *tile_bptr, *item_gptr;   /* device (out), sized as for me_plan_build */
+  int64_t n_tiles, n_items, item_base;                                  /* out of me_plan_jobs_init */
+} me_plan_job;
+int64_t me_plan_jobs_init(me_plan_job *jobs_host, int32_t n_jobs);
+int64_t me_plan_multi_workspace_bytes(int64_t total_items);
+int me_plan_build_multi(const me_plan_job *jobs_host, const me_plan_job *jobs_dev, int32_t n_jobs, void *workspace_dev,
+                        int64_t workspace_bytes, void *stream);
 
 /* ---- convolution feature kernels (replace ConvolutionForwardKernelGPU / BackwardKernelGPU,
  *      src/convolution_kernel.cu:320-496, 553-757; CPU twins src/convolution_kernel.hpp:33-144) -- */

@@ -43,6 +43,15 @@ class MePackJob(ctypes.Structure):
 ME_PACK_BF16, ME_PACK_F32X3 = 0, 1
 
 
+class MePlanJob(ctypes.Structure):
+    """me_plan_job of include/me_amd.h"""
+    _fields_ = [("tbl", ctypes.c_void_p), ("order", ctypes.c_void_p), ("n_tgt", ctypes.c_int64), ("volume", ctypes.c_int64),
+                ("tile_rows", ctypes.c_int32), ("batch_groups", ctypes.c_int32), ("plan_src", ctypes.c_void_p),
+                ("plan_dst", ctypes.c_void_p), ("batch_desc", ctypes.c_void_p), ("tile_bptr", ctypes.c_void_p),
+                ("item_gptr", ctypes.c_void_p), ("n_tiles", ctypes.c_int64), ("n_items", ctypes.c_int64),
+                ("item_base", ctypes.c_int64)]
+
+
 class MeSpatialGrid(ctypes.Structure):
     """struct me_spatial_grid (include/me_amd.h)."""
     _fields_ = [
@@ -93,6 +102,9 @@ SIGNATURES = {
     "me_plan_workspace_bytes": (c_i64, [c_i64, c_i64, c_i32]),
     "me_plan_build": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                      c_i64, c_vp]),
+    "me_plan_jobs_init": (c_i64, [c_vp, c_i32]),
+    "me_plan_multi_workspace_bytes": (c_i64, [c_i64]),
+    "me_plan_build_multi": (ctypes.c_int, [c_vp, c_vp, c_i32, c_vp, c_i64, c_vp]),
     "me_conv_packed_weight_elems": (c_i64, [c_i64, c_i32, c_i32]),
     "me_conv_pack_weights_f32": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "me_conv_target_f32": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp,

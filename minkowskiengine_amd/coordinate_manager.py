@@ -1,6 +1,8 @@
 """CoordinateManager: thin Python wrapper that owns a backend coordinate-map manager
 (reference: MinkowskiEngine/MinkowskiCoordinateManager.py:107-440)."""
+import collections
 import os
+import weakref
 
 import torch
 
@@ -19,7 +21,11 @@ _minkowski_algorithm = MinkowskiAlgorithm.DEFAULT
 # maps, tile plans) — a training loop builds the same maps for every scene, and building them in one burst keeps the
 # host read-backs of the build out of the forward pass (backend.CoordinateMapManagerGPU_c10.prefetch, docs/HISTORY.md 9.8).
 _map_prefetch = os.environ.get("ME_AMD_MAP_PREFETCH", "0") != "0"
-_last_manager = None   # weak reference to the most recent CoordinateManager made by a SparseTensor
+_recent_managers = collections.deque(maxlen=4)   # weak references to the latest CoordinateManagers made by SparseTensors
+# (D, native host?) -> [recipe, misses]: the request log a manager left behind when it was destroyed — a scene's manager
+# usually dies right after its step, which is exactly when its log is complete
+_published_recipes = {}
+_PUBLISH_PATIENCE = 8   # that many successive shorter logs replace a longer published one (the network has changed)
 
 
 def set_map_prefetch(enabled=True):
@@ -32,14 +38,26 @@ def map_prefetch_enabled():
 
 
 def _prefetch_from_previous(manager):
-    """Called by SparseTensor for a freshly created manager whose coordinates have just been inserted."""
-    global _last_manager
-    prev = _last_manager() if _last_manager is not None else None
-    if _map_prefetch and prev is not None and prev is not manager and prev.D == manager.D and \
-            prev._native == manager._native:     # (a request log belongs to the host layer that wrote it)
-        manager.prefetch(prev.recipe())
-    import weakref
-    _last_manager = weakref.ref(manager)
+    """Called by SparseTensor for a freshly created manager whose coordinates have just been inserted.  The recipe is
+    the LONGEST request log among the latest managers that are still alive: with a loader thread (utils.ScenePrefetcher)
+    the directly preceding manager has usually not run its step yet — its log is empty unless it was itself built from
+    a complete recipe, in which case it is complete at once (a replay logs what it serves) — and the log the last
+    destroyed manager left behind (CoordinateManager.__del__)."""
+    if _map_prefetch:
+        best = None
+        for ref in _recent_managers:
+            prev = ref()
+            if prev is None or prev is manager or prev.D != manager.D or prev._native != manager._native:
+                continue                         # (a request log belongs to the host layer that wrote it)
+            r = prev.recipe()
+            if best is None or len(r) > len(best):
+                best = r
+        pub = _published_recipes.get((manager.D, manager._native))
+        if pub is not None and (best is None or len(pub[0]) > len(best)):
+            best = pub[0]
+        if best:
+            manager.prefetch(best)
+    _recent_managers.append(weakref.ref(manager))
 
 
 def set_coordinate_map_type(coordinate_map_type):
@@ -82,6 +100,25 @@ class CoordinateManager:
         self._native = _host.is_native()
         self.D = D
         self.minkowski_algorithm = minkowski_algorithm
+
+    def __del__(self):
+        # leave the request log behind for the managers of later scenes (see _prefetch_from_previous)
+        try:
+            if not _map_prefetch:
+                return
+            r = self._manager.recipe()
+            if not r:
+                return
+            key = (self.D, self._native)
+            pub = _published_recipes.get(key)
+            if pub is None or len(r) >= len(pub[0]):
+                _published_recipes[key] = [r, 0]
+            else:
+                pub[1] += 1
+                if pub[1] >= _PUBLISH_PATIENCE:
+                    _published_recipes[key] = [r, 0]
+        except Exception:      # interpreter shutdown
+            pass
 
     # ---- build-request log (not in the reference; see set_map_prefetch) ---------------------------------------------
     def recipe(self):

@@ -449,12 +449,9 @@ __global__ __launch_bounds__(256) void k_kmap_transpose(const int32_t *__restric
 // valid entries are padded to groups of 16 (one MFMA N-tile) and its groups are cut into BATCHES of at
 // most `batch_groups` groups: a batch is what the convolution kernel stages in LDS at once, and it
 // never mixes offsets (one weight slice per batch).
-__global__ __launch_bounds__(256) void k_plan_count(const int32_t *__restrict__ tbl,
-                                                   const int32_t *__restrict__ order, int64_t n_tgt,
-                                                   int64_t volume, int64_t n_items, int tile_rows,
-                                                   int batch_groups, uint64_t *__restrict__ count_gb) {
-  const int64_t item = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (item >= n_items) return;  // wave-uniform
+__device__ __forceinline__ uint64_t plan_count_item(const int32_t *__restrict__ tbl, const int32_t *__restrict__ order,
+                                                    int64_t n_tgt, int64_t volume, int64_t item, int tile_rows,
+                                                    int batch_groups) {
   const int64_t t = item / volume, k = item % volume;
   const int64_t row0 = t * tile_rows;
   uint32_t count = 0;
@@ -465,11 +462,19 @@ __global__ __launch_bounds__(256) void k_plan_count(const int32_t *__restrict__ 
     if (local < tile_rows && pos < n_tgt) r = tbl[k * n_tgt + (order ? (int64_t)order[pos] : pos)];
     count += (uint32_t)__popcll(__ballot(r >= 0));
   }
-  if (lane_id() == 0) {
-    const uint32_t groups = (count + ME_GROUP_ROWS - 1) / ME_GROUP_ROWS;
-    // groups in the low word, batches in the high word: ONE scan yields both offsets
-    count_gb[item] = ((uint64_t)((groups + batch_groups - 1) / batch_groups) << 32) | groups;
-  }
+  const uint32_t groups = (count + ME_GROUP_ROWS - 1) / ME_GROUP_ROWS;
+  // groups in the low word, batches in the high word: ONE scan yields both offsets
+  return ((uint64_t)((groups + batch_groups - 1) / batch_groups) << 32) | groups;
+}
+
+__global__ __launch_bounds__(256) void k_plan_count(const int32_t *__restrict__ tbl,
+                                                   const int32_t *__restrict__ order, int64_t n_tgt,
+                                                   int64_t volume, int64_t n_items, int tile_rows,
+                                                   int batch_groups, uint64_t *__restrict__ count_gb) {
+  const int64_t item = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (item >= n_items) return;  // wave-uniform
+  const uint64_t c = plan_count_item(tbl, order, n_tgt, volume, item, tile_rows, batch_groups);
+  if (lane_id() == 0) count_gb[item] = c;
 }
 
 // The valid entries of an item are not stored in row order: they are DEALT to the item's groups and
@@ -480,22 +485,16 @@ __global__ __launch_bounds__(256) void k_plan_count(const int32_t *__restrict__ 
 // therefore ordered by (row mod 8) — position p —, entry p goes to group p % groups, step s = p / groups,
 // and even steps fill slots 0-7, odd steps slots 8-15: each half of a group then holds (close to) one
 // row of every residue, instead of ~3 rows in the fullest residue for 8 random rows.
-__global__ __launch_bounds__(256) void k_plan_fill(const int32_t *__restrict__ tbl,
-                                                  const int32_t *__restrict__ order, int64_t n_tgt,
-                                                  int64_t volume, int64_t n_items, int tile_rows,
-                                                  int batch_groups, const uint64_t *__restrict__ offs_gb,
-                                                  const uint64_t *__restrict__ total_gb,
-                                                  int32_t *__restrict__ plan_src,
-                                                  int32_t *__restrict__ plan_dst,
-                                                  int32_t *__restrict__ batch_desc,
-                                                  int32_t *__restrict__ tile_bptr,
-                                                  int32_t *__restrict__ item_gptr, int64_t n_tiles) {
-  const int64_t item = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (item >= n_items) return;  // wave-uniform
+// (one wave per item; the plan's totals — tile_bptr[n_tiles], item_gptr[n_items] — are the caller's to store)
+__device__ __forceinline__ void plan_fill_item(const int32_t *__restrict__ tbl, const int32_t *__restrict__ order,
+                                               int64_t n_tgt, int64_t volume, int64_t n_items, int64_t item, int tile_rows,
+                                               int batch_groups, uint64_t off_gb, int32_t *__restrict__ plan_src,
+                                               int32_t *__restrict__ plan_dst, int32_t *__restrict__ batch_desc,
+                                               int32_t *__restrict__ tile_bptr, int32_t *__restrict__ item_gptr) {
   const int lane = lane_id();
   const int64_t t = item / volume, k = item % volume;
   const int64_t row0 = t * tile_rows;
-  const uint64_t off_gb = offs_gb[item];  // first group (low word) and first batch (high word) of the item
+  // off_gb: first group (low word) and first batch (high word) of the item
   const uint32_t g0 = (uint32_t)off_gb;
   const int64_t slot0 = (int64_t)g0 * ME_GROUP_ROWS;
   constexpr int kChunks = ME_MAX_TILE_ROWS / 64;
@@ -562,10 +561,26 @@ __global__ __launch_bounds__(256) void k_plan_fill(const int32_t *__restrict__ t
   if (lane == 0) {
     item_gptr[item] = (int32_t)g0;
     if (k == 0) tile_bptr[t] = (int32_t)b0;
-    if (item == 0) {
-      tile_bptr[n_tiles] = (int32_t)(*total_gb >> 32);
-      item_gptr[n_items] = (int32_t)(uint32_t)(*total_gb);
-    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_plan_fill(const int32_t *__restrict__ tbl,
+                                                  const int32_t *__restrict__ order, int64_t n_tgt,
+                                                  int64_t volume, int64_t n_items, int tile_rows,
+                                                  int batch_groups, const uint64_t *__restrict__ offs_gb,
+                                                  const uint64_t *__restrict__ total_gb,
+                                                  int32_t *__restrict__ plan_src,
+                                                  int32_t *__restrict__ plan_dst,
+                                                  int32_t *__restrict__ batch_desc,
+                                                  int32_t *__restrict__ tile_bptr,
+                                                  int32_t *__restrict__ item_gptr, int64_t n_tiles) {
+  const int64_t item = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (item >= n_items) return;  // wave-uniform
+  plan_fill_item(tbl, order, n_tgt, volume, n_items, item, tile_rows, batch_groups, offs_gb[item], plan_src, plan_dst,
+                 batch_desc, tile_bptr, item_gptr);
+  if (item == 0 && lane_id() == 0) {
+    tile_bptr[n_tiles] = (int32_t)(*total_gb >> 32);
+    item_gptr[n_items] = (int32_t)(uint32_t)(*total_gb);
   }
 }
 
@@ -586,8 +601,8 @@ __global__ __launch_bounds__(256) void k_plan_fill(const int32_t *__restrict__ t
 int g_tile_dispatch = 0;   // me_debug_set_tile_dispatch: 0 = heaviest first over the whole launch, 1 = XCD chunks
 
 template <int XCD>
-__global__ __launch_bounds__(1024) void k_plan_tile_order(const int32_t *__restrict__ item_gptr, int64_t volume,
-                                                         int64_t n_tiles, int32_t *__restrict__ perm) {
+__device__ __forceinline__ void plan_tile_order(const int32_t *__restrict__ item_gptr, int64_t volume, int64_t n_tiles,
+                                                int32_t *__restrict__ perm) {   // one workgroup of 1024 threads
   constexpr int CH = XCD > 0 ? XCD : 1;          // chunks
   constexpr int NB = 256 * CH;                   // bins: chunk-major, heavy tiles in a chunk's low bins
   constexpr int PER = (NB + 1023) / 1024;        // bins per thread in the scan
@@ -668,6 +683,98 @@ __global__ __launch_bounds__(1024) void k_plan_tile_order(const int32_t *__restr
       perm[(int64_t)(m - (uint32_t)first(x)) * CH + x] = (int32_t)t;
     }
   }
+}
+
+template <int XCD>
+__global__ __launch_bounds__(1024) void k_plan_tile_order(const int32_t *__restrict__ item_gptr, int64_t volume,
+                                                         int64_t n_tiles, int32_t *__restrict__ perm) {
+  plan_tile_order<XCD>(item_gptr, volume, n_tiles, perm);
+}
+
+// ---- all plans of a scene in four launches (round 4) ------------------------------------------------------------
+// A network on a new scene needs ~45 plans (MinkUNet34C: 10 kernel maps x forward / dgrad x tile geometries); one
+// me_plan_build each is 4 launches + 2 memsets of 4 - 8 us on mostly idle hardware, and ~55 us of host time: 2.5 ms of
+// host and 1.2 ms of GPU time per scene.  me_plan_build_multi walks a table of jobs instead: the items of all jobs are
+// numbered through (item_base), one wave per item finds its job by bisection; the scan and the dispatch order take one
+// workgroup per job.  The arrays it writes are those of me_plan_build, bit for bit.
+__device__ __forceinline__ int plan_job_of(const me_plan_job *__restrict__ jobs, int n_jobs, int64_t gi) {
+  int lo = 0, hi = n_jobs - 1;   // last job with item_base <= gi (jobs without items share their successor's base)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].item_base <= gi) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void k_plan_count_multi(const me_plan_job *__restrict__ jobs, int n_jobs,
+                                                         int64_t total_items, uint64_t *__restrict__ count_gb) {
+  const int64_t gi = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (gi >= total_items) return;  // wave-uniform
+  const me_plan_job &j = jobs[plan_job_of(jobs, n_jobs, gi)];
+  const uint64_t c = plan_count_item(j.tbl, j.order, j.n_tgt, j.volume, gi - j.item_base, j.tile_rows, j.batch_groups);
+  if (lane_id() == 0) count_gb[gi] = c;
+}
+
+// exclusive scan of a job's item counts (one workgroup per job, 8192 items per pass with a running carry) + the
+// plan's totals
+__global__ __launch_bounds__(kScanSingleThreads) void k_plan_scan_multi(const me_plan_job *__restrict__ jobs,
+                                                                       const uint64_t *__restrict__ count_gb,
+                                                                       uint64_t *__restrict__ offs_gb) {
+  constexpr int kWaves = kScanSingleThreads / 64;
+  __shared__ uint64_t s_wave[kWaves];
+  const me_plan_job &j = jobs[blockIdx.x];
+  const uint64_t *in = count_gb + j.item_base;
+  uint64_t *out = offs_gb + j.item_base;
+  const int64_t n = j.n_items;
+  const int lane = lane_id(), wave = threadIdx.x >> 6;
+  uint64_t carry = 0;
+  for (int64_t blk = 0; blk < n; blk += kScanSingleThreads * kScanSingleItems) {
+    const int64_t base = blk + (int64_t)threadIdx.x * kScanSingleItems;
+    uint64_t v[kScanSingleItems];
+    uint64_t sum = 0;
+#pragma unroll
+    for (int i = 0; i < kScanSingleItems; ++i) {
+      v[i] = (base + i < n) ? in[base + i] : 0ull;
+      sum += v[i];
+    }
+    const uint64_t incl = wave_inclusive_scan_t(sum);
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint64_t wave_off = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) {
+      const uint64_t t = s_wave[w];
+      if (w < wave) wave_off += t;
+      total += t;
+    }
+    __syncthreads();
+    uint64_t ex = carry + wave_off + incl - sum;
+#pragma unroll
+    for (int i = 0; i < kScanSingleItems; ++i) {
+      if (base + i < n) out[base + i] = ex;
+      ex += v[i];
+    }
+    carry += total;
+  }
+  if (threadIdx.x == 0) {
+    j.tile_bptr[j.n_tiles] = (int32_t)(carry >> 32);
+    j.item_gptr[n] = (int32_t)(uint32_t)carry;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_plan_fill_multi(const me_plan_job *__restrict__ jobs, int n_jobs,
+                                                        int64_t total_items, const uint64_t *__restrict__ offs_gb) {
+  const int64_t gi = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (gi >= total_items) return;  // wave-uniform
+  const me_plan_job &j = jobs[plan_job_of(jobs, n_jobs, gi)];
+  plan_fill_item(j.tbl, j.order, j.n_tgt, j.volume, j.n_items, gi - j.item_base, j.tile_rows, j.batch_groups, offs_gb[gi],
+                 j.plan_src, j.plan_dst, j.batch_desc, j.tile_bptr, j.item_gptr);
+}
+
+template <int XCD>
+__global__ __launch_bounds__(1024) void k_plan_tile_order_multi(const me_plan_job *__restrict__ jobs) {
+  const me_plan_job &j = jobs[blockIdx.x];
+  plan_tile_order<XCD>(j.item_gptr, j.volume, j.n_tiles, j.tile_bptr + j.n_tiles + 1);
 }
 
 // Voxel labels (the reference's quantize_label, src/quantization.cpp:140-196): a voxel keeps the label of
@@ -1389,6 +1496,15 @@ int64_t me_plan_workspace_bytes(int64_t n_tgt, int64_t volume, int32_t tile_rows
   return 2 * align_up(items * 8, 256) + 256 + scan_workspace_bytes(items);
 }
 
+static void plan_dispatch_env() {
+  static const bool env_read = [] {   // ME_AMD_TILE_DISPATCH=1: XCD chunks from the first plan on (tuning runs)
+    const char *e = getenv("ME_AMD_TILE_DISPATCH");
+    if (e != nullptr && *e != 0) g_tile_dispatch = atoi(e);
+    return true;
+  }();
+  (void)env_read;
+}
+
 int me_plan_build(const int32_t *tbl, const int32_t *order, int64_t n_tgt, int64_t volume, int32_t tile_rows,
                   int32_t batch_groups, int32_t *plan_src, int32_t *plan_dst, int32_t *batch_desc, int32_t *tile_bptr,
                   int32_t *item_gptr, void *workspace, int64_t workspace_bytes, void *stream_) {
@@ -1422,12 +1538,7 @@ int me_plan_build(const int32_t *tbl, const int32_t *order, int64_t n_tgt, int64
                      (int)batch_groups, offs_gb, total_gb, plan_src, plan_dst, batch_desc, tile_bptr, item_gptr,
                      n_tiles);
   ME_LAUNCH_CHECK();
-  static const bool env_read = [] {   // ME_AMD_TILE_DISPATCH=1: XCD chunks from the first plan on (tuning runs)
-    const char *e = std::getenv("ME_AMD_TILE_DISPATCH");
-    if (e != nullptr && *e != 0) g_tile_dispatch = std::atoi(e);
-    return true;
-  }();
-  (void)env_read;
+  plan_dispatch_env();
   if (g_tile_dispatch == 1)
     hipLaunchKernelGGL(k_plan_tile_order<8>, dim3(1), dim3(1024), 0, stream, item_gptr, volume, n_tiles,
                        tile_bptr + n_tiles + 1);
@@ -1435,6 +1546,63 @@ int me_plan_build(const int32_t *tbl, const int32_t *order, int64_t n_tgt, int64
     hipLaunchKernelGGL(k_plan_tile_order<0>, dim3(1), dim3(1024), 0, stream, item_gptr, volume, n_tiles,
                        tile_bptr + n_tiles + 1);
   ME_LAUNCH_CHECK();
+  return 0;
+}
+
+int64_t me_plan_jobs_init(me_plan_job *jobs, int32_t n_jobs) {
+  if (jobs == nullptr || n_jobs < 0) return -1;
+  int64_t base = 0;
+  for (int32_t i = 0; i < n_jobs; ++i) {
+    me_plan_job &j = jobs[i];
+    if (j.volume < 1 || j.volume > 65535 || j.tile_rows < ME_GROUP_ROWS || j.tile_rows > ME_MAX_TILE_ROWS ||
+        j.batch_groups < 1 || j.batch_groups > ME_MAX_BATCH_GROUPS || j.n_tgt < 0)
+      return -1;
+    j.n_tiles = me_plan_num_tiles(j.n_tgt, j.tile_rows);
+    j.n_items = j.n_tiles * j.volume;
+    j.item_base = base;
+    base += j.n_items;
+  }
+  return base;
+}
+
+int64_t me_plan_multi_workspace_bytes(int64_t total_items) { return 2 * align_up((total_items < 1 ? 1 : total_items) * 8, 256); }
+
+int me_plan_build_multi(const me_plan_job *jobs_host, const me_plan_job *jobs_dev, int32_t n_jobs, void *workspace,
+                        int64_t workspace_bytes, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_jobs == 0) return 0;
+  ME_CHECK(jobs_host != nullptr && jobs_dev != nullptr && n_jobs > 0, "job tables must not be null");
+  const int64_t total = jobs_host[n_jobs - 1].item_base + jobs_host[n_jobs - 1].n_items;
+  for (int32_t i = 0; i < n_jobs; ++i) {
+    const me_plan_job &j = jobs_host[i];
+    ME_CHECK(j.n_tiles == me_plan_num_tiles(j.n_tgt, j.tile_rows) && j.n_items == j.n_tiles * j.volume &&
+                 j.item_base == (i ? jobs_host[i - 1].item_base + jobs_host[i - 1].n_items : 0),
+             "job table not initialised (me_plan_jobs_init)");
+    ME_CHECK(j.tile_bptr != nullptr && j.item_gptr != nullptr, "plan arrays must not be null");
+    ME_CHECK(j.n_items == 0 || (j.tbl != nullptr && j.plan_src != nullptr && j.plan_dst != nullptr && j.batch_desc != nullptr),
+             "plan arrays must not be null");
+  }
+  ME_CHECK(total < (1ll << 31), "too many (tile, offset) items");
+  ME_CHECK(workspace_bytes >= me_plan_multi_workspace_bytes(total), "workspace too small");
+  uint64_t *count_gb = reinterpret_cast<uint64_t *>(workspace);
+  uint64_t *offs_gb = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(workspace) + align_up((total < 1 ? 1 : total) * 8, 256));
+  if (total > 0) {
+    hipLaunchKernelGGL(k_plan_count_multi, dim3((unsigned)ceil_div(total, 4)), dim3(256), 0, stream, jobs_dev, (int)n_jobs,
+                       total, count_gb);
+    ME_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(k_plan_scan_multi, dim3((unsigned)n_jobs), dim3(kScanSingleThreads), 0, stream, jobs_dev, count_gb,
+                     offs_gb);
+  ME_LAUNCH_CHECK();
+  if (total > 0) {
+    hipLaunchKernelGGL(k_plan_fill_multi, dim3((unsigned)ceil_div(total, 4)), dim3(256), 0, stream, jobs_dev, (int)n_jobs,
+                       total, offs_gb);
+    ME_LAUNCH_CHECK();
+    plan_dispatch_env();
+    if (g_tile_dispatch == 1) hipLaunchKernelGGL(k_plan_tile_order_multi<8>, dim3((unsigned)n_jobs), dim3(1024), 0, stream, jobs_dev);
+    else hipLaunchKernelGGL(k_plan_tile_order_multi<0>, dim3((unsigned)n_jobs), dim3(1024), 0, stream, jobs_dev);
+    ME_LAUNCH_CHECK();
+  }
   return 0;
 }
 

@@ -154,6 +154,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("conv_bn_stats_hint", &conv_bn_stats_hint, py::arg("flag"));
   m.def("set_conv_bn_stats", &set_conv_bn_stats, py::arg("enabled"));
   m.def("invalidate_packed_weights", &invalidate_packed_weights);
+  m.def("set_policy", &Policy::set, "integer policies of the native host by name (tests, tuning scripts)");
   m.def("timing_enable", &timing_enable);
   m.def("timing_records", &timing_records, py::arg("clear") = true);
   m.def("is_cuda_available", [] { return true; });
@@ -195,7 +196,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
       .def("exists", [](CoordinateMapManager &s, const CoordinateMapKey *k) { return k->key_set && s.exists(k->key); })
       .def("insert_and_map",
            [](CoordinateMapManager &s, const Tensor &coords, const ivec &ts, const std::string &sid) {
-             auto r = s.insert_and_map(coords, ts, sid);
+             auto r = [&] {
+               py::gil_scoped_release nogil;   // (see prefetch)
+               return s.insert_and_map(coords, ts, sid);
+             }();
              return py::make_tuple(py::cast(new_key(std::get<0>(r)), py::return_value_policy::take_ownership),
                                    py::make_tuple(std::get<1>(r), std::get<2>(r)));
            },
@@ -262,11 +266,20 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
              const ConvCfg &c = km->conv_cfg(target, target == "out" ? km->n_out : km->n_in, c_src, c_dst, bf16);
              return py::make_tuple(c.tile_rows, c.batch_groups);
            })
-      .def("recipe", [](CoordinateMapManager &s) { return *s.recipe_log; })
-      .def("prefetch", [](CoordinateMapManager &s, const std::vector<std::string> &r) { return s.prefetch(r); })
+      .def("recipe", [](CoordinateMapManager &s) { return s.recipe_log->snapshot(); })
+      // (no GIL while the maps and plans of a scene are built: a loader thread can prepare the next scene — on its own
+      // stream — while the training thread launches the current step)
+      .def("prefetch", [](CoordinateMapManager &s, const std::vector<std::string> &r) { return s.prefetch(r); },
+           py::call_guard<py::gil_scoped_release>())
       .def("record_stream",
            [](CoordinateMapManager &s, const py::object &stream) {
-             for (const Tensor &t : s.device_tensors()) py::cast(t).attr("record_stream")(stream);
+             // (torch.cuda.Stream -> c10::Stream, then no Python object and no GIL: a loader thread hands a scene's
+             // ~300 map tensors to the training stream without stalling the training thread)
+             const c10::Stream st = c10::Stream::unpack3(stream.attr("stream_id").cast<int64_t>(),
+                                                         (c10::DeviceIndex)stream.attr("device_index").cast<int64_t>(),
+                                                         (c10::DeviceType)stream.attr("device_type").cast<int64_t>());
+             py::gil_scoped_release nogil;
+             for (const Tensor &t : s.device_tensors()) t.record_stream(st);
            })
       .def("__repr__", &CoordinateMapManager::repr);
   m.attr("CoordinateMapManagerGPU_default") = m.attr("CoordinateMapManagerGPU_c10");

@@ -16,6 +16,7 @@
 
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <tuple>
 #include <unordered_map>
@@ -66,6 +67,7 @@ struct Policy {
   bool conv_bn_stats;      // ME_AMD_CONV_BN_STATS: batch-norm statistics in the bf16 convolution's epilogue
   bool roctx;              // ME_AMD_ROCTX: roctx ranges around insert / stride / kernel map / plan / forward / dgrad / wgrad
   static const Policy &get();
+  static void set(const std::string &name, int64_t value);   // tests / tuning scripts (plans already cached keep theirs)
 };
 
 // roctx range of a scope (ranges around the phases of the path, for `rocprofv3 --marker-trace`): the
@@ -134,6 +136,22 @@ struct Plan {
   Tensor plan_src, plan_dst, batch_desc, tile_bptr, item_gptr;
 };
 
+// Build requests a manager served, in order (the "recipe" a new scene's manager replays: CoordinateMapManager::prefetch).
+// Locked: a loader thread may read the previous scene's log (to replay it on the next scene) while the training thread's
+// layers still append to it.
+struct RecipeLog {
+  std::mutex mu;
+  std::vector<std::string> v;
+  void push_back(const std::string &r) {
+    std::lock_guard<std::mutex> g(mu);
+    v.push_back(r);
+  }
+  std::vector<std::string> snapshot() {
+    std::lock_guard<std::mutex> g(mu);
+    return v;
+  }
+};
+
 struct ConvCfg {          // launch geometry of a (kernel map side, channel shape, dtype)
   int tile_rows, batch_groups;
   std::shared_ptr<Plan> plan;
@@ -161,7 +179,7 @@ struct KernelMap : std::enable_shared_from_this<KernelMap> {
   bool flip = false;
   std::map<std::string, ConvCfg> conv_cfgs;
   std::map<std::string, WgradCfg> wgrad_cfgs;
-  std::weak_ptr<std::vector<std::string>> log;   // the owning manager's request log (build recipe) ...
+  std::weak_ptr<RecipeLog> log;   // the owning manager's request log (build recipe) ...
   std::string log_key;                           // ... and this map's serialised cache key in it
 
   const std::vector<int64_t> &k_offsets() { return offsets->get(); }
@@ -221,7 +239,7 @@ struct CoordinateMapManager {
                                         bool is_transpose, bool is_pool);
   // every strided map, kernel map, tile plan and weight-gradient geometry a network asks for, built in ONE call for a
   // new scene (the replay of another scene's request log: docs/HISTORY.md 9.8, round-3 build recipe)
-  std::shared_ptr<std::vector<std::string>> recipe_log = std::make_shared<std::vector<std::string>>();   // serialised requests
+  std::shared_ptr<RecipeLog> recipe_log = std::make_shared<RecipeLog>();   // serialised requests
   int64_t prefetch(const std::vector<std::string> &recipe);
   void log_request(const std::string &r) { recipe_log->push_back(r); }
   std::vector<Tensor> device_tensors();

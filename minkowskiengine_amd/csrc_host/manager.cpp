@@ -1,6 +1,7 @@
 // CoordinateMapManager, coordinate maps, kernel maps and tile plans of the native host layer (see host.hpp).
 // C++ twin of the corresponding classes of minkowskiengine_amd/backend.py; reference: src/coordinate_map_manager.cpp
 // (insert_and_map :349-399, stride :402-429, kernel_map :655-823), src/coordinate_map_gpu.cu, src/kernel_map.cuh.
+#include <cstring>
 #include "host.hpp"
 
 #include <dlfcn.h>
@@ -46,6 +47,17 @@ const Policy &Policy::get() {
     return q;
   }();
   return p;
+}
+
+// tuning / test hook: the integer policies by name (the environment is read once, at the first use)
+void Policy::set(const std::string &name, int64_t value) {
+  Policy &p = const_cast<Policy &>(get());
+  if (name == "tile_spatial_src_bytes") p.tile_spatial_src_bytes = value;
+  else if (name == "spatial_maps") p.spatial_maps = (int)value;
+  else if (name == "f32_split") p.f32_split = (int)value;
+  else if (name == "tile_rows") p.tile_rows = (int)value;
+  else if (name == "batch_groups") p.batch_groups = (int)value;
+  else check(false, "unknown policy: " + name);
 }
 
 namespace {
@@ -306,6 +318,33 @@ Tensor KernelMap::order(const std::string &target, const std::string &tile_order
   return flat_order(target, tile_order_);
 }
 
+// Plans requested while a batch is open (CoordinateMapManager::prefetch) are allocated and cached at once but BUILT
+// together when the batch closes: me_plan_build_multi, four launches for all of them (round 4)
+struct PlanBatch {
+  std::vector<me_plan_job> jobs;
+  std::vector<Tensor> keep;      // neighbour tables / tile orders / plan arrays of the jobs
+  c10::Device dev = c10::Device(c10::kCPU);
+};
+static thread_local PlanBatch *g_plan_batch = nullptr;
+
+static void flush_plan_batch(PlanBatch &b) {
+  if (b.jobs.empty()) return;
+  RoctxRange rx("me:tile_plans_multi");
+  const int64_t total = me_plan_jobs_init(b.jobs.data(), (int32_t)b.jobs.size());
+  check(total >= 0, "invalid plan geometry in a batch of plans");
+  const int64_t bytes = (int64_t)(b.jobs.size() * sizeof(me_plan_job));
+  Tensor host = at::empty({bytes}, at::TensorOptions().dtype(at::kByte).pinned_memory(true));
+  std::memcpy(host.data_ptr(), b.jobs.data(), (size_t)bytes);
+  c10::DeviceGuard guard(b.dev);
+  Tensor jobs_dev = at::empty({bytes}, at::TensorOptions().dtype(at::kByte).device(b.dev));
+  jobs_dev.copy_(host, /*non_blocking=*/true);
+  Tensor ws = workspace(me_plan_multi_workspace_bytes(total), b.dev);
+  me_ok(me_plan_build_multi(b.jobs.data(), reinterpret_cast<const me_plan_job *>(jobs_dev.data_ptr()),
+                            (int32_t)b.jobs.size(), vptr(ws), ws.numel(), stream_of(b.dev)));
+  b.jobs.clear();
+  b.keep.clear();
+}
+
 std::shared_ptr<Plan> KernelMap::plan(const std::string &target, int tile_rows, int batch_groups,
                                       const std::string &tile_order_) {
   const std::string nm = name("plan", target) + "_" + std::to_string(tile_rows) + "_" + std::to_string(batch_groups) +
@@ -326,10 +365,31 @@ std::shared_ptr<Plan> KernelMap::plan(const std::string &target, int tile_rows, 
   p->batch_desc = empty_i32({2 * max_groups}, dev);
   p->tile_bptr = empty_i32({me_plan_tile_bptr_elems(n_tgt, tile_rows)}, dev);
   p->item_gptr = empty_i32({n_tiles * volume + 1}, dev);
-  Tensor ws = workspace(me_plan_workspace_bytes(n_tgt, volume, tile_rows), dev);
   Tensor gather_order;
   if (tp.second.defined()) gather_order = tile_order_ == "spatial" ? Tensor() : store_get(*store, name("pos", target));
   else gather_order = flat_order(target, tile_order_);
+  if (g_plan_batch != nullptr && (g_plan_batch->jobs.empty() || g_plan_batch->dev == dev)) {
+    me_plan_job j;
+    std::memset(&j, 0, sizeof(j));
+    j.tbl = ptr<int32_t>(tp.first);
+    j.order = ptr<int32_t>(gather_order);
+    j.n_tgt = n_tgt;
+    j.volume = volume;
+    j.tile_rows = tile_rows;
+    j.batch_groups = batch_groups;
+    j.plan_src = ptr<int32_t>(p->plan_src);
+    j.plan_dst = ptr<int32_t>(p->plan_dst);
+    j.batch_desc = ptr<int32_t>(p->batch_desc);
+    j.tile_bptr = ptr<int32_t>(p->tile_bptr);
+    j.item_gptr = ptr<int32_t>(p->item_gptr);
+    g_plan_batch->dev = dev;
+    g_plan_batch->jobs.push_back(j);
+    g_plan_batch->keep.push_back(tp.first);
+    if (gather_order.defined()) g_plan_batch->keep.push_back(gather_order);
+    store->plans[nm] = p;
+    return p;
+  }
+  Tensor ws = workspace(me_plan_workspace_bytes(n_tgt, volume, tile_rows), dev);
   c10::DeviceGuard guard(dev);
   me_ok(me_plan_build(ptr<int32_t>(tp.first), ptr<int32_t>(gather_order), n_tgt, volume, tile_rows, batch_groups,
                       ptr<int32_t>(p->plan_src), ptr<int32_t>(p->plan_dst), ptr<int32_t>(p->batch_desc),
@@ -865,18 +925,32 @@ int64_t CoordinateMapManager::prefetch(const std::vector<std::string> &recipe) {
       if (it != kernel_maps.end()) cfgs.push_back({it->second, f});
     }
   }
-  for (auto &c : cfgs) {
-    const auto &f = c.second;
-    KernelMap &km = *c.first;
-    if (f[0] == "conv_cfg") {
-      const std::string target = f[9];
-      km.conv_cfg(target, target == "out" ? km.n_out : km.n_in, std::atoi(f[10].c_str()), std::atoi(f[11].c_str()),
-                  f[12] == "1");
-    } else {
-      km.wgrad_cfg(std::atoi(f[9].c_str()), std::atoi(f[10].c_str()), f[11] == "1");
+  // (the plans of all these configurations are built together: see PlanBatch)
+  PlanBatch batch;
+  struct BatchScope {
+    PlanBatch *prev;
+    explicit BatchScope(PlanBatch *b) : prev(g_plan_batch) { g_plan_batch = b; }
+    ~BatchScope() { g_plan_batch = prev; }
+  };
+  try {
+    BatchScope scope(&batch);
+    for (auto &c : cfgs) {
+      const auto &f = c.second;
+      KernelMap &km = *c.first;
+      if (f[0] == "conv_cfg") {
+        const std::string target = f[9];
+        km.conv_cfg(target, target == "out" ? km.n_out : km.n_in, std::atoi(f[10].c_str()), std::atoi(f[11].c_str()),
+                    f[12] == "1");
+      } else {
+        km.wgrad_cfg(std::atoi(f[9].c_str()), std::atoi(f[10].c_str()), f[11] == "1");
+      }
+      ++done;
     }
-    ++done;
+  } catch (...) {
+    flush_plan_batch(batch);   // the plans requested so far are in the cache: they must exist
+    throw;
   }
+  flush_plan_batch(batch);
   return done;
 }
 

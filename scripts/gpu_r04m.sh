@@ -1,7 +1,21 @@
 #!/bin/bash
+# Round-4 session M: me_plan_build_multi + loader-thread scene prefetch — tests, then MinkUNet34C bf16 with a new scene
+# every step: lazy builds, recipe replay in one burst, loader thread; cached for reference.
 set +e
-OUT=$PWD/gpurun_out/r03_final
+OUT=$PWD/gpurun_out/r04m
 mkdir -p $OUT
-timeout 1500 python -m pytest tests -m gpu -q --timeout 900 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"
-grep -E "^(FAILED|ERROR)|passed|failed" $OUT/pytest_gpu.log | head -20
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $OUT/smoke.log
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_gpu_coords.py tests/test_gpu_prefetch.py tests/test_gpu_native_host.py tests/test_gpu_bf16.py tests/test_gpu_scene_prefetch.py -q -m gpu -k "plan or prefetch or recipe or tile_order" 2>&1 | tail -15 | tee $OUT/pytest.log
+run() {  # name, args...
+  name=$1; shift
+  timeout 300 python bench.py --workload minkunet --dtype bf16 --steps 10 --warmup 6 --cpu-budget 0 --pmc off "$@" > $OUT/unet_$name.json 2>$OUT/unet_$name.err
+  python - <<PY
+import json
+d = json.loads(open("$OUT/unet_$name.json").read().strip().splitlines()[-1])
+print("$name", d["ms_per_step"], d["config"].get("map_prefetch"))
+PY
+}
+run cached
+run fresh_lazy --scenes fresh
+run fresh_replay --scenes fresh --replay-maps
+run pipelined --scenes pipelined

@@ -1,17 +1,20 @@
 #!/bin/bash
-# two ranks sharing the one GPU: DDP MinkUNet34C bf16 line (with and without SyncBN) and the DDP example
 set +e
 OUT=$PWD/gpurun_out/r04p
 mkdir -p $OUT
-timeout 600 python bench.py --gpus 2 --workload minkunet --dtype bf16 --steps 5 --warmup 2 --cpu-budget 0 --no-graph-probe > $OUT/unet_n2.json 2> $OUT/unet_n2.err; echo "rc=$?"
-timeout 600 python bench.py --gpus 2 --workload minkunet --dtype bf16 --steps 5 --warmup 2 --cpu-budget 0 --no-graph-probe --sync-bn --imbalance > $OUT/unet_n2_syncbn_imbalance.json 2> $OUT/unet_n2_syncbn.err; echo "rc=$?"
-python - <<PY
-import json, glob, os
-for f in sorted(glob.glob("$OUT/*.json")):
-    try:
-        d = json.loads(open(f).read().strip().splitlines()[-1])
-        print(os.path.basename(f), d["value"], d["unit"], d["ms_per_step"], "ms n_gpus", d["n_gpus"], d["config"].get("parallelism"), d["config"].get("imbalance"))
-    except Exception as e:
-        print(os.path.basename(f), "unreadable", e)
+export TMPDIR=/tmp
+timeout 300 python -m pytest tests/test_gpu_scene_prefetch.py tests/test_gpu_prefetch.py -q -m gpu 2>&1 | tail -3
+run() {  # name, env..., -- args
+  name=$1; shift
+  timeout 300 env "$@" > $OUT/unet_$name.json 2>$OUT/unet_$name.err
+  python - <<PY
+import json
+d = json.loads(open("$OUT/unet_$name.json").read().strip().splitlines()[-1])
+print("$name", d["ms_per_step"], d["config"].get("loader"))
 PY
-tail -3 $OUT/unet_n2.err | cut -c1-200
+}
+B="python bench.py --workload minkunet --dtype bf16 --steps 10 --warmup 6 --cpu-budget 0 --pmc off"
+run cached A=1 $B
+run discard ME_BENCH_DISCARD_LOADED=1 $B --scenes pipelined
+run pipelined A=1 $B --scenes pipelined
+run graph A=1 $B --graph

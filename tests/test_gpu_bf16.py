@@ -499,3 +499,45 @@ def test_offset_synchronous_kernel_is_bit_identical(device, no_split_k, n, exten
     assert_bf16_close(res[1][0].float().cpu().numpy(), O.conv_forward(x.numpy(), w.numpy(), okm, len(out_c)), "forward")
     assert_bf16_close(res[1][1].float().cpu().numpy(), O.conv_backward(x.numpy(), res[0][3].numpy(), w.numpy(), okm)[0],
                       "grad_in")
+
+
+@pytest.mark.parametrize("n,extent,cin,cout", [(6000, 30, 96, 96), (5000, 16, 128, 96), (4000, 14, 64, 128), (2500, 12, 192, 128)])
+def test_bf16_tile_order_and_dispatch_do_not_change_a_bit(device, no_split_k, host_layer, monkeypatch, n, extent, cin, cout):
+    """Round 4: bf16 launches whose source matrix is larger than the L2s take spatially compact tiles
+    (ME_AMD_TILE_SPATIAL_SRC_MB; forced here with a threshold of one byte), and the tiles of a plan can be dealt to the
+    XCDs in contiguous chunks (me_debug_set_tile_dispatch).  Both only regroup target rows into tiles / permute the
+    dispatch: forward and both gradients of a layer are bit-identical to row tiles in heaviest-first order, on both
+    hosts — and the dispatch table stays a permutation of the tiles."""
+    import minkowskiengine_amd as ME
+    from minkowskiengine_amd import _lib, backend as MEB, host as H
+    lib = _lib.load()
+    native = H.native_module() if host_layer == "native" else None
+    coords = make_cloud(n, extent, 3, seed=n + cin, batch=2, negative=True)
+    res = {}
+
+    def policy(src_bytes):
+        monkeypatch.setattr(MEB, "_TILE_SPATIAL_MIN_SRC_BYTES", src_bytes)
+        if native is not None:
+            native.set_policy("tile_spatial_src_bytes", src_bytes)
+    try:
+        for name, src_bytes, dispatch in (("rows", 0, 0), ("spatial", 1, 0), ("rows_xcd", 0, 1), ("spatial_xcd", 1, 1)):
+            policy(src_bytes)
+            lib.me_debug_set_tile_dispatch(dispatch)
+            conv, x, y, feats, gy = _run_layer(device, coords, cin, cout, 3, seed=3)
+            res[name] = (y.F.clone(), x.F.grad.clone(), conv.kernel.grad.clone())
+            if host_layer == "python":
+                km = x.coordinate_manager._manager._kernel_map(x.coordinate_map_key, y.coordinate_map_key, [3] * 3, [1] * 3,
+                                                               [1] * 3, MEB.RegionType.HYPER_CUBE, None, False, False)
+                _, cfg = MEB._conv_launch_cfg(km, "out", km.n_out, cin, cout, True)
+                assert (cfg[6] is not None) == (src_bytes > 0)          # an order tensor <=> spatial tiles on a flat map
+                bptr = cfg[5].cpu().numpy()
+                n_tiles = -(-km.n_out // cfg[0])
+                assert sorted(bptr[n_tiles + 1:2 * n_tiles + 1].tolist()) == list(range(n_tiles))
+    finally:
+        lib.me_debug_set_tile_dispatch(0)
+        if native is not None:
+            native.set_policy("tile_spatial_src_bytes", 28 << 20)
+    for name in ("spatial", "rows_xcd", "spatial_xcd"):
+        for got, want, what in zip(res[name], res["rows"], ("forward", "grad_in", "grad_kernel")):
+            assert torch.equal(got, want), (name, what)
+    assert float(res["rows"][0].float().abs().max()) > 0

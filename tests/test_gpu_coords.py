@@ -230,6 +230,84 @@ def test_tile_plan_covers_every_pair_once(device, target, T, CAP, stride, tile_o
     assert len(seen) == int((tbl[:, :n_tgt] >= 0).sum()) == km.n_pairs
 
 
+def test_plan_build_multi_writes_the_arrays_of_plan_build(device):
+    """me_plan_build_multi (ABI 1.4): all plans of a scene in four launches.  A table of jobs over two kernel maps —
+    forward and transposed tables, row tiles and a permuted tile order, tile heights 16 ... 256, batches of 1 ... 4 groups,
+    K = 27 and K = 8, and a job without target rows in the middle — must leave every job's five arrays exactly as
+    me_plan_build leaves them."""
+    import ctypes
+    from minkowskiengine_amd import _lib
+    from minkowskiengine_amd import backend as MEB
+    lib = _lib.load()
+    coords = make_cloud(5000, 16, 3, seed=5, batch=2, negative=True)
+    mgr = MEB.CoordinateMapManagerGPU_c10()
+    key, _ = mgr.insert_and_map(coords.to(device), [1, 1, 1], "")
+    okey = mgr.stride(key, [2, 2, 2])
+    km1 = mgr._kernel_map(key, key, [3] * 3, [1] * 3, [1] * 3, MEB.RegionType.HYPER_CUBE, None, False, False)
+    km2 = mgr._kernel_map(key, okey, [2] * 3, [2] * 3, [1] * 3, MEB.RegionType.HYPER_CUBE, None, False, False)
+    g = torch.Generator().manual_seed(3)
+    specs = []   # (table, n_tgt, volume, order, tile_rows, batch_groups, pairs)
+    for km, target, T, cap, permuted in ((km1, "out", 128, 4, False), (km1, "in", 37, 1, True), (km2, "out", 16, 2, False),
+                                         (None, None, 64, 4, False), (km2, "in", 256, 3, True), (km1, "out", 131, 3, True)):
+        if km is None:
+            specs.append((torch.zeros(27, 1, dtype=torch.int32, device=device), 0, 27, None, T, cap, 0))
+            continue
+        tbl = km.table(target).contiguous()
+        n_tgt = km.n_out if target == "out" else km.n_in
+        assert tbl.shape == (km.volume, n_tgt)
+        order = torch.randperm(n_tgt, generator=g).to(torch.int32).to(device) if permuted else None
+        specs.append((tbl, n_tgt, km.volume, order, T, cap, km.n_pairs))
+
+    def arrays(n_tgt, volume, pairs, T):
+        mg = int(lib.me_plan_max_groups(n_tgt, volume, pairs, T))
+        n_tiles = int(lib.me_plan_num_tiles(n_tgt, T))
+        mk = lambda n: torch.full((n,), -7, dtype=torch.int32, device=device)
+        return [mk(mg * 16), mk(mg * 16), mk(2 * mg), mk(int(lib.me_plan_tile_bptr_elems(n_tgt, T))), mk(n_tiles * volume + 1)]
+    stream = torch.cuda.current_stream().cuda_stream
+    single, multi = [], []
+    jobs = (_lib.MePlanJob * len(specs))()
+    for i, (tbl, n_tgt, volume, order, T, cap, pairs) in enumerate(specs):
+        a = arrays(n_tgt, volume, pairs, T)
+        ws = torch.empty(int(lib.me_plan_workspace_bytes(n_tgt, volume, T)), dtype=torch.uint8, device=device)
+        _lib.check(lib.me_plan_build(tbl.data_ptr(), order.data_ptr() if order is not None else None, n_tgt, volume, T, cap,
+                                     *[t.data_ptr() for t in a], ws.data_ptr(), ws.numel(), stream))
+        single.append(a)
+        b = arrays(n_tgt, volume, pairs, T)
+        multi.append(b)
+        j = jobs[i]
+        j.tbl, j.order, j.n_tgt, j.volume = tbl.data_ptr(), (order.data_ptr() if order is not None else None), n_tgt, volume
+        j.tile_rows, j.batch_groups = T, cap
+        j.plan_src, j.plan_dst, j.batch_desc, j.tile_bptr, j.item_gptr = [t.data_ptr() for t in b]
+    total = int(lib.me_plan_jobs_init(ctypes.byref(jobs), len(specs)))
+    assert total == sum(-(-s[1] // s[4]) * s[2] for s in specs) and jobs[3].n_items == 0 and jobs[4].item_base == jobs[3].item_base
+    raw = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(device)
+    ws = torch.empty(int(lib.me_plan_multi_workspace_bytes(total)), dtype=torch.uint8, device=device)
+    _lib.check(lib.me_plan_build_multi(ctypes.byref(jobs), raw.data_ptr(), len(specs), ws.data_ptr(), ws.numel(), stream))
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(single, multi)):
+        n_tgt, volume, T = specs[i][1], specs[i][2], specs[i][4]
+        n_tiles = -(-n_tgt // T)
+        groups = int(a[4][n_tiles * volume])            # total groups of the plan
+        assert int(b[4][n_tiles * volume]) == groups and int(a[3][n_tiles]) == int(b[3][n_tiles])
+        used = [(groups + 4) * 16 if n_tgt else 0, (groups + 4) * 16 if n_tgt else 0, 2 * int(a[3][n_tiles]),
+                n_tiles + 1, n_tiles * volume + 1]
+        for name, u, v, n in zip(("plan_src", "plan_dst", "batch_desc", "tile_bptr", "item_gptr"), a, b, used):
+            assert torch.equal(u[:n], v[:n]), (i, name)
+        # the dispatch order behind the batch pointers: a counting sort by binned work whose order inside a bin is
+        # arbitrary (LDS atomics) — the same sequence of WORK BINS, both permutations of the tiles
+        if n_tiles:
+            ig = a[4].cpu().numpy()
+            work = np.array([ig[(t + 1) * volume] - ig[t * volume] for t in range(n_tiles)], np.int64)
+            span = max(int(work.max() - work.min()), 1)
+            bins = 255 - (work - work.min()) * 255 // span
+            pa, pb = a[3][n_tiles + 1:2 * n_tiles + 1].cpu().numpy(), b[3][n_tiles + 1:2 * n_tiles + 1].cpu().numpy()
+            assert sorted(pa.tolist()) == sorted(pb.tolist()) == list(range(n_tiles)), i
+            assert np.array_equal(bins[pa], bins[pb]), i
+    # an uninitialised table is refused
+    jobs[1].item_base = 12345
+    assert lib.me_plan_build_multi(ctypes.byref(jobs), raw.data_ptr(), len(specs), ws.data_ptr(), ws.numel(), stream) != 0
+
+
 def test_transposed_map_reuses_forward_map(device):  # src/coordinate_map_manager.cpp:763-774
     coords = make_cloud(3000, 14, 3, seed=31, negative=True)
     MEB, mgr = _mgr()

@@ -1,0 +1,49 @@
+"""ME.utils.ScenePrefetcher: the next scene's coordinate manager (maps, plans) is built by a loader thread on a side
+stream while the training thread runs the current step.  Results must equal the lazily built ones bit for bit, for
+every scene of a sequence of DIFFERENT scenes, on both hosts."""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("host_layer")]
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+
+
+def test_prefetched_scenes_train_like_lazily_built_ones(device):
+    import minkowskiengine_amd as ME
+    import minkunet as MU
+    torch.manual_seed(0)
+    net = MU.MinkUNet14(3, 5, D=3).to(device)
+    scenes = [MU.synthetic_scene(5000 + 500 * s, grid=48, seed=s).to(device) for s in range(5)]
+    feats = [torch.rand(c.shape[0], 3, device=device).bfloat16() for c in scenes]
+
+    def step(x):
+        net.zero_grad(set_to_none=True)
+        out = net(x)
+        out.F.float().square().mean().backward()
+        return out.F.detach().clone(), [p.grad.detach().clone() for p in net.parameters()]
+
+    assert not ME.map_prefetch_enabled()
+    want = [step(ME.SparseTensor(f, c)) for f, c in zip(feats, scenes)]
+    torch.cuda.synchronize()
+    got = [step(x) for x in ME.utils.ScenePrefetcher(zip(feats, scenes), depth=2)]
+    assert not ME.map_prefetch_enabled()           # restored
+    assert len(got) == len(want)
+    for (yo, go), (yw, gw) in zip(got, want):
+        assert torch.equal(yo, yw)
+        for a, b in zip(go, gw):
+            assert torch.equal(a, b)
+
+
+def test_prefetcher_hands_the_iterators_error_to_the_consumer(device):
+    import minkowskiengine_amd as ME
+
+    def scenes():
+        yield torch.rand(10, 3, device=device), torch.randint(0, 9, (10, 4), device=device, dtype=torch.int32)
+        raise ValueError("no more scenes")
+    it = iter(ME.utils.ScenePrefetcher(scenes()))
+    assert next(it).F.shape[0] <= 10
+    with pytest.raises(ValueError):
+        next(it)
