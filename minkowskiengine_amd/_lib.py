@@ -200,6 +200,8 @@ DEBUG_SIGNATURES = {
     "me_debug_set_bf16_shape": (None, [ctypes.c_int, ctypes.c_int]),
     "me_debug_set_bf16_deep": (None, [ctypes.c_int]),
     "me_debug_set_bf16_twobuf": (None, [ctypes.c_int]),
+    "me_debug_set_bf16_ws": (None, [ctypes.c_int]),
+    "me_debug_set_bf16_ws_depth": (None, [ctypes.c_int]),
     "me_debug_set_bf16_offsync": (None, [ctypes.c_int]),
     "me_debug_set_bf16_splitk": (None, [ctypes.c_int]),
     "me_debug_set_bf16_splitk_mode": (None, [ctypes.c_int]),
@@ -226,6 +228,12 @@ def load():
             fn.restype = restype
             fn.argtypes = argtypes
     _lib = lib
+    # tuning switches of the library by environment (A/B runs of bench.py): ME_AMD_BF16_WS=0 keeps k_conv_tile_bf16
+    # everywhere, ME_AMD_BF16_WS_DEPTH=2 its shallower producer pipeline
+    if os.environ.get("ME_AMD_BF16_WS", "") != "":
+        lib.me_debug_set_bf16_ws(int(os.environ["ME_AMD_BF16_WS"]))
+    if os.environ.get("ME_AMD_BF16_WS_DEPTH", "") != "":
+        lib.me_debug_set_bf16_ws_depth(int(os.environ["ME_AMD_BF16_WS_DEPTH"]))
     return lib
 
 

@@ -1246,6 +1246,7 @@ int g_bf16_offsync = 0;             // me_debug_set_bf16_offsync: 0 column-split
                                     // kernel where eligible, 2 / 3: the same with its other wave shapes
 int g_bf16_splitk = -1;             // me_debug_set_bf16_splitk: -1 policy, 0 / 1 never, G >= 2: G offset groups where eligible
 int g_bf16_splitk_same_tiles = 0;   // me_debug_set_bf16_splitk_mode: 1 = forced groups keep the unsplit tile height (G x the workgroups)
+int g_bf16_ws = -1;   // me_debug_set_bf16_ws: -1 policy, 0 never, 1 wherever the wave-specialised kernel is instantiated
 constexpr bool kTwoBufDefault = false;
 constexpr int kSplitKMaxTileRows = 48;   // policy: split launches whose unsplit tiles are at most this tall
 
@@ -1289,6 +1290,30 @@ static ConvVariantBf16 conv_variant_bf16(int c_src, int c_dst) {
     v.kc = g_bf16_kc;
   v.slabs = (int)ceil_div(c_dst, v.nc);
   return v;
+}
+
+// Tile height for the wave-specialised kernel (conv_bf16_ws.hip).  Measured per layer inside a MinkUNet34C step and in
+// sweeps over forced heights (profiles/r04_ws_tile_rows.log, r04_layers_minkunet34c_bf16_ws_*.log): a launch costs its
+// BATCHES — 1,000 - 2,000 cycles each, almost whatever their fill — so the tallest tile wins as long as an off-centre
+// (tile, offset) item stays within one batch of four groups (64 pairs on average: T <= 64 / p) and the LDS of the
+// resident workgroups holds it; with one or two rounds of tiles the height is cut so that the rounds are whole (uniform
+// scenes: 2.03 rounds take as long as 3); two workgroups per CU where the registers allow (<= 128 per lane: the
+// 64-column shapes, 128 columns up to 64-channel chunks), one when the tiles would get shorter than 64 rows.
+static int plan_tile_rows_ws(const ConvVariantBf16 &v, int64_t n_tgt, int64_t volume, double p) {
+  const int cus = device_cu_count();
+  int occ = (v.nc == 64 || v.kc <= 64) ? 2 : 1;
+  for (;; --occ) {
+    int t_max = ME_MAX_TILE_ROWS;
+    while (t_max > ME_GROUP_ROWS && (int64_t)conv_bf16_ws_lds_bytes(v.nc, v.kc, t_max) * occ > kLdsBudget) --t_max;
+    int64_t t_cap = t_max;
+    if (volume > 1 && p > 0.0) t_cap = std::min<int64_t>(t_max, std::max<int64_t>(64, (int64_t)(64.0 / p)));
+    const int64_t slots = (int64_t)cus * occ;
+    const int64_t rounds = ceil_div(n_tgt * v.slabs, slots * t_cap);
+    int64_t t = rounds <= 2 ? ceil_div(n_tgt * v.slabs, slots * rounds) : t_cap;
+    if (t < ME_GROUP_ROWS) t = ME_GROUP_ROWS;
+    if (occ > 1 && rounds == 1 && t < 64) continue;   // a launch of short tiles: one taller workgroup per CU
+    return (int)t;
+  }
 }
 
 // two stage buffers + one barrier per batch for the deep-pipeline (eight-wave) launches
@@ -1462,6 +1487,14 @@ int me_conv_plan_config_bf16(int64_t n_tgt, int64_t volume, int64_t n_pairs, int
   s.nc = v.nc;
   s.slabs = v.slabs;
   s.chunks = (int)ceil_div(c_src, v.kc);
+  // the wave-specialised kernel: one eight-wave workgroup per CU, two unpadded stage buffers — unless the map is so
+  // sparse that every tile height leaves fewer than 24 pairs per (tile, offset) item (the hosts' batch-fusion rule:
+  // those launches stay with k_conv_tile_bf16)
+  const double p_side = volume > 1 ? (double)(n_pairs > n_tgt ? n_pairs - n_tgt : 0) / ((double)(volume - 1) * (double)n_tgt) : 1.0;
+  if (g_bf16_ws != 0 && conv_bf16_ws_shape(v.nc, v.kc) && c_src % v.kc == 0 && p_side * ME_MAX_TILE_ROWS >= 24.0) {
+    *tile_rows = plan_tile_rows_ws(v, n_tgt, volume, p_side);
+    return 0;
+  }
   s.group_cycles = 64.0 + (v.kc / 32) * 24.0;  // LDS-bound: accumulator read-add-write + operand reads
   s.stage_row_bytes = (v.kc + 16) * 2 + 4;
   s.wave_slots = 4 * conv_bf16_waves_per_simd(v.nc, v.kc);
@@ -1521,6 +1554,7 @@ int64_t me_conv_splitk_workspace_bytes(int64_t n_tgt, int32_t tile_rows, int32_t
 }
 
 void me_debug_set_bf16_twobuf(int mode) { g_bf16_twobuf = mode; }
+void me_debug_set_bf16_ws(int mode) { g_bf16_ws = mode; }
 void me_debug_set_bf16_offsync(int mode) {
 #ifdef ME_DEBUG_VARIANTS
   g_bf16_offsync = mode;
@@ -1617,6 +1651,13 @@ static int conv_target_bf16(const uint16_t *src_, int64_t n_src, int32_t c_src, 
   }
 #endif
   const ConvVariantBf16 v = conv_variant_bf16(c_src, c_dst);
+  // the wave-specialised kernel (conv_bf16_ws.hip) wherever it is instantiated and the launch needs none of the things
+  // it does not do: multi-offset batches (sparse maps), split-K, 64-bit gather offsets.  Bit-identical output.
+  if (g_bf16_ws != 0 && small && !fuse && split_k <= 1 && g_conv_variant != 7) {
+    const int rc = launch_conv_bf16_ws(v.nc, v.kc, src, c_src, wp, c_dst, v.slabs, plan_src, plan_dst, batch_desc,
+                                       tile_bptr, order, dst, n_tgt, tile_rows, stream, stat_mean, stat_m2);
+    if (rc != -1) return rc;
+  }
 #define ME_CONV_CASE(NCV, KCV)                                                                                   \
   return launch_conv_tile_bf16<NCV, KCV>(src, c_src, wp, c_dst, v.slabs, plan_src, plan_dst, batch_desc, tile_bptr, \
                                          order, dst, n_tgt, tile_rows, batch_groups, stream, small, fuse, stat_mean,   \

@@ -1,0 +1,384 @@
+// bf16 sparse convolution (forward / dgrad), wave-specialised (round 4).
+//
+// k_conv_tile_bf16 (conv_bf16.hip) gives every wave of a workgroup every job of a batch, in lockstep: index window ->
+// gather -> barrier -> stage write -> barrier -> operands -> MFMA -> accumulate.  Its phase counters say what that costs
+// (docs/HISTORY.md 10.4): 3,200 - 4,600 cycles per batch for ~200 cycles of matrix work, waves waiting on s_waitcnt and
+// barriers 42 % of their cycles, issuing 24 %; more workgroups per CU, deeper prefetch, a second stage buffer, split-K
+// and an offset-synchronous schedule each moved it by a few per cent.  The fp32 kernel on the bf16 pipe
+// (k_conv_tile_f32x3_ws) pushes SIX MFMAs per product and twice the gather bytes through the same plan in 1.6x the
+// time — its structure, not its arithmetic, is the difference.  This is that structure with one operand plane:
+//   * waves 4-7 ONLY produce: index window three batches ahead, rows two batches ahead (two register sets), stage write
+//     into the free one of TWO stage buffers (swizzled, no padding: conv_ws.hpp StageLayout);
+//   * waves 0-3 ONLY multiply, NC / 4 columns each: every LDS operation of a batch is inline asm in a fixed order with
+//     counted waits (consume_batch_ws), weights of the next batch requested behind the first operand reads;
+//   * ONE barrier per batch separates the two streams; wave w and w + 4 share a SIMD (matrix stream at priority 2).
+// Same plan, same packed weights (k_pack_weights_bf16: the image is the MFMA A operand either way), same sums in the
+// same order as k_conv_tile_bf16: bit-identical output (tests/test_gpu_bf16.py).  Batch-norm statistics of the tile in
+// the epilogue as there.  Not covered (k_conv_tile_bf16 keeps them): multi-offset batch fusion for sparse maps, split-K,
+// 256-channel chunks, 32-column slabs, source channels that are no multiple of the chunk, 64-bit gather offsets.
+// Reference: src/convolution_kernel.cu:320-496 (one gather-GEMM-scatter launch per kernel offset).
+#include "conv_common.hpp"
+#include "conv_ws.hpp"
+
+namespace me {
+
+// accumulator tile + TWO stage buffers (one plane + the target indices of 64 rows each)
+__host__ __device__ constexpr int conv_bf16_ws_lds(int nc, int kc, int tile_rows) {
+  return (tile_rows + 1) * (nc + kAccPad) * 4 + 2 * ME_MAX_BATCH_GROUPS * 16 * (x3_stage_ld(kc) * 2 + 4);
+}
+
+// DEPTH: register sets of gathered rows in flight per producer thread — the rows of batch x + DEPTH are requested while
+// batch x is staged.  A batch lasts 1,500 - 2,000 cycles here and a miss to HBM under load about as long: two sets
+// (the fp32 kernel's pipeline, whose batches last twice as long) leave the producers waiting for rows.
+template <int NC, int KC, int DEPTH>
+__global__ __launch_bounds__(512, 1) void k_conv_tile_bf16_ws(
+    const __bf16 *__restrict__ src, int c_src, const bf16x8 *__restrict__ wp, int c_dst,
+    const int32_t *__restrict__ plan_src, const int32_t *__restrict__ plan_dst,
+    const int32_t *__restrict__ batch_desc, const int32_t *__restrict__ tile_bptr,
+    const int32_t *__restrict__ order, __bf16 *__restrict__ dst, int64_t n_tgt, int tile_rows,
+    float *__restrict__ stat_mean, float *__restrict__ stat_m2) {
+  typedef int i32x2 __attribute__((ext_vector_type(2)));
+  typedef StageLayout<KC> SL;
+  static_assert(NC == 64 || NC == 128, "multiplier waves of 16 or 32 columns");
+  constexpr int NCW = 4;               // multiplier waves
+  constexpr int CB = NC / (16 * NCW);  // 16-column blocks per multiplier wave
+  constexpr int NTP = 256;             // producer threads (four waves)
+  constexpr int NT = NCW * 64 + NTP;
+  constexpr int WAVES = NT / 64;
+  constexpr int LD = SL::kLd;
+  constexpr int ACC_LD = NC + kAccPad;
+  constexpr int KS = KC / 32;
+  constexpr int F8 = KC / 8;           // 16-byte pieces per gathered row
+  constexpr int CAP = ME_MAX_BATCH_GROUPS * 16;
+  constexpr int ITER = (CAP * F8 + NTP - 1) / NTP;
+  constexpr int PLANE = CAP * LD;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *s_acc = reinterpret_cast<float *>(smem);                              // [(tile_rows + 1) x ACC_LD]
+  __bf16 *s_a = reinterpret_cast<__bf16 *>(s_acc + (tile_rows + 1) * ACC_LD);  // [2][64 x LD]
+  int32_t *s_dst = reinterpret_cast<int32_t *>(s_a + 2 * PLANE);               // [2][64]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15;
+  const int q = lane >> 4;
+  const int tile = tile_bptr[gridDim.x + 1 + blockIdx.x];   // heaviest-first dispatch order (me_plan_build)
+  const int col_base = blockIdx.y * NC;
+  const int nchunks = c_src / KC;                           // (whole chunks: host-checked)
+  const int ncb = (c_dst + 15) / 16;
+
+  for (int x = tid; x < (tile_rows + 1) * ACC_LD / 4; x += NT)
+    reinterpret_cast<f32x4 *>(s_acc)[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int ORD = (ME_MAX_TILE_ROWS + NT - 1) / NT;
+  int32_t my_ord[ORD];
+#pragma unroll
+  for (int j = 0; j < ORD; ++j) {
+    const int r = j * NT + tid;
+    my_ord[j] = (order != nullptr && r < tile_rows && (int64_t)tile * tile_rows + r < n_tgt)
+                    ? order[(int64_t)tile * tile_rows + r] : 0;
+  }
+
+  const int b0 = tile_bptr[tile];
+  const int nb = tile_bptr[tile + 1] - b0;
+  const int n_it = nb * nchunks;     // chunk-major, as k_conv_tile_bf16 walks them
+  struct Desc {
+    int chunk, g0, ng, k;
+  };
+  auto locate = [&](int it) {
+    int r = min(it, n_it - 1);
+    Desc d;
+    d.chunk = 0;
+    while (r >= nb) {
+      r -= nb;
+      ++d.chunk;
+    }
+    const i32x2 v = *reinterpret_cast<const i32x2 *>(batch_desc + 2 * (int64_t)(b0 + r));
+    d.g0 = v.x;
+    d.ng = v.y & 255;
+    d.k = (int)((uint32_t)v.y >> 8);
+    return d;
+  };
+
+  if (n_it > 0 && wave >= NCW) {
+    // ------------------------------------------------ producer waves ------------------------------------------------
+    const int ptid = tid - NCW * 64;
+    bf16x8 stage[DEPTH][ITER];
+    int32_t dstv[DEPTH];
+    int32_t sidx[2][ITER];
+    // the 64-entry index window of a batch is read to its end (the plan is followed by 64 readable entries); slots
+    // behind the batch's own groups and padding slots (-1) gather row 0: nobody multiplies the former, the products of
+    // the latter land in the dummy accumulator row
+    auto load_sidx = [&](const Desc &d, int32_t (&sx)[ITER]) {
+      const char *pb = reinterpret_cast<const char *>(plan_src + (int64_t)d.g0 * 16);
+#pragma unroll
+      for (int j = 0; j < ITER; ++j)
+        sx[j] = *reinterpret_cast<const int32_t *>(pb + (unsigned)(min((j * NTP + ptid) / F8, CAP - 1) * 4));
+    };
+    const char *srcb = reinterpret_cast<const char *>(src);
+    const unsigned row_bytes = (unsigned)c_src * 2u;
+    auto gather = [&](const Desc &d, const int32_t (&sx)[ITER], bf16x8 (&st)[ITER], int32_t &dv) {
+      const int c0 = d.chunk * KC;
+      dv = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(plan_dst + (int64_t)d.g0 * 16) +
+                                             (unsigned)(min(ptid, CAP - 1) * 4));
+#pragma unroll
+      for (int j = 0; j < ITER; ++j) {
+        const int idx = j * NTP + ptid;
+        const int ch = c0 + (idx % F8) * 8;
+        const int sr = idx / F8 < d.ng * 16 ? max(sx[j], 0) : 0;
+        st[j] = *reinterpret_cast<const bf16x8 *>(srcb + (__umul24((unsigned)sr, row_bytes) + (unsigned)ch * 2u));
+      }
+    };
+    auto write_stage = [&](const bf16x8 (&st)[ITER], int32_t dv, int buf) {
+      __bf16 *base = s_a + buf * PLANE;
+#pragma unroll
+      for (int j = 0; j < ITER; ++j) {
+        const int idx = j * NTP + ptid;
+        const int r = idx / F8;
+        if (ITER * NTP == CAP * F8 || r < CAP) *reinterpret_cast<bf16x8 *>(base + SL::off(r, idx % F8)) = st[j];
+      }
+      if (ptid < CAP) s_dst[buf * CAP + ptid] = dv;
+    };
+    // produce(x): store batch x (register set x % DEPTH) into buffer x & 1, request the indices of batch x + DEPTH + 1 and,
+    // with the indices requested one step ago, the rows of batch x + DEPTH into the set just stored
+    static_assert(DEPTH == 2 || DEPTH == 4, "register sets: the loop is unrolled by DEPTH, buffers alternate");
+    Desc d0 = locate(DEPTH), d1 = locate(DEPTH + 1), d2 = locate(DEPTH + 2);   // batches x + DEPTH, + 1, + 2 of the next produce
+    auto produce = [&](int x, auto set_) {
+      constexpr int SET = decltype(set_)::value;     // = x % DEPTH
+      write_stage(stage[SET], dstv[SET], SET & 1);
+      load_sidx(d1, sidx[(SET + 1) & 1]);
+      gather(d0, sidx[SET & 1], stage[SET], dstv[SET]);
+      d0 = d1;
+      d1 = d2;
+      d2 = locate(x + DEPTH + 3);
+    };
+    {
+      // prologue: the first DEPTH batches two at a time (two index sets), then the indices of batch DEPTH
+#pragma unroll
+      for (int j = 0; j < DEPTH; j += 2) {
+        const Desc da = locate(j), db = locate(j + 1);
+        load_sidx(da, sidx[0]);
+        load_sidx(db, sidx[1]);
+        gather(da, sidx[0], stage[j], dstv[j]);
+        gather(db, sidx[1], stage[j + 1], dstv[j + 1]);
+      }
+      load_sidx(d0, sidx[0]);
+      produce(0, std::integral_constant<int, 0>{});   // batch 0 -> buffer 0
+    }
+    __syncthreads();
+    // iteration it: batch it + 1 is staged while batch it is multiplied
+    int it = 0;
+    for (; it + DEPTH <= n_it; it += DEPTH) {
+      produce(it + 1, std::integral_constant<int, 1 % DEPTH>{});
+      __syncthreads();
+      produce(it + 2, std::integral_constant<int, 2 % DEPTH>{});
+      __syncthreads();
+      if constexpr (DEPTH == 4) {
+        produce(it + 3, std::integral_constant<int, 3>{});
+        __syncthreads();
+        produce(it + 4, std::integral_constant<int, 0>{});
+        __syncthreads();
+      }
+    }
+    if (it < n_it) {
+      produce(it + 1, std::integral_constant<int, 1 % DEPTH>{});
+      __syncthreads();
+      ++it;
+    }
+    if constexpr (DEPTH == 4) {
+      if (it < n_it) {
+        produce(it + 1, std::integral_constant<int, 2>{});
+        __syncthreads();
+        ++it;
+      }
+      if (it < n_it) {
+        produce(it + 1, std::integral_constant<int, 3>{});
+        __syncthreads();
+        ++it;
+      }
+    }
+  } else if (n_it > 0) {
+    // ----------------------------------------------- multiplier waves -----------------------------------------------
+    __builtin_amdgcn_s_setprio(2);   // (the matrix stream wins the issue arbitration against the producer wave of its SIMD)
+    const int cbi0 = col_base / 16 + wave * CB;
+    bf16x8 w[2][CB][1][KS];
+    auto load_w = [&](const Desc &d, bf16x8 (&wd)[CB][1][KS]) {
+#pragma unroll
+      for (int c = 0; c < CB; ++c) {
+        const bf16x8 *p = wp + ((((int64_t)d.k * nchunks + d.chunk) * ncb + min(cbi0 + c, ncb - 1)) * KS) * 64 + lane;
+#pragma unroll
+        for (int v = 0; v < KS; ++v) wd[c][0][v] = p[v * 64];
+      }
+    };
+    int pofs[KS];
+#pragma unroll
+    for (int sx = 0; sx < KS; ++sx) pofs[sx] = ((sx * 4 + q) ^ SL::swz(i16)) * 8;
+    auto multiply = [&](const Desc &d, const bf16x8 (&wc)[CB][1][KS], int buf, auto &&next_w) {
+      const __bf16 *rowp = s_a + buf * PLANE + i16 * LD;
+      const int32_t *dstp = s_dst + buf * CAP + i16;
+      float *accp = &s_acc[wave * CB * 16 + q * 4];
+      if (d.ng >= 4) consume_batch_ws<2, 2, CB, KC, 1>(rowp, pofs, wc, dstp, accp, ACC_LD, next_w);
+      else if (d.ng == 3) consume_batch_ws<2, 1, CB, KC, 1>(rowp, pofs, wc, dstp, accp, ACC_LD, next_w);
+      else if (d.ng == 2) consume_batch_ws<2, 0, CB, KC, 1>(rowp, pofs, wc, dstp, accp, ACC_LD, next_w);
+      else consume_batch_ws<1, 0, CB, KC, 1>(rowp, pofs, wc, dstp, accp, ACC_LD, next_w);
+    };
+    Desc dA = locate(0), dB = locate(1);
+    load_w(dA, w[0]);
+    __syncthreads();                      // batch 0 is staged
+    auto iteration = [&](int it, int P, bf16x8 (&w_cu)[CB][1][KS], bf16x8 (&w_nx)[CB][1][KS]) {
+      multiply(dA, w_cu, P, [&]() { load_w(dB, w_nx); });
+      __syncthreads();
+      dA = dB;
+      dB = locate(it + 2);
+    };
+    int it = 0;
+    for (; it + 1 < n_it; it += 2) {
+      iteration(it, 0, w[0], w[1]);
+      iteration(it + 1, 1, w[1], w[0]);
+    }
+    if (it < n_it) iteration(it, 0, w[0], w[1]);
+    __builtin_amdgcn_s_setprio(0);
+  } else {
+    __syncthreads();
+  }
+
+  // ---- epilogue: every target row of the tile is written exactly once, rounded to bf16 (RNE); the tile's batch-norm
+  // statistics ride along (see k_conv_tile_bf16: same arithmetic, this kernel's thread count) ----
+  const int64_t row0 = (int64_t)tile * tile_rows;
+  const int rows_here = (int)min((int64_t)tile_rows, n_tgt - row0);
+  const bool vec_out = (c_dst % 4) == 0;
+  int32_t *s_ord = reinterpret_cast<int32_t *>(s_a);   // (the stage buffers are free now)
+  if (order != nullptr) {
+#pragma unroll
+    for (int j = 0; j < ORD; ++j)
+      if (j * NT + tid < tile_rows) s_ord[j * NT + tid] = my_ord[j];
+    __syncthreads();
+  }
+  constexpr int G4 = NC / 4;                       // threads per tile row = four-column groups
+  const bool do_stats = stat_mean != nullptr;      // uniform
+  float st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+  if (do_stats) {
+    const f32x4 v0 = *reinterpret_cast<const f32x4 *>(&s_acc[(tid % G4) * 4]);   // row 0 of the tile: the shift
+#pragma unroll
+    for (int t = 0; t < 4; ++t) sh[t] = (float)(__bf16)v0[t];
+  }
+  for (int x = tid; x < tile_rows * NC / 4; x += NT) {
+    const int row = x / G4;
+    const int c4 = x % G4;
+    const int cc = col_base + c4 * 4;
+    if (row < rows_here && (cc < c_dst || do_stats)) {
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(&s_acc[row * ACC_LD + c4 * 4]);
+      const bf16x4 vb = bf16x4{(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+      if (do_stats) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float d = (float)vb[t] - sh[t];
+          st1[t] += d;
+          st2[t] = fmaf(d, d, st2[t]);
+        }
+      }
+      if (cc < c_dst) {
+        const int64_t grow = order ? (int64_t)s_ord[row] : row0 + row;
+        __bf16 *o = dst + grow * c_dst + cc;
+        if (vec_out) {
+          *reinterpret_cast<bf16x4 *>(o) = vb;
+        } else {
+          o[0] = vb[0];
+          if (cc + 1 < c_dst) o[1] = vb[1];
+          if (cc + 2 < c_dst) o[2] = vb[2];
+          if (cc + 3 < c_dst) o[3] = vb[3];
+        }
+      }
+    }
+  }
+  if (do_stats) {
+    // lanes l, l + G4, l + 2 G4, ... of a wave hold the same four columns
+#pragma unroll
+    for (int off = G4; off < 64; off <<= 1) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        st1[t] += __shfl_xor(st1[t], off, 64);
+        st2[t] += __shfl_xor(st2[t], off, 64);
+      }
+    }
+    __syncthreads();                              // every wave is done with the accumulator tile
+    float *s_st = s_acc + ACC_LD;                 // [WAVES][G4][8] behind row 0 (8 x 32 x 8 floats <= 16 rows)
+    if (lane < G4) {
+      float *wv = s_st + (wave * G4 + lane) * 8;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        wv[t] = st1[t];
+        wv[4 + t] = st2[t];
+      }
+    }
+    __syncthreads();
+    if (tid < NC && col_base + tid < c_dst) {
+      const int c4 = tid >> 2, t = tid & 3;
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < WAVES; ++wv) {
+        a += s_st[(wv * G4 + c4) * 8 + t];
+        b += s_st[(wv * G4 + c4) * 8 + 4 + t];
+      }
+      const float shift = (float)(__bf16)s_acc[tid];
+      const float cnt = (float)rows_here, m = a / cnt;
+      stat_mean[(int64_t)tile * c_dst + col_base + tid] = shift + m;
+      stat_m2[(int64_t)tile * c_dst + col_base + tid] = fmaxf(b - a * m, 0.f);
+    }
+  }
+}
+
+// ---- launch (called by conv_bf16.hip's dispatcher) -------------------------------------------------------------------
+bool conv_bf16_ws_shape(int nc, int kc) { return (nc == 64 || nc == 128) && (kc == 32 || kc == 64 || kc == 96 || kc == 128); }
+
+int conv_bf16_ws_lds_bytes(int nc, int kc, int tile_rows) { return conv_bf16_ws_lds(nc, kc, tile_rows); }
+
+int g_bf16_ws_depth = 4;   // me_debug_set_bf16_ws_depth: 2 | 4 register sets of rows in flight
+
+template <int NC, int KC>
+static int launch_ws(const __bf16 *src, int c_src, const bf16x8 *wp, int c_dst, int slabs, const int32_t *plan_src,
+                     const int32_t *plan_dst, const int32_t *batch_desc, const int32_t *tile_bptr, const int32_t *order,
+                     __bf16 *dst, int64_t n_tgt, int tile_rows, hipStream_t stream, float *stat_mean, float *stat_m2) {
+  const int lds = conv_bf16_ws_lds(NC, KC, tile_rows);
+  typedef void (*kernel_t)(const __bf16 *, int, const bf16x8 *, int, const int32_t *, const int32_t *, const int32_t *,
+                           const int32_t *, const int32_t *, __bf16 *, int64_t, int, float *, float *);
+  const bool deep = g_bf16_ws_depth != 2;
+  kernel_t fn = deep ? &k_conv_tile_bf16_ws<NC, KC, 4> : &k_conv_tile_bf16_ws<NC, KC, 2>;
+  static bool attr_set[2] = {false, false};   // per instantiation
+  if (lds > 48 * 1024 && !attr_set[deep]) {
+    ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
+    attr_set[deep] = true;
+  }
+  const dim3 grid((unsigned)ceil_div(n_tgt, tile_rows), (unsigned)slabs);
+  hipLaunchKernelGGL(fn, grid, dim3(512), (size_t)lds, stream, src, c_src, wp, c_dst, plan_src, plan_dst, batch_desc,
+                     tile_bptr, order, dst, n_tgt, tile_rows, stat_mean, stat_m2);
+  ME_LAUNCH_CHECK();
+  return 0;
+}
+
+// -1: the shape / tile is not this kernel's (the caller runs k_conv_tile_bf16)
+int launch_conv_bf16_ws(int nc, int kc, const void *src, int c_src, const void *wp, int c_dst, int slabs,
+                        const int32_t *plan_src, const int32_t *plan_dst, const int32_t *batch_desc,
+                        const int32_t *tile_bptr, const int32_t *order, void *dst, int64_t n_tgt, int tile_rows,
+                        hipStream_t stream, float *stat_mean, float *stat_m2) {
+  if (!conv_bf16_ws_shape(nc, kc) || c_src % kc != 0 || conv_bf16_ws_lds(nc, kc, tile_rows) > kLdsBudget) return -1;
+#define ME_WS(NCV, KCV)                                                                                                     \
+  if (nc == NCV && kc == KCV)                                                                                               \
+  return launch_ws<NCV, KCV>(reinterpret_cast<const __bf16 *>(src), c_src, reinterpret_cast<const bf16x8 *>(wp), c_dst,     \
+                             slabs, plan_src, plan_dst, batch_desc, tile_bptr, order, reinterpret_cast<__bf16 *>(dst), n_tgt, \
+                             tile_rows, stream, stat_mean, stat_m2)
+  ME_WS(64, 32);
+  ME_WS(64, 64);
+  ME_WS(64, 96);
+  ME_WS(64, 128);
+  ME_WS(128, 32);
+  ME_WS(128, 64);
+  ME_WS(128, 96);
+  ME_WS(128, 128);
+#undef ME_WS
+  return -1;
+}
+
+}  // namespace me
+
+extern "C" void me_debug_set_bf16_ws_depth(int depth) { me::g_bf16_ws_depth = depth; }

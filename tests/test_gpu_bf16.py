@@ -22,10 +22,12 @@ def no_split_k():
     from minkowskiengine_amd import _lib
     lib = _lib.load()
     lib.me_debug_set_bf16_splitk(0)
+    lib.me_debug_set_bf16_ws(0)        # (and they compare schedules of k_conv_tile_bf16, not of the wave-specialised kernel)
     try:
         yield
     finally:
         lib.me_debug_set_bf16_splitk(-1)
+        lib.me_debug_set_bf16_ws(-1)
 
 
 def bf16_round(t):
@@ -541,3 +543,86 @@ def test_bf16_tile_order_and_dispatch_do_not_change_a_bit(device, no_split_k, ho
         for got, want, what in zip(res[name], res["rows"], ("forward", "grad_in", "grad_kernel")):
             assert torch.equal(got, want), (name, what)
     assert float(res["rows"][0].float().abs().max()) > 0
+
+
+WS_CASES = [
+    # n, extent, cin, cout, ks, D, stride
+    (6000, 16, 96, 96, 3, 3, 1),       # MinkUNet's widest layers on its largest maps: 96-channel chunks, 64 + 32 columns
+    (5000, 14, 64, 128, 3, 3, 1),      # config 2: one 128-column slab
+    (5000, 14, 128, 64, 3, 3, 1),      # its input gradient shape
+    (4000, 12, 128, 128, 3, 3, 1),
+    (4000, 12, 64, 64, 3, 3, 1),
+    (3000, 12, 192, 128, 3, 3, 1),     # two 96-channel chunks
+    (3000, 12, 384, 256, 3, 3, 1),     # three 128-channel chunks, two slabs
+    (4000, 14, 32, 64, 3, 3, 1),       # one 32-channel step
+    (4000, 14, 128, 96, 3, 3, 1),
+    (3000, 12, 64, 128, 2, 3, 2),      # strided map: targets != sources
+    (2000, 8, 64, 64, 3, 4, 1),        # 4-D
+    (70, 3, 128, 128, 3, 3, 1),        # one tile, a handful of batches
+    (1, 2, 64, 64, 3, 3, 1),
+]
+
+
+@pytest.mark.parametrize("n,extent,cin,cout,ks,D,stride", WS_CASES)
+@pytest.mark.parametrize("spatial", [False, True], ids=["rows", "spatial"])
+def test_bf16_wave_specialised_kernel_is_bit_identical(device, monkeypatch, n, extent, cin, cout, ks, D, stride, spatial):
+    """k_conv_tile_bf16_ws (round 4: producer waves / multiplier waves, two stage buffers, one barrier per batch, counted
+    LDS waits) walks the same plan with the same packed weights and adds in the same order as k_conv_tile_bf16: forward,
+    input gradient and the tile statistics' consumers must see the same bits — on row tiles and spatial tiles, one to
+    three source chunks, one and two column slabs, tiles of one batch."""
+    from minkowskiengine_amd import _lib, backend as MEB
+    lib = _lib.load()
+    monkeypatch.setattr(MEB, "_BF16_FUSE", "0")             # (multi-offset batches stay with k_conv_tile_bf16)
+    monkeypatch.setattr(MEB, "_TILE_ORDER", "spatial" if spatial else "rows")
+    coords = make_cloud(n, extent, D, seed=cin + cout + n, batch=2, negative=True)
+    g = torch.Generator().manual_seed(5)
+    w = (torch.rand(ks ** D, cin, cout, generator=g) - 0.5).to(device)
+    res = {}
+    try:
+        for mode in (0, 1):
+            lib.me_debug_set_bf16_ws(mode)
+            lib.me_debug_set_bf16_splitk(0)
+            mgr = MEB.CoordinateMapManagerGPU_c10()
+            key, _ = mgr.insert_and_map(coords.to(device), [1] * D, "")
+            okey = mgr.stride(key, [stride] * D) if stride > 1 else key
+            km = mgr._kernel_map(key, okey, [ks] * D, [stride] * D, [1] * D, MEB.RegionType.HYPER_CUBE, None, False, False)
+            gx = torch.Generator().manual_seed(6)
+            x = (torch.rand(km.n_in, cin, generator=gx) - 0.5).to(device).bfloat16()
+            gy = (torch.rand(km.n_out, cout, generator=gx) - 0.5).to(device).bfloat16()
+            y = MEB._conv_forward(x, w, km, "mfma")
+            gi = MEB._conv_target(gy, w, km, "in", km.n_in, name="d", transposed=True)
+            res[mode] = (y.clone(), gi.clone())
+    finally:
+        lib.me_debug_set_bf16_ws(-1)
+        lib.me_debug_set_bf16_splitk(-1)
+    assert torch.equal(res[0][0], res[1][0]), "forward"
+    assert torch.equal(res[0][1], res[1][1]), "input gradient"
+    assert torch.isfinite(res[1][0].float()).all() and (n < 10 or float(res[1][0].float().abs().max()) > 0)
+
+
+def test_bf16_wave_specialised_kernel_statistics(device, host_layer):
+    """conv -> batch norm through the module path with the wave-specialised kernel's statistics epilogue: the batch
+    norm's output equals the one computed from a pass over the convolution's output (1e-5 relative: regrouped fp32
+    partial sums), and the convolution's output does not depend on the epilogue."""
+    import minkowskiengine_amd as ME
+    from minkowskiengine_amd import _lib
+    lib = _lib.load()
+    coords = make_cloud(6000, 16, 3, seed=9, batch=2).to(device)
+    feats = (torch.rand(coords.shape[0], 64, generator=torch.Generator().manual_seed(1)) - 0.5).to(device).bfloat16()
+    torch.manual_seed(0)
+    conv = ME.MinkowskiConvolution(64, 128, kernel_size=3, dimension=3).to(device)
+    bn = ME.MinkowskiBatchNorm(128).to(device)
+    out = {}
+    try:
+        for mode in (0, 1):
+            lib.me_debug_set_bf16_ws(mode)
+            bn.bn.reset_running_stats()
+            x = ME.SparseTensor(feats, coords)
+            y = conv(x)
+            z = bn(y)
+            out[mode] = (y.F.clone(), z.F.clone(), bn.bn.running_var.clone())
+    finally:
+        lib.me_debug_set_bf16_ws(-1)
+    assert torch.equal(out[0][0], out[1][0])
+    assert torch.allclose(out[0][1].float(), out[1][1].float(), rtol=2e-2, atol=2e-2)     # bf16 outputs of the norm
+    assert torch.allclose(out[0][2], out[1][2], rtol=1e-4, atol=1e-6)
