@@ -201,6 +201,7 @@ DEBUG_SIGNATURES = {
     "me_debug_set_bf16_deep": (None, [ctypes.c_int]),
     "me_debug_set_bf16_twobuf": (None, [ctypes.c_int]),
     "me_debug_set_bf16_ws": (None, [ctypes.c_int]),
+    "me_debug_set_bf16_ws_fuse": (None, [ctypes.c_int]),
     "me_debug_set_bf16_ws_depth": (None, [ctypes.c_int]),
     "me_debug_set_bf16_offsync": (None, [ctypes.c_int]),
     "me_debug_set_bf16_splitk": (None, [ctypes.c_int]),

@@ -1246,6 +1246,7 @@ int g_bf16_offsync = 0;             // me_debug_set_bf16_offsync: 0 column-split
                                     // kernel where eligible, 2 / 3: the same with its other wave shapes
 int g_bf16_splitk = -1;             // me_debug_set_bf16_splitk: -1 policy, 0 / 1 never, G >= 2: G offset groups where eligible
 int g_bf16_splitk_same_tiles = 0;   // me_debug_set_bf16_splitk_mode: 1 = forced groups keep the unsplit tile height (G x the workgroups)
+int g_bf16_ws_fuse = 0;   // me_debug_set_bf16_ws_fuse: 1 = multi-offset batches (sparse maps) on the wave-specialised kernel too (tuning build)
 int g_bf16_ws = -1;   // me_debug_set_bf16_ws: -1 policy, 0 never, 1 wherever the wave-specialised kernel is instantiated
 constexpr bool kTwoBufDefault = false;
 constexpr int kSplitKMaxTileRows = 48;   // policy: split launches whose unsplit tiles are at most this tall
@@ -1555,6 +1556,7 @@ int64_t me_conv_splitk_workspace_bytes(int64_t n_tgt, int32_t tile_rows, int32_t
 
 void me_debug_set_bf16_twobuf(int mode) { g_bf16_twobuf = mode; }
 void me_debug_set_bf16_ws(int mode) { g_bf16_ws = mode; }
+void me_debug_set_bf16_ws_fuse(int mode) { g_bf16_ws_fuse = mode; }
 void me_debug_set_bf16_offsync(int mode) {
 #ifdef ME_DEBUG_VARIANTS
   g_bf16_offsync = mode;
@@ -1652,10 +1654,10 @@ static int conv_target_bf16(const uint16_t *src_, int64_t n_src, int32_t c_src, 
 #endif
   const ConvVariantBf16 v = conv_variant_bf16(c_src, c_dst);
   // the wave-specialised kernel (conv_bf16_ws.hip) wherever it is instantiated and the launch needs none of the things
-  // it does not do: multi-offset batches (sparse maps), split-K, 64-bit gather offsets.  Bit-identical output.
-  if (g_bf16_ws != 0 && small && !fuse && split_k <= 1 && g_conv_variant != 7) {
+  // it does not do: split-K, 64-bit gather offsets.  Bit-identical output.
+  if (g_bf16_ws != 0 && small && split_k <= 1 && g_conv_variant != 7 && (!fuse || g_bf16_ws_fuse != 0)) {
     const int rc = launch_conv_bf16_ws(v.nc, v.kc, src, c_src, wp, c_dst, v.slabs, plan_src, plan_dst, batch_desc,
-                                       tile_bptr, order, dst, n_tgt, tile_rows, stream, stat_mean, stat_m2);
+                                       tile_bptr, order, dst, n_tgt, tile_rows, stream, stat_mean, stat_m2, fuse);
     if (rc != -1) return rc;
   }
 #define ME_CONV_CASE(NCV, KCV)                                                                                   \

@@ -30,7 +30,15 @@ __host__ __device__ constexpr int conv_bf16_ws_lds(int nc, int kc, int tile_rows
 // DEPTH: register sets of gathered rows in flight per producer thread — the rows of batch x + DEPTH are requested while
 // batch x is staged.  A batch lasts 1,500 - 2,000 cycles here and a miss to HBM under load about as long: two sets
 // (the fp32 kernel's pipeline, whose batches last twice as long) leave the producers waiting for rows.
-template <int NC, int KC, int DEPTH>
+//
+// FUSE (sparse maps, the hosts' density rule): runs of single-group batches of consecutive offsets — what the plan of a
+// sparse map consists of — are staged and multiplied together, up to MAXSUB offsets per barrier, each group with its own
+// offset's weights (consume_super_ws); producers and multipliers walk the same super-batch sequence off the batch
+// descriptors.  Same sums in the same order: bit-identical to the unfused launch.  MEASURED SLOWER than k_conv_tile_bf16's
+// fused launch (96 -> 96 on 200k voxels, 8.7 pairs per item: 178 us against 92): one eight-wave workgroup per CU and
+// super-batches of two offsets do not beat three four-wave workgroups there.  Instantiated in the tuning build only
+// (-DME_DEBUG_VARIANTS, me_debug_set_bf16_ws_fuse(1)); sparse launches stay with k_conv_tile_bf16.
+template <int NC, int KC, int DEPTH, bool FUSE = false>
 __global__ __launch_bounds__(512, 1) void k_conv_tile_bf16_ws(
     const __bf16 *__restrict__ src, int c_src, const bf16x8 *__restrict__ wp, int c_dst,
     const int32_t *__restrict__ plan_src, const int32_t *__restrict__ plan_dst,
@@ -100,6 +108,50 @@ __global__ __launch_bounds__(512, 1) void k_conv_tile_bf16_ws(
     return d;
   };
 
+  // super-batch walker (FUSE): the next super-batch of the tile, or nsub = 0 behind the last one; every wave walks the
+  // same sequence.  MAXSUB offsets per super-batch while their weights fit the registers of a multiplier wave.
+  constexpr int MAXSUB = !FUSE ? 1 : (KS <= 2 ? 4 : 2);
+  struct Super {
+    int chunk, g0, ng, nsub;
+    int k[MAXSUB];
+  };
+  int cur_chunk = 0, cur_r = 0;
+  auto next_super = [&]() {
+    Super sb;
+    const bool valid = cur_chunk < nchunks && nb > 0;
+    const int r = valid ? cur_r : max(nb - 1, 0);
+    sb.chunk = valid ? cur_chunk : max(nchunks - 1, 0);
+    const int avail = valid ? nb - cur_r : 1;
+    i32x2 dd[MAXSUB];
+#pragma unroll
+    for (int j = 0; j < MAXSUB; ++j)   // (descriptors behind the tile's last batch are readable: me_plan_max_groups)
+      dd[j] = *reinterpret_cast<const i32x2 *>(batch_desc + 2 * (int64_t)(b0 + r + j));
+    sb.g0 = dd[0].x;
+    sb.ng = 0;
+    sb.nsub = 0;
+#pragma unroll
+    for (int j = 0; j < MAXSUB; ++j) {
+      const int g = dd[j].y & 255;
+      // (only single-group batches are fused: group r <-> sub-batch r)
+      const bool take = j == 0 || (sb.nsub == j && j < avail && sb.ng == j && g == 1);
+      sb.k[j] = take ? (int)((uint32_t)dd[j].y >> 8) : sb.k[j > 0 ? j - 1 : 0];
+      if (take) {
+        sb.ng += g;
+        sb.nsub = j + 1;
+      }
+    }
+    if (valid) {
+      cur_r += sb.nsub;
+      if (cur_r >= nb) {
+        cur_r = 0;
+        ++cur_chunk;
+      }
+    } else {
+      sb.nsub = 0;
+    }
+    return sb;
+  };
+
   if (n_it > 0 && wave >= NCW) {
     // ------------------------------------------------ producer waves ------------------------------------------------
     const int ptid = tid - NCW * 64;
@@ -109,7 +161,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_tile_bf16_ws(
     // the 64-entry index window of a batch is read to its end (the plan is followed by 64 readable entries); slots
     // behind the batch's own groups and padding slots (-1) gather row 0: nobody multiplies the former, the products of
     // the latter land in the dummy accumulator row
-    auto load_sidx = [&](const Desc &d, int32_t (&sx)[ITER]) {
+    auto load_sidx = [&](const auto &d, int32_t (&sx)[ITER]) {
       const char *pb = reinterpret_cast<const char *>(plan_src + (int64_t)d.g0 * 16);
 #pragma unroll
       for (int j = 0; j < ITER; ++j)
@@ -117,7 +169,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_tile_bf16_ws(
     };
     const char *srcb = reinterpret_cast<const char *>(src);
     const unsigned row_bytes = (unsigned)c_src * 2u;
-    auto gather = [&](const Desc &d, const int32_t (&sx)[ITER], bf16x8 (&st)[ITER], int32_t &dv) {
+    auto gather = [&](const auto &d, const int32_t (&sx)[ITER], bf16x8 (&st)[ITER], int32_t &dv) {
       const int c0 = d.chunk * KC;
       dv = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(plan_dst + (int64_t)d.g0 * 16) +
                                              (unsigned)(min(ptid, CAP - 1) * 4));
@@ -139,63 +191,115 @@ __global__ __launch_bounds__(512, 1) void k_conv_tile_bf16_ws(
       }
       if (ptid < CAP) s_dst[buf * CAP + ptid] = dv;
     };
-    // produce(x): store batch x (register set x % DEPTH) into buffer x & 1, request the indices of batch x + DEPTH + 1 and,
-    // with the indices requested one step ago, the rows of batch x + DEPTH into the set just stored
     static_assert(DEPTH == 2 || DEPTH == 4, "register sets: the loop is unrolled by DEPTH, buffers alternate");
-    Desc d0 = locate(DEPTH), d1 = locate(DEPTH + 1), d2 = locate(DEPTH + 2);   // batches x + DEPTH, + 1, + 2 of the next produce
-    auto produce = [&](int x, auto set_) {
-      constexpr int SET = decltype(set_)::value;     // = x % DEPTH
-      write_stage(stage[SET], dstv[SET], SET & 1);
-      load_sidx(d1, sidx[(SET + 1) & 1]);
-      gather(d0, sidx[SET & 1], stage[SET], dstv[SET]);
-      d0 = d1;
-      d1 = d2;
-      d2 = locate(x + DEPTH + 3);
-    };
-    {
-      // prologue: the first DEPTH batches two at a time (two index sets), then the indices of batch DEPTH
+    if constexpr (!FUSE) {
+      // produce(x): store batch x (register set x % DEPTH) into buffer x & 1, request the indices of batch x + DEPTH + 1 and,
+      // with the indices requested one step ago, the rows of batch x + DEPTH into the set just stored
+      Desc d0 = locate(DEPTH), d1 = locate(DEPTH + 1), d2 = locate(DEPTH + 2);   // batches x + DEPTH, + 1, + 2 of the next produce
+      auto produce = [&](int x, auto set_) {
+        constexpr int SET = decltype(set_)::value;     // = x % DEPTH
+        write_stage(stage[SET], dstv[SET], SET & 1);
+        load_sidx(d1, sidx[(SET + 1) & 1]);
+        gather(d0, sidx[SET & 1], stage[SET], dstv[SET]);
+        d0 = d1;
+        d1 = d2;
+        d2 = locate(x + DEPTH + 3);
+      };
+      {
+        // prologue: the first DEPTH batches two at a time (two index sets), then the indices of batch DEPTH
+#pragma unroll
+        for (int j = 0; j < DEPTH; j += 2) {
+          const Desc da = locate(j), db = locate(j + 1);
+          load_sidx(da, sidx[0]);
+          load_sidx(db, sidx[1]);
+          gather(da, sidx[0], stage[j], dstv[j]);
+          gather(db, sidx[1], stage[j + 1], dstv[j + 1]);
+        }
+        load_sidx(d0, sidx[0]);
+        produce(0, std::integral_constant<int, 0>{});   // batch 0 -> buffer 0
+      }
+      __syncthreads();
+      // iteration it: batch it + 1 is staged while batch it is multiplied
+      int it = 0;
+      for (; it + DEPTH <= n_it; it += DEPTH) {
+        produce(it + 1, std::integral_constant<int, 1 % DEPTH>{});
+        __syncthreads();
+        produce(it + 2, std::integral_constant<int, 2 % DEPTH>{});
+        __syncthreads();
+        if constexpr (DEPTH == 4) {
+          produce(it + 3, std::integral_constant<int, 3>{});
+          __syncthreads();
+          produce(it + 4, std::integral_constant<int, 0>{});
+          __syncthreads();
+        }
+      }
+      if (it < n_it) {
+        produce(it + 1, std::integral_constant<int, 1 % DEPTH>{});
+        __syncthreads();
+        ++it;
+      }
+      if constexpr (DEPTH == 4) {
+        if (it < n_it) {
+          produce(it + 1, std::integral_constant<int, 2>{});
+          __syncthreads();
+          ++it;
+        }
+        if (it < n_it) {
+          produce(it + 1, std::integral_constant<int, 3>{});
+          __syncthreads();
+          ++it;
+        }
+      }
+    } else {
+      // the same pipeline over super-batches: d0 / d1 / d2 are the super-batches x + DEPTH, + 1, + 2 of the next produce.
+      // Bit j of `live` says whether super-batch it + j exists (it = the one the multipliers are at): the loop ends with
+      // theirs.  produce() walks one super-batch further and records it at bit `at`.
+      Super first[DEPTH];
+      unsigned live = 0u;
+#pragma unroll
+      for (int j = 0; j < DEPTH; ++j) {
+        first[j] = next_super();
+        live |= (first[j].nsub > 0 ? 1u : 0u) << j;
+      }
+      Super d0 = next_super(), d1 = next_super(), d2 = next_super();
+      live |= (d0.nsub > 0 ? 1u : 0u) << DEPTH;
+      live |= (d1.nsub > 0 ? 1u : 0u) << (DEPTH + 1);
+      live |= (d2.nsub > 0 ? 1u : 0u) << (DEPTH + 2);
+      auto produce = [&](auto set_, int at) {
+        constexpr int SET = decltype(set_)::value;
+        write_stage(stage[SET], dstv[SET], SET & 1);
+        load_sidx(d1, sidx[(SET + 1) & 1]);
+        gather(d0, sidx[SET & 1], stage[SET], dstv[SET]);
+        d0 = d1;
+        d1 = d2;
+        d2 = next_super();
+        live |= (d2.nsub > 0 ? 1u : 0u) << at;
+      };
 #pragma unroll
       for (int j = 0; j < DEPTH; j += 2) {
-        const Desc da = locate(j), db = locate(j + 1);
-        load_sidx(da, sidx[0]);
-        load_sidx(db, sidx[1]);
-        gather(da, sidx[0], stage[j], dstv[j]);
-        gather(db, sidx[1], stage[j + 1], dstv[j + 1]);
+        load_sidx(first[j], sidx[0]);
+        load_sidx(first[j + 1], sidx[1]);
+        gather(first[j], sidx[0], stage[j], dstv[j]);
+        gather(first[j + 1], sidx[1], stage[j + 1], dstv[j + 1]);
       }
       load_sidx(d0, sidx[0]);
-      produce(0, std::integral_constant<int, 0>{});   // batch 0 -> buffer 0
-    }
-    __syncthreads();
-    // iteration it: batch it + 1 is staged while batch it is multiplied
-    int it = 0;
-    for (; it + DEPTH <= n_it; it += DEPTH) {
-      produce(it + 1, std::integral_constant<int, 1 % DEPTH>{});
+      produce(std::integral_constant<int, 0>{}, DEPTH + 3);   // super-batch 0 -> buffer 0; walks to super-batch DEPTH + 3
       __syncthreads();
-      produce(it + 2, std::integral_constant<int, 2 % DEPTH>{});
-      __syncthreads();
-      if constexpr (DEPTH == 4) {
-        produce(it + 3, std::integral_constant<int, 3>{});
-        __syncthreads();
-        produce(it + 4, std::integral_constant<int, 0>{});
-        __syncthreads();
+      // iteration it (while super-batch it exists): super-batch it + 1 is staged while super-batch it is multiplied
+#define ME_WS_STEP(SETV)                                              \
+  if (!(live & 1u)) break;                                            \
+  produce(std::integral_constant<int, SETV>{}, DEPTH + 4);            \
+  __syncthreads();                                                    \
+  live >>= 1;
+      for (;;) {
+        ME_WS_STEP(1 % DEPTH)
+        ME_WS_STEP(2 % DEPTH)
+        if constexpr (DEPTH == 4) {
+          ME_WS_STEP(3)
+          ME_WS_STEP(0)
+        }
       }
-    }
-    if (it < n_it) {
-      produce(it + 1, std::integral_constant<int, 1 % DEPTH>{});
-      __syncthreads();
-      ++it;
-    }
-    if constexpr (DEPTH == 4) {
-      if (it < n_it) {
-        produce(it + 1, std::integral_constant<int, 2>{});
-        __syncthreads();
-        ++it;
-      }
-      if (it < n_it) {
-        produce(it + 1, std::integral_constant<int, 3>{});
-        __syncthreads();
-        ++it;
-      }
+#undef ME_WS_STEP
     }
   } else if (n_it > 0) {
     // ----------------------------------------------- multiplier waves -----------------------------------------------
@@ -222,21 +326,59 @@ __global__ __launch_bounds__(512, 1) void k_conv_tile_bf16_ws(
       else if (d.ng == 2) consume_batch_ws<2, 0, CB, KC, 1>(rowp, pofs, wc, dstp, accp, ACC_LD, next_w);
       else consume_batch_ws<1, 0, CB, KC, 1>(rowp, pofs, wc, dstp, accp, ACC_LD, next_w);
     };
-    Desc dA = locate(0), dB = locate(1);
-    load_w(dA, w[0]);
-    __syncthreads();                      // batch 0 is staged
-    auto iteration = [&](int it, int P, bf16x8 (&w_cu)[CB][1][KS], bf16x8 (&w_nx)[CB][1][KS]) {
-      multiply(dA, w_cu, P, [&]() { load_w(dB, w_nx); });
-      __syncthreads();
-      dA = dB;
-      dB = locate(it + 2);
-    };
-    int it = 0;
-    for (; it + 1 < n_it; it += 2) {
-      iteration(it, 0, w[0], w[1]);
-      iteration(it + 1, 1, w[1], w[0]);
+    if constexpr (!FUSE) {
+      Desc dA = locate(0), dB = locate(1);
+      load_w(dA, w[0]);
+      __syncthreads();                      // batch 0 is staged
+      auto iteration = [&](int it, int P, bf16x8 (&w_cu)[CB][1][KS], bf16x8 (&w_nx)[CB][1][KS]) {
+        multiply(dA, w_cu, P, [&]() { load_w(dB, w_nx); });
+        __syncthreads();
+        dA = dB;
+        dB = locate(it + 2);
+      };
+      int it = 0;
+      for (; it + 1 < n_it; it += 2) {
+        iteration(it, 0, w[0], w[1]);
+        iteration(it + 1, 1, w[1], w[0]);
+      }
+      if (it < n_it) iteration(it, 0, w[0], w[1]);
+    } else {
+      // one weight slice per offset of a super-batch, two register sets: the next super-batch's are requested while this
+      // one is multiplied
+      bf16x8 wf[2][MAXSUB][CB][1][KS];
+      auto load_wf = [&](const Super &sb, bf16x8 (&wd)[MAXSUB][CB][1][KS]) {
+#pragma unroll
+        for (int j = 0; j < MAXSUB; ++j) {
+          if (j == 0 || j < sb.nsub) {     // wave-uniform: a dense batch loads one slice
+#pragma unroll
+            for (int c = 0; c < CB; ++c) {
+              const bf16x8 *p = wp + ((((int64_t)sb.k[j] * nchunks + sb.chunk) * ncb + min(cbi0 + c, ncb - 1)) * KS) * 64 + lane;
+#pragma unroll
+              for (int v = 0; v < KS; ++v) wd[j][c][0][v] = p[v * 64];
+            }
+          }
+        }
+      };
+      Super sA = next_super(), sB = next_super(), sC = next_super();
+      load_wf(sA, wf[0]);
+      __syncthreads();                      // super-batch 0 is staged
+      auto iteration = [&](int P, const bf16x8 (&w_cu)[MAXSUB][CB][1][KS], bf16x8 (&w_nx)[MAXSUB][CB][1][KS]) {
+        const __bf16 *rowp = s_a + P * PLANE + i16 * LD;
+        const int32_t *dstp = s_dst + P * CAP + i16;
+        float *accp = &s_acc[wave * CB * 16 + q * 4];
+        consume_super_ws<MAXSUB, CB, KC, 1>(rowp, pofs, w_cu, sA.nsub, sA.ng, dstp, accp, ACC_LD, [&]() { load_wf(sB, w_nx); });
+        __syncthreads();
+        sA = sB;
+        sB = sC;
+        sC = next_super();
+      };
+      for (;;) {
+        if (sA.nsub == 0) break;
+        iteration(0, wf[0], wf[1]);
+        if (sA.nsub == 0) break;
+        iteration(1, wf[1], wf[0]);
+      }
     }
-    if (it < n_it) iteration(it, 0, w[0], w[1]);
     __builtin_amdgcn_s_setprio(0);
   } else {
     __syncthreads();
@@ -338,16 +480,22 @@ int g_bf16_ws_depth = 4;   // me_debug_set_bf16_ws_depth: 2 | 4 register sets of
 template <int NC, int KC>
 static int launch_ws(const __bf16 *src, int c_src, const bf16x8 *wp, int c_dst, int slabs, const int32_t *plan_src,
                      const int32_t *plan_dst, const int32_t *batch_desc, const int32_t *tile_bptr, const int32_t *order,
-                     __bf16 *dst, int64_t n_tgt, int tile_rows, hipStream_t stream, float *stat_mean, float *stat_m2) {
+                     __bf16 *dst, int64_t n_tgt, int tile_rows, hipStream_t stream, float *stat_mean, float *stat_m2, bool fuse) {
   const int lds = conv_bf16_ws_lds(NC, KC, tile_rows);
   typedef void (*kernel_t)(const __bf16 *, int, const bf16x8 *, int, const int32_t *, const int32_t *, const int32_t *,
                            const int32_t *, const int32_t *, __bf16 *, int64_t, int, float *, float *);
   const bool deep = g_bf16_ws_depth != 2;
   kernel_t fn = deep ? &k_conv_tile_bf16_ws<NC, KC, 4> : &k_conv_tile_bf16_ws<NC, KC, 2>;
-  static bool attr_set[2] = {false, false};   // per instantiation
-  if (lds > 48 * 1024 && !attr_set[deep]) {
+#ifdef ME_DEBUG_VARIANTS   // measured 2x SLOWER than k_conv_tile_bf16's fused launch on MinkUNet34C's sparse levels
+  if (fuse) fn = &k_conv_tile_bf16_ws<NC, KC, 4, true>;   // (profiles/r04_layers_minkunet34c_bf16_ws_fuse.log): tuning build only
+#else
+  if (fuse) return -1;
+#endif
+  static bool attr_set[3] = {false, false, false};   // per instantiation
+  const int which = fuse ? 2 : (deep ? 1 : 0);
+  if (lds > 48 * 1024 && !attr_set[which]) {
     ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
-    attr_set[deep] = true;
+    attr_set[which] = true;
   }
   const dim3 grid((unsigned)ceil_div(n_tgt, tile_rows), (unsigned)slabs);
   hipLaunchKernelGGL(fn, grid, dim3(512), (size_t)lds, stream, src, c_src, wp, c_dst, plan_src, plan_dst, batch_desc,
@@ -360,13 +508,13 @@ static int launch_ws(const __bf16 *src, int c_src, const bf16x8 *wp, int c_dst, 
 int launch_conv_bf16_ws(int nc, int kc, const void *src, int c_src, const void *wp, int c_dst, int slabs,
                         const int32_t *plan_src, const int32_t *plan_dst, const int32_t *batch_desc,
                         const int32_t *tile_bptr, const int32_t *order, void *dst, int64_t n_tgt, int tile_rows,
-                        hipStream_t stream, float *stat_mean, float *stat_m2) {
+                        hipStream_t stream, float *stat_mean, float *stat_m2, bool fuse) {
   if (!conv_bf16_ws_shape(nc, kc) || c_src % kc != 0 || conv_bf16_ws_lds(nc, kc, tile_rows) > kLdsBudget) return -1;
 #define ME_WS(NCV, KCV)                                                                                                     \
   if (nc == NCV && kc == KCV)                                                                                               \
   return launch_ws<NCV, KCV>(reinterpret_cast<const __bf16 *>(src), c_src, reinterpret_cast<const bf16x8 *>(wp), c_dst,     \
                              slabs, plan_src, plan_dst, batch_desc, tile_bptr, order, reinterpret_cast<__bf16 *>(dst), n_tgt, \
-                             tile_rows, stream, stat_mean, stat_m2)
+                             tile_rows, stream, stat_mean, stat_m2, fuse)
   ME_WS(64, 32);
   ME_WS(64, 64);
   ME_WS(64, 96);

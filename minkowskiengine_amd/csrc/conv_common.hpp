@@ -131,6 +131,6 @@ int conv_bf16_ws_lds_bytes(int nc, int kc, int tile_rows);
 int launch_conv_bf16_ws(int nc, int kc, const void *src, int c_src, const void *wp, int c_dst, int slabs,
                         const int32_t *plan_src, const int32_t *plan_dst, const int32_t *batch_desc,
                         const int32_t *tile_bptr, const int32_t *order, void *dst, int64_t n_tgt, int tile_rows,
-                        hipStream_t stream, float *stat_mean, float *stat_m2);
+                        hipStream_t stream, float *stat_mean, float *stat_m2, bool fuse);
 
 }  // namespace me

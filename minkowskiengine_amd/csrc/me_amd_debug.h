@@ -31,6 +31,7 @@ void me_debug_set_bf16_deep(int deep);
 void me_debug_set_bf16_twobuf(int mode);
 // the wave-specialised bf16 tile kernel (conv_bf16_ws.hip): -1 policy (default), 0 never, 1 wherever instantiated
 void me_debug_set_bf16_ws(int mode);
+void me_debug_set_bf16_ws_fuse(int mode);    // 1: multi-offset batches (sparse maps) on the wave-specialised kernel too (tuning build; default 0)
 void me_debug_set_bf16_ws_depth(int depth);   // 2 | 4 register sets of gathered rows per producer thread (default 4)
 /* bf16 forward / dgrad schedule: 0 column-split k_conv_tile_bf16, 1 offset-synchronous k_conv_off_bf16 where eligible
  * (row-split waves, weights through LDS, one barrier per offset; bit-identical results), 2: its other wave shape.

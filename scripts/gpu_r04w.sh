@@ -1,5 +1,21 @@
 #!/bin/bash
+# Round-4 session W: batch fusion in the wave-specialised bf16 kernel — parity, the step, the layer table
 set +e
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-timeout 300 python -m pytest tests/test_gpu_bf16.py tests/test_gpu_norm.py -m gpu -q --timeout 300 2>&1 | tail -1
-timeout 300 python bench.py --cpu-budget 0 --extra-workloads off 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); print(d['value'], d['ms_per_step'])"
+OUT=$PWD/gpurun_out/r04w
+mkdir -p $OUT
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_gpu_bf16.py -x -q -m gpu -k "wave_specialised or oracle" 2>&1 | tail -4 | tee $OUT/pytest_ws.log
+run() {  # name, env...
+  name=$1; shift
+  env "$@" python bench.py --workload minkunet --dtype bf16 --steps 10 --warmup 3 --cpu-budget 0 --pmc off > $OUT/unet_$name.json 2>$OUT/unet_$name.err
+  python - <<PY
+import json
+d = json.loads(open("$OUT/unet_$name.json").read().strip().splitlines()[-1])
+print("$name", d["ms_per_step"])
+PY
+}
+cat > /tmp/nofuse.py <<'PY'
+PY
+run ws_fuse A=1
+ME_AMD_HOST=python python scripts/unet_layers.py > $OUT/layers_ws_fuse.log 2>&1
+head -3 $OUT/layers_ws_fuse.log

@@ -626,3 +626,43 @@ def test_bf16_wave_specialised_kernel_statistics(device, host_layer):
     assert torch.equal(out[0][0], out[1][0])
     assert torch.allclose(out[0][1].float(), out[1][1].float(), rtol=2e-2, atol=2e-2)     # bf16 outputs of the norm
     assert torch.allclose(out[0][2], out[1][2], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("n,extent,cin,cout,ks,D", [(6000, 40, 96, 96, 3, 3), (6000, 40, 128, 96, 3, 3), (5000, 30, 64, 64, 3, 3),
+                                                     (4000, 40, 64, 128, 3, 3), (4000, 30, 32, 64, 3, 3), (3000, 10, 64, 64, 3, 4),
+                                                     (3000, 24, 192, 128, 3, 3), (5000, 16, 96, 96, 3, 3), (40, 12, 64, 64, 3, 3)])
+@pytest.mark.parametrize("spatial", [False, True], ids=["rows", "spatial"])
+def test_bf16_wave_specialised_batch_fusion_is_bit_identical(device, monkeypatch, n, extent, cin, cout, ks, D, spatial):
+    """k_conv_tile_bf16_ws<.., FUSE>: on sparse maps runs of single-group batches of consecutive offsets are staged and
+    multiplied together (up to four offsets per barrier, each group with its own weights), producers and multipliers
+    walking the same super-batch sequence.  Forward and input gradient must equal k_conv_tile_bf16's fused launch bit for
+    bit — sparse and dense maps (where nothing fuses), K = 27 and 81, one and two chunks, one and two slabs."""
+    from minkowskiengine_amd import _lib, backend as MEB
+    lib = _lib.load()
+    if not lib.me_debug_variants_compiled():
+        pytest.skip("measured slower than k_conv_tile_bf16's fused launch: instantiated in a -DME_DEBUG_VARIANTS build only")
+    monkeypatch.setattr(MEB, "_BF16_FUSE", "1")
+    monkeypatch.setattr(MEB, "_TILE_ORDER", "spatial" if spatial else "rows")
+    coords = make_cloud(n, extent, D, seed=cin + cout + n, batch=2, negative=True)
+    g = torch.Generator().manual_seed(5)
+    w = (torch.rand(ks ** D, cin, cout, generator=g) - 0.5).to(device)
+    res = {}
+    try:
+        for mode in (0, 1):
+            lib.me_debug_set_bf16_ws_fuse(mode)
+            lib.me_debug_set_bf16_splitk(0)
+            mgr = MEB.CoordinateMapManagerGPU_c10()
+            key, _ = mgr.insert_and_map(coords.to(device), [1] * D, "")
+            km = mgr._kernel_map(key, key, [ks] * D, [1] * D, [1] * D, MEB.RegionType.HYPER_CUBE, None, False, False)
+            gx = torch.Generator().manual_seed(6)
+            x = (torch.rand(km.n_in, cin, generator=gx) - 0.5).to(device).bfloat16()
+            gy = (torch.rand(km.n_out, cout, generator=gx) - 0.5).to(device).bfloat16()
+            y = MEB._conv_forward(x, w, km, "mfma")
+            gi = MEB._conv_target(gy, w, km, "in", km.n_in, name="d", transposed=True)
+            res[mode] = (y.clone(), gi.clone())
+    finally:
+        lib.me_debug_set_bf16_ws_fuse(0)
+        lib.me_debug_set_bf16_splitk(-1)
+    assert torch.equal(res[0][0], res[1][0]), "forward"
+    assert torch.equal(res[0][1], res[1][1]), "input gradient"
+    assert torch.isfinite(res[1][0].float()).all() and float(res[1][0].float().abs().max()) > 0
