@@ -195,6 +195,7 @@ DEBUG_SIGNATURES = {
     "me_debug_conv_timing_f32x3": (ctypes.c_int, [c_vp, c_i32]),
     "me_debug_set_wgrad_config": (None, [ctypes.c_int, ctypes.c_int]),
     "me_debug_set_wgrad_order": (None, [ctypes.c_int]),
+    "me_debug_set_wgrad_ws": (None, [ctypes.c_int]),
     "me_debug_set_tile_dispatch": (None, [ctypes.c_int]),
     "me_debug_set_wgrad_mb": (None, [ctypes.c_int]),
     "me_debug_set_bf16_shape": (None, [ctypes.c_int, ctypes.c_int]),
@@ -233,6 +234,8 @@ def load():
     # everywhere, ME_AMD_BF16_WS_DEPTH=2 its shallower producer pipeline
     if os.environ.get("ME_AMD_BF16_WS", "") != "":
         lib.me_debug_set_bf16_ws(int(os.environ["ME_AMD_BF16_WS"]))
+    if os.environ.get("ME_AMD_WGRAD_WS", "") != "":
+        lib.me_debug_set_wgrad_ws(int(os.environ["ME_AMD_WGRAD_WS"]))
     if os.environ.get("ME_AMD_BF16_WS_DEPTH", "") != "":
         lib.me_debug_set_bf16_ws_depth(int(os.environ["ME_AMD_BF16_WS_DEPTH"]))
     return lib

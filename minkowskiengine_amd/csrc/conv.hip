@@ -1437,6 +1437,253 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_bf16(const __bf16 *__restrict_
   if (pending >= 0) flush(pending);
 }
 
+#ifdef ME_DEBUG_VARIANTS   // bit-identical and NOT faster (profiles/r04_wgrad_ws_sweep.log): tuning build only
+// =================================================================================================
+// k_wgrad_bf16_ws (round 4): the same weight gradient, wave-specialised
+// =================================================================================================
+// MEASURED: with four row sets (one workgroup per CU) 10 - 50 % slower than k_wgrad_bf16 on every MinkUNet34C layer, with
+// two sets (two workgroups per CU) within +-5 % of it; the step 11.48 -> 12.12 / 11.72 ms.  Unlike the forward kernels,
+// this loop is not waiting on its own latency chain: it gathers two rows per pair (5 - 6 TB/s through the L2s).
+// k_wgrad_bf16 runs its four waves in lock-step — wait for the rows, stage them, request the next, barrier, multiply:
+// 3,500 cycles per 64-pair step for ~250 cycles of MFMAs per SIMD (a MinkUNet34C step spends 2.5 of its 11.6 ms here).
+// As for the forward kernels (conv_bf16_ws.hip): waves 4-7 ONLY produce (pair indices DEPTH + 2 steps ahead, rows DEPTH
+// steps ahead in DEPTH register sets, stage writes into the free one of the two LDS buffers), waves 0-3 ONLY multiply
+// (transposed operand reads + MFMAs of k_wgrad_bf16, flushes at offset boundaries), one barrier per step.  Same pair
+// ranges, same slots, same order of additions inside a range: the partial images — and grad_w after k_wgrad_reduce — are
+// bit-identical to k_wgrad_bf16's.  Producer loads are plain C++ (no MFMAs in those waves for hipcc to sink them under).
+template <int NB, int KSTEPS, int MB, int DEPTH>
+__global__ __launch_bounds__(512, 1) void k_wgrad_bf16_ws(const __bf16 *__restrict__ x, int c_in,
+                                                         const __bf16 *__restrict__ dy, int c_out,
+                                                         const int32_t *__restrict__ in_pairs,
+                                                         const int32_t *__restrict__ out_pairs,
+                                                         const int64_t *__restrict__ koffs, int volume,
+                                                         int64_t n_pairs, int n_ranges, int n_cob,
+                                                         float *__restrict__ partial) {
+  typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+  static_assert(MB == 4 || MB == 8, "input-channel blocks per workgroup");
+  static_assert(DEPTH == 2 || DEPTH == 4, "row register sets (the loop is unrolled by four)");
+  constexpr int CI = 16 * MB;
+  constexpr int XQ = CI / 8;
+  constexpr int SP = 32 * KSTEPS;
+  constexpr int COB = 64 * NB;
+  constexpr int XLD = CI + kWgStepLd;
+  constexpr int DLD = COB + kWgStepLd;
+  constexpr int XP = SP * XQ / 256;      // 16-byte x pieces per producer thread and step
+  constexpr int DP = SP * (COB / 8) / 256;
+  static_assert(SP <= 64 && XP >= 1, "step size");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __bf16 *s_x = reinterpret_cast<__bf16 *>(smem);            // [2][SP][XLD]
+  __bf16 *s_d = s_x + 2 * SP * XLD;                           // [2][SP][DLD]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int range = blockIdx.x;
+  const int ci0 = blockIdx.y * CI;
+  const int cog = blockIdx.z * COB;
+  const int64_t e_lo = n_pairs * range / n_ranges;
+  const int64_t e_hi = n_pairs * (range + 1) / n_ranges;
+  if (e_lo >= e_hi) return;                                   // whole workgroup
+
+  // step cursor: offset k, first pair e, number of pairs cnt (0 = past the end of the range)
+  struct Cur {
+    int k;
+    int64_t e;
+    int cnt;
+  };
+  auto step_count = [&](int k, int64_t e) -> int {
+    if (e >= e_hi) return 0;
+    const int64_t kend = min(koffs[k + 1], e_hi);
+    return (int)min((int64_t)SP, kend - e);
+  };
+  auto first_cur = [&]() {
+    int lo = 0, hi = volume;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (koffs[mid] <= e_lo) lo = mid; else hi = mid;
+    }
+    Cur c;
+    c.k = lo;
+    c.e = e_lo;
+    c.cnt = step_count(c.k, c.e);
+    return c;
+  };
+  auto next_cur = [&](const Cur &c) {
+    Cur n = c;
+    n.e += c.cnt;
+    if (n.e < e_hi) {
+      while (koffs[n.k + 1] <= n.e) ++n.k;
+    }
+    n.cnt = step_count(n.k, n.e);
+    return n;
+  };
+
+  if (wave >= 4) {
+    // ------------------------------------------------ producer waves ------------------------------------------------
+    const int ptid = tid - 256;
+    int32_t pin[4], pout[4];              // pair indices of four steps (lane l: pair e + l)
+    bf16x8 rx[DEPTH][XP], rd[DEPTH][DP];
+    auto load_idx = [&](const Cur &c, int32_t &pi, int32_t &po) {
+      const int64_t ec = min(c.e + lane, n_pairs - 1);        // unconditional load from a valid address
+      pi = in_pairs[ec];
+      po = out_pairs[ec];
+    };
+    auto load_rows = [&](int32_t pi, int32_t po, bf16x8 (&ax)[XP], bf16x8 (&ad)[DP]) {
+#pragma unroll
+      for (int j = 0; j < XP; ++j) {
+        const int idx = j * 256 + ptid;
+        const int row = idx / XQ;
+        const int ch = ci0 + (idx % XQ) * 8;
+        const int32_t r = __shfl(pi, row, 64);
+        ax[j] = *reinterpret_cast<const bf16x8 *>(x + (int64_t)r * c_in + (ch < c_in ? ch : 0));
+      }
+#pragma unroll
+      for (int j = 0; j < DP; ++j) {
+        const int idx = j * 256 + ptid;
+        const int row = idx / (COB / 8);
+        const int ch = cog + (idx % (COB / 8)) * 8;
+        const int32_t r = __shfl(po, row, 64);
+        ad[j] = *reinterpret_cast<const bf16x8 *>(dy + (int64_t)r * c_out + (ch < c_out ? ch : 0));
+      }
+    };
+    auto write_lds = [&](int buf, int cnt, const bf16x8 (&ax)[XP], const bf16x8 (&ad)[DP]) {
+      const bf16x8 zero = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+#pragma unroll
+      for (int j = 0; j < XP; ++j) {
+        const int idx = j * 256 + ptid;
+        const int row = idx / XQ;
+        const int ch = ci0 + (idx % XQ) * 8;
+        const bool ok = row < cnt && ch < c_in;                // pairs beyond the step / channels beyond c_in: zeros
+        *reinterpret_cast<bf16x8 *>(s_x + (buf * SP + row) * XLD + (idx % XQ) * 8) = ok ? ax[j] : zero;
+      }
+#pragma unroll
+      for (int j = 0; j < DP; ++j) {
+        const int idx = j * 256 + ptid;
+        const int row = idx / (COB / 8);
+        const int pc = idx % (COB / 8);
+        const bool ok = row < cnt && cog + pc * 8 < c_out;
+        *reinterpret_cast<bf16x8 *>(s_d + (buf * SP + row) * DLD + pc * 8) = ok ? ad[j] : zero;
+      }
+    };
+    // cursors: cm = the step the multipliers are at, cw = the step staged next (cm + 1), ci = the step whose indices are
+    // requested next (cw + DEPTH + 2)
+    Cur cm = first_cur();
+    Cur ci = cm;
+    // prologue: indices of steps 0 .. DEPTH + 1, rows of steps 0 .. DEPTH - 1
+    Cur pro[DEPTH + 2];
+#pragma unroll
+    for (int j = 0; j < DEPTH + 2; ++j) {
+      pro[j] = ci;
+      ci = next_cur(ci);
+    }
+#pragma unroll
+    for (int j = 0; j < 4 && j < DEPTH + 2; ++j) load_idx(pro[j], pin[j], pout[j]);
+#pragma unroll
+    for (int j = 0; j < DEPTH; ++j) load_rows(pin[j], pout[j], rx[j], rd[j]);
+    if constexpr (DEPTH == 4) {           // (indices of steps 4 and 5 go into the sets of steps 0 and 1, whose rows are requested)
+      load_idx(pro[4], pin[0], pout[0]);
+      load_idx(pro[5], pin[1], pout[1]);
+    }
+    // produce(x), x = 4 n + X: stage step x (row set x % DEPTH) into buffer x & 1, request the rows of step x + DEPTH with
+    // the indices in set (x + DEPTH) % 4 and the indices of step x + DEPTH + 2 into set (x + DEPTH + 2) % 4
+    Cur cw = cm;
+    auto produce = [&](auto x_) {
+      constexpr int X = decltype(x_)::value;
+      constexpr int RS = X % DEPTH, IA = (X + DEPTH) % 4, IB = (X + DEPTH + 2) % 4;
+      write_lds(X & 1, cw.cnt, rx[RS], rd[RS]);
+      load_rows(pin[IA], pout[IA], rx[RS], rd[RS]);
+      load_idx(ci, pin[IB], pout[IB]);
+      ci = next_cur(ci);
+    };
+    produce(std::integral_constant<int, 0>{});   // step 0 -> buffer 0
+    __syncthreads();
+#define ME_WG_STEP(XV)                               \
+  if (cm.cnt == 0) break;                            \
+  cw = next_cur(cm);                                 \
+  produce(std::integral_constant<int, XV>{});        \
+  __syncthreads();                                   \
+  cm = cw;
+    for (;;) {
+      ME_WG_STEP(1)
+      ME_WG_STEP(2)
+      ME_WG_STEP(3)
+      ME_WG_STEP(0)
+    }
+#undef ME_WG_STEP
+  } else {
+    // ----------------------------------------------- multiplier waves -----------------------------------------------
+    __builtin_amdgcn_s_setprio(2);
+    const int i16 = lane & 15, q = lane >> 4;
+    const int cob = blockIdx.z * 4 + wave;                      // this wave's block of 16*NB output channels
+    constexpr int kImage = MB * NB * 4 * 64;
+    const int64_t image_stride = (int64_t)gridDim.y * n_cob * kImage;
+    float *const image0 = partial + ((int64_t)blockIdx.y * n_cob + min(cob, n_cob - 1)) * kImage + lane;
+    f32x4 acc[MB][NB];
+    auto zero_acc = [&]() {
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int n = 0; n < NB; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto flush = [&](int k) {
+      if (cob < n_cob) {
+        float *img = image0 + (int64_t)(range + k) * image_stride;
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+          for (int n = 0; n < NB; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) img[((m * NB + n) * 4 + r) * 64] = acc[m][n][r];
+      }
+    };
+    const int frag_row = 4 * q + (i16 >> 2);
+    const int frag_col = 4 * (i16 & 3);
+    auto multiply = [&](int buf) {
+      const __bf16 *bx = s_x + (buf * SP + frag_row) * XLD + frag_col;
+      const __bf16 *bd = s_d + (buf * SP + frag_row) * DLD + wave * 16 * NB + frag_col;
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        bf16x8 a[MB], b[NB];
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(bx + (ks * 32) * XLD + 16 * m));
+          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(bx + (ks * 32 + 16) * XLD + 16 * m));
+          a[m] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int n = 0; n < NB; ++n) {
+          const bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(bd + (ks * 32) * DLD + 16 * n));
+          const bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4 *)(bd + (ks * 32 + 16) * DLD + 16 * n));
+          b[n] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+          for (int n = 0; n < NB; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m], b[n], acc[m][n], 0, 0, 0);
+      }
+    };
+    Cur cA = first_cur();
+    Cur cB = next_cur(cA);
+    zero_acc();
+    __syncthreads();                      // step 0 is staged
+    int buf = 0;
+    while (cA.cnt > 0) {
+      multiply(buf);
+      if (cB.cnt == 0 || cB.k != cA.k) {  // last step of offset cA.k inside this range
+        flush(cA.k);
+        zero_acc();
+      }
+      __syncthreads();
+      buf ^= 1;
+      cA = cB;
+      cB = next_cur(cB);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  }
+}
+
+#endif  // ME_DEBUG_VARIANTS (k_wgrad_bf16_ws)
+
 // =================================================================================================
 // wgrad of fp32 rows on the bf16 matrix pipe (round 2): k_wgrad_f32x3
 // =================================================================================================
@@ -2271,6 +2518,7 @@ static WgradGeom wgrad_geom(int64_t n_pairs, int64_t volume, int c_in, int c_out
 
 // geometry of the LDS-staged kernels (k_wgrad_bf16, k_wgrad_lds_f32): always four waves side by side along the
 // output channels
+int g_wgrad_ws = 0;   // me_debug_set_wgrad_ws: 0 = k_wgrad_bf16 (default), 1 / 2 = k_wgrad_bf16_ws with four / two row register sets (tuning build)
 int g_wgrad_mb = 0;   // me_debug_set_wgrad_mb: 0 = policy, 4 / 8 = input-channel blocks per workgroup of k_wgrad_bf16
 
 // 128 x 128 blocks where at least two of them stand side by side along the input channels (c_in >= 192): measured per
@@ -2314,6 +2562,20 @@ static int launch_wgrad_bf16(const WgradGeom &g, const __bf16 *x, int c_in, cons
     attr_set = true;
   }
   const dim3 grid((unsigned)g.ranges, (unsigned)g.n_cib, (unsigned)g.gz);
+#ifdef ME_DEBUG_VARIANTS
+  if (g_wgrad_ws != 0) {   // wave-specialised (k_wgrad_bf16_ws): same geometry, slots and sums
+    auto ws = g_wgrad_ws == 2 ? &k_wgrad_bf16_ws<NB, KSTEPS, MB, 2> : &k_wgrad_bf16_ws<NB, KSTEPS, MB, (MB == 8 ? 2 : 4)>;
+    static bool ws_attr[2] = {false, false};
+    if (lds > 32 * 1024 && !ws_attr[g_wgrad_ws == 2]) {
+      ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(ws), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
+      ws_attr[g_wgrad_ws == 2] = true;
+    }
+    hipLaunchKernelGGL(ws, grid, dim3(512), (size_t)lds, stream, x, c_in, dy, c_out, in_pairs, out_pairs, k_offsets_dev,
+                       volume, n_pairs, (int)g.ranges, g.n_cob, partial);
+    ME_LAUNCH_CHECK();
+    return 0;
+  }
+#endif
   hipLaunchKernelGGL(fn, grid, dim3(256), (size_t)lds, stream, x, c_in, dy, c_out, in_pairs,
                      out_pairs, k_offsets_dev, volume, n_pairs, (int)g.ranges, g.n_cob, partial);
   ME_LAUNCH_CHECK();
@@ -2651,6 +2913,7 @@ int64_t me_conv_wgrad_workspace_bytes(const int64_t *k_offsets, int64_t volume, 
 
 void me_debug_set_wgrad_order(int mode) { g_wgrad_order = mode; }
 void me_debug_set_wgrad_mb(int mb) { g_wgrad_mb = mb; }
+void me_debug_set_wgrad_ws(int mode) { g_wgrad_ws = mode; }
 
 void me_debug_set_wgrad_config(int depth, int wgs_per_cu) {
   g_wgrad_depth = depth;

@@ -58,6 +58,8 @@ void me_debug_set_wgrad_order(int mode);
 void me_debug_set_tile_dispatch(int mode);
 /* k_wgrad_bf16: input-channel blocks of 16 per workgroup — 0 policy (8 where c_in >= 192 and c_out > 64), 4, 8 */
 void me_debug_set_wgrad_mb(int mb);
+// bf16 weight gradient: 0 = k_wgrad_bf16 (default), 1 / 2 = the wave-specialised kernel with four / two row register sets (tuning build)
+void me_debug_set_wgrad_ws(int mode);
 
 #ifdef __cplusplus
 }

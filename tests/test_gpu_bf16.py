@@ -666,3 +666,37 @@ def test_bf16_wave_specialised_batch_fusion_is_bit_identical(device, monkeypatch
     assert torch.equal(res[0][0], res[1][0]), "forward"
     assert torch.equal(res[0][1], res[1][1]), "input gradient"
     assert torch.isfinite(res[1][0].float()).all() and float(res[1][0].float().abs().max()) > 0
+
+
+@pytest.mark.parametrize("n,extent,cin,cout,ks,D,stride", [(6000, 16, 96, 96, 3, 3, 1), (5000, 14, 64, 128, 3, 3, 1), (4000, 12, 128, 128, 3, 3, 1),
+                                                            (3000, 12, 256, 256, 3, 3, 1), (3000, 12, 384, 256, 3, 3, 1), (4000, 30, 32, 32, 3, 3, 1),
+                                                            (4000, 14, 64, 64, 2, 3, 2), (2000, 8, 32, 64, 3, 4, 1), (300, 6, 256, 128, 3, 3, 1),
+                                                            (20000, 40, 64, 64, 3, 3, 1), (1, 2, 64, 64, 3, 3, 1)])
+def test_bf16_wave_specialised_weight_gradient_is_bit_identical(device, n, extent, cin, cout, ks, D, stride):
+    """k_wgrad_bf16_ws (round 4: producer waves stage the rows of the next steps while multiplier waves run the MFMAs of
+    this one) keeps the pair ranges, the slots and the order of additions of k_wgrad_bf16: grad_w must be the same bits —
+    64- and 128-channel blocks, one and two output blocks per wave, ranges that end inside an offset, more ranges than
+    pairs / 64, a grid larger than the chip, and both producer depths."""
+    from minkowskiengine_amd import _lib, backend as MEB
+    lib = _lib.load()
+    if not lib.me_debug_variants_compiled():
+        pytest.skip("not faster than k_wgrad_bf16 (profiles/r04_wgrad_ws_sweep.log): in a -DME_DEBUG_VARIANTS build only")
+    coords = make_cloud(n, extent, D, seed=cin + cout + n, batch=2, negative=True)
+    mgr = MEB.CoordinateMapManagerGPU_c10()
+    key, _ = mgr.insert_and_map(coords.to(device), [1] * D, "")
+    okey = mgr.stride(key, [stride] * D) if stride > 1 else key
+    km = mgr._kernel_map(key, okey, [ks] * D, [stride] * D, [1] * D, MEB.RegionType.HYPER_CUBE, None, False, False)
+    g = torch.Generator().manual_seed(7)
+    x = (torch.rand(km.n_in, cin, generator=g) - 0.5).to(device).bfloat16()
+    gy = (torch.rand(km.n_out, cout, generator=g) - 0.5).to(device).bfloat16()
+    w = (torch.rand(ks ** D, cin, cout, generator=g) - 0.5).to(device)
+    res = {}
+    try:
+        for mode in (0, 1, 2):
+            lib.me_debug_set_wgrad_ws(mode)
+            _, gw = MEB._conv_backward(x, gy, w, km, "mfma", need_grad_in=False)
+            res[mode] = gw.clone()
+    finally:
+        lib.me_debug_set_wgrad_ws(0)
+    assert torch.equal(res[0], res[1]) and torch.equal(res[0], res[2])
+    assert torch.isfinite(res[1]).all() and (n < 10 or float(res[1].abs().max()) > 0)
