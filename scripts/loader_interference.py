@@ -2,6 +2,7 @@
 ms per step of (a) eager launches and (b) a hipGraph replay of the step (no host work in the training thread), each
 alone and beside a thread that keeps building new scenes (insert + recipe replay) on a high-priority stream.
 (b) separates contention on the GPU from contention between the host threads (GIL, HIP runtime locks).
+(A loader spinning in pure Python instead starves the training thread of the GIL outright — seconds per step.)
 usage: python scripts/loader_interference.py  (GPU)"""
 import os, sys, threading, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -47,10 +48,7 @@ def loader(mode):
     torch.cuda.set_device(0)
     while not stop.is_set():
         with torch.cuda.stream(side):
-            if mode == "scenes":
-                t = ME.SparseTensor(feats, coords)
-            else:                                      # host-only load: pure Python spinning (GIL), no GPU work
-                sum(i * i for i in range(20000))
+            t = ME.SparseTensor(feats, coords)
         side.synchronize()
         built[0] += 1
 
@@ -77,7 +75,7 @@ with torch.cuda.graph(graph):
     step()
 print(f"eager alone            {timed(step):7.2f} ms")
 print(f"graph replay alone     {timed(graph.replay):7.2f} ms")
-for mode in ("scenes", "python"):
+for mode in ("scenes",):
     ms, nb = beside(step, mode)
     print(f"eager  + loader({mode:6s}) {ms:7.2f} ms   ({nb} loader iterations in 20 steps)")
     ms, nb = beside(graph.replay, mode)
