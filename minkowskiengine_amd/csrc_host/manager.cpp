@@ -369,6 +369,10 @@ std::shared_ptr<Plan> KernelMap::plan(const std::string &target, int tile_rows, 
   if (tp.second.defined()) gather_order = tile_order_ == "spatial" ? Tensor() : store_get(*store, name("pos", target));
   else gather_order = flat_order(target, tile_order_);
   if (g_plan_batch != nullptr && (g_plan_batch->jobs.empty() || g_plan_batch->dev == dev)) {
+    // (a deferred plan is in the cache before it is built: refuse what me_plan_build_multi would refuse NOW)
+    check(volume >= 1 && volume <= 65535 && tile_rows >= ME_GROUP_ROWS && tile_rows <= ME_MAX_TILE_ROWS &&
+              batch_groups >= 1 && batch_groups <= ME_MAX_BATCH_GROUPS && n_tiles * volume < (1ll << 31),
+          "invalid tile-plan geometry");
     me_plan_job j;
     std::memset(&j, 0, sizeof(j));
     j.tbl = ptr<int32_t>(tp.first);
