@@ -201,6 +201,7 @@ DEBUG_SIGNATURES = {
     "me_debug_set_bf16_shape": (None, [ctypes.c_int, ctypes.c_int]),
     "me_debug_set_bf16_deep": (None, [ctypes.c_int]),
     "me_debug_set_bf16_twobuf": (None, [ctypes.c_int]),
+    "me_debug_set_f32_fused_split": (None, [ctypes.c_int]),
     "me_debug_set_bf16_ws": (None, [ctypes.c_int]),
     "me_debug_set_bf16_ws_fuse": (None, [ctypes.c_int]),
     "me_debug_set_bf16_ws_depth": (None, [ctypes.c_int]),
@@ -234,6 +235,8 @@ def load():
     # everywhere, ME_AMD_BF16_WS_DEPTH=2 its shallower producer pipeline
     if os.environ.get("ME_AMD_BF16_WS", "") != "":
         lib.me_debug_set_bf16_ws(int(os.environ["ME_AMD_BF16_WS"]))
+    if os.environ.get("ME_AMD_F32_FUSED_SPLIT", "") != "":
+        lib.me_debug_set_f32_fused_split(int(os.environ["ME_AMD_F32_FUSED_SPLIT"]))
     if os.environ.get("ME_AMD_WGRAD_WS", "") != "":
         lib.me_debug_set_wgrad_ws(int(os.environ["ME_AMD_WGRAD_WS"]))
     if os.environ.get("ME_AMD_BF16_WS_DEPTH", "") != "":

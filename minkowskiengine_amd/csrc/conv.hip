@@ -2820,6 +2820,13 @@ static int conv_target_f32(const float *src, int64_t n_src, int32_t c_src, const
     }
   }
 #endif
+  // sparse maps (multi-offset batches): on the bf16 pipe with exactly split operands where that kernel is instantiated
+  // (conv_f32x3_fused.hip: the fp32 MFMA of k_conv_tile_f32 blocks its SIMD for every other wave)
+  if (fuse && small && g_conv_variant == 0) {
+    const int rc = launch_conv_f32x3_fused(v.nc, v.kc, src, n_src, c_src, wp, c_dst, v.slabs, plan_src, plan_dst, batch_desc,
+                                           tile_bptr, order, dst, n_tgt, tile_rows, stream);
+    if (rc != -1) return rc;
+  }
 #define ME_CONV_CASE(NCV, KCV) return launch_conv_tile<NCV, KCV, 0>(ME_CONV_ARGS, small, fuse)
   if (v.nc == 96) {
     if (v.kc == 96) ME_CONV_CASE(96, 96);

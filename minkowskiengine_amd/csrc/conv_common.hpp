@@ -125,6 +125,12 @@ struct PlanShape {
 };
 int plan_tile_rows(const PlanShape &s, int64_t n_tgt, int64_t volume, int64_t n_pairs);
 
+// fp32 rows on the bf16 pipe with multi-offset batches (conv_f32x3_fused.hip), dispatched by me_conv_target_f32_fused
+int launch_conv_f32x3_fused(int nc, int kc, const float *src, int64_t n_src, int c_src, const float *wp, int c_dst, int slabs,
+                            const int32_t *plan_src, const int32_t *plan_dst, const int32_t *batch_desc,
+                            const int32_t *tile_bptr, const int32_t *order, float *dst, int64_t n_tgt, int tile_rows,
+                            hipStream_t stream);
+
 // wave-specialised bf16 tile kernel (conv_bf16_ws.hip), dispatched by conv_bf16.hip
 bool conv_bf16_ws_shape(int nc, int kc);
 int conv_bf16_ws_lds_bytes(int nc, int kc, int tile_rows);

@@ -225,9 +225,9 @@ __device__ __forceinline__ void consume_batch_ws(const __bf16 *__restrict__ rowp
 // One SUPER-BATCH in a multiplier wave (sparse maps: multi-offset batches, see k_conv_tile_bf16's batch fusion): either
 // `nsub` > 1 single-group batches of DIFFERENT offsets staged together — group r multiplies with its own offset's weights
 // w[r] and the accumulator tile is updated in batch order (a later group may hit a row of an earlier one; LDS operations of a
-// wave execute in order) — or one batch of `ng` groups of one offset (weights w[0]; its rows are distinct).  All operand
-// reads first, `refill` (the caller requests the next super-batch's weights into its other register set), the MFMAs, then
-// the accumulator updates.  Plain loads and stores: the compiler schedules this path (the multi-group batches of dense maps
+// wave execute in order) — or one batch of `ng` groups of one offset (weights w[0]; its rows are distinct).  `refill` (the
+// caller requests the next super-batch's weights into its other register set) first, then per 32-channel step the operand
+// reads and the MFMAs, then the accumulator updates.  Plain loads and stores: the compiler schedules this path (the multi-group batches of dense maps
 // take consume_batch_ws).  Same sums in the same order as one consume_batch_ws per batch.
 template <int MAXSUB, int CB, int KC, int PL, typename Refill>
 __device__ __forceinline__ void consume_super_ws(const __bf16 *__restrict__ rowp, const int (&pofs)[KC / 32],
@@ -242,24 +242,24 @@ __device__ __forceinline__ void consume_super_ws(const __bf16 *__restrict__ rowp
   constexpr int WP[6] = {PL == 3 ? 2 : 0, 0, PL == 3 ? 1 : 0, PL == 3 ? 1 : 0, 0, 0};
   constexpr int AP[6] = {0, PL == 3 ? 2 : 0, PL == 3 ? 1 : 0, 0, PL == 3 ? 1 : 0, 0};
   int d[G];
-  bf16x8 a[G][PL][KS];
   f32x4 acc[G][CB];
 #pragma unroll
   for (int r = 0; r < G; ++r) {
     d[r] = (int)__umul24((unsigned)dstp[r * 16], (unsigned)acc_ld);
 #pragma unroll
-    for (int p = 0; p < PL; ++p) {
-#pragma unroll
-      for (int sx = 0; sx < KS; ++sx)
-        a[r][p][sx] = *reinterpret_cast<const bf16x8 *>(rowp + p * PLANE + r * 16 * LD + pofs[sx]);
-    }
-#pragma unroll
     for (int c = 0; c < CB; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
-  refill();         // (the next super-batch's weights, into the OTHER register set: issued behind the operand reads)
+  refill();         // (the next super-batch's weights, into the caller's OTHER register set — or nothing)
+  // operands of ONE 32-channel step at a time (all groups, all planes): G * PL registers of 16 bytes, whatever KC
   if (nsub > 1) {   // wave-uniform
 #pragma unroll
     for (int sx = 0; sx < KS; ++sx) {
+      bf16x8 a[MAXSUB][PL];
+#pragma unroll
+      for (int r = 0; r < MAXSUB; ++r) {
+#pragma unroll
+        for (int p = 0; p < PL; ++p) a[r][p] = *reinterpret_cast<const bf16x8 *>(rowp + p * PLANE + r * 16 * LD + pofs[sx]);
+      }
 #pragma unroll
       for (int t = 0; t < NT_; ++t) {
 #pragma unroll
@@ -267,7 +267,7 @@ __device__ __forceinline__ void consume_super_ws(const __bf16 *__restrict__ rowp
           if (r < nsub) {
 #pragma unroll
             for (int c = 0; c < CB; ++c)
-              acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[r][c][WP[t]][sx], a[r][AP[t]][sx], acc[r][c], 0, 0, 0);
+              acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[r][c][WP[t]][sx], a[r][AP[t]], acc[r][c], 0, 0, 0);
           }
         }
       }
@@ -286,6 +286,12 @@ __device__ __forceinline__ void consume_super_ws(const __bf16 *__restrict__ rowp
   } else {
 #pragma unroll
     for (int sx = 0; sx < KS; ++sx) {
+      bf16x8 a[G][PL];
+#pragma unroll
+      for (int r = 0; r < G; ++r) {
+#pragma unroll
+        for (int p = 0; p < PL; ++p) a[r][p] = *reinterpret_cast<const bf16x8 *>(rowp + p * PLANE + r * 16 * LD + pofs[sx]);
+      }
 #pragma unroll
       for (int t = 0; t < NT_; ++t) {
 #pragma unroll
@@ -293,7 +299,7 @@ __device__ __forceinline__ void consume_super_ws(const __bf16 *__restrict__ rowp
           if (r < ng) {
 #pragma unroll
             for (int c = 0; c < CB; ++c)
-              acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0][c][WP[t]][sx], a[r][AP[t]][sx], acc[r][c], 0, 0, 0);
+              acc[r][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0][c][WP[t]][sx], a[r][AP[t]], acc[r][c], 0, 0, 0);
           }
         }
       }

@@ -30,6 +30,8 @@ void me_debug_set_bf16_deep(int deep);
  * deep pipeline runs and the LDS holds the second buffer (bit-identical results) */
 void me_debug_set_bf16_twobuf(int mode);
 // the wave-specialised bf16 tile kernel (conv_bf16_ws.hip): -1 policy (default), 0 never, 1 wherever instantiated
+// fp32 multi-offset launches (sparse maps) on the bf16 pipe (conv_f32x3_fused.hip): 1 = where instantiated (tuning build), 0 never (default)
+void me_debug_set_f32_fused_split(int mode);
 void me_debug_set_bf16_ws(int mode);
 void me_debug_set_bf16_ws_fuse(int mode);    // 1: multi-offset batches (sparse maps) on the wave-specialised kernel too (tuning build; default 0)
 void me_debug_set_bf16_ws_depth(int depth);   // 2 | 4 register sets of gathered rows per producer thread (default 4)

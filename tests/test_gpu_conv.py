@@ -557,3 +557,49 @@ def test_multi_offset_batches_of_the_fp32_kernel_match_the_oracle(device, monkey
         assert_close(res[fuse][0][0], want_y, what=f"forward fuse={fuse}")
         assert_close(res[fuse][0][1], want_gi, what=f"grad_in fuse={fuse}")
     assert_close(res["1"][0][0], res["0"][0][0].cpu().numpy(), 5e-5, 5e-5, what="fused vs unfused")
+
+
+@pytest.mark.parametrize("n,extent,D,cin,cout", [(3000, 9, 4, 32, 64), (3000, 9, 4, 64, 32), (6000, 40, 3, 32, 32),
+                                                  (4000, 30, 3, 64, 64), (5000, 40, 3, 64, 128), (3000, 14, 3, 32, 64),
+                                                  (40, 10, 3, 32, 32)])
+def test_sparse_fp32_launches_on_the_bf16_pipe(device, monkeypatch, n, extent, D, cin, cout):
+    """k_conv_tile_f32x3_fused (round 4): the fp32 multi-offset launch of sparse maps with exactly split operands on the
+    bf16 matrix pipe, behind me_conv_target_f32_fused (same packed image, same plan).  Forward and input gradient against
+    the oracle per element, bitwise reproducible; against float64 ground truth its error is of fp32 order — at most 4x
+    the fp32-MFMA kernel's own (me_debug_set_f32_fused_split(0)) and <= 2e-6 of sum |x| |w|."""
+    from minkowskiengine_amd import _lib, backend as MEB
+    lib = _lib.load()
+    if not lib.me_debug_variants_compiled():
+        pytest.skip("2x slower than k_conv_tile_f32's fused launch on config 5: in a -DME_DEBUG_VARIANTS build only")
+    monkeypatch.setattr(MEB, "_F32_SPLIT", False)        # (the channel-count policy would send 64 -> 128 to the split kernels)
+    monkeypatch.setattr(MEB, "_BF16_FUSE", "1")
+    coords = make_cloud(n, extent, D, seed=cin + cout, batch=2, negative=True)
+    mgr = MEB.CoordinateMapManagerGPU_c10()
+    key, _ = mgr.insert_and_map(coords.to(device), [1] * D, "")
+    km = mgr._kernel_map(key, key, [3] * D, [1] * D, [1] * D, MEB.RegionType.HYPER_CUBE, None, False, False)
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(coords.shape[0], cin, generator=g) - 0.5
+    x[::7] = torch.nextafter(x[::7], torch.full_like(x[::7], 1e30))        # odd low bits
+    gy = torch.rand(coords.shape[0], cout, generator=g) - 0.5
+    w = torch.rand(3 ** D, cin, cout, generator=g) - 0.5
+    res = {}
+    try:
+        for mode in (1, 1, 0):
+            lib.me_debug_set_f32_fused_split(mode)
+            y = MEB._conv_forward(x.to(device), w.to(device), km, "mfma")
+            gi = MEB._conv_target(gy.to(device), w.to(device), km, "in", km.n_in, name="d", transposed=True)
+            res.setdefault(mode, []).append((y.cpu().numpy().astype(np.float64), gi.cpu().numpy().astype(np.float64)))
+    finally:
+        lib.me_debug_set_f32_fused_split(0)
+    assert np.array_equal(res[1][0][0], res[1][1][0]) and np.array_equal(res[1][0][1], res[1][1][1])
+    _, okm = O.kernel_map(coords.numpy(), coords.numpy(), O.make_region(D, 3))
+    x64, w64, gy64 = x.numpy().astype(np.float64), w.numpy().astype(np.float64), gy.numpy().astype(np.float64)
+    want_y = O.conv_forward(x64, w64, okm, len(coords))
+    want_gi = O.conv_backward(x64, gy64, w64, okm)[0]
+    mag_y = O.conv_forward(np.abs(x64), np.abs(w64), okm, len(coords))
+    mag_gi = O.conv_backward(np.abs(x64), np.abs(gy64), np.abs(w64), okm)[0]
+    for got, want, mag, what in ((0, want_y, mag_y, "forward"), (1, want_gi, mag_gi, "grad_in")):
+        assert_close(torch.from_numpy(res[1][0][got]), want, what=what)
+        err_split = np.abs(res[1][0][got] - want).max() / max(mag.max(), 1e-30)
+        err_mfma = np.abs(res[0][0][got] - want).max() / max(mag.max(), 1e-30)
+        assert err_split <= 2e-6 and err_split <= 4 * max(err_mfma, 1e-7), (what, err_split, err_mfma)
