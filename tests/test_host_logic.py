@@ -153,3 +153,79 @@ def test_bf16_tile_shape_policy_is_the_documented_one():
     header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "me_amd.h")).read()
     latest = max(int(v) for v in re.findall(r"\((\d{3})\)\s+round", header))
     assert lib.me_version() == latest
+
+
+def test_recipe_for_a_new_scene_is_the_longest_one_around():
+    """Map prefetch (round 4): a new scene's manager replays the LONGEST request log among the latest managers still alive
+    and the one the last destroyed manager left behind — with a loader thread the directly preceding manager has not run
+    its step yet, and a scene's manager usually dies right after its step, when its log is complete."""
+    import gc
+    from minkowskiengine_amd import coordinate_manager as CM
+
+    class FakeNative:
+        def __init__(self, log):
+            self.log = list(log)
+
+        def recipe(self):
+            return list(self.log)
+
+    class FakeManager:
+        def __init__(self, log, D=3, native=True):
+            self._manager, self.D, self._native, self.replayed = FakeNative(log), D, native, None
+
+        def recipe(self):
+            return self._manager.recipe()
+
+        def prefetch(self, recipe):
+            self.replayed = list(recipe)
+            self._manager.log = list(recipe)      # (a replay logs what it serves)
+            return len(recipe)
+
+    old_flag, old_recent, old_pub = CM._map_prefetch, list(CM._recent_managers), dict(CM._published_recipes)
+    try:
+        CM._recent_managers.clear()
+        CM._published_recipes.clear()
+        CM.set_map_prefetch(True)
+        full = [f"conv_cfg;{i}" for i in range(10)]
+        a = FakeManager([])                       # scene 1: built before any log exists
+        CM._prefetch_from_previous(a)
+        assert a.replayed is None
+        a._manager.log = list(full)               # ... its step fills its log
+        b = FakeManager([])                       # scene 2 was built by the loader BEFORE that: empty log
+        CM._recent_managers.append(__import__("weakref").ref(b))
+        c = FakeManager([])
+        CM._prefetch_from_previous(c)             # scene 3: the longest log around is scene 1's
+        assert c.replayed == full
+        other = FakeManager(["x"] * 20, D=4)      # another dimension's log is not a candidate
+        CM._prefetch_from_previous(other)
+        d = FakeManager([])
+        CM._prefetch_from_previous(d)
+        assert d.replayed == full
+        # a destroyed manager leaves its log behind (CoordinateManager.__del__ on a stand-in)
+        CM._recent_managers.clear()
+        CM.CoordinateManager.__del__(a)
+        del a, b, c, d
+        gc.collect()
+        e = FakeManager([])
+        CM._prefetch_from_previous(e)
+        assert e.replayed == full
+        # shorter logs replace the published one only after _PUBLISH_PATIENCE of them in a row (the network changed)
+        short = FakeManager(["conv_cfg;0"])
+        for _ in range(CM._PUBLISH_PATIENCE - 1):
+            CM.CoordinateManager.__del__(short)
+        assert CM._published_recipes[(3, True)][0] == full
+        CM.CoordinateManager.__del__(short)
+        assert CM._published_recipes[(3, True)][0] == ["conv_cfg;0"]
+        CM.set_map_prefetch(False)                # off: nothing is replayed, nothing published
+        CM._published_recipes.clear()
+        CM.CoordinateManager.__del__(FakeManager(full))
+        assert not CM._published_recipes
+        f = FakeManager([])
+        CM._prefetch_from_previous(f)
+        assert f.replayed is None
+    finally:
+        CM._map_prefetch = old_flag
+        CM._recent_managers.clear()
+        CM._recent_managers.extend(old_recent)
+        CM._published_recipes.clear()
+        CM._published_recipes.update(old_pub)
