@@ -205,6 +205,7 @@ DEBUG_SIGNATURES = {
     "me_debug_set_bf16_ws": (None, [ctypes.c_int]),
     "me_debug_set_bf16_ws_fuse": (None, [ctypes.c_int]),
     "me_debug_set_bf16_ws_depth": (None, [ctypes.c_int]),
+    "me_debug_ws_timing": (ctypes.c_int, [c_vp, c_i32]),
     "me_debug_set_bf16_offsync": (None, [ctypes.c_int]),
     "me_debug_set_bf16_splitk": (None, [ctypes.c_int]),
     "me_debug_set_bf16_splitk_mode": (None, [ctypes.c_int]),

@@ -27,6 +27,23 @@ __host__ __device__ constexpr int conv_bf16_ws_lds(int nc, int kc, int tile_rows
   return (tile_rows + 1) * (nc + kAccPad) * 4 + 2 * ME_MAX_BATCH_GROUPS * 16 * (x3_stage_ld(kc) * 2 + 4);
 }
 
+// Phase counters of a -DME_WS_TIMING build (scripts/ws_phase_timing.py; s_memtime ticks, summed over wave 0 — a multiplier —
+// and wave 4 — a producer — of every workgroup): [0] multiplier work between barriers, [1] multiplier barrier wait,
+// [2] producer work, [3] producer barrier wait, [4] batches, [5] tile prologue (to the first barrier), [6] epilogue, [7] tiles
+#ifdef ME_WS_TIMING
+__device__ unsigned long long d_ws_timing[8];
+#define ME_WS_SYNC(ROLE)                                                        \
+  do {                                                                          \
+    const unsigned long long t0_ = __builtin_amdgcn_s_memtime();                \
+    tm_[2 * (ROLE)] += t0_ - t_prev_;                                           \
+    __syncthreads();                                                            \
+    t_prev_ = __builtin_amdgcn_s_memtime();                                     \
+    tm_[2 * (ROLE) + 1] += t_prev_ - t0_;                                       \
+  } while (0)
+#else
+#define ME_WS_SYNC(ROLE) __syncthreads()
+#endif
+
 // DEPTH: register sets of gathered rows in flight per producer thread — the rows of batch x + DEPTH are requested while
 // batch x is staged.  A batch lasts 1,500 - 2,000 cycles here and a miss to HBM under load about as long: two sets
 // (the fp32 kernel's pipeline, whose batches last twice as long) leave the producers waiting for rows.
@@ -90,6 +107,11 @@ __global__ __launch_bounds__(512, 1) void k_conv_tile_bf16_ws(
   const int b0 = tile_bptr[tile];
   const int nb = tile_bptr[tile + 1] - b0;
   const int n_it = nb * nchunks;     // chunk-major, as k_conv_tile_bf16 walks them
+#ifdef ME_WS_TIMING
+  unsigned long long tm_[4] = {0, 0, 0, 0};
+  const unsigned long long t_start_ = __builtin_amdgcn_s_memtime();
+  unsigned long long t_prev_ = t_start_, t_first_ = 0, t_loop_end_ = 0;
+#endif
   struct Desc {
     int chunk, g0, ng, k;
   };
@@ -219,34 +241,37 @@ __global__ __launch_bounds__(512, 1) void k_conv_tile_bf16_ws(
         produce(0, std::integral_constant<int, 0>{});   // batch 0 -> buffer 0
       }
       __syncthreads();
+#ifdef ME_WS_TIMING
+      t_prev_ = t_first_ = __builtin_amdgcn_s_memtime();
+#endif
       // iteration it: batch it + 1 is staged while batch it is multiplied
       int it = 0;
       for (; it + DEPTH <= n_it; it += DEPTH) {
         produce(it + 1, std::integral_constant<int, 1 % DEPTH>{});
-        __syncthreads();
+        ME_WS_SYNC(1);
         produce(it + 2, std::integral_constant<int, 2 % DEPTH>{});
-        __syncthreads();
+        ME_WS_SYNC(1);
         if constexpr (DEPTH == 4) {
           produce(it + 3, std::integral_constant<int, 3>{});
-          __syncthreads();
+          ME_WS_SYNC(1);
           produce(it + 4, std::integral_constant<int, 0>{});
-          __syncthreads();
+          ME_WS_SYNC(1);
         }
       }
       if (it < n_it) {
         produce(it + 1, std::integral_constant<int, 1 % DEPTH>{});
-        __syncthreads();
+        ME_WS_SYNC(1);
         ++it;
       }
       if constexpr (DEPTH == 4) {
         if (it < n_it) {
           produce(it + 1, std::integral_constant<int, 2>{});
-          __syncthreads();
+          ME_WS_SYNC(1);
           ++it;
         }
         if (it < n_it) {
           produce(it + 1, std::integral_constant<int, 3>{});
-          __syncthreads();
+          ME_WS_SYNC(1);
           ++it;
         }
       }
@@ -321,7 +346,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_tile_bf16_ws(
       const __bf16 *rowp = s_a + buf * PLANE + i16 * LD;
       const int32_t *dstp = s_dst + buf * CAP + i16;
       float *accp = &s_acc[wave * CB * 16 + q * 4];
-      if (d.ng >= 4) consume_batch_ws<2, 2, CB, KC, 1>(rowp, pofs, wc, dstp, accp, ACC_LD, next_w);
+if (d.ng >= 4) consume_batch_ws<2, 2, CB, KC, 1>(rowp, pofs, wc, dstp, accp, ACC_LD, next_w);
       else if (d.ng == 3) consume_batch_ws<2, 1, CB, KC, 1>(rowp, pofs, wc, dstp, accp, ACC_LD, next_w);
       else if (d.ng == 2) consume_batch_ws<2, 0, CB, KC, 1>(rowp, pofs, wc, dstp, accp, ACC_LD, next_w);
       else consume_batch_ws<1, 0, CB, KC, 1>(rowp, pofs, wc, dstp, accp, ACC_LD, next_w);
@@ -330,9 +355,12 @@ __global__ __launch_bounds__(512, 1) void k_conv_tile_bf16_ws(
       Desc dA = locate(0), dB = locate(1);
       load_w(dA, w[0]);
       __syncthreads();                      // batch 0 is staged
+#ifdef ME_WS_TIMING
+      t_prev_ = t_first_ = __builtin_amdgcn_s_memtime();
+#endif
       auto iteration = [&](int it, int P, bf16x8 (&w_cu)[CB][1][KS], bf16x8 (&w_nx)[CB][1][KS]) {
         multiply(dA, w_cu, P, [&]() { load_w(dB, w_nx); });
-        __syncthreads();
+        ME_WS_SYNC(0);
         dA = dB;
         dB = locate(it + 2);
       };
@@ -384,6 +412,9 @@ __global__ __launch_bounds__(512, 1) void k_conv_tile_bf16_ws(
     __syncthreads();
   }
 
+#ifdef ME_WS_TIMING
+  t_loop_end_ = __builtin_amdgcn_s_memtime();
+#endif
   // ---- epilogue: every target row of the tile is written exactly once, rounded to bf16 (RNE); the tile's batch-norm
   // statistics ride along (see k_conv_tile_bf16: same arithmetic, this kernel's thread count) ----
   const int64_t row0 = (int64_t)tile * tile_rows;
@@ -468,6 +499,21 @@ __global__ __launch_bounds__(512, 1) void k_conv_tile_bf16_ws(
       stat_m2[(int64_t)tile * c_dst + col_base + tid] = fmaxf(b - a * m, 0.f);
     }
   }
+#ifdef ME_WS_TIMING
+  __builtin_amdgcn_s_waitcnt(0);
+  if (!FUSE && n_it > 0 && lane == 0 && (wave == 0 || wave == NCW)) {
+    const unsigned long long t_end_ = __builtin_amdgcn_s_memtime();
+    const int role = wave == 0 ? 0 : 1;
+    atomicAdd(&d_ws_timing[2 * role], tm_[2 * role]);
+    atomicAdd(&d_ws_timing[2 * role + 1], tm_[2 * role + 1]);
+    if (wave == 0) {
+      atomicAdd(&d_ws_timing[4], (unsigned long long)n_it);
+      atomicAdd(&d_ws_timing[5], t_first_ - t_start_);
+      atomicAdd(&d_ws_timing[6], t_end_ - t_loop_end_);
+      atomicAdd(&d_ws_timing[7], 1ull);
+    }
+  }
+#endif
 }
 
 // ---- launch (called by conv_bf16.hip's dispatcher) -------------------------------------------------------------------
@@ -530,3 +576,23 @@ int launch_conv_bf16_ws(int nc, int kc, const void *src, int c_src, const void *
 }  // namespace me
 
 extern "C" void me_debug_set_bf16_ws_depth(int depth) { me::g_bf16_ws_depth = depth; }
+
+// phase counters of a -DME_WS_TIMING build (zeros otherwise); reset != 0 clears them
+extern "C" int me_debug_ws_timing(uint64_t *out8, int32_t reset) {
+#ifdef ME_WS_TIMING
+  unsigned long long h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (out8 != nullptr) {
+    ME_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(me::d_ws_timing), sizeof(h)));
+    for (int i = 0; i < 8; ++i) out8[i] = h[i];
+  }
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    ME_HIP(hipMemcpyToSymbol(HIP_SYMBOL(me::d_ws_timing), z, sizeof(z)));
+  }
+#else
+  if (out8 != nullptr)
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+  (void)reset;
+#endif
+  return 0;
+}
