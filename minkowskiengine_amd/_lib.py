@@ -205,6 +205,7 @@ DEBUG_SIGNATURES = {
     "me_debug_set_bf16_ws": (None, [ctypes.c_int]),
     "me_debug_set_bf16_ws_fuse": (None, [ctypes.c_int]),
     "me_debug_set_bf16_ws_depth": (None, [ctypes.c_int]),
+    "me_debug_set_bf16_ws_ncw": (None, [ctypes.c_int]),
     "me_debug_ws_timing": (ctypes.c_int, [c_vp, c_i32]),
     "me_debug_set_bf16_offsync": (None, [ctypes.c_int]),
     "me_debug_set_bf16_splitk": (None, [ctypes.c_int]),
@@ -240,6 +241,8 @@ def load():
         lib.me_debug_set_f32_fused_split(int(os.environ["ME_AMD_F32_FUSED_SPLIT"]))
     if os.environ.get("ME_AMD_WGRAD_WS", "") != "":
         lib.me_debug_set_wgrad_ws(int(os.environ["ME_AMD_WGRAD_WS"]))
+    if os.environ.get("ME_AMD_BF16_WS_NCW", "") != "":
+        lib.me_debug_set_bf16_ws_ncw(int(os.environ["ME_AMD_BF16_WS_NCW"]))
     if os.environ.get("ME_AMD_BF16_WS_DEPTH", "") != "":
         lib.me_debug_set_bf16_ws_depth(int(os.environ["ME_AMD_BF16_WS_DEPTH"]))
     return lib

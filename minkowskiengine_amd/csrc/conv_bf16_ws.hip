@@ -55,8 +55,10 @@ __device__ unsigned long long d_ws_timing[8];
 // fused launch (96 -> 96 on 200k voxels, 8.7 pairs per item: 178 us against 92): one eight-wave workgroup per CU and
 // super-batches of two offsets do not beat three four-wave workgroups there.  Instantiated in the tuning build only
 // (-DME_DEBUG_VARIANTS, me_debug_set_bf16_ws_fuse(1)); sparse launches stay with k_conv_tile_bf16.
-template <int NC, int KC, int DEPTH, bool FUSE = false>
-__global__ __launch_bounds__(512, 1) void k_conv_tile_bf16_ws(
+// NCW: multiplier waves — 4 (NC / 4 columns each) or, for 128-column slabs, 8 (16 columns each: two multipliers per SIMD
+// next to the producer, one's MFMAs cover the other's LDS waits; the fp32 kernel's default there).
+template <int NC, int KC, int DEPTH, bool FUSE = false, int NCW = 4>
+__global__ __launch_bounds__((NCW + 4) * 64, 1) void k_conv_tile_bf16_ws(
     const __bf16 *__restrict__ src, int c_src, const bf16x8 *__restrict__ wp, int c_dst,
     const int32_t *__restrict__ plan_src, const int32_t *__restrict__ plan_dst,
     const int32_t *__restrict__ batch_desc, const int32_t *__restrict__ tile_bptr,
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(512, 1) void k_conv_tile_bf16_ws(
   typedef int i32x2 __attribute__((ext_vector_type(2)));
   typedef StageLayout<KC> SL;
   static_assert(NC == 64 || NC == 128, "multiplier waves of 16 or 32 columns");
-  constexpr int NCW = 4;               // multiplier waves
+  static_assert(NCW == 4 || (NCW == 8 && NC == 128 && !FUSE), "four multiplier waves, or eight on a 128-column slab");
   constexpr int CB = NC / (16 * NCW);  // 16-column blocks per multiplier wave
   constexpr int NTP = 256;             // producer threads (four waves)
   constexpr int NT = NCW * 64 + NTP;
@@ -475,7 +477,8 @@ if (d.ng >= 4) consume_batch_ws<2, 2, CB, KC, 1>(rowp, pofs, wc, dstp, accp, ACC
       }
     }
     __syncthreads();                              // every wave is done with the accumulator tile
-    float *s_st = s_acc + ACC_LD;                 // [WAVES][G4][8] behind row 0 (8 x 32 x 8 floats <= 16 rows)
+    float *s_st = s_acc + ACC_LD;                 // [WAVES][G4][8] behind row 0 (8 x 32 x 8 floats <= 16 rows; twelve
+                                                  // waves: 24 rows — the launcher keeps shorter tiles on eight waves)
     if (lane < G4) {
       float *wv = s_st + (wave * G4 + lane) * 8;
 #pragma unroll
@@ -522,6 +525,7 @@ bool conv_bf16_ws_shape(int nc, int kc) { return (nc == 64 || nc == 128) && (kc 
 int conv_bf16_ws_lds_bytes(int nc, int kc, int tile_rows) { return conv_bf16_ws_lds(nc, kc, tile_rows); }
 
 int g_bf16_ws_depth = 4;   // me_debug_set_bf16_ws_depth: 2 | 4 register sets of rows in flight
+int g_bf16_ws_ncw = 0;     // me_debug_set_bf16_ws_ncw: 0 policy | 4 | 8 multiplier waves on 128-column slabs
 
 template <int NC, int KC>
 static int launch_ws(const __bf16 *src, int c_src, const bf16x8 *wp, int c_dst, int slabs, const int32_t *plan_src,
@@ -532,19 +536,35 @@ static int launch_ws(const __bf16 *src, int c_src, const bf16x8 *wp, int c_dst, 
                            const int32_t *, const int32_t *, __bf16 *, int64_t, int, float *, float *);
   const bool deep = g_bf16_ws_depth != 2;
   kernel_t fn = deep ? &k_conv_tile_bf16_ws<NC, KC, 4> : &k_conv_tile_bf16_ws<NC, KC, 2>;
+  int which = deep ? 1 : 0, threads = 512;
+  if constexpr (NC == 128) {
+    // Eight multiplier waves where the slab runs one workgroup per CU anyway (chunks of 96 / 128 channels: > 128 registers):
+    // measured 4 - 11 % faster there (128 -> 128 @80k 72 -> 67 us, 384 -> 256 121 -> 108), 30 % SLOWER where four multipliers
+    // leave room for two workgroups per CU (64 -> 128 @100k 57 -> 74 us): profiles/r04_ws_sweep_ncw.log.
+    // (The statistics epilogue of twelve waves needs >= 24 tile rows.)
+    const bool eight = g_bf16_ws_ncw == 8 || (g_bf16_ws_ncw == 0 && KC >= 96);
+    if (eight && tile_rows >= 24 && !fuse) {
+      fn = &k_conv_tile_bf16_ws<NC, KC, 4, false, 8>;
+      which = 3;
+      threads = 768;
+    }
+  }
 #ifdef ME_DEBUG_VARIANTS   // measured 2x SLOWER than k_conv_tile_bf16's fused launch on MinkUNet34C's sparse levels
-  if (fuse) fn = &k_conv_tile_bf16_ws<NC, KC, 4, true>;   // (profiles/r04_layers_minkunet34c_bf16_ws_fuse.log): tuning build only
+  if (fuse) {               // (profiles/r04_layers_minkunet34c_bf16_ws_fuse.log): tuning build only
+    fn = &k_conv_tile_bf16_ws<NC, KC, 4, true>;
+    which = 2;
+    threads = 512;
+  }
 #else
   if (fuse) return -1;
 #endif
-  static bool attr_set[3] = {false, false, false};   // per instantiation
-  const int which = fuse ? 2 : (deep ? 1 : 0);
+  static bool attr_set[4] = {false, false, false, false};   // per instantiation
   if (lds > 48 * 1024 && !attr_set[which]) {
     ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
     attr_set[which] = true;
   }
   const dim3 grid((unsigned)ceil_div(n_tgt, tile_rows), (unsigned)slabs);
-  hipLaunchKernelGGL(fn, grid, dim3(512), (size_t)lds, stream, src, c_src, wp, c_dst, plan_src, plan_dst, batch_desc,
+  hipLaunchKernelGGL(fn, grid, dim3((unsigned)threads), (size_t)lds, stream, src, c_src, wp, c_dst, plan_src, plan_dst, batch_desc,
                      tile_bptr, order, dst, n_tgt, tile_rows, stat_mean, stat_m2);
   ME_LAUNCH_CHECK();
   return 0;
@@ -576,6 +596,7 @@ int launch_conv_bf16_ws(int nc, int kc, const void *src, int c_src, const void *
 }  // namespace me
 
 extern "C" void me_debug_set_bf16_ws_depth(int depth) { me::g_bf16_ws_depth = depth; }
+extern "C" void me_debug_set_bf16_ws_ncw(int ncw) { me::g_bf16_ws_ncw = ncw; }
 
 // phase counters of a -DME_WS_TIMING build (zeros otherwise); reset != 0 clears them
 extern "C" int me_debug_ws_timing(uint64_t *out8, int32_t reset) {

@@ -35,6 +35,7 @@ void me_debug_set_f32_fused_split(int mode);
 void me_debug_set_bf16_ws(int mode);
 void me_debug_set_bf16_ws_fuse(int mode);    // 1: multi-offset batches (sparse maps) on the wave-specialised kernel too (tuning build; default 0)
 void me_debug_set_bf16_ws_depth(int depth);
+void me_debug_set_bf16_ws_ncw(int ncw);       // 0 policy | 4 | 8 multiplier waves of the wave-specialised kernel on 128-column slabs
 // phase counters of k_conv_tile_bf16_ws in a -DME_WS_TIMING build (see conv_bf16_ws.hip); zeros otherwise
 int me_debug_ws_timing(uint64_t *out8, int32_t reset);   // 2 | 4 register sets of gathered rows per producer thread (default 4)
 /* bf16 forward / dgrad schedule: 0 column-split k_conv_tile_bf16, 1 offset-synchronous k_conv_off_bf16 where eligible

@@ -36,16 +36,17 @@ def timed(fn):
     torch.cuda.synchronize()
     return s.elapsed_time(e) / REPS * 1e3
 
-print(f"{'case':>10s} {'rows':>7s} {'layer':>10s}  {'k_conv_tile_bf16':>22s}  {'ws, 2 register sets':>22s}  {'ws, 4 register sets':>22s}   (forward / dgrad us, tile rows)")
+print(f"{'case':>10s} {'rows':>7s} {'layer':>10s}  {'k_conv_tile_bf16':>22s}  {'ws, 4 multipliers':>22s}  {'ws, 8 on 128 columns':>22s}   (forward / dgrad us, tile rows)")
 for name, c, ts, cin, cout in cases:
     g = torch.Generator().manual_seed(1)
     x = (torch.rand(c.shape[0], cin, generator=g) - 0.5).to(dev).bfloat16()
     gy = (torch.rand(c.shape[0], cout, generator=g) - 0.5).to(dev).bfloat16()
     w = (torch.rand(27, cin, cout, generator=g) - 0.5).to(dev)
     cells = []
-    for mode, depth in ((0, 4), (1, 2), (1, 4)):
+    for mode, depth, ncw in ((0, 4, 4), (1, 4, 4), (1, 4, 8)):
         lib.me_debug_set_bf16_ws(mode)
         lib.me_debug_set_bf16_ws_depth(depth)
+        lib.me_debug_set_bf16_ws_ncw(ncw)
         mgr = MEB.CoordinateMapManagerGPU_c10()
         k, _ = mgr.insert_and_map(c, [ts] * 3, "")
         km = mgr._kernel_map(k, k, [3] * 3, [1] * 3, [1] * 3, MEB.RegionType.HYPER_CUBE, None, False, False)
@@ -56,3 +57,4 @@ for name, c, ts, cin, cout in cases:
         cells.append(f"{f:6.1f} /{d:6.1f} T{tf}/{td}")
     print(f"{name:>10s} {c.shape[0]:7d} {str(cin) + '->' + str(cout):>10s}  " + "  ".join(f"{v:>22s}" for v in cells), flush=True)
 lib.me_debug_set_bf16_ws(-1)
+lib.me_debug_set_bf16_ws_ncw(0)

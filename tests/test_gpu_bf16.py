@@ -579,8 +579,9 @@ def test_bf16_wave_specialised_kernel_is_bit_identical(device, monkeypatch, n, e
     w = (torch.rand(ks ** D, cin, cout, generator=g) - 0.5).to(device)
     res = {}
     try:
-        for mode in (0, 1):
-            lib.me_debug_set_bf16_ws(mode)
+        for mode in (0, 1, 8):                      # lock-step kernel | four multiplier waves | eight (128-column slabs)
+            lib.me_debug_set_bf16_ws(min(mode, 1))
+            lib.me_debug_set_bf16_ws_ncw(8 if mode == 8 else 4)
             lib.me_debug_set_bf16_splitk(0)
             mgr = MEB.CoordinateMapManagerGPU_c10()
             key, _ = mgr.insert_and_map(coords.to(device), [1] * D, "")
@@ -594,9 +595,11 @@ def test_bf16_wave_specialised_kernel_is_bit_identical(device, monkeypatch, n, e
             res[mode] = (y.clone(), gi.clone())
     finally:
         lib.me_debug_set_bf16_ws(-1)
+        lib.me_debug_set_bf16_ws_ncw(0)
         lib.me_debug_set_bf16_splitk(-1)
-    assert torch.equal(res[0][0], res[1][0]), "forward"
-    assert torch.equal(res[0][1], res[1][1]), "input gradient"
+    for mode in (1, 8):
+        assert torch.equal(res[0][0], res[mode][0]), ("forward", mode)
+        assert torch.equal(res[0][1], res[mode][1]), ("input gradient", mode)
     assert torch.isfinite(res[1][0].float()).all() and (n < 10 or float(res[1][0].float().abs().max()) > 0)
 
 
