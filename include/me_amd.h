@@ -53,7 +53,9 @@ typedef struct me_region {
  *   1.4 (140)  round 4: split-K launches of the bf16 convolution for small coordinate maps
  *              (me_conv_plan_config_bf16_ex, me_conv_splitk_workspace_bytes, me_conv_target_bf16_ex); float64
  *              features (me_conv_target_f64, me_conv_wgrad_f64, me_pool_*_f64, me_global_pool_f64, me_broadcast_f64);
- *              all tile plans of a scene in four launches (me_plan_job, me_plan_jobs_init, me_plan_build_multi) */
+ *              all tile plans of a scene in four launches (me_plan_job, me_plan_jobs_init, me_plan_build_multi)
+ *   1.5 (150)  round 5: bf16 convolution on an LDS-staged source halo with register accumulators
+ *              (me_conv_halo_config_bf16, me_halo_plan_build, me_conv_halo_bf16) */
 int me_version(void);
 const char *me_last_error(void);
 /* kernel volume of a region: src/kernel_region.hpp:250-270 (set_volume) */
@@ -443,6 +445,44 @@ int me_conv_gather_pack_weights_bf16(const void *w_dev, int32_t w_is_f32, int64_
 int me_conv_gather_bf16(const uint16_t *src_feat_dev, int64_t n_src, int32_t c_src, const uint16_t *packed_dev,
                         int64_t volume, int32_t c_dst, const int32_t *tbl_dev, const int32_t *order_dev,
                         uint16_t *dst_feat_dev, int64_t n_tgt, void *stream);
+
+/* ---- bf16 convolution on a source halo staged in LDS (csrc/conv_halo.hip, ABI 1.5) ----------------------------
+ * The same operation as me_conv_target_bf16 — dst[t, :] = sum over offsets k of src[tbl[k][t], :] @ w[k], fp32 sums in a
+ * fixed order (per 64-channel chunk: ascending k, ascending source channel), one rounding to bf16 — on another schedule: a tile of
+ * `tile_rows` target positions keeps its fp32 sums in REGISTERS for all offsets; the distinct source rows the tile
+ * touches (its halo, <= s_cap of them) are staged in LDS once per channel chunk and every offset gathers from LDS;
+ * absent neighbours multiply a zero row, 16-row groups without any neighbour at an offset are skipped; no barrier and
+ * no read-modify-write inside the walk over the offsets.  The reference gathers, multiplies and scatter-adds once per
+ * offset (src/convolution_kernel.cu:320-496).  Results are NOT the bits of me_conv_target_bf16 (there every batch
+ * starts a new accumulator), they are bitwise reproducible.
+ *   me_conv_halo_use_bf16     the policy: 1 when a host should run this launch side on the halo kernel (0: the tile-plan
+ *                             kernel).  ME_AMD_HALO=0 | 1 | auto.  Both hosts of this repository follow it.
+ *   me_conv_halo_config_bf16  1 when the kernel is instantiated for (volume, c_src, c_dst): volume in [2, 32],
+ *                             c_src % 32 == 0, c_dst in {32, 64, 96} or a multiple of 128; answers the plan geometry.
+ *   me_halo_plan_build        tbl_dev int32 [volume, n_tgt] (source row of (offset, table column) or -1; nbr for forward,
+ *                             nbrT for dgrad), col_order_dev int32 [n_tgt] or NULL: table column of tile position p
+ *                             (NULL: p).  Out: halo_cnt_dev int32 [tiles] distinct source rows of each tile;
+ *                             halo_rows_dev int32 [tiles * s_cap] its first s_cap of them, ascending; lidx_dev uint16
+ *                             [tiles * volume * tile_rows]: 0 = no neighbour, 1 + halo slot, 0xffff = beyond s_cap;
+ *                             kmask_dev uint32 [tiles * volume]: bit g = 16-row group g has a neighbour at the offset.
+ *                             A tile whose halo exceeds s_cap is served by direct gathers off tbl_dev (any map works).
+ *   me_conv_halo_bf16         packed_w_dev: the image of me_conv_pack_weights_bf16 for (c_src, c_dst) (transposed = 1
+ *                             for dgrad); out_order_dev int32 [n_tgt] or NULL: target ROW of tile position p;
+ *                             part_mean_dev / part_m2_dev [tiles][c_dst] or NULL: the batch-norm partials of
+ *                             me_conv_target_bf16_stats with tile_rows = the halo tile. */
+int32_t me_conv_halo_use_bf16(int64_t n_tgt, int64_t volume, int64_t n_pairs, int32_t c_src, int32_t c_dst);
+int32_t me_conv_halo_config_bf16(int64_t n_tgt, int64_t volume, int64_t n_pairs, int32_t c_src, int32_t c_dst,
+                                 int32_t *tile_rows, int32_t *s_cap);
+int64_t me_halo_plan_num_tiles(int64_t n_tgt, int32_t tile_rows);
+int me_halo_plan_build(const int32_t *tbl_dev, const int32_t *col_order_dev, int64_t n_tgt, int64_t volume,
+                       int32_t tile_rows, int32_t s_cap, int32_t *halo_cnt_dev, int32_t *halo_rows_dev,
+                       uint16_t *lidx_dev, uint32_t *kmask_dev, void *stream);
+int me_conv_halo_bf16(const uint16_t *src_feat_dev, int64_t n_src, int32_t c_src, const uint16_t *packed_w_dev,
+                      int64_t volume, int32_t c_dst, const int32_t *halo_cnt_dev, const int32_t *halo_rows_dev,
+                      const uint16_t *lidx_dev, const uint32_t *kmask_dev, const int32_t *tbl_dev,
+                      const int32_t *col_order_dev, const int32_t *out_order_dev, uint16_t *dst_feat_dev,
+                      int64_t n_tgt, int32_t tile_rows, int32_t s_cap, float *part_mean_dev, float *part_m2_dev,
+                      void *stream);
 
 /* ---- fp32 convolution on the bf16 matrix pipe ("bf16x6" split, csrc/conv_f32x3.hip) ---------------------
  * Same contract as me_conv_target_f32 (fp32 features / weights in, fp32 out, the reference's

@@ -136,6 +136,12 @@ SIGNATURES = {
     "me_conv_pack_weights_f32x3": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "me_conv_target_f32x3": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp,
                                             c_vp, c_i64, c_i32, c_i32, c_vp]),
+    "me_conv_halo_use_bf16": (c_i32, [c_i64, c_i64, c_i64, c_i32, c_i32]),
+    "me_conv_halo_config_bf16": (c_i32, [c_i64, c_i64, c_i64, c_i32, c_i32, _P_I32, _P_I32]),
+    "me_halo_plan_num_tiles": (c_i64, [c_i64, c_i32]),
+    "me_halo_plan_build": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "me_conv_halo_bf16": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                         c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "me_conv_pack_chunk_bf16": (c_i32, [c_i32, c_i32]),
     "me_conv_pack_chunk_f32x3": (c_i32, [c_i32, c_i32]),
     "me_conv_pack_job_init": (ctypes.c_int, [ctypes.POINTER(MePackJob)]),
@@ -203,6 +209,9 @@ DEBUG_SIGNATURES = {
     "me_debug_set_bf16_twobuf": (None, [ctypes.c_int]),
     "me_debug_set_f32_fused_split": (None, [ctypes.c_int]),
     "me_debug_set_bf16_ws": (None, [ctypes.c_int]),
+    "me_debug_set_halo": (None, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "me_debug_halo_mode": (c_i32, []),
+    "me_debug_halo_timing": (ctypes.c_int, [c_vp, c_i32]),
     "me_debug_set_bf16_ws_fuse": (None, [ctypes.c_int]),
     "me_debug_set_bf16_ws_depth": (None, [ctypes.c_int]),
     "me_debug_set_bf16_ws_ncw": (None, [ctypes.c_int]),

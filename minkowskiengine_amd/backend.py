@@ -270,13 +270,29 @@ class _CoordinateMapGPU:
     src/coordinate_map_gpu.cuh:47-223); `bbox` (host ints: column minima, then maxima) came back with the
     insert's own read-back and sizes the spatial index, which is built on first use."""
 
-    __slots__ = ("coords", "table", "capacity", "tensor_stride", "n", "bbox", "_spatial")
+    __slots__ = ("coords", "table", "capacity", "tensor_stride", "n", "bbox", "_spatial", "_zorder")
 
     def __init__(self, coords, table, capacity, tensor_stride, n, bbox=None):
         self.coords, self.table, self.capacity = coords, table, capacity
         self.tensor_stride, self.n = tuple(tensor_stride), int(n)
         self.bbox = bbox
         self._spatial = False    # False: not tried yet; None: not available
+        self._zorder = None
+
+    def zorder(self):
+        """Rows in Z-order (Morton keys of the coordinates in units of the tensor stride, batch index on top;
+        me_coords_spatial_keys): runs of consecutive entries are spatially compact at EVERY length — what the halo
+        kernel's tiles need (the supercell order of spatial() is compact only down to a supercell).  int32 [n]."""
+        if self._zorder is None and self.n > 0:
+            lib = _lib.load()
+            dev = self.coords.device
+            keys = torch.empty(self.n, dtype=torch.int64, device=dev)
+            ts = (ctypes.c_int32 * len(self.tensor_stride))(*self.tensor_stride)
+            with _on(dev):
+                _lib.check(lib.me_coords_spatial_keys(_ptr(self.coords), self.n, self.coords.shape[1], ts, _ptr(keys),
+                                                      _stream(dev)))
+                self._zorder = torch.argsort(keys, stable=True).to(torch.int32)
+        return self._zorder
 
     def spatial(self):
         """-> _SpatialIndex or None (empty map, no bounding box, or a bounding box of too many supercells)."""
@@ -1052,7 +1068,9 @@ class CoordinateMapManagerGPU_c10:
                     _, key, target, c_src, c_dst, bf16 = op
                     km = self._kernel_maps.get(key)
                     if km is not None:
-                        _conv_launch_cfg(km, target, km.n_out if target == "out" else km.n_in, c_src, c_dst, bf16)
+                        n_tgt = km.n_out if target == "out" else km.n_in
+                        if not (bf16 and _halo_launch_cfg(km, target, n_tgt, c_src, c_dst) is not None):
+                            _conv_launch_cfg(km, target, n_tgt, c_src, c_dst, bf16)
                         done += 1
                 elif op[0] == "wgrad_cfg":
                     _, key, c_in, c_out, bf16 = op
@@ -1250,6 +1268,42 @@ def _conv_launch_cfg(km, target, n_tgt, c_src, c_dst, bf16):
         if km._recipe is not None:
             km._recipe.append(("conv_cfg", km._recipe_key, target, c_src, c_dst, bool(bf16)))
     return split, cfg
+
+
+def _halo_launch_cfg(km, target, n_tgt, c_src, c_dst):
+    """Halo plan (csrc/conv_halo.hip) of a launch side when libme_amd's policy (me_conv_halo_use_bf16: ME_AMD_HALO, shape,
+    density) sends it to the output-stationary kernel, else None -> the tile-plan kernels.  Tiles are runs of target
+    rows in the Z-order of the target's coordinate map (compact at every length: small halos)."""
+    lib = _lib.load()
+    if not lib.me_conv_halo_use_bf16(n_tgt, km.volume, km.n_pairs, c_src, c_dst):
+        return None
+    t, cap = ctypes.c_int32(0), ctypes.c_int32(0)
+    if not lib.me_conv_halo_config_bf16(n_tgt, km.volume, km.n_pairs, c_src, c_dst, ctypes.byref(t), ctypes.byref(cap)):
+        return None
+    tile_rows, s_cap = int(t.value), int(cap.value)
+    name = km._name("halo", target) + f"_{tile_rows}_{s_cap}"
+    if name not in km._store:
+        dev = km.device
+        tbl, native = km.table_pos(target)
+        cmap = km.out_map if target == "out" else km.in_map
+        out_order = cmap.zorder() if cmap is not None else None
+        if out_order is None or out_order.numel() != n_tgt:
+            km._store[name] = None
+            return None
+        # a position-space table (LDS-bucketed map build) is read through pos_of_row
+        col_order = out_order if native is None else km._store[km._name("pos", target)][out_order.long()].contiguous()
+        tiles = int(lib.me_halo_plan_num_tiles(n_tgt, tile_rows))
+        halo_cnt = torch.empty(tiles, dtype=torch.int32, device=dev)
+        halo_rows = torch.empty(tiles * s_cap, dtype=torch.int32, device=dev)
+        lidx = torch.empty(tiles * km.volume * tile_rows, dtype=torch.int16, device=dev)
+        kmask = torch.empty(tiles * km.volume, dtype=torch.int32, device=dev)
+        with _on(dev), _roctx("me:halo_plan"):
+            _lib.check(lib.me_halo_plan_build(_ptr(tbl), _ptr(col_order), n_tgt, km.volume, tile_rows, s_cap,
+                                              _ptr(halo_cnt), _ptr(halo_rows), _ptr(lidx), _ptr(kmask), _stream(dev)))
+        km._store[name] = (tile_rows, s_cap, halo_cnt, halo_rows, lidx, kmask, tbl, col_order, out_order)
+        if km._recipe is not None:
+            km._recipe.append(("conv_cfg", km._recipe_key, target, c_src, c_dst, True))
+    return km._store[name]
 
 
 def _wgrad_launch_cfg(km, c_in, c_out, bf16):
@@ -1452,6 +1506,32 @@ def _conv_target(src_feat, kernel, km, target, n_tgt, name="conv_target", transp
             _timed(name, dev, lambda: _lib.check(lib.me_conv_gather_bf16(
                 src_feat.data_ptr(), src_feat.shape[0], c_src, packed.data_ptr(), km.volume, c_dst, p_tbl, p_order,
                 out.data_ptr(), n_tgt, stream)), flops=2.0 * km.n_pairs * c_src * c_dst if KERNEL_TIMER else 0.0)
+        return out
+    halo = _halo_launch_cfg(km, target, n_tgt, c_src, c_dst) if bf16 else None
+    if halo is not None:
+        # output-stationary launch on the LDS-staged source halo (csrc/conv_halo.hip): the same packed weights, the
+        # batch-norm partials per halo tile
+        _check(kernel.dtype in (torch.float32, torch.bfloat16), "kernel must be float32 or bfloat16")
+        tile_rows, s_cap, halo_cnt, halo_rows, lidx, kmask, tbl, col_order, out_order = halo
+        elems = int(lib.me_conv_packed_weight_elems_bf16(volume, c_src, c_dst))
+        stream = _stream(dev)
+        with _on(dev):
+            if _PACK_CACHE:
+                packed = _packed_weights(kernel, _lib.ME_PACK_BF16, transposed, c_src, c_dst, elems)
+            else:
+                packed = torch.empty(elems, dtype=torch.bfloat16, device=dev)
+                _lib.check(lib.me_conv_pack_weights_bf16(kernel.data_ptr(), 1 if kernel.dtype == torch.float32 else 0,
+                                                         volume, c_src, c_dst, 1 if transposed else 0,
+                                                         packed.data_ptr(), stream))
+            want_stats = bool(_CONV_BN_STATS and _BN_STATS_HINT[0] and name == "conv_forward")
+            part = torch.empty(2, -(-n_tgt // tile_rows), c_dst, dtype=torch.float32, device=dev) if want_stats else None
+            _timed(name, dev, lambda: _lib.check(lib.me_conv_halo_bf16(
+                src_feat.data_ptr(), src_feat.shape[0], c_src, packed.data_ptr(), km.volume, c_dst, _ptr(halo_cnt),
+                _ptr(halo_rows), _ptr(lidx), _ptr(kmask), _ptr(tbl), _ptr(col_order), _ptr(out_order), out.data_ptr(),
+                n_tgt, tile_rows, s_cap, part[0].data_ptr() if want_stats else None,
+                part[1].data_ptr() if want_stats else None, stream)), flops=2.0 * km.n_pairs * c_src * c_dst)
+        if want_stats:
+            _bn_partials_put(out, part, tile_rows)
         return out
     split, cfg = _conv_launch_cfg(km, target, n_tgt, c_src, c_dst, bf16)
     tile_rows, batch_groups, _, _, _, _, _, elems, p_src, p_dst, p_desc, p_bptr, p_order, fuse, split_k = cfg

@@ -1184,7 +1184,7 @@ using namespace me;
 
 extern "C" {
 
-int me_version(void) { return 140; }   // 100 * major + 10 * minor: see the changelog in include/me_amd.h
+int me_version(void) { return 150; }   // 100 * major + 10 * minor: see the changelog in include/me_amd.h
 const char *me_last_error(void) { return g_last_error; }
 
 int64_t me_region_volume(const me_region *rg) {

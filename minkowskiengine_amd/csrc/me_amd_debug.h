@@ -66,6 +66,12 @@ void me_debug_set_wgrad_mb(int mb);
 // bf16 weight gradient: 0 = k_wgrad_bf16 (default), 1 / 2 = the wave-specialised kernel with four / two row register sets (tuning build)
 void me_debug_set_wgrad_ws(int mode);
 
+/* halo kernel (conv_halo.hip): mode -1 policy / 0 never / 1 wherever instantiated; tile_rows 0 | 64 | 128; kc 0 | 32 | 64 |
+ * 96 | 128 (channels staged per pass); skip 0 = multiply every 16-row group.  Set before plans are made. */
+void me_debug_set_halo(int mode, int tile_rows, int kc, int skip);
+int32_t me_debug_halo_mode(void);
+int me_debug_halo_timing(uint64_t *out8, int32_t reset);   /* phase counters of a -DME_HALO_TIMING build */
+
 #ifdef __cplusplus
 }
 #endif

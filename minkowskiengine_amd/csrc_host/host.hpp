@@ -112,6 +112,8 @@ struct CoordMap {         // one coordinate map resident in HBM (replaces Coordi
   int spatial_state = 0;  // 0: not tried, 1: built, -1: not available
   std::shared_ptr<SpatialIndex> sp;
   std::shared_ptr<SpatialIndex> spatial();
+  Tensor zorder_rows;     // rows in Z-order (me_coords_spatial_keys + argsort), built on first use: the halo kernel's tiles
+  Tensor zorder();
 };
 
 struct InsertResult {
@@ -134,6 +136,13 @@ struct LazyOffsets {
 
 struct Plan {
   Tensor plan_src, plan_dst, batch_desc, tile_bptr, item_gptr;
+};
+// plan of the output-stationary bf16 kernel (csrc/conv_halo.hip, me_halo_plan_build): tiles of `tile_rows` target
+// positions, the distinct source rows of each (its halo, staged in LDS), local slots and group masks per offset
+struct HaloPlan {
+  int tile_rows = 0, s_cap = 0;
+  Tensor halo_cnt, halo_rows, lidx, kmask;
+  Tensor tbl, col_order, out_order;   // neighbour table; table column / target row of a tile position (may be undefined)
 };
 
 // Build requests a manager served, in order (the "recipe" a new scene's manager replays: CoordinateMapManager::prefetch).
@@ -159,6 +168,7 @@ struct ConvCfg {          // launch geometry of a (kernel map side, channel shap
   int64_t elems;
   bool fuse, split;
   int split_k = 1;        // offset groups of a split-K launch (bf16 features on small maps; 1: not split)
+  std::shared_ptr<HaloPlan> halo;   // set: the launch runs on the halo kernel (me_conv_halo_use_bf16), `plan` is unset
 };
 struct WgradCfg {
   std::vector<int64_t> koffs;
@@ -168,6 +178,7 @@ struct WgradCfg {
 struct KernelMapStore {   // buffers shared by a kernel map and its swapped view
   std::map<std::string, Tensor> t;
   std::map<std::string, std::shared_ptr<Plan>> plans;
+  std::map<std::string, std::shared_ptr<HaloPlan>> halos;   // (a null entry: no spatial order for this side)
 };
 
 struct KernelMap : std::enable_shared_from_this<KernelMap> {
@@ -194,6 +205,7 @@ struct KernelMap : std::enable_shared_from_this<KernelMap> {
   Tensor flat_order(const std::string &target, const std::string &tile_order);
   Tensor order(const std::string &target, const std::string &tile_order);
   std::shared_ptr<Plan> plan(const std::string &target, int tile_rows, int batch_groups, const std::string &tile_order);
+  std::shared_ptr<HaloPlan> halo_plan(const std::string &target, int tile_rows, int s_cap);
   const ConvCfg &conv_cfg(const std::string &target, int64_t n_tgt, int c_src, int c_dst, bool bf16);
   const WgradCfg &wgrad_cfg(int c_in, int c_out, bool bf16);
   pybind11::dict to_dict();

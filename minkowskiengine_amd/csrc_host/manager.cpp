@@ -402,6 +402,56 @@ std::shared_ptr<Plan> KernelMap::plan(const std::string &target, int tile_rows, 
   return p;
 }
 
+// Rows in Z-order (Morton keys of the coordinates in units of the tensor stride, batch index on top): runs of consecutive
+// entries are spatially compact at EVERY length — the supercell order of spatial() only down to a supercell.
+Tensor CoordMap::zorder() {
+  if (!zorder_rows.defined() && n > 0) {
+    const c10::Device dev = coords.device();
+    Tensor keys = at::empty({n}, at::TensorOptions().dtype(at::kLong).device(dev));
+    std::vector<int32_t> ts(tensor_stride.begin(), tensor_stride.end());
+    c10::DeviceGuard guard(dev);
+    me_ok(me_coords_spatial_keys(ptr<int32_t>(coords), n, (int32_t)coords.size(1), ts.data(), ptr<int64_t>(keys), stream_of(dev)));
+    zorder_rows = at::argsort(keys, /*stable=*/true, /*dim=*/0, /*descending=*/false).to(at::kInt);
+  }
+  return zorder_rows;
+}
+
+// Halo plan of a launch side (csrc/conv_halo.hip): tiles are runs of target rows in the Z-order of the target's
+// coordinate map (small halos); null when the side has no coordinate map attached.
+std::shared_ptr<HaloPlan> KernelMap::halo_plan(const std::string &target, int tile_rows, int s_cap) {
+  const std::string nm = name("halo", target) + "_" + std::to_string(tile_rows) + "_" + std::to_string(s_cap);
+  auto it = store->halos.find(nm);
+  if (it != store->halos.end()) return it->second;
+  RoctxRange rx("me:halo_plan");
+  const c10::Device dev = device();
+  const int64_t n_tgt = target == "out" ? n_out : n_in;
+  auto tp = table_pos(target);
+  auto h = std::make_shared<HaloPlan>();
+  h->tile_rows = tile_rows;
+  h->s_cap = s_cap;
+  h->tbl = tp.first;
+  auto cmap = target == "out" ? out_map : in_map;
+  if (cmap) h->out_order = cmap->zorder();
+  if (!h->out_order.defined() || h->out_order.numel() != n_tgt) {
+    store->halos[nm] = nullptr;
+    return nullptr;
+  }
+  // a position-space table (LDS-bucketed map build) is read through pos_of_row
+  h->col_order = tp.second.defined() ? store_get(*store, name("pos", target)).index({h->out_order.to(at::kLong)}).contiguous()
+                                     : h->out_order;
+  const int64_t tiles = me_halo_plan_num_tiles(n_tgt, tile_rows);
+  h->halo_cnt = empty_i32({tiles}, dev);
+  h->halo_rows = empty_i32({tiles * s_cap}, dev);
+  h->lidx = at::empty({tiles * volume * tile_rows}, at::TensorOptions().dtype(at::kShort).device(dev));
+  h->kmask = empty_i32({tiles * volume}, dev);
+  c10::DeviceGuard guard(dev);
+  me_ok(me_halo_plan_build(ptr<int32_t>(h->tbl), ptr<int32_t>(h->col_order), n_tgt, volume, tile_rows, s_cap,
+                           ptr<int32_t>(h->halo_cnt), ptr<int32_t>(h->halo_rows), ptr<uint16_t>(h->lidx),
+                           ptr<uint32_t>(h->kmask), stream_of(dev)));
+  store->halos[nm] = h;
+  return h;
+}
+
 static bool use_split(int c_src, int c_dst) {
   const Policy &p = Policy::get();
   if (p.f32_split == 0 || !me_conv_f32x3_supported(c_src, c_dst)) return false;
@@ -424,6 +474,21 @@ const ConvCfg &KernelMap::conv_cfg(const std::string &target, int64_t n_tgt, int
     me_ok((bf16 ? me_conv_plan_config_bf16 : (split ? me_conv_plan_config_f32x3 : me_conv_plan_config))(
         n_tgt, volume, np, c_src, c_dst, &t, &g));
   ConvCfg c;
+  if (bf16 && me_conv_halo_use_bf16(n_tgt, volume, np, c_src, c_dst)) {
+    // libme_amd's policy sends this launch side to the output-stationary kernel on an LDS-staged halo
+    int32_t ht = 0, hc = 0;
+    if (me_conv_halo_config_bf16(n_tgt, volume, np, c_src, c_dst, &ht, &hc)) c.halo = halo_plan(target, ht, hc);
+    if (c.halo) {
+      c.tile_rows = ht;
+      c.batch_groups = 0;
+      c.split = false;
+      c.fuse = false;
+      c.elems = me_conv_packed_weight_elems_bf16(volume, c_src, c_dst);
+      if (auto lg = log.lock())
+        lg->push_back("conv_cfg;" + log_key + ";" + target + ";" + std::to_string(c_src) + ";" + std::to_string(c_dst) + ";1");
+      return conv_cfgs.emplace(ck, std::move(c)).first->second;
+    }
+  }
   c.tile_rows = pol.tile_rows ? pol.tile_rows : t;
   c.batch_groups = pol.batch_groups ? pol.batch_groups : g;
   c.split = split;
@@ -986,6 +1051,13 @@ std::vector<Tensor> CoordinateMapManager::device_tensors() {
       collect(out, p.second->batch_desc);
       collect(out, p.second->tile_bptr);
       collect(out, p.second->item_gptr);
+    }
+    for (auto &h : km.store->halos) {
+      if (!h.second) continue;
+      collect(out, h.second->halo_cnt);
+      collect(out, h.second->halo_rows);
+      collect(out, h.second->lidx);
+      collect(out, h.second->kmask);
     }
   }
   for (auto &kv : origin_rows_cache) collect(out, kv.second);

@@ -306,11 +306,43 @@ static Tensor conv_target(const Tensor &src, const Tensor &kernel, KernelMap &km
     return out;
   }
   const ConvCfg &cfg = km.conv_cfg(target, n_tgt, c_src, c_dst, bf16);
-  const Plan &p = *cfg.plan;
   c10::DeviceGuard guard(dev);
   void *st = stream_of(dev);
   auto timed_name = transposed ? "conv_dgrad" : "conv_forward";
   const double flops = g_timing ? 2.0 * (double)km.n_pairs() * c_src * c_dst : 0.0;
+  if (cfg.halo) {
+    // output-stationary launch on the LDS-staged source halo (csrc/conv_halo.hip): the same packed weights; the
+    // batch-norm partials per halo tile
+    check(kernel.scalar_type() == at::kFloat || kernel.scalar_type() == at::kBFloat16, "kernel must be float32 or bfloat16");
+    const HaloPlan &h = *cfg.halo;
+    Tensor packed;
+    if (Policy::get().pack_cache) {
+      packed = packed_weights(kernel, ME_PACK_BF16, transposed, c_src, c_dst, cfg.elems);
+    } else {
+      packed = at::empty({cfg.elems}, at::TensorOptions().dtype(at::kBFloat16).device(dev));
+      me_ok(me_conv_pack_weights_bf16(kernel.data_ptr(), kernel.scalar_type() == at::kFloat ? 1 : 0, volume, c_src, c_dst,
+                                      transposed ? 1 : 0, ptr<uint16_t>(packed), st));
+    }
+    const bool want_stats = !transposed && target == "out" && g_conv_bn_stats_hint && conv_bn_stats_enabled();
+    Tensor part;
+    int64_t tiles = 0;
+    if (want_stats) {
+      tiles = (n_tgt + h.tile_rows - 1) / h.tile_rows;
+      part = at::empty({2, tiles, (int64_t)c_dst}, at::TensorOptions().dtype(at::kFloat).device(dev));
+    }
+    {
+      ScopedTimer tm(timed_name, flops, st);
+      me_ok(me_conv_halo_bf16(ptr<uint16_t>(src), src.size(0), c_src, ptr<uint16_t>(packed), km.volume, c_dst,
+                              ptr<int32_t>(h.halo_cnt), ptr<int32_t>(h.halo_rows), ptr<uint16_t>(h.lidx),
+                              ptr<uint32_t>(h.kmask), ptr<int32_t>(h.tbl), ptr<int32_t>(h.col_order),
+                              ptr<int32_t>(h.out_order), ptr<uint16_t>(out), n_tgt, h.tile_rows, h.s_cap,
+                              want_stats ? ptr<float>(part) : nullptr, want_stats ? ptr<float>(part) + tiles * c_dst : nullptr,
+                              st));
+    }
+    if (want_stats) bn_partials_put(out, part, h.tile_rows);
+    return out;
+  }
+  const Plan &p = *cfg.plan;
   if (bf16) {
     check(kernel.scalar_type() == at::kFloat || kernel.scalar_type() == at::kBFloat16, "kernel must be float32 or bfloat16");
     Tensor packed;

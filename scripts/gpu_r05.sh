@@ -1,0 +1,32 @@
+#!/bin/bash
+# round-5 GPU sessions: scripts/gpu_r05.sh <step> [args]; everything lands in gpurun_out/r05_<step>*.log
+set -u
+mkdir -p gpurun_out
+step=${1:-halo1}; shift || true
+case "$step" in
+  halo1)   # first contact of the halo kernel: parity tests, then the per-layer sweep
+    timeout 900 python -m pytest tests/test_gpu_halo.py -x -q 2>&1 | tail -25 > gpurun_out/r05_halo1_pytest.log
+    cat gpurun_out/r05_halo1_pytest.log
+    timeout 600 python scripts/halo_sweep.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r05_halo1_sweep.log
+    cat gpurun_out/r05_halo1_sweep.log
+    ;;
+  halo_prof)   # kernel durations of the sweep on one level (rocprofv3 --kernel-trace --stats)
+    cd /tmp && export TMPDIR=/tmp
+    LEVELS=${LEVELS:-8} REPS=5 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_halo -o halo -- python $GRAFT_REPO_ROOT/scripts/halo_sweep.py > $GRAFT_REPO_ROOT/gpurun_out/r05_halo_prof_sweep.log 2>&1
+    cd $GRAFT_REPO_ROOT
+    f=$(find /tmp/prof_halo -name "*kernel_stats.csv" | head -1)
+    python3 - "$f" > gpurun_out/r05_halo_prof_stats.txt <<'PY'
+import csv, sys
+for r in csv.reader(open(sys.argv[1])):
+    if len(r) >= 4 and ("me::" in r[0] or r[0] == "Name"):
+        print(r[0][:78].ljust(78), r[1].rjust(6), r[3][:9].rjust(10))
+PY
+    head -30 gpurun_out/r05_halo_prof_stats.txt
+    tail -8 gpurun_out/r05_halo_prof_sweep.log
+    ;;
+  halo_sweep)  # LEVELS / CONFIGS / TARGET from the environment
+    timeout 900 python scripts/halo_sweep.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r05_halo_sweep_${TAG:-x}.log
+    cat gpurun_out/r05_halo_sweep_${TAG:-x}.log
+    ;;
+  *) echo "unknown step $step"; exit 2;;
+esac
