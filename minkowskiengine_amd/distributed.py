@@ -24,13 +24,22 @@ def pick_backend(world, n_gpus=None):
     return "nccl" if n_gpus >= world and n_gpus > 0 else "gloo"
 
 
+_SINGLE_RANK_GROUP = [False]   # a one-rank process group was asked for by name: the collectives really run (see init_from_env)
+
+
 def init_from_env(backend=None):
     """Initialise the default process group from RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT
-    (as torch.distributed.run sets them).  Returns (rank, world_size, local_rank)."""
+    (as torch.distributed.run sets them).  Returns (rank, world_size, local_rank).
+    With WORLD_SIZE = 1 a group is only created when `backend` is NAMED ("nccl" | "gloo"): a one-rank RCCL group on a
+    one-GPU box — DistributedDataParallel's bucket hooks, MinkowskiSyncBatchNorm and the all-reduce calls then run
+    through librccl exactly as on N GPUs, with nobody to talk to (tests/test_gpu_rccl.py, `bench.py --gpus 1 --backend
+    nccl`); without a named backend a single rank stays free of torch.distributed."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world > 1 and not dist.is_initialized():
+    if world == 1 and backend is not None and not dist.is_initialized():
+        _SINGLE_RANK_GROUP[0] = True
+    if (world > 1 or _SINGLE_RANK_GROUP[0]) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -50,6 +59,11 @@ def world_size():
     return dist.get_world_size() if dist.is_initialized() else 1
 
 
+def exchange_active():
+    """True when collectives are to be issued: more than one rank, or a one-rank group created by name (init_from_env)"""
+    return dist.is_initialized() and (dist.get_world_size() > 1 or _SINGLE_RANK_GROUP[0])
+
+
 def backend_name():
     return dist.get_backend() if dist.is_initialized() else None
 
@@ -60,7 +74,7 @@ def shard_scenes(n_scenes, rank, world):
 
 
 def broadcast_parameters(module, src=0):
-    if world_size() == 1:
+    if not exchange_active():
         return
     # (p.detach() shares p's version counter, `p.data` does not: the weight-image cache of the convolutions is keyed
     # by it, so a broadcast into `.data` would leave stale packed weights on the receiving ranks)
@@ -77,8 +91,9 @@ def data_parallel(module, device=None, bucket_cap_mb=25, sync_batchnorm=False):
     """Wrap `module` for sample-sharded training: torch DistributedDataParallel (parameters broadcast from rank 0,
     gradients averaged in `bucket_cap_mb` buckets overlapped with the backward pass; few, large collectives suit
     the per-link-bound xGMI rings).  `sync_batchnorm` converts MinkowskiBatchNorm layers first, as the reference's
-    example does (examples/multigpu_ddp.py:95).  With one rank the module is returned unchanged."""
-    if world_size() == 1:
+    example does (examples/multigpu_ddp.py:95).  With one rank (and no group created by name) the module is returned
+    unchanged."""
+    if not exchange_active():
         return module
     if sync_batchnorm:
         from .layers import MinkowskiSyncBatchNorm
@@ -97,7 +112,7 @@ def allreduce_gradients(module, average=True, bucket_bytes=25 * 1024 * 1024):
     (a missing gradient counts as zeros and is materialised), buckets never mix dtypes, and the reduced values are
     always copied back into `.grad` (also for a single-tensor bucket and for non-contiguous gradients)."""
     w = world_size()
-    if w == 1:
+    if not exchange_active():
         return
     params = [p for p in module.parameters() if p.requires_grad]
     for p in params:
@@ -129,7 +144,7 @@ def allreduce_gradients(module, average=True, bucket_bytes=25 * 1024 * 1024):
 
 
 def _reduce_scalar(value, op, device):
-    if world_size() == 1:
+    if not exchange_active():
         return float(value)
     if device is None and backend_name() == "nccl":
         device = torch.device("cuda", torch.cuda.current_device())
@@ -150,7 +165,7 @@ def sum_over_ranks(value, device=None):
 def gather_over_ranks(value, device=None):
     """-> [value of rank 0, value of rank 1, ...] of a python float, on every rank"""
     w = world_size()
-    if w == 1:
+    if not exchange_active():
         return [float(value)]
     if device is None and backend_name() == "nccl":
         device = torch.device("cuda", torch.cuda.current_device())
@@ -177,9 +192,16 @@ def no_sync(module):
     accumulation windows); a no-op for an unwrapped module (one rank)"""
     import contextlib
     fn = getattr(module, "no_sync", None)
-    return fn() if callable(fn) and world_size() > 1 else contextlib.nullcontext()
+    return fn() if callable(fn) and exchange_active() else contextlib.nullcontext()
 
 
 def barrier():
-    if world_size() > 1:
+    if exchange_active():
         dist.barrier()
+
+
+def shutdown():
+    """destroy the default process group (if any) and forget a one-rank group created by name"""
+    if dist.is_initialized():
+        dist.destroy_process_group()
+    _SINGLE_RANK_GROUP[0] = False

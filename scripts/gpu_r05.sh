@@ -28,5 +28,29 @@ PY
     timeout 900 python scripts/halo_sweep.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r05_halo_sweep_${TAG:-x}.log
     cat gpurun_out/r05_halo_sweep_${TAG:-x}.log
     ;;
+  rccl)   # RCCL first contact + bench --gpus 1 --backend nccl (multi_gpu block) + the default bench line
+    timeout 900 python -m pytest tests/test_gpu_rccl.py tests/test_gpu_halo.py -x -q 2>&1 | tail -15 > gpurun_out/r05_rccl_pytest.log
+    cat gpurun_out/r05_rccl_pytest.log
+    timeout 600 python bench.py --gpus 1 --backend nccl --steps 20 --warmup 5 --cpu-budget 0 --pmc off > gpurun_out/r05_bench_nccl1.json 2> gpurun_out/r05_bench_nccl1.err
+    tail -3 gpurun_out/r05_bench_nccl1.err
+    python - <<'PY'
+import json
+l = json.loads(open("gpurun_out/r05_bench_nccl1.json").read().strip().splitlines()[-1])
+print("headline", l["value"], l["ms_per_step"], "multi_gpu", json.dumps(l.get("multi_gpu"))[:400])
+for k, w in (l.get("workloads") or {}).items():
+    print(k, {x: w.get(x) for x in ("value", "ms_per_step", "error")}, json.dumps(w.get("multi_gpu"))[:300], json.dumps(w.get("timing")), json.dumps(w.get("gpu_state")))
+PY
+    ;;
+  bench)   # the driver's command
+    timeout 900 python bench.py > gpurun_out/r05_bench_${TAG:-default}.json 2> gpurun_out/r05_bench_${TAG:-default}.err
+    tail -3 gpurun_out/r05_bench_${TAG:-default}.err
+    python - <<PY
+import json
+l = json.loads(open("gpurun_out/r05_bench_${TAG:-default}.json").read().strip().splitlines()[-1])
+print("headline", l["value"], l["ms_per_step"], l["roofline"]["frac"], l["roofline"].get("traffic"))
+for k, w in (l.get("workloads") or {}).items():
+    print(k, {x: w.get(x) for x in ("value", "ms_per_step", "error")}, json.dumps(w.get("hip_graph")), json.dumps(w.get("timing")), json.dumps(w.get("gpu_state")))
+PY
+    ;;
   *) echo "unknown step $step"; exit 2;;
 esac
