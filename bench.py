@@ -77,7 +77,7 @@ import torch  # noqa: E402
 
 def pmc_traffic(kernel, n, extent, cin, cout):
     """HBM-side bytes per launch of `kernel`: a CITED constant from the committed rocprofv3 --pmc passes
-    (profiles/pmc_traffic.json, collected with scripts/gpu_pmc_traffic.sh on this exact workload in their own
+    (profiles/pmc_traffic.json, collected with scripts/archive/gpu_pmc_traffic.sh on this exact workload in their own
     runs — PMC passes cannot share a run with the timed region), or None for any other workload."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:

@@ -23,6 +23,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* libme_amd.so is built with -fvisibility=hidden: the entry points declared in this header (and the test hooks of
+ * csrc/me_amd_debug.h) are its ONLY exported symbols — no C++ internals, no device stubs. */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 #define ME_MAX_DIM 7 /* spatial dimensions D; coordinates carry D+1 int32 (batch index first) */
 
@@ -669,6 +674,9 @@ int me_conv_backward_naive_f32(const float *in_feat_dev, int32_t c_in, const flo
                                int64_t volume, int64_t n_pairs, float *grad_in_dev,
                                float *grad_w_dev, void *stream);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

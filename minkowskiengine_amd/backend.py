@@ -21,6 +21,8 @@ import weakref
 import random
 import string
 
+import threading
+
 import torch
 
 from . import _lib
@@ -1086,6 +1088,13 @@ class CoordinateMapManagerGPU_c10:
         return self._kernel_map(in_key, out_key, kernel_size, kernel_stride, kernel_dilation, region_type,
                                 offset, is_transpose, is_pool).to_dict()
 
+    def print_coordinate_map(self, key):
+        """one map's line of __repr__ (manager_type::to_string(key), pybind/extern.hpp:777-779,
+        src/coordinate_map_manager.hpp:383-387)"""
+        k = self._k(key)
+        m = self._get(key)
+        return f"{list(k[0])}{':' + k[1] if k[1] else ''} : CoordinateMapGPU:{m.n}x{m.coords.shape[1]}"
+
     def __repr__(self):
         s = f"{self.__class__.__name__}(\n"
         for k, m in self._maps.items():
@@ -2042,7 +2051,18 @@ def _bn_check(x):
 # entry per live convolution output; consumed (popped) by the first bn_stats on it.
 _CONV_BN_STATS = os.environ.get("ME_AMD_CONV_BN_STATS", "1") != "0"
 _BN_PARTIALS = {}
-_BN_STATS_HINT = [False]     # set by the convolution module around its forward call: True in training mode
+class _ThreadFlag(threading.local):
+    """[0] of a per-thread flag (a loader thread never sees the training thread's value)"""
+    value = False
+
+    def __getitem__(self, i):
+        return self.value
+
+    def __setitem__(self, i, v):
+        self.value = v
+
+
+_BN_STATS_HINT = _ThreadFlag()     # set by the convolution module around its forward call: True in training mode
 
 
 def conv_bn_stats_hint(flag):

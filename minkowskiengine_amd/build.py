@@ -12,7 +12,9 @@ CSRC = os.path.join(HERE, "csrc")
 _TAG = os.environ.get("ME_AMD_LIB_TAG", "")
 OUT = os.path.join(HERE, f"libme_amd_{_TAG}.so" if _TAG else "libme_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+# -fvisibility=hidden: only what include/me_amd.h and csrc/me_amd_debug.h declare (under `#pragma GCC visibility
+# push(default)`) leaves the library — no C++-mangled internals, no device stubs
+CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
           "-Wno-unused-lambda-capture"]
 
 

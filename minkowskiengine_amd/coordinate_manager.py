@@ -196,5 +196,10 @@ class CoordinateManager:
         """MinkowskiCoordinateManager.py:334-335"""
         return self._manager.origin_map_size()
 
+    def print_coordinate_map(self, coordinate_map_key):
+        """the map's line of repr(manager) (MinkowskiCoordinateManager.py: `_manager.print_coordinate_map`,
+        pybind/extern.hpp:777-779)"""
+        return self._manager.print_coordinate_map(coordinate_map_key)
+
     def __repr__(self):
         return f"{self.__class__.__name__}(\n{self._manager!r}\n)"

@@ -8,6 +8,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
 /* 1 when the library was built with -DME_DEBUG_VARIANTS (phase counters, timing ablations whose RESULTS ARE INVALID,
  * the LDS-DMA experiment family); the default build does not contain those kernels. */
@@ -72,6 +75,9 @@ void me_debug_set_halo(int mode, int tile_rows, int kc, int skip);
 int32_t me_debug_halo_mode(void);
 int me_debug_halo_timing(uint64_t *out8, int32_t reset);   /* phase counters of a -DME_HALO_TIMING build */
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -4,6 +4,8 @@
 // MinkowskiConvolution.py:42-121; this is where its per-layer host time goes).
 #include <torch/csrc/autograd/custom_function.h>
 
+#include <sstream>
+
 #include "host.hpp"
 
 namespace py = pybind11;
@@ -280,6 +282,16 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
                                                          (c10::DeviceType)stream.attr("device_type").cast<int64_t>());
              py::gil_scoped_release nogil;
              for (const Tensor &t : s.device_tensors()) t.record_stream(st);
+           })
+      .def("print_coordinate_map",   // manager_type::to_string(key): pybind/extern.hpp:777-779
+           [](CoordinateMapManager &s, const CoordinateMapKey *key) {
+             const KeyT &k = keyt(key);
+             auto m = s.get(k);
+             std::ostringstream o;
+             o << "[";
+             for (size_t i = 0; i < k.first.size(); ++i) o << (i ? ", " : "") << k.first[i];
+             o << "]" << (k.second.empty() ? "" : ":" + k.second) << " : CoordinateMapGPU:" << m->n << "x" << m->coords.size(1);
+             return o.str();
            })
       .def("__repr__", &CoordinateMapManager::repr);
   m.attr("CoordinateMapManagerGPU_default") = m.attr("CoordinateMapManagerGPU_c10");

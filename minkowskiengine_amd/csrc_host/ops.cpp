@@ -246,7 +246,7 @@ struct BnPartials {
 };
 std::unordered_map<const void *, BnPartials> g_bn_partials;
 std::mutex g_bn_partials_mu;
-bool g_conv_bn_stats_hint = false;
+thread_local bool g_conv_bn_stats_hint = false;   // per thread: a loader thread (ScenePrefetcher) never sees the training thread's flag
 int g_conv_bn_stats_enabled = -1;   // -1: Policy (ME_AMD_CONV_BN_STATS), 0 / 1: set_conv_bn_stats (tests)
 
 void bn_partials_put(const Tensor &out, const Tensor &part, int tile_rows) {

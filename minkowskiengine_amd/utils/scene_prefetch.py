@@ -39,7 +39,6 @@ class ScenePrefetcher:
 
     def __iter__(self):
         from .. import SparseTensor, set_map_prefetch, map_prefetch_enabled
-        main = torch.cuda.current_stream()
         # a HIGH-priority stream: the builds are hundreds of microsecond-sized kernels with a handful of size read-backs
         # between them; behind the training stream's queue of full-chip convolutions each read-back would wait its turn
         side = self._side or torch.cuda.Stream(priority=-1)
@@ -66,11 +65,10 @@ class ScenePrefetcher:
                         feats, coords = item[0], item[1]
                         kwargs = item[2] if len(item) > 2 else {}
                         t = SparseTensor(feats, coords, **kwargs)
-                        t.coordinate_manager.record_stream(main)
                         ev = torch.cuda.Event()
                         ev.record(side)
                     self.build_ms.append((time.perf_counter() - t0) * 1e3)
-                    q.put((t, ev))
+                    q.put((t, ev, (feats, coords)))
                 q.put(None)
             except BaseException as e:   # handed to the consumer
                 q.put(e)
@@ -86,8 +84,20 @@ class ScenePrefetcher:
                     break
                 if isinstance(got, BaseException):
                     raise got
-                t, ev = got
-                torch.cuda.current_stream().wait_event(ev)
+                t, ev, handed = got
+                # Everything the scene holds was allocated (or last written) under the LOADER's stream: the feature
+                # matrix (features[unique_index], a segment reduction, a host-to-device copy of the iterator), the
+                # coordinates, the unique / inverse maps and the manager's maps and plans.  The consumer's stream — the
+                # one that is current HERE, not the one that was current when iteration began — waits for the build and
+                # is recorded on every one of them: when the consumer drops the scene while its own kernels are still
+                # queued, the caching allocator must not hand those blocks back to the loader's pool for the next
+                # scene's build (a cross-stream use-after-free with silent corruption: ADVICE r4).
+                cur = torch.cuda.current_stream()
+                cur.wait_event(ev)
+                t.coordinate_manager.record_stream(cur)
+                for x in (t._F, t._C, getattr(t, "unique_index", None), getattr(t, "inverse_mapping", None)) + tuple(handed):
+                    if isinstance(x, torch.Tensor) and x.is_cuda:
+                        x.record_stream(cur)
                 yield t
         finally:
             stop.set()

@@ -47,3 +47,43 @@ def test_prefetcher_hands_the_iterators_error_to_the_consumer(device):
     assert next(it).F.shape[0] <= 10
     with pytest.raises(ValueError):
         next(it)
+
+
+def test_scenes_dropped_while_the_consumer_stream_is_still_busy(device):
+    """ADVICE r4 (cross-stream use-after-free): the scene's feature matrix, coordinates and maps are allocated under the
+    LOADER's stream — here by host-to-device copies the iterator issues, as the docstring recommends.  The consumer queues
+    a long kernel, then the step on the scene, and drops the scene at once while all of that is still queued; the loader
+    immediately builds the next scenes.  Without record_stream on the scene's own tensors the caching allocator hands
+    their blocks back to the loader's pool and the next build overwrites them under the queued kernels."""
+    import minkowskiengine_amd as ME
+    import minkunet as MU
+    torch.manual_seed(0)
+    conv = ME.MinkowskiConvolution(16, 32, kernel_size=3, dimension=3).to(device)
+    n_scenes = 12
+    host = [(torch.rand(20000, 16).pin_memory(), MU.synthetic_scene(20000, grid=64, seed=s).pin_memory())
+            for s in range(n_scenes)]
+
+    def lazily(f, c):
+        with torch.no_grad():
+            return conv(ME.SparseTensor(f.to(device), c.to(device))).F.clone()
+    want = [lazily(f, c) for f, c in host]
+    torch.cuda.synchronize()
+
+    def scenes():                 # runs in the loader thread under the loader's stream: the copies allocate there
+        for f, c in host:
+            yield f.to(device, non_blocking=True), c.to(device, non_blocking=True)
+    busy = torch.rand(4096, 4096, device=device)
+    got = []
+    side = torch.cuda.Stream()    # the consumer is NOT on the stream that was current when iteration began
+    it = iter(ME.utils.ScenePrefetcher(scenes(), depth=3))
+    with torch.cuda.stream(side):
+        for x in it:
+            for _ in range(6):
+                busy = (busy @ busy).clamp_(-1, 1)           # ~ms of queued work ahead of the step
+            with torch.no_grad():
+                got.append(conv(x).F.clone())
+            del x                                            # dropped while everything above is still queued
+    torch.cuda.synchronize()
+    assert len(got) == n_scenes
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert torch.equal(a, b), f"scene {i} was corrupted"
