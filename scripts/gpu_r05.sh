@@ -52,5 +52,10 @@ for k, w in (l.get("workloads") or {}).items():
     print(k, {x: w.get(x) for x in ("value", "ms_per_step", "error")}, json.dumps(w.get("hip_graph")), json.dumps(w.get("timing")), json.dumps(w.get("gpu_state")))
 PY
     ;;
+  suite)   # the whole GPU suite + smoke
+    timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > gpurun_out/r05_pytest_gpu_${TAG:-x}.log
+    cat gpurun_out/r05_pytest_gpu_${TAG:-x}.log
+    timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke OK')" 2>&1 | tail -3 | tee gpurun_out/r05_smoke_${TAG:-x}.log
+    ;;
   *) echo "unknown step $step"; exit 2;;
 esac

@@ -130,8 +130,11 @@ def test_halo_conv_channel_chunks_agree(device, halo, kc):
     ref = _run_layer(device, coords, 128, 128, 3, seed=7)
     halo(1, 128, kc, 1)
     got = _run_layer(device, coords, 128, 128, 3, seed=7)
-    assert_bf16_close(got[2].F.detach().float().cpu().numpy(), ref[2].F.detach().float().cpu().numpy(), "forward")
-    assert_bf16_close(got[1].F.grad.float().cpu().numpy(), ref[1].F.grad.float().cpu().numpy(), "grad_in")
+    # (two results that are each within one bf16 ulp of the exact sums: up to two ulps apart)
+    for what, a, b in (("forward", got[2].F, ref[2].F), ("grad_in", got[1].F.grad, ref[1].F.grad)):
+        a, b = a.detach().double().cpu().numpy(), b.detach().double().cpu().numpy()
+        tol = 2.0 ** -7 * np.abs(b) + 2e-3 * max(1.0, np.abs(b).max())
+        assert not (np.abs(a - b) > tol).any(), (what, float(np.abs(a - b).max()))
 
 
 def test_halo_conv_overflowing_halo_takes_the_direct_path(device, halo):
