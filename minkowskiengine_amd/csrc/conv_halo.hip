@@ -120,12 +120,26 @@ __global__ __launch_bounds__(256) void k_halo_plan(const int32_t *__restrict__ t
 // ---- the convolution --------------------------------------------------------------------------------------------------------
 // T rows per tile; a workgroup is NWR x NWC waves: wave (wr, wc) owns R = T / 16 / NWR row groups x CB 16-column blocks.
 // KC: source channels staged per pass over the offsets.  SKIP: skip the MFMAs of 16-row groups without a neighbour.
-__host__ __device__ constexpr int halo_s_cap(int t) { return t <= 64 ? 319 : 511; }   // halo slots of a tile (+ the zero row)
+__host__ __device__ constexpr int halo_s_cap(int t) { return t <= 64 ? 319 : 479; }   // halo slots of a tile (+ the zero row)
+
+// LDS image of the halo: slot r (0 = the zero row) is a row of KC bf16; inside the row the 16-byte piece p of 32-channel
+// step s sits at s * 64 + ((p ^ z(r)) * 16) — the XOR only permutes the four pieces of a step, so that the STEP is a plain
+// immediate offset of the operand read and the lane's part of the address is one XOR (q * 16) on a per-slot word that is
+// computed once per tile (s_atab).  96-channel rows are padded to 224 bytes and not permuted.
+template <int KC>
+struct HaloLayout {
+  static constexpr int kRowBytes = KC == 96 ? 224 : KC * 2;
+  static constexpr bool kXor = KC != 96;
+  __host__ __device__ static constexpr int z(int r) { return kXor ? ((r >> (KC == 32 ? 2 : 1)) & 3) : 0; }
+  __host__ __device__ static constexpr int slot_word(int r) { return r * kRowBytes + z(r) * 16; }            // lane part: ^ (q * 16) | + q * 16
+  __host__ __device__ static constexpr int piece_off(int r, int u) { return r * kRowBytes + (u >> 2) * 64 + (((u & 3) ^ z(r)) * 16); }
+};
+__host__ __device__ constexpr int halo_row_bytes(int kc) { return kc == 96 ? 224 : kc * 2; }
 __host__ __device__ constexpr int halo_out_ld(int nc) { return nc + 8; }   // bf16 elements per row of the output image
 __host__ __device__ constexpr int conv_halo_lds(int t, int nc, int kc, int s_cap, int volume, int nt) {
-  const int halo = (s_cap + 1) * x3_stage_ld(kc) * 2;
+  const int halo = (s_cap + 1) * halo_row_bytes(kc);
   const int outb = t * halo_out_ld(nc) * 2 + (nt / (nc / 4)) * (nc / 4) * 8 * 4;
-  return (halo > outb ? halo : outb) + volume * t * 2 + 64 * 4 + s_cap * 4;
+  return (halo > outb ? halo : outb) + volume * t * 4 + 64 * 4 + s_cap * 4;
 }
 
 // waves per SIMD the register budget is sized for: two workgroups per CU unless the two weight sets of a deep chunk need more
@@ -146,30 +160,30 @@ __device__ unsigned long long d_halo_timing[8];
 #endif
 
 template <int T, int CB, int NWC, int NWR, int KC, bool SKIP, int WD>
-__global__ __launch_bounds__(64 * NWC * NWR, WD == 4 ? 1 : halo_min_waves(T, KC)) void k_conv_halo_bf16(
+__global__ __launch_bounds__(64 * NWC * NWR, 1) void k_conv_halo_bf16(
     const __bf16 *__restrict__ src, int c_src, const bf16x8 *__restrict__ wp, int ksp, int nchp, int ncb, int c_dst,
     const int32_t *__restrict__ halo_cnt, const int32_t *__restrict__ halo_rows, const uint16_t *__restrict__ lidx,
     const uint32_t *__restrict__ kmask, const int32_t *__restrict__ tbl, const int32_t *__restrict__ col_order,
     const int32_t *__restrict__ out_order, __bf16 *__restrict__ dst, int64_t n_tgt, int volume, int s_cap,
     float *__restrict__ stat_mean, float *__restrict__ stat_m2) {
-  typedef StageLayout<KC> SL;
+  typedef HaloLayout<KC> HL;
   constexpr int NT = 64 * NWC * NWR;
   constexpr int NC = CB * 16 * NWC;
   constexpr int R = T / 16 / NWR;
   constexpr int KS = KC / 32;
   constexpr int F8 = KC / 8;
-  constexpr int LD = SL::kLd;
+  constexpr int RS = HL::kRowBytes;
   constexpr int OLD = halo_out_ld(NC);
   static_assert(T % (16 * NWR) == 0 && R >= 1 && R <= 16, "row groups per wave");
   static_assert(NT % (NC / 4) == 0, "threads per output row");
 
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int halo_bytes = (s_cap + 1) * LD * 2;
+  extern __shared__ __attribute__((aligned(128))) char smem[];
+  const int halo_bytes = (s_cap + 1) * RS;
   constexpr int OUT_BYTES = T * OLD * 2 + (NT / (NC / 4)) * (NC / 4) * 8 * 4;
   const int region = halo_bytes > OUT_BYTES ? halo_bytes : OUT_BYTES;
-  __bf16 *s_halo = reinterpret_cast<__bf16 *>(smem);
-  uint16_t *s_lidx = reinterpret_cast<uint16_t *>(smem + region);            // [volume][T]
-  uint32_t *s_kmask = reinterpret_cast<uint32_t *>(smem + region + volume * T * 2);   // [<= 64]
+  char *s_halo = smem;
+  uint32_t *s_atab = reinterpret_cast<uint32_t *>(smem + region);            // [volume][T]: LDS address word of the slot
+  uint32_t *s_kmask = reinterpret_cast<uint32_t *>(smem + region + volume * T * 4);   // [<= 64]
   int32_t *s_hrow = reinterpret_cast<int32_t *>(s_kmask + 64);                         // [s_cap] source rows of the halo
 
   const int tid = threadIdx.x;
@@ -186,13 +200,22 @@ __global__ __launch_bounds__(64 * NWC * NWR, WD == 4 ? 1 : halo_min_waves(T, KC)
   const int S = min(s_tot, s_cap);
   constexpr uint32_t RM = R >= 32 ? 0xffffffffu : ((1u << R) - 1u);
 
+  typedef __attribute__((address_space(3))) const char lds_char;
+  const unsigned halo_addr = (unsigned)(uintptr_t)(lds_char *)reinterpret_cast<const char *>(s_halo);   // (a multiple of 128)
   {
-    const uint4 *g = reinterpret_cast<const uint4 *>(lidx + tile * volume * T);
-    uint4 *l = reinterpret_cast<uint4 *>(s_lidx);
-    for (int x = tid; x < volume * T / 8; x += NT) l[x] = g[x];
+    // slot -> the LDS address word of its row (halo base + row + permutation), once per tile: the walk's operand address
+    // is this word ^ (q * 16) [+ q * 16 for the padded 96-channel rows] with the step as an immediate offset
+    const uint16_t *g = lidx + tile * volume * T;
+    for (int x = tid; x < volume * T; x += NT) {
+#if defined(ME_HALO_ABL) && ME_HALO_ABL == 1   // timing ablation (results invalid): every lane reads the zero row — no bank conflicts
+      s_atab[x] = halo_addr;
+#else
+      s_atab[x] = halo_addr + (unsigned)HL::slot_word((int)g[x]);
+#endif
+    }
     if (tid < 64) s_kmask[tid] = tid < volume ? kmask[tile * volume + tid] : 0u;
     for (int x = tid; x < S; x += NT) s_hrow[x] = halo_rows[tile * s_cap + x];
-    if (tid < F8) *reinterpret_cast<bf16x8 *>(s_halo + SL::off(0, tid)) = zero8();
+    if (tid < F8) *reinterpret_cast<bf16x8 *>(s_halo + HL::piece_off(0, tid)) = zero8();
   }
   __syncthreads();
   uint32_t act = 0u;   // offsets at which this wave's rows have a neighbour
@@ -233,24 +256,38 @@ __global__ __launch_bounds__(64 * NWC * NWR, WD == 4 ? 1 : halo_min_waves(T, KC)
     // reads), then `s_waitcnt vmcnt(KS * CB)` — this offset's weights, requested one offset ago — then operand reads
     // and MFMAs (compiler-scheduled: its own LDS waits stay correct next to the older asm reads, LDS returns in order).
     const unsigned lane16 = (unsigned)lane * 16u;
-    typedef __attribute__((address_space(3))) const char lds_char;
-    const unsigned lidx_addr = (unsigned)(uintptr_t)(lds_char *)reinterpret_cast<const char *>(s_lidx) + (unsigned)((rb + i16) * 2);
-    auto issue_w = [&](int chunk, int k, bf16x8 (&wd)[KS][CB]) {
+    const unsigned atab_addr = (unsigned)(uintptr_t)(lds_char *)reinterpret_cast<const char *>(s_atab) + (unsigned)((rb + i16) * 4);
+    const unsigned kmask_addr = (unsigned)(uintptr_t)(lds_char *)reinterpret_cast<const char *>(s_kmask);
+    const unsigned qx = (unsigned)q * 16u;
+    // weight image: byte offset of fragment (k, chunk, s, c) = k * w_stride_k + w_frag[s][c]; the k part goes into the scalar
+    // base of the load, the rest (+ this lane's 16 bytes) is a per-chunk vector offset: no address arithmetic per load
+    const int64_t w_stride_k = (int64_t)nchp * ncb * ksp * 1024;
+    unsigned w_voff[KS][CB];
+    auto set_chunk = [&](int chunk) {
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
         const int a = chunk * KS + s;
         const int cpk = a / ksp, v = a - cpk * ksp;
 #pragma unroll
-        for (int c = 0; c < CB; ++c) {
-          const bf16x8 *base = wp + ((((int64_t)k * nchp + cpk) * ncb + min(cb0 + c, ncb - 1)) * ksp + v) * 64;
-          asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(wd[s][c]) : "v"(lane16), "s"(base) : "memory");
-        }
+        for (int c = 0; c < CB; ++c) w_voff[s][c] = lane16 + (unsigned)(((cpk * ncb + min(cb0 + c, ncb - 1)) * ksp + v) * 1024);
       }
     };
-    auto issue_li = [&](int k, int (&li)[R]) {
-      const unsigned a0 = lidx_addr + (unsigned)(k * T * 2);
+    auto issue_w = [&](int k, bf16x8 (&wd)[KS][CB]) {
+      const char *base = reinterpret_cast<const char *>(wp) + (int64_t)k * w_stride_k;
 #pragma unroll
-      for (int g = 0; g < R; ++g) asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(li[g]) : "v"(a0), "n"(g * 32) : "memory");
+      for (int s = 0; s < KS; ++s) {
+#pragma unroll
+        for (int c = 0; c < CB; ++c)
+          asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(wd[s][c]) : "v"(w_voff[s][c]), "s"(base) : "memory");
+      }
+    };
+    // the next offset's slot words (R reads) and its group mask (one broadcast read)
+    auto issue_li = [&](int k, unsigned (&li)[R], unsigned &mk) {
+      const unsigned a0 = atab_addr + (unsigned)(k * T * 4);
+#pragma unroll
+      for (int g = 0; g < R; ++g) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(li[g]) : "v"(a0), "n"(g * 64) : "memory");
+      const unsigned am = kmask_addr + (unsigned)(k * 4);
+      asm volatile("ds_read_b32 %0, %1" : "=v"(mk) : "v"(am) : "memory");
     };
     auto wait_w = [&](bf16x8 (&w)[KS][CB], auto younger) {
 #pragma unroll
@@ -259,30 +296,22 @@ __global__ __launch_bounds__(64 * NWC * NWR, WD == 4 ? 1 : halo_min_waves(T, KC)
         for (int c = 0; c < CB; ++c) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(w[s][c]) : "n"(decltype(younger)::value) : "memory");
       }
     };
-    auto wait_li = [&](int (&li)[R]) {
+    auto wait_li = [&](unsigned (&li)[R], unsigned &mk) {
 #pragma unroll
       for (int g = 0; g < R; ++g) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(li[g]) : : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(mk) : : "memory");
     };
-    const char *hb = reinterpret_cast<const char *>(s_halo);
-    // byte address (inside the image) of this lane's piece of 32-channel step 0 of halo slot `slot`
-    auto piece0 = [&](int slot) {
-#if defined(ME_HALO_ABL) && ME_HALO_ABL == 1   // timing ablation (results invalid): every lane reads the zero row — no bank conflicts
-      slot = 0;
-#endif
-      if constexpr (SL::kSwizzled) return slot * (LD * 2) + ((q ^ SL::swz(slot)) * 16);
-      else return slot * (LD * 2) + q * 16;
-    };
-    auto step_off = [&](int a0, int s) {   // ... of step s: piece (s * 4 + q) ^ swz = (q ^ swz) ^ (s * 4) (swz < 4 * KS)
-      if constexpr (SL::kSwizzled) return a0 ^ (s * 64);
-      else return a0 + s * 64;
-    };
-    const unsigned halo_addr = (unsigned)(uintptr_t)(lds_char *)reinterpret_cast<const char *>(s_halo);
-    auto issue_x = [&](const int (&a0)[R], int s, bf16x8 (&x)[R]) {
+    auto lane_part = [&](unsigned (&li)[R]) {
 #pragma unroll
-      for (int g = 0; g < R; ++g) {
-        const unsigned a = halo_addr + (unsigned)step_off(a0[g], s);
-        asm volatile("ds_read_b128 %0, %1" : "=v"(x[g]) : "v"(a) : "memory");
-      }
+      for (int g = 0; g < R; ++g) li[g] = HL::kXor ? (li[g] ^ qx) : (li[g] + qx);
+    };
+    auto group_mask = [&](unsigned mk) {
+      return SKIP ? (uint32_t)__builtin_amdgcn_readfirstlane((int)((mk >> (wr * R)) & RM)) : RM;
+    };
+    auto issue_x = [&](const unsigned (&a0)[R], auto s_, bf16x8 (&x)[R]) {
+#pragma unroll
+      for (int g = 0; g < R; ++g)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(x[g]) : "v"(a0[g]), "n"(decltype(s_)::value * 64) : "memory");
     };
     auto wait_x = [&](bf16x8 (&x)[R], auto younger) {
 #pragma unroll
@@ -295,46 +324,52 @@ __global__ __launch_bounds__(64 * NWC * NWR, WD == 4 ? 1 : halo_min_waves(T, KC)
     // requested first; every step requests the operands of the step after it — the LAST one those of the next offset's
     // step 0, once its slots have landed — before it multiplies: an LDS round trip is always one step ahead of its use.
     using NWV = std::integral_constant<int, ((WD - 1) * KS * CB > 63 ? 63 : (WD - 1) * KS * CB)>;   // weight loads that may stay in flight
-    auto offset_step = [&](auto p0_, int chunk, int kn, int kw, const bf16x8 (&wC)[KS][CB], bf16x8 (&wN)[KS][CB],
-                           const int (&aC)[R], int (&aN)[R]) {
+    auto offset_step = [&](auto p0_, int kn, int kw, const bf16x8 (&wC)[KS][CB], bf16x8 (&wN)[KS][CB], const unsigned (&aC)[R],
+                           unsigned (&aN)[R], unsigned mC, unsigned &mN) {
       constexpr int P0 = decltype(p0_)::value;
-      issue_w(chunk, kw, wN);
-      if constexpr (KS == 1) issue_li(kn, aN);
-#pragma unroll
-      for (int s = 0; s < KS; ++s) {
+      const uint32_t m = group_mask(mC);     // 16-row groups of this wave with a neighbour at this offset
+      issue_w(kw, wN);
+      if constexpr (KS == 1) issue_li(kn, aN, mN);
+      auto step = [&](auto s_) {
+        constexpr int s = decltype(s_)::value;
         bf16x8(&xc)[R] = xb[(P0 + s) & 1];
         bf16x8(&xn)[R] = xb[(P0 + s + 1) & 1];
-        if (s + 1 < KS) {
-          issue_x(aC, s + 1, xn);
-          if (s == 0) {
-            issue_li(kn, aN);           // (the youngest LDS requests: the wait below does not cover them)
+        if constexpr (s + 1 < KS) {
+          issue_x(aC, std::integral_constant<int, (s + 1 < KS ? s + 1 : 0)>{}, xn);
+          if constexpr (s == 0) {
+            issue_li(kn, aN, mN);       // (the youngest LDS requests: the wait below does not cover them)
             wait_w(const_cast<bf16x8(&)[KS][CB]>(wC), NWV{});
-            wait_x(xc, std::integral_constant<int, (2 * R > 15 ? 15 : 2 * R)>{});
+            wait_x(xc, std::integral_constant<int, (2 * R + 1 > 15 ? 15 : 2 * R + 1)>{});
           } else {
             wait_x(xc, NR{});
           }
         } else {
-          wait_li(aN);                  // lgkmcnt(0): this step's operands and the next offset's slots
-#pragma unroll
-          for (int g = 0; g < R; ++g) aN[g] = piece0(aN[g]);
-          issue_x(aN, 0, xn);
-          if (s == 0) wait_w(const_cast<bf16x8(&)[KS][CB]>(wC), NWV{});
+          wait_li(aN, mN);              // lgkmcnt(0): this step's operands and the next offset's slot words
+          lane_part(aN);
+          issue_x(aN, std::integral_constant<int, 0>{}, xn);
+          if constexpr (s == 0) wait_w(const_cast<bf16x8(&)[KS][CB]>(wC), NWV{});
           wait_x(xc, NR{});
         }
         __builtin_amdgcn_sched_barrier(0);   // (hipcc otherwise sinks this step's MFMAs behind the NEXT step's waits)
 #pragma unroll
-        for (int c = 0; c < CB; ++c) {
+        for (int g = 0; g < R; ++g) {
+          if (!SKIP || ((m >> g) & 1u)) {    // (uniform: groups without a neighbour at this offset multiply nothing)
 #pragma unroll
-          for (int g = 0; g < R; ++g) {
+            for (int c = 0; c < CB; ++c) {
 #if defined(ME_HALO_ABL) && ME_HALO_ABL == 2   // timing ablation (results invalid): no MFMAs
-            asm volatile("" : "+v"(acc[g][c]) : "v"(wC[s][c]), "v"(xc[g]));
+              asm volatile("" : "+v"(acc[g][c]) : "v"(wC[s][c]), "v"(xc[g]));
 #else
-            acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wC[s][c], xc[g], acc[g][c], 0, 0, 0);
+              acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wC[s][c], xc[g], acc[g][c], 0, 0, 0);
 #endif
+            }
           }
         }
         __builtin_amdgcn_sched_barrier(0);
-      }
+      };
+      step(std::integral_constant<int, 0>{});
+      if constexpr (KS > 1) step(std::integral_constant<int, 1>{});
+      if constexpr (KS > 2) step(std::integral_constant<int, 2>{});
+      if constexpr (KS > 3) step(std::integral_constant<int, 3>{});
     };
     ME_HT(0);
     for (int chunk = 0; chunk < nchunks; ++chunk) {
@@ -352,7 +387,7 @@ __global__ __launch_bounds__(64 * NWC * NWR, WD == 4 ? 1 : halo_min_waves(T, KC)
 #pragma unroll
         for (int j = 0; j < NPB; ++j) {
           const int x = x0 + j * NT + tid;
-          if (x < S * F8) *reinterpret_cast<bf16x8 *>(s_halo + SL::off(x / F8 + 1, x % F8)) = v[j];
+          if (x < S * F8) *reinterpret_cast<bf16x8 *>(s_halo + HL::piece_off(x / F8 + 1, x % F8)) = v[j];
         }
       }
       __syncthreads();
@@ -363,7 +398,7 @@ __global__ __launch_bounds__(64 * NWC * NWR, WD == 4 ? 1 : halo_min_waves(T, KC)
         // the round trips).  `rw` walks WD - 1 offsets ahead of `rn`; behind the last offset the last one is requested
         // again, so that the counted waits stay the same.
         bf16x8 wr[WD][KS][CB];
-        int aA[R], aB[R];
+        unsigned aA[R], aB[R], mA, mB;
         uint32_t rn = act, rw = act;
         int k_last = 31 - __builtin_clz(act);
         auto pop = [&](uint32_t &r) {
@@ -373,23 +408,23 @@ __global__ __launch_bounds__(64 * NWC * NWR, WD == 4 ? 1 : halo_min_waves(T, KC)
         };
         int n_left = __builtin_popcount(act);
         pop(rn);   // (the first offset)
+        set_chunk(chunk);
 #pragma unroll
-        for (int j = 0; j < WD - 1; ++j) issue_w(chunk, pop(rw), wr[j]);
-        issue_li(__builtin_ctz(act), aA);
-        wait_li(aA);
-#pragma unroll
-        for (int g = 0; g < R; ++g) aA[g] = piece0(aA[g]);
-        issue_x(aA, 0, xb[0]);
+        for (int j = 0; j < WD - 1; ++j) issue_w(pop(rw), wr[j]);
+        issue_li(__builtin_ctz(act), aA, mA);
+        wait_li(aA, mA);
+        lane_part(aA);
+        issue_x(aA, std::integral_constant<int, 0>{}, xb[0]);
         static_assert(WD == 2 || WD == 4, "weight sets");
         for (;;) {
-          offset_step(std::integral_constant<int, 0>{}, chunk, pop(rn), pop(rw), wr[0], wr[(0 + WD - 1) % WD], aA, aB);
+          offset_step(std::integral_constant<int, 0>{}, pop(rn), pop(rw), wr[0], wr[(0 + WD - 1) % WD], aA, aB, mA, mB);
           if (--n_left == 0) break;
-          offset_step(std::integral_constant<int, KS & 1>{}, chunk, pop(rn), pop(rw), wr[1], wr[(1 + WD - 1) % WD], aB, aA);
+          offset_step(std::integral_constant<int, KS & 1>{}, pop(rn), pop(rw), wr[1], wr[(1 + WD - 1) % WD], aB, aA, mB, mA);
           if (--n_left == 0) break;
           if constexpr (WD == 4) {
-            offset_step(std::integral_constant<int, 0>{}, chunk, pop(rn), pop(rw), wr[2], wr[1], aA, aB);
+            offset_step(std::integral_constant<int, 0>{}, pop(rn), pop(rw), wr[2], wr[1], aA, aB, mA, mB);
             if (--n_left == 0) break;
-            offset_step(std::integral_constant<int, KS & 1>{}, chunk, pop(rn), pop(rw), wr[3], wr[2], aB, aA);
+            offset_step(std::integral_constant<int, KS & 1>{}, pop(rn), pop(rw), wr[3], wr[2], aB, aA, mB, mA);
             if (--n_left == 0) break;
           }
         }
@@ -654,12 +689,14 @@ static int launch_halo(const HaloShape &hs, const __bf16 *src, int c_src, const 
   typedef void (*kernel_t)(const __bf16 *, int, const bf16x8 *, int, int, int, int, const int32_t *, const int32_t *,
                            const uint16_t *, const uint32_t *, const int32_t *, const int32_t *, const int32_t *, __bf16 *,
                            int64_t, int, int, float *, float *);
-  const int wd = (g_halo_wd == 2 || g_halo_wd == 4) ? g_halo_wd : 4;
-  kernel_t fn = wd == 4 ? &k_conv_halo_bf16<T, CB, NWC, NWR, KC, true, 4> : &k_conv_halo_bf16<T, CB, NWC, NWR, KC, true, 2>;
-  static bool attr_set[2] = {false, false};
-  if (lds > 48 * 1024 && !attr_set[wd == 4 ? 1 : 0]) {
+  const int wd = (g_halo_wd == 2 || g_halo_wd == 4) ? g_halo_wd : 2;
+  const int which = !g_halo_skip ? 2 : (wd == 4 ? 1 : 0);
+  kernel_t fn = which == 2 ? &k_conv_halo_bf16<T, CB, NWC, NWR, KC, false, 2>
+                           : (which == 1 ? &k_conv_halo_bf16<T, CB, NWC, NWR, KC, true, 4> : &k_conv_halo_bf16<T, CB, NWC, NWR, KC, true, 2>);
+  static bool attr_set[3] = {false, false, false};
+  if (lds > 48 * 1024 && !attr_set[which]) {
     ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBudget));
-    attr_set[wd == 4 ? 1 : 0] = true;
+    attr_set[which] = true;
   }
   ME_CHECK(lds <= kLdsBudget, "halo kernel: LDS budget");
   const dim3 grid((unsigned)ceil_div(n_tgt, T), (unsigned)ceil_div(c_dst, NC));

@@ -190,9 +190,9 @@ def test_halo_conv_batch_norm_partials(device, halo):
     """the tile statistics the halo kernel leaves behind give the batch norm the mean / variance of the stored matrix"""
     import minkowskiengine_amd as ME
     halo(1, 128, 0, 1)
-    coords = make_cloud(5000, 16, 3, seed=4)
+    coords = make_cloud(5000, 20, 3, seed=4)
     g = torch.Generator().manual_seed(0)
-    feats = bf16_round(torch.rand(5000, 64, generator=g) - 0.4)
+    feats = bf16_round(torch.rand(coords.shape[0], 64, generator=g) - 0.4)
     for host in ("python", "native"):
         prev = ME.get_host()
         ME.set_host(host)
