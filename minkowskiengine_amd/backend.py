@@ -1279,6 +1279,34 @@ def _conv_launch_cfg(km, target, n_tgt, c_src, c_dst, bf16):
     return split, cfg
 
 
+# gradient destinations (distributed.GradientArena; csrc_host/ops.cpp twin): parameter storage address -> the fp32 buffer
+# its gradient is written into (a slice of one flat all-reduce buffer)
+_GRAD_DEST = {}
+
+
+def set_grad_destination(param, dest):
+    if dest is None:
+        _GRAD_DEST.pop(param.data_ptr(), None)
+    else:
+        _GRAD_DEST[param.data_ptr()] = dest
+
+
+def clear_grad_destinations():
+    _GRAD_DEST.clear()
+
+
+def _grad_destination(param, shape):
+    """a FRESH alias of the registered buffer in `shape` (autograd takes a gradient without a copy only when nobody else
+    holds the tensor object), or None"""
+    d = _GRAD_DEST.get(param.data_ptr()) if param is not None else None
+    n = 1
+    for v in shape:
+        n *= int(v)
+    if d is None or d.dtype != torch.float32 or d.numel() != n or d.device != param.device:
+        return None
+    return d.view(tuple(shape))
+
+
 def _halo_launch_cfg(km, target, n_tgt, c_src, c_dst):
     """Halo plan (csrc/conv_halo.hip) of a launch side when libme_amd's policy (me_conv_halo_use_bf16: ME_AMD_HALO, shape,
     density) sends it to the output-stationary kernel, else None -> the tile-plan kernels.  Tiles are runs of target
@@ -1651,7 +1679,9 @@ def _conv_backward(in_feat, grad_out, kernel, km, algo=None, need_grad_in=True):
     # inside this call (side waits for what the current stream has produced; the current stream waits for the side
     # stream before anything downstream can touch grad_w), so callers — autograd's AccumulateGrad, DDP's bucket
     # hooks, a hipGraph capture — see plain stream-ordered tensors.
-    grad_w = torch.empty(kernel.shape, dtype=torch.float32, device=dev)
+    grad_w = _grad_destination(kernel, kernel.shape) if kernel.dtype == torch.float32 else None
+    if grad_w is None:
+        grad_w = torch.empty(kernel.shape, dtype=torch.float32, device=dev)
     cfg = _wgrad_launch_cfg(km, c_in, c_out, bf16)
     koffs, wsb, p_in, p_out, p_koffs = cfg
     if _WGRAD_TUNING:   # the debug switches change the workspace need
@@ -2190,8 +2220,9 @@ def bn_backward_residual(x, dy, yout, mean, rstd, gamma, beta=None, relu=True, n
     dy = dy.contiguous()
     dx = torch.empty_like(x)
     dskip = torch.empty_like(x) if (need_dskip and relu) else None
-    gg = torch.empty(c, dtype=torch.float32, device=dev)
-    gb = torch.empty(c, dtype=torch.float32, device=dev)
+    gg, gb = _grad_destination(gamma, (c,)), _grad_destination(beta, (c,))
+    gg = torch.empty(c, dtype=torch.float32, device=dev) if gg is None else gg
+    gb = torch.empty(c, dtype=torch.float32, device=dev) if gb is None else gb
     ws = _workspace(int(lib.me_bn_workspace_bytes(n, c)), dev)
     with _on(dev):
         _lib.check(lib.me_bn_backward_residual(_ptr(x), _ptr(dy), _ptr(yout), 1 if x.dtype == torch.bfloat16 else 0, n,
@@ -2212,8 +2243,9 @@ def bn_backward(x, dy, mean, rstd, gamma, beta=None, relu=False):
         dy = dy.to(x.dtype)
     dy = dy.contiguous()
     dx = torch.empty_like(x)
-    gg = torch.empty(c, dtype=torch.float32, device=dev)
-    gb = torch.empty(c, dtype=torch.float32, device=dev)
+    gg, gb = _grad_destination(gamma, (c,)), _grad_destination(beta, (c,))
+    gg = torch.empty(c, dtype=torch.float32, device=dev) if gg is None else gg
+    gb = torch.empty(c, dtype=torch.float32, device=dev) if gb is None else gb
     ws = _workspace(int(lib.me_bn_workspace_bytes(n, c)), dev)
     with _on(dev):
         _lib.check(lib.me_bn_backward(_ptr(x), _ptr(dy), 1 if x.dtype == torch.bfloat16 else 0, n, c, _ptr(mean),

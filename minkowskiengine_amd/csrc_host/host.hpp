@@ -294,6 +294,11 @@ Tensor pruning_forward(const Tensor &in_feat, const Tensor &keep, CoordinateMapK
 Tensor pruning_backward(const Tensor &grad_out, CoordinateMapKey *in_key, CoordinateMapKey *out_key,
                         CoordinateMapManager *mgr);
 
+// gradient destinations (ops.cpp; distributed.GradientArena): parameter -> the buffer its gradient is written into
+void set_grad_destination(const Tensor &param, const Tensor &dest);   // dest undefined: forget it
+void clear_grad_destinations();
+Tensor grad_destination(const Tensor &param, at::IntArrayRef shape);
+
 // batch normalisation over feature rows (csrc/norm.hip)
 void conv_bn_stats_hint(bool flag);   // the convolution module's training flag (a training-mode batch norm may follow)
 void set_conv_bn_stats(int enabled);  // -1: ME_AMD_CONV_BN_STATS, 0 / 1: override (tests)

@@ -143,6 +143,100 @@ def allreduce_gradients(module, average=True, bucket_bytes=25 * 1024 * 1024):
     flush()
 
 
+class GradientArena:
+    """Gradients that are BORN in their all-reduce buffer (MI355X-first alternative to torch DDP for this engine).
+
+    DistributedDataParallel hooks every parameter, copies every gradient into a bucket view and synchronises its
+    communication stream with the backward pass bucket by bucket: on a step that is already bound by its ~900 kernel
+    launches that machinery costs 1.7 ms of a 12.1 ms MinkUNet34C step on ONE rank, where the all-reduce itself is free
+    (bench.py --gpus 1 --backend nccl: multi_gpu.allreduce_ms.exposed_in_step; scripts/ddp_overhead.py).  Here every
+    parameter owns a slice of ONE flat fp32 buffer per device; the host layers hand that slice to the kernels that produce
+    the gradient (weight gradient of a convolution, weight / bias gradient of a batch norm: host.set_grad_destination), so
+    autograd receives an alias of the slice and keeps it as `p.grad` without a copy; gradients produced by other operators
+    are copied in by one multi-tensor launch.  The exchange is ONE RCCL all-reduce per buffer after the backward pass — 151 MB
+    for MinkUNet34C: ~1 ms on an 8-GPU xGMI ring, the size few-large-collectives rings like — and the average is folded into
+    the same buffer.  Same arithmetic as DDP's: sum over ranks in RCCL's ring order, one division.
+
+        arena = D.GradientArena(model)          # after model.to(device); parameters are broadcast from rank 0
+        for x, y in data:
+            arena.zero_grad()                    # p.grad = None (the slices are overwritten, not accumulated into)
+            loss(model(x), y).backward()
+            arena.all_reduce()                   # no-op without a process group
+            optimizer.step()
+    """
+
+    def __init__(self, module, average=True, broadcast=True):
+        from . import host
+        self.average = average
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        self._flat, self._views = {}, {}
+        sizes = {}
+        for p in self.params:
+            key = (p.device, torch.float32 if p.dtype in (torch.float32, torch.bfloat16, torch.float16) else p.dtype)
+            sizes[key] = sizes.get(key, 0) + (p.numel() + 63) // 64 * 64       # slices start on 256-byte boundaries
+        for key, n in sizes.items():
+            self._flat[key] = torch.zeros(n, dtype=key[1], device=key[0])
+        offs = {k: 0 for k in sizes}
+        for p in self.params:
+            key = (p.device, torch.float32 if p.dtype in (torch.float32, torch.bfloat16, torch.float16) else p.dtype)
+            v = self._flat[key][offs[key]:offs[key] + p.numel()].view(p.shape)
+            offs[key] += (p.numel() + 63) // 64 * 64
+            self._views[id(p)] = v
+            if p.dtype == torch.float32 and p.is_cuda:
+                host.set_grad_destination(p, v)           # the producing kernels write here
+        self._born = self._copied = 0
+        if broadcast:
+            broadcast_parameters(module)
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+    def all_reduce(self):
+        """gradients that were not born in the arena are copied in (one multi-tensor launch) and re-pointed at their
+        slice; then one all-reduce (+ average) per flat buffer.  With a process group a parameter WITHOUT a gradient on
+        this rank counts as zeros and receives the average of the others (as allreduce_gradients: every rank must apply
+        the same update); without one it keeps `grad = None`."""
+        src, dst, missing = [], [], []
+        born = 0
+        active = exchange_active()
+        for p in self.params:
+            g = p.grad
+            v = self._views[id(p)]
+            if g is None:
+                if active:
+                    missing.append(v)
+                    p.grad = v
+                continue
+            if g.data_ptr() == v.data_ptr() and g.dtype == v.dtype:
+                born += 1
+                continue
+            src.append(g.detach())
+            dst.append(v)
+            p.grad = v
+        if src:
+            torch._foreach_copy_(dst, src)
+        if missing:
+            torch._foreach_zero_(missing)
+        self._born, self._copied = born, len(src)
+        if not active:
+            return
+        w = world_size()
+        for flat in self._flat.values():
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            if self.average and w > 1:
+                flat.div_(w)
+
+    def describe(self):
+        return {"buffers": {f"{k[1]}@{k[0]}": int(v.numel() * v.element_size()) for k, v in self._flat.items()},
+                "born_in_place": self._born, "copied_in": self._copied}
+
+    def close(self):
+        from . import host
+        for p in self.params:
+            host.set_grad_destination(p, None)
+
+
 def _reduce_scalar(value, op, device):
     if not exchange_active():
         return float(value)

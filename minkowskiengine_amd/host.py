@@ -106,6 +106,20 @@ def invalidate_packed_weights():
         _native.invalidate_packed_weights()
 
 
+def set_grad_destination(param, dest):
+    """Both hosts: the gradient of `param` (a convolution kernel, a batch-norm weight / bias; fp32) is written into
+    `dest` (None: forget it) instead of a fresh tensor — distributed.GradientArena."""
+    _python_backend.set_grad_destination(param, dest)
+    if _native is not None:
+        _native.set_grad_destination(param, dest)
+
+
+def clear_grad_destinations():
+    _python_backend.clear_grad_destinations()
+    if _native is not None:
+        _native.clear_grad_destinations()
+
+
 def _key_types():
     return (_python_backend.CoordinateMapKey,) + ((_native.CoordinateMapKey,) if _native is not None else ())
 

@@ -107,3 +107,64 @@ def test_backend_choice():
     assert D.pick_backend(8, n_gpus=8) == "nccl" and D.pick_backend(2, n_gpus=8) == "nccl"
     assert D.pick_backend(2, n_gpus=1) == "gloo"      # ranks sharing a GPU: RCCL refuses, gloo stages through host
     assert D.pick_backend(2, n_gpus=0) == "gloo"
+
+
+def _arena_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from minkowskiengine_amd import distributed as D
+    D.init_from_env(backend="gloo")
+    torch.manual_seed(50 + rank)                       # different weights per rank: the arena broadcasts rank 0's
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+    net[2].bias.requires_grad_(False)                  # a frozen parameter is not in the arena
+    extra = torch.nn.Parameter(torch.zeros(4, dtype=torch.float64))      # a second dtype: its own flat buffer
+    net.register_parameter("extra", extra)
+    arena = D.GradientArena(net)
+    w0 = net[0].weight.detach().clone()
+    x = torch.full((4, 6), float(rank + 1))
+    res = []
+    for step in range(2):                              # the second step reuses the slices
+        arena.zero_grad()
+        loss = net(x).sum()
+        if rank == 0 or step == 0:                     # step 1: rank 1 has NO gradient for `extra`
+            loss = loss + (extra * float(rank + 1)).sum()
+        loss.backward()
+        arena.all_reduce()
+        res.append((net[0].weight.grad.clone(), net[2].weight.grad.clone(),
+                    None if extra.grad is None else extra.grad.clone(), net[2].bias.grad))
+    desc = arena.describe()
+    out[rank] = (w0, res, desc)
+    D.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_gradient_arena_averages_like_ddp_on_two_gloo_ranks():
+    """distributed.GradientArena on CPU tensors (no producing kernels here: every gradient takes the copy-in path): flat
+    buffers per dtype, parameters broadcast from rank 0, gradients averaged by ONE all-reduce per buffer, `p.grad`
+    re-pointed at its slice, a parameter without a gradient on one rank, a frozen parameter left alone"""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_arena_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    (w0a, ra, da), (w0b, rb, db) = out[0], out[1]
+    assert torch.equal(w0a, w0b), "parameters were not broadcast"
+    # one process, both inputs, same weights: the averaged gradient
+    torch.manual_seed(50)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+    assert torch.equal(net[0].weight.detach(), w0a)
+    grads = []
+    for r in range(world):
+        net.zero_grad(set_to_none=True)
+        net(torch.full((4, 6), float(r + 1))).sum().backward()
+        grads.append((net[0].weight.grad.clone(), net[2].weight.grad.clone()))
+    for step in range(2):
+        for res in (ra, rb):
+            assert torch.allclose(res[step][0], (grads[0][0] + grads[1][0]) / 2)
+            assert torch.allclose(res[step][1], (grads[0][1] + grads[1][1]) / 2)
+            assert res[step][3] is None                                  # frozen
+    # `extra`: gradients 1 (rank 0) and 2 (rank 1) in step 0 -> 1.5 on both; step 1: only rank 0 produces one (1.0), rank
+    # 1's missing gradient counts as zeros and is materialised: 0.5 on BOTH ranks (every rank applies the same update)
+    assert torch.allclose(ra[0][2], torch.full((4,), 1.5, dtype=torch.float64)) and torch.allclose(rb[0][2], ra[0][2])
+    assert torch.allclose(ra[1][2], torch.full((4,), 0.5, dtype=torch.float64)) and torch.allclose(rb[1][2], ra[1][2])
+    assert set(da["buffers"]) == {"torch.float32@cpu", "torch.float64@cpu"} and da["copied_in"] >= 3 and da["born_in_place"] == 0

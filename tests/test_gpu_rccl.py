@@ -97,6 +97,35 @@ def _worker(rank, port, host, out):
         # csrc/norm.hip: same formula, another summation order)
         err = float((a - b).abs().max() / max(1e-6, float(b.abs().max())))
         assert err < 2e-3, (k, err)
+    # 3. gradients born in the all-reduce buffer (distributed.GradientArena): the same gradients as the plain module, bit
+    # for bit (an average over one rank), every convolution / batch-norm gradient written in place by its kernel
+    nets = []
+    for use_arena in (False, True):
+        net = minkunet.MinkUNet14(3, 5, D=3)
+        seeded_parameters(net.named_parameters())
+        net = net.to(dev).train()
+        arena = D.GradientArena(net) if use_arena else None
+        for _ in range(2):                                   # the second step reuses the slices
+            if arena is not None:
+                arena.zero_grad()
+            else:
+                net.zero_grad(set_to_none=True)
+            y = net(ME.SparseTensor(f3.to(dev).to(torch.bfloat16), scene.to(dev)))
+            (y.F.float() * lw.to(dev)).sum().backward()
+            if arena is not None:
+                arena.all_reduce()
+        torch.cuda.synchronize()
+        nets.append({n: p.grad.detach().clone() for n, p in net.named_parameters()})
+        if arena is not None:
+            d = arena.describe()
+            n_params = len(list(net.parameters()))
+            # all but the head's bias (a torch broadcast-add gradient) and the two kernels whose channels are padded for
+            # the tile kernels (3 -> 8 input channels of the stem, 5 -> 16 classes of the head: torch slices the gradient)
+            assert d["born_in_place"] >= n_params - 4 and d["born_in_place"] + d["copied_in"] == n_params, d
+            res["arena"] = d
+            arena.close()
+    for k in nets[0]:
+        assert torch.equal(nets[0][k], nets[1][k]), k
     res["libs"] = [l for l in _mapped_libraries() if "rccl" in l or "me_amd" in l or "_me_host" in l]
     out["res"] = res
     D.barrier()
