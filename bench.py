@@ -389,6 +389,55 @@ def set_kernel_timer(MEB, timer):
 LAST_RUN = {}    # side results of the last run_timed call: per-rank times of the reported block
 
 
+class Exchange:
+    """The data-parallel gradient exchange of a bench step, two ways (--exchange):
+      arena  (default) distributed.GradientArena: gradients are born in one flat buffer, ONE RCCL all-reduce after the
+             backward pass — no per-parameter hooks, no bucket copies (torch DDP costs the host-bound MinkUNet34C step
+             1.6 ms on ONE rank where the all-reduce itself is free: scripts/ddp_overhead.py);
+      ddp    torch DistributedDataParallel, 25 MB buckets overlapped with the backward pass (the reference's recipe,
+             examples/multigpu_ddp.py:81-95).
+    Without a process group both are the plain module."""
+
+    def __init__(self, module, dev, dist_utils, mode, sync_bn=False, chunks=1):
+        self.dist, self.mode, self.module = dist_utils, mode, module
+        self.active = dist_utils.exchange_active()
+        self.arena, self.net = None, module
+        if not self.active:
+            self.mode = "none"
+        elif mode == "ddp":
+            self.net = dist_utils.data_parallel(module, dev, sync_batchnorm=sync_bn)
+        else:
+            if sync_bn:
+                import minkowskiengine_amd as ME
+                self.net = self.module = ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm(module)
+            self.arena = dist_utils.GradientArena(self.module, chunks=chunks)
+
+    def zero_grad(self):
+        if self.arena is not None:
+            self.arena.zero_grad()
+        else:
+            for p in self.module.parameters():
+                p.grad = None
+
+    def backward(self, fn, sync=True):
+        """run fn() (the backward pass) with (sync) or without the exchange"""
+        if self.mode == "ddp" and not sync:
+            with self.dist.no_sync(self.net):
+                fn()
+            return
+        fn()
+        if self.arena is not None and sync:
+            self.arena.all_reduce()
+
+    def describe(self):
+        if self.mode == "ddp":
+            return f"torch DDP over {self.dist.backend_name()} (25 MB gradient buckets overlapped with backward)"
+        if self.mode == "arena":
+            return (f"gradient arena over {self.dist.backend_name()} (gradients born in one flat buffer, one all-reduce "
+                    "per step after backward)")
+        return ""
+
+
 def gpu_state_under_load(step, min_steps=4):
     """Clock / power / temperature of GPU 0 sampled by rocm-smi WHILE `step` keeps the device busy (a sample taken after the
     timed region would show the idle clocks).  -> dict or None (no rocm-smi, unparsable output)."""
@@ -575,7 +624,8 @@ def bench_conv(args, ME, MEB, dist_utils, rank, world, dev, startup):
     feats = torch.rand(n, cin, generator=g)
     torch.manual_seed(0)
     conv = ME.MinkowskiConvolution(cin, cout, kernel_size=3, stride=1, dimension=D, bias=False).to(dev)
-    net = dist_utils.data_parallel(conv, dev)                 # DDP when world > 1 (broadcasts rank 0's weights)
+    ex = Exchange(conv, dev, dist_utils, args.exchange)       # broadcasts rank 0's weights when a group exists
+    net = ex.net
 
     # cold path: coordinate insertion + kernel map + tile plans + first forward/backward, in pieces
     torch.cuda.synchronize()
@@ -600,12 +650,12 @@ def bench_conv(args, ME, MEB, dist_utils, rank, world, dev, startup):
                                    ME.RegionType.HYPER_CUBE, None, False, False).n_pairs
     grad_seed = torch.ones_like(y.F)
 
-    def step(zero=True):
+    def step(zero=True, sync=True):
         if zero:
-            conv.kernel.grad = None
+            ex.zero_grad()
         x.F.grad = None
         out = net(x)
-        out.F.backward(grad_seed)
+        ex.backward(lambda: out.F.backward(grad_seed), sync)
 
     if getattr(args, "pmc_child_mode", False):     # profiled child (measure_traffic): the steps and nothing else
         for _ in range(args.steps):
@@ -623,8 +673,7 @@ def bench_conv(args, ME, MEB, dist_utils, rank, world, dev, startup):
         # own, and a gradient-accumulation window (A - 1 micro-steps under no_sync, the A-th reduces) — the loop a
         # one-layer data-parallel job would actually run.
         def step_nosync(zero=True):
-            with dist_utils.no_sync(net):
-                step(zero)
+            step(zero, sync=False)
         A = max(2, args.accum)
 
         def window():
@@ -639,7 +688,7 @@ def bench_conv(args, ME, MEB, dist_utils, rank, world, dev, startup):
         ms_sync = best / args.steps * 1e3
         ms_nosync = t_nosync / args.steps * 1e3
         ms_window = t_window / (max(1, args.steps // A) * A) * 1e3
-        multi = dict(dist_utils.collective_info(),
+        multi = dict(dist_utils.collective_info(), exchange=ex.mode,
                      per_rank_ms_per_step=per_rank,
                      no_sync_ms_per_step=round(ms_nosync, 4),
                      allreduce_ms={"standalone": round(ar_ms, 4), "buckets": n_buckets,
@@ -693,9 +742,7 @@ def bench_conv(args, ME, MEB, dist_utils, rank, world, dev, startup):
                                f"kernel map cached ({cfg})",
                    "host_layer": ME.get_host(),
                    "points_per_gpu": n, "pairs_per_gpu": n_pairs, "pairs_total": int(pairs_all),
-                   "parallelism": f"scene-sharded dp{world}" + (
-                       f", torch DDP over {dist_utils.backend_name()} (gradient buckets overlapped with backward)"
-                       if world > 1 else ""),
+                   "parallelism": f"scene-sharded dp{world}" + (", " + ex.describe() if dist_utils.exchange_active() else ""),
                    "imbalance": bool(args.imbalance and world > 1),
                    "oversubscribed": world > max(1, dist_utils.visible_gpus())},
         "multi_gpu": multi,
@@ -741,7 +788,8 @@ def bench_minkunet(args, ME, MEB, dist_utils, rank, world, dev, startup):
     torch.manual_seed(0)
     model = MU.MinkUNet34C(3, 20, D=3).to(dev)
     n_params = sum(p.numel() for p in model.parameters())
-    net = dist_utils.data_parallel(model, dev, sync_batchnorm=args.sync_bn)
+    ex = Exchange(model, dev, dist_utils, args.exchange, sync_bn=args.sync_bn, chunks=args.arena_chunks)
+    net = ex.net
     opt = torch.optim.SGD(net.parameters(), lr=1e-3, momentum=0.9)
     labels = torch.randint(0, 20, (n,), generator=g).to(dev)
     crit = torch.nn.CrossEntropyLoss() if args.torch_loss else MU.cross_entropy   # same value and gradient
@@ -776,8 +824,8 @@ def bench_minkunet(args, ME, MEB, dist_utils, rank, world, dev, startup):
         loader = ME.utils.ScenePrefetcher(scenes_forever(), depth=args.loader_depth)
         pending[0] = iter(loader)
 
-    def step():
-        opt.zero_grad(set_to_none=True)
+    def step(sync=True):
+        ex.zero_grad()
         if args.scenes == "cached":
             xin = x
         elif args.scenes == "fresh":
@@ -787,7 +835,7 @@ def bench_minkunet(args, ME, MEB, dist_utils, rank, world, dev, startup):
             if os.environ.get("ME_BENCH_DISCARD_LOADED") == "1":   # (interference experiment: the loader runs, the step
                 xin = x                                            # trains on the cached scene)
         loss = crit(net(xin).F.float(), labels)   # mean cross-entropy over the voxels
-        loss.backward()
+        ex.backward(loss.backward, sync)
         opt.step()
 
     if getattr(args, "pmc_child_mode", False):     # profiled child (measure_traffic): exactly `steps` steps
@@ -817,13 +865,13 @@ def bench_minkunet(args, ME, MEB, dist_utils, rank, world, dev, startup):
         # BASELINE configs[3]: what the exchange costs THIS step — the step without it (DDP.no_sync: same kernels, no
         # collectives), the 151 MB of gradients all-reduced on their own, and the difference the bucketed overlap leaves
         def step_nosync():
-            with dist_utils.no_sync(net):
-                step()
+            step(sync=False)
         t_nosync = timed_block(step_nosync, args.steps, dist_utils, dev)
         grad_bytes = sum(p.numel() * p.element_size() for p in model.parameters() if p.requires_grad)
         ar_ms, n_buckets = allreduce_probe(grad_bytes, dist_utils, dev)
         ms_sync, ms_nosync = best / args.steps * 1e3, t_nosync / args.steps * 1e3
-        multi = dict(dist_utils.collective_info(),
+        multi = dict(dist_utils.collective_info(), exchange=ex.mode,
+                     arena=(ex.arena.describe() if ex.arena is not None else None),
                      per_rank_ms_per_step=per_rank,
                      per_rank_points=[int(v) for v in dist_utils.gather_over_ranks(n, dev)],
                      no_sync_ms_per_step=round(ms_nosync, 3),
@@ -888,8 +936,7 @@ def bench_minkunet(args, ME, MEB, dist_utils, rank, world, dev, startup):
                    "host_layer": ME.get_host(),
                    "points_per_gpu": n,
                    "parallelism": f"scene-sharded dp{world}" + (
-                       f", torch DDP over {dist_utils.backend_name()} (25 MB gradient buckets overlapped with backward)"
-                       + (", MinkowskiSyncBatchNorm" if args.sync_bn else ", per-rank batch norm")
+                       ", " + ex.describe() + (", MinkowskiSyncBatchNorm" if args.sync_bn else ", per-rank batch norm")
                        if dist_utils.exchange_active() else ""),
                    "hip_graph": graphed,
                    "imbalance": bool(args.imbalance and world > 1),
@@ -1024,6 +1071,12 @@ def main():
                          "a quarter of the timed blocks, the step time is the median over all of them")
     ap.add_argument("--max-blocks", type=int, default=200)
     ap.add_argument("--backend", choices=("auto", "nccl", "gloo"), default="auto")
+    ap.add_argument("--arena-chunks", type=int, default=1,
+                    help="--exchange arena: pieces of the flat gradient buffer all-reduced from inside the backward pass "
+                         "(1 = one all-reduce after it; see distributed.GradientArena)")
+    ap.add_argument("--exchange", choices=("arena", "ddp"), default="arena",
+                    help="gradient exchange of the N > 1 step: distributed.GradientArena (one all-reduce of a flat buffer the "
+                         "gradients are born in) or torch DistributedDataParallel (bucketed, overlapped)")
     ap.add_argument("--scenes", choices=("cached", "fresh", "pipelined"), default="cached",
                     help="minkunet: reuse one scene's maps (default, BASELINE configs[2]), or rebuild them every step")
     ap.add_argument("--loader-depth", type=int, default=1, help="minkunet --scenes pipelined: scenes built ahead")

@@ -1281,14 +1281,19 @@ def _conv_launch_cfg(km, target, n_tgt, c_src, c_dst, bf16):
 
 # gradient destinations (distributed.GradientArena; csrc_host/ops.cpp twin): parameter storage address -> the fp32 buffer
 # its gradient is written into (a slice of one flat all-reduce buffer)
-_GRAD_DEST = {}
+_GRAD_DEST = {}     # address -> [dest, armed]: an entry is used ONCE per arming (see csrc_host/ops.cpp)
 
 
 def set_grad_destination(param, dest):
     if dest is None:
         _GRAD_DEST.pop(param.data_ptr(), None)
     else:
-        _GRAD_DEST[param.data_ptr()] = dest
+        _GRAD_DEST[param.data_ptr()] = [dest, False]
+
+
+def arm_grad_destinations():
+    for e in _GRAD_DEST.values():
+        e[1] = True
 
 
 def clear_grad_destinations():
@@ -1298,12 +1303,16 @@ def clear_grad_destinations():
 def _grad_destination(param, shape):
     """a FRESH alias of the registered buffer in `shape` (autograd takes a gradient without a copy only when nobody else
     holds the tensor object), or None"""
-    d = _GRAD_DEST.get(param.data_ptr()) if param is not None else None
+    e = _GRAD_DEST.get(param.data_ptr()) if param is not None else None
+    if e is None or not e[1]:
+        return None
+    d = e[0]
     n = 1
     for v in shape:
         n *= int(v)
-    if d is None or d.dtype != torch.float32 or d.numel() != n or d.device != param.device:
+    if d.dtype != torch.float32 or d.numel() != n or d.device != param.device:
         return None
+    e[1] = False
     return d.view(tuple(shape))
 
 

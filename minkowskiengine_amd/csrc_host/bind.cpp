@@ -158,6 +158,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("invalidate_packed_weights", &invalidate_packed_weights);
   m.def("set_grad_destination", [](const Tensor &param, const py::object &dest) { set_grad_destination(param, opt_tensor(dest)); });
   m.def("clear_grad_destinations", &clear_grad_destinations);
+  m.def("arm_grad_destinations", &arm_grad_destinations);
   m.def("set_policy", &Policy::set, "integer policies of the native host by name (tests, tuning scripts)");
   m.def("timing_enable", &timing_enable);
   m.def("timing_records", &timing_records, py::arg("clear") = true);

@@ -297,6 +297,7 @@ Tensor pruning_backward(const Tensor &grad_out, CoordinateMapKey *in_key, Coordi
 // gradient destinations (ops.cpp; distributed.GradientArena): parameter -> the buffer its gradient is written into
 void set_grad_destination(const Tensor &param, const Tensor &dest);   // dest undefined: forget it
 void clear_grad_destinations();
+void arm_grad_destinations();          // every entry may be used once (again)
 Tensor grad_destination(const Tensor &param, at::IntArrayRef shape);
 
 // batch normalisation over feature rows (csrc/norm.hip)

@@ -287,15 +287,26 @@ static bool conv_bn_stats_enabled() {
 // returned alias as p.grad without a copy, and the data-parallel exchange is one RCCL all-reduce over the flat buffer (no
 // per-parameter hooks, no bucket copies: torch DDP costs this host-bound step 1.7 ms on ONE rank).  Keyed by the
 // parameter's storage address; fp32 only (the dtype the kernels accumulate in).
+// An entry is used ONCE per arming (GradientArena.zero_grad arms all of them): a second backward pass before the next
+// zero_grad — a gradient-accumulation window — gets fresh tensors, which autograd then ADDS to p.grad (the slice); writing
+// into the slice again would destroy what it has accumulated.
 namespace {
-std::unordered_map<const void *, Tensor> g_grad_dest;
+struct GradDest {
+  Tensor dest;
+  bool armed;
+};
+std::unordered_map<const void *, GradDest> g_grad_dest;
 std::mutex g_grad_dest_mu;
 }  // namespace
 
 void set_grad_destination(const Tensor &param, const Tensor &dest) {
   std::lock_guard<std::mutex> lk(g_grad_dest_mu);
-  if (dest.defined()) g_grad_dest[param.data_ptr()] = dest;
+  if (dest.defined()) g_grad_dest[param.data_ptr()] = GradDest{dest, false};
   else g_grad_dest.erase(param.data_ptr());
+}
+void arm_grad_destinations() {
+  std::lock_guard<std::mutex> lk(g_grad_dest_mu);
+  for (auto &kv : g_grad_dest) kv.second.armed = true;
 }
 void clear_grad_destinations() {
   std::lock_guard<std::mutex> lk(g_grad_dest_mu);
@@ -307,11 +318,12 @@ Tensor grad_destination(const Tensor &param, at::IntArrayRef shape) {
   if (!param.defined()) return Tensor();
   std::lock_guard<std::mutex> lk(g_grad_dest_mu);
   auto it = g_grad_dest.find(param.data_ptr());
-  if (it == g_grad_dest.end()) return Tensor();
-  const Tensor &d = it->second;
+  if (it == g_grad_dest.end() || !it->second.armed) return Tensor();
+  const Tensor &d = it->second.dest;
   int64_t n = 1;
   for (auto v : shape) n *= v;
   if (d.scalar_type() != at::kFloat || d.numel() != n || d.device() != param.device()) return Tensor();
+  it->second.armed = false;
   return d.view(shape);
 }
 

@@ -114,6 +114,12 @@ def set_grad_destination(param, dest):
         _native.set_grad_destination(param, dest)
 
 
+def arm_grad_destinations():
+    _python_backend.arm_grad_destinations()
+    if _native is not None:
+        _native.arm_grad_destinations()
+
+
 def clear_grad_destinations():
     _python_backend.clear_grad_destinations()
     if _native is not None:

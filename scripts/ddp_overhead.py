@@ -16,7 +16,7 @@ g = torch.Generator().manual_seed(0)
 feats = torch.rand(coords.shape[0], 3, generator=g)
 labels = torch.randint(0, 20, (coords.shape[0],), generator=g).to(dev)
 x = ME.SparseTensor(feats.to(dev).bfloat16(), coords.to(dev))
-MODES = os.environ.get("MODES", "plain,ddp25,ddp1000,flat,arena").split(",")
+MODES = os.environ.get("MODES", "plain,ddp25,ddp1000,flat,arena,arena4").split(",")
 STEPS = int(os.environ.get("STEPS", "20"))
 for mode in MODES:
     torch.manual_seed(0)
@@ -24,8 +24,8 @@ for mode in MODES:
     net, arena = model, None
     if mode.startswith("ddp"):
         net = D.data_parallel(model, dev, bucket_cap_mb=int(mode[3:]))
-    if mode == "arena":
-        arena = D.GradientArena(model)
+    if mode.startswith("arena"):
+        arena = D.GradientArena(model, chunks=int(mode[5:] or 1))
     opt = torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.9)
 
     def step():

@@ -168,3 +168,63 @@ def test_gradient_arena_averages_like_ddp_on_two_gloo_ranks():
     assert torch.allclose(ra[0][2], torch.full((4,), 1.5, dtype=torch.float64)) and torch.allclose(rb[0][2], ra[0][2])
     assert torch.allclose(ra[1][2], torch.full((4,), 0.5, dtype=torch.float64)) and torch.allclose(rb[1][2], ra[1][2])
     assert set(da["buffers"]) == {"torch.float32@cpu", "torch.float64@cpu"} and da["copied_in"] >= 3 and da["born_in_place"] == 0
+
+
+def _arena_overlap_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from minkowskiengine_amd import distributed as D
+    D.init_from_env(backend="gloo")
+    torch.manual_seed(9)
+    layers = [torch.nn.Linear(8, 8) for _ in range(12)]
+    net = torch.nn.Sequential(*layers)
+    arena = D.GradientArena(net, chunks=4)
+    x = torch.full((3, 8), 0.1 * (rank + 1))
+    res = []
+    for step in range(5):
+        arena.zero_grad()
+        if step < 3:
+            net(x).sum().backward()
+        elif step == 3:
+            net[:6](x).sum().backward()                # layers 6..11 get no gradient: their pieces cannot be launched early
+        else:
+            net(x).sum().backward()                    # ... and the full network again
+        arena.all_reduce()
+        res.append(([None if p.grad is None else p.grad.clone() for p in net.parameters()], arena.describe()))
+    out[rank] = res
+    D.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_gradient_arena_overlapped_pieces_on_two_gloo_ranks():
+    """chunks = 4 on a 24-parameter network: step 0 learns the arrival order (and still averages correctly), steps 1 - 2
+    all-reduce three pieces from inside the backward pass and the rest at the end, step 3 runs half the network (the
+    pieces of the unused half fall back to the closing all-reduce, missing gradients count as zeros), step 4 is the full
+    network again — every step's gradients equal the two-rank average"""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_arena_overlap_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    torch.manual_seed(9)
+    net = torch.nn.Sequential(*[torch.nn.Linear(8, 8) for _ in range(12)])
+
+    def expected(half):
+        gs = []
+        for r in range(world):
+            net.zero_grad(set_to_none=True)
+            (net[:6] if half else net)(torch.full((3, 8), 0.1 * (r + 1))).sum().backward()
+            gs.append([torch.zeros_like(p) if p.grad is None else p.grad.clone() for p in net.parameters()])
+        return [(a + b) / 2 for a, b in zip(*gs)]
+    full, half = expected(False), expected(True)
+    for rank in range(world):
+        for step, (grads, desc) in enumerate(out[rank]):
+            want = half if step == 3 else full
+            for g, w_ in zip(grads, want):
+                assert g is not None and torch.allclose(g, w_, rtol=1e-5, atol=1e-7), (rank, step)
+            if step in (1, 2, 4):
+                assert desc["overlapped_pieces"] == 3, (step, desc)
+            if step == 0:
+                assert desc["overlapped_pieces"] == 0
+            if step == 3:
+                assert desc["overlapped_pieces"] < 3, desc

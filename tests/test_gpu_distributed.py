@@ -161,3 +161,71 @@ def test_ddp_with_sync_batchnorm_matches_one_process_on_the_batched_scenes(devic
         rel = float((got - want).norm() / want.norm())
         cos = float((got * want).sum() / (got.norm() * want.norm()))
         assert rel <= 0.03 and cos >= 0.999, (key, rel, cos)
+
+
+def _arena_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import minkowskiengine_amd as ME
+    from minkowskiengine_amd import distributed as D
+    import minkunet
+    from make_golden_minkunet_weights import seeded_parameters
+    r, w, lr = D.init_from_env()
+    dev = D.local_device(lr)
+    net = minkunet.MinkUNet14(3, 5, D=3)
+    if rank == 0:
+        seeded_parameters(net.named_parameters())      # rank 1 starts from torch's init: the arena broadcasts rank 0's
+    net = net.to(dev).train()
+    arena = D.GradientArena(net, chunks=4)
+    coords = minkunet.synthetic_scene(3000, grid=48, seed=3 + rank)
+    g = torch.Generator().manual_seed(60 + rank)
+    feats = torch.rand(coords.shape[0], 3, generator=g)
+    lw = torch.rand(coords.shape[0], 5, generator=g) - 0.5
+    for _ in range(3):                                  # step 0 learns the arrival order, steps 1 - 2 overlap pieces
+        arena.zero_grad()
+        y = net(ME.SparseTensor(feats.to(dev), coords.to(dev)))
+        (y.F * lw.to(dev)).sum().backward()
+        arena.all_reduce()
+    torch.cuda.synchronize()
+    out[rank] = ({n: p.grad.cpu() for n, p in net.named_parameters()}, arena.describe())
+    D.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_gradient_arena_on_two_ranks_averages_the_hip_gradients(device):
+    """distributed.GradientArena (gradients born in one flat buffer by the HIP kernels, pieces all-reduced from inside the
+    backward pass) on two ranks sharing the GPU over gloo == the average of the two scenes' gradients computed by one
+    process (per-rank batch statistics: each scene on its own)"""
+    import minkowskiengine_amd as ME
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import minkunet
+    from make_golden_minkunet_weights import seeded_parameters
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_arena_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    (g0, d0), (g1, d1) = out[0], out[1]
+    assert d0["overlapped_pieces"] == 3 and d1["overlapped_pieces"] == 3, (d0, d1)
+    net = minkunet.MinkUNet14(3, 5, D=3)
+    seeded_parameters(net.named_parameters())
+    net = net.to(device).train()
+    acc = None
+    for rank in range(world):
+        net.zero_grad(set_to_none=True)
+        coords = minkunet.synthetic_scene(3000, grid=48, seed=3 + rank)
+        g = torch.Generator().manual_seed(60 + rank)
+        feats = torch.rand(coords.shape[0], 3, generator=g)
+        lw = torch.rand(coords.shape[0], 5, generator=g) - 0.5
+        y = net(ME.SparseTensor(feats.to(device), coords.to(device)))
+        (y.F * lw.to(device)).sum().backward()
+        cur = {n: p.grad.double().cpu() for n, p in net.named_parameters()}
+        acc = cur if acc is None else {n: acc[n] + cur[n] for n in cur}
+    for n in g0:
+        assert torch.equal(g0[n], g1[n]), n                     # both ranks hold the same averaged gradient
+        want = (acc[n] / 2).float()
+        assert torch.allclose(g0[n], want, rtol=1e-4, atol=1e-5 * float(want.abs().max()) + 1e-7), n

@@ -104,8 +104,8 @@ def _worker(rank, port, host, out):
         net = minkunet.MinkUNet14(3, 5, D=3)
         seeded_parameters(net.named_parameters())
         net = net.to(dev).train()
-        arena = D.GradientArena(net) if use_arena else None
-        for _ in range(2):                                   # the second step reuses the slices
+        arena = D.GradientArena(net, chunks=4) if use_arena else None
+        for _ in range(3):                                   # step 0 learns the arrival order, steps 1 - 2 overlap
             if arena is not None:
                 arena.zero_grad()
             else:
@@ -122,6 +122,7 @@ def _worker(rank, port, host, out):
             # all but the head's bias (a torch broadcast-add gradient) and the two kernels whose channels are padded for
             # the tile kernels (3 -> 8 input channels of the stem, 5 -> 16 classes of the head: torch slices the gradient)
             assert d["born_in_place"] >= n_params - 4 and d["born_in_place"] + d["copied_in"] == n_params, d
+            assert d["overlapped_pieces"] == 3, d            # three pieces all-reduced through RCCL inside the backward pass
             res["arena"] = d
             arena.close()
     for k in nets[0]:
