@@ -63,6 +63,9 @@ typedef struct me_region {
  *              (me_conv_halo_config_bf16, me_halo_plan_build, me_conv_halo_bf16) */
 int me_version(void);
 const char *me_last_error(void);
+/* Load the device code of every translation unit of the library now (needs a GPU; ABI 1.5): HIP loads a unit's code object
+ * at the first launch from it, which put 88 ms into the first backward pass of a process.  The hosts call it at import. */
+int me_preload(void);
 /* kernel volume of a region: src/kernel_region.hpp:250-270 (set_volume) */
 int64_t me_region_volume(const me_region *region);
 

@@ -71,6 +71,7 @@ _P_I32 = ctypes.POINTER(c_i32)
 # name -> (restype, argtypes); must list every symbol include/me_amd.h declares
 SIGNATURES = {
     "me_version": (ctypes.c_int, []),
+    "me_preload": (ctypes.c_int, []),
     "me_last_error": (ctypes.c_char_p, []),
     "me_region_volume": (c_i64, [_P_REGION]),
     "me_hash_capacity": (c_i64, [c_i64]),
@@ -242,6 +243,15 @@ def load():
             fn.restype = restype
             fn.argtypes = argtypes
     _lib = lib
+    # device code of every translation unit loaded now rather than at the first launch from it (the first backward pass of a
+    # process paid 88 ms for that); ME_AMD_PRELOAD=0 keeps HIP's lazy loading
+    if os.environ.get("ME_AMD_PRELOAD", "1") != "0":
+        try:
+            import torch
+            if torch.cuda.is_available():
+                lib.me_preload()
+        except Exception:  # noqa: BLE001  (no torch / no device: nothing to preload)
+            pass
     # tuning switches of the library by environment (A/B runs of bench.py): ME_AMD_BF16_WS=0 keeps k_conv_tile_bf16
     # everywhere, ME_AMD_BF16_WS_DEPTH=2 its shallower producer pipeline
     if os.environ.get("ME_AMD_BF16_WS", "") != "":

@@ -2539,7 +2539,10 @@ static WgradGeom wgrad_geom_staged(int64_t n_pairs, int c_in, int c_out, int wpc
   g.n_cob = (int)ceil_div(c_out, 16 * g.nb);
   g.waves = 4;
   g.gz = (int)ceil_div(g.n_cob, 4);
-  const int wpc = g_wgrad_wgs_per_cu > 0 ? g_wgrad_wgs_per_cu : wpc_default;
+  // (three input-channel blocks side by side — 384 -> 256 on 21k voxels — leave 86 ranges x 6 = 516 workgroups at two per CU:
+  // a third of a round idle; at three per CU 148 -> 110 us, profiles/r05_wgrad_ranges_sweep.log; every other MinkUNet34C
+  // shape is fastest at two)
+  const int wpc = g_wgrad_wgs_per_cu > 0 ? g_wgrad_wgs_per_cu : (g.n_cib == 3 ? 3 : wpc_default);
   int64_t r = ceil_div((int64_t)device_cu_count() * wpc, (int64_t)g.n_cib * g.gz);
   if (r > n_pairs / 64) r = n_pairs / 64;
   if (r < 1) r = 1;
@@ -3088,3 +3091,10 @@ int me_conv_backward_naive_f32(const float *in_feat, int32_t c_in, const float *
 }
 
 }  // extern "C"
+
+// code-object preload (me_preload, coords.hip): resolving one kernel of this translation unit makes the runtime load the
+// unit's whole code object now instead of at the first launch from it
+extern "C" __attribute__((visibility("hidden"))) void me_preload_conv(void) {
+  hipFuncAttributes attr;
+  (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&me::k_transpose_kernel));
+}

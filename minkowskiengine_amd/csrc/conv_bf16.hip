@@ -1810,3 +1810,10 @@ int me_conv_gather_bf16(const uint16_t *src_, int64_t n_src, int32_t c_src, cons
 }
 
 }  // extern "C"
+
+// code-object preload (me_preload, coords.hip): resolving one kernel of this translation unit makes the runtime load the
+// unit's whole code object now instead of at the first launch from it
+extern "C" __attribute__((visibility("hidden"))) void me_preload_conv_bf16(void) {
+  hipFuncAttributes attr;
+  (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&me::k_pack_weights_bf16<128, true>));
+}

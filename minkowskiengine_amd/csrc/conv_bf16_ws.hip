@@ -617,3 +617,10 @@ extern "C" int me_debug_ws_timing(uint64_t *out8, int32_t reset) {
 #endif
   return 0;
 }
+
+// code-object preload (me_preload, coords.hip): resolving one kernel of this translation unit makes the runtime load the
+// unit's whole code object now instead of at the first launch from it
+extern "C" __attribute__((visibility("hidden"))) void me_preload_conv_bf16_ws(void) {
+  hipFuncAttributes attr;
+  (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&me::k_conv_tile_bf16_ws<64, 64, 4>));
+}

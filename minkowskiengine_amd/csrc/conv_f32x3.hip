@@ -989,3 +989,10 @@ int me_conv_target_f32x3(const float *src, int64_t n_src, int32_t c_src, const u
 }
 
 }  // extern "C"
+
+// code-object preload (me_preload, coords.hip): resolving one kernel of this translation unit makes the runtime load the
+// unit's whole code object now instead of at the first launch from it
+extern "C" __attribute__((visibility("hidden"))) void me_preload_conv_f32x3(void) {
+  hipFuncAttributes attr;
+  (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&me::k_pack_weights_f32x3<128>));
+}

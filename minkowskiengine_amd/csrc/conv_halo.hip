@@ -753,3 +753,10 @@ extern "C" int me_conv_halo_bf16(const uint16_t *src_feat_dev, int64_t n_src, in
 #undef ME_HALO
   ME_FAIL("no halo kernel instantiation for this shape");
 }
+
+// code-object preload (me_preload, coords.hip): resolving one kernel of this translation unit makes the runtime load the
+// unit's whole code object now instead of at the first launch from it
+extern "C" __attribute__((visibility("hidden"))) void me_preload_conv_halo(void) {
+  hipFuncAttributes attr;
+  (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&me::k_halo_plan<256>));
+}

@@ -1875,3 +1875,25 @@ int me_kernel_map_transpose_ordered(const int32_t *in_pairs, const int32_t *out_
 }
 
 }  // extern "C"
+
+// code-object preload (me_preload, coords.hip): resolving one kernel of this translation unit makes the runtime load the
+// unit's whole code object now instead of at the first launch from it
+extern "C" __attribute__((visibility("hidden"))) void me_preload_coords(void) {
+  hipFuncAttributes attr;
+  (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&me::k_rs_hist));
+}
+
+// Load every code object of the library now (ABI 1.5).  HIP loads a translation unit's device code when the first kernel
+// of it is launched: the first backward pass of a process paid 88 ms for the weight-gradient / reduce / batch-norm units
+// (BENCH_r04 cold_breakdown_ms.first_backward_plans).  Called by the hosts at import; costs what those first launches cost.
+extern "C" {
+void me_preload_conv(void); void me_preload_conv_bf16(void); void me_preload_conv_bf16_ws(void); void me_preload_conv_f32x3(void);
+void me_preload_conv_halo(void); void me_preload_coords(void); void me_preload_norm(void); void me_preload_pack(void);
+void me_preload_f64(void); void me_preload_pool(void);
+int me_preload(void) {
+  me_preload_coords(); me_preload_conv(); me_preload_conv_bf16(); me_preload_conv_bf16_ws(); me_preload_conv_f32x3();
+  me_preload_conv_halo(); me_preload_norm(); me_preload_pack(); me_preload_pool(); me_preload_f64();
+  ME_HIP(hipGetLastError());
+  return 0;
+}
+}

@@ -251,3 +251,10 @@ int me_broadcast_f64(const double *in, const double *glob, const int32_t *batch_
 }
 
 }  // extern "C"
+
+// code-object preload (me_preload, coords.hip): resolving one kernel of this translation unit makes the runtime load the
+// unit's whole code object now instead of at the first launch from it
+extern "C" __attribute__((visibility("hidden"))) void me_preload_f64(void) {
+  hipFuncAttributes attr;
+  (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&me::k_conv_target_f64<true>));
+}

@@ -101,3 +101,10 @@ int me_conv_pack_weights_multi(const me_pack_job *jobs_dev, int32_t n_jobs, cons
 }
 
 }  // extern "C"
+
+// code-object preload (me_preload, coords.hip): resolving one kernel of this translation unit makes the runtime load the
+// unit's whole code object now instead of at the first launch from it
+extern "C" __attribute__((visibility("hidden"))) void me_preload_pack(void) {
+  hipFuncAttributes attr;
+  (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&me::k_pack_weights_multi));
+}

@@ -613,3 +613,10 @@ int me_segment_sum_f32(const float *src, int32_t c, const int64_t *perm, const i
 }
 
 }  // extern "C"
+
+// code-object preload (me_preload, coords.hip): resolving one kernel of this translation unit makes the runtime load the
+// unit's whole code object now instead of at the first launch from it
+extern "C" __attribute__((visibility("hidden"))) void me_preload_pool(void) {
+  hipFuncAttributes attr;
+  (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&me::k_pool_sum<float, 4>));
+}
