@@ -135,7 +135,7 @@ def measure_traffic(workload, dtype, kernel_match, steps, deadline, extra_steps=
     kernels): FETCH_SIZE x 2 (gfx950 tallies 128-byte requests at 64 B: MI355X_MICROARCH.md, HBM) + WRITE_SIZE, both in
     KiB.  -> dict(per_launch bytes, per_step bytes, launches_per_step, fetch / write split) or None when the profiler is
     absent, a pass failed or the time budget (`deadline`, perf_counter seconds) is used up."""
-    res = {}
+    res, per_kernel = {}, {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         left = deadline - time.perf_counter()
         if left < 20:
@@ -147,6 +147,10 @@ def measure_traffic(workload, dtype, kernel_match, steps, deadline, extra_steps=
         for name, cs in agg.items():
             if counter not in cs:
                 continue
+            if any(m in name for m in PMC_CONV_KERNELS):      # every convolution kernel of the pass, by name
+                e = per_kernel.setdefault(name, {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0, "launches": 0})
+                e[counter] += cs[counter][0] * 1024.0
+                e["launches"] = max(e["launches"], cs[counter][1])
             hit = all(m in name for m in kernel_match) if kernel_match else any(m in name for m in PMC_CONV_KERNELS)
             if hit:
                 tot += cs[counter][0]
@@ -158,9 +162,16 @@ def measure_traffic(workload, dtype, kernel_match, steps, deadline, extra_steps=
     write = res["WRITE_SIZE"][0]
     n = res["FETCH_SIZE"][1]
     ran = steps + extra_steps     # (the convolution workloads run one cold forward + backward before their steps)
+    by_kernel = {}
+    for name, e in per_kernel.items():
+        short = name.split("(")[0].replace("void ", "").replace("me::", "")
+        by_kernel[short] = {"launches_per_step": round(e["launches"] / ran, 2),
+                            "bytes_per_launch": int((2.0 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) / max(e["launches"], 1)),
+                            "fetch_bytes_per_launch": int(2.0 * e["FETCH_SIZE"] / max(e["launches"], 1)),
+                            "write_bytes_per_launch": int(e["WRITE_SIZE"] / max(e["launches"], 1))}
     return {"per_launch": int((fetch + write) / n), "per_step": int((fetch + write) / ran),
             "launches_per_step": round(n / ran, 2), "fetch_bytes_per_launch": int(fetch / n),
-            "write_bytes_per_launch": int(write / n),
+            "write_bytes_per_launch": int(write / n), "by_kernel": by_kernel,
             "source": f"measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one pass each over a child process "
                       f"running {steps} steps of the workload (FETCH_SIZE doubled: gfx950 tallies 128-byte requests at 64 B)"}
 
@@ -180,6 +191,17 @@ def attach_traffic(line, args, deadline):
             r["traffic_note"] = "HBM-side bytes per launch of this kernel — " + t["source"]
             r["traffic_over_compulsory"] = round(t["per_launch"] / r["compulsory_bytes_per_launch"], 3) \
                 if r.get("compulsory_bytes_per_launch") else None
+            # the same passes, every convolution kernel of the step: forward (this kernel), input gradient (the other tile
+            # kernel), weight gradient (+ its reduce) against SURVEY 8(d)'s compulsory bytes of each
+            comp = r.get("compulsory_by_pass")
+            if comp and t.get("by_kernel"):
+                rows = {}
+                for short, e in t["by_kernel"].items():
+                    which = "forward" if all(m in short + "(" for m in tag) else \
+                        ("wgrad_reduce" if "reduce" in short else ("wgrad" if "wgrad" in short else "dgrad"))
+                    rows[which] = dict(e, kernel=short,
+                                       over_compulsory=(round(e["bytes_per_launch"] / comp[which], 3) if comp.get(which) else None))
+                r["traffic_by_pass"] = rows
     for name, wl, dt in (("minkunet34c_bf16_200k", "minkunet", "bf16"), ("conv4d_f32_400k", "conv4d", "f32")):
         ent = (line.get("workloads") or {}).get(name)
         if not isinstance(ent, dict) or "roofline" not in ent:
@@ -768,6 +790,14 @@ def bench_conv(args, ME, MEB, dist_utils, rank, world, dev, startup):
                                       "host synchronisations of the build; the warm build is under `cold`"},
         "cold": cold,
     }
+    # compulsory HBM bytes of each pass (every tensor touched once, the pair lists read once): forward = X + Y +
+    # W + 8P; input gradient = dY + dX + W + 8P; weight gradient = X + dY + dW + 8P (its reduce: the partial images are
+    # not compulsory — dW once)
+    line["roofline"]["compulsory_by_pass"] = {
+        "forward": int(compulsory),
+        "dgrad": int(esz * (n * cout + n * cin + K * cin * cout) + 8 * n_pairs),
+        "wgrad": int(esz * (n * cin + n * cout) + 4 * K * cin * cout + 8 * n_pairs),
+        "wgrad_reduce": int(4 * K * cin * cout)}
     if world == 1 and args.cpu_budget > 0:      # the reference CPU path is fp32 whatever our feature dtype
         w_cpu = conv.kernel.detach().float().cpu()
         line["cpu_baseline"] = cpu_baseline_both(lambda b: cpu_baseline(coords, feats, w_cpu, b), args.cpu_budget)
