@@ -38,6 +38,9 @@ parser.add_argument("--dtype", choices=("f32", "bf16"), default="bf16")
 parser.add_argument("--sync-bn", action="store_true", help="MinkowskiSyncBatchNorm, as the reference's example")
 parser.add_argument("--oversubscribe", type=int, default=0,
                     help="run this many ranks although fewer GPUs are visible (gloo; functional test only)")
+parser.add_argument("--exchange", choices=("arena", "ddp"), default="arena",
+                    help="gradient exchange: distributed.GradientArena (one all-reduce of a flat buffer the gradients are "
+                         "born in) or torch DistributedDataParallel (the reference's recipe)")
 
 
 def load_scene(points, seed, device):
@@ -60,13 +63,23 @@ def main_worker(rank, world, args, port=None):
     torch.cuda.set_device(device)
     torch.manual_seed(0)
     model = MinkUNet34C(3, 20, D=3).to(device)
-    net = D.data_parallel(model, device, sync_batchnorm=args.sync_bn)     # DDP (+ SyncBN): the reference's recipe
+    arena = None
+    if args.exchange == "ddp":
+        net = D.data_parallel(model, device, sync_batchnorm=args.sync_bn)     # DDP (+ SyncBN): the reference's recipe
+    else:
+        # gradients born in ONE flat buffer, one RCCL all-reduce per step (distributed.GradientArena): no per-parameter
+        # hooks or bucket copies on this launch-bound step
+        net = ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm(model) if (args.sync_bn and world > 1) else model
+        arena = D.GradientArena(net)
     criterion = nn.CrossEntropyLoss()
     optimizer = torch.optim.SGD(net.parameters(), lr=1e-1)
     tdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     min_time = float("inf")
     for iteration in range(args.iterations):
-        optimizer.zero_grad()
+        if arena is not None:
+            arena.zero_grad()
+        else:
+            optimizer.zero_grad()
         batch = [load_scene(args.points, seed=1000 * iteration + rank * args.batch_size + b, device=device)
                  for b in range(args.batch_size)]
         coords_, feats_, labels_ = zip(*batch)
@@ -78,6 +91,8 @@ def main_worker(rank, world, args, port=None):
         outputs = net(inputs)
         loss = criterion(outputs.F.float(), labels)
         loss.backward()
+        if arena is not None:
+            arena.all_reduce()
         optimizer.step()
         torch.cuda.synchronize()
         t = D.max_over_ranks(time.perf_counter() - st, device if D.backend_name() == "nccl" else None)
@@ -86,8 +101,7 @@ def main_worker(rank, world, args, port=None):
             n = inputs.F.shape[0]
             print(f"Iteration: {iteration}, Loss: {loss.item():.4f}, Time: {t * 1e3:.1f} ms, Min time: "
                   f"{min_time * 1e3:.1f} ms, voxels/rank: {n}, ranks: {world}", flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    D.shutdown()
 
 
 def main():

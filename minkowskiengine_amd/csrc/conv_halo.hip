@@ -554,16 +554,46 @@ int g_halo_tile = 0;     // forced tile height (64 | 128), 0 = policy
 int g_halo_kc = 0;       // forced channel chunk, 0 = policy
 int g_halo_skip = 1;     // 0: walk every offset (no kmask test)
 int g_halo_wd = 0;       // weight register sets (look-ahead + 1): 0 policy | 2 | 4
+int g_halo_cb4 = 0;      // 1: 128-column slabs as 2 x 2 waves of 64 columns (four MFMAs per operand read) instead of 1 x 4 of 32
 
 struct HaloShape {
   int t, cb, nwc, nwr, kc, s_cap;
 };
 
+// Which form of the kernel a channel shape takes: forced (me_debug_set_halo(1, ...) / ME_AMD_HALO=1: the tuning globals) or
+// the auto policy's per-shape choice.  Depends on (c_src, c_dst) only, so that plan build and launch agree without sharing
+// state.  The policy table (profiles/r05_halo_sweep*.log, MinkUNet34C scene, us per launch, tile-plan kernel -> halo):
+//   192 -> 128 @80k   137 -> 98    T 128, 2 x 2 waves of 64 columns, group masks
+//   256 -> 384 @21k   126 -> 103   (the input gradient of 384 -> 256) the same form
+//    64 ->  32 @80k    33 -> 26    (the input gradient of 32 -> 64) T 64, one column wave, no masks
+// Every other MinkUNet shape is faster on the tile-plan kernels and keeps them.
+struct HaloVariant {
+  int tile, cb4, skip, wd;
+  bool listed;      // the auto policy has an entry for this shape
+};
+static int halo_env_mode() {
+  static int env_mode = -2;
+  if (env_mode == -2) {
+    const char *e = getenv("ME_AMD_HALO");
+    env_mode = (e && e[0] == '0') ? 0 : ((e && e[0] == '1') ? 1 : -1);
+  }
+  return env_mode;
+}
+static HaloVariant halo_variant(int c_src, int c_dst) {
+  const int mode = g_halo_mode >= 0 ? g_halo_mode : halo_env_mode();
+  if (mode == 1) return HaloVariant{g_halo_tile == 64 ? 64 : 128, g_halo_cb4, g_halo_skip, g_halo_wd, false};
+  if ((c_src == 192 && c_dst == 128) || (c_src == 256 && c_dst == 384)) return HaloVariant{128, 1, 1, 2, true};
+  if (c_src == 64 && c_dst == 32) return HaloVariant{64, 0, 0, 2, true};
+  return HaloVariant{128, 0, 1, 2, false};
+}
+
 static bool halo_shape(int64_t volume, int c_src, int c_dst, HaloShape *hs) {
   if (volume < 2 || volume > 32 || c_src % 32 != 0 || c_dst % 16 != 0) return false;
+  const HaloVariant hv = halo_variant(c_src, c_dst);
   HaloShape s;
-  s.t = g_halo_tile == 64 ? 64 : 128;
-  if (c_dst % 128 == 0) { s.cb = 2; s.nwc = 4; s.nwr = 1; }
+  s.t = hv.tile;
+  if (c_dst % 128 == 0 && hv.cb4) { s.cb = 4; s.nwc = 2; s.nwr = 2; }
+  else if (c_dst % 128 == 0) { s.cb = 2; s.nwc = 4; s.nwr = 1; }
   else if (c_dst == 96) { s.cb = 2; s.nwc = 3; s.nwr = 1; }
   else if (c_dst == 64) { s.cb = 2; s.nwc = 2; s.nwr = 2; }
   else if (c_dst == 32) { s.cb = 2; s.nwc = 1; s.nwr = 4; }
@@ -572,6 +602,7 @@ static bool halo_shape(int64_t volume, int c_src, int c_dst, HaloShape *hs) {
   auto has = [&](int kc) {
     if (c_src % kc != 0) return false;
     if (s.nwc == 4) return kc == 32 || kc == 64 || kc == 96 || kc == 128;
+    if (s.cb == 4) return kc == 64;
     if (s.nwc == 3) return kc == 32 || kc == 64 || kc == 96;
     return kc == 32 || kc == 64;
   };
@@ -583,10 +614,12 @@ static bool halo_shape(int64_t volume, int c_src, int c_dst, HaloShape *hs) {
   return true;
 }
 
-// auto policy: measured per layer inside a MinkUNet34C step (profiles/r05_halo_*.log)
+// auto policy: a listed shape (halo_variant) on a map like the ones it was measured on — 3^3 offsets, at least 10k target
+// rows (fewer tiles than CUs otherwise), at least 6 pairs per row (the dense walk multiplies absent neighbours: on sparse
+// maps the tile-plan kernels win by a wide margin)
 static bool halo_policy(int64_t n_tgt, int64_t volume, int64_t n_pairs, int c_src, int c_dst) {
-  (void)n_tgt; (void)volume; (void)n_pairs; (void)c_src; (void)c_dst;
-  return false;
+  if (!halo_variant(c_src, c_dst).listed) return false;
+  return volume == 27 && n_tgt >= 10000 && n_pairs >= 6 * n_tgt;
 }
 
 }  // namespace me
@@ -598,7 +631,8 @@ extern "C" void me_debug_set_halo(int mode, int tile_rows, int kc, int skip) {
   g_halo_tile = tile_rows;
   g_halo_kc = kc;
   g_halo_skip = skip & 1;
-  g_halo_wd = skip >> 1;      // (tuning: skip = 1 + 2 * weight sets, e.g. 5 = skip + two sets, 9 = skip + four sets)
+  g_halo_wd = (skip >> 1) & 7;   // (tuning: skip = 1 + 2 * weight sets, e.g. 5 = skip + two sets, 9 = skip + four sets)
+  g_halo_cb4 = (skip >> 4) & 1;  // (+ 16: the 2 x 2-wave shape of 64 columns per wave on 128-column slabs)
 }
 extern "C" int32_t me_debug_halo_mode(void) { return g_halo_mode; }
 // phase counters of a -DME_HALO_TIMING build (zeros otherwise); reset != 0 clears them
@@ -638,15 +672,7 @@ extern "C" int32_t me_conv_halo_config_bf16(int64_t n_tgt, int64_t volume, int64
 extern "C" int32_t me_conv_halo_use_bf16(int64_t n_tgt, int64_t volume, int64_t n_pairs, int32_t c_src, int32_t c_dst) {
   HaloShape s;
   if (n_tgt <= 0 || !halo_shape(volume, c_src, c_dst, &s)) return 0;
-  int mode = g_halo_mode;
-  if (mode < 0) {
-    static int env_mode = -2;
-    if (env_mode == -2) {
-      const char *e = getenv("ME_AMD_HALO");
-      env_mode = (e && e[0] == '0') ? 0 : ((e && e[0] == '1') ? 1 : -1);
-    }
-    mode = env_mode;
-  }
+  const int mode = g_halo_mode >= 0 ? g_halo_mode : halo_env_mode();
   if (mode >= 0) return mode ? 1 : 0;
   return halo_policy(n_tgt, volume, n_pairs, c_src, c_dst) ? 1 : 0;
 }
@@ -689,8 +715,9 @@ static int launch_halo(const HaloShape &hs, const __bf16 *src, int c_src, const 
   typedef void (*kernel_t)(const __bf16 *, int, const bf16x8 *, int, int, int, int, const int32_t *, const int32_t *,
                            const uint16_t *, const uint32_t *, const int32_t *, const int32_t *, const int32_t *, __bf16 *,
                            int64_t, int, int, float *, float *);
-  const int wd = (g_halo_wd == 2 || g_halo_wd == 4) ? g_halo_wd : 2;
-  const int which = !g_halo_skip ? 2 : (wd == 4 ? 1 : 0);
+  const HaloVariant hv = halo_variant(c_src, c_dst);
+  const int wd = (hv.wd == 2 || hv.wd == 4) ? hv.wd : 2;
+  const int which = !hv.skip ? 2 : (wd == 4 ? 1 : 0);
   kernel_t fn = which == 2 ? &k_conv_halo_bf16<T, CB, NWC, NWR, KC, false, 2>
                            : (which == 1 ? &k_conv_halo_bf16<T, CB, NWC, NWR, KC, true, 4> : &k_conv_halo_bf16<T, CB, NWC, NWR, KC, true, 2>);
   static bool attr_set[3] = {false, false, false};
@@ -746,7 +773,8 @@ extern "C" int me_conv_halo_bf16(const uint16_t *src_feat_dev, int64_t n_src, in
   ME_HALO(TV, 2, 2, 2, 32);      \
   ME_HALO(TV, 2, 2, 2, 64);      \
   ME_HALO(TV, 2, 1, 4, 32);      \
-  ME_HALO(TV, 2, 1, 4, 64)
+  ME_HALO(TV, 2, 1, 4, 64);      \
+  ME_HALO(TV, 4, 2, 2, 64)
   ME_HALO_T(128);
   ME_HALO_T(64);
 #undef ME_HALO_T

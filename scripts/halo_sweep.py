@@ -22,6 +22,8 @@ for ts in (2, 4, 8, 16):
     levels[ts] = mgr0.get_coordinates(key).clone()
 ALL = {1: [(96, 96), (128, 96)], 2: [(96, 96), (32, 32), (128, 96)], 4: [(128, 128), (64, 64), (192, 128), (32, 64)],
        8: [(128, 128), (256, 256), (384, 256), (64, 128)], 16: [(256, 256), (128, 256)]}
+if os.environ.get("DGRAD_SHAPES", "0") == "1":     # the input-gradient launches of the same layers: (Cout, Cin) as (src, dst)
+    ALL = {ts: [(b, a) for a, b in v if a != b] for ts, v in ALL.items()}
 want = os.environ.get("LEVELS", "1,2,4,8,16")
 CONFIGS = os.environ.get("CONFIGS", "off;128,0,1;64,0,1;128,0,0").split(";")
 REPS = int(os.environ.get("REPS", "20"))

@@ -211,3 +211,31 @@ def test_halo_conv_batch_norm_partials(device, halo):
             assert torch.allclose(bn.bn.running_mean.float(), 0.1 * mean, atol=1e-3, rtol=1e-2), host
         finally:
             ME.set_host(prev)
+
+
+@pytest.mark.parametrize("cin,cout", [(192, 128), (32, 64)])
+def test_halo_auto_policy_selects_the_measured_shapes(device, host_layer, cin, cout):
+    """ME_AMD_HALO=auto (the default): the shapes the policy lists — 192 -> 128 forward, 256 -> 384 and 64 -> 32 as input
+    gradients (here: the backward pass of 32 -> 64) — run on the halo kernel when the map is large and dense enough, every
+    other launch of the layer on the tile-plan kernels; results against the oracle as everywhere"""
+    from minkowskiengine_amd import _lib
+    lib = _lib.load()
+    assert lib.me_debug_halo_mode() == -1
+    assert lib.me_conv_halo_use_bf16(80000, 27, 700000, 192, 128) == 1
+    assert lib.me_conv_halo_use_bf16(80000, 27, 700000, 64, 32) == 1 and lib.me_conv_halo_use_bf16(21000, 27, 220000, 256, 384) == 1
+    assert lib.me_conv_halo_use_bf16(80000, 27, 700000, 128, 128) == 0      # not listed
+    assert lib.me_conv_halo_use_bf16(80000, 27, 200000, 192, 128) == 0      # too sparse
+    assert lib.me_conv_halo_use_bf16(5000, 27, 60000, 192, 128) == 0        # too small
+    assert lib.me_conv_halo_use_bf16(80000, 8, 80000, 192, 128) == 0        # not a 3^3 kernel
+    coords = make_cloud(12000, 24, 3, seed=21)
+    conv, x, y, feats, gy = _run_layer(device, coords, cin, cout, 3)
+    plans = [(n, v) for n, v in _halo_plans(x.coordinate_manager._manager) if v is not None]
+    if host_layer == "python":
+        assert len(plans) == 1, [n for n, _ in plans]        # exactly one side of the layer takes the halo kernel
+        assert ("halo_out" in plans[0][0]) == (cin == 192)
+    _, km = O.kernel_map(coords.numpy(), y.C.cpu().numpy(), O.make_region(3, 3, 1, 1))
+    w = conv.kernel.detach().float().cpu().numpy()
+    assert_bf16_close(y.F.detach().float().cpu().numpy(), O.conv_forward(feats.numpy(), w, km, len(coords)), "forward")
+    gi, gw = O.conv_backward(feats.numpy(), gy.numpy(), w, km)
+    assert_bf16_close(x.F.grad.float().cpu().numpy(), gi, "grad_in")
+    assert_close(conv.kernel.grad.cpu().numpy(), gw)
