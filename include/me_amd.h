@@ -469,8 +469,12 @@ int me_conv_gather_bf16(const uint16_t *src_feat_dev, int64_t n_src, int32_t c_s
  *                             c_src % 32 == 0, c_dst in {32, 64, 96} or a multiple of 128; answers the plan geometry.
  *   me_halo_plan_build        tbl_dev int32 [volume, n_tgt] (source row of (offset, table column) or -1; nbr for forward,
  *                             nbrT for dgrad), col_order_dev int32 [n_tgt] or NULL: table column of tile position p
- *                             (NULL: p).  Out: halo_cnt_dev int32 [tiles] distinct source rows of each tile;
- *                             halo_rows_dev int32 [tiles * s_cap] its first s_cap of them, ascending; lidx_dev uint16
+ *                             (NULL: p); src_pos_dev int32 [n_src] position of every SOURCE row in a spatial order of
+ *                             the source map and src_order_dev int32 [n_src] its inverse (both or neither): the halo
+ *                             slots are then in position order (fewer LDS bank conflicts among the rows a gather
+ *                             touches together), else in row order.  Out: halo_cnt_dev int32 [tiles] distinct source
+ *                             rows of each tile; halo_rows_dev int32 [tiles * s_cap] its first s_cap of them in slot
+ *                             order; lidx_dev uint16
  *                             [tiles * volume * tile_rows]: 0 = no neighbour, 1 + halo slot, 0xffff = beyond s_cap;
  *                             kmask_dev uint32 [tiles * volume]: bit g = 16-row group g has a neighbour at the offset.
  *                             A tile whose halo exceeds s_cap is served by direct gathers off tbl_dev (any map works).
@@ -482,8 +486,8 @@ int32_t me_conv_halo_use_bf16(int64_t n_tgt, int64_t volume, int64_t n_pairs, in
 int32_t me_conv_halo_config_bf16(int64_t n_tgt, int64_t volume, int64_t n_pairs, int32_t c_src, int32_t c_dst,
                                  int32_t *tile_rows, int32_t *s_cap);
 int64_t me_halo_plan_num_tiles(int64_t n_tgt, int32_t tile_rows);
-int me_halo_plan_build(const int32_t *tbl_dev, const int32_t *col_order_dev, int64_t n_tgt, int64_t volume,
-                       int32_t tile_rows, int32_t s_cap, int32_t *halo_cnt_dev, int32_t *halo_rows_dev,
+int me_halo_plan_build(const int32_t *tbl_dev, const int32_t *col_order_dev, const int32_t *src_pos_dev,
+                       const int32_t *src_order_dev, int64_t n_tgt, int64_t volume, int32_t tile_rows, int32_t s_cap, int32_t *halo_cnt_dev, int32_t *halo_rows_dev,
                        uint16_t *lidx_dev, uint32_t *kmask_dev, void *stream);
 int me_conv_halo_bf16(const uint16_t *src_feat_dev, int64_t n_src, int32_t c_src, const uint16_t *packed_w_dev,
                       int64_t volume, int32_t c_dst, const int32_t *halo_cnt_dev, const int32_t *halo_rows_dev,

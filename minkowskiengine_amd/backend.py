@@ -272,7 +272,7 @@ class _CoordinateMapGPU:
     src/coordinate_map_gpu.cuh:47-223); `bbox` (host ints: column minima, then maxima) came back with the
     insert's own read-back and sizes the spatial index, which is built on first use."""
 
-    __slots__ = ("coords", "table", "capacity", "tensor_stride", "n", "bbox", "_spatial", "_zorder")
+    __slots__ = ("coords", "table", "capacity", "tensor_stride", "n", "bbox", "_spatial", "_zorder", "_zorder_inv")
 
     def __init__(self, coords, table, capacity, tensor_stride, n, bbox=None):
         self.coords, self.table, self.capacity = coords, table, capacity
@@ -280,6 +280,16 @@ class _CoordinateMapGPU:
         self.bbox = bbox
         self._spatial = False    # False: not tried yet; None: not available
         self._zorder = None
+        self._zorder_inv = None
+
+    def zorder_inv(self):
+        """row -> its position in zorder() (int32 [n])"""
+        if self._zorder_inv is None and self.n > 0:
+            z = self.zorder()
+            inv = torch.empty_like(z)
+            inv[z.long()] = torch.arange(self.n, dtype=torch.int32, device=z.device)
+            self._zorder_inv = inv
+        return self._zorder_inv
 
     def zorder(self):
         """Rows in Z-order (Morton keys of the coordinates in units of the tensor stride, batch index on top;
@@ -1338,13 +1348,17 @@ def _halo_launch_cfg(km, target, n_tgt, c_src, c_dst):
             return None
         # a position-space table (LDS-bucketed map build) is read through pos_of_row
         col_order = out_order if native is None else km._store[km._name("pos", target)][out_order.long()].contiguous()
+        # the halo slots in the Z-order of the SOURCE map: rows that are gathered together sit in neighbouring slots
+        smap = km.in_map if target == "out" else km.out_map
+        src_order = smap.zorder() if smap is not None else None
+        src_pos = smap.zorder_inv() if smap is not None else None
         tiles = int(lib.me_halo_plan_num_tiles(n_tgt, tile_rows))
         halo_cnt = torch.empty(tiles, dtype=torch.int32, device=dev)
         halo_rows = torch.empty(tiles * s_cap, dtype=torch.int32, device=dev)
         lidx = torch.empty(tiles * km.volume * tile_rows, dtype=torch.int16, device=dev)
         kmask = torch.empty(tiles * km.volume, dtype=torch.int32, device=dev)
         with _on(dev), _roctx("me:halo_plan"):
-            _lib.check(lib.me_halo_plan_build(_ptr(tbl), _ptr(col_order), n_tgt, km.volume, tile_rows, s_cap,
+            _lib.check(lib.me_halo_plan_build(_ptr(tbl), _ptr(col_order), _ptr(src_pos), _ptr(src_order), n_tgt, km.volume, tile_rows, s_cap,
                                               _ptr(halo_cnt), _ptr(halo_rows), _ptr(lidx), _ptr(kmask), _stream(dev)))
         km._store[name] = (tile_rows, s_cap, halo_cnt, halo_rows, lidx, kmask, tbl, col_order, out_order)
         if km._recipe is not None:

@@ -32,6 +32,7 @@ constexpr uint32_t kHaloNone = 0xffffffffu;
 
 template <int N>
 __global__ __launch_bounds__(256) void k_halo_plan(const int32_t *__restrict__ tbl, const int32_t *__restrict__ col_order,
+                                                   const int32_t *__restrict__ src_pos, const int32_t *__restrict__ src_order,
                                                    int64_t n_tgt, int volume, int T, int s_cap,
                                                    int32_t *__restrict__ halo_cnt, int32_t *__restrict__ halo_rows,
                                                    uint16_t *__restrict__ lidx, uint32_t *__restrict__ kmask) {
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(256) void k_halo_plan(const int32_t *__restrict__ t
     uint32_t key = kHaloNone;
     if (e < n_cand) {
       const int32_t s = source_of(e);
-      if (s >= 0) key = (uint32_t)s;
+      if (s >= 0) key = (uint32_t)(src_pos ? src_pos[s] : s);     // slots in POSITION order of the source map when given
     }
     s_key[e] = key;
   }
@@ -97,15 +98,17 @@ __global__ __launch_bounds__(256) void k_halo_plan(const int32_t *__restrict__ t
   }
   __syncthreads();
   if (tid == 0) halo_cnt[tile] = S;
-  for (int j = tid; j < min(S, s_cap); j += 256) halo_rows[tile * s_cap + j] = (int32_t)s_uniq[j];
+  for (int j = tid; j < min(S, s_cap); j += 256)
+    halo_rows[tile * s_cap + j] = src_order ? src_order[s_uniq[j]] : (int32_t)s_uniq[j];
   for (int e = tid; e < n_cand; e += 256) {
     const int32_t s = source_of(e);
     uint16_t li = 0;
     if (s >= 0) {
-      int lo = 0, hi = S;   // first slot with s_uniq[slot] >= s
+      const uint32_t key = (uint32_t)(src_pos ? src_pos[s] : s);
+      int lo = 0, hi = S;   // first slot with s_uniq[slot] >= key
       while (lo < hi) {
         const int mid = (lo + hi) >> 1;
-        if (s_uniq[mid] < (uint32_t)s) lo = mid + 1;
+        if (s_uniq[mid] < key) lo = mid + 1;
         else hi = mid;
       }
       li = lo < s_cap ? (uint16_t)(lo + 1) : (uint16_t)0xffffu;
@@ -120,21 +123,23 @@ __global__ __launch_bounds__(256) void k_halo_plan(const int32_t *__restrict__ t
 // ---- the convolution --------------------------------------------------------------------------------------------------------
 // T rows per tile; a workgroup is NWR x NWC waves: wave (wr, wc) owns R = T / 16 / NWR row groups x CB 16-column blocks.
 // KC: source channels staged per pass over the offsets.  SKIP: skip the MFMAs of 16-row groups without a neighbour.
-__host__ __device__ constexpr int halo_s_cap(int t) { return t <= 64 ? 319 : 479; }   // halo slots of a tile (+ the zero row)
+__host__ __device__ constexpr int halo_s_cap(int t) { return t <= 64 ? 319 : 383; }   // halo slots of a tile (+ the zero row)
 
-// LDS image of the halo: slot r (0 = the zero row) is a row of KC bf16; inside the row the 16-byte piece p of 32-channel
-// step s sits at s * 64 + ((p ^ z(r)) * 16) — the XOR only permutes the four pieces of a step, so that the STEP is a plain
-// immediate offset of the operand read and the lane's part of the address is one XOR (q * 16) on a per-slot word that is
-// computed once per tile (s_atab).  96-channel rows are padded to 224 bytes and not permuted.
+// LDS image of the halo: slot r (0 = the zero row) is a row of KC bf16 padded by 32 bytes, its 16-byte pieces in order.
+// A ds_read_b128 serves 16 lanes per LDS cycle — eight rows' piece of one 8-channel quarter and eight rows' piece of the
+// next — over 16 bank slots of 16 bytes; the rows of a gather are unrelated, so what matters is that the slot is a good
+// hash of (row, piece): with 128-byte rows a read of one 32-channel step could only ever touch HALF the slots (simulated on
+// the MinkUNet scene, LDS cycles per read, conflict-free = 4: 13.6 for that layout, 10.0 for an XOR of the whole piece
+// index, 9.1 for 32 bytes of padding, 7.6 with the slots also ordered by position: halo plan).  Padding keeps the step
+// an immediate offset and the lane's part a plain add.
 template <int KC>
 struct HaloLayout {
-  static constexpr int kRowBytes = KC == 96 ? 224 : KC * 2;
-  static constexpr bool kXor = KC != 96;
-  __host__ __device__ static constexpr int z(int r) { return kXor ? ((r >> (KC == 32 ? 2 : 1)) & 3) : 0; }
-  __host__ __device__ static constexpr int slot_word(int r) { return r * kRowBytes + z(r) * 16; }            // lane part: ^ (q * 16) | + q * 16
-  __host__ __device__ static constexpr int piece_off(int r, int u) { return r * kRowBytes + (u >> 2) * 64 + (((u & 3) ^ z(r)) * 16); }
+  static constexpr int kRowBytes = KC * 2 + 32;
+  static constexpr bool kXor = false;
+  __host__ __device__ static constexpr int slot_word(int r) { return r * kRowBytes; }            // lane part: + q * 16
+  __host__ __device__ static constexpr int piece_off(int r, int u) { return r * kRowBytes + u * 16; }
 };
-__host__ __device__ constexpr int halo_row_bytes(int kc) { return kc == 96 ? 224 : kc * 2; }
+__host__ __device__ constexpr int halo_row_bytes(int kc) { return kc * 2 + 32; }
 __host__ __device__ constexpr int halo_out_ld(int nc) { return nc + 8; }   // bf16 elements per row of the output image
 __host__ __device__ constexpr int conv_halo_lds(int t, int nc, int kc, int s_cap, int volume, int nt) {
   const int halo = (s_cap + 1) * halo_row_bytes(kc);
@@ -679,10 +684,12 @@ extern "C" int32_t me_conv_halo_use_bf16(int64_t n_tgt, int64_t volume, int64_t 
 
 extern "C" int64_t me_halo_plan_num_tiles(int64_t n_tgt, int32_t tile_rows) { return tile_rows > 0 ? ceil_div(n_tgt, tile_rows) : 0; }
 
-extern "C" int me_halo_plan_build(const int32_t *tbl_dev, const int32_t *col_order_dev, int64_t n_tgt, int64_t volume,
+extern "C" int me_halo_plan_build(const int32_t *tbl_dev, const int32_t *col_order_dev, const int32_t *src_pos_dev,
+                                  const int32_t *src_order_dev, int64_t n_tgt, int64_t volume,
                                   int32_t tile_rows, int32_t s_cap, int32_t *halo_cnt_dev, int32_t *halo_rows_dev,
                                   uint16_t *lidx_dev, uint32_t *kmask_dev, void *stream) {
   ME_CHECK(tbl_dev && halo_cnt_dev && halo_rows_dev && lidx_dev && kmask_dev, "null argument");
+  ME_CHECK((src_pos_dev == nullptr) == (src_order_dev == nullptr), "halo plan: source positions and their inverse, or neither");
   ME_CHECK(volume >= 1 && volume <= 64 && tile_rows >= 16 && tile_rows % 16 == 0 && volume * tile_rows <= 4096,
            "halo plan: volume x tile_rows must be <= 4096");
   ME_CHECK(s_cap >= 1 && s_cap < 0xffff, "halo plan: s_cap");
@@ -692,7 +699,7 @@ extern "C" int me_halo_plan_build(const int32_t *tbl_dev, const int32_t *col_ord
   const dim3 grid((unsigned)tiles), block(256);
   hipStream_t st = (hipStream_t)stream;
 #define ME_HP(NV)                                                                                                        \
-  hipLaunchKernelGGL((k_halo_plan<NV>), grid, block, 0, st, tbl_dev, col_order_dev, n_tgt, (int)volume, (int)tile_rows, \
+  hipLaunchKernelGGL((k_halo_plan<NV>), grid, block, 0, st, tbl_dev, col_order_dev, src_pos_dev, src_order_dev, n_tgt, (int)volume, (int)tile_rows, \
                      (int)s_cap, halo_cnt_dev, halo_rows_dev, lidx_dev, kmask_dev)
   if (cand <= 256) ME_HP(256);
   else if (cand <= 512) ME_HP(512);

@@ -114,6 +114,8 @@ struct CoordMap {         // one coordinate map resident in HBM (replaces Coordi
   std::shared_ptr<SpatialIndex> spatial();
   Tensor zorder_rows;     // rows in Z-order (me_coords_spatial_keys + argsort), built on first use: the halo kernel's tiles
   Tensor zorder();
+  Tensor zorder_inverse;  // row -> its position in zorder()
+  Tensor zorder_inv();
 };
 
 struct InsertResult {

@@ -416,6 +416,15 @@ Tensor CoordMap::zorder() {
   return zorder_rows;
 }
 
+Tensor CoordMap::zorder_inv() {
+  if (!zorder_inverse.defined() && n > 0) {
+    Tensor z = zorder();
+    zorder_inverse = at::empty_like(z);
+    zorder_inverse.index_put_({z.to(at::kLong)}, at::arange(n, z.options()));
+  }
+  return zorder_inverse;
+}
+
 // Halo plan of a launch side (csrc/conv_halo.hip): tiles are runs of target rows in the Z-order of the target's
 // coordinate map (small halos); null when the side has no coordinate map attached.
 std::shared_ptr<HaloPlan> KernelMap::halo_plan(const std::string &target, int tile_rows, int s_cap) {
@@ -439,13 +448,17 @@ std::shared_ptr<HaloPlan> KernelMap::halo_plan(const std::string &target, int ti
   // a position-space table (LDS-bucketed map build) is read through pos_of_row
   h->col_order = tp.second.defined() ? store_get(*store, name("pos", target)).index({h->out_order.to(at::kLong)}).contiguous()
                                      : h->out_order;
+  // the halo slots in the Z-order of the SOURCE map: rows that are gathered together sit in neighbouring slots
+  auto smap = target == "out" ? in_map : out_map;
+  Tensor src_order = smap ? smap->zorder() : Tensor(), src_pos = smap ? smap->zorder_inv() : Tensor();
   const int64_t tiles = me_halo_plan_num_tiles(n_tgt, tile_rows);
   h->halo_cnt = empty_i32({tiles}, dev);
   h->halo_rows = empty_i32({tiles * s_cap}, dev);
   h->lidx = at::empty({tiles * volume * tile_rows}, at::TensorOptions().dtype(at::kShort).device(dev));
   h->kmask = empty_i32({tiles * volume}, dev);
   c10::DeviceGuard guard(dev);
-  me_ok(me_halo_plan_build(ptr<int32_t>(h->tbl), ptr<int32_t>(h->col_order), n_tgt, volume, tile_rows, s_cap,
+  me_ok(me_halo_plan_build(ptr<int32_t>(h->tbl), ptr<int32_t>(h->col_order), ptr<int32_t>(src_pos), ptr<int32_t>(src_order), n_tgt,
+                           volume, tile_rows, s_cap,
                            ptr<int32_t>(h->halo_cnt), ptr<int32_t>(h->halo_rows), ptr<uint16_t>(h->lidx),
                            ptr<uint32_t>(h->kmask), stream_of(dev)));
   store->halos[nm] = h;

@@ -27,8 +27,9 @@ def halo():
         lib.me_debug_set_halo(-1, 0, 0, 1)
 
 
-def numpy_halo_plan(tbl, col_order, n_tgt, tile_rows, s_cap):
-    """the arrays of me_halo_plan_build, restated: per tile the sorted distinct source rows, local slots, group masks"""
+def numpy_halo_plan(tbl, col_order, n_tgt, tile_rows, s_cap, src_pos=None):
+    """the arrays of me_halo_plan_build, restated: per tile the distinct source rows sorted by position (src_pos: row ->
+    position; None: by row), local slots, group masks"""
     volume = tbl.shape[0]
     tiles = -(-n_tgt // tile_rows)
     cnt = np.zeros(tiles, np.int32)
@@ -40,9 +41,13 @@ def numpy_halo_plan(tbl, col_order, n_tgt, tile_rows, s_cap):
         cols = col_order[p] if col_order is not None else p
         v = tbl[:, cols]                                    # [volume, rows_here]
         u = np.unique(v[v >= 0])
+        if src_pos is not None:
+            u = u[np.argsort(src_pos[u], kind="stable")]
         cnt[t] = len(u)
         rows[t, :min(len(u), s_cap)] = u[:s_cap]
-        slot = np.searchsorted(u, np.maximum(v, 0))
+        rank = np.empty(int(u.max()) + 1 if len(u) else 1, np.int64)
+        rank[u] = np.arange(len(u))
+        slot = rank[np.maximum(v, 0)] if len(u) else np.zeros_like(v)
         li = np.where(v >= 0, np.where(slot < s_cap, slot + 1, 0xffff), 0)
         lidx[t, :, :len(p)] = li
         for g in range(tile_rows // 16):
@@ -71,12 +76,28 @@ def test_halo_plan_matches_numpy(device, n, extent, tile_rows, s_cap):
         rows = torch.full((tiles * s_cap,), -1, dtype=torch.int32, device=device)
         lidx = torch.empty(tiles * km.volume * tile_rows, dtype=torch.int16, device=device)
         kmask = torch.empty(tiles * km.volume, dtype=torch.int32, device=device)
-        _lib.check(lib.me_halo_plan_build(tbl.data_ptr(), col_order.data_ptr() if col_order is not None else None, n_tgt,
+        # both slot orders: by row (no position arrays) and by the source map's Z-order
+        smap = km.in_map if target == "out" else km.out_map
+        for spos, sord in ((None, None), (smap.zorder_inv(), smap.zorder())):
+            _check_plan(lib, _lib, km, tbl, col_order, spos, sord, n_tgt, tile_rows, s_cap, device, target)
+
+
+def _check_plan(lib, _lib, km, tbl, col_order, spos, sord, n_tgt, tile_rows, s_cap, device, target):
+    if True:
+        tiles = -(-n_tgt // tile_rows)
+        cnt = torch.empty(tiles, dtype=torch.int32, device=device)
+        rows = torch.full((tiles * s_cap,), -1, dtype=torch.int32, device=device)
+        lidx = torch.empty(tiles * km.volume * tile_rows, dtype=torch.int16, device=device)
+        kmask = torch.empty(tiles * km.volume, dtype=torch.int32, device=device)
+        _lib.check(lib.me_halo_plan_build(tbl.data_ptr(), col_order.data_ptr() if col_order is not None else None,
+                                          spos.data_ptr() if spos is not None else None,
+                                          sord.data_ptr() if sord is not None else None, n_tgt,
                                           km.volume, tile_rows, s_cap, cnt.data_ptr(), rows.data_ptr(), lidx.data_ptr(),
                                           kmask.data_ptr(), None))
         torch.cuda.synchronize()
         r_cnt, r_rows, r_lidx, r_kmask = numpy_halo_plan(tbl.cpu().numpy()[:, :n_tgt], None if col_order is None else
-                                                          col_order.cpu().numpy(), n_tgt, tile_rows, s_cap)
+                                                          col_order.cpu().numpy(), n_tgt, tile_rows, s_cap,
+                                                          None if spos is None else spos.cpu().numpy())
         assert np.array_equal(cnt.cpu().numpy(), r_cnt), target
         assert np.array_equal(rows.cpu().numpy().reshape(tiles, s_cap), r_rows), target
         assert np.array_equal(lidx.cpu().numpy().view(np.uint16).reshape(r_lidx.shape), r_lidx), target
