@@ -57,5 +57,19 @@ PY
     cat gpurun_out/r05_pytest_gpu_${TAG:-x}.log
     timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke OK')" 2>&1 | tail -3 | tee gpurun_out/r05_smoke_${TAG:-x}.log
     ;;
+  final)   # closing session: GPU suite, smoke, the driver's bench command, kernel statistics of the default line and of the MinkUNet34C step
+    OUT=gpurun_out/r05_final; mkdir -p $OUT
+    timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -8 > $OUT/pytest_gpu.log; cat $OUT/pytest_gpu.log
+    timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke OK')" 2>&1 | tail -3 | tee $OUT/smoke.log
+    timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; tail -c 600 $OUT/bench_default.json | head -c 300; echo
+    cd /tmp && export TMPDIR=/tmp
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_def -o default -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --cpu-budget 0 --extra-workloads off --pmc off > $GRAFT_REPO_ROOT/$OUT/prof_default.log 2>&1
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_unet -o unet -- python $GRAFT_REPO_ROOT/bench.py --workload minkunet --dtype bf16 --steps 5 --warmup 3 --cpu-budget 0 --pmc off --min-time 0 --min-blocks 5 --max-blocks 5 --no-gpu-state > $GRAFT_REPO_ROOT/$OUT/prof_unet.log 2>&1
+    cd $GRAFT_REPO_ROOT
+    cp $(find /tmp/prof_def -name "*kernel_stats.csv" | head -1) $OUT/rocprof_kernel_stats_default.csv
+    cp $(find /tmp/prof_unet -name "*kernel_stats.csv" | head -1) $OUT/rocprof_kernel_stats_minkunet34c_bf16.csv
+    head -8 $OUT/rocprof_kernel_stats_default.csv | cut -c1-160
+    timeout 600 python scripts/unet_layers.py > $OUT/layers_minkunet34c_bf16.log 2>&1; head -12 $OUT/layers_minkunet34c_bf16.log
+    ;;
   *) echo "unknown step $step"; exit 2;;
 esac

@@ -3,6 +3,7 @@ Prints every (kernel, layer shape) row with calls, us per call, TFLOP/s, tile ge
 import os, sys, collections, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "examples"))
+os.environ.setdefault("ME_AMD_HOST", "python")     # (the table is recorded by patching the ctypes host's launch functions)
 import torch
 import minkowskiengine_amd as ME
 from minkowskiengine_amd import backend as MEB
