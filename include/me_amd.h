@@ -60,7 +60,8 @@ typedef struct me_region {
  *              features (me_conv_target_f64, me_conv_wgrad_f64, me_pool_*_f64, me_global_pool_f64, me_broadcast_f64);
  *              all tile plans of a scene in four launches (me_plan_job, me_plan_jobs_init, me_plan_build_multi)
  *   1.5 (150)  round 5: bf16 convolution on an LDS-staged source halo with register accumulators
- *              (me_conv_halo_config_bf16, me_halo_plan_build, me_conv_halo_bf16) */
+ *              (me_conv_halo_config_bf16, me_halo_plan_build, me_conv_halo_bf16); stacked-offset kernel for layers
+ *              with at most 8 source channels (me_conv_stem_use_bf16, me_conv_stem_tile_rows, me_conv_stem_bf16) */
 int me_version(void);
 const char *me_last_error(void);
 /* Load the device code of every translation unit of the library now (needs a GPU; ABI 1.5): HIP loads a unit's code object
@@ -495,6 +496,26 @@ int me_conv_halo_bf16(const uint16_t *src_feat_dev, int64_t n_src, int32_t c_src
                       const int32_t *col_order_dev, const int32_t *out_order_dev, uint16_t *dst_feat_dev,
                       int64_t n_tgt, int32_t tile_rows, int32_t s_cap, float *part_mean_dev, float *part_m2_dev,
                       void *stream);
+
+/* ---- bf16 convolution with the offsets stacked into the MFMA reduction (csrc/conv_stem.hip, ABI 1.5) -------------
+ * For layers with AT MOST 8 source channels (a network's stem: 3 -> 32 channels over 5^3 offsets): one MFMA step
+ * multiplies FOUR offsets (4 x 8 channels = its 32-deep reduction), every neighbour row is one 16-byte load, a wave keeps
+ * 32 target rows x all output columns in registers over all offsets; the weights are read from the layer's OWN kernel
+ * tensor (no packed image) and kept in LDS as MFMA fragments.  The reference runs one gather - GEMM - scatter launch per
+ * offset (src/convolution_kernel.cu:320-496).  Semantics of me_conv_target_bf16 (weights rounded to bf16, exact products,
+ * fp32 sums in a fixed order, one rounding); results are bitwise reproducible, not the bits of the tile-plan kernel.
+ *   me_conv_stem_use_bf16   the policy both hosts follow: c_src <= 8, c_dst in {16, 32, 64}, volume >= 8 (ME_AMD_STEM=0 | 1)
+ *   me_conv_stem_tile_rows  rows per tile (256): the tile of the batch-norm partials
+ *   me_conv_stem_bf16       src_feat_dev bf16 [n_src, 8] (rows padded with zeros to 8 channels, 16-byte aligned; c_src
+ *                           must be 8), w_dev the kernel [volume, 8, c_dst] (transposed != 0: [volume, c_dst, 8]) in
+ *                           fp32 (w_is_f32) or bf16; tbl_dev / col_order_dev / out_order_dev as me_conv_halo_bf16;
+ *                            part_mean_dev / part_m2_dev [ceil(n_tgt / tile rows)][c_dst] or NULL. */
+int32_t me_conv_stem_use_bf16(int64_t n_tgt, int64_t volume, int32_t c_src, int32_t c_dst);
+int32_t me_conv_stem_tile_rows(void);
+int me_conv_stem_bf16(const uint16_t *src_feat_dev, int64_t n_src, int32_t c_src, const void *w_dev, int32_t w_is_f32,
+                      int32_t transposed, int64_t volume, int32_t c_dst, const int32_t *tbl_dev,
+                      const int32_t *col_order_dev, const int32_t *out_order_dev, uint16_t *dst_feat_dev, int64_t n_tgt,
+                      float *part_mean_dev, float *part_m2_dev, void *stream);
 
 /* ---- fp32 convolution on the bf16 matrix pipe ("bf16x6" split, csrc/conv_f32x3.hip) ---------------------
  * Same contract as me_conv_target_f32 (fp32 features / weights in, fp32 out, the reference's

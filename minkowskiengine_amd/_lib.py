@@ -137,6 +137,10 @@ SIGNATURES = {
     "me_conv_pack_weights_f32x3": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "me_conv_target_f32x3": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp,
                                             c_vp, c_i64, c_i32, c_i32, c_vp]),
+    "me_conv_stem_use_bf16": (c_i32, [c_i64, c_i64, c_i32, c_i32]),
+    "me_conv_stem_tile_rows": (c_i32, []),
+    "me_conv_stem_bf16": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_i64,
+                                         c_vp, c_vp, c_vp]),
     "me_conv_halo_use_bf16": (c_i32, [c_i64, c_i64, c_i64, c_i32, c_i32]),
     "me_conv_halo_config_bf16": (c_i32, [c_i64, c_i64, c_i64, c_i32, c_i32, _P_I32, _P_I32]),
     "me_halo_plan_num_tiles": (c_i64, [c_i64, c_i32]),
@@ -212,6 +216,7 @@ DEBUG_SIGNATURES = {
     "me_debug_set_bf16_ws": (None, [ctypes.c_int]),
     "me_debug_set_halo": (None, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "me_debug_halo_mode": (c_i32, []),
+    "me_debug_set_stem": (None, [ctypes.c_int, ctypes.c_int]),
     "me_debug_halo_timing": (ctypes.c_int, [c_vp, c_i32]),
     "me_debug_set_bf16_ws_fuse": (None, [ctypes.c_int]),
     "me_debug_set_bf16_ws_depth": (None, [ctypes.c_int]),

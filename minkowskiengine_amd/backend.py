@@ -1081,7 +1081,9 @@ class CoordinateMapManagerGPU_c10:
                     km = self._kernel_maps.get(key)
                     if km is not None:
                         n_tgt = km.n_out if target == "out" else km.n_in
-                        if not (bf16 and _halo_launch_cfg(km, target, n_tgt, c_src, c_dst) is not None):
+                        if bf16 and c_src == 8 and _lib.load().me_conv_stem_use_bf16(n_tgt, km.volume, c_src, c_dst):
+                            km.table_pos(target)       # (the stacked-offset kernel reads the neighbour table: no plan)
+                        elif not (bf16 and _halo_launch_cfg(km, target, n_tgt, c_src, c_dst) is not None):
                             _conv_launch_cfg(km, target, n_tgt, c_src, c_dst, bf16)
                         done += 1
                 elif op[0] == "wgrad_cfg":
@@ -1566,6 +1568,29 @@ def _conv_target(src_feat, kernel, km, target, n_tgt, name="conv_target", transp
             _timed(name, dev, lambda: _lib.check(lib.me_conv_gather_bf16(
                 src_feat.data_ptr(), src_feat.shape[0], c_src, packed.data_ptr(), km.volume, c_dst, p_tbl, p_order,
                 out.data_ptr(), n_tgt, stream)), flops=2.0 * km.n_pairs * c_src * c_dst if KERNEL_TIMER else 0.0)
+        return out
+    if bf16 and c_src == 8 and lib.me_conv_stem_use_bf16(n_tgt, volume, c_src, c_dst):
+        # at most 8 source channels (a stem): four offsets per MFMA step straight off the neighbour table and the layer's
+        # own kernel tensor — no tile plan, no packed image (csrc/conv_stem.hip)
+        _check(kernel.dtype in (torch.float32, torch.bfloat16), "kernel must be float32 or bfloat16")
+        ck = ("stem", target)
+        cfg = km._launch_cache.get(ck)
+        if cfg is None:
+            tbl, order = km.table_pos(target)
+            cfg = km._launch_cache[ck] = (tbl, order, _ptr(tbl), _ptr(order), int(lib.me_conv_stem_tile_rows()))
+        _, _, p_tbl, p_order, tile_rows = cfg
+        kern = kernel if kernel.is_contiguous() else kernel.contiguous()
+        stream = _stream(dev)
+        with _on(dev):
+            want_stats = bool(_CONV_BN_STATS and _BN_STATS_HINT[0] and name == "conv_forward")
+            part = torch.empty(2, -(-n_tgt // tile_rows), c_dst, dtype=torch.float32, device=dev) if want_stats else None
+            _timed(name, dev, lambda: _lib.check(lib.me_conv_stem_bf16(
+                src_feat.data_ptr(), src_feat.shape[0], c_src, kern.data_ptr(), 1 if kern.dtype == torch.float32 else 0,
+                1 if transposed else 0, volume, c_dst, p_tbl, None, p_order, out.data_ptr(), n_tgt,
+                part[0].data_ptr() if want_stats else None, part[1].data_ptr() if want_stats else None, stream)),
+                flops=2.0 * km.n_pairs * c_src * c_dst)
+        if want_stats:
+            _bn_partials_put(out, part, tile_rows)
         return out
     halo = _halo_launch_cfg(km, target, n_tgt, c_src, c_dst) if bf16 else None
     if halo is not None:

@@ -1889,10 +1889,10 @@ extern "C" __attribute__((visibility("hidden"))) void me_preload_coords(void) {
 extern "C" {
 void me_preload_conv(void); void me_preload_conv_bf16(void); void me_preload_conv_bf16_ws(void); void me_preload_conv_f32x3(void);
 void me_preload_conv_halo(void); void me_preload_coords(void); void me_preload_norm(void); void me_preload_pack(void);
-void me_preload_f64(void); void me_preload_pool(void);
+void me_preload_f64(void); void me_preload_pool(void); void me_preload_conv_stem(void);
 int me_preload(void) {
   me_preload_coords(); me_preload_conv(); me_preload_conv_bf16(); me_preload_conv_bf16_ws(); me_preload_conv_f32x3();
-  me_preload_conv_halo(); me_preload_norm(); me_preload_pack(); me_preload_pool(); me_preload_f64();
+  me_preload_conv_halo(); me_preload_conv_stem(); me_preload_norm(); me_preload_pack(); me_preload_pool(); me_preload_f64();
   ME_HIP(hipGetLastError());
   return 0;
 }

@@ -74,6 +74,8 @@ void me_debug_set_wgrad_ws(int mode);
 void me_debug_set_halo(int mode, int tile_rows, int kc, int skip);
 int32_t me_debug_halo_mode(void);
 int me_debug_halo_timing(uint64_t *out8, int32_t reset);   /* phase counters of a -DME_HALO_TIMING build */
+/* stacked-offset kernel (conv_stem.hip): -1 policy / 0 never / 1 wherever the shape is supported */
+void me_debug_set_stem(int mode, int groups);   /* groups: 16-row groups per wave, 0 policy | 1 | 2 | 4 */
 
 #if defined(__GNUC__) || defined(__clang__)
 #pragma GCC visibility pop

@@ -351,6 +351,32 @@ static Tensor conv_target(const Tensor &src, const Tensor &kernel, KernelMap &km
                              ptr<int32_t>(tbl), ptr<double>(out), n_tgt, st));
     return out;
   }
+  if (bf16 && c_src == 8 && me_conv_stem_use_bf16(n_tgt, volume, c_src, c_dst)) {
+    // at most 8 source channels (a stem): four offsets per MFMA step straight off the neighbour table and the layer's own
+    // kernel tensor — no tile plan, no packed image (csrc/conv_stem.hip)
+    check(kernel.scalar_type() == at::kFloat || kernel.scalar_type() == at::kBFloat16, "kernel must be float32 or bfloat16");
+    auto tp = km.table_pos(target);
+    Tensor w = kernel.contiguous();
+    c10::DeviceGuard guard(dev);
+    void *st = stream_of(dev);
+    const int tile_rows = me_conv_stem_tile_rows();
+    const bool want_stats = !transposed && target == "out" && g_conv_bn_stats_hint && conv_bn_stats_enabled();
+    Tensor part;
+    int64_t tiles = 0;
+    if (want_stats) {
+      tiles = (n_tgt + tile_rows - 1) / tile_rows;
+      part = at::empty({2, tiles, (int64_t)c_dst}, at::TensorOptions().dtype(at::kFloat).device(dev));
+    }
+    {
+      ScopedTimer tm(transposed ? "conv_dgrad" : "conv_forward", g_timing ? 2.0 * (double)km.n_pairs() * c_src * c_dst : 0.0, st);
+      me_ok(me_conv_stem_bf16(ptr<uint16_t>(src), src.size(0), c_src, w.data_ptr(), w.scalar_type() == at::kFloat ? 1 : 0,
+                              transposed ? 1 : 0, volume, c_dst, ptr<int32_t>(tp.first), nullptr, ptr<int32_t>(tp.second),
+                              ptr<uint16_t>(out), n_tgt, want_stats ? ptr<float>(part) : nullptr,
+                              want_stats ? ptr<float>(part) + tiles * c_dst : nullptr, st));
+    }
+    if (want_stats) bn_partials_put(out, part, tile_rows);
+    return out;
+  }
   const ConvCfg &cfg = km.conv_cfg(target, n_tgt, c_src, c_dst, bf16);
   c10::DeviceGuard guard(dev);
   void *st = stream_of(dev);

@@ -52,6 +52,20 @@ for k, w in (l.get("workloads") or {}).items():
     print(k, {x: w.get(x) for x in ("value", "ms_per_step", "error")}, json.dumps(w.get("hip_graph")), json.dumps(w.get("timing")), json.dumps(w.get("gpu_state")))
 PY
     ;;
+  stem)    # stacked-offset kernel: parity tests, the bf16 layer tests it now serves, sweep against the tile-plan kernel
+    timeout 600 python -m pytest tests/test_gpu_stem.py tests/test_gpu_bf16.py -m gpu -x -q 2>&1 | grep -v "^  File\|^Extension" | tail -25 | tee gpurun_out/r05_stem_tests.log
+    grep -q " passed" gpurun_out/r05_stem_tests.log && ! grep -q "failed\|error\|core" gpurun_out/r05_stem_tests.log || exit 1
+    timeout 300 python scripts/stem_sweep.py 2>&1 | grep -v "^$" | tee gpurun_out/r05_stem_sweep.txt
+    (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stem -o stem -- python $GRAFT_REPO_ROOT/scripts/stem_sweep.py > /dev/null 2>&1; python - <<'PY'
+import csv, glob
+for f in glob.glob('/tmp/prof_stem/**/*kernel_stats.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        if any(t in r['Name'] for t in ('stem', 'conv_tile', 'conv_ws', 'k_conv')):
+            print(r['Name'][:90], r['Calls'], 'avg_us', float(r['AverageNs']) / 1e3, 'min_us', float(r['MinNs']) / 1e3)
+PY
+    ) 2>&1 | tee gpurun_out/r05_stem_kernels.txt
+    timeout 300 python bench.py --workload minkunet --dtype bf16 --steps 20 --warmup 5 --cpu-budget 0 --pmc off > gpurun_out/r05_stem_unet.json 2> gpurun_out/r05_stem_unet.err; tail -c 1500 gpurun_out/r05_stem_unet.json
+    ;;
   suite)   # the whole GPU suite + smoke
     timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > gpurun_out/r05_pytest_gpu_${TAG:-x}.log
     cat gpurun_out/r05_pytest_gpu_${TAG:-x}.log
