@@ -84,6 +84,13 @@ PY
     cp $(find /tmp/prof_unet -name "*kernel_stats.csv" | head -1) $OUT/rocprof_kernel_stats_minkunet34c_bf16.csv
     head -8 $OUT/rocprof_kernel_stats_default.csv | cut -c1-160
     timeout 600 python scripts/unet_layers.py > $OUT/layers_minkunet34c_bf16.log 2>&1; head -12 $OUT/layers_minkunet34c_bf16.log
+    # a new scene every step: lazily, as one recipe replay, with a loader thread
+    for mode in "fresh" "fresh --replay-maps" "pipelined"; do
+      timeout 300 python bench.py --workload minkunet --dtype bf16 --scenes $mode --steps 10 --warmup 3 --cpu-budget 0 --pmc off --no-gpu-state --no-graph-probe 2> /dev/null | tail -1 | python -c "
+import json, sys
+d = json.loads(sys.stdin.readline())
+print('scenes $mode', d.get('ms_per_step'), 'ms/step', d.get('timing', {}).get('blocks_ms_per_step'))" | tee -a $OUT/unet_scenes.log
+    done
     ;;
   *) echo "unknown step $step"; exit 2;;
 esac
