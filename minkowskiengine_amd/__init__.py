@@ -22,7 +22,7 @@ from .convolution import (  # noqa: F401
 from .pruning import MinkowskiPruning, MinkowskiPruningFunction  # noqa: F401
 from .union import MinkowskiUnion, MinkowskiUnionFunction  # noqa: F401
 from .coordinate_manager import (  # noqa: F401
-    CoordinateManager, set_gpu_allocator, set_memory_manager_backend, set_map_prefetch, map_prefetch_enabled)
+    CoordinateManager, set_gpu_allocator, set_memory_manager_backend, set_map_prefetch, map_prefetch_enabled, map_prefetch_tag)
 from .kernel_generator import KernelGenerator, get_kernel_volume  # noqa: F401
 from .layers import (  # noqa: F401
     MinkowskiBatchNorm, MinkowskiDropout, MinkowskiELU, MinkowskiLeakyReLU, MinkowskiLinear, MinkowskiReLU,
@@ -43,8 +43,8 @@ from . import utils  # noqa: F401
 
 def _install_optimizer_hook():
     """The weight-image cache is validated by tensor version counters, which writes through `p.data` do not bump
-    (Apex / DeepSpeed-style optimizers update that way).  Every torch.optim.Optimizer step therefore advances the
-    cache epoch: the first convolution after it repacks all images in one launch — which a training step does anyway.
+    (Apex / DeepSpeed-style optimizers update that way).  Every torch.optim.Optimizer step therefore marks the images of
+    ITS parameters stale: the first convolution after it repacks them in one launch — which a training step does anyway.
     ME_AMD_PACK_CACHE_HOOK=0 leaves the cache to the version counters alone."""
     import os
     if os.environ.get("ME_AMD_PACK_CACHE_HOOK", "1") == "0":
@@ -53,7 +53,11 @@ def _install_optimizer_hook():
         from torch.optim.optimizer import register_optimizer_step_post_hook
     except ImportError:  # pragma: no cover  (torch < 2.0)
         return
-    register_optimizer_step_post_hook(lambda opt, args, kwargs: invalidate_packed_weights())
+    def _after_step(opt, args, kwargs):
+        # only the stepping optimizer's own parameters: the images of frozen / teacher networks stay valid
+        invalidate_packed_weights([p for g in opt.param_groups for p in g["params"]])
+
+    register_optimizer_step_post_hook(_after_step)
 
 
 _install_optimizer_hook()

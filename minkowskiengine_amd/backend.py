@@ -1510,11 +1510,19 @@ _PACKERS = {}
 _PACK_EPOCH = [0]
 
 
-def invalidate_packed_weights():
+def invalidate_packed_weights(ptrs=None):
     """Every cached weight image is repacked at its next use.  For weight updates the tensor version counter cannot
     see — writes through `p.data` (Apex / DeepSpeed-style optimizers, EMA, clipping); in-place operations on the
-    parameter itself (`with torch.no_grad(): p.add_(...)`, `copy_`, torch.optim) are seen without it."""
-    _PACK_EPOCH[0] += 1
+    parameter itself (`with torch.no_grad(): p.add_(...)`, `copy_`, torch.optim) are seen without it.
+    ptrs: a set of storage addresses (`p.data_ptr()`) — only the images of THOSE weights go stale (the optimizer-step
+    hook passes its own parameters: frozen / teacher networks keep their images)."""
+    if ptrs is None:
+        _PACK_EPOCH[0] += 1
+        return
+    for pk in _PACKERS.values():
+        for e in pk.entries.values():
+            if e.ptr in ptrs:
+                e.epoch = -1
 
 
 def _packed_weights(kernel, mode, transposed, c_src, c_dst, elems):

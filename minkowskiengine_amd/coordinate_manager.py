@@ -1,7 +1,9 @@
 """CoordinateManager: thin Python wrapper that owns a backend coordinate-map manager
 (reference: MinkowskiEngine/MinkowskiCoordinateManager.py:107-440)."""
 import collections
+import contextlib
 import os
+import threading
 import weakref
 
 import torch
@@ -22,7 +24,7 @@ _minkowski_algorithm = MinkowskiAlgorithm.DEFAULT
 # host read-backs of the build out of the forward pass (backend.CoordinateMapManagerGPU_c10.prefetch, docs/HISTORY.md 9.8).
 _map_prefetch = os.environ.get("ME_AMD_MAP_PREFETCH", "0") != "0"
 _recent_managers = collections.deque(maxlen=4)   # weak references to the latest CoordinateManagers made by SparseTensors
-# (D, native host?) -> [recipe, misses]: the request log a manager left behind when it was destroyed — a scene's manager
+# (D, native host?, tag) -> [recipe, misses]: the request log a manager left behind when it was destroyed — a scene's manager
 # usually dies right after its step, which is exactly when its log is complete
 _published_recipes = {}
 _PUBLISH_PATIENCE = 8   # that many successive shorter logs replace a longer published one (the network has changed)
@@ -37,6 +39,23 @@ def map_prefetch_enabled():
     return _map_prefetch
 
 
+# Two networks of the same dimension in one process (train + eval, student + teacher, alternating models): the scenes of
+# the smaller one would replay the larger one's recipe — the longest log wins — and build maps and plans it never uses,
+# every scene.  A tag keeps their request logs apart: managers created inside `with map_prefetch_tag("eval"):`
+# publish and replay only logs of the same tag (per thread; the default tag is "").
+_prefetch_tag = threading.local()
+
+
+@contextlib.contextmanager
+def map_prefetch_tag(tag):
+    prev = getattr(_prefetch_tag, "value", "")
+    _prefetch_tag.value = str(tag)
+    try:
+        yield
+    finally:
+        _prefetch_tag.value = prev
+
+
 def _prefetch_from_previous(manager):
     """Called by SparseTensor for a freshly created manager whose coordinates have just been inserted.  The recipe is
     the LONGEST request log among the latest managers that are still alive: with a loader thread (utils.ScenePrefetcher)
@@ -47,12 +66,13 @@ def _prefetch_from_previous(manager):
         best = None
         for ref in _recent_managers:
             prev = ref()
-            if prev is None or prev is manager or prev.D != manager.D or prev._native != manager._native:
-                continue                         # (a request log belongs to the host layer that wrote it)
+            if (prev is None or prev is manager or prev.D != manager.D or prev._native != manager._native
+                    or prev._tag != manager._tag):
+                continue                         # (a request log belongs to the host layer — and the tag — that wrote it)
             r = prev.recipe()
             if best is None or len(r) > len(best):
                 best = r
-        pub = _published_recipes.get((manager.D, manager._native))
+        pub = _published_recipes.get((manager.D, manager._native, manager._tag))
         if pub is not None and (best is None or len(pub[0]) > len(best)):
             best = pub[0]
         if best:
@@ -98,6 +118,7 @@ class CoordinateManager:
                                         else B.CoordinateMapManagerGPU_default)
         self._manager = self._CoordinateManagerClass(int(minkowski_algorithm), num_threads)
         self._native = _host.is_native()
+        self._tag = getattr(_prefetch_tag, "value", "")     # see map_prefetch_tag
         self.D = D
         self.minkowski_algorithm = minkowski_algorithm
 
@@ -109,7 +130,7 @@ class CoordinateManager:
             r = self._manager.recipe()
             if not r:
                 return
-            key = (self.D, self._native)
+            key = (self.D, self._native, self._tag)
             pub = _published_recipes.get(key)
             if pub is None or len(r) >= len(pub[0]):
                 _published_recipes[key] = [r, 0]

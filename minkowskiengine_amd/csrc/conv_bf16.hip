@@ -1493,8 +1493,18 @@ int me_conv_plan_config_bf16(int64_t n_tgt, int64_t volume, int64_t n_pairs, int
   // those launches stay with k_conv_tile_bf16)
   const double p_side = volume > 1 ? (double)(n_pairs > n_tgt ? n_pairs - n_tgt : 0) / ((double)(volume - 1) * (double)n_tgt) : 1.0;
   if (g_bf16_ws != 0 && conv_bf16_ws_shape(v.nc, v.kc) && c_src % v.kc == 0 && p_side * ME_MAX_TILE_ROWS >= 24.0) {
-    *tile_rows = plan_tile_rows_ws(v, n_tgt, volume, p_side);
-    return 0;
+    const int t_ws = plan_tile_rows_ws(v, n_tgt, volume, p_side);
+    // The hosts fuse offsets when an off-centre (tile, offset) item holds fewer than 24 pairs AT THE TILE HEIGHT THEY GET,
+    // and a fused launch runs on k_conv_tile_bf16: a short wave-specialised tile (a small map: few rounds) would send it
+    // there on a geometry tuned for the other kernel.  Same rule here: pairs per item at t_ws (the hosts' figure
+    // when both sides of the map have n_tgt rows; strided maps differ by the rows of the smaller side).
+    const int64_t tiles_ws = ceil_div(n_tgt, t_ws);
+    const double per_item = volume > 1 ? (double)(n_pairs > n_tgt ? n_pairs - n_tgt : 0) / (double)std::max<int64_t>(1, (volume - 1) * tiles_ws)
+                                       : 1e9;
+    if (per_item >= 24.0) {
+      *tile_rows = t_ws;
+      return 0;
+    }
   }
   s.group_cycles = 64.0 + (v.kc / 32) * 24.0;  // LDS-bound: accumulator read-add-write + operand reads
   s.stage_row_bytes = (v.kc + 16) * 2 + 4;

@@ -156,8 +156,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("conv_bn_stats_hint", &conv_bn_stats_hint, py::arg("flag"));
   m.def("set_conv_bn_stats", &set_conv_bn_stats, py::arg("enabled"));
   m.def("invalidate_packed_weights", &invalidate_packed_weights);
+  m.def("invalidate_packed_weights_for", &invalidate_packed_weights_for, py::arg("sorted_ptrs"));
   m.def("set_grad_destination", [](const Tensor &param, const py::object &dest) { set_grad_destination(param, opt_tensor(dest)); });
   m.def("clear_grad_destinations", &clear_grad_destinations);
+  m.def("debug_fail_next_plan_batch", &debug_fail_next_plan_batch);
   m.def("arm_grad_destinations", &arm_grad_destinations);
   m.def("set_policy", &Policy::set, "integer policies of the native host by name (tests, tuning scripts)");
   m.def("timing_enable", &timing_enable);

@@ -138,6 +138,7 @@ struct LazyOffsets {
 
 struct Plan {
   Tensor plan_src, plan_dst, batch_desc, tile_bptr, item_gptr;
+  bool failed = false;   // a deferred plan whose batched build threw: out of the caches, never launched (manager.cpp PlanBatch)
 };
 // plan of the output-stationary bf16 kernel (csrc/conv_halo.hip, me_halo_plan_build): tiles of `tile_rows` target
 // positions, the distinct source rows of each (its halo, staged in LDS), local slots and group masks per offset
@@ -299,6 +300,7 @@ Tensor pruning_backward(const Tensor &grad_out, CoordinateMapKey *in_key, Coordi
 // gradient destinations (ops.cpp; distributed.GradientArena): parameter -> the buffer its gradient is written into
 void set_grad_destination(const Tensor &param, const Tensor &dest);   // dest undefined: forget it
 void clear_grad_destinations();
+void debug_fail_next_plan_batch();   // the next batched tile-plan build throws (tests)
 void arm_grad_destinations();          // every entry may be used once (again)
 Tensor grad_destination(const Tensor &param, at::IntArrayRef shape);
 
@@ -322,5 +324,6 @@ std::vector<std::tuple<std::string, double, double>> timing_records(bool clear);
 Tensor packed_weights(const Tensor &kernel, int mode, bool transposed, int c_src, int c_dst, int64_t elems);
 // every cached image is repacked at its next use: for weight updates the version counter cannot see (`p.data` writes)
 void invalidate_packed_weights();
+void invalidate_packed_weights_for(const std::vector<int64_t> &sorted_ptrs);
 
 }  // namespace meh

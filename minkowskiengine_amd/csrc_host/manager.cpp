@@ -3,6 +3,7 @@
 // (insert_and_map :349-399, stride :402-429, kernel_map :655-823), src/coordinate_map_gpu.cu, src/kernel_map.cuh.
 #include <cstring>
 #include "host.hpp"
+#include <functional>
 
 #include <dlfcn.h>
 
@@ -323,13 +324,39 @@ Tensor KernelMap::order(const std::string &target, const std::string &tile_order
 struct PlanBatch {
   std::vector<me_plan_job> jobs;
   std::vector<Tensor> keep;      // neighbour tables / tile orders / plan arrays of the jobs
+  std::vector<std::function<void()>> undo;   // takes a deferred plan (and the configurations holding it) out of the caches
   c10::Device dev = c10::Device(c10::kCPU);
 };
 static thread_local PlanBatch *g_plan_batch = nullptr;
 
+static void build_plan_batch(PlanBatch &b);
+
+// A deferred plan is in the cache BEFORE it is built.  If the build fails (allocation, geometry) the cached plans of the
+// batch hold uninitialised arrays: they — and the launch configurations that point at them — leave the caches before the
+// error travels on, so that a caller who catches it (an out-of-memory retry) rebuilds them on the next use.
 static void flush_plan_batch(PlanBatch &b) {
   if (b.jobs.empty()) return;
+  try {
+    build_plan_batch(b);
+  } catch (...) {
+    for (auto &u : b.undo) u();
+    b.jobs.clear();
+    b.keep.clear();
+    b.undo.clear();
+    throw;
+  }
+  b.undo.clear();
+}
+
+static bool g_fail_next_plan_batch = false;   // debug_fail_next_plan_batch(): fault injection for the test of the undo path
+void debug_fail_next_plan_batch() { g_fail_next_plan_batch = true; }
+
+static void build_plan_batch(PlanBatch &b) {
   RoctxRange rx("me:tile_plans_multi");
+  if (g_fail_next_plan_batch) {
+    g_fail_next_plan_batch = false;
+    check(false, "injected failure of a batched tile-plan build (debug_fail_next_plan_batch)");
+  }
   const int64_t total = me_plan_jobs_init(b.jobs.data(), (int32_t)b.jobs.size());
   check(total >= 0, "invalid plan geometry in a batch of plans");
   const int64_t bytes = (int64_t)(b.jobs.size() * sizeof(me_plan_job));
@@ -391,6 +418,15 @@ std::shared_ptr<Plan> KernelMap::plan(const std::string &target, int tile_rows, 
     g_plan_batch->keep.push_back(tp.first);
     if (gather_order.defined()) g_plan_batch->keep.push_back(gather_order);
     store->plans[nm] = p;
+    {
+      std::shared_ptr<KernelMapStore> st = store;
+      KernelMap *self = this;     // (alive for the batch: the manager holds the kernel maps while it replays a recipe)
+      g_plan_batch->undo.push_back([st, self, nm, p]() {
+        p->failed = true;           // (configurations of other views of this map that hold it: see conv_cfg)
+        st->plans.erase(nm);
+        self->conv_cfgs.clear();
+      });
+    }
     return p;
   }
   Tensor ws = workspace(me_plan_workspace_bytes(n_tgt, volume, tile_rows), dev);
@@ -477,7 +513,10 @@ const ConvCfg &KernelMap::conv_cfg(const std::string &target, int64_t n_tgt, int
   const std::string ck = target + "/" + std::to_string(c_src) + "/" + std::to_string(c_dst) + (bf16 ? "/b" : "/f") +
                          (split ? "s" : "-");
   auto it = conv_cfgs.find(ck);
-  if (it != conv_cfgs.end()) return it->second;
+  if (it != conv_cfgs.end()) {
+    if (!(it->second.plan && it->second.plan->failed)) return it->second;
+    conv_cfgs.erase(it);   // (held a plan of a batch whose build failed: configured again)
+  }
   // the plan geometry depends on the pair count (density): the one host value a first launch on a new map waits for
   const int64_t np = n_pairs();
   int32_t t = 0, g = 0, sk = 1;

@@ -76,6 +76,15 @@ void pack_one(PackEntry &e, const c10::Device &dev) {
 
 void invalidate_packed_weights() { g_pack_epoch.fetch_add(1); }
 
+// only the images of the weights at these storage addresses (the optimizer-step hook passes the stepping optimizer's
+// own parameters: frozen / teacher networks keep their images)
+void invalidate_packed_weights_for(const std::vector<int64_t> &ptrs) {
+  std::lock_guard<std::mutex> lk(g_packers_mu);
+  for (auto &pk : g_packers)
+    for (auto &kv : pk.second.entries)
+      if (std::binary_search(ptrs.begin(), ptrs.end(), (int64_t)(intptr_t)kv.second->ptr)) kv.second->epoch = -1;
+}
+
 Tensor packed_weights(const Tensor &kernel, int mode, bool transposed, int c_src, int c_dst, int64_t elems) {
   const c10::Device dev = kernel.device();
   std::lock_guard<std::mutex> lk(g_packers_mu);

@@ -98,12 +98,19 @@ def key_like(key, *args):
     return backend_of(key).CoordinateMapKey(*(args if args else (key.get_coordinate_size(),)))
 
 
-def invalidate_packed_weights():
-    """Repack every cached weight image (both hosts) at its next use: for weight updates the tensor version counter
-    cannot see, i.e. writes through `p.data`.  Called by the package after every torch.optim step."""
-    _python_backend.invalidate_packed_weights()
+def invalidate_packed_weights(params=None):
+    """Repack cached weight images (both hosts) at their next use: for weight updates the tensor version counter cannot
+    see, i.e. writes through `p.data`.  params=None: every image; an iterable of tensors: only the images of those
+    weights (what the package's optimizer-step hook passes: the stepping optimizer's own parameters)."""
+    if params is None:
+        _python_backend.invalidate_packed_weights()
+        if _native is not None:
+            _native.invalidate_packed_weights()
+        return
+    ptrs = {int(p.data_ptr()) for p in params}
+    _python_backend.invalidate_packed_weights(ptrs)
     if _native is not None:
-        _native.invalidate_packed_weights()
+        _native.invalidate_packed_weights_for(sorted(ptrs))
 
 
 def set_grad_destination(param, dest):

@@ -38,7 +38,9 @@ class ScenePrefetcher:
         self.build_ms, self.wait_ms = [], []
 
     def __iter__(self):
-        from .. import SparseTensor, set_map_prefetch, map_prefetch_enabled
+        from .. import SparseTensor, set_map_prefetch, map_prefetch_enabled, map_prefetch_tag
+        from ..coordinate_manager import _prefetch_tag
+        tag = getattr(_prefetch_tag, "value", "")     # the consumer's tag travels to the loader thread (thread-local)
         # a HIGH-priority stream: the builds are hundreds of microsecond-sized kernels with a handful of size read-backs
         # between them; behind the training stream's queue of full-chip convolutions each read-back would wait its turn
         side = self._side or torch.cuda.Stream(priority=-1)
@@ -51,6 +53,7 @@ class ScenePrefetcher:
         def work():
             try:
                 torch.cuda.set_device(device)
+                _prefetch_tag.value = tag
                 it = iter(self._scenes)
                 while not stop.is_set():
                     # the iterator itself runs under the loader's stream: host-to-device copies it issues are ordered

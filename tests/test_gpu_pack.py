@@ -138,6 +138,17 @@ def test_data_writes_need_the_invalidate_call_and_optimizer_steps_do_not(device,
     assert conv.kernel._version == v
     y2 = conv(x).F.clone()
     assert not torch.equal(y1, y2) and torch.equal(y2, fresh(conv.kernel.detach()))
+    # the hook invalidates only the stepping optimizer's OWN parameters: a frozen layer that is not in the
+    # optimizer keeps its image — shown with a .data write on it that nothing announces: still the old output after the
+    # other layer's optimizer step, the new one after the targeted call
+    frozen = ME.MinkowskiConvolution(64, 128, kernel_size=3, dimension=3).to(device)
+    z0 = frozen(x).F.clone()
+    frozen.kernel.data.add_(0.25)
+    opt.step()
+    assert torch.equal(frozen(x).F, z0)
+    ME.invalidate_packed_weights([frozen.kernel])
+    z1 = frozen(x).F.clone()
+    assert not torch.equal(z1, z0) and torch.equal(z1, fresh(frozen.kernel.detach()))
     # reset_parameters writes in place on the parameter itself: seen by the version counter
     torch.manual_seed(3)
     conv.reset_parameters()

@@ -170,8 +170,8 @@ def test_recipe_for_a_new_scene_is_the_longest_one_around():
             return list(self.log)
 
     class FakeManager:
-        def __init__(self, log, D=3, native=True):
-            self._manager, self.D, self._native, self.replayed = FakeNative(log), D, native, None
+        def __init__(self, log, D=3, native=True, tag=""):
+            self._manager, self.D, self._native, self.replayed, self._tag = FakeNative(log), D, native, None, tag
 
         def recipe(self):
             return self._manager.recipe()
@@ -213,9 +213,29 @@ def test_recipe_for_a_new_scene_is_the_longest_one_around():
         short = FakeManager(["conv_cfg;0"])
         for _ in range(CM._PUBLISH_PATIENCE - 1):
             CM.CoordinateManager.__del__(short)
-        assert CM._published_recipes[(3, True)][0] == full
+        assert CM._published_recipes[(3, True, "")][0] == full
         CM.CoordinateManager.__del__(short)
-        assert CM._published_recipes[(3, True)][0] == ["conv_cfg;0"]
+        assert CM._published_recipes[(3, True, "")][0] == ["conv_cfg;0"]
+        # tags keep the logs of two networks apart (map_prefetch_tag): a tagged scene sees neither the untagged published
+        # log nor an untagged live manager, and publishes under its own key
+        live = FakeManager(full)
+        CM._recent_managers.append(__import__("weakref").ref(live))
+        with CM.map_prefetch_tag("eval"):
+            assert CM._prefetch_tag.value == "eval"
+        assert getattr(CM._prefetch_tag, "value", "") == ""
+        t1 = FakeManager([], tag="eval")
+        CM._prefetch_from_previous(t1)
+        assert t1.replayed is None
+        t1._manager.log = ["kernel_map;e"]
+        CM.CoordinateManager.__del__(t1)
+        assert CM._published_recipes[(3, True, "eval")][0] == ["kernel_map;e"]
+        t2 = FakeManager([], tag="eval")
+        CM._prefetch_from_previous(t2)
+        assert t2.replayed == ["kernel_map;e"]
+        u = FakeManager([])
+        CM._prefetch_from_previous(u)
+        assert u.replayed == full                 # (the untagged live manager's log; not the tagged ones)
+        CM._recent_managers.clear()
         CM.set_map_prefetch(False)                # off: nothing is replayed, nothing published
         CM._published_recipes.clear()
         CM.CoordinateManager.__del__(FakeManager(full))
