@@ -465,7 +465,9 @@ int me_conv_gather_bf16(const uint16_t *src_feat_dev, int64_t n_src, int32_t c_s
  * offset (src/convolution_kernel.cu:320-496).  Results are NOT the bits of me_conv_target_bf16 (there every batch
  * starts a new accumulator), they are bitwise reproducible.
  *   me_conv_halo_use_bf16     the policy: 1 when a host should run this launch side on the halo kernel (0: the tile-plan
- *                             kernel).  ME_AMD_HALO=0 | 1 | auto.  Both hosts of this repository follow it.
+ *                             kernel).  ME_AMD_HALO=0 | 1 | auto.  Both hosts of this repository follow it — from the
+ *                             me_conv_halo_min_uses()-th launch on the same kernel-map side on (the plan costs more
+ *                             than one launch saves: scenes that are not reused never build it).
  *   me_conv_halo_config_bf16  1 when the kernel is instantiated for (volume, c_src, c_dst): volume in [2, 32],
  *                             c_src % 32 == 0, c_dst in {32, 64, 96} or a multiple of 128; answers the plan geometry.
  *   me_halo_plan_build        tbl_dev int32 [volume, n_tgt] (source row of (offset, table column) or -1; nbr for forward,
@@ -484,6 +486,7 @@ int me_conv_gather_bf16(const uint16_t *src_feat_dev, int64_t n_src, int32_t c_s
  *                             part_mean_dev / part_m2_dev [tiles][c_dst] or NULL: the batch-norm partials of
  *                             me_conv_target_bf16_stats with tile_rows = the halo tile. */
 int32_t me_conv_halo_use_bf16(int64_t n_tgt, int64_t volume, int64_t n_pairs, int32_t c_src, int32_t c_dst);
+int32_t me_conv_halo_min_uses(void);   /* the launch count on one kernel-map side at which a host builds the halo plan (2; forced: 1) */
 int32_t me_conv_halo_config_bf16(int64_t n_tgt, int64_t volume, int64_t n_pairs, int32_t c_src, int32_t c_dst,
                                  int32_t *tile_rows, int32_t *s_cap);
 int64_t me_halo_plan_num_tiles(int64_t n_tgt, int32_t tile_rows);

@@ -141,6 +141,7 @@ SIGNATURES = {
     "me_conv_stem_tile_rows": (c_i32, []),
     "me_conv_stem_bf16": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_i64,
                                          c_vp, c_vp, c_vp]),
+    "me_conv_halo_min_uses": (c_i32, []),
     "me_conv_halo_use_bf16": (c_i32, [c_i64, c_i64, c_i64, c_i32, c_i32]),
     "me_conv_halo_config_bf16": (c_i32, [c_i64, c_i64, c_i64, c_i32, c_i32, _P_I32, _P_I32]),
     "me_halo_plan_num_tiles": (c_i64, [c_i64, c_i32]),

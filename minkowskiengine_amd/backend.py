@@ -1083,7 +1083,7 @@ class CoordinateMapManagerGPU_c10:
                         n_tgt = km.n_out if target == "out" else km.n_in
                         if bf16 and c_src == 8 and _lib.load().me_conv_stem_use_bf16(n_tgt, km.volume, c_src, c_dst):
                             km.table_pos(target)       # (the stacked-offset kernel reads the neighbour table: no plan)
-                        elif not (bf16 and _halo_launch_cfg(km, target, n_tgt, c_src, c_dst) is not None):
+                        elif not (bf16 and _halo_launch_cfg(km, target, n_tgt, c_src, c_dst, count=False) is not None):
                             _conv_launch_cfg(km, target, n_tgt, c_src, c_dst, bf16)
                         done += 1
                 elif op[0] == "wgrad_cfg":
@@ -1328,12 +1328,19 @@ def _grad_destination(param, shape):
     return d.view(tuple(shape))
 
 
-def _halo_launch_cfg(km, target, n_tgt, c_src, c_dst):
+def _halo_launch_cfg(km, target, n_tgt, c_src, c_dst, count=True):
     """Halo plan (csrc/conv_halo.hip) of a launch side when libme_amd's policy (me_conv_halo_use_bf16: ME_AMD_HALO, shape,
     density) sends it to the output-stationary kernel, else None -> the tile-plan kernels.  Tiles are runs of target
-    rows in the Z-order of the target's coordinate map (compact at every length: small halos)."""
+    rows in the Z-order of the target's coordinate map (compact at every length: small halos).
+    The plan is built at the me_conv_halo_min_uses()-th LAUNCH on this side (count=False: a recipe replay asks, no launch
+    follows) — it costs more than one launch saves, so a scene that is used once never builds it."""
     lib = _lib.load()
     if not lib.me_conv_halo_use_bf16(n_tgt, km.volume, km.n_pairs, c_src, c_dst):
+        return None
+    uk = ("halo_uses", target, c_src, c_dst)
+    uses = km._launch_cache.get(uk, 0) + (1 if count else 0)
+    km._launch_cache[uk] = uses
+    if uses < int(lib.me_conv_halo_min_uses()):
         return None
     t, cap = ctypes.c_int32(0), ctypes.c_int32(0)
     if not lib.me_conv_halo_config_bf16(n_tgt, km.volume, km.n_pairs, c_src, c_dst, ctypes.byref(t), ctypes.byref(cap)):
@@ -1363,7 +1370,8 @@ def _halo_launch_cfg(km, target, n_tgt, c_src, c_dst):
             _lib.check(lib.me_halo_plan_build(_ptr(tbl), _ptr(col_order), _ptr(src_pos), _ptr(src_order), n_tgt, km.volume, tile_rows, s_cap,
                                               _ptr(halo_cnt), _ptr(halo_rows), _ptr(lidx), _ptr(kmask), _stream(dev)))
         km._store[name] = (tile_rows, s_cap, halo_cnt, halo_rows, lidx, kmask, tbl, col_order, out_order)
-        if km._recipe is not None:
+        if km._recipe is not None and int(lib.me_conv_halo_min_uses()) <= 1:
+            # (forced mode only: under the policy the plan is a reward for reuse, not a request the next scene inherits)
             km._recipe.append(("conv_cfg", km._recipe_key, target, c_src, c_dst, True))
     return km._store[name]
 

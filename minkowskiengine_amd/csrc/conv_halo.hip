@@ -682,6 +682,15 @@ extern "C" int32_t me_conv_halo_use_bf16(int64_t n_tgt, int64_t volume, int64_t 
   return halo_policy(n_tgt, volume, n_pairs, c_src, c_dst) ? 1 : 0;
 }
 
+// A halo plan costs 75 - 110 us to build (a sort per tile) and saves 10 - 40 us per launch: it pays from the SECOND launch
+// on the same kernel-map side (a scene that is reused — cached maps), and loses 0.3 ms per scene when every step brings a
+// new one (profiles/r05_rocprof_kernel_stats_minkunet34c_bf16_fresh.csv).  The hosts build the plan at this launch count:
+// 2 under the policy (the first launch runs on the tile-plan kernel), 1 when the kernel is forced (ME_AMD_HALO=1, tests).
+extern "C" int32_t me_conv_halo_min_uses(void) {
+  const int mode = g_halo_mode >= 0 ? g_halo_mode : halo_env_mode();
+  return mode == 1 ? 1 : 2;
+}
+
 extern "C" int64_t me_halo_plan_num_tiles(int64_t n_tgt, int32_t tile_rows) { return tile_rows > 0 ? ceil_div(n_tgt, tile_rows) : 0; }
 
 extern "C" int me_halo_plan_build(const int32_t *tbl_dev, const int32_t *col_order_dev, const int32_t *src_pos_dev,

@@ -171,7 +171,9 @@ struct ConvCfg {          // launch geometry of a (kernel map side, channel shap
   int64_t elems;
   bool fuse, split;
   int split_k = 1;        // offset groups of a split-K launch (bf16 features on small maps; 1: not split)
-  std::shared_ptr<HaloPlan> halo;   // set: the launch runs on the halo kernel (me_conv_halo_use_bf16), `plan` is unset
+  std::shared_ptr<HaloPlan> halo;   // set: the launch runs on the halo kernel (me_conv_halo_use_bf16)
+  int halo_at_use = 0;    // > 0: the policy wants the halo kernel here from that launch count on (me_conv_halo_min_uses)
+  int uses = 0;           // launches that asked for this configuration (recipe replays do not count)
 };
 struct WgradCfg {
   std::vector<int64_t> koffs;

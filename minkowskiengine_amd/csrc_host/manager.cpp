@@ -514,7 +514,26 @@ const ConvCfg &KernelMap::conv_cfg(const std::string &target, int64_t n_tgt, int
                          (split ? "s" : "-");
   auto it = conv_cfgs.find(ck);
   if (it != conv_cfgs.end()) {
-    if (!(it->second.plan && it->second.plan->failed)) return it->second;
+    if (!(it->second.plan && it->second.plan->failed)) {
+      ConvCfg &c = it->second;
+      if (c.halo_at_use > 0 && g_plan_batch == nullptr && ++c.uses >= c.halo_at_use) {
+        // the side is launched again (a reused scene): now the halo plan pays (me_conv_halo_min_uses)
+        c.halo_at_use = 0;
+        int32_t ht = 0, hc = 0;
+        std::shared_ptr<HaloPlan> h;
+        if (me_conv_halo_config_bf16(n_tgt, volume, n_pairs(), c_src, c_dst, &ht, &hc)) h = halo_plan(target, ht, hc);
+        if (h) {
+          c.halo = h;
+          c.tile_rows = ht;
+          c.batch_groups = 0;
+          c.split = false;
+          c.fuse = false;
+          c.split_k = 1;
+          c.elems = me_conv_packed_weight_elems_bf16(volume, c_src, c_dst);
+        }
+      }
+      return c;
+    }
     conv_cfgs.erase(it);   // (held a plan of a batch whose build failed: configured again)
   }
   // the plan geometry depends on the pair count (density): the one host value a first launch on a new map waits for
@@ -526,7 +545,14 @@ const ConvCfg &KernelMap::conv_cfg(const std::string &target, int64_t n_tgt, int
     me_ok((bf16 ? me_conv_plan_config_bf16 : (split ? me_conv_plan_config_f32x3 : me_conv_plan_config))(
         n_tgt, volume, np, c_src, c_dst, &t, &g));
   ConvCfg c;
-  if (bf16 && me_conv_halo_use_bf16(n_tgt, volume, np, c_src, c_dst)) {
+  const bool halo_wanted = bf16 && me_conv_halo_use_bf16(n_tgt, volume, np, c_src, c_dst);
+  const int halo_min_uses = halo_wanted ? me_conv_halo_min_uses() : 0;
+  if (halo_wanted && halo_min_uses > 1) {
+    // ... from the halo_min_uses-th launch on: the plan costs more than one launch saves (a scene used once never builds it)
+    c.halo_at_use = halo_min_uses;
+    c.uses = g_plan_batch == nullptr ? 1 : 0;
+  }
+  if (halo_wanted && halo_min_uses <= 1) {
     // libme_amd's policy sends this launch side to the output-stationary kernel on an LDS-staged halo
     int32_t ht = 0, hc = 0;
     if (me_conv_halo_config_bf16(n_tgt, volume, np, c_src, c_dst, &ht, &hc)) c.halo = halo_plan(target, ht, hc);

@@ -250,10 +250,25 @@ def test_halo_auto_policy_selects_the_measured_shapes(device, host_layer, cin, c
     assert lib.me_conv_halo_use_bf16(80000, 8, 80000, 192, 128) == 0        # not a 3^3 kernel
     coords = make_cloud(12000, 24, 3, seed=21)
     conv, x, y, feats, gy = _run_layer(device, coords, cin, cout, 3)
+    # the FIRST launch on a kernel-map side runs on the tile-plan kernel: a halo plan costs more than one launch saves
+    # (me_conv_halo_min_uses() == 2 under the policy) — a scene that is used once never builds it
+    assert lib.me_conv_halo_min_uses() == 2
+    assert not [n for n, v in _halo_plans(x.coordinate_manager._manager) if v is not None]
+    first = (y.F.detach().clone(), x.F.grad.detach().clone())
+    # ... the second launch on the same maps (a reused scene) builds it: exactly one side of the layer takes the halo kernel
+    x.F.grad = None
+    conv.kernel.grad = None
+    y = conv(x)
+    y.F.backward(gy.to(device).to(torch.bfloat16))
     plans = [(n, v) for n, v in _halo_plans(x.coordinate_manager._manager) if v is not None]
     if host_layer == "python":
-        assert len(plans) == 1, [n for n, _ in plans]        # exactly one side of the layer takes the halo kernel
+        assert len(plans) == 1, [n for n, _ in plans]
         assert ("halo_out" in plans[0][0]) == (cin == 192)
+    # the two schedules agree to bf16 rounding (another summation order)
+    for what, a, b in (("forward", y.F, first[0]), ("grad_in", x.F.grad, first[1])):
+        a, b = a.detach().double().cpu().numpy(), b.double().cpu().numpy()
+        tol = 2.0 ** -7 * np.abs(b) + 2e-3 * max(1.0, np.abs(b).max())
+        assert not (np.abs(a - b) > tol).any(), (what, float(np.abs(a - b).max()))
     _, km = O.kernel_map(coords.numpy(), y.C.cpu().numpy(), O.make_region(3, 3, 1, 1))
     w = conv.kernel.detach().float().cpu().numpy()
     assert_bf16_close(y.F.detach().float().cpu().numpy(), O.conv_forward(feats.numpy(), w, km, len(coords)), "forward")
