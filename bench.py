@@ -94,7 +94,7 @@ def pmc_traffic(kernel, n, extent, cin, cout):
 # ------------------------------------------------------------------------------------------------------
 # HBM-side traffic, measured in THIS run (round 4): rocprofv3 --pmc passes over a child process
 # ------------------------------------------------------------------------------------------------------
-PMC_CONV_KERNELS = ("k_conv_tile", "k_wgrad", "k_conv_splitk_reduce", "k_conv_off")
+PMC_CONV_KERNELS = ("k_conv_tile", "k_wgrad", "k_conv_splitk_reduce", "k_conv_off", "k_conv_halo", "k_conv_stem")
 
 
 def pmc_pass(workload, dtype, counters, steps, timeout_s):
@@ -983,7 +983,7 @@ def bench_minkunet(args, ME, MEB, dist_utils, rank, world, dev, startup):
                    "fastest_block_ms_per_step": round(min(blocks) / args.steps * 1e3, 3),
                    "reported": "median block (max over ranks inside each block); per-kernel HIP events recorded in one "
                                "extra block outside the timed region"},
-        "roofline": {"bound": "mfma", "kernel": "all convolution launches of a step (k_conv_tile_* forward + dgrad, "
+        "roofline": {"bound": "mfma", "kernel": "all convolution launches of a step (k_conv_tile_* / k_conv_halo / k_conv_stem forward + dgrad, "
                                                 "k_wgrad_*); HIP-event timed" + (" in a separate eager pass: the timed "
                                                 "region replays a hipGraph" if graphed else ""),
                      "achieved": achieved if achieved is not None else whole,
