@@ -298,8 +298,20 @@ extern "C" int me_conv_stem_bf16(const uint16_t *src_feat_dev, int64_t n_src, in
                                  int32_t transposed, int64_t volume, int32_t c_dst, const int32_t *tbl_dev,
                                  const int32_t *col_order_dev, const int32_t *out_order_dev, uint16_t *dst_feat_dev,
                                  int64_t n_tgt, float *part_mean_dev, float *part_m2_dev, void *stream) {
-  ME_CHECK(src_feat_dev && w_dev && tbl_dev && dst_feat_dev, "null argument");
   ME_CHECK((part_mean_dev == nullptr) == (part_m2_dev == nullptr), "statistics: both partial arrays or none");
+  if (n_tgt > 0 && n_src <= 0) {
+    // a source side without rows: every neighbour is absent -> zeros (and statistics of zeros)
+    ME_CHECK(dst_feat_dev != nullptr && c_dst > 0, "null argument");
+    hipStream_t st0 = (hipStream_t)stream;
+    ME_HIP(hipMemsetAsync(dst_feat_dev, 0, (size_t)n_tgt * c_dst * 2, st0));
+    if (part_mean_dev != nullptr) {
+      const size_t bytes = (size_t)ceil_div(n_tgt, me_conv_stem_tile_rows()) * c_dst * 4;
+      ME_HIP(hipMemsetAsync(part_mean_dev, 0, bytes, st0));
+      ME_HIP(hipMemsetAsync(part_m2_dev, 0, bytes, st0));
+    }
+    return 0;
+  }
+  ME_CHECK(src_feat_dev && w_dev && tbl_dev && dst_feat_dev, "null argument");
   ME_CHECK(c_src == 8, "stacked-offset kernel: feature rows must be padded to 8 channels (16 bytes)");
   ME_CHECK(stem_shape(n_tgt, volume, c_src, c_dst), "no stacked-offset kernel for this shape");
   ME_CHECK((uintptr_t)src_feat_dev % 16 == 0 && (uintptr_t)dst_feat_dev % 8 == 0, "stacked-offset kernel: feature rows must be 16-byte aligned");

@@ -140,3 +140,19 @@ def test_stem_policy(device, stem):
     assert lib.me_conv_stem_use_bf16(200000, 125, 8, 32) == 0
     stem(1)
     assert lib.me_conv_stem_use_bf16(200000, 1, 8, 32) == 1
+
+
+def test_stem_conv_without_source_rows(device):
+    """a source side without rows (every neighbour absent): zeros and statistics of zeros, no launch on a null matrix"""
+    from minkowskiengine_amd import _lib
+    lib = _lib.load()
+    n_tgt, K, cout = 300, 27, 32
+    tbl = torch.full((K, n_tgt), -1, dtype=torch.int32, device=device)
+    w = torch.rand(K, 8, cout, device=device)
+    out = torch.full((n_tgt, cout), 7.0, dtype=torch.bfloat16, device=device)
+    tiles = -(-n_tgt // int(lib.me_conv_stem_tile_rows()))
+    part = torch.full((2, tiles, cout), 3.0, dtype=torch.float32, device=device)
+    _lib.check(lib.me_conv_stem_bf16(None, 0, 8, w.data_ptr(), 1, 0, K, cout, tbl.data_ptr(), None, None, out.data_ptr(), n_tgt,
+                                     part[0].data_ptr(), part[1].data_ptr(), None))
+    torch.cuda.synchronize()
+    assert float(out.float().abs().max()) == 0.0 and float(part.abs().max()) == 0.0
