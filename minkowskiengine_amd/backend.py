@@ -1585,7 +1585,8 @@ def _conv_target(src_feat, kernel, km, target, n_tgt, name="conv_target", transp
                 src_feat.data_ptr(), src_feat.shape[0], c_src, packed.data_ptr(), km.volume, c_dst, p_tbl, p_order,
                 out.data_ptr(), n_tgt, stream)), flops=2.0 * km.n_pairs * c_src * c_dst if KERNEL_TIMER else 0.0)
         return out
-    if bf16 and c_src == 8 and lib.me_conv_stem_use_bf16(n_tgt, volume, c_src, c_dst):
+    if (bf16 and c_src == 8 and src_feat.shape[0] < (1 << 28) and
+            lib.me_conv_stem_use_bf16(n_tgt, volume, c_src, c_dst)):
         # at most 8 source channels (a stem): four offsets per MFMA step straight off the neighbour table and the layer's
         # own kernel tensor — no tile plan, no packed image (csrc/conv_stem.hip)
         _check(kernel.dtype in (torch.float32, torch.bfloat16), "kernel must be float32 or bfloat16")

@@ -258,7 +258,9 @@ static int stem_groups() { return g_stem_g ? g_stem_g : 4; }
 static bool stem_shape(int64_t n_tgt, int64_t volume, int c_src, int c_dst) {
   return volume >= 1 && volume <= 512 && c_src == 8 && (c_dst == 16 || c_dst == 32 || c_dst == 64) &&
          conv_stem_lds((int)((volume + 15) / 16 * 4), c_dst / 16) <= kLdsBudget / 2 &&
-         volume * std::max<int64_t>(n_tgt, 1) < (1ll << 30);   // (32-bit byte offsets into the neighbour table)
+         // 32-bit byte offsets into the neighbour table — of the clamped look-ahead as well: the walk counts up to offset
+         // volume + 42 before it clamps to the last one
+         (volume + 43) * std::max<int64_t>(n_tgt, 1) < (1ll << 30);
 }
 
 }  // namespace me

@@ -360,7 +360,7 @@ static Tensor conv_target(const Tensor &src, const Tensor &kernel, KernelMap &km
                              ptr<int32_t>(tbl), ptr<double>(out), n_tgt, st));
     return out;
   }
-  if (bf16 && c_src == 8 && me_conv_stem_use_bf16(n_tgt, volume, c_src, c_dst)) {
+  if (bf16 && c_src == 8 && src.size(0) < (1ll << 28) && me_conv_stem_use_bf16(n_tgt, volume, c_src, c_dst)) {
     // at most 8 source channels (a stem): four offsets per MFMA step straight off the neighbour table and the layer's own
     // kernel tensor — no tile plan, no packed image (csrc/conv_stem.hip)
     check(kernel.scalar_type() == at::kFloat || kernel.scalar_type() == at::kBFloat16, "kernel must be float32 or bfloat16");

@@ -249,3 +249,19 @@ def test_recipe_for_a_new_scene_is_the_longest_one_around():
         CM._recent_managers.extend(old_recent)
         CM._published_recipes.clear()
         CM._published_recipes.update(old_pub)
+
+
+def test_stem_policy_keeps_32_bit_table_offsets_in_range():
+    """csrc/conv_stem.hip addresses the neighbour table with 32-bit byte offsets, look-ahead included (the walk counts up
+    to offset volume + 42 before it clamps): the policy must refuse maps where (volume + 43) * n_tgt * 4 reaches 2^32 —
+    a pure host function, no GPU needed"""
+    from minkowskiengine_amd import _lib
+    lib = _lib.load()
+    assert lib.me_conv_stem_use_bf16(200000, 125, 8, 32) == 1
+    for volume in (8, 27, 125):
+        limit = (1 << 30) // (volume + 43)
+        assert lib.me_conv_stem_use_bf16(limit - 1, volume, 8, 32) == 1, volume
+        assert lib.me_conv_stem_use_bf16(limit + 1, volume, 8, 32) == 0, volume
+        assert (volume + 42) * (limit - 1) * 4 + (limit - 1) * 4 < (1 << 32)
+    assert lib.me_conv_stem_use_bf16(200000, 125, 8, 128) == 0 and lib.me_conv_stem_use_bf16(200000, 125, 16, 32) == 0
+    assert lib.me_conv_stem_tile_rows() == 256
