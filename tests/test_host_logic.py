@@ -265,3 +265,47 @@ def test_stem_policy_keeps_32_bit_table_offsets_in_range():
         assert (volume + 42) * (limit - 1) * 4 + (limit - 1) * 4 < (1 << 32)
     assert lib.me_conv_stem_use_bf16(200000, 125, 8, 128) == 0 and lib.me_conv_stem_use_bf16(200000, 125, 16, 32) == 0
     assert lib.me_conv_stem_tile_rows() == 256
+
+
+def test_halo_plan_waits_for_the_second_launch_on_a_side(monkeypatch):
+    """backend._halo_launch_cfg: under the policy (me_conv_halo_min_uses() == 2) the first LAUNCH on a kernel-map side
+    stays on the tile-plan kernel, a recipe replay (count=False) never counts, the second launch gets the plan; forced
+    mode (min uses 1) gets it at once.  Host logic only: the library is a stand-in, the plan is already in the store."""
+    class FakeLib:
+        def __init__(self, min_uses):
+            self.min_uses, self.asked = min_uses, 0
+
+        def me_conv_halo_use_bf16(self, *a):
+            return 1
+
+        def me_conv_halo_min_uses(self):
+            return self.min_uses
+
+        def me_conv_halo_config_bf16(self, n_tgt, volume, n_pairs, c_src, c_dst, t, cap):
+            self.asked += 1
+            t._obj.value, cap._obj.value = 128, 383
+            return 1
+
+    class FakeMap:
+        volume, n_pairs, _recipe = 27, 10 ** 6, None
+
+        def __init__(self):
+            self._launch_cache, self._store = {}, {"halo_out_128_383": "PLAN"}
+
+        def _name(self, kind, target):
+            return kind + "_" + target
+
+    lib = FakeLib(2)
+    monkeypatch.setattr(MEB._lib, "load", lambda: lib)
+    km = FakeMap()
+    assert MEB._halo_launch_cfg(km, "out", 80000, 192, 128, count=False) is None      # a replay asks: no launch follows
+    assert MEB._halo_launch_cfg(km, "out", 80000, 192, 128) is None                   # first launch: tile-plan kernel
+    assert MEB._halo_launch_cfg(km, "out", 80000, 192, 128, count=False) is None
+    assert lib.asked == 0
+    assert MEB._halo_launch_cfg(km, "out", 80000, 192, 128) == "PLAN"                 # second launch: the plan
+    assert MEB._halo_launch_cfg(km, "out", 80000, 192, 128, count=False) == "PLAN"    # ... and replays see it from now on
+    assert MEB._halo_launch_cfg(km, "in", 80000, 192, 128) is None                    # the other side counts for itself
+    lib1 = FakeLib(1)
+    monkeypatch.setattr(MEB._lib, "load", lambda: lib1)
+    km1 = FakeMap()
+    assert MEB._halo_launch_cfg(km1, "out", 80000, 192, 128) == "PLAN"                # forced (ME_AMD_HALO=1): at once
