@@ -309,3 +309,29 @@ def test_halo_plan_waits_for_the_second_launch_on_a_side(monkeypatch):
     monkeypatch.setattr(MEB._lib, "load", lambda: lib1)
     km1 = FakeMap()
     assert MEB._halo_launch_cfg(km1, "out", 80000, 192, 128) == "PLAN"                # forced (ME_AMD_HALO=1): at once
+
+
+def test_targeted_invalidation_touches_only_the_named_weights():
+    """backend.invalidate_packed_weights(ptrs): the images of the weights at those storage addresses go stale, the others —
+    a frozen / teacher network — stay valid; without an argument the global epoch moves (every image stale)"""
+    class Entry:
+        def __init__(self, ptr):
+            self.ptr, self.epoch = ptr, MEB._PACK_EPOCH[0]
+
+    class Packer:
+        def __init__(self, ptrs):
+            self.entries = {(p, 0, False): Entry(p) for p in ptrs}
+
+    saved = dict(MEB._PACKERS)
+    try:
+        MEB._PACKERS.clear()
+        MEB._PACKERS[0] = Packer([100, 200, 300])
+        MEB.invalidate_packed_weights({200, 999})
+        ep = {e.ptr: e.epoch for e in MEB._PACKERS[0].entries.values()}
+        assert ep[200] == -1 and ep[100] == ep[300] == MEB._PACK_EPOCH[0]
+        before = MEB._PACK_EPOCH[0]
+        MEB.invalidate_packed_weights()
+        assert MEB._PACK_EPOCH[0] == before + 1 and all(e.epoch != MEB._PACK_EPOCH[0] for e in MEB._PACKERS[0].entries.values())
+    finally:
+        MEB._PACKERS.clear()
+        MEB._PACKERS.update(saved)
