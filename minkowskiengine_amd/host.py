@@ -21,6 +21,8 @@ _native_error = None
 def native_module():
     """-> the native operator module, or None when it is not built / cannot be loaded (reason in native_error())"""
     global _native, _native_error
+    if _native is None and _native_error is not None and "not built" in _native_error and os.path.exists(NATIVE_PATH):
+        _native_error = None          # built since the first look (__graft_entry__.build() on a clean tree): look again
     if _native is None and _native_error is None:
         if not os.path.exists(NATIVE_PATH):
             _native_error = f"{NATIVE_PATH} not built (python -c 'import __graft_entry__ as g; g.build()')"
