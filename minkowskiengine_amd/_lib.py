@@ -249,15 +249,9 @@ def load():
             fn.restype = restype
             fn.argtypes = argtypes
     _lib = lib
-    # device code of every translation unit loaded now rather than at the first launch from it (the first backward pass of a
-    # process paid 88 ms for that); ME_AMD_PRELOAD=0 keeps HIP's lazy loading
-    if os.environ.get("ME_AMD_PRELOAD", "1") != "0":
-        try:
-            import torch
-            if torch.cuda.is_available():
-                lib.me_preload()
-        except Exception:  # noqa: BLE001  (no torch / no device: nothing to preload)
-            pass
+    # (no device work here: importing the package must not create a HIP context — ranks import before
+    # torch.cuda.set_device(local_rank), and a parent that imports and then forks GPU workers must keep torch's lazy
+    # initialisation intact; the code objects are preloaded per device at first use: preload_device)
     # tuning switches of the library by environment (A/B runs of bench.py): ME_AMD_BF16_WS=0 keeps k_conv_tile_bf16
     # everywhere, ME_AMD_BF16_WS_DEPTH=2 its shallower producer pipeline
     if os.environ.get("ME_AMD_BF16_WS", "") != "":
@@ -271,6 +265,24 @@ def load():
     if os.environ.get("ME_AMD_BF16_WS_DEPTH", "") != "":
         lib.me_debug_set_bf16_ws_depth(int(os.environ["ME_AMD_BF16_WS_DEPTH"]))
     return lib
+
+
+_preloaded = set()
+
+
+def preload_device(index):
+    """Load the device code of every translation unit on device `index` now rather than at the first launch from each
+    (the first backward pass of a process paid 88 ms for that).  Called by the hosts at the first map insert on a device
+    (under that device's guard) and by distributed.init_from_env after set_device — never at import.  Code objects are
+    per device: every device a process uses is preloaded once.  ME_AMD_PRELOAD=0 keeps HIP's lazy loading."""
+    if index is None or index in _preloaded:
+        return
+    _preloaded.add(index)
+    if os.environ.get("ME_AMD_PRELOAD", "1") == "0":
+        return
+    import torch
+    with torch.cuda.device(index):
+        load().me_preload()
 
 
 def check(rc):

@@ -739,6 +739,7 @@ class CoordinateMapManagerGPU_c10:
         ts = tuple(int(s) for s in tensor_stride)
         _check(coordinates.shape[1] - 1 == len(ts), "The coordinate dimension (coordinate_size - 1):",
                coordinates.shape[1] - 1, " must match the size of tensor stride:", list(ts))
+        _lib.preload_device(coordinates.device.index)       # (once per device; never at import)
         key = (ts, str(string_id))
         if key in self._maps:
             k = self.get_random_string_id(ts, string_id)
@@ -1303,9 +1304,22 @@ def set_grad_destination(param, dest):
         _GRAD_DEST[param.data_ptr()] = [dest, False]
 
 
-def arm_grad_destinations():
-    for e in _GRAD_DEST.values():
-        e[1] = True
+def arm_grad_destinations(ptrs=None):
+    """ptrs=None: every registered destination; an iterable of parameter addresses: only those (one arena's own —
+    another arena's slices may hold live gradients: ADVICE r5)"""
+    if ptrs is None:
+        for e in _GRAD_DEST.values():
+            e[1] = True
+        return
+    for a in ptrs:
+        e = _GRAD_DEST.get(a)
+        if e is not None:
+            e[1] = True
+
+
+def drop_grad_destinations(ptrs):
+    for a in ptrs:
+        _GRAD_DEST.pop(a, None)
 
 
 def clear_grad_destinations():
@@ -1518,19 +1532,29 @@ _PACKERS = {}
 _PACK_EPOCH = [0]
 
 
-def invalidate_packed_weights(ptrs=None):
+def invalidate_packed_weights(ptrs=None, ranges=None):
     """Every cached weight image is repacked at its next use.  For weight updates the tensor version counter cannot
     see — writes through `p.data` (Apex / DeepSpeed-style optimizers, EMA, clipping); in-place operations on the
     parameter itself (`with torch.no_grad(): p.add_(...)`, `copy_`, torch.optim) are seen without it.
-    ptrs: a set of storage addresses (`p.data_ptr()`) — only the images of THOSE weights go stale (the optimizer-step
-    hook passes its own parameters: frozen / teacher networks keep their images)."""
-    if ptrs is None:
+    ptrs: a set of storage addresses (`p.data_ptr()`) / ranges: sorted [(begin, end)) byte ranges of parameter storage —
+    only the images of weights that live THERE go stale (the optimizer-step hook passes its own parameters: frozen /
+    teacher networks keep their images).  -> (images matched, images cached)."""
+    if ptrs is None and ranges is None:
         _PACK_EPOCH[0] += 1
-        return
+        return (0, 0)
+    matched = total = 0
     for pk in _PACKERS.values():
         for e in pk.entries.values():
-            if e.ptr in ptrs:
+            total += 1
+            hit = ptrs is not None and e.ptr in ptrs
+            if not hit and ranges:
+                import bisect
+                i = bisect.bisect_right(ranges, (e.ptr, float("inf"))) - 1
+                hit = i >= 0 and ranges[i][0] <= e.ptr < ranges[i][1]
+            if hit:
                 e.epoch = -1
+                matched += 1
+    return (matched, total)
 
 
 def _packed_weights(kernel, mode, transposed, c_src, c_dst, elems):

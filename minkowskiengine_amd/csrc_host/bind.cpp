@@ -157,10 +157,13 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("set_conv_bn_stats", &set_conv_bn_stats, py::arg("enabled"));
   m.def("invalidate_packed_weights", &invalidate_packed_weights);
   m.def("invalidate_packed_weights_for", &invalidate_packed_weights_for, py::arg("sorted_ptrs"));
+  m.def("invalidate_packed_weights_in", &invalidate_packed_weights_in, py::arg("begins"), py::arg("ends"));
   m.def("set_grad_destination", [](const Tensor &param, const py::object &dest) { set_grad_destination(param, opt_tensor(dest)); });
   m.def("clear_grad_destinations", &clear_grad_destinations);
   m.def("debug_fail_next_plan_batch", &debug_fail_next_plan_batch);
   m.def("arm_grad_destinations", &arm_grad_destinations);
+  m.def("arm_grad_destinations_for", &arm_grad_destinations_for);
+  m.def("drop_grad_destinations", &drop_grad_destinations);
   m.def("set_policy", &Policy::set, "integer policies of the native host by name (tests, tuning scripts)");
   m.def("timing_enable", &timing_enable);
   m.def("timing_records", &timing_records, py::arg("clear") = true);

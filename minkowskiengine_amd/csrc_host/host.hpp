@@ -304,6 +304,8 @@ void set_grad_destination(const Tensor &param, const Tensor &dest);   // dest un
 void clear_grad_destinations();
 void debug_fail_next_plan_batch();   // the next batched tile-plan build throws (tests)
 void arm_grad_destinations();          // every entry may be used once (again)
+void arm_grad_destinations_for(const std::vector<int64_t> &param_addresses);   // ... only these parameters' entries
+void drop_grad_destinations(const std::vector<int64_t> &param_addresses);
 Tensor grad_destination(const Tensor &param, at::IntArrayRef shape);
 
 // batch normalisation over feature rows (csrc/norm.hip)
@@ -327,5 +329,6 @@ Tensor packed_weights(const Tensor &kernel, int mode, bool transposed, int c_src
 // every cached image is repacked at its next use: for weight updates the version counter cannot see (`p.data` writes)
 void invalidate_packed_weights();
 void invalidate_packed_weights_for(const std::vector<int64_t> &sorted_ptrs);
+std::pair<int64_t, int64_t> invalidate_packed_weights_in(const std::vector<int64_t> &begins, const std::vector<int64_t> &ends);
 
 }  // namespace meh

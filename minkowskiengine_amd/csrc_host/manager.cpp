@@ -11,6 +11,7 @@
 
 #include <cstdlib>
 #include <random>
+#include <set>
 #include <sstream>
 
 namespace meh {
@@ -729,6 +730,21 @@ KeyT CoordinateMapManager::register_map(const ivec &ts, const std::shared_ptr<Co
   return key;
 }
 
+// Code objects of every translation unit of libme_amd, loaded on `dev` at the first map insert there (once per device of
+// the process, under the device's guard) — not at import: a rank imports the package before it selects its device, and
+// code objects are per device.  ME_AMD_PRELOAD=0 keeps HIP's lazy loading.
+void preload_device(const c10::Device &dev) {
+  static std::mutex mu;
+  static std::set<int> done;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (!done.insert((int)dev.index()).second) return;
+  }
+  if (env_str("ME_AMD_PRELOAD", "1") == "0") return;
+  c10::DeviceGuard guard(dev);
+  me_ok(me_preload());
+}
+
 std::tuple<KeyT, Tensor, Tensor> CoordinateMapManager::insert_and_map(Tensor coordinates, const ivec &tensor_stride,
                                                                        const std::string &string_id) {
   RoctxRange rx("me:insert_and_map");
@@ -738,6 +754,7 @@ std::tuple<KeyT, Tensor, Tensor> CoordinateMapManager::insert_and_map(Tensor coo
   check(coordinates.is_cuda(), "coordinates must be on the GPU (the MI355X path has no CPU map)");
   check(coordinates.size(1) - 1 == (int64_t)tensor_stride.size(),
         "The coordinate dimension (coordinate_size - 1) must match the size of tensor stride");
+  preload_device(coordinates.device());
   KeyT key(tensor_stride, string_id);
   if (maps.count(key)) key = random_string_id(tensor_stride, string_id);
   if ((uintptr_t)coordinates.data_ptr() % 16 != 0) coordinates = coordinates.clone();

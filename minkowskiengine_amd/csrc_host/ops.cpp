@@ -85,6 +85,28 @@ void invalidate_packed_weights_for(const std::vector<int64_t> &ptrs) {
       if (std::binary_search(ptrs.begin(), ptrs.end(), (int64_t)(intptr_t)kv.second->ptr)) kv.second->epoch = -1;
 }
 
+// ... of the weights that live inside one of the byte ranges [begins[i], ends[i]) (sorted, disjoint or nested starts):
+// a kernel that is an offset view of a stepping parameter is matched too.  -> (images matched, images cached): a caller
+// that matched nothing holds master copies, not the model's tensors, and bumps the global epoch
+std::pair<int64_t, int64_t> invalidate_packed_weights_in(const std::vector<int64_t> &begins,
+                                                         const std::vector<int64_t> &ends) {
+  std::lock_guard<std::mutex> lk(g_packers_mu);
+  int64_t matched = 0, total = 0;
+  for (auto &pk : g_packers)
+    for (auto &kv : pk.second.entries) {
+      ++total;
+      const int64_t a = (int64_t)(intptr_t)kv.second->ptr;
+      auto it = std::upper_bound(begins.begin(), begins.end(), a);
+      if (it == begins.begin()) continue;
+      const size_t i = (size_t)(it - begins.begin()) - 1;
+      if (i < ends.size() && a < ends[i]) {
+        kv.second->epoch = -1;
+        ++matched;
+      }
+    }
+  return {matched, total};
+}
+
 Tensor packed_weights(const Tensor &kernel, int mode, bool transposed, int c_src, int c_dst, int64_t elems) {
   const c10::Device dev = kernel.device();
   std::lock_guard<std::mutex> lk(g_packers_mu);
@@ -316,6 +338,17 @@ void set_grad_destination(const Tensor &param, const Tensor &dest) {
 void arm_grad_destinations() {
   std::lock_guard<std::mutex> lk(g_grad_dest_mu);
   for (auto &kv : g_grad_dest) kv.second.armed = true;
+}
+void arm_grad_destinations_for(const std::vector<int64_t> &ptrs) {   // one arena's own parameters
+  std::lock_guard<std::mutex> lk(g_grad_dest_mu);
+  for (int64_t a : ptrs) {
+    auto it = g_grad_dest.find(reinterpret_cast<const void *>((uintptr_t)a));
+    if (it != g_grad_dest.end()) it->second.armed = true;
+  }
+}
+void drop_grad_destinations(const std::vector<int64_t> &ptrs) {
+  std::lock_guard<std::mutex> lk(g_grad_dest_mu);
+  for (int64_t a : ptrs) g_grad_dest.erase(reinterpret_cast<const void *>((uintptr_t)a));
 }
 void clear_grad_destinations() {
   std::lock_guard<std::mutex> lk(g_grad_dest_mu);

@@ -46,6 +46,8 @@ def init_from_env(backend=None):
             backend = pick_backend(world)
         if torch.cuda.is_available():
             torch.cuda.set_device(local_rank % visible_gpus())
+            from . import _lib
+            _lib.preload_device(local_rank % visible_gpus())   # this rank's device, now that it is selected (not at import)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
 
@@ -163,6 +165,12 @@ class GradientArena:
             loss(model(x), y).backward()
             arena.all_reduce()                   # no-op without a process group
             optimizer.step()
+
+    Gradient accumulation (several backward passes between zero_grad and all_reduce): with chunks = 1 nothing is sent
+    before all_reduce(), so a window needs no marking.  With chunks > 1 every backward pass but the LAST of a window must
+    run inside `with arena.no_sync():` (DistributedDataParallel.no_sync's contract) — a piece that has been sent cannot
+    take further local gradients; a backward pass that reaches such a piece raises instead of corrupting it.
+    Parameters are keyed by their own dtype: bf16 / fp16 parameters get their own flat buffer and are reduced in it.
     """
 
     def __init__(self, module, average=True, broadcast=True, chunks=1):
@@ -182,13 +190,25 @@ class GradientArena:
         self._learn_hooks, self._arrival = [], []
         self._sent_hooks, self._pieces, self._work = [], [], []
         self._born = self._copied = self._overlapped = 0
+        self._defer = 0                                  # depth of no_sync(): overlapped pieces are not sent inside it
+        self._ptrs = []                                  # parameter addresses whose destinations this arena registered
         self._layout()
+        # the host layers keep the slices alive through their destination tables: release them with the arena
+        import weakref
+        self._finalizer = weakref.finalize(self, GradientArena._release, self._ptrs)
         if broadcast:
             broadcast_parameters(module)
 
     @staticmethod
+    def _release(ptrs):
+        from . import host
+        host.drop_grad_destinations(list(ptrs))
+        del ptrs[:]
+
+    @staticmethod
     def _key(p):
-        return (p.device, torch.float32 if p.dtype in (torch.float32, torch.bfloat16, torch.float16) else p.dtype)
+        # (a gradient has its parameter's dtype: a bf16 parameter cannot take an fp32 slice as p.grad — ADVICE r5)
+        return (p.device, p.dtype)
 
     def _layout(self):
         """(re)allocate the flat buffers with the slices in self._order and hand the slices to the host layers"""
@@ -208,6 +228,8 @@ class GradientArena:
             offs[k] += (p.numel() + 63) // 64 * 64
             if p.dtype == torch.float32 and p.is_cuda:
                 host.set_grad_destination(p, self._views[id(p)])           # the producing kernels write here
+                if p.data_ptr() not in self._ptrs:
+                    self._ptrs.append(p.data_ptr())
 
     # ---- learning the arrival order (first backward pass) -----------------------------------------------------------------
     def _start_learning(self):
@@ -275,9 +297,32 @@ class GradientArena:
                 p.grad = self._views[id(p)]
         return True
 
+    def no_sync(self):
+        """Context manager for every backward pass of an accumulation window but the last (chunks > 1): the overlapped
+        pieces are not sent inside it, gradients only accumulate in their slices."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            self._defer += 1
+            try:
+                yield self
+            finally:
+                self._defer -= 1
+        return ctx()
+
     def _launch(self, piece):
-        if not exchange_active() or piece.get("done"):
+        if not exchange_active():
             return
+        if piece.get("done"):
+            # the piece has been all-reduced and autograd has just ADDED this rank's next gradient to the sum: the slice
+            # can no longer be repaired (sum over ranks of pass 1 + local pass 2).  Loud, not wrong (ADVICE r5).
+            raise RuntimeError(
+                "GradientArena(chunks > 1): a backward pass reached gradients that were already all-reduced in this "
+                "window; run every backward pass of an accumulation window except the last inside "
+                "`with arena.no_sync():` (or use chunks=1)")
+        if self._defer > 0:
+            return                                   # (inside no_sync(): the closing backward pass or all_reduce() sends it)
         if not self._settle(piece["params"]):
             return                                   # (the order changed: this piece is reduced at the end)
         flat = self._flat[piece["key"]]
@@ -298,7 +343,7 @@ class GradientArena:
         self._born = self._copied = self._overlapped = 0
         if not self._learned and not self._learn_hooks and exchange_active():
             self._start_learning()
-        host.arm_grad_destinations()
+        host.arm_grad_destinations(self._ptrs)      # this arena's slices only: another arena's may hold live gradients
 
     def all_reduce(self):
         """Finish the exchange: gradients that were not born in the arena are copied in (one multi-tensor launch) and
@@ -366,8 +411,7 @@ class GradientArena:
         for h in self._learn_hooks + self._sent_hooks:
             h.remove()
         self._learn_hooks, self._sent_hooks = [], []
-        for p in self.params:
-            host.set_grad_destination(p, None)
+        self._finalizer()                            # (idempotent: drops this arena's destinations on both hosts)
 
 
 def _reduce_scalar(value, op, device):

@@ -102,17 +102,32 @@ def key_like(key, *args):
 
 def invalidate_packed_weights(params=None):
     """Repack cached weight images (both hosts) at their next use: for weight updates the tensor version counter cannot
-    see, i.e. writes through `p.data`.  params=None: every image; an iterable of tensors: only the images of those
-    weights (what the package's optimizer-step hook passes: the stepping optimizer's own parameters)."""
+    see, i.e. writes through `p.data`.  params=None: every image; an iterable of tensors: only the images of weights that
+    live inside the storage of those tensors (what the package's optimizer-step hook passes: the stepping optimizer's
+    own parameters; a kernel that is an offset view of a parameter is matched by its address range).
+    If NONE of the cached images belongs to `params` the optimizer does not hold the model's tensors at all — fp32 master
+    copies written back through `.data.copy_` (Apex / DeepSpeed style), exactly the updates the hook exists for: then
+    every image goes stale (the global epoch), as before round 5."""
     if params is None:
         _python_backend.invalidate_packed_weights()
         if _native is not None:
             _native.invalidate_packed_weights()
         return
-    ptrs = {int(p.data_ptr()) for p in params}
-    _python_backend.invalidate_packed_weights(ptrs)
+    ranges = sorted({(int(p.data_ptr()), int(p.data_ptr()) + int(p.numel()) * int(p.element_size())) for p in params
+                     if p.numel() > 0})
+    merged = []                      # (overlapping parameter storages — a flat buffer and its views — become one range)
+    for a, b in ranges:
+        if merged and a <= merged[-1][1]:
+            merged[-1] = (merged[-1][0], max(merged[-1][1], b))
+        else:
+            merged.append((a, b))
+    ranges = merged
+    m0, t0 = _python_backend.invalidate_packed_weights(None, ranges)
+    m1, t1 = (0, 0)
     if _native is not None:
-        _native.invalidate_packed_weights_for(sorted(ptrs))
+        m1, t1 = _native.invalidate_packed_weights_in([a for a, _ in ranges], [b for _, b in ranges])
+    if (t0 + t1) > 0 and (m0 + m1) == 0:
+        invalidate_packed_weights(None)
 
 
 def set_grad_destination(param, dest):
@@ -123,10 +138,23 @@ def set_grad_destination(param, dest):
         _native.set_grad_destination(param, dest)
 
 
-def arm_grad_destinations():
-    _python_backend.arm_grad_destinations()
+def arm_grad_destinations(ptrs=None):
+    """ptrs=None: every registered destination; a list of parameter addresses: only those (GradientArena arms its own)"""
+    if ptrs is None:
+        _python_backend.arm_grad_destinations()
+        if _native is not None:
+            _native.arm_grad_destinations()
+        return
+    _python_backend.arm_grad_destinations(ptrs)
     if _native is not None:
-        _native.arm_grad_destinations()
+        _native.arm_grad_destinations_for(list(ptrs))
+
+
+def drop_grad_destinations(ptrs):
+    """forget the destinations of these parameter addresses on both hosts (an arena that goes away)"""
+    _python_backend.drop_grad_destinations(ptrs)
+    if _native is not None:
+        _native.drop_grad_destinations(list(ptrs))
 
 
 def clear_grad_destinations():

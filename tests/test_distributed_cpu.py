@@ -228,3 +228,95 @@ def test_gradient_arena_overlapped_pieces_on_two_gloo_ranks():
                 assert desc["overlapped_pieces"] == 0
             if step == 3:
                 assert desc["overlapped_pieces"] < 3, desc
+
+
+def _arena_accum_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from minkowskiengine_amd import distributed as D
+    D.init_from_env(backend="gloo")
+    torch.manual_seed(11)
+    net = torch.nn.Sequential(*[torch.nn.Linear(8, 8) for _ in range(12)])
+    arena = D.GradientArena(net, chunks=4)
+    xs = [torch.full((3, 8), 0.1 * (rank + 1)), torch.full((3, 8), -0.05 * (rank + 2))]
+    res = []
+    for step in range(4):
+        arena.zero_grad()
+        with arena.no_sync():                          # every backward pass of the window but the last
+            net(xs[0]).sum().backward()
+        net(xs[1]).sum().backward()
+        arena.all_reduce()
+        res.append(([p.grad.clone() for p in net.parameters()], arena.describe()))
+    # the same window WITHOUT no_sync: the second pass reaches pieces that are already reduced -> loud, not wrong
+    arena.zero_grad()
+    net(xs[0]).sum().backward()
+    raised = False
+    try:
+        net(xs[1]).sum().backward()
+    except RuntimeError as e:
+        raised = "no_sync" in str(e)
+    out[rank] = (res, raised)
+    D.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_gradient_arena_accumulation_window_with_overlapped_pieces():
+    """chunks > 1 with TWO backward passes per step.  Inside `arena.no_sync()` nothing is sent, the closing
+    pass sends the pieces: every step's gradients equal the two-rank average of the summed passes on both ranks; the
+    same window without no_sync raises instead of mixing a reduced sum with a local gradient."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_arena_accum_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    torch.manual_seed(11)
+    net = torch.nn.Sequential(*[torch.nn.Linear(8, 8) for _ in range(12)])
+    gs = []
+    for r in range(world):
+        net.zero_grad(set_to_none=True)
+        net(torch.full((3, 8), 0.1 * (r + 1))).sum().backward()
+        net(torch.full((3, 8), -0.05 * (r + 2))).sum().backward()
+        gs.append([p.grad.clone() for p in net.parameters()])
+    want = [(a + b) / 2 for a, b in zip(*gs)]
+    for rank in range(world):
+        res, raised = out[rank]
+        assert raised, "a second backward pass on reduced pieces must raise"
+        for step, (grads, desc) in enumerate(res):
+            for g, w_ in zip(grads, want):
+                assert torch.allclose(g, w_, rtol=1e-5, atol=1e-7), (rank, step)
+            if step >= 1:
+                assert desc["overlapped_pieces"] == 3, (step, desc)
+    for a, b in zip(out[0][0][-1][0], out[1][0][-1][0]):
+        assert torch.equal(a, b), "ranks disagree"
+
+
+def test_gradient_arena_low_precision_parameters_and_two_arenas():
+    """bf16 parameters get a bf16 flat buffer (p.grad must have the parameter's dtype); two arenas in
+    one process arm only their own destinations (zero_grad of one leaves the other's live gradients alone) and release
+    their host-layer entries when closed."""
+    from minkowskiengine_amd import distributed as D
+    from minkowskiengine_amd import backend as MEB
+    net = torch.nn.Sequential(torch.nn.Linear(4, 4), torch.nn.Linear(4, 2)).bfloat16()
+    arena = D.GradientArena(net, broadcast=False)
+    arena.zero_grad()
+    net(torch.ones(3, 4, dtype=torch.bfloat16)).sum().backward()
+    arena.all_reduce()                                                    # (no process group: copy-in + re-point only)
+    assert all(p.grad is not None and p.grad.dtype == torch.bfloat16 for p in net.parameters())
+    assert set(arena.describe()["buffers"]) == {"torch.bfloat16@cpu"}
+    # per-arena arming, on the Python host's table (CPU tensors are never registered: use fake entries)
+    saved = dict(MEB._GRAD_DEST)
+    try:
+        MEB._GRAD_DEST.clear()
+        MEB._GRAD_DEST[1000] = ["a", False]
+        MEB._GRAD_DEST[2000] = ["b", False]
+        MEB.arm_grad_destinations([1000])
+        assert MEB._GRAD_DEST[1000][1] is True and MEB._GRAD_DEST[2000][1] is False
+        MEB.drop_grad_destinations([1000])
+        assert 1000 not in MEB._GRAD_DEST and 2000 in MEB._GRAD_DEST
+        MEB.arm_grad_destinations()
+        assert MEB._GRAD_DEST[2000][1] is True
+    finally:
+        MEB._GRAD_DEST.clear()
+        MEB._GRAD_DEST.update(saved)
+    arena.close()
+    arena.close()                                                         # idempotent

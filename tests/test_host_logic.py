@@ -335,3 +335,48 @@ def test_targeted_invalidation_touches_only_the_named_weights():
     finally:
         MEB._PACKERS.clear()
         MEB._PACKERS.update(saved)
+
+
+def test_invalidation_by_storage_range_and_master_copy_fallback():
+    """host.invalidate_packed_weights(params) (the optimizer-step hook's call): an image whose weight is an OFFSET
+    VIEW of a stepping parameter is matched by its address range; an optimizer that holds none of the cached weights — fp32
+    master copies written back through `.data.copy_` — makes EVERY image stale (global epoch), as before targeted
+    invalidation existed."""
+    import torch
+    from minkowskiengine_amd import host
+
+    class Entry:
+        def __init__(self, ptr):
+            self.ptr, self.epoch = ptr, MEB._PACK_EPOCH[0]
+
+    class Packer:
+        def __init__(self, ptrs):
+            self.entries = {(p, 0, False): Entry(p) for p in ptrs}
+
+    saved = dict(MEB._PACKERS)
+    try:
+        flat = torch.zeros(64)
+        view = flat[16:32]                                   # the model's kernel: a view into a flat parameter
+        other = torch.zeros(8)
+        MEB._PACKERS.clear()
+        MEB._PACKERS[0] = Packer([view.data_ptr(), other.data_ptr()])
+        before = MEB._PACK_EPOCH[0]
+        host.invalidate_packed_weights([flat])               # the optimizer steps `flat`
+        ep = {e.ptr: e.epoch for e in MEB._PACKERS[0].entries.values()}
+        assert ep[view.data_ptr()] == -1 and ep[other.data_ptr()] == before and MEB._PACK_EPOCH[0] == before
+        # master copies: nothing cached lives in the optimizer's tensors -> everything stale
+        for e in MEB._PACKERS[0].entries.values():
+            e.epoch = MEB._PACK_EPOCH[0]
+        master = torch.zeros(64)
+        host.invalidate_packed_weights([master])
+        assert MEB._PACK_EPOCH[0] == before + 1
+        # an empty cache: nothing to do, no epoch churn
+        MEB._PACKERS.clear()
+        e0 = MEB._PACK_EPOCH[0]
+        host.invalidate_packed_weights([master])
+        n = host.native_module()
+        if n is None:
+            assert MEB._PACK_EPOCH[0] == e0
+    finally:
+        MEB._PACKERS.clear()
+        MEB._PACKERS.update(saved)
