@@ -123,6 +123,19 @@ def pmc_pass(workload, dtype, counters, steps, timeout_s):
                     c = k.setdefault(row["Counter_Name"], [0.0, 0])
                     c[0] += float(row["Counter_Value"])
                     c[1] += 1
+        # durations of the same (serialised, profiled) launches: the counter passes' own clock — never compared with the
+        # timed region (MI355X_MICROARCH.md: profiled passes run at another clock)
+        for f in glob.glob(os.path.join(out, "**", "*kernel_trace.csv"), recursive=True):
+            with open(f) as fh:
+                for row in csv.DictReader(fh):
+                    try:
+                        d = float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+                    except (KeyError, ValueError):
+                        continue
+                    k = agg.setdefault(row.get("Kernel_Name", ""), {})
+                    c = k.setdefault("_duration_ns", [0.0, 0])
+                    c[0] += d
+                    c[1] += 1
         return agg or None
     except Exception:  # noqa: BLE001  (a missing profiler / a timeout must not cost the benchmark line)
         return None
@@ -176,6 +189,91 @@ def measure_traffic(workload, dtype, kernel_match, steps, deadline, extra_steps=
                       f"running {steps} steps of the workload (FETCH_SIZE doubled: gfx950 tallies 128-byte requests at 64 B)"}
 
 
+SQ_COUNTERS = ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY",
+               "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU_MFMA_MOPS_BF16"]
+N_SIMDS, N_XCDS = 1024, 8
+
+
+def measure_sq(workload, dtype, steps, deadline):
+    """Counter-based matrix-pipe utilisation of every convolution kernel of the workload (north_star
+    "rocprof MFMA utilisation reported"): ONE rocprofv3 pass (7 SQ counters + GRBM_GUI_ACTIVE: within the 8 SQ slots of
+    MI355X_MICROARCH.md) over a child process.  Per kernel, averages per launch:
+      mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) — rocprofiler's own MfmaUtil
+                       (counter_defs.yaml: reduce(SQ_VALU_MFMA_BUSY_CYCLES,sum) / (reduce(GRBM_GUI_ACTIVE,max) * SIMD_NUM));
+      wave_wait_frac / issue_stall_frac / active_frac = SQ_WAIT_ANY / SQ_WAIT_INST_ANY / SQ_ACTIVE_INST_ANY over
+                       SQ_WAVE_CYCLES (disjoint shares of a wave's life: parked in s_waitcnt / barrier, stalled at
+                       issue, issuing).
+    -> {short kernel name: {...}} or None."""
+    left = deadline - time.perf_counter()
+    if left < 25:
+        return None
+    agg = pmc_pass(workload, dtype, SQ_COUNTERS, steps, min(left, 150))
+    if not agg:      # (a counter this profiler build does not know: the three that define MfmaUtil alone)
+        left = deadline - time.perf_counter()
+        if left < 25:
+            return None
+        agg = pmc_pass(workload, dtype, SQ_COUNTERS[:3], steps, min(left, 150))
+    if not agg:
+        return None
+    out = {}
+    for name, cs in agg.items():
+        if not any(m in name for m in PMC_CONV_KERNELS) or "SQ_VALU_MFMA_BUSY_CYCLES" not in cs:
+            continue
+        n = max(cs["SQ_VALU_MFMA_BUSY_CYCLES"][1], 1)
+        per = {c: v[0] / max(v[1], 1) for c, v in cs.items()}
+        cycles = per.get("GRBM_GUI_ACTIVE", 0.0) / N_XCDS
+        short = name.split("(")[0].replace("void ", "").replace("me::", "")
+        e = {"launches": n, "mfma_busy_frac": round(per["SQ_VALU_MFMA_BUSY_CYCLES"] / (cycles * N_SIMDS), 4) if cycles else None,
+             "gpu_cycles": int(cycles)}
+        wc = per.get("SQ_WAVE_CYCLES", 0.0)
+        if wc:
+            e["wave_wait_frac"] = round(per.get("SQ_WAIT_ANY", 0.0) / wc, 4)
+            e["issue_stall_frac"] = round(per.get("SQ_WAIT_INST_ANY", 0.0) / wc, 4)
+            e["active_frac"] = round(per.get("SQ_ACTIVE_INST_ANY", 0.0) / wc, 4)
+        if "SQ_BUSY_CYCLES" in per and cycles:
+            e["sq_busy_frac"] = round(per["SQ_BUSY_CYCLES"] / 32.0 / cycles, 4)      # (32 shader engines)
+        if "SQ_INSTS_VALU_MFMA_MOPS_BF16" in per:
+            e["mfma_mops_bf16"] = int(per["SQ_INSTS_VALU_MFMA_MOPS_BF16"])
+        if "_duration_ns" in per:
+            e["profiled_us"] = round(per["_duration_ns"] / 1e3, 2)
+            if cycles:
+                e["profiled_clock_ghz"] = round(cycles / per["_duration_ns"], 3)
+        out[short] = e
+    return out or None
+
+
+def attach_sq(line, args, deadline):
+    """roofline.mfma_busy_frac (+ by_pass / by_kernel tables) from measure_sq, for the headline and — budget permitting —
+    the MinkUNet34C entry (weighted by launches x cycles over its convolution kernels)"""
+    if args.pmc == "off":
+        return
+    r = line.get("roofline") or {}
+    tag = r.get("pmc_match")
+    if tag:
+        sq = measure_sq(args.workload, args.dtype, 3, deadline)
+        if sq:
+            rows = {}
+            for short, e in sq.items():
+                which = "forward" if all(m in short + "(" for m in tag) else \
+                    ("wgrad_reduce" if "reduce" in short else ("wgrad" if "wgrad" in short else "dgrad"))
+                rows[which if args.workload != "minkunet" else short] = dict(e, kernel=short)
+            r["mfma_busy_frac"] = (rows.get("forward") or {}).get("mfma_busy_frac")
+            r["mfma_busy_by_pass"] = rows
+            r["mfma_busy_note"] = ("rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE ... in this run, one pass over a "
+                                   "child process: busy cycles of the matrix pipes / (kernel cycles x 1024 SIMDs) = rocprofiler's "
+                                   "MfmaUtil; `frac` beside it is flops / time / peak")
+    ent = (line.get("workloads") or {}).get("minkunet34c_bf16_200k")
+    if isinstance(ent, dict) and "roofline" in ent:
+        sq = measure_sq("minkunet", "bf16", 2, deadline)
+        if sq:
+            tot_busy = sum(e["mfma_busy_frac"] * e["gpu_cycles"] * e["launches"] for e in sq.values() if e.get("mfma_busy_frac"))
+            tot_cyc = sum(e["gpu_cycles"] * e["launches"] for e in sq.values() if e.get("mfma_busy_frac") is not None)
+            ent["roofline"]["mfma_busy_frac"] = round(tot_busy / tot_cyc, 4) if tot_cyc else None
+            top = sorted(sq.items(), key=lambda kv: -kv[1]["gpu_cycles"] * kv[1]["launches"])[:12]
+            ent["roofline"]["mfma_busy_by_kernel"] = {k: v for k, v in top}
+            ent["roofline"]["mfma_busy_note"] = "all convolution kernels of the step, cycle-weighted; the 12 heaviest listed"
+
+
 def attach_traffic(line, args, deadline):
     """fill line['roofline']['traffic'] (and the compact workload entries) from in-run PMC passes, most important first,
     while the budget lasts; entries that are not reached keep their cited constant / null"""
@@ -214,6 +312,21 @@ def attach_traffic(line, args, deadline):
             rr["traffic_detail"] = t
             rr["traffic_note"] = ("HBM-side bytes per STEP of all convolution launches — " if wl == "minkunet" else
                                   "HBM-side bytes per launch of this kernel — ") + t["source"]
+
+
+
+def arena_per_rank(ex, dist_utils, dev):
+    """what every rank's GradientArena did in its last step — bytes of its flat buffers, gradients born in place, copied
+    in, pieces, pieces all-reduced from inside the backward pass — as lists over the ranks (the first
+    SCALE run explains itself: a rank that copies gradients in, or whose pieces fall back to the closing all-reduce, shows
+    up here)."""
+    if ex.arena is None:
+        return None
+    d = ex.arena.describe()
+    own = {"bytes": float(sum(d["buffers"].values())), "born_in_place": float(d["born_in_place"]),
+           "copied_in": float(d["copied_in"]), "pieces": float(d["pieces"]),
+           "overlapped_pieces": float(d["overlapped_pieces"])}
+    return {k: [int(v) for v in dist_utils.gather_over_ranks(own[k], dev)] for k in own}
 
 
 
@@ -711,6 +824,8 @@ def bench_conv(args, ME, MEB, dist_utils, rank, world, dev, startup):
         ms_nosync = t_nosync / args.steps * 1e3
         ms_window = t_window / (max(1, args.steps // A) * A) * 1e3
         multi = dict(dist_utils.collective_info(), exchange=ex.mode,
+                     arena=(ex.arena.describe() if ex.arena is not None else None),
+                     arena_per_rank=arena_per_rank(ex, dist_utils, dev),
                      per_rank_ms_per_step=per_rank,
                      no_sync_ms_per_step=round(ms_nosync, 4),
                      allreduce_ms={"standalone": round(ar_ms, 4), "buckets": n_buckets,
@@ -907,6 +1022,7 @@ def bench_minkunet(args, ME, MEB, dist_utils, rank, world, dev, startup):
         ms_sync, ms_nosync = best / args.steps * 1e3, t_nosync / args.steps * 1e3
         multi = dict(dist_utils.collective_info(), exchange=ex.mode,
                      arena=(ex.arena.describe() if ex.arena is not None else None),
+                     arena_per_rank=arena_per_rank(ex, dist_utils, dev),
                      per_rank_ms_per_step=per_rank,
                      per_rank_points=[int(v) for v in dist_utils.gather_over_ranks(n, dev)],
                      no_sync_ms_per_step=round(ms_nosync, 3),
@@ -1132,7 +1248,7 @@ def main():
     ap.add_argument("--pmc", choices=("auto", "on", "off"), default="auto",
                     help="measure roofline.traffic in this run with rocprofv3 --pmc passes over child processes (auto: "
                          "single-GPU runs when rocprofv3 is installed; bounded by --pmc-budget)")
-    ap.add_argument("--pmc-budget", type=float, default=100.0, help="seconds the in-run PMC passes may take in total")
+    ap.add_argument("--pmc-budget", type=float, default=140.0, help="seconds the in-run PMC passes may take in total")
     ap.add_argument("--pmc-child", type=int, default=0, help=argparse.SUPPRESS)   # internal: run N untimed steps and exit
     ap.add_argument("--accum", type=int, default=4,
                     help="N > 1, conv workloads: length of the gradient-accumulation window reported under "
@@ -1212,7 +1328,9 @@ def main():
         if line is not None:
             line["workloads"] = extra
     if rank == 0 and world == 1 and args.pmc != "off":
-        attach_traffic(line, args, time.perf_counter() + args.pmc_budget)
+        t_pmc = time.perf_counter()
+        attach_sq(line, args, t_pmc + 0.45 * args.pmc_budget)      # MFMA utilisation first (two passes at most)
+        attach_traffic(line, args, t_pmc + args.pmc_budget)
     if rank == 0:
         for r in [line.get("roofline")] + [w.get("roofline") for w in (line.get("workloads") or {}).values()
                                            if isinstance(w, dict)]:

@@ -61,11 +61,15 @@ typedef struct me_region {
  *              all tile plans of a scene in four launches (me_plan_job, me_plan_jobs_init, me_plan_build_multi)
  *   1.5 (150)  round 5: bf16 convolution on an LDS-staged source halo with register accumulators
  *              (me_conv_halo_config_bf16, me_halo_plan_build, me_conv_halo_bf16); stacked-offset kernel for layers
- *              with at most 8 source channels (me_conv_stem_use_bf16, me_conv_stem_tile_rows, me_conv_stem_bf16) */
+ *              with at most 8 source channels (me_conv_stem_use_bf16, me_conv_stem_tile_rows, me_conv_stem_bf16)
+ *   1.6 (160)  round 6: row-wise launches for kernel-map sides with exactly one pair per target row — K = 1 layers
+ *              (the reference's `input.F.mm(kernel)`) and the fine side of kernel_size == stride maps
+ *              (me_conv_rowwise_supported_bf16, me_conv_rowwise_bf16) */
 int me_version(void);
 const char *me_last_error(void);
 /* Load the device code of every translation unit of the library now (needs a GPU; ABI 1.5): HIP loads a unit's code object
- * at the first launch from it, which put 88 ms into the first backward pass of a process.  The hosts call it at import. */
+ * at the first launch from it, which put 88 ms into the first backward pass of a process.  The hosts call it at the first
+ * map insert on a device, under that device's guard (code objects are per device) — not at import. */
 int me_preload(void);
 /* kernel volume of a region: src/kernel_region.hpp:250-270 (set_volume) */
 int64_t me_region_volume(const me_region *region);
@@ -402,6 +406,30 @@ int me_conv_target_bf16_ex(const uint16_t *src_feat_dev, int64_t n_src, int32_t 
                            const int32_t *order_dev, uint16_t *dst_feat_dev,
                            int64_t n_tgt, int32_t tile_rows, int32_t batch_groups, int32_t fused, int32_t split_k,
                            void *workspace_dev, float *part_mean_dev, float *part_m2_dev, void *stream);
+/* Row-wise launches (round 6, csrc/conv_rowwise.hip).  For a kernel-map side on which EVERY target row has EXACTLY ONE
+ * pair, dst[tgt_rows[e]] = src[src_rows[e]] @ W[k(e)] for every pair e — no sum, hence no tile plan, no LDS accumulator:
+ * the x rows stream from global memory into the MFMA operand registers, W[k] comes from the packed image of
+ * me_conv_pack_weights_bf16 / me_conv_pack_weights_multi (the SAME image the tile-plan launch of the layer uses; the
+ * transposed image for an input gradient).  Replaces, for those sides, what me_conv_target_bf16 does:
+ *   - kernel volume 1, stride 1: the reference's dense `input.F.mm(kernel)` (MinkowskiEngine/MinkowskiConvolution.py:304-308)
+ *     and its input gradient;
+ *   - kernel_size == stride maps (src/coordinate_map_manager.cpp:402-429 out maps): forward of
+ *     ConvolutionTransposeForwardGPU (pybind/extern.hpp:99-143) and the input gradient of ConvolutionBackwardGPU
+ *     (src/convolution_gpu.cu:161-244) — the fine side of the map.
+ * src_rows_dev / tgt_rows_dev: the kernel map's pair lists (kernel_map.hpp:40-53 layout: pairs of an offset contiguous)
+ * with the side's SOURCE rows in src_rows; k_offsets_dev int64 [volume + 1] on the device; n_pairs_bound >= the pair
+ * count (the launch is sized by it; for such a side the pair count IS n_tgt).  The caller guarantees the one-pair-per-
+ * row property (a row without a pair is not written, a row with two pairs is written twice).  Semantics of the tile-plan
+ * launch: fp32 sums over the channels, one rounding to bf16.
+ * me_conv_rowwise_supported_bf16: 1 when (volume <= 64, c_src % 8 == 0, c_dst % 4 == 0, W[k] of one 128-column slab
+ * within 64 KB of LDS) the kernel takes the shape.
+ * No batch-norm statistics epilogue: a layer whose statistics are wanted either stays on me_conv_target_bf16_stats or
+ * is followed by the ordinary pass over its output (me_bn_stats). */
+int32_t me_conv_rowwise_supported_bf16(int64_t volume, int32_t c_src, int32_t c_dst);
+int me_conv_rowwise_bf16(const uint16_t *src_feat_dev, int64_t n_src, int32_t c_src, const uint16_t *packed_w_dev,
+                         int64_t volume, int32_t c_dst, const int32_t *src_rows_dev, const int32_t *tgt_rows_dev,
+                         const int64_t *k_offsets_dev, int64_t n_pairs_bound, uint16_t *dst_feat_dev, int64_t n_tgt,
+                         void *stream);
 int64_t me_conv_wgrad_workspace_bytes_bf16(const int64_t *k_offsets, int64_t volume, int32_t c_in, int32_t c_out);
 int me_conv_wgrad_bf16(const uint16_t *x_dev, int64_t n_in, int32_t c_in, const uint16_t *dy_dev, int64_t n_out,
                        int32_t c_out,

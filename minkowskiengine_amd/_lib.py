@@ -141,6 +141,9 @@ SIGNATURES = {
     "me_conv_stem_tile_rows": (c_i32, []),
     "me_conv_stem_bf16": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_i64,
                                          c_vp, c_vp, c_vp]),
+    "me_conv_rowwise_supported_bf16": (c_i32, [c_i64, c_i32, c_i32]),
+    "me_conv_rowwise_bf16": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64,
+                                            c_vp]),
     "me_conv_halo_min_uses": (c_i32, []),
     "me_conv_halo_use_bf16": (c_i32, [c_i64, c_i64, c_i64, c_i32, c_i32]),
     "me_conv_halo_config_bf16": (c_i32, [c_i64, c_i64, c_i64, c_i32, c_i32, _P_I32, _P_I32]),
@@ -222,6 +225,8 @@ DEBUG_SIGNATURES = {
     "me_debug_set_bf16_ws_fuse": (None, [ctypes.c_int]),
     "me_debug_set_bf16_ws_depth": (None, [ctypes.c_int]),
     "me_debug_set_bf16_ws_ncw": (None, [ctypes.c_int]),
+    "me_debug_set_rowwise_groups": (None, [ctypes.c_int]),
+    "me_debug_set_insert_fused": (None, [ctypes.c_int]),
     "me_debug_ws_timing": (ctypes.c_int, [c_vp, c_i32]),
     "me_debug_set_bf16_offsync": (None, [ctypes.c_int]),
     "me_debug_set_bf16_splitk": (None, [ctypes.c_int]),
@@ -262,6 +267,8 @@ def load():
         lib.me_debug_set_wgrad_ws(int(os.environ["ME_AMD_WGRAD_WS"]))
     if os.environ.get("ME_AMD_BF16_WS_NCW", "") != "":
         lib.me_debug_set_bf16_ws_ncw(int(os.environ["ME_AMD_BF16_WS_NCW"]))
+    if os.environ.get("ME_AMD_RW_G", "") != "":
+        lib.me_debug_set_rowwise_groups(int(os.environ["ME_AMD_RW_G"]))
     if os.environ.get("ME_AMD_BF16_WS_DEPTH", "") != "":
         lib.me_debug_set_bf16_ws_depth(int(os.environ["ME_AMD_BF16_WS_DEPTH"]))
     return lib

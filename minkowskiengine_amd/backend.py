@@ -423,6 +423,9 @@ class KernelMapGPU:
         self._flip = flip
         self._launch_cache = {}               # per view: launch geometry and device addresses of the plans
         self._recipe, self._recipe_key = None, None   # the owning manager's request log (CoordinateMapManager.prefetch)
+        # sides on which a row has AT MOST one pair by construction (bit 0: "in" rows, bit 1: "out" rows; csrc_host twin:
+        # KernelMap::one_pair_sides) — with n_pairs == rows of the side: exactly one -> row-wise launch (conv_rowwise.hip)
+        self.one_pair_sides = 0
 
     @property
     def k_offsets(self):
@@ -452,9 +455,11 @@ class KernelMapGPU:
         return kind + "_" + target
 
     def swapped(self):
-        return KernelMapGPU(self.volume, self.n_out, self.n_in, self._k_offsets, self.k_offsets_dev,
-                            self.out_pairs_buf, self.in_pairs_buf, store=self._store, flip=not self._flip,
-                            in_map=self.out_map, out_map=self.in_map)
+        km = KernelMapGPU(self.volume, self.n_out, self.n_in, self._k_offsets, self.k_offsets_dev,
+                          self.out_pairs_buf, self.in_pairs_buf, store=self._store, flip=not self._flip,
+                          in_map=self.out_map, out_map=self.in_map)
+        km.one_pair_sides = ((self.one_pair_sides & 1) << 1) | ((self.one_pair_sides >> 1) & 1)
+        return km
 
     def table_pos(self, target):
         """(table, order): table [volume, n_tgt] of source ROWS indexed by target POSITION, order int32 [n_tgt]
@@ -997,12 +1002,14 @@ class CoordinateMapManagerGPU_c10:
             km = KernelMapGPU(1, n, n, [0, n], torch.tensor([0, n], dtype=torch.int64, device=rows.device), rows, rows,
                               store={"nbr_out": rows.view(1, n) if n else rows.new_empty((1, 1))},
                               in_map=in_map, out_map=out_map)
+            km.one_pair_sides = 3
             self._kernel_maps[key] = km
             return km
         if not is_transpose:
             # (pooling with stride == kernel uses the same generic path: the result is identical)
             region = _lib.make_region(len(ks) + 1, int(region_type), ks, dl, in_map.tensor_stride)
             km = _build_kernel_map(in_map, out_map, region)
+            km.one_pair_sides = _one_pair_sides(ks, dl, int(region_type), in_map.tensor_stride, out_map.tensor_stride)
         else:
             swapped_key = (ok, ik, ks, st, dl, int(region_type), False, bool(is_pool))
             fwd = self._kernel_maps.get(swapped_key)
@@ -1010,6 +1017,7 @@ class CoordinateMapManagerGPU_c10:
                 # out -> in map with the (finer) out tensor stride, then swap
                 region = _lib.make_region(len(ks) + 1, int(region_type), ks, dl, out_map.tensor_stride)
                 fwd = _build_kernel_map(out_map, in_map, region)
+                fwd.one_pair_sides = _one_pair_sides(ks, dl, int(region_type), out_map.tensor_stride, in_map.tensor_stride)
             km = fwd.swapped()
         self._kernel_maps[key] = km
         km._recipe, km._recipe_key = self._recipe, key
@@ -1084,6 +1092,8 @@ class CoordinateMapManagerGPU_c10:
                         n_tgt = km.n_out if target == "out" else km.n_in
                         if bf16 and c_src == 8 and _lib.load().me_conv_stem_use_bf16(n_tgt, km.volume, c_src, c_dst):
                             km.table_pos(target)       # (the stacked-offset kernel reads the neighbour table: no plan)
+                        elif bf16 and _rowwise_cfg(km, target, n_tgt, c_src, c_dst) is not None:
+                            pass                       # (one pair per row: the launch reads the pair lists, no plan)
                         elif not (bf16 and _halo_launch_cfg(km, target, n_tgt, c_src, c_dst, count=False) is not None):
                             _conv_launch_cfg(km, target, n_tgt, c_src, c_dst, bf16)
                         done += 1
@@ -1258,6 +1268,42 @@ def plan_config(n_tgt, volume, n_pairs, c_src, c_dst, bf16=False, split=False, w
         _lib.check(fn(n_tgt, volume, n_pairs, c_src, c_dst, ctypes.byref(t), ctypes.byref(g)))
     out = (_TILE_ROWS or int(t.value), _BATCH_GROUPS or int(g.value))
     return out + (int(sk.value),) if with_split_k else out
+
+
+def _one_pair_sides(ks, dl, region_type, fine_ts, coarse_ts):
+    """Sides of a hyper-cube map (looked-up map at `fine_ts`, iterated map at `coarse_ts`) on which a row has at most ONE
+    pair by construction (csrc_host/manager.cpp one_pair_sides_of): a single-offset kernel -> both (3); windows that tile
+    space without overlap (coarse stride = kernel_size x fine stride, no dilation) -> the fine ("in") side (1)."""
+    if all(k == 1 for k in ks):
+        return 3
+    tiling = region_type == 0 and len(fine_ts) == len(ks) == len(coarse_ts) and \
+        all(d == 1 and c == f * k for k, d, f, c in zip(ks, dl, fine_ts, coarse_ts))
+    return 1 if tiling else 0
+
+
+_ROWWISE = os.environ.get("ME_AMD_ROWWISE", "1") != "0"   # 0: one-pair-per-row sides stay on the tile-plan kernels
+# a K = 1 FORWARD launch whose batch-norm statistics are wanted takes the row-wise kernel (no statistics epilogue: the batch
+# norm reads the output once more) only on maps of at least this many rows (csrc_host/host.hpp Policy, measured per layer)
+_ROWWISE_MIN_ROWS_WITH_STATS = int(os.environ.get("ME_AMD_ROWWISE_STATS_ROWS", "100000"))
+
+
+def _rowwise_cfg(km, target, n_tgt, c_src, c_dst):
+    """(src_rows, tgt_rows, elems) when the launch side has exactly one pair per target row and libme_amd takes the
+    shape (csrc/conv_rowwise.hip: K = 1 layers, the fine side of kernel_size == stride maps), else None"""
+    if not _ROWWISE or not (km.one_pair_sides & (1 if target == "in" else 2)):
+        return None
+    ck = ("rowwise", target, c_src, c_dst)
+    cfg = km._launch_cache.get(ck)
+    if cfg is None:
+        lib = _lib.load()
+        ok = bool(lib.me_conv_rowwise_supported_bf16(km.volume, c_src, c_dst)) and km.n_pairs == n_tgt
+        src_rows = km.in_pairs_buf if target == "out" else km.out_pairs_buf
+        tgt_rows = km.out_pairs_buf if target == "out" else km.in_pairs_buf
+        cfg = km._launch_cache[ck] = (src_rows, tgt_rows, int(lib.me_conv_packed_weight_elems_bf16(km.volume, c_src, c_dst))) \
+            if ok else False
+        if ok and km._recipe is not None:
+            km._recipe.append(("conv_cfg", km._recipe_key, target, c_src, c_dst, True))
+    return cfg or None
 
 
 def _conv_launch_cfg(km, target, n_tgt, c_src, c_dst, bf16):
@@ -1632,6 +1678,29 @@ def _conv_target(src_feat, kernel, km, target, n_tgt, name="conv_target", transp
                 flops=2.0 * km.n_pairs * c_src * c_dst)
         if want_stats:
             _bn_partials_put(out, part, tile_rows)
+        return out
+    rw = _rowwise_cfg(km, target, n_tgt, c_src, c_dst) if bf16 else None
+    if rw is not None and name == "conv_forward" and _CONV_BN_STATS and _BN_STATS_HINT[0] and \
+            n_tgt < _ROWWISE_MIN_ROWS_WITH_STATS:
+        rw = None       # (the tile-plan kernel leaves the batch-norm statistics behind: cheaper on small maps)
+    if rw is not None:
+        # exactly one pair per target row (K = 1 layers — the reference's input.F.mm(kernel) —, the fine side of a
+        # kernel_size == stride map): rows stream through the MFMA registers, no plan (csrc/conv_rowwise.hip)
+        _check(kernel.dtype in (torch.float32, torch.bfloat16), "kernel must be float32 or bfloat16")
+        src_rows, tgt_rows, elems = rw
+        stream = _stream(dev)
+        with _on(dev):
+            if _PACK_CACHE:
+                packed = _packed_weights(kernel, _lib.ME_PACK_BF16, transposed, c_src, c_dst, elems)
+            else:
+                packed = torch.empty(elems, dtype=torch.bfloat16, device=dev)
+                _lib.check(lib.me_conv_pack_weights_bf16(kernel.data_ptr(), 1 if kernel.dtype == torch.float32 else 0,
+                                                         volume, c_src, c_dst, 1 if transposed else 0,
+                                                         packed.data_ptr(), stream))
+            _timed(name, dev, lambda: _lib.check(lib.me_conv_rowwise_bf16(
+                src_feat.data_ptr(), src_feat.shape[0], c_src, packed.data_ptr(), km.volume, c_dst, _ptr(src_rows),
+                _ptr(tgt_rows), km.k_offsets_dev.data_ptr(), n_tgt, out.data_ptr(), n_tgt, stream)),
+                flops=2.0 * km.n_pairs * c_src * c_dst if KERNEL_TIMER else 0.0)
         return out
     halo = _halo_launch_cfg(km, target, n_tgt, c_src, c_dst) if bf16 else None
     if halo is not None:

@@ -254,6 +254,151 @@ __global__ __launch_bounds__(256) void k_insert_finalize(
   }
 }
 
+// ---- fused resolve / rank / emit (round 6) -----------------------------------------------------------------------------
+// The pipeline above needed resolve -> scan (ONE 1024-thread block for up to 2^20 rows: 25 us at 100k rows, the longest
+// kernel of an insert) -> finalize, plus a bounding-box kernel with its own initialising copy.  Here the rank of a first
+// occurrence is never materialised: k_insert_flags leaves, per 64 consecutive rows, the ballot of the "first occurrence"
+// flags and the count of flags before them inside their 4096-row block, per block its flag count and bounding box;
+// k_insert_emit rebuilds any row's new index as  base[block] + prefix[64-row group] + popcount(ballot below the row)
+// — three small loads — after every block has scanned the (at most 4096) block counts in LDS.  No scan kernel, no
+// bounding-box kernel, no initialising copies: insert = fill + 3 launches.  Same results (first occurrence wins, unique rows
+// in input order): bit-identical maps.
+constexpr int kInsBlockRows = 4096;               // rows per block of the two kernels below (256 threads x 16)
+constexpr int kInsMaxBlocks = 4096;               // block counts scanned in LDS by every block: n <= 2^24 rows
+
+template <int NCOL>
+__global__ __launch_bounds__(256) void k_insert_flags(const int32_t *__restrict__ coords, const uint64_t *__restrict__ table,
+                                                     const uint32_t *__restrict__ slot_of_row, int64_t n,
+                                                     uint32_t *__restrict__ wrow, uint64_t *__restrict__ flagbits,
+                                                     uint32_t *__restrict__ group_prefix, uint32_t *__restrict__ blk_count,
+                                                     int32_t *__restrict__ blk_bbox) {
+  __shared__ uint32_t s_cnt[64];
+  __shared__ int32_t s_lo[4][NCOL], s_hi[4][NCOL];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t base = (int64_t)blockIdx.x * kInsBlockRows;
+  int32_t lo[NCOL], hi[NCOL];
+#pragma unroll
+  for (int d = 0; d < NCOL; ++d) {
+    lo[d] = INT32_MAX;
+    hi[d] = INT32_MIN;
+  }
+#pragma unroll 4
+  for (int j = 0; j < 16; ++j) {
+    const int64_t i = base + j * 256 + threadIdx.x;      // 64-row group j * 4 + wave of the block
+    bool first = false;
+    if (i < n) {
+      const uint32_t s = slot_of_row[i];
+      const uint32_t w = (s == 0xffffffffu) ? (uint32_t)i : (uint32_t)table[s];
+      wrow[i] = w;
+      first = w == (uint32_t)i;
+      int32_t c[NCOL];
+      load_coords<NCOL>(coords, i, c);
+#pragma unroll
+      for (int d = 0; d < NCOL; ++d) {
+        lo[d] = min(lo[d], c[d]);
+        hi[d] = max(hi[d], c[d]);
+      }
+    }
+    const unsigned long long bits = __ballot(first);
+    if (lane == 0) {
+      const int64_t grp = (base >> 6) + j * 4 + wave;
+      if (grp * 64 < n) flagbits[grp] = bits;
+      s_cnt[j * 4 + wave] = (uint32_t)__popcll(bits);
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < NCOL; ++d) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      lo[d] = min(lo[d], __shfl_xor(lo[d], off, 64));
+      hi[d] = max(hi[d], __shfl_xor(hi[d], off, 64));
+    }
+    if (lane == 0) {
+      s_lo[wave][d] = lo[d];
+      s_hi[wave][d] = hi[d];
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const uint32_t c = s_cnt[lane];
+    const uint32_t incl = wave_inclusive_scan(c);
+    const int64_t grp = (base >> 6) + lane;
+    if (grp * 64 < n) group_prefix[grp] = incl - c;
+    if (lane == 63) blk_count[blockIdx.x] = incl;
+    if (lane < NCOL) {
+      blk_bbox[(int64_t)blockIdx.x * 2 * NCOL + lane] = min(min(s_lo[0][lane], s_lo[1][lane]), min(s_lo[2][lane], s_lo[3][lane]));
+      blk_bbox[(int64_t)blockIdx.x * 2 * NCOL + NCOL + lane] =
+          max(max(s_hi[0][lane], s_hi[1][lane]), max(s_hi[2][lane], s_hi[3][lane]));
+    }
+  }
+}
+
+template <int NCOL>
+__global__ __launch_bounds__(256) void k_insert_emit(const int32_t *__restrict__ coords, int64_t n, uint64_t *table,
+                                                    const uint32_t *__restrict__ slot_of_row,
+                                                    const uint32_t *__restrict__ wrow, const uint64_t *__restrict__ flagbits,
+                                                    const uint32_t *__restrict__ group_prefix,
+                                                    const uint32_t *__restrict__ blk_count, const int32_t *__restrict__ blk_bbox,
+                                                    int nb, int32_t *__restrict__ coords_unique,
+                                                    int64_t *__restrict__ unique_map, int64_t *__restrict__ inverse_map,
+                                                    uint32_t *__restrict__ total_and_bbox) {
+  __shared__ uint32_t s_base[kInsMaxBlocks];
+  __shared__ uint32_t s_wsum[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // exclusive scan of the block counts (nb <= 4096: 16 per thread), the same in every block
+  constexpr int PER = kInsMaxBlocks / 256;
+  uint32_t v[PER], run = 0;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int b = threadIdx.x * PER + j;
+    v[j] = b < nb ? blk_count[b] : 0u;
+    run += v[j];
+  }
+  const uint32_t incl = wave_inclusive_scan(run);
+  if (lane == 63) s_wsum[wave] = incl;
+  __syncthreads();
+  uint32_t off = incl - run;
+  for (int wv = 0; wv < wave; ++wv) off += s_wsum[wv];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    s_base[threadIdx.x * PER + j] = off;
+    off += v[j];
+  }
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    // the number of unique rows and the bounding box of the INPUT rows (the one read-back of an insert)
+    if (threadIdx.x == 0) total_and_bbox[0] = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+    if (threadIdx.x < 2 * NCOL) {
+      const int d = threadIdx.x;
+      int32_t r = d < NCOL ? INT32_MAX : INT32_MIN;
+      for (int b = 0; b < nb; ++b) {
+        const int32_t x = blk_bbox[(int64_t)b * 2 * NCOL + d];
+        r = d < NCOL ? min(r, x) : max(r, x);
+      }
+      reinterpret_cast<int32_t *>(total_and_bbox)[1 + d] = r;
+    }
+  }
+  const int64_t base = (int64_t)blockIdx.x * kInsBlockRows;
+#pragma unroll 4
+  for (int j = 0; j < 16; ++j) {
+    const int64_t i = base + j * 256 + threadIdx.x;
+    if (i >= n) continue;
+    const uint32_t w = wrow[i];
+    const uint32_t grp = w >> 6;
+    const uint32_t id = s_base[w >> 12] + group_prefix[grp] +
+                        (uint32_t)__popcll(flagbits[grp] & ((1ull << (w & 63u)) - 1ull));
+    inverse_map[i] = (int64_t)id;
+    if (w == (uint32_t)i) {
+      unique_map[id] = i;
+      int32_t key[NCOL];
+      load_coords<NCOL>(coords, i, key);
+      store_coords<NCOL>(coords_unique, id, key);
+      const uint32_t s = slot_of_row[i];
+      if (s != 0xffffffffu) table[s] = (table[s] & 0xffffffff00000000ull) | (uint64_t)id;
+    }
+  }
+}
+
 // =================================================================================================
 // stride / find
 // =================================================================================================
@@ -1184,7 +1329,7 @@ using namespace me;
 
 extern "C" {
 
-int me_version(void) { return 150; }   // 100 * major + 10 * minor: see the changelog in include/me_amd.h
+int me_version(void) { return 160; }   // 100 * major + 10 * minor: see the changelog in include/me_amd.h
 const char *me_last_error(void) { return g_last_error; }
 
 int64_t me_region_volume(const me_region *rg) {
@@ -1207,7 +1352,8 @@ int64_t me_hash_capacity(int64_t n) {
 }
 
 // workspace layout of insert: slot_of_row[n] | wrow[n] | flag/newid[n] | total | scan ws
-static int64_t insert_ws_arrays(int64_t n) { return align_up(n * 4, 256); }
+static int64_t insert_ws_arrays(int64_t n) { return align_up(n * 4, 256) + 1024; }
+int g_insert_fused = 1;   // me_debug_set_insert_fused: 0 = the resolve / scan / finalize / bbox pipeline of rounds 1 - 5
 int64_t me_insert_workspace_bytes(int64_t n) {
   if (n < 1) n = 1;
   return 3 * insert_ws_arrays(n) + 256 + scan_workspace_bytes(n);
@@ -1247,6 +1393,26 @@ int me_coords_insert_and_map_bbox(const int32_t *coords, int64_t n, int32_t ncol
   ME_DISPATCH_NCOL(ncol, hipLaunchKernelGGL(k_insert<NCOL>, grid, block, 0, stream, coords, n, table,
                                             mask, slot_of_row));
   ME_LAUNCH_CHECK();
+  uint32_t host_buf[1 + 2 * (ME_MAX_DIM + 1)];
+  const int64_t nb = ceil_div(n, (int64_t)kInsBlockRows);
+  if (nb <= kInsMaxBlocks && g_insert_fused) {
+    // fused resolve / rank / emit (see k_insert_flags): the `flag` array holds the ballots, the group prefixes and the
+    // per-block counts / bounding boxes instead
+    const int64_t groups = ceil_div(n, (int64_t)64);
+    char *fb = reinterpret_cast<char *>(flag);
+    uint64_t *flagbits = reinterpret_cast<uint64_t *>(fb);
+    uint32_t *group_prefix = reinterpret_cast<uint32_t *>(fb + groups * 8);
+    uint32_t *blk_count = group_prefix + groups;
+    int32_t *blk_bbox = reinterpret_cast<int32_t *>(blk_count + nb);
+    const dim3 bgrid((unsigned)nb);
+    ME_DISPATCH_NCOL(ncol, hipLaunchKernelGGL(k_insert_flags<NCOL>, bgrid, block, 0, stream, coords, table, slot_of_row, n,
+                                              wrow, flagbits, group_prefix, blk_count, blk_bbox));
+    ME_LAUNCH_CHECK();
+    ME_DISPATCH_NCOL(ncol, hipLaunchKernelGGL(k_insert_emit<NCOL>, bgrid, block, 0, stream, coords, n, table, slot_of_row,
+                                              wrow, flagbits, group_prefix, blk_count, blk_bbox, (int)nb, coords_unique,
+                                              unique_map, inverse_map, total));
+    ME_LAUNCH_CHECK();
+  } else {
   hipLaunchKernelGGL(k_insert_resolve, grid, block, 0, stream, table, slot_of_row, n, wrow, flag);
   ME_LAUNCH_CHECK();
   if (int rc = exclusive_scan_u32(flag, flag, n, total, scan_ws, scan_workspace_bytes(n), stream)) return rc;
@@ -1256,7 +1422,6 @@ int me_coords_insert_and_map_bbox(const int32_t *coords, int64_t n, int32_t ncol
   ME_LAUNCH_CHECK();
   // the bounding box of the coordinates rides on the one read-back this function needs anyway: it sizes the dense
   // supercell directory of the map's spatial index (me_spatial_index_build) without a synchronisation of its own
-  uint32_t host_buf[1 + 2 * (ME_MAX_DIM + 1)];
   int32_t *bbox_dev = reinterpret_cast<int32_t *>(total + 1);   // (inside the 256-byte `total` slot)
   int32_t init[2 * (ME_MAX_DIM + 1)];   // source of an asynchronous copy: must live until the synchronisation below
   if (bbox) {
@@ -1277,7 +1442,16 @@ int me_coords_insert_and_map_bbox(const int32_t *coords, int64_t n, int32_t ncol
   if (bbox)
     for (int d = 0; d < 2 * ncol; ++d) bbox[d] = (int32_t)host_buf[1 + d];
   return 0;
+  }
+  ME_HIP(hipMemcpyAsync(host_buf, total, (size_t)(1 + (bbox ? 2 * ncol : 0)) * 4, hipMemcpyDeviceToHost, stream));
+  ME_HIP(hipStreamSynchronize(stream));
+  *n_unique = (int64_t)host_buf[0];
+  if (bbox)
+    for (int d = 0; d < 2 * ncol; ++d) bbox[d] = (int32_t)host_buf[1 + d];
+  return 0;
 }
+
+void me_debug_set_insert_fused(int on) { g_insert_fused = on ? 1 : 0; }
 
 int me_coords_insert_and_map(const int32_t *coords, int64_t n, int32_t ncol, uint64_t *table,
                              int64_t capacity, int32_t *coords_unique, int64_t *unique_map,
@@ -1885,14 +2059,14 @@ extern "C" __attribute__((visibility("hidden"))) void me_preload_coords(void) {
 
 // Load every code object of the library now (ABI 1.5).  HIP loads a translation unit's device code when the first kernel
 // of it is launched: the first backward pass of a process paid 88 ms for the weight-gradient / reduce / batch-norm units
-// (BENCH_r04 cold_breakdown_ms.first_backward_plans).  Called by the hosts at import; costs what those first launches cost.
+// (BENCH_r04 cold_breakdown_ms.first_backward_plans).  Called by the hosts at the first map insert on a device; costs what those first launches cost.
 extern "C" {
 void me_preload_conv(void); void me_preload_conv_bf16(void); void me_preload_conv_bf16_ws(void); void me_preload_conv_f32x3(void);
 void me_preload_conv_halo(void); void me_preload_coords(void); void me_preload_norm(void); void me_preload_pack(void);
-void me_preload_f64(void); void me_preload_pool(void); void me_preload_conv_stem(void);
+void me_preload_f64(void); void me_preload_pool(void); void me_preload_conv_stem(void); void me_preload_conv_rowwise(void);
 int me_preload(void) {
   me_preload_coords(); me_preload_conv(); me_preload_conv_bf16(); me_preload_conv_bf16_ws(); me_preload_conv_f32x3();
-  me_preload_conv_halo(); me_preload_conv_stem(); me_preload_norm(); me_preload_pack(); me_preload_pool(); me_preload_f64();
+  me_preload_conv_halo(); me_preload_conv_stem(); me_preload_conv_rowwise(); me_preload_norm(); me_preload_pack(); me_preload_pool(); me_preload_f64();
   ME_HIP(hipGetLastError());
   return 0;
 }

@@ -76,6 +76,10 @@ int32_t me_debug_halo_mode(void);
 int me_debug_halo_timing(uint64_t *out8, int32_t reset);   /* phase counters of a -DME_HALO_TIMING build */
 /* stacked-offset kernel (conv_stem.hip): -1 policy / 0 never / 1 wherever the shape is supported */
 void me_debug_set_stem(int mode, int groups);   /* groups: 16-row groups per wave, 0 policy | 1 | 2 | 4 */
+/* insert_and_map: 1 (default) = fused resolve / rank / emit kernels (round 6), 0 = resolve + scan + finalize + bbox */
+void me_debug_set_insert_fused(int on);
+/* row-wise kernel (conv_rowwise.hip): 16-row groups per wave, 0 policy | 1 | 2 */
+void me_debug_set_rowwise_groups(int groups);
 
 #if defined(__GNUC__) || defined(__clang__)
 #pragma GCC visibility pop

@@ -57,6 +57,12 @@ inline void *vptr(const Tensor &t) { return t.defined() ? t.data_ptr() : nullptr
 // environment switches shared with backend.py (same names, same defaults)
 struct Policy {
   int spatial_maps;        // ME_AMD_SPATIAL_MAPS: 1 / 0 / -1 (auto)
+  bool rowwise = true;     // ME_AMD_ROWWISE=0: one-pair-per-row sides stay on the tile-plan kernels
+  // a K = 1 FORWARD launch whose batch-norm statistics are wanted (training, bf16) takes the row-wise kernel — which has no
+  // statistics epilogue: the batch norm then reads the output once more — only on maps of at least this many rows
+  // (measured per layer, gpurun_out/r06_layers_rowwise_*.log: 128 -> 96 on 161k / 200k rows 43 / 51 -> 36 / 42 us with the
+  // extra pass, 192 -> 128 on 80k even, 32 -> 64 on 80k and everything smaller slower)
+  int64_t rowwise_min_rows_with_stats = 100000;   // ME_AMD_ROWWISE_STATS_ROWS
   std::string tile_order;  // ME_AMD_TILE_ORDER: auto | rows | spatial
   int64_t tile_spatial_src_bytes = 28ll << 20;  // ME_AMD_TILE_SPATIAL_SRC_MB: bf16 sources of at least this size take spatial tiles
   std::string bf16_fuse;   // ME_AMD_BF16_FUSE: auto | 1 | 0
@@ -171,6 +177,7 @@ struct ConvCfg {          // launch geometry of a (kernel map side, channel shap
   int64_t elems;
   bool fuse, split;
   int split_k = 1;        // offset groups of a split-K launch (bf16 features on small maps; 1: not split)
+  bool rowwise = false;   // the side has exactly one pair per target row: no plan, csrc/conv_rowwise.hip (round 6)
   std::shared_ptr<HaloPlan> halo;   // set: the launch runs on the halo kernel (me_conv_halo_use_bf16)
   int halo_at_use = 0;    // > 0: the policy wants the halo kernel here from that launch count on (me_conv_halo_min_uses)
   int uses = 0;           // launches that asked for this configuration (recipe replays do not count)
@@ -193,6 +200,9 @@ struct KernelMap : std::enable_shared_from_this<KernelMap> {
   Tensor k_offsets_dev, in_pairs_buf, out_pairs_buf;
   std::shared_ptr<KernelMapStore> store;
   bool flip = false;
+  // sides on which a row has AT MOST one pair by construction (bit 0: "in" rows, bit 1: "out" rows): the 1x1 identity map
+  // (both), the fine side of a kernel_size == stride map.  With n_pairs == rows of the side: exactly one -> row-wise launch
+  int one_pair_sides = 0;
   std::map<std::string, ConvCfg> conv_cfgs;
   std::map<std::string, WgradCfg> wgrad_cfgs;
   std::weak_ptr<RecipeLog> log;   // the owning manager's request log (build recipe) ...
@@ -211,7 +221,7 @@ struct KernelMap : std::enable_shared_from_this<KernelMap> {
   Tensor order(const std::string &target, const std::string &tile_order);
   std::shared_ptr<Plan> plan(const std::string &target, int tile_rows, int batch_groups, const std::string &tile_order);
   std::shared_ptr<HaloPlan> halo_plan(const std::string &target, int tile_rows, int s_cap);
-  const ConvCfg &conv_cfg(const std::string &target, int64_t n_tgt, int c_src, int c_dst, bool bf16);
+  const ConvCfg &conv_cfg(const std::string &target, int64_t n_tgt, int c_src, int c_dst, bool bf16, bool no_rowwise = false);
   const WgradCfg &wgrad_cfg(int c_in, int c_out, bool bf16);
   pybind11::dict to_dict();
 };

@@ -35,6 +35,8 @@ const Policy &Policy::get() {
     Policy q;
     const std::string sm = env_str("ME_AMD_SPATIAL_MAPS", "auto");
     q.spatial_maps = sm == "1" ? 1 : (sm == "0" ? 0 : -1);
+    q.rowwise = env_str("ME_AMD_ROWWISE", "1") != "0";
+    q.rowwise_min_rows_with_stats = std::atoll(env_str("ME_AMD_ROWWISE_STATS_ROWS", "100000").c_str());
     q.tile_order = env_str("ME_AMD_TILE_ORDER", "auto");
     q.tile_spatial_src_bytes = (int64_t)std::atoi(env_str("ME_AMD_TILE_SPATIAL_SRC_MB", "28").c_str()) << 20;
     q.bf16_fuse = env_str("ME_AMD_BF16_FUSE", "auto");
@@ -56,6 +58,8 @@ void Policy::set(const std::string &name, int64_t value) {
   Policy &p = const_cast<Policy &>(get());
   if (name == "tile_spatial_src_bytes") p.tile_spatial_src_bytes = value;
   else if (name == "spatial_maps") p.spatial_maps = (int)value;
+  else if (name == "rowwise") p.rowwise = value != 0;
+  else if (name == "rowwise_min_rows_with_stats") p.rowwise_min_rows_with_stats = value;
   else if (name == "f32_split") p.f32_split = (int)value;
   else if (name == "tile_rows") p.tile_rows = (int)value;
   else if (name == "batch_groups") p.batch_groups = (int)value;
@@ -255,6 +259,7 @@ std::shared_ptr<KernelMap> KernelMap::swapped() {
   k->out_pairs_buf = in_pairs_buf;
   k->store = store;
   k->flip = !flip;
+  k->one_pair_sides = ((one_pair_sides & 1) << 1) | ((one_pair_sides >> 1) & 1);
   return k;
 }
 
@@ -508,11 +513,12 @@ static bool use_split(int c_src, int c_dst) {
   return p.f32_split == 1 ? true : (int64_t)c_src * c_dst >= 8192;
 }
 
-const ConvCfg &KernelMap::conv_cfg(const std::string &target, int64_t n_tgt, int c_src, int c_dst, bool bf16) {
+const ConvCfg &KernelMap::conv_cfg(const std::string &target, int64_t n_tgt, int c_src, int c_dst, bool bf16,
+                                   bool no_rowwise) {
   const Policy &pol = Policy::get();
   const bool split = !bf16 && use_split(c_src, c_dst);
   const std::string ck = target + "/" + std::to_string(c_src) + "/" + std::to_string(c_dst) + (bf16 ? "/b" : "/f") +
-                         (split ? "s" : "-");
+                         (split ? "s" : "-") + (no_rowwise ? "/p" : "");
   auto it = conv_cfgs.find(ck);
   if (it != conv_cfgs.end()) {
     if (!(it->second.plan && it->second.plan->failed)) {
@@ -539,6 +545,21 @@ const ConvCfg &KernelMap::conv_cfg(const std::string &target, int64_t n_tgt, int
   }
   // the plan geometry depends on the pair count (density): the one host value a first launch on a new map waits for
   const int64_t np = n_pairs();
+  if (bf16 && pol.rowwise && !no_rowwise && (one_pair_sides & (target == "in" ? 1 : 2)) && np == n_tgt &&
+      me_conv_rowwise_supported_bf16(volume, c_src, c_dst)) {
+    // every target row has exactly one pair (at most one by construction, and as many pairs as rows): no sum, no plan —
+    // out[t] = src[s(t)] @ W[k(t)] straight off the pair lists (csrc/conv_rowwise.hip)
+    ConvCfg c;
+    c.tile_rows = 0;
+    c.batch_groups = 0;
+    c.split = false;
+    c.fuse = false;
+    c.rowwise = true;
+    c.elems = me_conv_packed_weight_elems_bf16(volume, c_src, c_dst);
+    if (auto lg = log.lock())
+      lg->push_back("conv_cfg;" + log_key + ";" + target + ";" + std::to_string(c_src) + ";" + std::to_string(c_dst) + ";1");
+    return conv_cfgs.emplace(ck, std::move(c)).first->second;
+  }
   int32_t t = 0, g = 0, sk = 1;
   if (bf16 && !pol.tile_rows && !pol.batch_groups)
     me_ok(me_conv_plan_config_bf16_ex(n_tgt, volume, np, c_src, c_dst, &t, &g, &sk));   // may answer a split-K geometry
@@ -972,6 +993,20 @@ Tensor CoordinateMapManager::origin_rows(const KeyT &in_key) {
   return rows;
 }
 
+// Sides of a hyper-cube map (looked-up map `fine_ts`, iterated map `coarse_ts`) on which a row has at most ONE pair by
+// construction: windows of kernel_size voxels that tile space without overlap (coarse stride = kernel_size x fine stride,
+// no dilation) hold every fine voxel exactly once -> bit 0 (the "in" = fine side).  A single-offset kernel pairs a row
+// with at most one row on BOTH sides.
+static int one_pair_sides_of(const ivec &kernel_size, const ivec &dilation, int region_type, const ivec &fine_ts,
+                             const ivec &coarse_ts, bool) {
+  bool single = true, tiling = region_type == 0 && fine_ts.size() == kernel_size.size() && coarse_ts.size() == kernel_size.size();
+  for (size_t i = 0; i < kernel_size.size(); ++i) {
+    single = single && kernel_size[i] == 1;
+    tiling = tiling && dilation[i] == 1 && coarse_ts[i] == fine_ts[i] * kernel_size[i];
+  }
+  return single ? 3 : (tiling ? 1 : 0);
+}
+
 std::shared_ptr<KernelMap> CoordinateMapManager::kernel_map(const KeyT &in_key, const KeyT &out_key,
                                                             const ivec &kernel_size, const ivec &kernel_stride,
                                                             const ivec &kernel_dilation, int region_type,
@@ -1002,6 +1037,7 @@ std::shared_ptr<KernelMap> CoordinateMapManager::kernel_map(const KeyT &in_key, 
     km->in_pairs_buf = km->out_pairs_buf = rows;
     km->store = std::make_shared<KernelMapStore>();
     km->store->t["nbr_out"] = n ? rows.view({1, n}) : empty_i32({1, 1}, dev);
+    km->one_pair_sides = 3;
     kernel_maps[key] = km;
     return km;
   }
@@ -1009,6 +1045,8 @@ std::shared_ptr<KernelMap> CoordinateMapManager::kernel_map(const KeyT &in_key, 
     me_region region = make_region((int)kernel_size.size() + 1, region_type, kernel_size, kernel_dilation,
                                    in_map->tensor_stride);
     km = build_kernel_map(in_map, out_map, region);
+    km->one_pair_sides = one_pair_sides_of(kernel_size, kernel_dilation, region_type, in_map->tensor_stride,
+                                           out_map->tensor_stride, false);
   } else {
     KernelMapKeyT swapped_key(out_key, in_key, kernel_size, kernel_stride, kernel_dilation, region_type, false, is_pool);
     auto fit = kernel_maps.find(swapped_key);
@@ -1020,6 +1058,8 @@ std::shared_ptr<KernelMap> CoordinateMapManager::kernel_map(const KeyT &in_key, 
       me_region region = make_region((int)kernel_size.size() + 1, region_type, kernel_size, kernel_dilation,
                                      out_map->tensor_stride);
       fwd = build_kernel_map(out_map, in_map, region);
+      fwd->one_pair_sides = one_pair_sides_of(kernel_size, kernel_dilation, region_type, out_map->tensor_stride,
+                                              in_map->tensor_stride, false);
     }
     km = fwd->swapped();
   }

@@ -419,11 +419,37 @@ static Tensor conv_target(const Tensor &src, const Tensor &kernel, KernelMap &km
     if (want_stats) bn_partials_put(out, part, tile_rows);
     return out;
   }
-  const ConvCfg &cfg = km.conv_cfg(target, n_tgt, c_src, c_dst, bf16);
+  // (a forward launch whose batch-norm statistics are wanted keeps the tile-plan kernel — which leaves them behind — on
+  // small maps: ConvCfg::rowwise_min_rows_with_stats)
+  const bool stats_wanted = bf16 && !transposed && target == "out" && g_conv_bn_stats_hint && conv_bn_stats_enabled();
+  const ConvCfg &cfg0 = km.conv_cfg(target, n_tgt, c_src, c_dst, bf16);
+  const ConvCfg &cfg = (cfg0.rowwise && stats_wanted && n_tgt < Policy::get().rowwise_min_rows_with_stats)
+                           ? km.conv_cfg(target, n_tgt, c_src, c_dst, bf16, /*no_rowwise=*/true)
+                           : cfg0;
   c10::DeviceGuard guard(dev);
   void *st = stream_of(dev);
   auto timed_name = transposed ? "conv_dgrad" : "conv_forward";
   const double flops = g_timing ? 2.0 * (double)km.n_pairs() * c_src * c_dst : 0.0;
+  if (cfg.rowwise) {
+    // exactly one pair per target row (K = 1 layers — the reference's input.F.mm(kernel) —, the fine side of a
+    // kernel_size == stride map): rows stream through the MFMA registers, no plan (csrc/conv_rowwise.hip)
+    check(kernel.scalar_type() == at::kFloat || kernel.scalar_type() == at::kBFloat16, "kernel must be float32 or bfloat16");
+    Tensor packed;
+    if (Policy::get().pack_cache) {
+      packed = packed_weights(kernel, ME_PACK_BF16, transposed, c_src, c_dst, cfg.elems);
+    } else {
+      packed = at::empty({cfg.elems}, at::TensorOptions().dtype(at::kBFloat16).device(dev));
+      me_ok(me_conv_pack_weights_bf16(kernel.data_ptr(), kernel.scalar_type() == at::kFloat ? 1 : 0, volume, c_src, c_dst,
+                                      transposed ? 1 : 0, ptr<uint16_t>(packed), st));
+    }
+    const Tensor &src_rows = target == "out" ? km.in_pairs_buf : km.out_pairs_buf;
+    const Tensor &tgt_rows = target == "out" ? km.out_pairs_buf : km.in_pairs_buf;
+    ScopedTimer tm(timed_name, flops, st);
+    me_ok(me_conv_rowwise_bf16(ptr<uint16_t>(src), src.size(0), c_src, ptr<uint16_t>(packed), km.volume, c_dst,
+                               ptr<int32_t>(src_rows), ptr<int32_t>(tgt_rows), ptr<int64_t>(km.k_offsets_dev), n_tgt,
+                               ptr<uint16_t>(out), n_tgt, st));
+    return out;
+  }
   if (cfg.halo) {
     // output-stationary launch on the LDS-staged source halo (csrc/conv_halo.hip): the same packed weights; the
     // batch-norm partials per halo tile

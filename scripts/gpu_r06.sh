@@ -1,0 +1,71 @@
+#!/bin/bash
+# round-6 GPU sessions: scripts/gpu_r06.sh <step> [args]; everything lands in gpurun_out/r06_<step>*.log
+set -u
+mkdir -p gpurun_out
+step=${1:-base}; shift || true
+summ() {  # headline summary of a bench JSON line
+python - "$1" <<'PY'
+import json, sys
+l = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+r = l["roofline"]
+print(sys.argv[1].split("/")[-1], "ms/step", l["ms_per_step"], "Mpts/s", round(l["value"], 1), "frac", r.get("frac"),
+      "traffic_by_pass", json.dumps(r.get("traffic_by_pass")), "kernels_us", json.dumps(l.get("kernel_us") or l.get("timers") or {})[:300])
+for k, w in (l.get("workloads") or {}).items():
+    print("   ", k, {x: w.get(x) for x in ("value", "ms_per_step", "error")})
+PY
+}
+case "$step" in
+  base)   # state of the tree on the GPU: whole GPU suite + the driver's bench command
+    timeout 3000 python -m pytest tests -m gpu -x -q 2>&1 | grep -v "^  File\|^Extension\|amdgpu.ids" | tail -15 > gpurun_out/r06_base_pytest.log
+    cat gpurun_out/r06_base_pytest.log
+    timeout 900 python bench.py > gpurun_out/r06_bench_base.json 2> gpurun_out/r06_bench_base.err
+    tail -3 gpurun_out/r06_bench_base.err
+    summ gpurun_out/r06_bench_base.json
+    ;;
+  headline_knobs)   # headline only, with the existing locality knobs (traffic per pass from the in-run PMC passes)
+    for cfg in "default:" "spatialmaps:ME_AMD_SPATIAL_MAPS=1" "dispatch:ME_AMD_TILE_DISPATCH=1" "both:ME_AMD_SPATIAL_MAPS=1 ME_AMD_TILE_DISPATCH=1"; do
+      tag=${cfg%%:*}; envs=${cfg#*:}
+      env $envs timeout 600 python bench.py --extra-workloads off --cpu-budget 0 --pmc on > gpurun_out/r06_knob_$tag.json 2> gpurun_out/r06_knob_$tag.err
+      tail -2 gpurun_out/r06_knob_$tag.err
+      summ gpurun_out/r06_knob_$tag.json
+    done
+    ;;
+  rowwise)   # row-wise kernel: parity tests (+ the bf16 layer tests it now serves), per-layer table of the MinkUNet34C step per variant
+    timeout 1200 python -m pytest tests/test_gpu_rowwise.py tests/test_gpu_bf16.py tests/test_gpu_minkunet.py tests/test_gpu_norm.py -m gpu -x -q 2>&1 | grep -v "^  File\|^Extension\|amdgpu.ids" | tail -25 | tee gpurun_out/r06_rowwise_tests.log
+    for cfg in "on:ME_AMD_ROWWISE=1" "g1:ME_AMD_ROWWISE=1 ME_AMD_RW_G=1" "g2:ME_AMD_ROWWISE=1 ME_AMD_RW_G=2" "off:ME_AMD_ROWWISE=0"; do
+      tag=${cfg%%:*}; envs=${cfg#*:}
+      env $envs timeout 600 python scripts/unet_layers.py 2>&1 | grep -v amdgpu.ids > gpurun_out/r06_layers_rowwise_$tag.log
+      echo "== $tag"; head -1 gpurun_out/r06_layers_rowwise_$tag.log
+      grep -E "\((1|8), " gpurun_out/r06_layers_rowwise_$tag.log | grep -v wgrad | sort -k6 | awk '{printf "%s %s %s%s%s%s%s%s | ", $3, $5, $6,$7,$8,$9,$10,$11} END {print ""}'
+      env $envs timeout 600 python bench.py --workload minkunet --dtype bf16 --steps 20 --warmup 5 --cpu-budget 0 --pmc off --extra-workloads off > gpurun_out/r06_unet_rowwise_$tag.json 2> gpurun_out/r06_unet_rowwise_$tag.err
+      python -c "import json; l=json.loads(open('gpurun_out/r06_unet_rowwise_$tag.json').read().strip().splitlines()[-1]); print('unet $tag', l['ms_per_step'], l['value'])"
+    done
+    ;;
+  insert)   # fused insert: equivalence tests + cold numbers of the bench (insert_ms / insert_GBs) + the rowwise / norm tests again
+    timeout 1500 python -m pytest tests/test_gpu_coords.py tests/test_gpu_rowwise.py tests/test_gpu_norm.py tests/test_gpu_prefetch.py tests/test_gpu_native_host.py -m gpu -x -q 2>&1 | grep -v "^  File\|^Extension\|amdgpu.ids" | tail -15 | tee gpurun_out/r06_insert_tests.log
+    timeout 600 python bench.py --extra-workloads off --cpu-budget 0 --pmc off > gpurun_out/r06_bench_insert.json 2> gpurun_out/r06_bench_insert.err
+    python -c "import json; l=json.loads(open('gpurun_out/r06_bench_insert.json').read().strip().splitlines()[-1]); print('headline', l['ms_per_step'], 'cold', json.dumps(l['cold']))"
+    for sc in cached fresh pipelined; do
+      timeout 600 python bench.py --workload minkunet --dtype bf16 --steps 20 --warmup 5 --cpu-budget 0 --pmc off --extra-workloads off --scenes $sc $( [ $sc = fresh ] && echo --replay-maps ) > gpurun_out/r06_unet_scenes_$sc.json 2> gpurun_out/r06_unet_scenes_$sc.err
+      python -c "import json; l=json.loads(open('gpurun_out/r06_unet_scenes_$sc.json').read().strip().splitlines()[-1]); print('unet $sc', l['ms_per_step'], l['value'])"
+    done
+    ;;
+  sq)   # the counter-based MFMA utilisation pass of bench.py (headline + MinkUNet34C entry)
+    timeout 900 python bench.py --cpu-budget 0 --pmc on > gpurun_out/r06_bench_sq.json 2> gpurun_out/r06_bench_sq.err
+    tail -3 gpurun_out/r06_bench_sq.err
+    python - <<'PY'
+import json
+l = json.loads(open("gpurun_out/r06_bench_sq.json").read().strip().splitlines()[-1])
+r = l["roofline"]
+print("headline", l["ms_per_step"], "frac", r.get("frac"), "mfma_busy_frac", r.get("mfma_busy_frac"))
+for k, v in (r.get("mfma_busy_by_pass") or {}).items():
+    print("  ", k, json.dumps(v))
+w = (l.get("workloads") or {}).get("minkunet34c_bf16_200k") or {}
+rr = w.get("roofline") or {}
+print("minkunet", w.get("ms_per_step"), "mfma_busy_frac", rr.get("mfma_busy_frac"), "traffic", rr.get("traffic"))
+for k, v in (rr.get("mfma_busy_by_kernel") or {}).items():
+    print("  ", k[:70], json.dumps(v))
+PY
+    ;;
+  *) echo "unknown step $step"; exit 1 ;;
+esac

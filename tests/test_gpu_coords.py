@@ -36,6 +36,32 @@ def test_insert_and_map_bit_exact(device, host_layer, n, extent, D, dup):
     assert np.array_equal(coords.numpy(), got[inv.cpu().numpy()])
 
 
+@pytest.mark.parametrize("n,extent,D,dup", [(1, 4, 3, 0), (70, 6, 3, 40), (5000, 12, 3, 900), (60000, 60, 3, 30000),
+                                             (300000, 90, 3, 5000), (9000, 8, 4, 4000), (4097, 40, 2, 0)])
+def test_fused_insert_equals_the_resolve_scan_finalize_pipeline(device, n, extent, D, dup):
+    """Round 6: insert = fill + k_insert + k_insert_flags + k_insert_emit (ranks rebuilt from ballots, group prefixes and
+    block counts; bounding box from per-block boxes) instead of resolve + one-block scan + finalize + bbox.  Same maps,
+    same table, same bounding box, bit for bit — one block, many blocks, a partial last block, heavy duplication."""
+    from minkowskiengine_amd import _lib
+    lib = _lib.load()
+    coords = make_cloud(n, extent, D, seed=n + D, batch=2, dup=dup, negative=True).to(device)
+    res = []
+    for fused in (1, 0):
+        lib.me_debug_set_insert_fused(fused)
+        try:
+            MEB, mgr = _mgr()
+            key, (um, inv) = mgr.insert_and_map(coords, [1] * D, "")
+            cm = mgr._maps[mgr._k(key)]
+            res.append((um.clone(), inv.clone(), mgr.get_coordinates(key).clone(), cm.table.clone(), tuple(cm.bbox or ())))
+        finally:
+            lib.me_debug_set_insert_fused(1)
+    for a, b in zip(res[0][:4], res[1][:4]):
+        assert torch.equal(a, b)
+    assert res[0][4] == res[1][4] and len(res[0][4]) == 2 * (D + 1)
+    um_o, inv_o = O.insert_and_map(coords.cpu().numpy())
+    assert np.array_equal(res[0][0].cpu().numpy(), um_o) and np.array_equal(res[0][1].cpu().numpy(), inv_o)
+
+
 def test_insert_all_duplicates_and_empty(device, host_layer):
     MEB, mgr = _mgr()
     coords = torch.IntTensor([[0, 1, 2, 3]] * 257).to(device)
