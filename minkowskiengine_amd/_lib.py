@@ -267,6 +267,8 @@ def load():
         lib.me_debug_set_wgrad_ws(int(os.environ["ME_AMD_WGRAD_WS"]))
     if os.environ.get("ME_AMD_BF16_WS_NCW", "") != "":
         lib.me_debug_set_bf16_ws_ncw(int(os.environ["ME_AMD_BF16_WS_NCW"]))
+    if os.environ.get("ME_INSERT_FUSED", "") != "":
+        lib.me_debug_set_insert_fused(int(os.environ["ME_INSERT_FUSED"]))
     if os.environ.get("ME_AMD_RW_G", "") != "":
         lib.me_debug_set_rowwise_groups(int(os.environ["ME_AMD_RW_G"]))
     if os.environ.get("ME_AMD_BF16_WS_DEPTH", "") != "":

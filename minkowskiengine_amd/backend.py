@@ -1092,10 +1092,14 @@ class CoordinateMapManagerGPU_c10:
                         n_tgt = km.n_out if target == "out" else km.n_in
                         if bf16 and c_src == 8 and _lib.load().me_conv_stem_use_bf16(n_tgt, km.volume, c_src, c_dst):
                             km.table_pos(target)       # (the stacked-offset kernel reads the neighbour table: no plan)
-                        elif bf16 and _rowwise_cfg(km, target, n_tgt, c_src, c_dst) is not None:
-                            pass                       # (one pair per row: the launch reads the pair lists, no plan)
                         elif not (bf16 and _halo_launch_cfg(km, target, n_tgt, c_src, c_dst, count=False) is not None):
                             _conv_launch_cfg(km, target, n_tgt, c_src, c_dst, bf16)
+                        done += 1
+                elif op[0] == "rowwise_cfg":       # (one pair per row: the launch reads the pair lists, no plan)
+                    _, key, target, c_src, c_dst = op
+                    km = self._kernel_maps.get(key)
+                    if km is not None:
+                        _rowwise_cfg(km, target, km.n_out if target == "out" else km.n_in, c_src, c_dst)
                         done += 1
                 elif op[0] == "wgrad_cfg":
                     _, key, c_in, c_out, bf16 = op
@@ -1302,7 +1306,7 @@ def _rowwise_cfg(km, target, n_tgt, c_src, c_dst):
         cfg = km._launch_cache[ck] = (src_rows, tgt_rows, int(lib.me_conv_packed_weight_elems_bf16(km.volume, c_src, c_dst))) \
             if ok else False
         if ok and km._recipe is not None:
-            km._recipe.append(("conv_cfg", km._recipe_key, target, c_src, c_dst, True))
+            km._recipe.append(("rowwise_cfg", km._recipe_key, target, c_src, c_dst))
     return cfg or None
 
 

@@ -193,15 +193,13 @@ __global__ __launch_bounds__(256) void k_insert(const int32_t *__restrict__ coor
   const uint64_t mine = ((uint64_t)h << 32) | (uint32_t)i;
   uint32_t pos = h & mask;
   for (uint32_t probe = 0; probe <= mask; ++probe) {
-    uint64_t cur = table[pos];
+    // claim first, look afterwards (round 6): at <= 50 % load most first probes hit an empty slot, and a plain load before
+    // the CAS was a second dependent round trip to the L2 for every one of them
+    const uint64_t cur = atomicCAS(reinterpret_cast<unsigned long long *>(&table[pos]), (unsigned long long)kEmptySlot,
+                                   (unsigned long long)mine);
     if (cur == kEmptySlot) {
-      const uint64_t old = atomicCAS(reinterpret_cast<unsigned long long *>(&table[pos]),
-                                     (unsigned long long)kEmptySlot, (unsigned long long)mine);
-      if (old == kEmptySlot) {
-        slot_of_row[i] = pos;
-        return;
-      }
-      cur = old;  // somebody else claimed the slot first: compare against it
+      slot_of_row[i] = pos;
+      return;
     }
     if ((uint32_t)(cur >> 32) == h) {
       const uint32_t r = (uint32_t)cur;
@@ -260,11 +258,13 @@ __global__ __launch_bounds__(256) void k_insert_finalize(
 // occurrence is never materialised: k_insert_flags leaves, per 64 consecutive rows, the ballot of the "first occurrence"
 // flags and the count of flags before them inside their 4096-row block, per block its flag count and bounding box;
 // k_insert_emit rebuilds any row's new index as  base[block] + prefix[64-row group] + popcount(ballot below the row)
-// — three small loads — after every block has scanned the (at most 4096) block counts in LDS.  No scan kernel, no
+// — three small loads — after every block has scanned the block counts (n / 1024 of them) in LDS.  No scan kernel, no
 // bounding-box kernel, no initialising copies: insert = fill + 3 launches.  Same results (first occurrence wins, unique rows
 // in input order): bit-identical maps.
-constexpr int kInsBlockRows = 4096;               // rows per block of the two kernels below (256 threads x 16)
-constexpr int kInsMaxBlocks = 4096;               // block counts scanned in LDS by every block: n <= 2^24 rows
+constexpr int kInsBlockRows = 1024;               // rows per block of the two kernels below (256 threads x 4: 98 blocks at 100k rows)
+constexpr int kInsBlockShift = 10;
+constexpr int kInsJ = kInsBlockRows / 256;        // rows per thread; the block holds 4 * kInsJ groups of 64 rows
+constexpr int kInsMaxBlocks = 8192;               // block counts scanned in LDS by every block: n <= 2^23 rows (beyond: the scan pipeline)
 
 template <int NCOL>
 __global__ __launch_bounds__(256) void k_insert_flags(const int32_t *__restrict__ coords, const uint64_t *__restrict__ table,
@@ -282,8 +282,10 @@ __global__ __launch_bounds__(256) void k_insert_flags(const int32_t *__restrict_
     lo[d] = INT32_MAX;
     hi[d] = INT32_MIN;
   }
-#pragma unroll 4
-  for (int j = 0; j < 16; ++j) {
+  if (threadIdx.x < 64) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kInsJ; ++j) {
     const int64_t i = base + j * 256 + threadIdx.x;      // 64-row group j * 4 + wave of the block
     bool first = false;
     if (i < n) {
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(256) void k_insert_flags(const int32_t *__restrict_
     const uint32_t c = s_cnt[lane];
     const uint32_t incl = wave_inclusive_scan(c);
     const int64_t grp = (base >> 6) + lane;
-    if (grp * 64 < n) group_prefix[grp] = incl - c;
+    if (lane < 4 * kInsJ && grp * 64 < n) group_prefix[grp] = incl - c;
     if (lane == 63) blk_count[blockIdx.x] = incl;
     if (lane < NCOL) {
       blk_bbox[(int64_t)blockIdx.x * 2 * NCOL + lane] = min(min(s_lo[0][lane], s_lo[1][lane]), min(s_lo[2][lane], s_lo[3][lane]));
@@ -343,50 +345,53 @@ __global__ __launch_bounds__(256) void k_insert_emit(const int32_t *__restrict__
                                                     int64_t *__restrict__ unique_map, int64_t *__restrict__ inverse_map,
                                                     uint32_t *__restrict__ total_and_bbox) {
   __shared__ uint32_t s_base[kInsMaxBlocks];
-  __shared__ uint32_t s_wsum[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // exclusive scan of the block counts (nb <= 4096: 16 per thread), the same in every block
-  constexpr int PER = kInsMaxBlocks / 256;
-  uint32_t v[PER], run = 0;
-#pragma unroll
-  for (int j = 0; j < PER; ++j) {
-    const int b = threadIdx.x * PER + j;
-    v[j] = b < nb ? blk_count[b] : 0u;
-    run += v[j];
-  }
-  const uint32_t incl = wave_inclusive_scan(run);
-  if (lane == 63) s_wsum[wave] = incl;
-  __syncthreads();
-  uint32_t off = incl - run;
-  for (int wv = 0; wv < wave; ++wv) off += s_wsum[wv];
-#pragma unroll
-  for (int j = 0; j < PER; ++j) {
-    s_base[threadIdx.x * PER + j] = off;
-    off += v[j];
+  // (this thread's row: requested before the scan below, used after it)
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool valid = i < n;
+  const uint32_t w = valid ? wrow[i] : 0u;
+  const uint32_t grp = w >> 6;
+  const uint32_t gp = valid ? group_prefix[grp] : 0u;
+  const uint64_t fb = valid ? flagbits[grp] : 0ull;
+  // exclusive scan of the block counts, the same in every block: wave 0 walks them 64 at a time
+  __shared__ uint32_t s_total;
+  if (wave == 0) {
+    uint32_t run = 0;
+    for (int b0 = 0; b0 < nb; b0 += 64) {
+      const int b = b0 + lane;
+      const uint32_t c = b < nb ? blk_count[b] : 0u;
+      const uint32_t incl = wave_inclusive_scan(c);
+      if (b < nb) s_base[b] = run + incl - c;
+      run += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) s_total = run;
   }
   __syncthreads();
   if (blockIdx.x == 0) {
-    // the number of unique rows and the bounding box of the INPUT rows (the one read-back of an insert)
-    if (threadIdx.x == 0) total_and_bbox[0] = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
-    if (threadIdx.x < 2 * NCOL) {
-      const int d = threadIdx.x;
+    // the number of unique rows and the bounding box of the INPUT rows (the one read-back of an insert); the per-block
+    // boxes are folded by all threads of this block — 2 NCOL columns x 256 / (2 NCOL) strided walkers, LDS atomics —:
+    // eight threads walking nb dependent loads each made this block the whole kernel's duration (15 of 17 us at 100k rows)
+    __shared__ int32_t s_bb[2 * (ME_MAX_DIM + 1)];
+    if (threadIdx.x < 2 * NCOL) s_bb[threadIdx.x] = threadIdx.x < NCOL ? INT32_MAX : INT32_MIN;
+    __syncthreads();
+    constexpr int kWalkers = 256 / (2 * NCOL);
+    const int d = threadIdx.x % (2 * NCOL), j0 = threadIdx.x / (2 * NCOL);
+    if (j0 < kWalkers) {
       int32_t r = d < NCOL ? INT32_MAX : INT32_MIN;
-      for (int b = 0; b < nb; ++b) {
+      for (int b = j0; b < nb; b += kWalkers) {
         const int32_t x = blk_bbox[(int64_t)b * 2 * NCOL + d];
         r = d < NCOL ? min(r, x) : max(r, x);
       }
-      reinterpret_cast<int32_t *>(total_and_bbox)[1 + d] = r;
+      if (d < NCOL) atomicMin(&s_bb[d], r);
+      else atomicMax(&s_bb[d], r);
     }
+    __syncthreads();
+    if (threadIdx.x == 0) total_and_bbox[0] = s_total;
+    if (threadIdx.x < 2 * NCOL) reinterpret_cast<int32_t *>(total_and_bbox)[1 + threadIdx.x] = s_bb[threadIdx.x];
   }
-  const int64_t base = (int64_t)blockIdx.x * kInsBlockRows;
-#pragma unroll 4
-  for (int j = 0; j < 16; ++j) {
-    const int64_t i = base + j * 256 + threadIdx.x;
-    if (i >= n) continue;
-    const uint32_t w = wrow[i];
-    const uint32_t grp = w >> 6;
-    const uint32_t id = s_base[w >> 12] + group_prefix[grp] +
-                        (uint32_t)__popcll(flagbits[grp] & ((1ull << (w & 63u)) - 1ull));
+  // (one row per thread, as many blocks as that takes: the ranks only need the scanned counts of the 1024-row blocks)
+  if (valid) {
+    const uint32_t id = s_base[w >> kInsBlockShift] + gp + (uint32_t)__popcll(fb & ((1ull << (w & 63u)) - 1ull));
     inverse_map[i] = (int64_t)id;
     if (w == (uint32_t)i) {
       unique_map[id] = i;
@@ -1408,7 +1413,7 @@ int me_coords_insert_and_map_bbox(const int32_t *coords, int64_t n, int32_t ncol
     ME_DISPATCH_NCOL(ncol, hipLaunchKernelGGL(k_insert_flags<NCOL>, bgrid, block, 0, stream, coords, table, slot_of_row, n,
                                               wrow, flagbits, group_prefix, blk_count, blk_bbox));
     ME_LAUNCH_CHECK();
-    ME_DISPATCH_NCOL(ncol, hipLaunchKernelGGL(k_insert_emit<NCOL>, bgrid, block, 0, stream, coords, n, table, slot_of_row,
+    ME_DISPATCH_NCOL(ncol, hipLaunchKernelGGL(k_insert_emit<NCOL>, grid, block, 0, stream, coords, n, table, slot_of_row,
                                               wrow, flagbits, group_prefix, blk_count, blk_bbox, (int)nb, coords_unique,
                                               unique_map, inverse_map, total));
     ME_LAUNCH_CHECK();
@@ -1443,11 +1448,21 @@ int me_coords_insert_and_map_bbox(const int32_t *coords, int64_t n, int32_t ncol
     for (int d = 0; d < 2 * ncol; ++d) bbox[d] = (int32_t)host_buf[1 + d];
   return 0;
   }
-  ME_HIP(hipMemcpyAsync(host_buf, total, (size_t)(1 + (bbox ? 2 * ncol : 0)) * 4, hipMemcpyDeviceToHost, stream));
-  ME_HIP(hipStreamSynchronize(stream));
-  *n_unique = (int64_t)host_buf[0];
-  if (bbox)
-    for (int d = 0; d < 2 * ncol; ++d) bbox[d] = (int32_t)host_buf[1 + d];
+  {
+    // the read-back lands in PINNED host memory (one small buffer per host thread, allocated once): a copy into pageable
+    // stack memory goes through the runtime's staging path and made the synchronisation below ~10 us longer
+    static thread_local uint32_t *pinned = nullptr;
+    if (pinned == nullptr && hipHostMalloc(reinterpret_cast<void **>(&pinned), 256, hipHostMallocDefault) != hipSuccess) {
+      pinned = nullptr;
+      (void)hipGetLastError();
+    }
+    uint32_t *dst = pinned != nullptr ? pinned : host_buf;
+    ME_HIP(hipMemcpyAsync(dst, total, (size_t)(1 + (bbox ? 2 * ncol : 0)) * 4, hipMemcpyDeviceToHost, stream));
+    ME_HIP(hipStreamSynchronize(stream));
+    *n_unique = (int64_t)dst[0];
+    if (bbox)
+      for (int d = 0; d < 2 * ncol; ++d) bbox[d] = (int32_t)dst[1 + d];
+  }
   return 0;
 }
 

@@ -606,7 +606,7 @@ const ConvCfg &KernelMap::conv_cfg(const std::string &target, int64_t n_tgt, int
   if (c.split_k > 1) c.fuse = false;
   if (auto lg = log.lock())
     lg->push_back("conv_cfg;" + log_key + ";" + target + ";" + std::to_string(c_src) + ";" + std::to_string(c_dst) + ";" +
-                  (bf16 ? "1" : "0"));
+                  (bf16 ? "1" : "0") + (no_rowwise ? ";p" : ""));   // (";p": the tile plan of a side that could run row-wise)
   return conv_cfgs.emplace(ck, std::move(c)).first->second;
 }
 
@@ -1144,7 +1144,7 @@ int64_t CoordinateMapManager::prefetch(const std::vector<std::string> &recipe) {
       if (f[0] == "conv_cfg") {
         const std::string target = f[9];
         km.conv_cfg(target, target == "out" ? km.n_out : km.n_in, std::atoi(f[10].c_str()), std::atoi(f[11].c_str()),
-                    f[12] == "1");
+                    f[12] == "1", f.size() >= 14 && f[13] == "p");
       } else {
         km.wgrad_cfg(std::atoi(f[9].c_str()), std::atoi(f[10].c_str()), f[11] == "1");
       }

@@ -50,6 +50,18 @@ case "$step" in
       python -c "import json; l=json.loads(open('gpurun_out/r06_unet_scenes_$sc.json').read().strip().splitlines()[-1]); print('unet $sc', l['ms_per_step'], l['value'])"
     done
     ;;
+  insert_prof)   # kernel statistics of insert_and_map (fused vs the scan pipeline)
+    for f in 1 0; do
+      (cd /tmp && export TMPDIR=/tmp && ME_INSERT_FUSED=$f timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ins$f -o ins -- python $GRAFT_REPO_ROOT/scripts/insert_prof.py 2>&1 | grep insert_and_map)
+      python3 - /tmp/prof_ins$f <<'PY'
+import csv, glob, sys
+for f in glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True):
+    for r in csv.reader(open(f)):
+        if len(r) >= 4 and r[0] != "Name":
+            print(r[0][:80].ljust(80), r[1].rjust(6), f"{float(r[3])/1e3:9.2f} us")
+PY
+    done
+    ;;
   sq)   # the counter-based MFMA utilisation pass of bench.py (headline + MinkUNet34C entry)
     timeout 900 python bench.py --cpu-budget 0 --pmc on > gpurun_out/r06_bench_sq.json 2> gpurun_out/r06_bench_sq.err
     tail -3 gpurun_out/r06_bench_sq.err

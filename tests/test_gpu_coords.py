@@ -52,11 +52,18 @@ def test_fused_insert_equals_the_resolve_scan_finalize_pipeline(device, n, exten
             MEB, mgr = _mgr()
             key, (um, inv) = mgr.insert_and_map(coords, [1] * D, "")
             cm = mgr._maps[mgr._k(key)]
-            res.append((um.clone(), inv.clone(), mgr.get_coordinates(key).clone(), cm.table.clone(), tuple(cm.bbox or ())))
+            # (the slot a key lands in depends on the race of the claims: the table is compared through its lookups)
+            rows = torch.empty(coords.shape[0], dtype=torch.int32, device=device)
+            with torch.cuda.device(device):
+                _lib.check(lib.me_coords_find(cm.table.data_ptr(), cm.capacity, cm.coords.data_ptr(), D + 1,
+                                              coords.data_ptr(), coords.shape[0], rows.data_ptr(), None))
+            torch.cuda.synchronize()
+            res.append((um.clone(), inv.clone(), mgr.get_coordinates(key).clone(), rows, tuple(cm.bbox or ())))
         finally:
             lib.me_debug_set_insert_fused(1)
     for a, b in zip(res[0][:4], res[1][:4]):
         assert torch.equal(a, b)
+    assert torch.equal(res[0][3].long(), res[0][1]), "a lookup of every input row must give its inverse-map entry"
     assert res[0][4] == res[1][4] and len(res[0][4]) == 2 * (D + 1)
     um_o, inv_o = O.insert_and_map(coords.cpu().numpy())
     assert np.array_equal(res[0][0].cpu().numpy(), um_o) and np.array_equal(res[0][1].cpu().numpy(), inv_o)
