@@ -421,7 +421,7 @@ int me_conv_target_bf16_ex(const uint16_t *src_feat_dev, int64_t n_src, int32_t 
  * count (the launch is sized by it; for such a side the pair count IS n_tgt).  The caller guarantees the one-pair-per-
  * row property (a row without a pair is not written, a row with two pairs is written twice).  Semantics of the tile-plan
  * launch: fp32 sums over the channels, one rounding to bf16.
- * me_conv_rowwise_supported_bf16: 1 when (volume <= 64, c_src % 8 == 0, c_dst % 4 == 0, W[k] of one 128-column slab
+ * me_conv_rowwise_supported_bf16: 1 when (volume <= 64, c_src % 8 == 0, c_dst % 8 == 0, W[k] of one 128-column slab
  * within 64 KB of LDS) the kernel takes the shape.
  * No batch-norm statistics epilogue: a layer whose statistics are wanted either stays on me_conv_target_bf16_stats or
  * is followed by the ordinary pass over its output (me_bn_stats). */

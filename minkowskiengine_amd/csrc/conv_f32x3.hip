@@ -791,27 +791,37 @@ static int launch_conv_tile_f32x3(const float *src, int c_src, const bf16x8 *wp,
   const bool exact = (c_src % KC) == 0;
   typedef void (*kernel_t)(const float *, int, const bf16x8 *, int, const int32_t *, const int32_t *, const int32_t *,
                            const int32_t *, const int32_t *, float *, int64_t, int, int);
-  kernel_t fn = small ? (exact ? &k_conv_tile_f32x3<NC, KC, true, true> : &k_conv_tile_f32x3<NC, KC, false, true>)
-                      : (exact ? &k_conv_tile_f32x3<NC, KC, true, false> : &k_conv_tile_f32x3<NC, KC, false, false>);
+#ifdef ME_DEBUG_VARIANTS
+  constexpr bool kHasPingPong = true;    // (tuning build: the round-2 ping-pong kernel for every shape, variants 30 / 256)
+#else
+  constexpr bool kHasPingPong = !(NC == 64 || NC == 128);   // shipped: only where no wave-specialised kernel exists
+#endif
+  kernel_t fn = nullptr;
+  if constexpr (kHasPingPong)
+    fn = small ? (exact ? &k_conv_tile_f32x3<NC, KC, true, true> : &k_conv_tile_f32x3<NC, KC, false, true>)
+               : (exact ? &k_conv_tile_f32x3<NC, KC, true, false> : &k_conv_tile_f32x3<NC, KC, false, false>);
   if constexpr (NC == 64 || NC == 128) {
     // default: the wave-specialised kernel; debug variant 30 = the ping-pong kernel, 256 = its phase counters,
-    // 257 = the wave-specialised kernel's phase counters
-    if (g_conv_variant != 30 && g_conv_variant != 256) {
+    // 257 = the wave-specialised kernel's phase counters (tuning build)
+    if (!kHasPingPong || (g_conv_variant != 30 && g_conv_variant != 256)) {
       kernel_t ws;
       int wi = (small ? 2 : 0) + (exact ? 1 : 0);
       int wthreads = 512;
       static bool ws_attr[20] = {};
       if constexpr (NC == 128) {
-        if (g_conv_variant != 31) {   // default: eight multiplier waves (variant 31: four)
+#ifdef ME_DEBUG_VARIANTS
+        if (g_conv_variant == 31) {   // (tuning build: four multiplier waves)
+          ws = small ? (exact ? &k_conv_tile_f32x3_ws<NC, KC, true, true> : &k_conv_tile_f32x3_ws<NC, KC, false, true>)
+                     : (exact ? &k_conv_tile_f32x3_ws<NC, KC, true, false> : &k_conv_tile_f32x3_ws<NC, KC, false, false>);
+        } else
+#endif
+        {   // eight multiplier waves
           ws = small ? (exact ? &k_conv_tile_f32x3_ws<NC, KC, true, true, false, 2, 0, 8>
                               : &k_conv_tile_f32x3_ws<NC, KC, false, true, false, 2, 0, 8>)
                      : (exact ? &k_conv_tile_f32x3_ws<NC, KC, true, false, false, 2, 0, 8>
                               : &k_conv_tile_f32x3_ws<NC, KC, false, false, false, 2, 0, 8>);
           wi += 13;
           wthreads = 768;
-        } else {
-          ws = small ? (exact ? &k_conv_tile_f32x3_ws<NC, KC, true, true> : &k_conv_tile_f32x3_ws<NC, KC, false, true>)
-                     : (exact ? &k_conv_tile_f32x3_ws<NC, KC, true, false> : &k_conv_tile_f32x3_ws<NC, KC, false, false>);
         }
       } else {
         ws = small ? (exact ? &k_conv_tile_f32x3_ws<NC, KC, true, true> : &k_conv_tile_f32x3_ws<NC, KC, false, true>)

@@ -19,8 +19,9 @@
 // the pair indices arrive two items ahead); the weights W[k] come from the layer's packed image (the tile kernels' own:
 // pack.hip), staged into LDS once per OFFSET the workgroup meets (coalesced 16-byte copies; conflict-free ds_read_b128
 // per fragment) and shared by the four waves.  No index window, no padding groups, no stage buffer, no accumulator in
-// LDS, no barrier inside an item.  Every output row is written once, by 8-byte stores from the accumulators (one rounding:
-// fp32 sums over the channels in ascending 32-channel steps -> bf16, RNE): the semantics of the tile-plan kernels.
+// LDS, no barrier inside an item.  Every output row is written once (one rounding: fp32 sums over the channels in ascending
+// 32-channel steps -> bf16, RNE: the semantics of the tile-plan kernels), as whole rows: the accumulators pass through a
+// wave-private LDS tile that turns "4 columns of 16 rows per lane group" into 16-byte pieces along the rows.
 //
 // Bound: HBM streaming (x rows in, output rows out, 8 bytes of indices per pair); the weights are L2 -> LDS traffic of
 // Cin x Cout x 2 bytes per 64 G pairs.
@@ -168,22 +169,31 @@ __global__ __launch_bounds__(256) void k_conv_rowwise_bf16(
       }
     }
 
-    // ---- epilogue: lane (i16, q) holds columns 16 cb + 4 q .. + 3 of row i16: one 8-byte store per block ----
-    bf16x4 y[G][NCB];
-#pragma unroll
-    for (int g = 0; g < G; ++g)
-#pragma unroll
-      for (int cb = 0; cb < NCB; ++cb)
-        y[g][cb] = bf16x4{(__bf16)acc[g][cb][0], (__bf16)acc[g][cb][1], (__bf16)acc[g][cb][2], (__bf16)acc[g][cb][3]};
+    // ---- epilogue: one rounding to bf16; lane (i16, q) holds columns 16 cb + 4 q .. + 3 of row i16.  The rows leave
+    // through a wave-private LDS tile (16 rows x NC columns, pitch + 16 bytes: 16-byte aligned pieces, the 8-byte writes of
+    // 16 rows x 4 quads at most two-way conflicting) as 16-BYTE pieces, consecutive lanes = consecutive
+    // pieces of a row: whole rows per store instead of 32-byte fragments of 16 different rows — straight 8-byte stores
+    // from the accumulators were 8.8 of the launch's 25 us on 200k x 128 -> 96 (scripts/rowwise_bench.py ablations) ----
+    constexpr int NC = NCB * 16, PITCH = NC * 2 + 16, PPR = NC / 8;    // bytes per tile row, 16-byte pieces per row
+    char *s_y = smem + (size_t)steps * NCB * 1024 + wave * (16 * PITCH);
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      if (trow[g] >= 0) {
-        __bf16 *o = dst + (int64_t)trow[g] * c_dst + cb0 * 16 + q * 4;
 #pragma unroll
-        for (int cb = 0; cb < NCB; ++cb)
-          if ((cb0 + cb) * 16 + q * 4 < c_dst)          // (c_dst % 4 == 0: a quad is inside the row or outside)
-            *reinterpret_cast<bf16x4 *>(o + cb * 16) = y[g][cb];
+      for (int cb = 0; cb < NCB; ++cb) {
+        const bf16x4 y = {(__bf16)acc[g][cb][0], (__bf16)acc[g][cb][1], (__bf16)acc[g][cb][2], (__bf16)acc[g][cb][3]};
+        *reinterpret_cast<bf16x4 *>(s_y + i16 * PITCH + (cb * 16 + q * 4) * 2) = y;
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < NC / 32; ++it) {
+        const int p = it * 64 + lane, row = p / PPR, c8 = p - row * PPR;
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(s_y + row * PITCH + c8 * 16);
+        const int32_t t = __shfl(trow[g], row, 64);       // (lane `row` = (i16 = row, q = 0) holds the row's target)
+        if (t >= 0 && (cb0 * 16 + c8 * 8) < c_dst)         // (c_dst % 8 == 0: a piece is inside the row or outside)
+          *reinterpret_cast<u32x4 *>(dst + (int64_t)t * c_dst + cb0 * 16 + c8 * 8) = v;
+      }
+      __builtin_amdgcn_wave_barrier();                    // (the tile is rewritten by the next group)
     }
     // ---- rotate: next item becomes current ----
     k_cur = k_nxt; e0_cur = e0_nxt; e1_cur = e1_nxt;
@@ -222,7 +232,7 @@ static RwGeom rowwise_geom(int64_t volume, int c_src, int c_dst, int64_t n_pairs
   r.steps = r.nchunks * r.ks;
   r.ncb = rowwise_ncb(c_dst);
   r.slabs = (int)ceil_div(r.ncb_total, r.ncb);
-  r.lds = r.steps * r.ncb * 1024;
+  r.lds = r.steps * r.ncb * 1024 + 4 * 16 * (r.ncb * 32 + 16);   // W[k] fragments + the four waves' output tiles
   // row groups per wave: 128-pair items where they still fill the chip a few times over, 64-pair items on small maps
   r.g = g_rw_groups ? g_rw_groups : (n_pairs_bound >= (int64_t)device_cu_count() * 4 * 128 ? 2 : 1);
   r.d = r.steps <= 2 ? 2 : 4;
@@ -246,10 +256,9 @@ extern "C" {
 
 void me_debug_set_rowwise_groups(int g) { g_rw_groups = (g == 1 || g == 2) ? g : 0; }
 
-// 1: the row-wise kernel takes a (c_src, c_dst, volume) launch — whole 16-byte pieces of a source row per lane, whole
-// 8-byte quads of an output row, the offsets within one wave's scan, W[k] of one column slab within 64 KB of LDS
+// 1: the row-wise kernel takes a (c_src, c_dst, volume) launch — whole 16-byte pieces of a source and of an output row, the offsets within one wave's scan, W[k] of one column slab within 64 KB of LDS
 int32_t me_conv_rowwise_supported_bf16(int64_t volume, int32_t c_src, int32_t c_dst) {
-  if (volume < 1 || volume > 64 || c_src < 8 || (c_src % 8) != 0 || c_dst < 4 || (c_dst % 4) != 0) return 0;
+  if (volume < 1 || volume > 64 || c_src < 8 || (c_src % 8) != 0 || c_dst < 8 || (c_dst % 8) != 0) return 0;
   const int kc = me_conv_pack_chunk_bf16(c_src, c_dst);
   if (kc < 32 || (kc % 32) != 0) return 0;
   const int64_t steps = ceil_div(c_src, kc) * (kc / 32);
@@ -266,7 +275,7 @@ int me_conv_rowwise_bf16(const uint16_t *src_feat_dev, int64_t n_src, int32_t c_
   if (n_pairs_bound == 0 || n_tgt == 0) return 0;
   ME_CHECK(src_feat_dev && packed_w_dev && src_rows_dev && tgt_rows_dev && k_offsets_dev && dst_feat_dev,
            "device pointers must not be null");
-  ME_CHECK((uintptr_t)src_feat_dev % 16 == 0 && (uintptr_t)dst_feat_dev % 8 == 0 && (uintptr_t)packed_w_dev % 16 == 0,
+  ME_CHECK((uintptr_t)src_feat_dev % 16 == 0 && (uintptr_t)dst_feat_dev % 16 == 0 && (uintptr_t)packed_w_dev % 16 == 0,
            "feature / weight pointers must be 16-byte aligned");
   const RwGeom r = rowwise_geom(volume, c_src, c_dst, n_pairs_bound);
   const int ks = r.ks, nchunks = r.nchunks, ncb_total = r.ncb_total, ncb = r.ncb, lds = r.lds, g = r.g;

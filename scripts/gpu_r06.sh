@@ -62,6 +62,14 @@ for f in glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True):
 PY
     done
     ;;
+  rowwise_bench)   # microbenchmark + ablations of the row-wise kernel
+    BASE=1 python scripts/rowwise_bench.py 2>&1 | grep -v amdgpu.ids
+    # (the ablations of round 6 — no stores 25.2 -> 16.4 us, no loads behind the first ring 20.6, no MFMAs 23.5 — needed a
+    # kernel argument that is not in the tree any more: profiles/r06_rowwise_bench.log)
+    for g in 1 2; do ME_AMD_RW_G=$g python scripts/rowwise_bench.py 2>&1 | grep -v amdgpu.ids; done
+    SHAPE=200000,96,96 python scripts/rowwise_bench.py 2>&1 | grep -v amdgpu.ids
+    SHAPE=80000,192,128 python scripts/rowwise_bench.py 2>&1 | grep -v amdgpu.ids
+    ;;
   sq)   # the counter-based MFMA utilisation pass of bench.py (headline + MinkUNet34C entry)
     timeout 900 python bench.py --cpu-budget 0 --pmc on > gpurun_out/r06_bench_sq.json 2> gpurun_out/r06_bench_sq.err
     tail -3 gpurun_out/r06_bench_sq.err

