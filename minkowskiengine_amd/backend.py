@@ -515,6 +515,11 @@ class KernelMapGPU:
         neighbour table is small enough for the plan builder's scattered reads."""
         if _TILE_ORDER != "auto":
             return _TILE_ORDER
+        if matrix_bound and self._store.get(self._name("order", target)) is None:
+            # Z-order tiles on row-space tables (csrc_host/manager.cpp KernelMap::tile_order: smaller source halos)
+            cmap = self.out_map if target == "out" else self.in_map
+            if cmap is not None and cmap.n > 0:
+                return "zorder"
         if matrix_bound or (_TILE_SPATIAL_MIN_SRC_BYTES > 0 and src_bytes >= _TILE_SPATIAL_MIN_SRC_BYTES):
             return "spatial"
         n_tgt = self.n_out if target == "out" else self.n_in
@@ -525,6 +530,8 @@ class KernelMapGPU:
         "spatial" tiles (None when that map has no spatial index: the tiles are then row tiles), the argsort of the
         Z-order keys with ME_AMD_SPATIAL_TILES=1 (round-1 experiment), else None."""
         cmap = self.out_map if target == "out" else self.in_map
+        if tile_order == "zorder" and cmap is not None and cmap.n > 0:
+            return cmap.zorder()
         if tile_order == "spatial" and cmap is not None and cmap.n > 0:
             sp = cmap.spatial()
             if sp is not None:
