@@ -64,7 +64,8 @@ typedef struct me_region {
  *              with at most 8 source channels (me_conv_stem_use_bf16, me_conv_stem_tile_rows, me_conv_stem_bf16)
  *   1.6 (160)  round 6: row-wise launches for kernel-map sides with exactly one pair per target row — K = 1 layers
  *              (the reference's `input.F.mm(kernel)`) and the fine side of kernel_size == stride maps
- *              (me_conv_rowwise_supported_bf16, me_conv_rowwise_bf16) */
+ *              (me_conv_rowwise_supported_bf16, me_conv_rowwise_bf16); Z-order of a map by the library's own radix sort
+ *              (me_coords_zorder) */
 int me_version(void);
 const char *me_last_error(void);
 /* Load the device code of every translation unit of the library now (needs a GPU; ABI 1.5): HIP loads a unit's code object
@@ -112,6 +113,14 @@ int me_coords_stride(const int32_t *coords_dev, int64_t n, int32_t ncol,
  * counterpart (the reference never reorders work); the row order of the maps is NOT changed. */
 int me_coords_spatial_keys(const int32_t *coords_dev, int64_t n, int32_t ncol,
                            const int32_t *tensor_stride /* host [ncol-1] */, int64_t *keys_dev, void *stream);
+/* Rows in Z-order (round 6): order_dev int32 [n] = the STABLE argsort of me_coords_spatial_keys' keys, by the library's
+ * own LSD radix sort (the reference sorts with thrust on its map path, src/coordinate_map_gpu.cu:766-772).  bbox: host
+ * ints [2 * ncol], column minima then maxima of the rows as me_coords_insert_and_map_bbox returns them, or NULL (then
+ * every key byte is sorted: eight passes instead of three for a 70^3 scene).  The tile plans of the fp32 kernels on
+ * row-space tables and the halo plans are cut from this order. */
+int64_t me_coords_zorder_workspace_bytes(int64_t n);
+int me_coords_zorder(const int32_t *coords_dev, int64_t n, int32_t ncol, const int32_t *tensor_stride,
+                     const int32_t *bbox, int32_t *order_dev, void *workspace_dev, int64_t workspace_bytes, void *stream);
 
 /* rows[q] = row of query q in the map, or -1.  Replaces CoordinateMapGPU::find
  * (src/coordinate_map_gpu.cu:284-361). */

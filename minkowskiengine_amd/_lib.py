@@ -91,6 +91,8 @@ SIGNATURES = {
     "me_kernel_map_transpose_ordered": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp]),
     "me_coords_stride": (ctypes.c_int, [c_vp, c_i64, c_i32, _P_I32, c_vp, c_vp]),
     "me_coords_spatial_keys": (ctypes.c_int, [c_vp, c_i64, c_i32, _P_I32, c_vp, c_vp]),
+    "me_coords_zorder_workspace_bytes": (c_i64, [c_i64]),
+    "me_coords_zorder": (ctypes.c_int, [c_vp, c_i64, c_i32, _P_I32, _P_I32, c_vp, c_vp, c_i64, c_vp]),
     "me_coords_find": (ctypes.c_int, [c_vp, c_i64, c_vp, c_i32, c_vp, c_i64, c_vp, c_vp]),
     "me_kernel_map_workspace_bytes": (c_i64, [c_i64, c_i64]),
     "me_kernel_map_probe": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, _P_REGION, c_vp, _P_I64, c_vp, c_vp,

@@ -298,12 +298,19 @@ class _CoordinateMapGPU:
         if self._zorder is None and self.n > 0:
             lib = _lib.load()
             dev = self.coords.device
-            keys = torch.empty(self.n, dtype=torch.int64, device=dev)
+            ncol = int(self.coords.shape[1])
             ts = (ctypes.c_int32 * len(self.tensor_stride))(*self.tensor_stride)
+            bb = None
+            if self.bbox is not None and len(self.bbox) == 2 * ncol:
+                bb = (ctypes.c_int32 * (2 * ncol))(*[int(v) for v in self.bbox])
+            order = torch.empty(self.n, dtype=torch.int32, device=dev)
+            ws = torch.empty(int(lib.me_coords_zorder_workspace_bytes(self.n)), dtype=torch.uint8, device=dev)
             with _on(dev):
-                _lib.check(lib.me_coords_spatial_keys(_ptr(self.coords), self.n, self.coords.shape[1], ts, _ptr(keys),
-                                                      _stream(dev)))
-                self._zorder = torch.argsort(keys, stable=True).to(torch.int32)
+                # the library's own radix sort over the key bytes that can differ inside the bounding box (round 6: no
+                # torch.argsort on the map path)
+                _lib.check(lib.me_coords_zorder(_ptr(self.coords), self.n, ncol, ts, bb, _ptr(order), _ptr(ws), ws.numel(),
+                                                _stream(dev)))
+            self._zorder = order
         return self._zorder
 
     def spatial(self):
@@ -543,14 +550,7 @@ class KernelMapGPU:
             if cmap is None or cmap.n == 0:
                 self._store[name] = None
             else:
-                lib = _lib.load()
-                dev = self.device
-                keys = torch.empty(cmap.n, dtype=torch.int64, device=dev)
-                ts = (ctypes.c_int32 * len(cmap.tensor_stride))(*cmap.tensor_stride)
-                with _on(dev):
-                    _lib.check(lib.me_coords_spatial_keys(_ptr(cmap.coords), cmap.n, cmap.coords.shape[1], ts,
-                                                          _ptr(keys), _stream(dev)))
-                self._store[name] = torch.argsort(keys, stable=True).to(torch.int32)
+                self._store[name] = cmap.zorder()       # (me_coords_zorder: the library's own sort)
         return self._store[name]
 
     @_ranged("me:tile_plan")

@@ -1023,7 +1023,8 @@ __global__ __launch_bounds__(256) void k_sp_directory(const uint32_t *__restrict
 
 // ---- stable LSD radix sort of (key, value) pairs, 8-bit digits ------------------------------------------------
 constexpr int kRsTile = 1024;   // elements per block in both passes
-__global__ __launch_bounds__(256) void k_rs_hist(const uint32_t *__restrict__ keys, int64_t n, int shift,
+template <typename K = uint32_t>
+__global__ __launch_bounds__(256) void k_rs_hist(const K *__restrict__ keys, int64_t n, int shift,
                                                 int64_t nblocks, uint32_t *__restrict__ hist) {
   __shared__ uint32_t s_h[256];
   s_h[threadIdx.x] = 0;
@@ -1032,7 +1033,7 @@ __global__ __launch_bounds__(256) void k_rs_hist(const uint32_t *__restrict__ ke
 #pragma unroll
   for (int j = 0; j < kRsTile / 256; ++j) {
     const int64_t e = base + j * 256 + threadIdx.x;
-    if (e < n) atomicAdd(&s_h[(keys[e] >> shift) & 255u], 1u);
+    if (e < n) atomicAdd(&s_h[(uint32_t)(keys[e] >> shift) & 255u], 1u);
   }
   __syncthreads();
   hist[(int64_t)threadIdx.x * nblocks + blockIdx.x] = s_h[threadIdx.x];   // digit-major: one scan gives all offsets
@@ -1040,10 +1041,12 @@ __global__ __launch_bounds__(256) void k_rs_hist(const uint32_t *__restrict__ ke
 
 // one wave per block walks its tile 64 elements at a time; inside a step the rank of an element among the
 // equal digits of lower lanes comes from eight ballots (match-any), across steps from a running count per digit
-__global__ __launch_bounds__(64) void k_rs_scatter(const uint32_t *__restrict__ keys_in,
+// (vals_in == nullptr: the values are the positions themselves — the first pass of an argsort)
+template <typename K = uint32_t>
+__global__ __launch_bounds__(64) void k_rs_scatter(const K *__restrict__ keys_in,
                                                   const uint32_t *__restrict__ vals_in, int64_t n, int shift,
                                                   int64_t nblocks, const uint32_t *__restrict__ offs,
-                                                  uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out) {
+                                                  K *__restrict__ keys_out, uint32_t *__restrict__ vals_out) {
   __shared__ uint32_t s_cnt[256];
   const int lane = threadIdx.x;
   for (int d = lane; d < 256; d += 64) s_cnt[d] = offs[(int64_t)d * nblocks + blockIdx.x];
@@ -1053,9 +1056,9 @@ __global__ __launch_bounds__(64) void k_rs_scatter(const uint32_t *__restrict__ 
   for (int r = 0; r < kRsTile / 64; ++r) {
     const int64_t e = base + r * 64 + lane;
     const bool valid = e < n;
-    const uint32_t key = valid ? keys_in[e] : 0u;
-    const uint32_t val = valid ? vals_in[e] : 0u;
-    const uint32_t d = (key >> shift) & 255u;
+    const K key = valid ? keys_in[e] : (K)0;
+    const uint32_t val = valid ? (vals_in != nullptr ? vals_in[e] : (uint32_t)e) : 0u;
+    const uint32_t d = (uint32_t)(key >> shift) & 255u;
     unsigned long long peers = __ballot(valid);
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
@@ -1356,6 +1359,8 @@ int64_t me_hash_capacity(int64_t n) {
   return cap;
 }
 
+static int64_t rs_blocks_fwd(int64_t n) { return ceil_div(n < 1 ? 1 : n, kRsTile); }   // blocks of the radix-sort passes
+
 // workspace layout of insert: slot_of_row[n] | wrow[n] | flag/newid[n] | total | scan ws
 static int64_t insert_ws_arrays(int64_t n) { return align_up(n * 4, 256) + 1024; }
 int g_insert_fused = 1;   // me_debug_set_insert_fused: 0 = the resolve / scan / finalize / bbox pipeline of rounds 1 - 5
@@ -1552,6 +1557,81 @@ int me_coords_spatial_keys(const int32_t *coords, int64_t n, int32_t ncol, const
   const dim3 grid((unsigned)ceil_div(n, 256)), block(256);
   ME_DISPATCH_NCOL(ncol, hipLaunchKernelGGL(k_spatial_keys<NCOL>, grid, block, 0, stream, coords, n, arg, bits, keys));
   ME_LAUNCH_CHECK();
+  return 0;
+}
+
+// Rows of a coordinate map in Z-order: the STABLE argsort of me_coords_spatial_keys' keys, by the library's own LSD radix
+// sort (round 6: the hosts called at::argsort — rocPRIM inside torch — here, on the plan build of the headline layer
+// since its tiles are Morton-ordered; the reference uses thrust on its map path, src/coordinate_map_gpu.cu:766-772).
+// Only the key bytes that can differ are sorted: with the bounding box of the rows (host ints, column minima then maxima,
+// as me_coords_insert_and_map_bbox returns them; NULL: unknown) the varying bits of every axis are known — an axis
+// whose biased values lo .. hi differ first at bit h varies in bits [0, h] — so a 70^3 scene takes three 8-bit passes
+// over the interleaved coordinate bits (+ one over the batch byte when there are several scenes) instead of eight.
+int64_t me_coords_zorder_workspace_bytes(int64_t n) {
+  if (n < 1) n = 1;
+  return 2 * align_up(n * 8, 256) + 2 * align_up(n * 4, 256) + align_up(256 * rs_blocks_fwd(n) * 4, 256) + 256 +
+         scan_workspace_bytes(256 * rs_blocks_fwd(n));
+}
+
+int me_coords_zorder(const int32_t *coords, int64_t n, int32_t ncol, const int32_t *tensor_stride, const int32_t *bbox,
+                     int32_t *order, void *workspace, int64_t workspace_bytes, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ME_CHECK(ncol >= 2 && ncol <= ME_MAX_DIM + 1, "invalid coordinate size");
+  ME_CHECK(n >= 0 && n < (1ll << 31), "number of rows must fit in int32");
+  if (n == 0) return 0;
+  ME_CHECK(order != nullptr && workspace != nullptr && workspace_bytes >= me_coords_zorder_workspace_bytes(n),
+           "order / workspace");
+  char *ws = reinterpret_cast<char *>(workspace);
+  const int64_t ksz = align_up(n * 8, 256), vsz = align_up(n * 4, 256);
+  uint64_t *keys[2] = {reinterpret_cast<uint64_t *>(ws), reinterpret_cast<uint64_t *>(ws + ksz)};
+  uint32_t *vbuf = reinterpret_cast<uint32_t *>(ws + 2 * ksz);            // the one value buffer besides `order`
+  const int64_t nblocks = rs_blocks_fwd(n);
+  uint32_t *hist = reinterpret_cast<uint32_t *>(ws + 2 * ksz + 2 * vsz);
+  uint32_t *hist_total = reinterpret_cast<uint32_t *>(ws + 2 * ksz + 2 * vsz + align_up(256 * nblocks * 4, 256));
+  void *scan_ws = reinterpret_cast<char *>(hist_total) + 256;
+  if (int rc = me_coords_spatial_keys(coords, n, ncol, tensor_stride, reinterpret_cast<int64_t *>(keys[0]), stream_)) return rc;
+  // key bytes to sort (me_coords_spatial_keys: bit b of axis d at position b * D + d, the batch index from bit 56)
+  const int D = ncol - 1;
+  int kbits = 56 / D;
+  if (kbits > 21) kbits = 21;
+  int span = kbits * D;                       // interleaved coordinate bits that may vary
+  bool batch_varies = true;
+  if (bbox != nullptr) {
+    const uint32_t bias = 1u << (kbits - 1), mask = (1u << kbits) - 1u;
+    int top = 0;
+    for (int d = 0; d < D; ++d) {
+      const int32_t ts = tensor_stride[d];
+      const int64_t lo = (int64_t)floor((double)bbox[1 + d] / ts), hi = (int64_t)floor((double)bbox[ncol + 1 + d] / ts);
+      if (hi - lo >= (int64_t)mask) { top = kbits; continue; }          // wraps around the key's range: every bit
+      const uint32_t a = ((uint32_t)lo + bias) & mask, b = ((uint32_t)hi + bias) & mask;
+      // values lo .. hi (consecutive integers, biased, no wrap when a <= b) agree above the highest bit where a and b differ
+      uint32_t x = a <= b ? (a ^ b) : mask;
+      int h = 0;
+      while (x) { ++h; x >>= 1; }
+      if (h > top) top = h;
+    }
+    span = top * D;
+    batch_varies = bbox[0] != bbox[ncol];
+  }
+  int shifts[9], np = 0;
+  for (int sft = 0; sft < span; sft += 8) shifts[np++] = sft;
+  if (batch_varies) shifts[np++] = 56;
+  if (np == 0) shifts[np++] = 0;              // (one row / all keys equal: one pass produces the identity order)
+  // the values ping-pong between `order` and vbuf so that the LAST pass lands in `order`
+  uint32_t *ord = reinterpret_cast<uint32_t *>(order);
+  int cur = 0;
+  for (int p = 0; p < np; ++p) {
+    uint32_t *v_out = ((np - 1 - p) % 2 == 0) ? ord : vbuf;
+    const uint32_t *v_in = p == 0 ? nullptr : (v_out == ord ? vbuf : ord);
+    hipLaunchKernelGGL(k_rs_hist<uint64_t>, dim3((unsigned)nblocks), dim3(256), 0, stream, keys[cur], n, shifts[p], nblocks, hist);
+    ME_LAUNCH_CHECK();
+    if (int rc = exclusive_scan_u32(hist, hist, 256 * nblocks, hist_total, scan_ws, scan_workspace_bytes(256 * nblocks), stream))
+      return rc;
+    hipLaunchKernelGGL(k_rs_scatter<uint64_t>, dim3((unsigned)nblocks), dim3(64), 0, stream, keys[cur], v_in, n, shifts[p],
+                       nblocks, hist, keys[cur ^ 1], v_out);
+    ME_LAUNCH_CHECK();
+    cur ^= 1;
+  }
   return 0;
 }
 
@@ -1821,7 +1901,7 @@ int64_t me_spatial_cells(const me_spatial_grid *g) {
   return m;
 }
 
-static int64_t rs_blocks(int64_t n) { return ceil_div(n < 1 ? 1 : n, kRsTile); }
+static int64_t rs_blocks(int64_t n) { return rs_blocks_fwd(n); }
 
 int64_t me_spatial_index_workspace_bytes(int64_t n, int64_t m) {
   if (n < 1) n = 1;
@@ -1863,12 +1943,12 @@ int me_spatial_index_build(const int32_t *coords, int64_t n, const me_spatial_gr
   while ((1ll << bits) < m) ++bits;
   int cur = 0;
   for (int shift = 0; shift < bits; shift += 8) {
-    hipLaunchKernelGGL(k_rs_hist, dim3((unsigned)nblocks), dim3(256), 0, stream, keys[cur], n, shift, nblocks, hist);
+    hipLaunchKernelGGL(k_rs_hist<uint32_t>, dim3((unsigned)nblocks), dim3(256), 0, stream, keys[cur], n, shift, nblocks, hist);
     ME_LAUNCH_CHECK();
     if (int rc = exclusive_scan_u32(hist, hist, 256 * nblocks, hist_total, scan_ws, scan_workspace_bytes(scan_items),
                                     stream))
       return rc;
-    hipLaunchKernelGGL(k_rs_scatter, dim3((unsigned)nblocks), dim3(64), 0, stream, keys[cur], vals[cur], n, shift,
+    hipLaunchKernelGGL(k_rs_scatter<uint32_t>, dim3((unsigned)nblocks), dim3(64), 0, stream, keys[cur], vals[cur], n, shift,
                        nblocks, hist, keys[cur ^ 1], vals[cur ^ 1]);
     ME_LAUNCH_CHECK();
     cur ^= 1;
@@ -2069,7 +2149,7 @@ int me_kernel_map_transpose_ordered(const int32_t *in_pairs, const int32_t *out_
 // unit's whole code object now instead of at the first launch from it
 extern "C" __attribute__((visibility("hidden"))) void me_preload_coords(void) {
   hipFuncAttributes attr;
-  (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&me::k_rs_hist));
+  (void)hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(&me::k_rs_hist<uint32_t>));
 }
 
 // Load every code object of the library now (ABI 1.5).  HIP loads a translation unit's device code when the first kernel

@@ -459,11 +459,17 @@ std::shared_ptr<Plan> KernelMap::plan(const std::string &target, int tile_rows, 
 Tensor CoordMap::zorder() {
   if (!zorder_rows.defined() && n > 0) {
     const c10::Device dev = coords.device();
-    Tensor keys = at::empty({n}, at::TensorOptions().dtype(at::kLong).device(dev));
+    const int32_t ncol = (int32_t)coords.size(1);
     std::vector<int32_t> ts(tensor_stride.begin(), tensor_stride.end());
+    std::vector<int32_t> bb(bbox.begin(), bbox.end());
+    Tensor order = empty_i32({n}, dev);
+    Tensor ws = workspace(me_coords_zorder_workspace_bytes(n), dev);
     c10::DeviceGuard guard(dev);
-    me_ok(me_coords_spatial_keys(ptr<int32_t>(coords), n, (int32_t)coords.size(1), ts.data(), ptr<int64_t>(keys), stream_of(dev)));
-    zorder_rows = at::argsort(keys, /*stable=*/true, /*dim=*/0, /*descending=*/false).to(at::kInt);
+    // (the library's own radix sort over the key bytes that can differ inside the map's bounding box: no torch sort on
+    // the map path — round 6)
+    me_ok(me_coords_zorder(ptr<int32_t>(coords), n, ncol, ts.data(), (int64_t)bb.size() == 2 * ncol ? bb.data() : nullptr,
+                           ptr<int32_t>(order), vptr(ws), ws.numel(), stream_of(dev)));
+    zorder_rows = order;
   }
   return zorder_rows;
 }

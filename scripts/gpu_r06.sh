@@ -70,6 +70,13 @@ PY
     SHAPE=200000,96,96 python scripts/rowwise_bench.py 2>&1 | grep -v amdgpu.ids
     SHAPE=80000,192,128 python scripts/rowwise_bench.py 2>&1 | grep -v amdgpu.ids
     ;;
+  fresh_prof)   # kernel statistics of the MinkUNet34C step with a new scene every step (recipe replay) and cached
+    for sc in fresh cached; do
+      (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$sc -o trace -- python $GRAFT_REPO_ROOT/bench.py --workload minkunet --dtype bf16 --scenes $sc $( [ $sc = fresh ] && echo --replay-maps ) --steps 16 --warmup 4 --min-time 0 --max-blocks 1 --cpu-budget 0 --pmc off --extra-workloads off --no-graph-probe --no-gpu-state > $GRAFT_REPO_ROOT/gpurun_out/r06_prof_bench_$sc.json 2> /dev/null)
+      find /tmp/prof_$sc -name "*kernel_stats*.csv" -exec cp {} gpurun_out/r06_rocprof_kernel_stats_minkunet34c_bf16_$sc.csv \;
+      python -c "import json; print('$sc', json.loads(open('gpurun_out/r06_prof_bench_$sc.json').read().strip().splitlines()[-1])['ms_per_step'])"
+    done
+    ;;
   sq)   # the counter-based MFMA utilisation pass of bench.py (headline + MinkUNet34C entry)
     timeout 900 python bench.py --cpu-budget 0 --pmc on > gpurun_out/r06_bench_sq.json 2> gpurun_out/r06_bench_sq.err
     tail -3 gpurun_out/r06_bench_sq.err
@@ -86,6 +93,25 @@ print("minkunet", w.get("ms_per_step"), "mfma_busy_frac", rr.get("mfma_busy_frac
 for k, v in (rr.get("mfma_busy_by_kernel") or {}).items():
     print("  ", k[:70], json.dumps(v))
 PY
+    ;;
+  final)   # closing session: GPU suite, smoke, the driver's bench command, kernel statistics of the default line and of the MinkUNet34C step
+    OUT=gpurun_out/r06_final; mkdir -p $OUT
+    timeout 2400 python -m pytest tests -m gpu -q 2>&1 | grep -v "^  File\|^Extension\|amdgpu.ids" | tail -8 > $OUT/pytest_gpu.log; cat $OUT/pytest_gpu.log
+    timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke OK')" 2>&1 | tail -3 | tee $OUT/smoke.log
+    timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; summ $OUT/bench_default.json
+    (cd /tmp && export TMPDIR=/tmp
+     timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_def -o default -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --cpu-budget 0 --extra-workloads off --pmc off > $GRAFT_REPO_ROOT/$OUT/prof_default.log 2>&1
+     timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_unet -o unet -- python $GRAFT_REPO_ROOT/bench.py --workload minkunet --dtype bf16 --steps 5 --warmup 3 --cpu-budget 0 --pmc off --min-time 0 --min-blocks 5 --max-blocks 5 --no-gpu-state --extra-workloads off > $GRAFT_REPO_ROOT/$OUT/prof_unet.log 2>&1)
+    cp $(find /tmp/prof_def -name "*kernel_stats.csv" | head -1) $OUT/rocprof_kernel_stats_default.csv
+    cp $(find /tmp/prof_unet -name "*kernel_stats.csv" | head -1) $OUT/rocprof_kernel_stats_minkunet34c_bf16_cached.csv
+    head -8 $OUT/rocprof_kernel_stats_default.csv | cut -c1-160
+    timeout 600 python scripts/unet_layers.py 2>&1 | grep -v amdgpu.ids > $OUT/layers_minkunet34c_bf16.log; head -12 $OUT/layers_minkunet34c_bf16.log
+    for mode in "cached" "fresh" "fresh --replay-maps" "pipelined"; do
+      timeout 300 python bench.py --workload minkunet --dtype bf16 --scenes $mode --steps 10 --warmup 3 --cpu-budget 0 --pmc off --no-gpu-state --no-graph-probe --extra-workloads off 2> /dev/null | tail -1 | python -c "
+import json, sys
+d = json.loads(sys.stdin.readline())
+print('scenes $mode', d.get('ms_per_step'), 'ms/step', d.get('timing', {}).get('blocks_ms_per_step'))" | tee -a $OUT/unet_scenes.log
+    done
     ;;
   *) echo "unknown step $step"; exit 1 ;;
 esac

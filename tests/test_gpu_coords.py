@@ -69,6 +69,36 @@ def test_fused_insert_equals_the_resolve_scan_finalize_pipeline(device, n, exten
     assert np.array_equal(res[0][0].cpu().numpy(), um_o) and np.array_equal(res[0][1].cpu().numpy(), inv_o)
 
 
+@pytest.mark.parametrize("n,extent,D,batch,ts,with_bbox", [(1, 4, 3, 1, 1, True), (5000, 12, 3, 1, 1, True), (60000, 70, 3, 2, 1, True),
+                                                            (20000, 300, 3, 3, 2, True), (9000, 8, 4, 2, 1, True),
+                                                            (4097, 1000, 2, 1, 4, True), (7000, 40, 3, 2, 1, False),
+                                                            (3000, 2000, 1, 1, 1, True)])
+def test_zorder_equals_the_stable_argsort_of_the_spatial_keys(device, n, extent, D, batch, ts, with_bbox):
+    """me_coords_zorder (round 6: the library's own LSD radix sort, only over the key bytes that can differ inside the
+    bounding box) = numpy's STABLE argsort of me_coords_spatial_keys' 64-bit keys, bit for bit — one pass, several,
+    negative coordinates, several scenes (the batch byte), tensor strides, no bounding box (all eight bytes)."""
+    from minkowskiengine_amd import _lib
+    lib = _lib.load()
+    coords = make_cloud(n, extent, D, seed=n + D, batch=batch, negative=True)
+    coords[:, 1:] *= ts
+    c = coords.to(device)
+    m = c.shape[0]
+    tsa = (ctypes.c_int32 * D)(*([ts] * D))
+    keys = torch.empty(m, dtype=torch.int64, device=device)
+    order = torch.empty(m, dtype=torch.int32, device=device)
+    ws = torch.empty(int(lib.me_coords_zorder_workspace_bytes(m)), dtype=torch.uint8, device=device)
+    cn = coords.numpy()
+    bb = None
+    if with_bbox:
+        bb = (ctypes.c_int32 * (2 * (D + 1)))(*([int(v) for v in cn.min(0)] + [int(v) for v in cn.max(0)]))
+    with torch.cuda.device(device):
+        _lib.check(lib.me_coords_spatial_keys(c.data_ptr(), m, D + 1, tsa, keys.data_ptr(), None))
+        _lib.check(lib.me_coords_zorder(c.data_ptr(), m, D + 1, tsa, bb, order.data_ptr(), ws.data_ptr(), ws.numel(), None))
+    torch.cuda.synchronize()
+    want = np.argsort(keys.cpu().numpy(), kind="stable")
+    assert np.array_equal(order.cpu().numpy(), want.astype(np.int32))
+
+
 def test_insert_all_duplicates_and_empty(device, host_layer):
     MEB, mgr = _mgr()
     coords = torch.IntTensor([[0, 1, 2, 3]] * 257).to(device)
