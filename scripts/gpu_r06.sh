@@ -77,6 +77,9 @@ PY
       python -c "import json; print('$sc', json.loads(open('gpurun_out/r06_prof_bench_$sc.json').read().strip().splitlines()[-1])['ms_per_step'])"
     done
     ;;
+  sq2)   # LDS / VALU / VMEM activity counters of the headline kernels (fractions of the wave cycles)
+    python scripts/sq_pass2.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r06_sq_pass2_${WL:-conv3d}_${DT:-f32}.log
+    ;;
   sq)   # the counter-based MFMA utilisation pass of bench.py (headline + MinkUNet34C entry)
     timeout 900 python bench.py --cpu-budget 0 --pmc on > gpurun_out/r06_bench_sq.json 2> gpurun_out/r06_bench_sq.err
     tail -3 gpurun_out/r06_bench_sq.err
