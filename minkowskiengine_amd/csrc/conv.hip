@@ -2877,7 +2877,7 @@ int32_t me_debug_variants_compiled(void) {
 
 // The default build holds the shipped kernels and the alternates whose results are VALID (the bit-identity tests
 // compare them): 6 = 64-bit gather addresses, 7 = no batch fusion, 9 = 32-wide passes for 96 channels, 30 / 31 =
-// ping-pong / four-multiplier split kernels.  Everything else (phase counters, timing ablations with invalid
+// ping-pong / four-multiplier split kernels.  Everything else (40 / 41 / 43: ring and persistent split kernels, phase counters, timing ablations with invalid
 // results, the LDS-DMA family) exists only in a -DME_DEBUG_VARIANTS build (scripts/) and is refused otherwise.
 int me_debug_set_conv_variant(int variant) {
 #ifndef ME_DEBUG_VARIANTS

@@ -758,6 +758,680 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void k_conv_tile_f32x3_ws(
   }
 }
 
+
+#ifdef ME_DEBUG_VARIANTS   // (measured, not adopted: profiles/r06_ring_persistent_ab.md; tuning build only)
+// =================================================================================================
+// free-running variant (round 6): k_conv_tile_f32x3_ring
+// =================================================================================================
+// Same plan, arithmetic, stage layout, multiplier batch step (consume_batch_ws) and epilogue as
+// k_conv_tile_f32x3_ws — outputs are bit-identical — but NO workgroup barrier inside the batch loop.  The barrier
+// per batch phase-locks the waves: both multipliers of a SIMD wait for the LDS at the same time, run their MFMAs
+// at the same time and store at the same time, and a batch costs max(produce, multiply) + the skew of twelve waves
+// (matrix pipe busy 0.36, waves parked 0.35 by counter).  Here the stage buffers form a ring of NS slots with two
+// LDS counters per slot: `full` (+1 per producer wave once its part of a batch is stored) and `free` (+1 per
+// multiplier wave once it has read the batch).  A producer wave writes batch b into slot b % NS as soon as the
+// NCW multipliers have released the slot's previous batch; a multiplier wave starts batch b as soon as the four
+// producers have published it.  Multipliers own disjoint accumulator columns and never wait for each other, so the
+// two of a SIMD drift apart and one's MFMAs cover the other's LDS round trips; producers run up to NS - 1 batches
+// ahead.  LDS operations of one wave execute in order, so a counter update issued behind a wave's stage stores /
+// operand reads is performed behind them.
+// (inline asm on the LDS byte address: through a generic pointer the poll became a flat load with `s_waitcnt vmcnt(0)`,
+// which drains the gathers and weight loads that are meant to stay in flight)
+__device__ __forceinline__ unsigned ring_addr(const int32_t *p) {
+  typedef __attribute__((address_space(3))) const char lds_char;
+  return (unsigned)(uintptr_t)(lds_char *)p;
+}
+__device__ __forceinline__ void ring_wait(unsigned flag_addr, int target) {
+  for (;;) {
+    int v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(flag_addr) : "memory");
+    if (__builtin_amdgcn_readfirstlane(v) >= target) break;
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+__device__ __forceinline__ void ring_signal(unsigned flag_addr, int lane) {
+  if (lane == 0) asm volatile("ds_add_u32 %0, %1" : : "v"(flag_addr), "v"(1) : "memory");
+}
+
+__host__ __device__ constexpr int conv_f32x3_ring_lds_bytes(int nc, int kc, int tile_rows, int ns) {
+  return (tile_rows + 1) * (nc + kAccPad) * 4 + ns * ME_MAX_BATCH_GROUPS * 16 * (3 * x3_stage_ld(kc) * 2 + 4) + 64;
+}
+
+template <int NC, int KC, bool EXACT, bool SMALL, int NCW, int NS>
+__global__ __launch_bounds__((NCW + 4) * 64, 1) void k_conv_tile_f32x3_ring(
+    const float *__restrict__ src, int c_src, const bf16x8 *__restrict__ wp, int c_dst,
+    const int32_t *__restrict__ plan_src, const int32_t *__restrict__ plan_dst,
+    const int32_t *__restrict__ batch_desc, const int32_t *__restrict__ tile_bptr,
+    const int32_t *__restrict__ order, float *__restrict__ dst, int64_t n_tgt, int tile_rows, int batch_groups) {
+  typedef int i32x2 __attribute__((ext_vector_type(2)));
+  typedef StageLayout<KC> SL;
+  static_assert(NC == 64 || NC == 128, "multiplier waves of 16 or 32 columns");
+  static_assert(NCW == 4 || (NCW == 8 && NC == 128), "four multiplier waves, or eight on a 128-column slab");
+  static_assert(NS == 2 || NS == 3, "ring of two or three stage slots");
+  constexpr int CB = NC / (16 * NCW);  // 16-column blocks per multiplier wave
+  constexpr int NTP = 256;             // producer threads (four waves)
+  constexpr int NT = NCW * 64 + NTP;   // threads
+  constexpr int LD = SL::kLd;
+  constexpr int ACC_LD = NC + kAccPad;
+  constexpr int KS = KC / 32;
+  constexpr int F8 = KC / 8;
+  constexpr int CAP = ME_MAX_BATCH_GROUPS * 16;
+  constexpr int ITER = (CAP * F8 + NTP - 1) / NTP;
+  constexpr int PLANE = CAP * LD;
+  (void)batch_groups;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float *s_acc = reinterpret_cast<float *>(smem);                              // [(tile_rows + 1) x ACC_LD]
+  __bf16 *s_a = reinterpret_cast<__bf16 *>(s_acc + (tile_rows + 1) * ACC_LD);  // [NS][3][64 x LD]
+  int32_t *s_dst = reinterpret_cast<int32_t *>(s_a + NS * 3 * PLANE);          // [NS][64]
+  int32_t *s_full = s_dst + NS * CAP;                                          // [NS] producer waves that published
+  int32_t *s_free = s_full + 4;                                                // [NS] multiplier waves that released
+  const unsigned full_addr = ring_addr(s_full), free_addr = ring_addr(s_free);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15;
+  const int q = lane >> 4;
+  const int tile = tile_bptr[gridDim.x + 1 + blockIdx.x];   // heaviest-first dispatch order (me_plan_build)
+  const int col_base = blockIdx.y * NC;
+  const int nchunks = (c_src + KC - 1) / KC;
+  const int ncb = (c_dst + 15) / 16;
+
+  for (int x = tid; x < (tile_rows + 1) * ACC_LD / 4; x += NT)
+    reinterpret_cast<f32x4 *>(s_acc)[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (tid < 8) s_full[tid] = 0;
+  constexpr int ORD = (ME_MAX_TILE_ROWS + NT - 1) / NT;
+  int32_t my_ord[ORD];
+#pragma unroll
+  for (int j = 0; j < ORD; ++j) {
+    const int r = j * NT + tid;
+    my_ord[j] = (order != nullptr && r < tile_rows && (int64_t)tile * tile_rows + r < n_tgt)
+                    ? order[(int64_t)tile * tile_rows + r] : 0;
+  }
+
+  const int b0 = tile_bptr[tile];
+  const int nb = tile_bptr[tile + 1] - b0;
+  const int n_it = nb * nchunks;
+  struct Desc {
+    int chunk, g0, ng, k;
+  };
+  auto locate = [&](int it) {
+    int r = min(it, n_it - 1);
+    Desc d;
+    d.chunk = 0;
+    while (r >= nb) {
+      r -= nb;
+      ++d.chunk;
+    }
+    const i32x2 v = *reinterpret_cast<const i32x2 *>(batch_desc + 2 * (int64_t)(b0 + r));
+    d.g0 = v.x;
+    d.ng = v.y & 255;
+    d.k = (int)((uint32_t)v.y >> 8);
+    return d;
+  };
+
+  if (n_it > 0 && wave >= NCW) {
+    // ------------------------------------------------ producer waves ------------------------------------------------
+    const int ptid = tid - NCW * 64;
+    f32x4 stage[2][ITER][2];
+    int32_t dstv[2] = {tile_rows, tile_rows};
+    int32_t sidx[2][ITER];
+    auto load_sidx = [&](const Desc &d, int32_t (&sx)[ITER]) {
+      const char *pb = reinterpret_cast<const char *>(plan_src + (int64_t)d.g0 * 16);
+#pragma unroll
+      for (int j = 0; j < ITER; ++j)
+        sx[j] = *reinterpret_cast<const int32_t *>(pb + (unsigned)(min((j * NTP + ptid) / F8, CAP - 1) * 4));
+    };
+    const char *srcb = reinterpret_cast<const char *>(src);
+    const unsigned row_bytes = (unsigned)c_src * 4u;
+    auto gather = [&](const Desc &d, const int32_t (&sx)[ITER], f32x4 (&st)[ITER][2], int32_t &dv) {
+      const int c0 = d.chunk * KC;
+      dv = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(plan_dst + (int64_t)d.g0 * 16) +
+                                             (unsigned)(min(ptid, CAP - 1) * 4));
+#pragma unroll
+      for (int j = 0; j < ITER; ++j) {
+        const int ch = c0 + ((j * NTP + ptid) % F8) * 8;
+        const int chl = EXACT ? ch : min(ch, c_src - 8);
+        const int sr = max(sx[j], 0);
+        const f32x4 *p;
+        if (SMALL) p = reinterpret_cast<const f32x4 *>(srcb + (__umul24((unsigned)sr, row_bytes) + (unsigned)chl * 4u));
+        else p = reinterpret_cast<const f32x4 *>(src + (int64_t)sr * c_src + chl);
+        st[j][0] = p[0];
+        st[j][1] = p[1];
+      }
+    };
+    auto write_stage = [&](const Desc &d, const f32x4 (&st)[ITER][2], int32_t dv, int slot) {
+      const int c0 = d.chunk * KC;
+      __bf16 *base = s_a + slot * 3 * PLANE;
+      uint32_t flag = 0u;      // non-finite rows: conv_common.hpp (split3_flag / split3_fix)
+#pragma unroll
+      for (int j = 0; j < ITER; ++j) {
+        const int idx = j * NTP + ptid;
+        const int r = idx / F8;
+        const int ch = c0 + (idx % F8) * 8;
+        u32x4 p1, p2, p3;
+        split3_raw(st[j][0], st[j][1], p1, p2, p3);
+        flag = split3_flag(flag, p3);
+        if (!EXACT && ch >= c_src) p1 = p2 = p3 = u32x4{0u, 0u, 0u, 0u};
+        if (ITER * NTP == CAP * F8 || r < CAP) {
+          __bf16 *o = base + SL::off(r, idx % F8);
+          *reinterpret_cast<u32x4 *>(o) = p1;
+          *reinterpret_cast<u32x4 *>(o + PLANE) = p2;
+          *reinterpret_cast<u32x4 *>(o + 2 * PLANE) = p3;
+        }
+      }
+      if (__builtin_expect(__any(split3_suspect(flag)), 0)) {   // rare: split again, exactly, over the first attempt
+#pragma unroll
+        for (int j = 0; j < ITER; ++j) {
+          const int idx = j * NTP + ptid;
+          const int r = idx / F8;
+          const int ch = c0 + (idx % F8) * 8;
+          u32x4 p1, p2, p3;
+          split3_fix(st[j][0], st[j][1], p1, p2, p3);
+          if (!EXACT && ch >= c_src) p1 = p2 = p3 = u32x4{0u, 0u, 0u, 0u};
+          if (ITER * NTP == CAP * F8 || r < CAP) {
+            __bf16 *o = base + SL::off(r, idx % F8);
+            *reinterpret_cast<u32x4 *>(o) = p1;
+            *reinterpret_cast<u32x4 *>(o + PLANE) = p2;
+            *reinterpret_cast<u32x4 *>(o + 2 * PLANE) = p3;
+          }
+        }
+      }
+      if (ptid < CAP) s_dst[slot * CAP + ptid] = dv;
+    };
+    Desc dA = locate(0), dB = locate(1), dC = locate(2), dD = locate(3);
+    load_sidx(dA, sidx[0]);
+    load_sidx(dB, sidx[1]);
+    gather(dA, sidx[0], stage[0], dstv[0]);
+    gather(dB, sidx[1], stage[1], dstv[1]);
+    load_sidx(dC, sidx[0]);
+    __syncthreads();                      // accumulator tile and counters are zero
+    int slot = 0, round = 0;
+    // batch b: wait for its slot, split + store it, publish; then request the indices of batch b + 3 and the rows of
+    // batch b + 2 (register slot = batch parity, as in k_conv_tile_f32x3_ws)
+    auto iteration = [&](int b, f32x4 (&st)[ITER][2], int32_t &dv, int32_t (&sx_nx)[ITER], int32_t (&sx_cu)[ITER]) {
+      if (round > 0) ring_wait(free_addr + 4u * slot, NCW * round);
+      write_stage(dA, st, dv, slot);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      ring_signal(full_addr + 4u * slot, lane);
+      load_sidx(dD, sx_cu);
+      gather(dC, sx_nx, st, dv);
+      dA = dB; dB = dC; dC = dD;
+      dD = locate(b + 4);
+      if (++slot == NS) {
+        slot = 0;
+        ++round;
+      }
+    };
+    int b = 0;
+    for (; b + 1 < n_it; b += 2) {
+      iteration(b, stage[0], dstv[0], sidx[0], sidx[1]);
+      iteration(b + 1, stage[1], dstv[1], sidx[1], sidx[0]);
+    }
+    if (b < n_it) iteration(b, stage[0], dstv[0], sidx[0], sidx[1]);
+  } else if (n_it > 0) {
+    // ----------------------------------------------- multiplier waves -----------------------------------------------
+    __builtin_amdgcn_s_setprio(2);
+    const int cbi0 = col_base / 16 + wave * CB;
+    bf16x8 w[2][CB][3][KS];
+    auto load_w = [&](const Desc &d, bf16x8 (&wd)[CB][3][KS]) {
+#pragma unroll
+      for (int c = 0; c < CB; ++c) {
+        const bf16x8 *p = wp + (((((int64_t)d.k * nchunks + d.chunk) * ncb + min(cbi0 + c, ncb - 1)) * 3) * KS) * 64 + lane;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+          for (int v = 0; v < KS; ++v) wd[c][pl][v] = p[(pl * KS + v) * 64];
+        }
+      }
+    };
+    int pofs[KS];
+#pragma unroll
+    for (int sx = 0; sx < KS; ++sx) pofs[sx] = ((sx * 4 + q) ^ SL::swz(i16)) * 8;
+    auto multiply = [&](const Desc &d, const bf16x8 (&wc)[CB][3][KS], int slot, auto &&next_w) {
+      const __bf16 *rowp = s_a + slot * 3 * PLANE + i16 * LD;
+      const int32_t *dstp = s_dst + slot * CAP + i16;
+      float *accp = &s_acc[wave * CB * 16 + q * 4];
+      if (d.ng >= 4) consume_batch_ws<2, 2, CB, KC, 3, 0>(rowp, pofs, wc, dstp, accp, ACC_LD, next_w);
+      else if (d.ng == 3) consume_batch_ws<2, 1, CB, KC, 3, 0>(rowp, pofs, wc, dstp, accp, ACC_LD, next_w);
+      else if (d.ng == 2) consume_batch_ws<2, 0, CB, KC, 3, 0>(rowp, pofs, wc, dstp, accp, ACC_LD, next_w);
+      else consume_batch_ws<1, 0, CB, KC, 3, 0>(rowp, pofs, wc, dstp, accp, ACC_LD, next_w);
+    };
+    Desc dA = locate(0), dB = locate(1);
+    load_w(dA, w[0]);
+    __syncthreads();                      // accumulator tile and counters are zero
+    int slot = 0, round = 0;
+    auto iteration = [&](int b, bf16x8 (&w_cu)[CB][3][KS], bf16x8 (&w_nx)[CB][3][KS]) {
+      ring_wait(full_addr + 4u * slot, 4 * (round + 1));
+      multiply(dA, w_cu, slot, [&]() { load_w(dB, w_nx); });
+      ring_signal(free_addr + 4u * slot, lane);
+      dA = dB;
+      dB = locate(b + 2);
+      if (++slot == NS) {
+        slot = 0;
+        ++round;
+      }
+    };
+    int b = 0;
+    for (; b + 1 < n_it; b += 2) {
+      iteration(b, w[0], w[1]);
+      iteration(b + 1, w[1], w[0]);
+    }
+    if (b < n_it) iteration(b, w[0], w[1]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  } else {
+    __syncthreads();
+  }
+  __syncthreads();                        // every multiplier has added its last batch
+
+  // every target row of the tile is written exactly once (rows without neighbours get zeros)
+  const int64_t row0 = (int64_t)tile * tile_rows;
+  const int rows_here = (int)min((int64_t)tile_rows, n_tgt - row0);
+  const bool vec_out = (c_dst % 4) == 0;
+  int32_t *s_ord = reinterpret_cast<int32_t *>(s_a);   // the stage buffers are free now
+  if (order != nullptr) {
+#pragma unroll
+    for (int j = 0; j < ORD; ++j)
+      if (j * NT + tid < tile_rows) s_ord[j * NT + tid] = my_ord[j];
+    __syncthreads();
+  }
+  for (int x = tid; x < tile_rows * NC / 4; x += NT) {
+    const int row = x / (NC / 4);
+    const int c4 = x % (NC / 4);
+    const int cc = col_base + c4 * 4;
+    if (row < rows_here && cc < c_dst) {
+      const f32x4 v = *reinterpret_cast<const f32x4 *>(&s_acc[row * ACC_LD + c4 * 4]);
+      const int64_t grow = order ? (int64_t)s_ord[row] : row0 + row;
+      float *o = dst + grow * c_dst + cc;
+      if (vec_out) {
+        *reinterpret_cast<f32x4 *>(o) = v;
+      } else {
+        o[0] = v.x;
+        if (cc + 1 < c_dst) o[1] = v.y;
+        if (cc + 2 < c_dst) o[2] = v.z;
+        if (cc + 3 < c_dst) o[3] = v.w;
+      }
+    }
+  }
+}
+
+
+// =================================================================================================
+// persistent variant (round 6): k_conv_tile_f32x3_pers — tiles stream through ONE resident workgroup per CU
+// =================================================================================================
+// k_conv_tile_f32x3_ws holds one workgroup per CU (LDS), so every tile's prologue (zero fill, the dependent chain tile ->
+// batch descriptors -> pair indices -> rows: three memory round trips) and epilogue (the accumulator tile to global
+// memory, with every CU storing at the same moment) run with the matrix pipes idle: 5.8 of 27 us per tile by the phase
+// counters (profiles/r04_ws_phase_timing.log).  Here a workgroup takes the tiles wg, wg + G, wg + 2 G, ... of the
+// heaviest-first order (G = workgroups of the launch) as ONE stream of batches through the ring of
+// k_conv_tile_f32x3_ring (two stage slots, full / free counters, no barrier), with TWO accumulator tiles: while the
+// multipliers add tile s + 1 into one, the producer waves store tile s from the other (each wave its own rows, then
+// zeros) as soon as the last multiplier has signalled it (`done`), and hand it back (`afree`) for tile s + 2.
+// Only the producers walk the plan: a slot carries a header {groups, first / last / end flags, offset and chunk of the
+// NEXT batch} from which a multiplier requests its weights one batch ahead.  Same plan, same sums in the same order:
+// outputs are bit-identical to k_conv_tile_f32x3_ws.
+// Every vector-memory load of the batch loop is unconditional (hipcc's counted `s_waitcnt vmcnt` keeps the younger
+// gathers in flight only then; a first version with loads inside the tile roll-over ran at vmcnt(0): 2.2x slower): the
+// workgroup's tiles {id, first batch, batches} sit in an LDS table filled before the loop, a row's output position is
+// requested with every batch, the source-channel chunk of a batch is found without a loop (<= 4 chunks, host-checked).
+constexpr int kPersMaxTiles = 192;   // tiles per workgroup the LDS table holds (host-checked)
+constexpr int kPersMaxRows = 128;    // tallest tile
+__host__ __device__ constexpr int conv_f32x3_pers_lds_bytes(int nc, int kc, int tile_rows) {
+  return 2 * (tile_rows + 1) * (nc + kAccPad) * 4 + 2 * ME_MAX_BATCH_GROUPS * 16 * (3 * x3_stage_ld(kc) * 2 + 4) +
+         3 * 16 + 64 + 2 * kPersMaxRows * 4 + kPersMaxTiles * 16;
+}
+__device__ __forceinline__ void lds_read4(unsigned addr, int &a, int &b, int &c, int &d) {
+  typedef int i32x4_ __attribute__((ext_vector_type(4)));
+  i32x4_ v;
+  asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+  a = __builtin_amdgcn_readfirstlane(v.x);
+  b = __builtin_amdgcn_readfirstlane(v.y);
+  c = __builtin_amdgcn_readfirstlane(v.z);
+  d = __builtin_amdgcn_readfirstlane(v.w);
+}
+__device__ __forceinline__ void lds_write4(unsigned addr, int a, int b, int c, int d) {
+  typedef int i32x4_ __attribute__((ext_vector_type(4)));
+  const i32x4_ v = {a, b, c, d};
+  asm volatile("ds_write_b128 %0, %1" : : "v"(addr), "v"(v) : "memory");
+}
+
+template <int NC, int KC, int NCW>
+__global__ __launch_bounds__((NCW + 4) * 64, 1) void k_conv_tile_f32x3_pers(
+    const float *__restrict__ src, int c_src, const bf16x8 *__restrict__ wp, int c_dst,
+    const int32_t *__restrict__ plan_src, const int32_t *__restrict__ plan_dst,
+    const int32_t *__restrict__ batch_desc, const int32_t *__restrict__ tile_bptr,
+    const int32_t *__restrict__ order, float *__restrict__ dst, int64_t n_tgt, int tile_rows, int n_tiles) {
+  typedef int i32x2 __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(3))) float lds_f32;
+  typedef __attribute__((address_space(3))) int32_t lds_i32;
+  typedef StageLayout<KC> SL;
+  static_assert(NC == 64 || NC == 128, "multiplier waves of 16 or 32 columns");
+  static_assert(NCW == 4 || (NCW == 8 && NC == 128), "four multiplier waves, or eight on a 128-column slab");
+  constexpr int NS = 2;
+  constexpr int CB = NC / (16 * NCW);  // 16-column blocks per multiplier wave
+  constexpr int NTP = 256;             // producer threads (four waves)
+  constexpr int NT = NCW * 64 + NTP;   // threads
+  constexpr int LD = SL::kLd;
+  constexpr int ACC_LD = NC + kAccPad;
+  constexpr int KS = KC / 32;
+  constexpr int F8 = KC / 8;
+  constexpr int CAP = ME_MAX_BATCH_GROUPS * 16;
+  constexpr int ITER = (CAP * F8 + NTP - 1) / NTP;
+  constexpr int PLANE = CAP * LD;
+  constexpr int EPN = ((kPersMaxRows / 4 + 1) * (NC / 4) + 63) / 64;   // 16-byte pieces of a tile per producer lane
+  constexpr int F_FIRST = 1, F_LAST = 2, F_END = 4;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int acc_tile = (tile_rows + 1) * ACC_LD;                               // floats of one accumulator tile
+  float *s_acc = reinterpret_cast<float *>(smem);                              // [2][(tile_rows + 1) x ACC_LD]
+  __bf16 *s_a = reinterpret_cast<__bf16 *>(s_acc + 2 * acc_tile);              // [NS][3][64 x LD]
+  int32_t *s_dst = reinterpret_cast<int32_t *>(s_a + NS * 3 * PLANE);          // [NS][64]
+  int32_t *s_hdr = s_dst + NS * CAP;    // [NS + 1][4]: slot headers; [NS] = offset / chunk of the stream's first batch
+  int32_t *s_flag = s_hdr + 3 * 4;      // [0..1] full, [4..5] free (stage slots); [8..9] done, [12..13] afree; [15] init
+  int32_t *s_ord = s_flag + 16;         // [2][kPersMaxRows] output rows of an accumulator tile's rows
+  int32_t *s_tiles = s_ord + 2 * kPersMaxRows;   // [kPersMaxTiles][4] this workgroup's tiles {id, first batch, batches}
+  const unsigned full_addr = ring_addr(s_flag), free_addr = ring_addr(s_flag + 4);
+  const unsigned done_addr = ring_addr(s_flag + 8), afree_addr = ring_addr(s_flag + 12), init_addr = ring_addr(s_flag + 15);
+  const unsigned hdr_addr = ring_addr(s_hdr), tiles_addr = ring_addr(s_tiles);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int i16 = lane & 15;
+  const int q = lane >> 4;
+  const int wg = blockIdx.x, G = gridDim.x;
+  const int n_my = (n_tiles - wg + G - 1) / G;   // tiles of this workgroup (G <= n_tiles: at least one)
+  const int col_base = blockIdx.y * NC;
+  const int nchunks = c_src / KC;
+  const int ncb = (c_dst + 15) / 16;
+
+  for (int x = tid; x < 2 * acc_tile / 4; x += NT)
+    reinterpret_cast<f32x4 *>(s_acc)[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (tid < 16) s_flag[tid] = 0;
+  for (int i = tid; i < n_my; i += NT) {
+    const int tile = tile_bptr[n_tiles + 1 + wg + i * G];   // heaviest-first dispatch order (me_plan_build)
+    const int b0 = tile_bptr[tile];
+    s_tiles[4 * i + 0] = tile;
+    s_tiles[4 * i + 1] = b0;
+    s_tiles[4 * i + 2] = tile_bptr[tile + 1] - b0;
+    s_tiles[4 * i + 3] = 0;
+  }
+  __syncthreads();                        // accumulator tiles, counters and the tile table are in place
+
+  if (wave >= NCW) {
+    // ------------------------------------------------ producer waves ------------------------------------------------
+    const int ptid = tid - NCW * 64;
+    const int pw = wave - NCW;
+    struct Desc {
+      int chunk, g0, ng, k;
+      int seq, tile;          // running tile number of this workgroup (accumulator tile = seq & 1), tile id
+      bool first, last, valid;
+    };
+    // the workgroup's batch stream: tiles in dispatch order, batches (x chunks) of a tile in plan order; past the end the
+    // last batch again with valid = false (requested, never staged)
+    int g_s = 0, g_it = 0, g_tile, g_b0, g_nb, g_nit;
+    {
+      int pad;
+      lds_read4(tiles_addr, g_tile, g_b0, g_nb, pad);
+      g_nit = max(g_nb * nchunks, 1);     // (a tile without pairs is one empty batch: its rows are written as zeros)
+    }
+    auto next = [&]() __attribute__((always_inline)) {
+      if (g_it >= g_nit && g_s + 1 < n_my) {
+        ++g_s;
+        int pad;
+        lds_read4(tiles_addr + 16u * g_s, g_tile, g_b0, g_nb, pad);
+        g_nit = max(g_nb * nchunks, 1);
+        g_it = 0;
+      }
+      Desc d;
+      d.seq = g_s;
+      d.tile = g_tile;
+      d.valid = g_it < g_nit;
+      const int it = min(g_it, g_nit - 1);
+      d.first = it == 0;
+      d.last = it == g_nit - 1;
+      d.chunk = (it >= g_nb ? 1 : 0) + (it >= 2 * g_nb ? 1 : 0) + (it >= 3 * g_nb ? 1 : 0);
+      d.g0 = 0;
+      d.ng = 0;
+      d.k = 0;
+      if (g_nb > 0) {
+        const i32x2 v = *reinterpret_cast<const i32x2 *>(batch_desc + 2 * (int64_t)(g_b0 + it - d.chunk * g_nb));
+        d.g0 = v.x;
+        d.ng = v.y & 255;
+        d.k = (int)((uint32_t)v.y >> 8);
+      } else {
+        d.chunk = 0;
+      }
+      ++g_it;
+      return d;
+    };
+    f32x4 stage[2][ITER][2];
+    int32_t dstv[2] = {tile_rows, tile_rows};
+    int32_t sidx[2][ITER];
+    int32_t ordv[2];
+    auto load_sidx = [&](const Desc &d, int32_t (&sx)[ITER]) {
+      const char *pb = reinterpret_cast<const char *>(plan_src + (int64_t)d.g0 * 16);
+#pragma unroll
+      for (int j = 0; j < ITER; ++j)
+        sx[j] = *reinterpret_cast<const int32_t *>(pb + (unsigned)(min((j * NTP + ptid) / F8, CAP - 1) * 4));
+    };
+    const char *srcb = reinterpret_cast<const char *>(src);
+    const unsigned row_bytes = (unsigned)c_src * 4u;
+    // lane l of producer wave pw requests the output row of tile row 4 l + pw (the wave stores the rows = pw mod 4)
+    const int my_row = min(4 * (lane & 31) + pw, tile_rows - 1);
+    auto gather = [&](const Desc &d, const int32_t (&sx)[ITER], f32x4 (&st)[ITER][2], int32_t &dv, int32_t &ov) {
+      const int c0 = d.chunk * KC;
+      dv = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(plan_dst + (int64_t)d.g0 * 16) +
+                                             (unsigned)(min(ptid, CAP - 1) * 4));
+      const int64_t orow = min((int64_t)d.tile * tile_rows + my_row, n_tgt - 1);
+      ov = order != nullptr ? order[orow] : plan_dst[0];
+      if (order == nullptr) ov = (int32_t)orow;
+#pragma unroll
+      for (int j = 0; j < ITER; ++j) {
+        const int ch = c0 + ((j * NTP + ptid) % F8) * 8;
+        const int sr = max(sx[j], 0);
+        const f32x4 *p = reinterpret_cast<const f32x4 *>(srcb + (__umul24((unsigned)sr, row_bytes) + (unsigned)ch * 4u));
+        st[j][0] = p[0];
+        st[j][1] = p[1];
+      }
+    };
+    auto write_stage = [&](const f32x4 (&st)[ITER][2], int32_t dv, int slot) {
+      __bf16 *base = s_a + slot * 3 * PLANE;
+      uint32_t flag = 0u;      // non-finite rows: conv_common.hpp (split3_flag / split3_fix)
+#pragma unroll
+      for (int j = 0; j < ITER; ++j) {
+        const int idx = j * NTP + ptid;
+        const int r = idx / F8;
+        u32x4 p1, p2, p3;
+        split3_raw(st[j][0], st[j][1], p1, p2, p3);
+        flag = split3_flag(flag, p3);
+        if (ITER * NTP == CAP * F8 || r < CAP) {
+          __bf16 *o = base + SL::off(r, idx % F8);
+          *reinterpret_cast<u32x4 *>(o) = p1;
+          *reinterpret_cast<u32x4 *>(o + PLANE) = p2;
+          *reinterpret_cast<u32x4 *>(o + 2 * PLANE) = p3;
+        }
+      }
+      if (__builtin_expect(__any(split3_suspect(flag)), 0)) {   // rare: split again, exactly, over the first attempt
+#pragma unroll
+        for (int j = 0; j < ITER; ++j) {
+          const int idx = j * NTP + ptid;
+          const int r = idx / F8;
+          u32x4 p1, p2, p3;
+          split3_fix(st[j][0], st[j][1], p1, p2, p3);
+          if (ITER * NTP == CAP * F8 || r < CAP) {
+            __bf16 *o = base + SL::off(r, idx % F8);
+            *reinterpret_cast<u32x4 *>(o) = p1;
+            *reinterpret_cast<u32x4 *>(o + PLANE) = p2;
+            *reinterpret_cast<u32x4 *>(o + 2 * PLANE) = p3;
+          }
+        }
+      }
+      if (ptid < CAP) s_dst[slot * CAP + ptid] = dv;
+    };
+    // the finished tile `ep_seq` (accumulator tile ep_seq & 1): this wave's rows (row = pw mod 4) to global memory, zeros
+    // behind them
+    int ep_seq = -1, ep_tile = 0;
+    auto ep_ready = [&]() __attribute__((always_inline)) {
+      int v;
+      asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(done_addr + 4u * (ep_seq & 1)) : "memory");
+      return __builtin_amdgcn_readfirstlane(v) >= NCW * ((ep_seq >> 1) + 1);
+    };
+    auto ep_run = [&]() __attribute__((always_inline)) {
+      lds_f32 *acc = (lds_f32 *)(s_acc + (ep_seq & 1) * acc_tile);
+      const lds_i32 *ordl = (const lds_i32 *)(s_ord + (ep_seq & 1) * kPersMaxRows);
+      const int64_t row0 = (int64_t)ep_tile * tile_rows;
+      const int rows_here = (int)min((int64_t)tile_rows, n_tgt - row0);
+      const bool vec_out = (c_dst % 4) == 0;
+#pragma unroll 4
+      for (int j = 0; j < EPN; ++j) {
+        const int x = j * 64 + lane;
+        const int row = 4 * (x / (NC / 4)) + pw;
+        const int c4 = x % (NC / 4);
+        const int cc = col_base + c4 * 4;
+        if (row <= tile_rows) {
+          typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+          lds_f32x4 *a = (lds_f32x4 *)(acc + row * ACC_LD + c4 * 4);
+          const f32x4 v = *a;
+          *a = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (row < rows_here && cc < c_dst) {
+            float *o = dst + (int64_t)ordl[row] * c_dst + cc;
+            if (vec_out) {
+              *reinterpret_cast<f32x4 *>(o) = v;
+            } else {
+              o[0] = v.x;
+              if (cc + 1 < c_dst) o[1] = v.y;
+              if (cc + 2 < c_dst) o[2] = v.z;
+              if (cc + 3 < c_dst) o[3] = v.w;
+            }
+          }
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      ring_signal(afree_addr + 4u * (ep_seq & 1), lane);
+      ep_seq = -1;
+    };
+    Desc dA = next(), dB = next(), dC = next(), dD = next();
+    load_sidx(dA, sidx[0]);
+    load_sidx(dB, sidx[1]);
+    gather(dA, sidx[0], stage[0], dstv[0], ordv[0]);
+    gather(dB, sidx[1], stage[1], dstv[1], ordv[1]);
+    load_sidx(dC, sidx[0]);
+    if (ptid == 0) {
+      lds_write4(hdr_addr + 16u * NS, dA.k, dA.chunk, 0, 0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      ring_signal(init_addr, 0);
+    }
+    int slot = 0, round = 0;
+    // batch b: wait for its slot, split + store it, publish it with its header; then request the indices of batch b + 3
+    // and the rows of batch b + 2 (register slot = batch parity, as in k_conv_tile_f32x3_ws)
+    auto iteration = [&](f32x4 (&st)[ITER][2], int32_t &dv, int32_t &ov, int32_t (&sx_nx)[ITER], int32_t (&sx_cu)[ITER]) {
+      // the previous tile leaves as soon as the multipliers are through with it (at the latest NS batches into this
+      // tile; before this tile's last batch in any case: its accumulator tile is the next one's)
+      if (ep_seq >= 0) {
+        bool go = true;
+        if (dA.last) ring_wait(done_addr + 4u * (ep_seq & 1), NCW * ((ep_seq >> 1) + 1));
+        else go = ep_ready();
+        if (go) ep_run();
+      }
+      if (round > 0) ring_wait(free_addr + 4u * slot, NCW * round);
+      if (dA.ng > 0) write_stage(st, dv, slot);
+      if (ptid == 0)
+        lds_write4(hdr_addr + 16u * slot, dA.ng, (dA.first ? F_FIRST : 0) | (dA.last ? F_LAST : 0) | (dB.valid ? 0 : F_END),
+                   dB.k, dB.chunk);
+      if (dA.last && lane < 32) ((lds_i32 *)s_ord)[(dA.seq & 1) * kPersMaxRows + min(4 * lane + pw, kPersMaxRows - 1)] = ov;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      ring_signal(full_addr + 4u * slot, lane);
+      load_sidx(dD, sx_cu);
+      gather(dC, sx_nx, st, dv, ov);
+      if (dA.last) {
+        ep_seq = dA.seq;
+        ep_tile = dA.tile;
+      }
+      dA = dB; dB = dC; dC = dD;
+      dD = next();
+      if (++slot == NS) {
+        slot = 0;
+        ++round;
+      }
+    };
+    for (;;) {
+      if (!dA.valid) break;
+      iteration(stage[0], dstv[0], ordv[0], sidx[0], sidx[1]);
+      if (!dA.valid) break;
+      iteration(stage[1], dstv[1], ordv[1], sidx[1], sidx[0]);
+    }
+    if (ep_seq >= 0) {
+      ring_wait(done_addr + 4u * (ep_seq & 1), NCW * ((ep_seq >> 1) + 1));
+      ep_run();
+    }
+  } else {
+    // ----------------------------------------------- multiplier waves -----------------------------------------------
+    __builtin_amdgcn_s_setprio(2);
+    const int cbi0 = col_base / 16 + wave * CB;
+    bf16x8 w[2][CB][3][KS];
+    auto load_w = [&](int k, int chunk, bf16x8 (&wd)[CB][3][KS]) {
+#pragma unroll
+      for (int c = 0; c < CB; ++c) {
+        const bf16x8 *p = wp + (((((int64_t)k * nchunks + chunk) * ncb + min(cbi0 + c, ncb - 1)) * 3) * KS) * 64 + lane;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+          for (int v = 0; v < KS; ++v) wd[c][pl][v] = p[(pl * KS + v) * 64];
+        }
+      }
+    };
+    int pofs[KS];
+#pragma unroll
+    for (int sx = 0; sx < KS; ++sx) pofs[sx] = ((sx * 4 + q) ^ SL::swz(i16)) * 8;
+    auto multiply = [&](int ng, int buf, const bf16x8 (&wc)[CB][3][KS], int slot, auto &&next_w) {
+      const __bf16 *rowp = s_a + slot * 3 * PLANE + i16 * LD;
+      const int32_t *dstp = s_dst + slot * CAP + i16;
+      float *accp = &s_acc[buf * acc_tile + wave * CB * 16 + q * 4];
+      if (ng >= 4) consume_batch_ws<2, 2, CB, KC, 3, 0>(rowp, pofs, wc, dstp, accp, ACC_LD, next_w);
+      else if (ng == 3) consume_batch_ws<2, 1, CB, KC, 3, 0>(rowp, pofs, wc, dstp, accp, ACC_LD, next_w);
+      else if (ng == 2) consume_batch_ws<2, 0, CB, KC, 3, 0>(rowp, pofs, wc, dstp, accp, ACC_LD, next_w);
+      else if (ng == 1) consume_batch_ws<1, 0, CB, KC, 3, 0>(rowp, pofs, wc, dstp, accp, ACC_LD, next_w);
+      else next_w();
+    };
+    ring_wait(init_addr, 1);
+    {
+      int k0, chunk0, p0, p1;
+      lds_read4(hdr_addr + 16u * NS, k0, chunk0, p0, p1);
+      load_w(k0, chunk0, w[0]);
+    }
+    int slot = 0, round = 0, tile_n = 0;
+    bool end = false;
+    auto iteration = [&](bf16x8 (&w_cu)[CB][3][KS], bf16x8 (&w_nx)[CB][3][KS]) {
+      ring_wait(full_addr + 4u * slot, 4 * (round + 1));
+      int ng, fl, nk, nchunk;
+      lds_read4(hdr_addr + 16u * slot, ng, fl, nk, nchunk);
+      // the tile's accumulator: stored and zeroed by the producers after tile tile_n - 2
+      if ((fl & F_FIRST) && tile_n >= 2) ring_wait(afree_addr + 4u * (tile_n & 1), 4 * (tile_n >> 1));
+      multiply(ng, tile_n & 1, w_cu, slot, [&]() { load_w(nk, nchunk, w_nx); });
+      ring_signal(free_addr + 4u * slot, lane);
+      if (fl & F_LAST) {
+        ring_signal(done_addr + 4u * (tile_n & 1), lane);   // (behind this wave's last stores: LDS order)
+        ++tile_n;
+      }
+      end = (fl & F_END) != 0;
+      if (++slot == NS) {
+        slot = 0;
+        ++round;
+      }
+    };
+    for (;;) {
+      iteration(w[0], w[1]);
+      if (end) break;
+      iteration(w[1], w[0]);
+      if (end) break;
+    }
+  }
+}
+
+#endif  // ME_DEBUG_VARIANTS (ring / persistent kernels)
+
 extern int g_conv_variant;  // conv.hip: variant 6 = 64-bit gather addresses, 256 = phase counters
 
 struct ConvVariantX3 {
@@ -803,6 +1477,56 @@ static int launch_conv_tile_f32x3(const float *src, int c_src, const bf16x8 *wp,
   if constexpr (NC == 64 || NC == 128) {
     // default: the wave-specialised kernel; debug variant 30 = the ping-pong kernel, 256 = its phase counters,
     // 257 = the wave-specialised kernel's phase counters (tuning build)
+#ifdef ME_DEBUG_VARIANTS
+    // free-running ring kernel (no barrier in the batch loop): exact 64- / 128-channel chunks with 32-bit offsets;
+    // three stage slots where they fit next to the accumulator tile, else two.  Debug variant 40 selects it, 41 with two slots.
+    if constexpr (KC == 64 || KC == 128) {
+      if (small && exact && (g_conv_variant == 40 || g_conv_variant == 41)) {
+        constexpr int RNCW = NC == 128 ? 8 : 4;
+        constexpr bool kHas3 = KC == 64;
+        const bool three = kHas3 && g_conv_variant != 41 && conv_f32x3_ring_lds_bytes(NC, KC, tile_rows, 3) <= kLdsBudget;
+        kernel_t rk = &k_conv_tile_f32x3_ring<NC, KC, true, true, RNCW, 2>;
+        if constexpr (kHas3) {
+          if (three) rk = &k_conv_tile_f32x3_ring<NC, KC, true, true, RNCW, 3>;
+        }
+        const int rlds = conv_f32x3_ring_lds_bytes(NC, KC, tile_rows, three ? 3 : 2);
+        ME_CHECK(rlds <= kLdsBudget, "tile_rows too large for the LDS of one workgroup (ring kernel)");
+        static bool ring_attr[2] = {false, false};
+        if (rlds > 48 * 1024 && !ring_attr[three ? 1 : 0]) {
+          ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(rk), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     kLdsBudget));
+          ring_attr[three ? 1 : 0] = true;
+        }
+        const dim3 rgrid((unsigned)ceil_div(n_tgt, tile_rows), (unsigned)slabs);
+        hipLaunchKernelGGL(rk, rgrid, dim3((RNCW + 4) * 64), (size_t)rlds, stream, src, c_src, wp, c_dst, plan_src, plan_dst,
+                           batch_desc, tile_bptr, order, dst, n_tgt, tile_rows, batch_groups);
+        ME_LAUNCH_CHECK();
+        return 0;
+      }
+    }
+    // persistent kernel (tiles stream through one resident workgroup per CU, two accumulator tiles): debug variant 43
+    if constexpr (KC == 64 || KC == 128) {
+      const int pers_tiles = (int)ceil_div(n_tgt, tile_rows);
+      const int pers_wgs = std::min(pers_tiles, std::max(1, device_cu_count() / slabs));
+      if (small && exact && g_conv_variant == 43 && tile_rows <= kPersMaxRows && c_src <= 4 * KC &&
+          ceil_div(pers_tiles, pers_wgs) <= kPersMaxTiles && conv_f32x3_pers_lds_bytes(NC, KC, tile_rows) <= kLdsBudget) {
+        constexpr int RNCW = NC == 128 ? 8 : 4;
+        kernel_t pk = &k_conv_tile_f32x3_pers<NC, KC, RNCW>;
+        const int plds = conv_f32x3_pers_lds_bytes(NC, KC, tile_rows);
+        static bool pers_attr = false;
+        if (plds > 48 * 1024 && !pers_attr) {
+          ME_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(pk), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     kLdsBudget));
+          pers_attr = true;
+        }
+        const int n_tiles = pers_tiles, wgs = pers_wgs;
+        hipLaunchKernelGGL(pk, dim3((unsigned)wgs, (unsigned)slabs), dim3((RNCW + 4) * 64), (size_t)plds, stream, src, c_src,
+                           wp, c_dst, plan_src, plan_dst, batch_desc, tile_bptr, order, dst, n_tgt, tile_rows, n_tiles);
+        ME_LAUNCH_CHECK();
+        return 0;
+      }
+    }
+#endif
     if (!kHasPingPong || (g_conv_variant != 30 && g_conv_variant != 256)) {
       kernel_t ws;
       int wi = (small ? 2 : 0) + (exact ? 1 : 0);

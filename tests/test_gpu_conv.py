@@ -305,14 +305,17 @@ def test_wave_specialised_split_kernel_is_bit_identical(device, monkeypatch, n, 
     w = (torch.rand(27, cin, cout, generator=g) - 0.5)
     res = {}
     try:
-        for variant in (0, 31, 30):      # shipped (eight multipliers on 128-column slabs), four multipliers, ping-pong
+        # shipped, four multipliers, ping-pong; in a tuning build also the round-6 experiments that were measured and not
+        # adopted (profiles/r06_ring_persistent_ab.md): ring kernel with three / two stage slots, persistent kernel
+        extra = (40, 41, 43) if lib.me_debug_variants_compiled() else ()
+        for variant in (0, 31, 30) + extra:
             _lib.check(lib.me_debug_set_conv_variant(variant))
             y = MEB._conv_forward(x.to(device), w.to(device), km, "mfma")
             gi = MEB._conv_target(gy.to(device), w.to(device), km, "in", km.n_in, name="d", transposed=True)
             res[variant] = (y.clone(), gi.clone())
     finally:
         lib.me_debug_set_conv_variant(0)
-    for v in (31, 30):
+    for v in (31, 30) + extra:
         assert torch.equal(res[0][0], res[v][0]) and torch.equal(res[0][1], res[v][1]), v
     _, okm = O.kernel_map(coords.numpy(), coords.numpy(), O.make_region(3, 3))
     assert_close(res[0][0], O.conv_forward(x.numpy(), w.numpy(), okm, coords.shape[0]))
