@@ -1145,7 +1145,11 @@ def extra_workloads(args, ME, MEB, dist_utils, rank, world, dev, startup):
         plan = (("minkunet34c_bf16_200k", dict(workload="minkunet", dtype="bf16", steps=20, warmup=5, min_time=1.0,
                                                 min_blocks=5, cpu_budget=min(args.cpu_budget, 1.0))),
                 ("conv4d_f32_400k", dict(workload="conv4d", dtype="f32", steps=10, warmup=3, min_time=0.1,
-                                         cpu_budget=min(args.cpu_budget, 4.0))))
+                                         cpu_budget=min(args.cpu_budget, 4.0))),
+                # the headline layer at the SPARSE density: 100k voxels in 215^3 — one voxel in a
+                # hundred occupied, 79 % of the pairs on the centre offset — beside the dense one (70^3, P ~ 8.4 N)
+                ("conv3d_f32_100k_sparse", dict(workload="conv3d", dtype="f32", extent=215, steps=20, warmup=5,
+                                                min_time=0.1, cpu_budget=0.0)))
     else:
         # N > 1 (the driver's scaling run): BASELINE configs[3] — MinkUNet34C, one 200k-voxel scene per rank, torch DDP
         # over RCCL — with the exchange priced (multi_gpu); --sync-bn / --imbalance of the command line carry over
