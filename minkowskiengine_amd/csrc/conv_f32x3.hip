@@ -1592,10 +1592,18 @@ static int launch_conv_tile_f32x3(const float *src, int c_src, const bf16x8 *wp,
                                    kLdsBudget));
         ws_attr[wi] = true;
       }
-      // bit 8 of `batch_groups`: weight registers are reused for the next batch of the same offset (default; the
-      // variable is read per launch so that scripts/ab_reuse_w.py can switch inside one process)
-      const char *reuse_env = std::getenv("ME_AMD_X3_REUSE_W");
-      const int reuse_w = (reuse_env && reuse_env[0] == '0') ? 0 : 256;
+      // bit 8 of `batch_groups`: weight registers are reused for the next batch of the same offset (default;
+      // ME_AMD_X3_REUSE_W=0 reloads them).  Read once per process — per launch in the tuning build, where
+      // scripts/ab_reuse_w.py switches inside one process.
+      auto reuse_flag = []() {
+        const char *e = std::getenv("ME_AMD_X3_REUSE_W");
+        return (e && e[0] == '0') ? 0 : 256;
+      };
+#ifdef ME_DEBUG_VARIANTS
+      const int reuse_w = reuse_flag();
+#else
+      static const int reuse_w = reuse_flag();
+#endif
       const dim3 wgrid((unsigned)ceil_div(n_tgt, tile_rows), (unsigned)slabs);
       hipLaunchKernelGGL(ws, wgrid, dim3(wthreads), (size_t)lds, stream, src, c_src, wp, c_dst, plan_src, plan_dst, batch_desc,
                          tile_bptr, order, dst, n_tgt, tile_rows, batch_groups | reuse_w);

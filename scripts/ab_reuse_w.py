@@ -1,5 +1,5 @@
-"""A/B inside one process: weight registers reused for the next batch of the same offset (ME_AMD_X3_REUSE_W, read per
-launch by libme_amd) against a reload per batch — split fp32 tile kernel, forward / dgrad of the config-2 scene."""
+"""A/B inside one process (TUNING build, scripts/build_debug.sh: the default build reads the variable once): weight
+registers reused for the next batch of the same offset (ME_AMD_X3_REUSE_W) against a reload per batch — split fp32 tile kernel, forward / dgrad of the config-2 scene."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
