@@ -354,11 +354,6 @@ if (d.ng >= 4) consume_batch_ws<2, 2, CB, KC, 1>(rowp, pofs, wc, dstp, accp, ACC
       else consume_batch_ws<1, 0, CB, KC, 1>(rowp, pofs, wc, dstp, accp, ACC_LD, next_w);
     };
     if constexpr (!FUSE) {
-#ifdef ME_WS_NO_WEIGHT_REUSE
-      constexpr bool reuse_w = false;     // (A/B builds)
-#else
-      constexpr bool reuse_w = true;
-#endif
       Desc dA = locate(0), dB = locate(1);
       load_w(dA, w[0]);
       __syncthreads();                      // batch 0 is staged
@@ -366,18 +361,7 @@ if (d.ng >= 4) consume_batch_ws<2, 2, CB, KC, 1>(rowp, pofs, wc, dstp, accp, ACC
       t_prev_ = t_first_ = __builtin_amdgcn_s_memtime();
 #endif
       auto iteration = [&](int it, int P, bf16x8 (&w_cu)[CB][1][KS], bf16x8 (&w_nx)[CB][1][KS]) {
-        multiply(dA, w_cu, P, [&]() {
-          // the next batch of the SAME offset and chunk (an item of more than 64 pairs) takes a register copy instead of
-          // another pass over the weight slice in the L2 (conv_f32x3.hip, round 6: -1 ... -3 % on dense layers)
-          if (reuse_w && dB.k == dA.k && dB.chunk == dA.chunk) {
-#pragma unroll
-            for (int c = 0; c < CB; ++c)
-#pragma unroll
-              for (int v = 0; v < KS; ++v) w_nx[c][0][v] = w_cu[c][0][v];
-          } else {
-            load_w(dB, w_nx);
-          }
-        });
+        multiply(dA, w_cu, P, [&]() { load_w(dB, w_nx); });
         ME_WS_SYNC(0);
         dA = dB;
         dB = locate(it + 2);

@@ -19,7 +19,6 @@
 // batches, heaviest-first tile order) with fp32 rows gathered into registers, split while they are written to the
 // three LDS stage planes, and fp32 output.  The reference computes this path in fp32
 // (src/convolution_gpu.cu:137-155, AT_DISPATCH_FLOATING_TYPES).
-#include <cstdlib>
 #include <type_traits>
 #include "conv_common.hpp"
 #include "conv_ws.hpp"
@@ -496,6 +495,7 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void k_conv_tile_f32x3_ws(
   constexpr int CAP = ME_MAX_BATCH_GROUPS * 16;
   constexpr int ITER = (CAP * F8 + NTP - 1) / NTP;
   constexpr int PLANE = CAP * LD;
+  (void)batch_groups;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float *s_acc = reinterpret_cast<float *>(smem);                              // [(tile_rows + 1) x ACC_LD]
@@ -695,19 +695,7 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void k_conv_tile_f32x3_ws(
     unsigned long long tm_a = 0, tm_b = 0, t_prev = TIMED ? __builtin_amdgcn_s_memtime() : 0ull;
     auto iteration = [&](int it, int P, bf16x8 (&w_cu)[CB][3][KS], bf16x8 (&w_nx)[CB][3][KS]) {
       multiply(dA, w_cu, P, [&]() {
-        // the next batch of the SAME offset and chunk (an item of more than 64 pairs) takes a register copy instead of
-        // another 6 - 12 KB per wave from the L2
-        const bool same = (batch_groups & 256) != 0 && dB.k == dA.k && dB.chunk == dA.chunk;
-        if (same) {
-#pragma unroll
-          for (int c = 0; c < CB; ++c)
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-              for (int v = 0; v < KS; ++v) w_nx[c][pl][v] = w_cu[c][pl][v];
-        } else if (ABL != 4 || it == 0) {
-          load_w(dB, w_nx);    // (ABL 4: the weights are loaded once — timing ablation)
-        }
+        if (ABL != 4 || it == 0) load_w(dB, w_nx);    // (ABL 4: the weights are loaded once — timing ablation)
       });
       if (TIMED) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1592,21 +1580,9 @@ static int launch_conv_tile_f32x3(const float *src, int c_src, const bf16x8 *wp,
                                    kLdsBudget));
         ws_attr[wi] = true;
       }
-      // bit 8 of `batch_groups`: weight registers are reused for the next batch of the same offset (default;
-      // ME_AMD_X3_REUSE_W=0 reloads them).  Read once per process — per launch in the tuning build, where
-      // scripts/ab_reuse_w.py switches inside one process.
-      auto reuse_flag = []() {
-        const char *e = std::getenv("ME_AMD_X3_REUSE_W");
-        return (e && e[0] == '0') ? 0 : 256;
-      };
-#ifdef ME_DEBUG_VARIANTS
-      const int reuse_w = reuse_flag();
-#else
-      static const int reuse_w = reuse_flag();
-#endif
       const dim3 wgrid((unsigned)ceil_div(n_tgt, tile_rows), (unsigned)slabs);
       hipLaunchKernelGGL(ws, wgrid, dim3(wthreads), (size_t)lds, stream, src, c_src, wp, c_dst, plan_src, plan_dst, batch_desc,
-                         tile_bptr, order, dst, n_tgt, tile_rows, batch_groups | reuse_w);
+                         tile_bptr, order, dst, n_tgt, tile_rows, batch_groups);
       ME_LAUNCH_CHECK();
       return 0;
     }
