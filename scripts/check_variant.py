@@ -7,8 +7,9 @@ from bench import make_scene
 dev = torch.device("cuda:0")
 lib = _lib.load()
 variants = [int(v) for v in os.environ.get("VARIANTS", "0,31,30").split(",")]
+extent = int(os.environ.get("EXTENT", "70"))     # 70: the dense headline scene (P ~ 8.4 N); 215: the sparse one (P ~ 1.27 N)
 for cin, cout in ((64, 128), (128, 64), (128, 128), (64, 64)):
-    coords = make_scene(100000, 70, 0).to(dev)
+    coords = make_scene(100000, extent, 0).to(dev)
     mgr = MEB.CoordinateMapManagerGPU_c10()
     key, _ = mgr.insert_and_map(coords, [1, 1, 1], "")
     km = mgr._kernel_map(key, key, [3] * 3, [1] * 3, [1] * 3, MEB.RegionType.HYPER_CUBE, None, False, False)

@@ -11,6 +11,9 @@ import minkunet as MU
 if os.environ.get("BF16_SHAPE"):     # "nc,kc": tuning override of the bf16 tile kernel's slab width / chunk depth
     from minkowskiengine_amd import _lib
     _lib.load().me_debug_set_bf16_shape(*[int(v) for v in os.environ["BF16_SHAPE"].split(",")])
+if os.environ.get("BF16_WS_DEPTH"):  # 2 / 4: register sets of gathered rows in flight in the wave-specialised bf16 kernel's producers
+    from minkowskiengine_amd import _lib
+    _lib.load().me_debug_set_bf16_ws_depth(int(os.environ["BF16_WS_DEPTH"]))
 if os.environ.get("WGRAD_WPC"):      # workgroups per CU the weight-gradient ranges are sized for (0 = policy)
     from minkowskiengine_amd import _lib
     _lib.load().me_debug_set_wgrad_config(0, int(os.environ["WGRAD_WPC"]))
