@@ -2404,10 +2404,9 @@ static int launch_conv_tile(const float *src, int c_src, const float *wp, int c_
   small = small && kHasSmall;
   typedef void (*kernel_t)(const float *, int, const f32x4 *, int, const int32_t *, const int32_t *, const int32_t *,
                            const int32_t *, const int32_t *, float *, int64_t, int, int);
-  kernel_t fn = small ? (exact ? &k_conv_tile_f32<NC, KC, true, VAR, kHasSmall>
-                               : &k_conv_tile_f32<NC, KC, false, VAR, kHasSmall>)
-                      : (exact ? &k_conv_tile_f32<NC, KC, true, VAR, false>
-                               : &k_conv_tile_f32<NC, KC, false, VAR, false>);
+  // two instantiations per shape (round 6; four before): the fast one (exact chunk AND 32-bit gather offsets) and the
+  // general one, which also serves the two mixed cases — same sums in the same order
+  kernel_t fn = (small && exact) ? &k_conv_tile_f32<NC, KC, true, VAR, kHasSmall> : &k_conv_tile_f32<NC, KC, false, VAR, false>;
   // multi-offset batches (sparse maps; host policy): narrow shapes with the small-address path only — wide layers
   // run the split kernels, and the weights of four offsets have to fit the registers
   constexpr bool kHasFuse = VAR == 0 && NC <= 64 && KC <= 64;

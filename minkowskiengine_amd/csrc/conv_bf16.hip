@@ -1337,12 +1337,12 @@ static int launch_conv_tile_bf16(const __bf16 *src, int c_src, const bf16x8 *wp,
   typedef void (*kernel_t)(const __bf16 *, int, const bf16x8 *, int, const int32_t *, const int32_t *, const int32_t *,
                            const int32_t *, const int32_t *, __bf16 *, int64_t, int, int, int, float *, float *, float *,
                            int);
-  kernel_t fn = small ? (exact ? &k_conv_tile_bf16<NC, KC, true, true> : &k_conv_tile_bf16<NC, KC, false, true>)
-                      : (exact ? &k_conv_tile_bf16<NC, KC, true, false> : &k_conv_tile_bf16<NC, KC, false, false>);
+  // two instantiations per shape and mode (round 6; four before): the fast one (exact chunk AND 32-bit gather offsets) and
+  // the general one, which also serves the two mixed cases — same sums in the same order
+  const bool fast = small && exact;
+  kernel_t fn = fast ? &k_conv_tile_bf16<NC, KC, true, true> : &k_conv_tile_bf16<NC, KC, false, false>;
   if constexpr (NC <= 96 && KC <= 128) {   // batch fusion: four- and six-wave workgroups (sparse maps of narrow layers)
-    if (fuse)
-      fn = small ? (exact ? &k_conv_tile_bf16<NC, KC, true, true, true> : &k_conv_tile_bf16<NC, KC, false, true, true>)
-                 : (exact ? &k_conv_tile_bf16<NC, KC, true, false, true> : &k_conv_tile_bf16<NC, KC, false, false, true>);
+    if (fuse) fn = fast ? &k_conv_tile_bf16<NC, KC, true, true, true> : &k_conv_tile_bf16<NC, KC, false, false, true>;
   } else {
     fuse = false;
   }

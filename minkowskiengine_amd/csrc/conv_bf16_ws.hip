@@ -534,8 +534,15 @@ static int launch_ws(const __bf16 *src, int c_src, const bf16x8 *wp, int c_dst, 
   const int lds = conv_bf16_ws_lds(NC, KC, tile_rows);
   typedef void (*kernel_t)(const __bf16 *, int, const bf16x8 *, int, const int32_t *, const int32_t *, const int32_t *,
                            const int32_t *, const int32_t *, __bf16 *, int64_t, int, float *, float *);
+  // (two register sets of rows in flight instead of four — me_debug_set_bf16_ws_depth(2) — measure the same on every
+  // MinkUNet34C layer, profiles/r06_ws_depth.log: instantiated in the tuning build only)
+#ifdef ME_DEBUG_VARIANTS
   const bool deep = g_bf16_ws_depth != 2;
   kernel_t fn = deep ? &k_conv_tile_bf16_ws<NC, KC, 4> : &k_conv_tile_bf16_ws<NC, KC, 2>;
+#else
+  const bool deep = true;
+  kernel_t fn = &k_conv_tile_bf16_ws<NC, KC, 4>;
+#endif
   int which = deep ? 1 : 0, threads = 512;
   if constexpr (NC == 128) {
     // Eight multiplier waves where the slab runs one workgroup per CU anyway (chunks of 96 / 128 channels: > 128 registers):

@@ -1463,6 +1463,10 @@ static int launch_conv_tile_f32x3(const float *src, int c_src, const bf16x8 *wp,
   const int lds = conv_f32x3_lds_bytes(NC, KC, tile_rows);
   ME_CHECK(lds <= kLdsBudget, "tile_rows too large for the LDS of one workgroup");
   const bool exact = (c_src % KC) == 0;
+  // two instantiations per shape (round 6; four before): the fast one — source channels a multiple of the chunk AND 32-bit
+  // gather offsets — and the general one, which also serves the two mixed cases (bit-identical results, a few per cent
+  // slower on shapes no BASELINE configuration has)
+  const bool fast = small && exact;
   typedef void (*kernel_t)(const float *, int, const bf16x8 *, int, const int32_t *, const int32_t *, const int32_t *,
                            const int32_t *, const int32_t *, float *, int64_t, int, int);
 #ifdef ME_DEBUG_VARIANTS
@@ -1472,8 +1476,7 @@ static int launch_conv_tile_f32x3(const float *src, int c_src, const bf16x8 *wp,
 #endif
   kernel_t fn = nullptr;
   if constexpr (kHasPingPong)
-    fn = small ? (exact ? &k_conv_tile_f32x3<NC, KC, true, true> : &k_conv_tile_f32x3<NC, KC, false, true>)
-               : (exact ? &k_conv_tile_f32x3<NC, KC, true, false> : &k_conv_tile_f32x3<NC, KC, false, false>);
+    fn = fast ? &k_conv_tile_f32x3<NC, KC, true, true> : &k_conv_tile_f32x3<NC, KC, false, false>;
   if constexpr (NC == 64 || NC == 128) {
     // default: the wave-specialised kernel; debug variant 30 = the ping-pong kernel, 256 = its phase counters,
     // 257 = the wave-specialised kernel's phase counters (tuning build)
@@ -1535,21 +1538,17 @@ static int launch_conv_tile_f32x3(const float *src, int c_src, const bf16x8 *wp,
       if constexpr (NC == 128) {
 #ifdef ME_DEBUG_VARIANTS
         if (g_conv_variant == 31) {   // (tuning build: four multiplier waves)
-          ws = small ? (exact ? &k_conv_tile_f32x3_ws<NC, KC, true, true> : &k_conv_tile_f32x3_ws<NC, KC, false, true>)
-                     : (exact ? &k_conv_tile_f32x3_ws<NC, KC, true, false> : &k_conv_tile_f32x3_ws<NC, KC, false, false>);
+          ws = fast ? &k_conv_tile_f32x3_ws<NC, KC, true, true> : &k_conv_tile_f32x3_ws<NC, KC, false, false>;
         } else
 #endif
         {   // eight multiplier waves
-          ws = small ? (exact ? &k_conv_tile_f32x3_ws<NC, KC, true, true, false, 2, 0, 8>
-                              : &k_conv_tile_f32x3_ws<NC, KC, false, true, false, 2, 0, 8>)
-                     : (exact ? &k_conv_tile_f32x3_ws<NC, KC, true, false, false, 2, 0, 8>
-                              : &k_conv_tile_f32x3_ws<NC, KC, false, false, false, 2, 0, 8>);
+          ws = fast ? &k_conv_tile_f32x3_ws<NC, KC, true, true, false, 2, 0, 8>
+                    : &k_conv_tile_f32x3_ws<NC, KC, false, false, false, 2, 0, 8>;
           wi += 13;
           wthreads = 768;
         }
       } else {
-        ws = small ? (exact ? &k_conv_tile_f32x3_ws<NC, KC, true, true> : &k_conv_tile_f32x3_ws<NC, KC, false, true>)
-                   : (exact ? &k_conv_tile_f32x3_ws<NC, KC, true, false> : &k_conv_tile_f32x3_ws<NC, KC, false, false>);
+        ws = fast ? &k_conv_tile_f32x3_ws<NC, KC, true, true> : &k_conv_tile_f32x3_ws<NC, KC, false, false>;
       }
 #ifdef ME_DEBUG_VARIANTS   // phase counters, priority A/B and timing ablations (results invalid): tuning builds only
       if constexpr (KC >= 64) {
